@@ -1,0 +1,137 @@
+"""Pin the oracle (oracle/link_oracle.{c,py}) against the golden fixtures generated from the
+reference (tests/golden/make_golden.py) and -- when prebuilt -- the reference's own C++ CPU ops in
+oracle/_ref.  CPU-only, seconds."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden_files, load_golden, rel_err
+from oracle import link_oracle as O
+
+
+def test_hash_known_answers():
+    g = load_golden("g_hash.npz")
+    # SURVEY.md section 8c known answers, independently reproduced by the reference CPU op
+    kat = {(0, 0, 0, 0): 947293587111810033, (1, 2, 3, 0): 1043245732202901914,
+           (-1, 5, 7, 1): 348679674271016180, (255, 255, 255, 0): 670648651708156917,
+           (1, 1, 1, 0): 419080468822848237, (1, 1, 1, 1): 419081568334476434}
+    for row, h in zip(g["kat_coords"], g["kat_hash"]):
+        assert kat[tuple(int(v) for v in row)] == int(h)
+    assert np.array_equal(O.sphash(g["kat_coords"]), g["kat_hash"])
+    assert np.array_equal(O.sphash(g["rnd_coords"]), g["rnd_hash"])
+
+
+def test_kernel_hash():
+    g = load_golden("g_hash.npz")
+    assert np.array_equal(O.sphash_offsets(g["single_coords"], O.get_kernel_offsets(3)), g["khash_r3"])
+    assert np.array_equal(O.sphash_offsets(g["single_coords"], O.get_kernel_offsets(2)), g["khash_r2"])
+    # the reference CPU twin's batch defect (hash_cpu.cpp:29) reproduced bit-exactly on demand
+    assert np.array_equal(O.sphash_offsets(g["rnd_coords"], O.get_kernel_offsets(3), cpu_batch_bug=True),
+                          g["khash_r3_cpu_defect"])
+    # and the CUDA semantics differ from it exactly where batch != batch[0]
+    good = O.sphash_offsets(g["rnd_coords"], O.get_kernel_offsets(3))
+    same = (g["rnd_coords"][:, 3] == g["rnd_coords"][0, 3])
+    assert np.array_equal(good[:, same], g["khash_r3_cpu_defect"][:, same])
+    assert not np.array_equal(good[:, ~same], g["khash_r3_cpu_defect"][:, ~same])
+
+
+def test_query_count_unique_offsets():
+    g = load_golden("g_hash.npz")
+    assert np.array_equal(O.sphashquery(g["query_q"], g["query_ref"]), g["query_out"])
+    assert list(g["query_out"]) == [0, 3, -1, -1]
+    assert np.array_equal(O.spcount(g["count_idx"], 7), g["count_out"])
+    assert np.array_equal(O.unique_rows(g["unique_in"]), g["unique_out"])
+    k = load_golden("g_koff.npz")
+    for r in (2, 3, 4, 5):
+        assert np.array_equal(O.get_kernel_offsets(r), k[f"r{r}"])
+    assert O.get_kernel_offsets(2)[:4].tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1]]
+    assert O.get_kernel_offsets(3)[:4].tolist() == [[-1, -1, -1], [0, -1, -1], [1, -1, -1], [-1, 0, -1]]
+
+
+@pytest.mark.parametrize("name", golden_files("g_agg_*.npz"))
+def test_aggregate_vs_reference(name):
+    g = load_golden(name)
+    s, r = g["meta"]["s"], g["meta"]["r"]
+    small_c, idx, counts = O.voxel_to_aux_index(g["coords"], s)
+    assert np.array_equal(small_c, g["small_c"])          # bit-exact indexing
+    assert np.array_equal(idx, g["idx_query"])
+    assert np.array_equal(counts, g["counts"])
+    if "nbr" in g:
+        assert np.array_equal(O.neighbor_index(small_c, r), g["nbr"])
+    aux_f, _, _, _ = O.voxel_to_aux(g["feats"], g["coords"], s)
+    assert np.array_equal(aux_f, g["aux_f"])               # same op order as voxelize_cpu.cpp -> exact
+    out = O.aux_to_voxel(aux_f, small_c, idx, counts, r)
+    assert rel_err(out, g["out"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", golden_files("g_block_*.npz"))
+def test_block_core_and_grads_vs_reference(name):
+    import torch
+    g = load_golden(name)
+    m = g["meta"]
+    params = {k[4:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items()
+              if k.startswith("sd__") and "local_mix" not in k and "norm_local" not in k}
+    feats = torch.from_numpy(g["feats"]).clone().requires_grad_(True)
+    coords = torch.from_numpy(g["coords"])
+    core = O.elk_core_torch(feats, coords, params, m["s"], m["r"], m["baseop"], m["groups"],
+                            m["variant"], m["tensor_stride"])
+    assert rel_err(core.detach().numpy(), g["core"]) < 1e-5
+    core_c = O.elk_core_torch(feats.detach(), coords, {k: v.detach() for k, v in params.items()},
+                              m["s"], m["r"], m["baseop"], m["groups"], m["variant"],
+                              m["tensor_stride"], agg=O.aggregate_c)
+    assert rel_err(core_c.numpy(), g["core"]) < 1e-5
+    names = sorted(params)
+    grads = torch.autograd.grad(core, [feats] + [params[n] for n in names], torch.from_numpy(g["grad_out"]))
+    assert rel_err(grads[0].numpy(), g["grad_feats"]) < 1e-4
+    for n, gr in zip(names, grads[1:]):
+        assert rel_err(gr.numpy(), g["grad__" + n]) < 1e-4, n
+
+
+def test_size_checkpoints():
+    """SURVEY.md section 8d generator checkpoints: M and sha256 of the index arrays at cfg1/cfg2."""
+    import hashlib
+    import json
+    from helpers import GOLDEN, s_uniform
+    with open(os.path.join(GOLDEN, "g_size.json")) as f:
+        sizes = json.load(f)["sizes"]
+    for key, n, s in (("N10000_s7", 10_000, 7), ("N100000_s7", 100_000, 7)):
+        coords = s_uniform(n).numpy()
+        small_c, idx, counts = O.voxel_to_aux_index(coords, s)
+        assert small_c.shape[0] == sizes[key]["M"]
+        assert hashlib.sha256(idx.astype(np.int64).tobytes()).hexdigest() == sizes[key]["sha256_idx"]
+        assert hashlib.sha256(counts.astype(np.int32).tobytes()).hexdigest() == sizes[key]["sha256_counts"]
+        assert hashlib.sha256(small_c.astype(np.int32).tobytes()).hexdigest() == sizes[key]["sha256_small_c"]
+        nbr = O.neighbor_index(small_c, 3)
+        assert hashlib.sha256(nbr.astype(np.int32).tobytes()).hexdigest() == sizes[key]["sha256_nbr_r3"]
+    assert sizes["N10000_s7"]["M"] == 9047 and sizes["N100000_s7"]["M"] == 43334
+
+
+def test_oracle_vs_compiled_reference_ops():
+    """Bit-exact check of the C restatement against the reference's own C++ ops (oracle/_ref)."""
+    from oracle import build_ref
+    if not os.path.exists(build_ref.SO) and not build_ref.available():
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    import torch
+    ref = build_ref.load_module()
+    rng = np.random.default_rng(0)
+    coords = rng.integers(-500, 500, (5000, 4)).astype(np.int32)
+    coords[:, 3] = 0
+    t = torch.from_numpy(coords)
+    assert np.array_equal(ref.hash_cpu(t).numpy(), O.sphash(coords))
+    off = torch.from_numpy(O.get_kernel_offsets(3))
+    assert np.array_equal(ref.kernel_hash_cpu(t, off).numpy(), O.sphash_offsets(coords, off.numpy()))
+    idx = rng.integers(-1, 300, 5000).astype(np.int32)
+    assert np.array_equal(ref.count_cpu(torch.from_numpy(idx), 300).numpy(), O.spcount(idx, 300))
+    idxp = np.abs(idx)
+    counts = O.spcount(idxp, 300)
+    feats = rng.standard_normal((5000, 24)).astype(np.float32)
+    a = ref.voxelize_forward_cpu(torch.from_numpy(feats), torch.from_numpy(idxp), torch.from_numpy(counts)).numpy()
+    assert np.array_equal(a, O.spvoxelize_fwd(feats, idxp, counts))
+    top = rng.standard_normal((300, 24)).astype(np.float32)
+    b = ref.voxelize_backward_cpu(torch.from_numpy(top), torch.from_numpy(idxp), torch.from_numpy(counts), 5000).numpy()
+    assert np.array_equal(b, O.spvoxelize_bwd(top, idxp, counts, 5000))
+    ind = rng.integers(-1, 300, (700, 8)).astype(np.int32)
+    w = rng.random((700, 8)).astype(np.float32)
+    c = ref.devoxelize_forward_cpu(torch.from_numpy(top), torch.from_numpy(ind), torch.from_numpy(w)).numpy()
+    assert np.array_equal(c, O.spdevoxelize_fwd(top, ind, w))   # K=8: identical op order
