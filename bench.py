@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of one LinK (3x7)^3 block on MI355X (BASELINE.json metric).
+
+Step      = one pass of the hot path R_core (pre_mix -> theta -> modulate ->
+            voxel_to_aux -> aux_to_voxel -> de-modulate -> norm) over ONE synthetic frame, index
+            structures rebuilt inside the step ("cold", as the reference does on every call).
+Workload  = BASELINE.json configs[1]: 100k unique voxels uniform in a 256^3 grid (S-uniform generator,
+            seed = rank), C = 64, baseop cos, groups 2, r = 3, s = 7, fp32.
+N GPUs    = one process per GPU, one independent frame per rank per step, NO data-path collective
+            (weak scaling); after the timed region the per-rank summaries (voxels, blocks, checksum,
+            elapsed) are all-gathered over RCCL -- the "trivial result gather".
+Timing    = W warm-up steps, barrier + synchronize, EXACTLY K steps, synchronize + barrier, max over
+            ranks; value = voxels processed by all ranks / that time.  Inputs are resident in HBM.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel: algorithmic bytes / its average duration,
+                measured with HIP events on the launch stream in a second, instrumented replay of the
+                same K steps (so the events do not perturb `value`); peak 8.0 TB/s HBM.
+  cpu_baseline  the scalar C/torch oracle port (oracle/) timed on this host, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def s_uniform(n, grid=256, seed=0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    lin = torch.randperm(grid ** 3, generator=g)[:n]
+    return torch.stack([lin % grid, (lin // grid) % grid, lin // (grid * grid), torch.zeros_like(lin)], 1).int()
+
+
+def alg_bytes(n, m, c, parts=2):
+    """B_alg = N*16 + N*4C + N*4C + 2*M*4*(W+1), and its per-kernel split
+    (each term charged once, to the kernel that must move it)."""
+    w = parts * c
+    table = m * 4 * (w + 1)
+    return {"total": n * 16 + 2 * n * 4 * c + 2 * table,
+            "premix_ln": n * 4 * c,
+            "modulate_block_sum": n * 16 + table,
+            "gather_demod_ln": table + n * 4 * c}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--voxels", type=int, default=100_000)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import link_amd as la
+
+    N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
+    torch.manual_seed(2)
+    blk = la.ELKBlock(C, C, groups=G, baseop="cos").to(dev).eval()
+    coords = s_uniform(N, seed=rank).to(dev)
+    feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    plan = la.ElkCorePlan(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
+    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+              None, blk.norm.weight, blk.norm.bias)
+
+    def step(build_index=True):
+        return plan.run(feats, coords, build_index=build_index)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(k, build_index=True):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(build_index)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        return t1 - t0
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt each step)
+    M = plan.blocks()
+    out = step()
+    checksum = float(out.double().sum().item())
+    for _ in range(3):
+        step(False)
+    elapsed_warm = timed(args.steps, build_index=False)
+
+    # ---- max over ranks + the trivial result gather (per-frame summaries only)
+    if world > 1:
+        mine = torch.tensor([float(N), float(M), checksum, elapsed, elapsed_warm], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu()
+        elapsed = float(rows[:, 3].max())
+        elapsed_warm = float(rows[:, 4].max())
+        total_vox = float(rows[:, 0].sum())
+    else:
+        total_vox = float(N)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- instrumented replay: per-kernel durations with HIP events on the launch stream ---------
+    import ctypes
+    from link_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    b, grid, desc = plan.buf, plan.grid, plan.desc
+    stages = {
+        "index_build(4 kernels)": lambda: lib.link_index_build(
+            coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch, b.scratch_bytes, b.cell_blk,
+            b.vox_blk, b.idx_query, b.perm, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
+        "premix_ln": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
+        "modulate_block_sum": lambda: lib.link_modulate_block_sum(
+            b.fin, b.coords, b.w_pos, b.alpha, b.perm, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
+        "gather_demod_ln": lambda: lib.link_gather_demod_ln(
+            b.S, b.fin, b.coords, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.perm, b.blk_start, b.blk_coords,
+            b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, N, b.out, st),
+    }
+    k_inst = min(args.steps, 100)
+    evs = {name: [] for name in stages}
+    for _ in range(k_inst):
+        for name, fn in stages.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            evs[name].append((e0, e1))
+    torch.cuda.synchronize()
+    kern_us = {name: 1e3 * sum(a.elapsed_time(b_) for a, b_ in v) / len(v) for name, v in evs.items()}
+    ab = alg_bytes(N, M, C)
+    core = {k: v for k, v in kern_us.items() if k in ab}
+    dom = max(core, key=core.get)
+    achieved = ab[dom] / (core[dom] * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": ab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
+                "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / args.steps, 2),
+                               "frac": round(ab["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    # ---- CPU baseline: the oracle port on this host (rank 0, N=1 only) ---------------------------
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import link_oracle as O
+        torch.set_num_threads(1)
+        params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+        fc, cc = feats.cpu(), coords.cpu()
+        reps, t_cpu = 0, 0.0
+        ref = None
+        while reps < 20 and t_cpu < 12.0:
+            t0 = time.perf_counter()
+            ref = O.elk_core_torch(fc, cc, params, S_, R, "cos", G, agg=O.aggregate_c)
+            t_cpu += time.perf_counter() - t0
+            reps += 1
+        err = float((out.cpu() - ref).abs().max() / ref.abs().max())
+        cpu = {"value": round(N * reps / t_cpu, 1), "unit": "voxels/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} full passes of the same workload (R_core, N={N}, C={C}) through oracle/ "
+                         f"(scalar C aggregation + single-thread torch dense ops), {t_cpu:.1f} s",
+               "host_cpus": os.cpu_count(), "gpu_vs_oracle_max_rel_err": err}
+
+    ms = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
+        "value": round(total_vox * args.steps / elapsed, 1), "unit": "voxels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: S-uniform 100k voxels in 256^3, C=64, one LinK "
+                               "cos:(3x7)^3 block forward (R_core, index rebuilt every step)",
+                   "voxels_per_frame": N, "blocks_per_frame": M, "channels": C, "baseop": "cos", "groups": G,
+                   "r": R, "s": S_, "frames_per_step": world, "parallelism": f"{world} independent frame(s), "
+                   "one per GPU, no data-path collective"},
+        "warm_index_value": round(total_vox * args.steps / elapsed_warm, 1),
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

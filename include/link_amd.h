@@ -1,0 +1,261 @@
+/*
+ * include/link_amd.h -- C ABI of the MI355X-native LinK hot path (liblink_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers + sizes + a HIP stream, no torch types.  All
+ * pointers are DEVICE pointers unless a parameter says "host".  Every entry point
+ *   - launches asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *   - never allocates, never synchronises, never throws; caller owns every buffer,
+ *   - returns LINK_OK (0) or a negative LINK_ERR_* code (argument/launch errors only; data-dependent
+ *     conditions are reported through the device-side status word documented per call).
+ *
+ * Section A replaces, one for one, the functions the reference registers in its pybind11 module
+ * `torchsparse.backend` (/root/reference/segmentation/torchsparse-u/torchsparse/backend/
+ * pybind_cuda.cpp:18-39) that lie on the LinK path.  Section B is the fused form of the Python layer
+ * above them (segmentation/core/models/utils.py:44-84 voxel_to_aux / aux_to_voxel,
+ * detection/det3d/models/utils/ts_elk.py:68-107).  Section C is the fused R_core of
+ * ELKBlock.forward / TSELKBlock.forward_ (segmentation/core/models/semantic_kitti/linkunet.py:124-185,
+ * detection/det3d/models/utils/ts_elk.py:144-230).
+ *
+ * Feature dtype: fp32 (the shipped reference runs this path in fp32; voxelnet.py:55 has autocast
+ * commented out).  Integer results are bit-exact with the reference; fp32 within 1e-4 rel.
+ */
+#ifndef LINK_AMD_H_
+#define LINK_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINK_OK 0
+#define LINK_ERR_ARG (-1)       /* null pointer / negative size / unsupported width */
+#define LINK_ERR_LAUNCH (-2)    /* hipGetLastError() != hipSuccess after a launch */
+#define LINK_ERR_WORKSPACE (-3) /* caller-provided workspace too small */
+
+/* Version of this ABI (bumped on any signature change). */
+int link_abi_version(void);
+/* Human-readable last HIP error string of the calling thread ("" if none). Host pointer. */
+const char *link_last_error(void);
+
+/* =============================================================================================
+ * A. torchsparse.backend drop-ins
+ * ============================================================================================= */
+
+/* hash_cuda(idx[N,4] i32) -> i64[N]           backend/hash/hash_cuda.cu:10-23,67-73
+ * 64-bit FNV-1a over the four 32-bit words, folded to 60 bits.  Bit-exact. */
+int link_hash(const int32_t *coords, int64_t n, int64_t *out, void *stream);
+
+/* kernel_hash_cuda(idx[N,4] i32, off[K,3] i32) -> i64[K,N] (k-major)
+ *                                             backend/hash/hash_cuda.cu:27-55,75-84
+ * Hash of (x+ox, y+oy, z+oz, b); batch taken from the row itself (CUDA semantics). Bit-exact. */
+int link_kernel_hash(const int32_t *coords, int64_t n, const int32_t *offsets, int64_t k,
+                     int64_t *out, void *stream);
+
+/* hash_query_cuda(q i64[n1], tgt i64[n], tgt_idx i64[n]) -> i64[n1]
+ *                                             backend/others/query_cuda.cu:9-58,
+ *                                             backend/hashmap/hashmap_cuda.cu:9-130
+ * out[i] = tgt_idx[j]+1 for the FIRST j with tgt[j]==q[i], else 0 (the Python wrapper subtracts 1,
+ * nn/functional/query.py:32).  The reference builds a 3-function cuckoo table with host-side
+ * rehash retries and two device syncs per call; here: one open-addressing table in `workspace`
+ * (linear probing, 64-bit CAS insert of the key, atomicMin on the index for first-wins), no sync,
+ * no reserved key.  Workspace need not be initialised.  `link_hash_query_workspace_bytes(n)`. */
+size_t link_hash_query_workspace_bytes(int64_t n_target);
+int link_hash_query(const int64_t *query, int64_t n1, const int64_t *target,
+                    const int64_t *target_idx, int64_t n, int64_t *out, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* count_cuda(idx i32[N], s) -> i32[s]         backend/others/count_cuda.cu:10-31
+ * Histogram; idx<0 (or >= s) ignored.  `out` is zeroed by the call. */
+int link_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stream);
+
+/* voxelize_forward_cuda(in fp[N,c], idx i32[N], counts i32[N1]) -> fp[N1,c]
+ *                                             backend/voxelize/voxelize_cuda.cu:12-25,44-61
+ * out[idx[i]] += in[i] / (float)counts[idx[i]].  `out` is zeroed by the call.  Generic form for an
+ * arbitrary idx (fp32 atomics, like the reference); the indexed, deterministic form is B.2. */
+int link_voxelize_forward(const float *in, const int32_t *idx, const int32_t *counts, int64_t n,
+                          int64_t c, int64_t n1, float *out, void *stream);
+
+/* voxelize_backward_cuda(top fp[N1,c], idx, counts, N) -> fp[N,c]
+ *                                             backend/voxelize/voxelize_cuda.cu:28-42,63-80
+ * bottom[i] = top[idx[i]] / counts[idx[i]]  (0 where idx[i] < 0). */
+int link_voxelize_backward(const float *top, const int32_t *idx, const int32_t *counts, int64_t n,
+                           int64_t c, float *bottom, void *stream);
+
+/* devoxelize_forward_cuda(feat fp[n,c], ind i32[N,K], w fp[N,K], r) -> fp[N,c],  K = r^3
+ *                                             backend/devoxelize/devoxelize_cuda.cu:11-34,63-81
+ * out[i] = sum_{k<K, ind>=0} w[i,k]*feat[ind[i,k]], k ascending (deterministic). */
+int link_devoxelize_forward(const float *feat, const int32_t *ind, const float *w, int64_t nq,
+                            int64_t c, int64_t k, float *out, void *stream);
+
+/* devoxelize_backward_cuda(top fp[N,c], ind, w, n, r) -> fp[n,c]
+ *                                             backend/devoxelize/devoxelize_cuda.cu:37-59,85-101
+ * bottom[ind[i,k]] += w[i,k]*top[i].  `bottom` is zeroed by the call (fp32 atomics). */
+int link_devoxelize_backward(const float *top, const int32_t *ind, const float *w, int64_t nq,
+                             int64_t n, int64_t c, int64_t k, float *bottom, void *stream);
+
+/* =============================================================================================
+ * B. Block index + indexed aggregation (fused voxel_to_aux / aux_to_voxel)
+ * ============================================================================================= */
+
+/* Dense block grid covering the frame.  Block coordinate of a voxel = (floor(x/s), floor(y/s),
+ * floor(z/s), b) (utils.py:45); `lo` is the smallest block coordinate per axis, `dim` the extent in
+ * blocks.  Cells are linearised x-major: cell = (((bx-lo0)*dim1 + (by-lo1))*dim2 + (bz-lo2))*dim3 +
+ * (bb-lo3), which is exactly the signed lexicographic row order torch.unique(dim=0) produces
+ * (utils.py:47), so the rank of an occupied cell among occupied cells IS the reference's block id. */
+typedef struct {
+  int32_t s;       /* block edge in voxel-coordinate units (the `s` of voxel_to_aux) */
+  int32_t lo[4];   /* block-coordinate lower bound (x,y,z,b) */
+  int32_t dim[4];  /* block-grid extent (x,y,z,b); product = number of cells V (< 2^30) */
+} link_grid_t;
+
+/* Host helper: grid from inclusive voxel-coordinate bounds lo/hi[4] (x,y,z,b).  Returns V or -1. */
+int64_t link_grid_from_bounds(const int32_t lo[4], const int32_t hi[4], int32_t s, link_grid_t *g);
+
+/* Device bounding box of coords (for callers that do not know the bounds): writes
+ * bbox[8] = {min x,y,z,b, max x,y,z,b}.  One pass, per-workgroup reduction + 8 atomics per
+ * workgroup.  `bbox` must be initialised by the caller to {INT_MAX x4, INT_MIN x4}. */
+int link_coords_bbox(const int32_t *coords, int64_t n, int32_t *bbox, void *stream);
+
+/* Index header written by link_index_build (device int32[LINK_HDR_WORDS]). */
+#define LINK_HDR_M 0        /* number of occupied blocks M */
+#define LINK_HDR_STATUS 1   /* 0 ok; bit0: a voxel lay outside the grid (index invalid) */
+#define LINK_HDR_NVALID 2   /* number of voxels indexed (= N when status == 0) */
+#define LINK_HDR_WORDS 8
+
+/* Scratch sizes for link_index_build (bytes). `cell_counts` (V u32) MUST be all-zero on entry and is
+ * all-zero again on exit (the scan clears what it consumes), so one allocation zeroed once serves
+ * every later call.  `scratch` needs no initialisation. */
+size_t link_index_scratch_bytes(int64_t n, int64_t v);
+
+/* Build the block index of a frame: replaces sphash + torch.unique + sphash + sphashquery + spcount
+ * of voxel_to_aux (utils.py:45-51) by counting into the dense grid + one decoupled-look-back scan.
+ * Outputs (caller-allocated; M <= N so N rows always suffice):
+ *   cell_blk   i32[V]    block id + 1 of each cell, 0 = empty       (neighbour lookup table)
+ *   vox_blk    i32[N]    block id of each voxel                      (== idx_query, utils.py:50)
+ *   idx_query  i64[N]    same as int64 (may be NULL)                 (reference dtype)
+ *   perm       i32[N]    voxel ids grouped by block, ascending voxel id inside a block
+ *   blk_start  i32[N+1]  start of each block's segment in perm; blk_start[M] = N
+ *   blk_coords i32[N,4]  block coordinates, rows [0,M) valid         (== small_x.C, utils.py:47)
+ *   counts     i32[N]    voxels per block, rows [0,M) valid          (== spcount, utils.py:51)
+ *   hdr        i32[8]    see LINK_HDR_*
+ * Bit-exact with the reference for small_x.C / idx_query / counts. */
+int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /* host */,
+                     uint32_t *cell_counts, void *scratch, size_t scratch_bytes, int32_t *cell_blk,
+                     int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *blk_start,
+                     int32_t *blk_coords, int32_t *counts, int32_t *hdr, void *stream);
+
+/* Neighbour map nbr i32[M,K] (K = r^3, offsets in get_kernel_offsets(r) order, nn/utils/kernel.py:
+ * 11-32: odd r x fastest, even r z fastest): replaces sphash(C, offsets) + sphash + sphashquery +
+ * transpose of aux_to_voxel (utils.py:65-73).  -1 = absent.  `m` may be an upper bound (rows past
+ * hdr[M] are not written); transpose != 0 uses negated offsets (the adjoint relation, needed by the
+ * backward pass when r is even).  Bit-exact. */
+int link_neighbor_map(const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid,
+                      const int32_t *hdr, int64_t m, int32_t r, int32_t transpose, int32_t *nbr,
+                      void *stream);
+
+/* Same for arbitrary (foreign) block rows: first scatter row ids into a cell table that the caller
+ * zero-initialised (first row wins for duplicates), then look up.  Rows outside the grid -> status. */
+int link_cell_table_build(const int32_t *rows, int64_t m, const link_grid_t *grid, int32_t *cell_blk,
+                          int32_t *hdr, void *stream);
+
+/* Indexed block mean (spvoxelize forward, utils.py:52): out[b] = sum_{i in block b, ascending i}
+ * in[i]/counts[b].  Deterministic, no atomics; rows [0,M) of out[.,c] written.  `m_cap` = rows
+ * allocated in `out` (>= M). */
+int link_block_mean(const float *in, const int32_t *perm, const int32_t *blk_start,
+                    const int32_t *hdr, int64_t n, int64_t c, int64_t m_cap, float *out, void *stream);
+
+/* Adjoint of link_block_mean (spvoxelize backward): bottom[i] = top[vox_blk[i]]/counts[vox_blk[i]]
+ * is link_voxelize_backward (A). */
+
+/* aux_to_voxel feature half (utils.py:75-82):
+ *   new[m] = sum_k small_f[nbr[m,k]]*counts[nbr[m,k]] / sum_k counts[nbr[m,k]] ; out[i] = new[idx[i]].
+ * small_f fp[M,c] block means, nbr i32[M,K], idx i64[N].  `new_feat` fp[M,c] and `denom` fp[M]
+ * (sum of neighbour counts) are kept for the backward pass.  k ascending, deterministic. */
+int link_aux_to_voxel_forward(const float *small_f, const int32_t *counts, const int32_t *nbr,
+                              const int64_t *idx, int64_t n, int64_t m, int64_t c, int64_t k,
+                              float *new_feat, float *denom, float *out, void *stream);
+
+/* Backward of the above wrt small_f: given g_out fp[N,c]:
+ *   g_new[m] = sum_{i: idx[i]==m} g_out[i]            (segmented via perm/blk_start: deterministic)
+ *   g_small[j] = counts[j] * sum_{m: j in nbr(m)} g_new[m]/denom[m]   (via the transposed map nbr_t)
+ * g_new fp[M,c] is scratch. */
+int link_aux_to_voxel_backward(const float *g_out, const int32_t *perm, const int32_t *blk_start,
+                               const int32_t *counts, const int32_t *nbr_t, const float *denom,
+                               int64_t n, int64_t m, int64_t c, int64_t k, float *g_new,
+                               float *g_small, void *stream);
+
+/* =============================================================================================
+ * C. Fused ELKBlock core (R_core of SURVEY.md section 8d)
+ * ============================================================================================= */
+
+#define LINK_OP_COS 0   /* linkunet.py:150-162 / ts_elk.py:166-177   X = [F cos, F sin]            */
+#define LINK_OP_SIN 1   /* linkunet.py:136-148 / ts_elk.py:155-164   X = [F sin, F cos], minus sign */
+#define LINK_OP_COSX 2  /* linkunet.py:164-176                       X = [F cos, F sin, F theta]    */
+
+typedef struct {
+  int32_t op;            /* LINK_OP_* */
+  int32_t c;             /* channels C (inc) */
+  int32_t cg;            /* theta channels: channel j uses theta[j % cg]  (C/groups; C for cos_x) */
+  int32_t r;             /* neighbourhood edge in blocks */
+  float coord_div;       /* theta input = float(coord) / coord_div (float division, as the reference
+                            does it): 1.0 everywhere except the encoder cos_x variant, which feeds
+                            coords / tensor_stride (linkencoder.py:165) */
+  float eps;             /* LayerNorm eps (1e-6, linkunet.py:111,121) */
+} link_elk_desc_t;
+
+/* pre_mix: fin = LayerNorm(F @ Wpre^T) * g + b  (linkunet.py:109-112,132).  F fp[N,C], Wpre fp[C,C]
+ * (nn.Linear layout [out,in]).  C <= 256. */
+int link_premix_ln(const float *feats, const float *w_pre, const float *ln_w, const float *ln_b,
+                   int64_t n, int32_t c, float eps, float *fin, void *stream);
+
+/* Modulate + per-block pre-aggregation (linkunet.py:151-160 + utils.py:52,75-76 fused):
+ *   theta = (float(xyz)/coord_div) @ Wpos^T (* alpha), tiled by cg;
+ *   S[b] = [ sum_i fin_i*cos(theta_i), sum_i fin_i*sin(theta_i) (, sum_i fin_i*theta_i), count_b ]
+ * over the voxels of block b in ascending voxel id.  S fp[M_cap, nparts*C + 1] (block SUMS, not
+ * means: mean*count of the reference re-multiplies what it just divided).  w_pos fp[cg,3]; alpha
+ * fp[cg] or NULL. */
+int link_modulate_block_sum(const float *fin, const int32_t *coords, const float *w_pos,
+                            const float *alpha, const int32_t *perm, const int32_t *blk_start,
+                            const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
+                            int64_t m_cap, float *S, void *stream);
+
+/* Neighbour-block sum + normalise + broadcast + de-modulate + LayerNorm(norm)
+ * (utils.py:65-82 + linkunet.py:162,178 fused): for every block the r^3 neighbour rows of S are
+ * summed in get_kernel_offsets order, divided by the summed count, and every voxel of the block gets
+ *   new = A_cos*cos(theta) + A_sin*sin(theta) [+ (A_lin - fin*theta)]   ('sin': A_cos*cos - A_sin*sin
+ *   with X=[F sin, F cos]) ; out = LayerNorm(new)*g + b.
+ * `fin` is only read for LINK_OP_COSX (may be NULL otherwise).  out fp[N,C]. */
+int link_gather_demod_ln(const float *S, const float *fin, const int32_t *coords, const float *w_pos,
+                         const float *alpha, const float *ln_w, const float *ln_b,
+                         const int32_t *perm, const int32_t *blk_start, const int32_t *blk_coords,
+                         const int32_t *cell_blk, const link_grid_t *grid /* host */,
+                         const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
+                         int64_t m_cap, float *out, void *stream);
+
+/* One-call form of the whole R_core step (what bench.py times): optional index build (section B)
+ * followed by the three section-C kernels, all on `stream`, from caller-owned buffers.  Exists so
+ * that a host written in an interpreted language pays ONE FFI crossing per LinK block instead of one
+ * per kernel.  All pointers are device pointers with the meanings documented above. */
+typedef struct {
+  const float *feats;        /* fp[N,C]  block input (st.F) */
+  const int32_t *coords;     /* i32[N,4] (st.C) */
+  const float *w_pre, *pre_ln_w, *pre_ln_b;   /* pre_mix.0.weight [C,C], pre_mix.1.{weight,bias} [C] */
+  const float *w_pos, *alpha;                 /* pos_weight.0.weight [cg,3]; alpha [cg] or NULL */
+  const float *ln_w, *ln_b;                   /* norm.{weight,bias} [C] */
+  uint32_t *cell_counts; void *scratch; size_t scratch_bytes;          /* link_index_build scratch */
+  int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *blk_start, *blk_coords, *counts, *hdr;
+  float *fin;                /* fp[N,C]            scratch: pre_mix output */
+  float *S;                  /* fp[m_cap, P*C+4]   scratch: block table */
+  float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
+} link_elk_buffers_t;
+
+int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
+                          const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
+                          int32_t build_index, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINK_AMD_H_ */

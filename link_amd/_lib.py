@@ -1,0 +1,140 @@
+"""link_amd/_lib.py -- ctypes binding of liblink_amd.so (the C ABI declared in include/link_amd.h).
+
+The product path is HIP-only: if the shared library is missing this module raises at import of the
+first symbol -- there is no CPU or PyTorch fallback (the oracle under oracle/ is test infrastructure
+and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
+
+LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
+HDR_M, HDR_STATUS, HDR_NVALID, HDR_WORDS = 0, 1, 2, 8
+OP_COS, OP_SIN, OP_COSX = 0, 1, 2
+ABI_VERSION = 1
+
+
+class LinkGrid(Structure):
+    """link_grid_t"""
+    _fields_ = [("s", c_int32), ("lo", c_int32 * 4), ("dim", c_int32 * 4)]
+
+    @property
+    def cells(self) -> int:
+        v = 1
+        for d in self.dim:
+            v *= int(d)
+        return v
+
+    def key(self):
+        return (int(self.s), tuple(int(x) for x in self.lo), tuple(int(x) for x in self.dim))
+
+
+class LinkElkDesc(Structure):
+    """link_elk_desc_t"""
+    _fields_ = [("op", c_int32), ("c", c_int32), ("cg", c_int32), ("r", c_int32),
+                ("coord_div", c_float), ("eps", c_float)]
+
+
+class LinkElkBuffers(Structure):
+    """link_elk_buffers_t"""
+    _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha",
+                                        "ln_w", "ln_b", "cell_counts", "scratch")] + \
+               [("scratch_bytes", c_size_t)] + \
+               [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "blk_start", "blk_coords",
+                                        "counts", "hdr", "fin", "S", "out")]
+
+
+# name -> (restype, argtypes); every symbol include/link_amd.h declares
+SIGNATURES = {
+    "link_abi_version": (c_int, []),
+    "link_last_error": (c_char_p, []),
+    "link_hash": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "link_kernel_hash": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "link_hash_query_workspace_bytes": (c_size_t, [c_int64]),
+    "link_hash_query": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
+    "link_count": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "link_voxelize_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                      c_void_p]),
+    "link_voxelize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "link_devoxelize_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                        c_void_p]),
+    "link_devoxelize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                         c_void_p, c_void_p]),
+    "link_grid_from_bounds": (c_int64, [POINTER(c_int32), POINTER(c_int32), c_int32, POINTER(LinkGrid)]),
+    "link_coords_bbox": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "link_index_scratch_bytes": (c_size_t, [c_int64, c_int64]),
+    "link_index_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_size_t,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "link_neighbor_map": (c_int, [c_void_p, c_void_p, POINTER(LinkGrid), c_void_p, c_int64, c_int32,
+                                  c_int32, c_void_p, c_void_p]),
+    "link_cell_table_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_void_p]),
+    "link_block_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                c_void_p, c_void_p]),
+    "link_aux_to_voxel_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                          c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_aux_to_voxel_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                           c_void_p]),
+    "link_premix_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                               c_void_p, c_void_p]),
+    "link_modulate_block_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, POINTER(LinkElkDesc), c_int64, c_int64, c_void_p,
+                                        c_void_p]),
+    "link_gather_demod_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, POINTER(LinkGrid), c_void_p,
+                                     POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
+    "link_elk_core_forward": (c_int, [POINTER(LinkElkBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc),
+                                      c_int64, c_int64, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+class LinkAmdError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblink_amd.so (once).  Fails loudly: no fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LinkAmdError(
+                f"{SO_PATH} not found: the HIP extension is not built. Run `python link_amd/build.py` "
+                "(or __graft_entry__.build()). link_amd has no CPU/PyTorch fallback.")
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.link_abi_version() != ABI_VERSION:
+            raise LinkAmdError("liblink_amd.so ABI version mismatch; rebuild with link_amd/build.py")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != LINK_OK:
+        msg = {LINK_ERR_ARG: "invalid argument", LINK_ERR_LAUNCH: "HIP launch failure",
+               LINK_ERR_WORKSPACE: "workspace too small"}.get(rc, f"error {rc}")
+        detail = lib().link_last_error()
+        raise LinkAmdError(f"{what}: {msg}" + (f" ({detail.decode()})" if detail else ""))
+
+
+def grid_from_bounds(lo, hi, s: int) -> LinkGrid:
+    """Host helper (no GPU needed): block grid covering voxel coords lo..hi (inclusive)."""
+    g = LinkGrid()
+    lo_a = (c_int32 * 4)(*[int(x) for x in lo])
+    hi_a = (c_int32 * 4)(*[int(x) for x in hi])
+    v = lib().link_grid_from_bounds(lo_a, hi_a, int(s), ctypes.byref(g))
+    if v < 0:
+        raise LinkAmdError(f"grid_from_bounds({list(lo)}, {list(hi)}, s={s}): bounds invalid or grid "
+                           ">= 2^30 cells")
+    return g

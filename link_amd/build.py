@@ -1,0 +1,65 @@
+"""link_amd/build.py -- compile the HIP sources into link_amd/lib/liblink_amd.so (gfx950 only).
+
+One plain `hipcc --offload-arch=gfx950 -shared -fPIC` invocation per translation unit + one link;
+no torch involved (the library's ABI is include/link_amd.h: pointers, sizes, a stream).  hipcc
+cross-compiles without a GPU, so this runs in the build container; the .so travels to the GPU box
+with the snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+SO = os.path.join(LIBDIR, "liblink_amd.so")
+SOURCES = ["ops.hip", "index.hip", "aggregate.hip", "elk.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+         "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for p in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if p == "hipcc" or os.path.exists(p):
+            return p
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ["../../include/link_amd.h"]:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode()); h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp_file = os.path.join(LIBDIR, "stamp")
+    stamp = _stamp()
+    if not force and os.path.exists(SO) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return SO
+    cc = _hipcc()
+
+    def one(src):
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SOURCES))
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

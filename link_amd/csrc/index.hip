@@ -1,0 +1,429 @@
+// link_amd/csrc/index.hip -- section B (index half) of include/link_amd.h.
+//
+// Replaces the reference's  sphash -> torch.unique(dim=0) -> sphash -> sphashquery -> spcount  chain
+// (segmentation/core/models/utils.py:45-51) and the neighbour query sphash(C,offsets) -> sphashquery
+// (utils.py:65-73) by direct addressing into a dense block grid:
+//
+//   k_cell_count   one thread per voxel: block coordinate -> cell, rank = atomicAdd(cell_counts[cell])
+//   k_cell_scan    ONE decoupled-look-back scan over the V cells: exclusive prefix of (occupied, count)
+//                  gives at once the block id of every occupied cell -- its rank in x-major cell order,
+//                  which is torch.unique's lexicographic row order -- and the start of the block's
+//                  voxel segment; it also clears the counters it consumed (self-cleaning scratch)
+//   k_place        scatter voxel ids to blk_start[blk] + rank
+//   k_sort_seg     order each block's segment by voxel id (ranks came from atomics, so their order
+//                  is arbitrary; downstream reductions must not depend on it)
+//
+// No hashing, no sort passes, no host sync; 4 launches, O(N + V) bytes.
+#include <limits.h>
+
+#include "common.h"
+
+using namespace link;
+
+// ---------------------------------------------------------------------------------------------
+// host helper
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t link_grid_from_bounds(const int32_t lo[4], const int32_t hi[4], int32_t s,
+                                         link_grid_t *g) {
+  if (!lo || !hi || !g || s <= 0) return -1;
+  g->s = s;
+  int64_t v = 1;
+  for (int a = 0; a < 4; a++) {
+    if (hi[a] < lo[a]) return -1;
+    int32_t blo = (a < 3) ? floordiv(lo[a], s) : lo[a];
+    int32_t bhi = (a < 3) ? floordiv(hi[a], s) : hi[a];
+    g->lo[a] = blo;
+    int64_t d = (int64_t)bhi - (int64_t)blo + 1;
+    if (d <= 0 || d >= (1LL << 30)) return -1;
+    g->dim[a] = (int32_t)d;
+    v *= d;
+    if (v >= (1LL << 30)) return -1;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bbox
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bbox(const int4 *__restrict__ coords, int64_t n, int32_t *bbox) {
+  int mn[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+  int mx[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int4 c = coords[i];
+    mn[0] = min(mn[0], c.x); mx[0] = max(mx[0], c.x);
+    mn[1] = min(mn[1], c.y); mx[1] = max(mx[1], c.y);
+    mn[2] = min(mn[2], c.z); mx[2] = max(mx[2], c.z);
+    mn[3] = min(mn[3], c.w); mx[3] = max(mx[3], c.w);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  __shared__ int smn[4][4], smx[4][4];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    for (int a = 0; a < 4; a++) { smn[wave][a] = mn[a]; smx[wave][a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    int a = threadIdx.x;
+    int m0 = min(min(smn[0][a], smn[1][a]), min(smn[2][a], smn[3][a]));
+    int m1 = max(max(smx[0][a], smx[1][a]), max(smx[2][a], smx[3][a]));
+    atomicMin(&bbox[a], m0);
+    atomicMax(&bbox[4 + a], m1);
+  }
+}
+
+extern "C" int link_coords_bbox(const int32_t *coords, int64_t n, int32_t *bbox, void *stream) {
+  if (n < 0 || !bbox || (n > 0 && !coords)) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  unsigned nb = blocks_for(n, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords),
+                     n, bbox);
+  return check_launch("link_coords_bbox");
+}
+
+// ---------------------------------------------------------------------------------------------
+// index build
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 cells per workgroup
+
+struct IndexScratch {
+  int32_t *vox_cell;   // [n]
+  int32_t *vox_rank;   // [n]
+  int32_t *perm_tmp;   // [n]
+  unsigned long long *desc;  // [tiles]
+  unsigned int *ticket;      // [1] (+pad)
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline int64_t scan_tiles(int64_t v) { return (v + SCAN_TILE - 1) / SCAN_TILE; }
+
+extern "C" size_t link_index_scratch_bytes(int64_t n, int64_t v) {
+  if (n < 0) n = 0;
+  if (v < 0) v = 0;
+  return 3 * align256((size_t)n * 4) + align256((size_t)scan_tiles(v) * 8) + 256;
+}
+
+static IndexScratch carve(void *scratch, int64_t n, int64_t v) {
+  char *p = reinterpret_cast<char *>(scratch);
+  IndexScratch s;
+  s.vox_cell = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
+  s.vox_rank = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
+  s.perm_tmp = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
+  s.desc = reinterpret_cast<unsigned long long *>(p); p += align256((size_t)scan_tiles(v) * 8);
+  s.ticket = reinterpret_cast<unsigned int *>(p);
+  return s;
+}
+
+__global__ void __launch_bounds__(256) k_cell_count(const int4 *__restrict__ coords, int64_t n,
+                                                    link_grid_t g, unsigned int *cell_counts,
+                                                    int32_t *__restrict__ vox_cell,
+                                                    int32_t *__restrict__ vox_rank,
+                                                    unsigned long long *desc, int64_t tiles,
+                                                    unsigned int *ticket) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // side job: reset the scan's tile descriptors and ticket (ordered before k_cell_scan by the
+  // kernel boundary)
+  for (int64_t t = gid; t < tiles; t += (int64_t)gridDim.x * blockDim.x) desc[t] = 0ULL;
+  if (gid == 0) *ticket = 0u;
+  if (gid >= n) return;
+  int4 c = coords[gid];
+  int32_t cell = cell_of(g, floordiv(c.x, g.s), floordiv(c.y, g.s), floordiv(c.z, g.s), c.w);
+  vox_cell[gid] = cell;
+  if (cell >= 0) vox_rank[gid] = (int32_t)atomicAdd(&cell_counts[cell], 1u);
+}
+
+// descriptor: [63:62] flag (0 invalid, 1 aggregate, 2 inclusive prefix) [61:31] occupied [30:0] voxels
+__device__ __forceinline__ unsigned long long pack_desc(unsigned flag, unsigned occ, unsigned cnt) {
+  return ((unsigned long long)flag << 62) | ((unsigned long long)occ << 31) | (unsigned long long)cnt;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_cell_scan(
+    unsigned int *cell_counts, int64_t v, link_grid_t g, unsigned long long *desc, unsigned int *ticket,
+    int64_t tiles, int32_t *__restrict__ cell_blk, int32_t *__restrict__ blk_start,
+    int32_t *__restrict__ blk_coords, int32_t *__restrict__ counts, int32_t *__restrict__ hdr) {
+  __shared__ unsigned int s_tile;
+  __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+  __shared__ unsigned long long s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // dynamic tile id: predecessors have all started
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int64_t base = tile * SCAN_TILE + (int64_t)tid * SCAN_ITEMS;
+
+  unsigned int cnt[SCAN_ITEMS];
+  if (base + SCAN_ITEMS <= v) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(cell_counts + base);
+    uint4 a = p[0], b = p[1];
+    cnt[0] = a.x; cnt[1] = a.y; cnt[2] = a.z; cnt[3] = a.w;
+    cnt[4] = b.x; cnt[5] = b.y; cnt[6] = b.z; cnt[7] = b.w;
+    uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 *q = reinterpret_cast<uint4 *>(cell_counts + base);
+    q[0] = z; q[1] = z;  // self-clean
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      cnt[k] = (base + k < v) ? cell_counts[base + k] : 0u;
+      if (base + k < v) cell_counts[base + k] = 0u;
+    }
+  }
+  // thread aggregate as (occ << 32 | voxels)
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) mine += ((unsigned long long)(cnt[k] != 0u) << 32) | cnt[k];
+  // inclusive wave scan
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    unsigned long long x = s_wave[w];
+    if (w < wave) wave_off += x;
+    total += x;
+  }
+  // ---- decoupled look-back by wave 0
+  if (wave == 0) {
+    const unsigned t_occ = (unsigned)(total >> 32), t_cnt = (unsigned)(total & 0xFFFFFFFFu);
+    unsigned long long excl = 0;  // (occ << 32 | cnt) of all earlier tiles
+    if (tile == 0) {
+      if (lane == 0)
+        __hip_atomic_store(&desc[0], pack_desc(2u, t_occ, t_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(&desc[tile], pack_desc(1u, t_occ, t_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t look = tile - 1;
+      for (;;) {
+        int64_t t = look - lane;
+        unsigned long long d;
+        if (t >= 0) {
+          do {
+            d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((d >> 62) == 0ULL);
+        } else {
+          d = pack_desc(2u, 0u, 0u);  // virtual tiles before tile 0: prefix 0
+        }
+        unsigned flag = (unsigned)(d >> 62);
+        unsigned long long val = (((d >> 31) & 0x7FFFFFFFULL) << 32) | (d & 0x7FFFFFFFULL);
+        unsigned long long pmask = __ballot(flag == 2u);
+        if (pmask != 0ULL) {
+          int first = __ffsll((long long)pmask) - 1;  // nearest tile holding an inclusive prefix
+          unsigned long long contrib = (lane <= first) ? val : 0ULL;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+          excl += contrib;
+          break;
+        }
+        unsigned long long contrib = val;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+        excl += contrib;
+        look -= 64;
+      }
+      if (lane == 0) {
+        unsigned long long inc = excl + total;
+        __hip_atomic_store(&desc[tile], pack_desc(2u, (unsigned)(inc >> 32), (unsigned)(inc & 0xFFFFFFFFu)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == tiles - 1) {  // grand totals
+        unsigned long long inc = excl + total;
+        int32_t m = (int32_t)(inc >> 32), nv = (int32_t)(inc & 0xFFFFFFFFu);
+        hdr[LINK_HDR_M] = m;
+        hdr[LINK_HDR_STATUS] = 0;
+        hdr[LINK_HDR_NVALID] = nv;
+        blk_start[m] = nv;
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long pre = s_excl + wave_off + (incl - mine);
+  unsigned occ = (unsigned)(pre >> 32), vox = (unsigned)(pre & 0xFFFFFFFFu);
+  const uint32_t d3 = (uint32_t)g.dim[3], d2 = (uint32_t)g.dim[2], d1 = (uint32_t)g.dim[1];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    int64_t cell = base + k;
+    if (cell < v) {
+      if (cnt[k] != 0u) {
+        cell_blk[cell] = (int32_t)occ + 1;
+        blk_start[occ] = (int32_t)vox;
+        counts[occ] = (int32_t)cnt[k];
+        uint32_t cc = (uint32_t)cell;
+        uint32_t ub = cc % d3; cc /= d3;
+        uint32_t uz = cc % d2; cc /= d2;
+        uint32_t uy = cc % d1; cc /= d1;
+        int4 bc = make_int4((int32_t)cc + g.lo[0], (int32_t)uy + g.lo[1], (int32_t)uz + g.lo[2],
+                            (int32_t)ub + g.lo[3]);
+        reinterpret_cast<int4 *>(blk_coords)[occ] = bc;
+        occ++;
+        vox += cnt[k];
+      } else {
+        cell_blk[cell] = 0;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_place(const int32_t *__restrict__ vox_cell,
+                                               const int32_t *__restrict__ vox_rank, int64_t n,
+                                               const int32_t *__restrict__ cell_blk,
+                                               const int32_t *__restrict__ blk_start,
+                                               int32_t *__restrict__ perm_tmp,
+                                               int32_t *__restrict__ vox_blk,
+                                               int64_t *__restrict__ idx_query, int32_t *hdr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t cell = vox_cell[i];
+  int32_t blk = -1;
+  if (cell >= 0) {
+    blk = cell_blk[cell] - 1;
+    perm_tmp[blk_start[blk] + vox_rank[i]] = (int32_t)i;
+  } else {
+    atomicOr(&hdr[LINK_HDR_STATUS], 1);
+  }
+  vox_blk[i] = blk;
+  if (idx_query) idx_query[i] = (int64_t)blk;
+}
+
+// Order every block's segment by voxel id.  Segment lengths are tiny (<= s^3 for unique voxels), so
+// each position counts its smaller neighbours directly: sum of n_b^2 loads, all L1/L2 hits.
+constexpr int SORT_MAX_SEG = 8192;
+__global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ perm_tmp,
+                                                  const int32_t *__restrict__ vox_blk,
+                                                  const int32_t *__restrict__ blk_start,
+                                                  const int32_t *__restrict__ hdr, int64_t n,
+                                                  int32_t *__restrict__ perm) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || p >= hdr[LINK_HDR_NVALID]) return;
+  int32_t i = perm_tmp[p];
+  int32_t b = vox_blk[i];
+  int32_t st = blk_start[b], en = blk_start[b + 1];
+  int32_t len = en - st;
+  int64_t dst = p;
+  if (len > 1 && len <= SORT_MAX_SEG) {
+    int32_t r = 0;
+    for (int32_t q = st; q < en; q++) r += (perm_tmp[q] < i);
+    dst = st + r;
+  }
+  perm[dst] = i;
+}
+
+extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid,
+                                uint32_t *cell_counts, void *scratch, size_t scratch_bytes,
+                                int32_t *cell_blk, int32_t *vox_blk, int64_t *idx_query, int32_t *perm,
+                                int32_t *blk_start, int32_t *blk_coords, int32_t *counts, int32_t *hdr,
+                                void *stream) {
+  if (n < 0 || n >= (1LL << 31) || !grid || !hdr) return LINK_ERR_ARG;
+  int64_t v = 1;
+  for (int a = 0; a < 4; a++) {
+    if (grid->dim[a] <= 0) return LINK_ERR_ARG;
+    v *= grid->dim[a];
+    if (v >= (1LL << 30)) return LINK_ERR_ARG;
+  }
+  if (grid->s <= 0) return LINK_ERR_ARG;
+  if (!cell_counts || !scratch || !cell_blk || !blk_start || !blk_coords || !counts) return LINK_ERR_ARG;
+  if (n > 0 && (!coords || !vox_blk || !perm)) return LINK_ERR_ARG;
+  if (scratch_bytes < link_index_scratch_bytes(n, v)) return LINK_ERR_WORKSPACE;
+  IndexScratch sc = carve(scratch, n, v);
+  const int64_t tiles = scan_tiles(v);
+  hipStream_t st = S(stream);
+  int64_t cc_threads = n > tiles ? n : tiles;
+  if (cc_threads > (1 << 22)) cc_threads = (n > (1 << 22)) ? n : (1 << 22);
+  hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(cc_threads, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const int4 *>(coords), n, *grid, cell_counts, sc.vox_cell,
+                     sc.vox_rank, sc.desc, tiles, sc.ticket);
+  hipLaunchKernelGGL(k_cell_scan, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, st, cell_counts, v,
+                     *grid, sc.desc, sc.ticket, tiles, cell_blk, blk_start, blk_coords, counts, hdr);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_place, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.vox_cell, sc.vox_rank, n,
+                       cell_blk, blk_start, sc.perm_tmp, vox_blk, idx_query, hdr);
+    hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, vox_blk,
+                       blk_start, hdr, n, perm);
+  }
+  return check_launch("link_index_build");
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour map
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kernel_offset(int r, int k, int &ox, int &oy, int &oz) {
+  // get_kernel_offsets(r, 1, 1) (nn/utils/kernel.py:11-32): per axis arange(-r//2+1, r//2+1);
+  // odd volume: x fastest (z outer); even volume: z fastest (x outer).
+  int lo = -((r + 1) / 2) + 1;
+  int a = k % r, b = (k / r) % r, c = k / (r * r);
+  if ((r & 1) != 0) { ox = lo + a; oy = lo + b; oz = lo + c; }
+  else { oz = lo + a; oy = lo + b; ox = lo + c; }
+}
+
+__global__ void __launch_bounds__(256) k_neighbor_map(const int4 *__restrict__ blk_coords,
+                                                      const int32_t *__restrict__ cell_blk,
+                                                      link_grid_t g, const int32_t *__restrict__ hdr,
+                                                      int64_t m_cap, int r, int K, int sign,
+                                                      int32_t *__restrict__ nbr) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t m = hdr ? (int64_t)hdr[LINK_HDR_M] : m_cap;
+  if (m > m_cap) m = m_cap;
+  if (t >= m * K) return;
+  int64_t row = t / K;
+  int k = (int)(t - row * K);
+  int4 c = blk_coords[row];
+  int ox, oy, oz;
+  kernel_offset(r, k, ox, oy, oz);
+  int32_t cell = cell_of(g, c.x + sign * ox, c.y + sign * oy, c.z + sign * oz, c.w);
+  nbr[t] = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+}
+
+extern "C" int link_neighbor_map(const int32_t *blk_coords, const int32_t *cell_blk,
+                                 const link_grid_t *grid, const int32_t *hdr, int64_t m, int32_t r,
+                                 int32_t transpose, int32_t *nbr, void *stream) {
+  if (m < 0 || r <= 0 || r > 15 || !grid) return LINK_ERR_ARG;
+  if (m == 0) return LINK_OK;
+  if (!blk_coords || !cell_blk || !nbr) return LINK_ERR_ARG;
+  int K = r * r * r;
+  hipLaunchKernelGGL(k_neighbor_map, dim3(blocks_for(m * K, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(blk_coords), cell_blk, *grid, hdr, m, (int)r, K,
+                     transpose ? -1 : 1, nbr);
+  return check_launch("link_neighbor_map");
+}
+
+__global__ void __launch_bounds__(256) k_cell_table(const int4 *__restrict__ rows, int64_t m,
+                                                    link_grid_t g, unsigned int *cell_blk, int32_t *hdr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int4 c = rows[i];
+  int32_t cell = cell_of(g, c.x, c.y, c.z, c.w);
+  if (cell < 0) { if (hdr) atomicOr(&hdr[LINK_HDR_STATUS], 1); return; }
+  unsigned v = (unsigned)i + 1u;  // first (smallest) row wins, like the reference's insert-if-absent
+  unsigned old = atomicCAS(&cell_blk[cell], 0u, v);
+  while (old != 0u && old > v) {
+    unsigned prev = atomicCAS(&cell_blk[cell], old, v);
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+extern "C" int link_cell_table_build(const int32_t *rows, int64_t m, const link_grid_t *grid,
+                                     int32_t *cell_blk, int32_t *hdr, void *stream) {
+  if (m < 0 || !grid) return LINK_ERR_ARG;
+  if (m == 0) return LINK_OK;
+  if (!rows || !cell_blk) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_cell_table, dim3(blocks_for(m, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(rows), m, *grid,
+                     reinterpret_cast<unsigned int *>(cell_blk), hdr);
+  return check_launch("link_cell_table_build");
+}

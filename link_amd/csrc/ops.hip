@@ -1,0 +1,321 @@
+// link_amd/csrc/ops.hip -- section A of include/link_amd.h: gfx950 replacements for the
+// `torchsparse.backend` functions on the LinK path (reference:
+// segmentation/torchsparse-u/torchsparse/backend/{hash,others,hashmap,voxelize,devoxelize}).
+// Written for CDNA4 directly: 64-wide waves, row-per-wave feature kernels with 16-byte lanes where
+// the width allows, no host syncs, no allocation.
+#include <string.h>
+
+#include <string>
+
+#include "common.h"
+
+namespace link {
+static thread_local std::string g_err;
+void set_error(const char *what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+}  // namespace link
+
+using namespace link;
+
+extern "C" int link_abi_version(void) { return 1; }
+extern "C" const char *link_last_error(void) { return link::g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// hash / kernel_hash: one thread per row; rows are 16 B so a wave reads 1 KiB contiguous (int4).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hash(const int4 *__restrict__ coords, int64_t n,
+                                              int64_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int4 c = coords[i];
+    out[i] = fnv4(c.x, c.y, c.z, c.w);
+  }
+}
+
+extern "C" int link_hash(const int32_t *coords, int64_t n, int64_t *out, void *stream) {
+  if (n < 0 || (n > 0 && (!coords || !out))) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  hipLaunchKernelGGL(k_hash, dim3(blocks_for(n, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(coords), n, out);
+  return check_launch("link_hash");
+}
+
+// out is k-major [K,N]: thread -> (k = blockIdx.y, i) so that stores are coalesced along i and the
+// row is re-read from L2 K times (16 B/row, negligible) instead of scattering 8-byte stores.
+__global__ void __launch_bounds__(256) k_kernel_hash(const int4 *__restrict__ coords, int64_t n,
+                                                     const int32_t *__restrict__ offsets,
+                                                     int64_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (i < n) {
+    int4 c = coords[i];
+    int ox = offsets[3 * k + 0], oy = offsets[3 * k + 1], oz = offsets[3 * k + 2];
+    out[(int64_t)k * n + i] = fnv4(c.x + ox, c.y + oy, c.z + oz, c.w);
+  }
+}
+
+extern "C" int link_kernel_hash(const int32_t *coords, int64_t n, const int32_t *offsets, int64_t k,
+                                int64_t *out, void *stream) {
+  if (n < 0 || k < 0 || k > 65535) return LINK_ERR_ARG;
+  if (n == 0 || k == 0) return LINK_OK;
+  if (!coords || !offsets || !out) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_kernel_hash, dim3(blocks_for(n, 256), (unsigned)k), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(coords), n, offsets, out);
+  return check_launch("link_kernel_hash");
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash_query: open addressing, linear probing, power-of-two table of {key, val} pairs.
+//   slot.val: 0 = empty, otherwise (smallest target position claiming this key) + 1
+//   insert: CAS val 0 -> pos+1 claims an empty slot and then publishes the key; a later arrival that
+//   finds the slot claimed must know the key, so keys are written FIRST by a 64-bit CAS on the key
+//   word guarded by a separate `state` word.  To stay simple and race-free the table stores
+//   key (u64), pos (u32, atomicMin for first-wins), state (u32: 0 empty, 1 key valid).
+// Two kernels (insert, lookup) on the same stream; the kernel boundary orders them.
+// ---------------------------------------------------------------------------------------------
+struct QSlot {
+  unsigned long long key;
+  unsigned int state;  // 0 empty, 1 claimed (key being written), 2 key valid
+  unsigned int pos;    // min target position with this key
+};
+
+static inline uint64_t query_cap(int64_t n) {
+  uint64_t cap = 64;
+  while (cap < (uint64_t)(2 * n + 1)) cap <<= 1;
+  return cap;
+}
+
+extern "C" size_t link_hash_query_workspace_bytes(int64_t n_target) {
+  return (size_t)query_cap(n_target < 0 ? 0 : n_target) * sizeof(QSlot);
+}
+
+__global__ void __launch_bounds__(256) k_q_clear(QSlot *__restrict__ tab, uint64_t cap) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) { tab[i].key = 0ULL; tab[i].state = 0u; tab[i].pos = 0xFFFFFFFFu; }
+}
+
+__global__ void __launch_bounds__(256) k_q_insert(const int64_t *__restrict__ target, int64_t n,
+                                                  QSlot *tab, uint64_t mask) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key = (unsigned long long)target[i];
+  uint64_t s = mix64(key) & mask;
+  // Every iteration is non-blocking (no lane ever spins on another lane of its own wave): a lane
+  // that finds the slot mid-publication (state 1) simply retries the same slot next iteration.
+  bool done = false;
+  while (!done) {
+    unsigned int expect = 0u;
+    bool won = __hip_atomic_compare_exchange_strong(&tab[s].state, &expect, 1u, __ATOMIC_ACQUIRE,
+                                                    __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (won) {  // we claimed the slot: publish the key, then mark it valid
+      __hip_atomic_store(&tab[s].key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&tab[s].state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      atomicMin(&tab[s].pos, (unsigned int)i);
+      done = true;
+    } else if (expect == 2u) {
+      unsigned long long k2 = __hip_atomic_load(&tab[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k2 == key) {
+        atomicMin(&tab[s].pos, (unsigned int)i);
+        done = true;
+      } else {
+        s = (s + 1) & mask;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_q_lookup(const int64_t *__restrict__ query, int64_t n1,
+                                                  const int64_t *__restrict__ target_idx,
+                                                  const QSlot *__restrict__ tab, uint64_t mask,
+                                                  int64_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n1) return;
+  unsigned long long key = (unsigned long long)query[i];
+  uint64_t s = mix64(key) & mask;
+  int64_t r = 0;
+  for (;;) {
+    QSlot q = tab[s];
+    if (q.state == 0u) break;
+    if (q.key == key) { r = target_idx[q.pos] + 1; break; }
+    s = (s + 1) & mask;
+  }
+  out[i] = r;
+}
+
+extern "C" int link_hash_query(const int64_t *query, int64_t n1, const int64_t *target,
+                               const int64_t *target_idx, int64_t n, int64_t *out, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  if (n1 < 0 || n < 0 || n >= (1LL << 31)) return LINK_ERR_ARG;
+  if (n1 == 0) return LINK_OK;
+  if (!query || !out || !workspace || (n > 0 && (!target || !target_idx))) return LINK_ERR_ARG;
+  uint64_t cap = query_cap(n);
+  if (workspace_bytes < cap * sizeof(QSlot)) return LINK_ERR_WORKSPACE;
+  QSlot *tab = reinterpret_cast<QSlot *>(workspace);
+  hipLaunchKernelGGL(k_q_clear, dim3(blocks_for((int64_t)cap, 256)), dim3(256), 0, S(stream), tab, cap);
+  if (n > 0)
+    hipLaunchKernelGGL(k_q_insert, dim3(blocks_for(n, 256)), dim3(256), 0, S(stream), target, n, tab,
+                       cap - 1);
+  hipLaunchKernelGGL(k_q_lookup, dim3(blocks_for(n1, 256)), dim3(256), 0, S(stream), query, n1,
+                     target_idx, tab, cap - 1, out);
+  return check_launch("link_hash_query");
+}
+
+// ---------------------------------------------------------------------------------------------
+// count
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count(const int32_t *__restrict__ idx, int64_t n,
+                                               int32_t *out, int64_t s) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int32_t v = idx[i];
+    if (v >= 0 && v < s) atomicAdd(&out[v], 1);
+  }
+}
+
+extern "C" int link_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stream) {
+  if (n < 0 || s < 0) return LINK_ERR_ARG;
+  if (s == 0) return LINK_OK;
+  if (!out || (n > 0 && !idx)) return LINK_ERR_ARG;
+  if (hipMemsetAsync(out, 0, (size_t)s * sizeof(int32_t), S(stream)) != hipSuccess)
+    return check_launch("link_count memset");
+  if (n > 0)
+    hipLaunchKernelGGL(k_count, dim3(blocks_for(n, 256)), dim3(256), 0, S(stream), idx, n, out, s);
+  return check_launch("link_count");
+}
+
+// ---------------------------------------------------------------------------------------------
+// voxelize forward (generic idx): one wave per input row, lanes stride the channels -> coalesced
+// row reads; fp32 atomics into the output row like the reference kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_voxelize_fwd(const float *__restrict__ in,
+                                                      const int32_t *__restrict__ idx,
+                                                      const int32_t *__restrict__ counts, int64_t n,
+                                                      int c, int64_t n1, float *out) {
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int32_t pos = idx[row];
+  if (pos < 0 || pos >= n1) return;
+  int32_t cn = counts[pos];
+  if (cn == 0) return;
+  float fc = (float)cn;
+  const float *src = in + row * (int64_t)c;
+  float *dst = out + (int64_t)pos * c;
+  for (int j = lane; j < c; j += 64) atomicAdd(&dst[j], src[j] / fc);
+}
+
+extern "C" int link_voxelize_forward(const float *in, const int32_t *idx, const int32_t *counts,
+                                     int64_t n, int64_t c, int64_t n1, float *out, void *stream) {
+  if (n < 0 || c < 0 || n1 < 0 || c > (1 << 20)) return LINK_ERR_ARG;
+  if (n1 == 0 || c == 0) return LINK_OK;
+  if (!out || (n > 0 && (!in || !idx || !counts))) return LINK_ERR_ARG;
+  if (hipMemsetAsync(out, 0, (size_t)(n1 * c) * sizeof(float), S(stream)) != hipSuccess)
+    return check_launch("link_voxelize_forward memset");
+  if (n > 0)
+    hipLaunchKernelGGL(k_voxelize_fwd, dim3(blocks_for(n * 64, 256)), dim3(256), 0, S(stream), in,
+                       idx, counts, n, (int)c, n1, out);
+  return check_launch("link_voxelize_forward");
+}
+
+// voxelize backward: pure row gather with a per-row scale.
+__global__ void __launch_bounds__(256) k_voxelize_bwd(const float *__restrict__ top,
+                                                      const int32_t *__restrict__ idx,
+                                                      const int32_t *__restrict__ counts, int64_t n,
+                                                      int c, float *__restrict__ bottom) {
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int32_t pos = idx[row];
+  float *dst = bottom + row * (int64_t)c;
+  int32_t cn = (pos >= 0) ? counts[pos] : 0;
+  if (cn == 0) {
+    for (int j = lane; j < c; j += 64) dst[j] = 0.f;
+    return;
+  }
+  float fc = (float)cn;
+  const float *src = top + (int64_t)pos * c;
+  for (int j = lane; j < c; j += 64) dst[j] = src[j] / fc;
+}
+
+extern "C" int link_voxelize_backward(const float *top, const int32_t *idx, const int32_t *counts,
+                                      int64_t n, int64_t c, float *bottom, void *stream) {
+  if (n < 0 || c < 0 || c > (1 << 20)) return LINK_ERR_ARG;
+  if (n == 0 || c == 0) return LINK_OK;
+  if (!top || !idx || !counts || !bottom) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_voxelize_bwd, dim3(blocks_for(n * 64, 256)), dim3(256), 0, S(stream), top, idx,
+                     counts, n, (int)c, bottom);
+  return check_launch("link_voxelize_backward");
+}
+
+// ---------------------------------------------------------------------------------------------
+// devoxelize forward: one wave per query row; the K indices/weights are loaded once by lanes 0..K-1
+// and broadcast with readlane; accumulate in registers in k order (deterministic), one store.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_devox_fwd(const float *__restrict__ feat,
+                                                   const int32_t *__restrict__ ind,
+                                                   const float *__restrict__ w, int64_t nq, int c,
+                                                   int K, float *__restrict__ out) {
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= nq) return;
+  for (int j0 = 0; j0 < c; j0 += 64) {
+    int j = j0 + lane;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      int kk = k0 + lane;
+      int32_t my_i = (kk < K) ? ind[row * K + kk] : -1;
+      float my_w = (kk < K) ? w[row * K + kk] : 0.f;
+      int lim = (K - k0 < 64) ? (K - k0) : 64;
+      for (int t = 0; t < lim; t++) {
+        int32_t q = __shfl(my_i, t, 64);
+        float wk = __shfl(my_w, t, 64);
+        float cur = 0.f;
+        if (q >= 0 && j < c) cur = feat[(int64_t)q * c + j];
+        acc += wk * cur;
+      }
+    }
+    if (j < c) out[row * (int64_t)c + j] = acc;
+  }
+}
+
+extern "C" int link_devoxelize_forward(const float *feat, const int32_t *ind, const float *w,
+                                       int64_t nq, int64_t c, int64_t k, float *out, void *stream) {
+  if (nq < 0 || c < 0 || k < 0 || c > (1 << 20) || k > (1 << 20)) return LINK_ERR_ARG;
+  if (nq == 0 || c == 0) return LINK_OK;
+  if (!out || (k > 0 && (!feat || !ind || !w))) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_devox_fwd, dim3(blocks_for(nq * 64, 256)), dim3(256), 0, S(stream), feat, ind, w,
+                     nq, (int)c, (int)k, out);
+  return check_launch("link_devoxelize_forward");
+}
+
+__global__ void __launch_bounds__(256) k_devox_bwd(const float *__restrict__ top,
+                                                   const int32_t *__restrict__ ind,
+                                                   const float *__restrict__ w, int64_t nq, int c,
+                                                   int K, float *bottom) {
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (row >= nq) return;
+  for (int k = 0; k < K; k++) {
+    int32_t q = ind[row * K + k];
+    if (q < 0) continue;
+    float wk = w[row * K + k];
+    for (int j = lane; j < c; j += 64) atomicAdd(&bottom[(int64_t)q * c + j], wk * top[row * (int64_t)c + j]);
+  }
+}
+
+extern "C" int link_devoxelize_backward(const float *top, const int32_t *ind, const float *w,
+                                        int64_t nq, int64_t n, int64_t c, int64_t k, float *bottom,
+                                        void *stream) {
+  if (nq < 0 || n < 0 || c < 0 || k < 0 || c > (1 << 20)) return LINK_ERR_ARG;
+  if (n == 0 || c == 0) return LINK_OK;
+  if (!bottom) return LINK_ERR_ARG;
+  if (hipMemsetAsync(bottom, 0, (size_t)(n * c) * sizeof(float), S(stream)) != hipSuccess)
+    return check_launch("link_devoxelize_backward memset");
+  if (nq > 0 && k > 0) {
+    if (!top || !ind || !w) return LINK_ERR_ARG;
+    hipLaunchKernelGGL(k_devox_bwd, dim3(blocks_for(nq * 64, 256)), dim3(256), 0, S(stream), top, ind, w,
+                       nq, (int)c, (int)k, bottom);
+  }
+  return check_launch("link_devoxelize_backward");
+}

@@ -1,0 +1,354 @@
+"""link_amd/elk.py -- the LinK block modules behind the reference's names.
+
+  ELKBlock(inc, outc, groups=1, baseop='cos_x').forward(st, s, r)
+      /root/reference/segmentation/core/models/semantic_kitti/linkunet.py:94-185
+      (variant='encoder' reproduces linkencoder.py:165: cos_x feeds coords / tensor stride)
+  TSELKBlock(inc, outc, baseop='cos').forward(sct, stride) / .forward_(st, stride)
+      /root/reference/detection/det3d/models/utils/ts_elk.py:110-230
+  spconv2ts / ts2spconv                                   ts_elk.py:10-59
+
+Parameter names and shapes match the reference state_dict (alpha [1,C/g], pos_weight.0.weight,
+pre_mix.0.weight, pre_mix.1.{weight,bias}, local_mix.0.kernel [27,C,C], norm_local.*, norm.*), so
+released checkpoints load.  forward() overwrites `st.F` of its INPUT object and returns that object
+(linkunet.py:158,183-185).
+
+Two execution paths, both HIP:
+  * inference (no grad): the fused R_core -- link_premix_ln -> link_modulate_block_sum ->
+    link_gather_demod_ln (include/link_amd.h section C), no host sync when the index is cached or
+    bounds are known;
+  * training (grad enabled): the same maths composed from differentiable pieces -- torch for the
+    dense elementwise/Linear/LayerNorm steps, the HIP autograd Functions of aggregate.py for the
+    aggregation (deterministic forward and backward).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import _lib as L
+from .aggregate import _AuxToVoxel, _BlockMean, link_index_of
+from .index import BlockIndex, foreign_neighbor_map
+from .tensor import SparseTensor
+from .utils import make_ntuple
+
+__all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
+           "elk_core_fused", "elk_core_autograd", "ElkCorePlan"]
+
+_OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------
+# fused R_core (inference)
+# ------------------------------------------------------------------------------------------------
+def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex, w_pre: torch.Tensor,
+                   pre_ln_w: torch.Tensor, pre_ln_b: torch.Tensor, w_pos: torch.Tensor,
+                   alpha: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor, baseop: str,
+                   cg: int, r: int, coord_div: float = 1.0, eps: float = 1e-6,
+                   m_cap: Optional[int] = None) -> torch.Tensor:
+    """R_core of ELKBlock.forward: pre_mix -> theta -> modulate -> block
+    pre-aggregation -> r^3 neighbour sum -> de-modulate -> norm.  3 kernel launches, no host sync.
+    w_pos fp32[cg,3]; channel j uses theta[j % cg]."""
+    n, c = feats.shape
+    dev = feats.device
+    feats = feats.contiguous().float()
+    op = _OPS[baseop]
+    parts = 3 if op == L.OP_COSX else 2
+    if m_cap is None:
+        m_cap = index._m if index._m is not None else n
+    fin = torch.empty((n, c), dtype=torch.float32, device=dev)
+    S = torch.empty((max(m_cap, 1), parts * c + 4), dtype=torch.float32, device=dev)
+    out = torch.empty((n, c), dtype=torch.float32, device=dev)
+    desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
+    lib, st = L.lib(), _st()
+    w_pos = w_pos.contiguous().float()
+    al = alpha.contiguous().float().view(-1) if alpha is not None else None
+    L.check(lib.link_premix_ln(feats.data_ptr(), w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(),
+                               pre_ln_b.data_ptr(), n, c, float(eps), fin.data_ptr(), st), "link_premix_ln")
+    L.check(lib.link_modulate_block_sum(fin.data_ptr(), coords.data_ptr(), w_pos.data_ptr(),
+                                        al.data_ptr() if al is not None else None, index.perm.data_ptr(),
+                                        index.blk_start.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc),
+                                        n, m_cap, S.data_ptr(), st), "link_modulate_block_sum")
+    L.check(lib.link_gather_demod_ln(S.data_ptr(), fin.data_ptr(), coords.data_ptr(), w_pos.data_ptr(),
+                                     al.data_ptr() if al is not None else None, ln_w.data_ptr(),
+                                     ln_b.data_ptr(), index.perm.data_ptr(), index.blk_start.data_ptr(),
+                                     index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
+                                     ctypes.byref(index.grid), index.hdr.data_ptr(), ctypes.byref(desc), n,
+                                     m_cap, out.data_ptr(), st), "link_gather_demod_ln")
+    return out
+
+
+class ElkCorePlan:
+    """Preallocated arena for repeated R_core steps (what bench.py times and what a serving loop would
+    hold per stream): every buffer of link_elk_buffers_t is allocated once for frames of <= n_cap
+    voxels inside fixed coordinate `bounds`, so one step = ONE FFI call = 7 kernel launches (4 index +
+    3 core) with no allocation and no host sync.  `run(..., build_index=False)` reuses the index of
+    the previous call (same coords): the "warm" number of SURVEY.md section 8d."""
+
+    def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
+                 coord_div: float = 1.0, eps: float = 1e-6):
+        self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
+        self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
+        v = self.grid.cells
+        self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
+        parts = 3 if baseop == "cos_x" else 2
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.cell_counts = torch.zeros(max(v, 1), **i32)            # self-cleaning
+        nbytes = L.lib().link_index_scratch_bytes(n_cap, v)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.cell_blk = torch.empty(max(v, 1), **i32)
+        self.vox_blk = torch.empty(n_cap, **i32)
+        self.idx_query = torch.empty(n_cap, dtype=torch.int64, device=device)
+        self.perm = torch.empty(n_cap, **i32)
+        self.blk_start = torch.empty(n_cap + 1, **i32)
+        self.blk_coords = torch.empty((n_cap, 4), **i32)
+        self.counts = torch.empty(n_cap, **i32)
+        self.hdr = torch.zeros(L.HDR_WORDS, **i32)
+        self.fin = torch.empty((n_cap, c), **f32)
+        self.S = torch.empty((n_cap, parts * c + 4), **f32)
+        self.out = torch.empty((n_cap, c), **f32)
+        b = self.buf = L.LinkElkBuffers()
+        b.cell_counts, b.scratch, b.scratch_bytes = self.cell_counts.data_ptr(), self.scratch.data_ptr(), nbytes
+        b.cell_blk, b.vox_blk, b.idx_query = self.cell_blk.data_ptr(), self.vox_blk.data_ptr(), self.idx_query.data_ptr()
+        b.perm, b.blk_start, b.blk_coords = self.perm.data_ptr(), self.blk_start.data_ptr(), self.blk_coords.data_ptr()
+        b.counts, b.hdr = self.counts.data_ptr(), self.hdr.data_ptr()
+        b.fin, b.S, b.out = self.fin.data_ptr(), self.S.data_ptr(), self.out.data_ptr()
+        self._fn = L.lib().link_elk_core_forward
+        self.m_cap = n_cap
+
+    def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
+        """Bind the block's parameters (fp32, contiguous, on the plan's device)."""
+        self._params = tuple(None if t is None else t.detach().contiguous().float().view(-1)
+                             for t in (w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b))
+        b = self.buf
+        (b.w_pre, b.pre_ln_w, b.pre_ln_b, b.w_pos, b.alpha, b.ln_w, b.ln_b) = [
+            None if t is None else t.data_ptr() for t in self._params]
+        return self
+
+    def run(self, feats: torch.Tensor, coords: torch.Tensor, build_index: bool = True) -> torch.Tensor:
+        n = feats.shape[0]
+        assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype == torch.float32
+        assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
+        self.buf.feats, self.buf.coords = feats.data_ptr(), coords.data_ptr()
+        rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
+                      min(self.m_cap, n), 1 if build_index else 0, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            L.check(rc, "link_elk_core_forward")
+        return self.out[:n]
+
+    def blocks(self) -> int:
+        """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds."""
+        h = self.hdr.tolist()
+        if h[L.HDR_STATUS] != 0:
+            raise L.LinkAmdError("ElkCorePlan: voxels outside the plan's bounds")
+        return int(h[L.HDR_M])
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable R_core (training)
+# ------------------------------------------------------------------------------------------------
+def _aggregate(x: torch.Tensor, index: BlockIndex, r: int) -> torch.Tensor:
+    mean = _BlockMean.apply(x, index)
+    return _AuxToVoxel.apply(mean, index.counts, index.neighbor_map(r), index.idx_query, index, r)
+
+
+def elk_core_autograd(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, baseop,
+                      cg, r, coord_div=1.0, eps=1e-6):
+    c = feats.shape[1]
+    fin = TF.layer_norm(TF.linear(feats, w_pre), (c,), pre_ln_w, pre_ln_b, eps)
+    xyz = coords[:, :3].float()
+    if coord_div != 1.0:
+        xyz = xyz / coord_div
+    th = TF.linear(xyz, w_pos)
+    if alpha is not None:
+        th = th * alpha
+    if c != cg:
+        th = th.repeat([1, c // cg])
+    sin, cos = torch.sin(th), torch.cos(th)
+    if baseop == "sin":
+        v = _aggregate(torch.cat([fin * sin, fin * cos], dim=1), index, r)
+        new = v[:, :c] * cos - v[:, c:] * sin
+    elif baseop == "cos":
+        v = _aggregate(torch.cat([fin * cos, fin * sin], dim=1), index, r)
+        new = v[:, :c] * cos + v[:, c:] * sin
+    else:
+        lin = fin * th
+        v = _aggregate(torch.cat([fin * cos, fin * sin, lin], dim=1), index, r)
+        new = v[:, :c] * cos + v[:, c:2 * c] * sin + (v[:, 2 * c:] - lin)
+    return TF.layer_norm(new, (c,), ln_w, ln_b, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# local 3^3 sparse convolution (row N1 of SURVEY.md section 8f, minimal form)
+# ------------------------------------------------------------------------------------------------
+class Conv3d(nn.Module):
+    """Stride-1 submanifold sparse convolution with the reference's parameter layout
+    (`kernel` [K, Cin, Cout], torchsparse/nn/modules/conv.py:15-72; init U(+-1/sqrt(Cin*K))).
+    Neighbour map from the dense cell table (HIP), contraction as K gather + rocBLAS GEMMs.
+    Only what ELKBlock.local_mix needs: odd kernel_size, stride 1, no bias."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
+                 dilation: int = 1, bias: bool = False, transposed: bool = False) -> None:
+        super().__init__()
+        if make_ntuple(stride, 3) != (1, 1, 1) or transposed or bias:
+            raise NotImplementedError("link_amd.Conv3d implements the stride-1, bias-free form used by "
+                                      "ELKBlock.local_mix")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = make_ntuple(kernel_size, 3)
+        if len(set(self.kernel_size)) != 1 or self.kernel_size[0] % 2 != 1:
+            raise NotImplementedError("cubic odd kernel sizes only")
+        self.stride, self.dilation, self.transposed = (1, 1, 1), dilation, False
+        self.kernel_volume = self.kernel_size[0] ** 3
+        if self.kernel_volume > 1:
+            self.kernel = nn.Parameter(torch.zeros(self.kernel_volume, in_channels, out_channels))
+        else:
+            self.kernel = nn.Parameter(torch.zeros(in_channels, out_channels))
+        self.register_parameter("bias", None)
+        std = 1.0 / math.sqrt(in_channels * self.kernel_volume)
+        self.kernel.data.uniform_(-std, std)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        feats = x.F
+        if self.kernel_volume == 1:
+            out = feats.matmul(self.kernel)
+        else:
+            key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
+            nbr = x.kmaps.get(key)
+            if nbr is None:
+                ts = x.s[0]
+                rows = x.C if ts == 1 else torch.cat(
+                    [torch.div(x.C[:, :3], ts, rounding_mode="floor").int(), x.C[:, 3:]], dim=1)
+                nbr = foreign_neighbor_map(rows, self.kernel_size[0]).long()
+                nbr = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr)   # -> zero pad row
+                x.kmaps[key] = nbr
+            padded = torch.cat([feats, feats.new_zeros(1, feats.shape[1])], dim=0)
+            out = feats.new_zeros(feats.shape[0], self.out_channels)
+            for k in range(self.kernel_volume):
+                out = out + padded[nbr[:, k]].matmul(self.kernel[k])
+        y = SparseTensor(out, x.C, x.s)
+        y.cmaps, y.kmaps = x.cmaps, x.kmaps
+        return y
+
+
+# ------------------------------------------------------------------------------------------------
+# modules
+# ------------------------------------------------------------------------------------------------
+class _ELKBase(nn.Module):
+    def _core(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
+        index = link_index_of(st, s_eff)
+        args = (st.F, st.C, index, self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias,
+                w_pos, alpha, self.norm.weight, self.norm.bias, self.baseop, cg, r, coord_div, 1e-6)
+        needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(
+            p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return elk_core_autograd(*args)
+        return elk_core_fused(*args)
+
+
+class ELKBlock(_ELKBase):
+    def __init__(self, inc, outc, groups=1, baseop="cos_x", variant="unet"):
+        super().__init__()
+        self.inc, self.outc, self.groups, self.baseop, self.variant = inc, outc, groups, baseop, variant
+        assert inc % groups == 0
+        assert baseop in ("cos", "sin", "cos_x")
+        assert variant in ("unet", "encoder")
+        if baseop == "cos_x":
+            self.alpha = nn.Parameter(torch.ones(1, inc // groups).float(), requires_grad=True)
+        self.pos_weight = nn.Sequential(nn.Linear(3, inc // groups, bias=False))
+        self.pre_mix = nn.Sequential(nn.Linear(inc, inc, bias=False), nn.LayerNorm(inc, eps=1e-6))
+        self.local_mix = nn.Sequential(Conv3d(inc, inc, kernel_size=3, dilation=1, stride=1))
+        self.norm_local = nn.LayerNorm(inc, eps=1e-6)
+        self.norm = nn.LayerNorm(inc, eps=1e-6)
+        self.activate = nn.ReLU(True)
+
+    def forward(self, st: SparseTensor, s, r):
+        """st: SparseTensor; s: block edge (in st's coordinate units); r: neighbourhood edge in blocks."""
+        if self.baseop == "cos_x" and self.groups != 1:
+            # linkunet.py:165 does not tile theta for cos_x: only groups == 1 is shape-consistent
+            raise ValueError("baseop='cos_x' requires groups == 1 (as in the reference configs)")
+        local = self.local_mix(st)
+        alpha = self.alpha if self.baseop == "cos_x" else None
+        coord_div = float(st.s[0]) if (self.variant == "encoder" and self.baseop == "cos_x") else 1.0
+        cg = self.inc // self.groups
+        new = self._core(st, int(s), int(r), self.pos_weight[0].weight, alpha, cg, coord_div)
+        st.F = self.activate(new + self.norm_local(local.F))
+        return st
+
+
+class SparseConvTensor:
+    """Minimal stand-in for spconv.SparseConvTensor (the wheel is an external dependency of the
+    reference, detection/INSTALL.md:56): features [N,C], indices int32 [N,4] = (batch, z, y, x)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
+                 indice_dict=None, benchmark=False):
+        self.features, self.indices = features, indices
+        self.spatial_shape, self.batch_size = spatial_shape, batch_size
+        self.grid, self.voxel_num = grid, voxel_num
+        self.indice_dict = {} if indice_dict is None else indice_dict
+        self.benchmark, self.benchmark_record = benchmark, {}
+
+
+def spconv2ts(sct):
+    """ts_elk.py:10-33: (batch,z,y,x) indices -> (x,y,z,batch) coords, stride 1; keep spconv metadata."""
+    coords = sct.indices[:, [3, 2, 1, 0]].contiguous()
+    st = SparseTensor(sct.features, coords, 1)
+    save = {k: getattr(sct, k, None) for k in ("batch_size", "benchmark", "benchmark_record", "grid",
+                                               "indice_dict", "spatial_shape", "voxel_num")}
+    save["_cls"] = type(sct)
+    return st, save
+
+
+def ts2spconv(st: SparseTensor, sct_save: dict):
+    """ts_elk.py:36-59."""
+    indices = st.coords[:, [3, 2, 1, 0]].contiguous()
+    cls = sct_save.get("_cls", SparseConvTensor)
+    sct = cls(st.feats, indices, spatial_shape=sct_save["spatial_shape"], batch_size=sct_save["batch_size"],
+              grid=sct_save["grid"], voxel_num=sct_save["voxel_num"], indice_dict=sct_save["indice_dict"],
+              benchmark=sct_save["benchmark"])
+    sct.benchmark_record = sct_save["benchmark_record"]
+    return sct
+
+
+class TSELKBlock(_ELKBase):
+    """ts_elk.py:110-230 ('cos' and 'sin' base ops; the other branches of the reference are dead or
+    reference an undefined self.alpha)."""
+
+    def __init__(self, inc, outc, baseop="cos"):
+        super().__init__()
+        assert baseop in ("cos", "sin")
+        self.inc, self.outc, self.baseop = inc, outc, baseop
+        self.pre_mix = nn.Sequential(nn.Linear(inc, inc, bias=False), nn.LayerNorm(inc, eps=1e-6))
+        self.local_mix = nn.Sequential(Conv3d(inc, inc, kernel_size=3, dilation=1, stride=1))
+        self.pos_weight = nn.Sequential(nn.Linear(3, inc, bias=False))
+        self.norm = nn.LayerNorm(inc, eps=1e-6)
+        self.norm_local = nn.LayerNorm(inc, eps=1e-6)
+        self.activate = nn.ReLU(True)
+
+    def forward(self, sct, stride):
+        st, save = spconv2ts(sct)
+        bounds = None
+        shape = save.get("spatial_shape")
+        if shape is not None and save.get("batch_size") is not None:   # bounds for free: no bbox sync
+            z, y, x = [int(v) for v in shape]
+            bounds = ((0, 0, 0, 0), (x - 1, y - 1, z - 1, int(save["batch_size"]) - 1))
+            st.cmaps.setdefault(("link_bounds", st.C.data_ptr(), st.C.shape[0]), bounds)
+        return ts2spconv(self.forward_(st, stride), save)
+
+    def forward_(self, st: SparseTensor, stride):
+        local = self.local_mix(st)
+        if self.baseop == "cos":      # ts_elk.py:168: first C/2 columns, tiled twice
+            w_pos, cg = self.pos_weight[0].weight[: self.inc // 2], self.inc // 2
+        else:                          # 'sin' (ts_elk.py:155-156): all C columns, untiled
+            w_pos, cg = self.pos_weight[0].weight, self.inc
+        new = self._core(st, int(stride), 3, w_pos, None, cg, 1.0)
+        st.F = self.activate(new + self.norm_local(local.F))
+        return st

@@ -1,0 +1,89 @@
+"""link_amd/functional.py -- the `torchsparse.nn.functional` names on the LinK path.
+
+sphash / sphashquery / spcount / spvoxelize / spdevoxelize with the reference's signatures and
+dtype conventions (torchsparse/nn/functional/{hash,query,count,voxelize,devoxelize}.py), dispatching
+to the HIP library only.  The reference wraps voxelize/devoxelize in `custom_fwd(cast_inputs=half)`;
+this path computes in fp32 (half/bf16 inputs are up-cast, results returned in fp32) -- fp32
+accumulation is what the parity gate is defined on.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import backend
+
+__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize"]
+
+
+def sphash(coords: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """hash.py:10-37.  int32[N,4] -> int64[N]; with offsets int32[K,3] -> int64[K,N]."""
+    assert coords.dtype == torch.int, coords.dtype
+    assert coords.ndim == 2 and coords.shape[1] == 4, coords.shape
+    if offsets is None:
+        return backend.hash_cuda(coords)
+    assert offsets.dtype == torch.int, offsets.dtype
+    assert offsets.ndim == 2 and offsets.shape[1] == 3, offsets.shape
+    return backend.kernel_hash_cuda(coords, offsets.to(coords.device))
+
+
+def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
+    """query.py:8-33.  Position of each query hash in `references` (first duplicate wins) or -1;
+    the query tensor's shape is preserved."""
+    shape = queries.shape
+    indices = torch.arange(references.numel(), device=queries.device, dtype=torch.long)
+    out = backend.hash_query_cuda(queries.contiguous().view(-1), references.contiguous().view(-1), indices)
+    return (out - 1).view(shape)
+
+
+def spcount(coords: torch.Tensor, num) -> torch.Tensor:
+    """count.py:8-16.  int32[N] -> int32[num]."""
+    return backend.count_cuda(coords.contiguous(), int(num))
+
+
+class VoxelizeFunction(Function):
+    """voxelize.py:10-52."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, counts):
+        feats = feats.contiguous().float()
+        coords = coords.contiguous().int()
+        counts = counts.contiguous().int()
+        out = backend.voxelize_forward_cuda(feats, coords, counts)
+        ctx.for_backwards = (coords, counts, feats.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, counts, n = ctx.for_backwards
+        g = backend.voxelize_backward_cuda(grad_output.contiguous().float(), coords, counts, n)
+        return g, None, None
+
+
+class DevoxelizeFunction(Function):
+    """devoxelize.py:51-93 (with LinK's `r`)."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, weights, r):
+        feats = feats.contiguous().float()
+        coords = coords.contiguous().int()
+        weights = weights.contiguous().float()
+        out = backend.devoxelize_forward_cuda(feats, coords, weights, r)
+        ctx.for_backwards = (coords, weights, feats.shape[0], r)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, weights, n, r = ctx.for_backwards
+        g = backend.devoxelize_backward_cuda(grad_output.contiguous().float(), coords, weights, n, r)
+        return g, None, None, None
+
+
+def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    return VoxelizeFunction.apply(feats, coords, counts)
+
+
+def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor, r: int = 2) -> torch.Tensor:
+    return DevoxelizeFunction.apply(feats, coords, weights, r)

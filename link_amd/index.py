@@ -1,0 +1,176 @@
+"""link_amd/index.py -- BlockIndex: the per-frame block structure of LinK's aggregation.
+
+One BlockIndex replaces everything `voxel_to_aux` / `aux_to_voxel` recompute on every call in the
+reference (segmentation/core/models/utils.py:45-51,65-73): block coordinates, the voxel->block map
+(`idx_query`), per-block counts, and the r^3 neighbour lookup.  It is built by 4 kernel launches
+without host synchronisation (link_index_build, include/link_amd.h section B); the only sync is the
+optional read-back of M when a caller needs exactly-sized tensors (`.M`).
+
+HBM layout (all int32 unless noted, N = voxels, V = cells of the dense block grid, M <= N blocks):
+  cell_blk[V]  block id + 1 per cell (0 = empty)      vox_blk[N]      block of each voxel
+  idx_query[N] int64 copy (reference dtype)           perm[N]         voxel ids grouped by block
+  blk_start[N+1] segment starts                       blk_coords[N,4] rows [0,M) valid
+  counts[N]    rows [0,M) valid                       hdr[8]          M, status, nvalid
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+MAX_CELLS = 1 << 28   # dense-grid path limit (1 GiB of int32 cell table); beyond -> generic hash path
+
+
+class _Workspace:
+    """Per (device, stream) scratch: zero-initialised cell counters (self-cleaning) + index scratch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.cell_counts = None
+        self.scratch = None
+
+    def ensure(self, n: int, v: int):
+        if self.cell_counts is None or self.cell_counts.numel() < v:
+            self.cell_counts = torch.zeros(max(v, 1 << 16), dtype=torch.int32, device=self.device)
+        need = L.lib().link_index_scratch_bytes(n, v)
+        if self.scratch is None or self.scratch.numel() < need:
+            self.scratch = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        return self.cell_counts, self.scratch
+
+
+_workspaces: Dict[Tuple[int, int], _Workspace] = {}
+
+
+def _workspace(device) -> _Workspace:
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = _Workspace(device)
+    return ws
+
+
+def coords_bounds(coords: torch.Tensor) -> Tuple[Tuple[int, ...], Tuple[int, ...]]:
+    """Inclusive (lo, hi) of int32 coords[N,4] via the HIP bbox kernel (one 32-byte D2H sync)."""
+    imax, imin = 2 ** 31 - 1, -2 ** 31
+    bbox = torch.tensor([imax] * 4 + [imin] * 4, dtype=torch.int32, device=coords.device)
+    L.check(L.lib().link_coords_bbox(coords.data_ptr(), coords.shape[0], bbox.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "link_coords_bbox")
+    b = bbox.tolist()
+    return tuple(b[:4]), tuple(b[4:])
+
+
+class GridTooLarge(L.LinkAmdError):
+    pass
+
+
+class BlockIndex:
+    """Block structure of `coords` for block edge `s` (built on the GPU, see module docstring)."""
+
+    def __init__(self, coords: torch.Tensor, s: int, bounds: Optional[Tuple[Sequence[int], Sequence[int]]] = None,
+                 want_idx64: bool = True):
+        if coords.device.type != "cuda":
+            raise L.LinkAmdError("BlockIndex needs GPU coords (HIP path; no CPU fallback)")
+        if coords.dtype != torch.int32 or coords.ndim != 2 or coords.shape[1] != 4:
+            raise ValueError(f"coords must be int32[N,4], got {coords.dtype} {tuple(coords.shape)}")
+        if not isinstance(s, int) or s <= 0:
+            raise ValueError(f"block edge s must be a positive int, got {s!r}")
+        self.coords = coords.contiguous()
+        self.s = s
+        self.n = n = coords.shape[0]
+        dev = coords.device
+        if bounds is None:
+            if n == 0:
+                bounds = ((0, 0, 0, 0), (0, 0, 0, 0))
+            else:
+                bounds = coords_bounds(self.coords)
+        self.bounds = (tuple(int(x) for x in bounds[0]), tuple(int(x) for x in bounds[1]))
+        try:
+            self.grid = L.grid_from_bounds(self.bounds[0], self.bounds[1], s)
+        except L.LinkAmdError as e:
+            raise GridTooLarge(str(e))
+        self.v = v = self.grid.cells
+        if v > MAX_CELLS:
+            raise GridTooLarge(f"dense block grid would need {v} cells (> {MAX_CELLS})")
+        ws = _workspace(dev)
+        cell_counts, scratch = ws.ensure(n, v)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cell_blk = torch.empty(v, **i32)
+        self.vox_blk = torch.empty(n, **i32)
+        self.idx_query = torch.empty(n, dtype=torch.int64, device=dev) if want_idx64 else None
+        self.perm = torch.empty(n, **i32)
+        self.blk_start = torch.empty(n + 1, **i32)
+        self.blk_coords = torch.empty((max(n, 1), 4), **i32)
+        self.counts_buf = torch.empty(max(n, 1), **i32)
+        self.hdr = torch.empty(L.HDR_WORDS, **i32)
+        self._m: Optional[int] = None
+        self._nbr: Dict[Tuple[int, bool], torch.Tensor] = {}
+        L.check(L.lib().link_index_build(
+            self.coords.data_ptr(), n, ctypes.byref(self.grid), cell_counts.data_ptr(), scratch.data_ptr(),
+            scratch.numel(), self.cell_blk.data_ptr(), self.vox_blk.data_ptr(),
+            self.idx_query.data_ptr() if want_idx64 else None, self.perm.data_ptr(),
+            self.blk_start.data_ptr(), self.blk_coords.data_ptr(), self.counts_buf.data_ptr(),
+            self.hdr.data_ptr(), torch.cuda.current_stream().cuda_stream), "link_index_build")
+
+    # -- lazily synchronised facts ------------------------------------------------------------------
+    @property
+    def M(self) -> int:
+        """Number of blocks (one 32-byte D2H sync on first use; also validates the status word)."""
+        if self._m is None:
+            h = self.hdr.tolist()
+            if h[L.HDR_STATUS] != 0:
+                raise L.LinkAmdError("BlockIndex: voxels outside the supplied bounds "
+                                     f"{self.bounds} (status={h[L.HDR_STATUS]})")
+            self._m = int(h[L.HDR_M])
+        return self._m
+
+    @property
+    def counts(self) -> torch.Tensor:
+        return self.counts_buf[: self.M]
+
+    @property
+    def block_coords(self) -> torch.Tensor:
+        return self.blk_coords[: self.M]
+
+    def neighbor_map(self, r: int, transpose: bool = False) -> torch.Tensor:
+        """int32[M, r^3] neighbour block ids in get_kernel_offsets(r) order, -1 = absent."""
+        if r % 2 == 1:
+            transpose = False   # symmetric offset set: the adjoint relation is the relation itself
+        key = (int(r), bool(transpose))
+        if key not in self._nbr:
+            m = self.M
+            nbr = torch.empty((m, r ** 3), dtype=torch.int32, device=self.coords.device)
+            L.check(L.lib().link_neighbor_map(self.blk_coords.data_ptr(), self.cell_blk.data_ptr(),
+                                              ctypes.byref(self.grid), self.hdr.data_ptr(), m, int(r),
+                                              1 if transpose else 0, nbr.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "link_neighbor_map")
+            self._nbr[key] = nbr
+        return self._nbr[key]
+
+
+def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False) -> torch.Tensor:
+    """Neighbour map for arbitrary block rows int32[M,4] (not produced by a BlockIndex): dense cell
+    table over the rows' bounding box (first duplicate row wins), then the same lookup kernel."""
+    rows = rows.contiguous()
+    m = rows.shape[0]
+    dev = rows.device
+    nbr = torch.empty((m, r ** 3), dtype=torch.int32, device=dev)
+    if m == 0:
+        return nbr
+    lo, hi = coords_bounds(rows)
+    try:
+        grid = L.grid_from_bounds(lo, hi, 1)
+    except L.LinkAmdError as e:
+        raise GridTooLarge(str(e))
+    if grid.cells > MAX_CELLS:
+        raise GridTooLarge(f"dense block grid would need {grid.cells} cells")
+    table = torch.zeros(grid.cells, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().link_cell_table_build(rows.data_ptr(), m, ctypes.byref(grid), table.data_ptr(), None, st),
+            "link_cell_table_build")
+    L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
+                                      1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
+    return nbr

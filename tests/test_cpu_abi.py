@@ -1,0 +1,138 @@
+"""CPU-only checks (run with -m "not gpu"): the C-ABI library loads and exports every symbol
+include/link_amd.h declares, host-side logic, the data model, and loud failure on CPU tensors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, golden_files, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from link_amd import _lib as L
+    from link_amd import build as hip_build
+    hip_build.build()
+    hdr = open(os.path.join(ROOT, "include", "link_amd.h")).read()
+    declared = set(re.findall(r"\b(link_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"link_grid_t", "link_elk_desc_t", "link_elk_buffers_t"}
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    handle = ctypes.CDLL(L.SO_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert L.lib().link_abi_version() == L.ABI_VERSION
+    # struct layouts agree with the header (sizes in bytes)
+    assert ctypes.sizeof(L.LinkGrid) == 36 and ctypes.sizeof(L.LinkElkDesc) == 24
+    assert ctypes.sizeof(L.LinkElkBuffers) == 23 * 8
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    from link_amd import _lib as L
+    lib = L.lib()
+    assert lib.link_hash(None, -1, None, None) == L.LINK_ERR_ARG
+    assert lib.link_hash(None, 5, None, None) == L.LINK_ERR_ARG
+    assert lib.link_hash(None, 0, None, None) == L.LINK_OK          # empty input is a no-op
+    assert lib.link_kernel_hash(None, 0, None, 27, None, None) == L.LINK_OK
+    assert lib.link_premix_ln(None, None, None, None, 10, 0, 1e-6, None, None) == L.LINK_ERR_ARG
+    assert lib.link_premix_ln(None, None, None, None, 10, 512, 1e-6, None, None) == L.LINK_ERR_ARG
+    assert lib.link_hash_query_workspace_bytes(1000) >= 2 * 1000 * 16
+    assert lib.link_index_scratch_bytes(1000, 50000) >= 3 * 4000
+
+
+def test_grid_from_bounds_host_logic():
+    from link_amd import _lib as L
+    g = L.grid_from_bounds((0, 0, 0, 0), (255, 255, 255, 0), 7)
+    assert g.key() == (7, (0, 0, 0, 0), (37, 37, 37, 1)) and g.cells == 50653
+    g = L.grid_from_bounds((-15, -1, 0, 1), (14, 20, 6, 3), 7)       # floor division for negatives
+    assert tuple(g.lo) == (-3, -1, 0, 1) and tuple(g.dim) == (6, 4, 1, 3)
+    with pytest.raises(L.LinkAmdError):
+        L.grid_from_bounds((0, 0, 0, 0), (2 ** 31 - 1, 2 ** 31 - 1, 0, 0), 1)   # >= 2^30 cells
+    with pytest.raises(L.LinkAmdError):
+        L.grid_from_bounds((5, 0, 0, 0), (4, 0, 0, 0), 1)
+
+
+def test_kernel_offsets_match_reference():
+    import link_amd as la
+    k = load_golden("g_koff.npz")
+    for r in (2, 3, 4, 5):
+        out = la.get_kernel_offsets(r)
+        assert out.dtype == torch.int32 and np.array_equal(out.numpy(), k[f"r{r}"])
+    assert la.get_kernel_offsets(3, stride=2)[0].tolist() == [-2, -2, -2]
+    assert la.make_ntuple(3, 3) == (3, 3, 3) and la.make_ntuple([1, 2, 3], 3) == (1, 2, 3)
+    assert la.make_ntuple(torch.tensor([4, 5, 6]), 3) == (4, 5, 6)
+
+
+def test_sparse_tensor_surface():
+    import link_amd as la
+    f, c = torch.randn(5, 3), torch.zeros(5, 4, dtype=torch.int32)
+    st = la.SparseTensor(f, c, 2)
+    assert st.F is f and st.C is c and st.s == (2, 2, 2) and st.stride == (2, 2, 2)
+    st.F = f * 2
+    assert torch.equal(st.feats, f * 2)
+    st.s = 4
+    assert st.stride == (4, 4, 4)
+    other = la.SparseTensor(f, c, 4)
+    tot = st + other
+    assert tot.cmaps is st.cmaps and tot.kmaps is st.kmaps and torch.equal(tot.F, f * 3)
+    cat = la.cat([st, other])
+    assert cat.F.shape == (5, 6) and cat.kmaps is st.kmaps
+    pt = la.PointTensor(f, c.float())
+    assert set(pt.additional_features) == {"idx_query", "counts"}
+
+
+@pytest.mark.parametrize("name", golden_files("g_block_*_s3_r2.npz"))
+def test_state_dict_compatible_with_reference(name):
+    """Reference checkpoints must load: same keys, same shapes (checkpoint row)."""
+    import link_amd as la
+    g = load_golden(name)
+    m = g["meta"]
+    blk = la.ELKBlock(m["C"], m["C"], groups=m["groups"], baseop=m["baseop"], variant=m["variant"])
+    ref = {k[4:]: tuple(v.shape) for k, v in g.items() if k.startswith("sd__")}
+    mine = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    assert mine == ref
+    det = la.TSELKBlock(16, 16).state_dict()
+    assert tuple(det["pos_weight.0.weight"].shape) == (16, 3) and "local_mix.0.kernel" in det
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly on CPU tensors, never fall back."""
+    import link_amd as la
+    from link_amd._lib import LinkAmdError
+    c = torch.zeros((4, 4), dtype=torch.int32)
+    with pytest.raises(LinkAmdError):
+        la.sphash(c)
+    with pytest.raises(LinkAmdError):
+        la.BlockIndex(c, 3)
+    with pytest.raises(LinkAmdError):
+        la.spvoxelize(torch.zeros(4, 2), torch.zeros(4, dtype=torch.int32), torch.ones(1, dtype=torch.int32))
+    with pytest.raises(Exception):
+        la.voxel_to_aux(la.SparseTensor(torch.zeros(4, 2), c, 1), 3)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "link_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "link_oracle" not in src, fn
+
+
+def test_install_as_torchsparse():
+    import sys
+    import link_amd as la
+    la.install_as_torchsparse()
+    import torchsparse
+    import torchsparse.nn.functional as F
+    from torchsparse.nn.utils import get_kernel_offsets
+    from torchsparse.utils import make_ntuple
+    assert torchsparse.SparseTensor is la.SparseTensor and F.sphash is la.sphash
+    assert get_kernel_offsets is la.get_kernel_offsets and make_ntuple is la.make_ntuple
+    import torchsparse.backend as B
+    for name in ("hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda", "voxelize_forward_cuda",
+                 "voxelize_backward_cuda", "devoxelize_forward_cuda", "devoxelize_backward_cuda"):
+        assert callable(getattr(B, name))
+    for k in [k for k in sys.modules if k == "torchsparse" or k.startswith("torchsparse.")]:
+        del sys.modules[k]

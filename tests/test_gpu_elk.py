@@ -1,0 +1,130 @@
+"""GPU parity of the LinK block (include/link_amd.h section C + link_amd/elk.py) vs the fixtures
+generated from the reference's ELKBlock and vs the oracle.  fp32 tolerance: 1e-4 rel (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_files, load_golden, rel_err, s_uniform
+from oracle import link_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def make_block(g, variant=None):
+    import link_amd as la
+    m = g["meta"]
+    blk = la.ELKBlock(m["C"], m["C"], groups=m["groups"], baseop=m["baseop"],
+                      variant=variant or m["variant"]).cuda().eval()
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+    missing, unexpected = blk.load_state_dict(sd, strict=True)      # reference checkpoint loads as is
+    return blk
+
+
+@pytest.mark.parametrize("name", golden_files("g_block_*.npz"))
+def test_block_forward_vs_reference(name):
+    import link_amd as la
+    g = load_golden(name)
+    m = g["meta"]
+    blk = make_block(g)
+    st = la.SparseTensor(torch.from_numpy(g["feats"]).cuda(), torch.from_numpy(g["coords"]).cuda(),
+                         m["tensor_stride"])
+    cap = {}
+    h = blk.local_mix.register_forward_hook(lambda mod, i, o: cap.__setitem__("local", o.F))
+    with torch.no_grad():
+        core = blk._core(st, m["s"], m["r"], blk.pos_weight[0].weight,
+                         blk.alpha if m["baseop"] == "cos_x" else None, m["C"] // m["groups"],
+                         float(m["tensor_stride"]) if (m["variant"] == "encoder" and m["baseop"] == "cos_x") else 1.0)
+        assert rel_err(core.cpu().numpy(), g["core"]) < TOL
+        out = blk(st, m["s"], m["r"])
+    h.remove()
+    assert out is st                                             # in-place contract
+    assert rel_err(cap["local"].cpu().numpy(), g["local"]) < TOL
+    assert rel_err(st.F.cpu().numpy(), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("name", golden_files("g_block_*.npz"))
+def test_block_grads_vs_reference(name):
+    import link_amd as la
+    g = load_golden(name)
+    m = g["meta"]
+    blk = make_block(g).train()
+    feats = torch.from_numpy(g["feats"]).cuda().requires_grad_(True)
+    st = la.SparseTensor(feats, torch.from_numpy(g["coords"]).cuda(), m["tensor_stride"])
+    core = blk._core(st, m["s"], m["r"], blk.pos_weight[0].weight,
+                     blk.alpha if m["baseop"] == "cos_x" else None, m["C"] // m["groups"],
+                     float(m["tensor_stride"]) if (m["variant"] == "encoder" and m["baseop"] == "cos_x") else 1.0)
+    assert rel_err(core.detach().cpu().numpy(), g["core"]) < TOL
+    core.backward(torch.from_numpy(g["grad_out"]).cuda())
+    assert rel_err(feats.grad.cpu().numpy(), g["grad_feats"]) < 5e-4
+    params = dict(blk.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            assert rel_err(params[k[6:]].grad.cpu().numpy(), v) < 5e-4, k
+
+
+@pytest.mark.parametrize("C,groups,baseop,s,r,n", [(64, 2, "cos", 7, 3, 20000), (16, 2, "cos", 7, 3, 10000),
+                                                    (32, 1, "cos_x", 3, 2, 8000), (128, 2, "sin", 5, 3, 6000),
+                                                    (48, 1, "cos_x", 4, 2, 5000), (20, 2, "cos", 3, 2, 3000)])
+def test_core_fused_vs_oracle_wide(C, groups, baseop, s, r, n):
+    """Widths of the BASELINE configs (16..128) incl. the non-MFMA width 20, on S-uniform inputs."""
+    import link_amd as la
+    torch.manual_seed(2)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    with torch.no_grad():
+        for nme, p in blk.named_parameters():
+            if "norm" in nme or "pre_mix.1" in nme or nme == "alpha":
+                p.add_(0.2 * torch.randn_like(p))
+    coords = s_uniform(n, grid=96, seed=C)
+    gen = torch.Generator().manual_seed(1)
+    feats = torch.randn(n, C, generator=gen)
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, agg=O.aggregate_c)
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), 1)
+    with torch.no_grad():
+        core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None,
+                         C // groups, 1.0)
+    assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_tselk_block_vs_oracle():
+    """Detection twin: Linear(3,C) with the first C/2 columns tiled twice, r=3, spconv-layout indices."""
+    import link_amd as la
+    torch.manual_seed(3)
+    C, n, stride = 32, 6000, 7
+    blk = la.TSELKBlock(C, C, baseop="cos").cuda().eval()
+    coords = s_uniform(n, grid=80, seed=9)
+    gen = torch.Generator().manual_seed(4)
+    feats = torch.randn(n, C, generator=gen)
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref_core = O.elk_core_torch(feats, coords, params, stride, 3, "cos", 1, variant="det", agg=O.aggregate_c)
+    indices = coords[:, [3, 2, 1, 0]].contiguous().cuda()          # (batch, z, y, x)
+    sct = la.SparseConvTensor(feats.cuda(), indices, spatial_shape=[80, 80, 80], batch_size=1)
+    cap = {}
+    h = blk.local_mix.register_forward_hook(lambda mod, i, o: cap.__setitem__("local", o.F))
+    with torch.no_grad():
+        out = blk(sct, stride)
+    h.remove()
+    assert isinstance(out, la.SparseConvTensor) and torch.equal(out.indices, indices)
+    local = torch.nn.functional.layer_norm(cap["local"].cpu(), (C,), params["norm_local.weight"],
+                                           params["norm_local.bias"], 1e-6)
+    ref = torch.relu(ref_core + local)
+    assert rel_err(out.features.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_cfg2_full_size_core():
+    """BASELINE cfg2: N=100k, C=64, cos g=2, r=3, s=7 through the fused core vs the oracle (a few s)."""
+    import link_amd as la
+    torch.manual_seed(2)
+    blk = la.ELKBlock(64, 64, groups=2, baseop="cos").cuda().eval()
+    coords = s_uniform(100_000)
+    gen = torch.Generator().manual_seed(1)
+    feats = torch.randn(100_000, 64, generator=gen)
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords, params, 7, 3, "cos", 2, agg=O.aggregate_c)
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), 1)
+    with torch.no_grad():
+        core = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
+        core2 = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
+    assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
+    assert torch.equal(core, core2)                     # deterministic
