@@ -59,8 +59,8 @@ int link_kernel_hash(const int32_t *coords, int64_t n, const int32_t *offsets, i
  * out[i] = tgt_idx[j]+1 for the FIRST j with tgt[j]==q[i], else 0 (the Python wrapper subtracts 1,
  * nn/functional/query.py:32).  The reference builds a 3-function cuckoo table with host-side
  * rehash retries and two device syncs per call; here: one open-addressing table in `workspace`
- * (linear probing, 64-bit CAS insert of the key, atomicMin on the index for first-wins), no sync,
- * no reserved key.  Workspace need not be initialised.  `link_hash_query_workspace_bytes(n)`. */
+ * (linear probing, wait-free 64-bit CAS insert of the key, atomicMin on the index for first-wins),
+ * no sync, no reserved key.  Workspace need not be initialised.  `link_hash_query_workspace_bytes(n)`. */
 size_t link_hash_query_workspace_bytes(int64_t n_target);
 int link_hash_query(const int64_t *query, int64_t n1, const int64_t *target,
                     const int64_t *target_idx, int64_t n, int64_t *out, void *workspace,
@@ -149,11 +149,13 @@ int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /
 /* Neighbour map nbr i32[M,K] (K = r^3, offsets in get_kernel_offsets(r) order, nn/utils/kernel.py:
  * 11-32: odd r x fastest, even r z fastest): replaces sphash(C, offsets) + sphash + sphashquery +
  * transpose of aux_to_voxel (utils.py:65-73).  -1 = absent.  `m` may be an upper bound (rows past
- * hdr[M] are not written); transpose != 0 uses negated offsets (the adjoint relation, needed by the
- * backward pass when r is even).  Bit-exact. */
+ * hdr[M] are not written); offsets are multiplied by `step` (1 for LinK blocks; the tensor stride when
+ * the rows are strided voxel coordinates, as sparse-conv kernel maps use them, nn/functional/conv.py:
+ * 105-107); transpose != 0 uses negated offsets (the adjoint relation, needed by the backward pass
+ * when r is even).  `hdr` may be NULL (then all m rows are valid).  Bit-exact. */
 int link_neighbor_map(const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid,
-                      const int32_t *hdr, int64_t m, int32_t r, int32_t transpose, int32_t *nbr,
-                      void *stream);
+                      const int32_t *hdr, int64_t m, int32_t r, int32_t step, int32_t transpose,
+                      int32_t *nbr, void *stream);
 
 /* Same for arbitrary (foreign) block rows: first scatter row ids into a cell table that the caller
  * zero-initialised (first row wins for duplicates), then look up.  Rows outside the grid -> status. */

@@ -73,7 +73,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "link_neighbor_map": (c_int, [c_void_p, c_void_p, POINTER(LinkGrid), c_void_p, c_int64, c_int32,
-                                  c_int32, c_void_p, c_void_p]),
+                                  c_int32, c_int32, c_void_p, c_void_p]),
     "link_cell_table_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_void_p]),
     "link_block_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p]),

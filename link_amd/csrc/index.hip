@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) k_neighbor_map(const int4 *__restrict__ b
                                                       const int32_t *__restrict__ cell_blk,
                                                       link_grid_t g, const int32_t *__restrict__ hdr,
                                                       int64_t m_cap, int r, int K, int sign,
-                                                      int32_t *__restrict__ nbr) {
+                                                      int32_t *__restrict__ nbr) {  // sign = +-step
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t m = hdr ? (int64_t)hdr[LINK_HDR_M] : m_cap;
   if (m > m_cap) m = m_cap;
@@ -390,14 +390,14 @@ __global__ void __launch_bounds__(256) k_neighbor_map(const int4 *__restrict__ b
 
 extern "C" int link_neighbor_map(const int32_t *blk_coords, const int32_t *cell_blk,
                                  const link_grid_t *grid, const int32_t *hdr, int64_t m, int32_t r,
-                                 int32_t transpose, int32_t *nbr, void *stream) {
-  if (m < 0 || r <= 0 || r > 15 || !grid) return LINK_ERR_ARG;
+                                 int32_t step, int32_t transpose, int32_t *nbr, void *stream) {
+  if (m < 0 || r <= 0 || r > 15 || step <= 0 || !grid) return LINK_ERR_ARG;
   if (m == 0) return LINK_OK;
   if (!blk_coords || !cell_blk || !nbr) return LINK_ERR_ARG;
   int K = r * r * r;
   hipLaunchKernelGGL(k_neighbor_map, dim3(blocks_for(m * K, 256)), dim3(256), 0, S(stream),
                      reinterpret_cast<const int4 *>(blk_coords), cell_blk, *grid, hdr, m, (int)r, K,
-                     transpose ? -1 : 1, nbr);
+                     transpose ? -step : step, nbr);
   return check_launch("link_neighbor_map");
 }
 

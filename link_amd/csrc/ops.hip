@@ -66,19 +66,16 @@ extern "C" int link_kernel_hash(const int32_t *coords, int64_t n, const int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// hash_query: open addressing, linear probing, power-of-two table of {key, val} pairs.
-//   slot.val: 0 = empty, otherwise (smallest target position claiming this key) + 1
-//   insert: CAS val 0 -> pos+1 claims an empty slot and then publishes the key; a later arrival that
-//   finds the slot claimed must know the key, so keys are written FIRST by a 64-bit CAS on the key
-//   word guarded by a separate `state` word.  To stay simple and race-free the table stores
-//   key (u64), pos (u32, atomicMin for first-wins), state (u32: 0 empty, 1 key valid).
-// Two kernels (insert, lookup) on the same stream; the kernel boundary orders them.
+// hash_query: open addressing, linear probing, power-of-two table; WAIT-FREE insert.
+//   keys[cap] u64 (SENT = empty), pos[cap] u32 (smallest target position holding that key).
+//   insert = one 64-bit CAS on the key word (claims an empty slot or finds the key already there)
+//   followed by atomicMin on pos (first duplicate wins, query_cpu.cpp:24 insert-if-absent).  No lane
+//   ever waits for another lane (a spin on a same-wave lane's store can deadlock under SIMT).
+//   The one key equal to the empty sentinel is kept in a dedicated side slot, so there is NO reserved
+//   key (the reference reserves 0: hashmap_cuda.cuh:13, query_cpu.cpp:19).
+// Three kernels (clear, insert, lookup) on one stream; kernel boundaries order them.
 // ---------------------------------------------------------------------------------------------
-struct QSlot {
-  unsigned long long key;
-  unsigned int state;  // 0 empty, 1 claimed (key being written), 2 key valid
-  unsigned int pos;    // min target position with this key
-};
+constexpr unsigned long long Q_SENT = 0x8000000000000000ULL;
 
 static inline uint64_t query_cap(int64_t n) {
   uint64_t cap = 64;
@@ -86,59 +83,54 @@ static inline uint64_t query_cap(int64_t n) {
   return cap;
 }
 
+// workspace layout: keys u64[cap] | pos u32[cap] | sent_pos u32 (+pad)
 extern "C" size_t link_hash_query_workspace_bytes(int64_t n_target) {
-  return (size_t)query_cap(n_target < 0 ? 0 : n_target) * sizeof(QSlot);
+  uint64_t cap = query_cap(n_target < 0 ? 0 : n_target);
+  return (size_t)cap * 12 + 64;
 }
 
-__global__ void __launch_bounds__(256) k_q_clear(QSlot *__restrict__ tab, uint64_t cap) {
+__global__ void __launch_bounds__(256) k_q_clear(unsigned long long *__restrict__ keys,
+                                                 unsigned int *__restrict__ pos, uint64_t cap) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap) { tab[i].key = 0ULL; tab[i].state = 0u; tab[i].pos = 0xFFFFFFFFu; }
+  if (i < cap) { keys[i] = Q_SENT; pos[i] = 0xFFFFFFFFu; }
+  if (i == 0) pos[cap] = 0xFFFFFFFFu;  // side slot for the sentinel-valued key
 }
 
 __global__ void __launch_bounds__(256) k_q_insert(const int64_t *__restrict__ target, int64_t n,
-                                                  QSlot *tab, uint64_t mask) {
+                                                  unsigned long long *keys, unsigned int *pos,
+                                                  uint64_t mask) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   unsigned long long key = (unsigned long long)target[i];
+  if (key == Q_SENT) { atomicMin(&pos[mask + 1], (unsigned int)i); return; }
   uint64_t s = mix64(key) & mask;
-  // Every iteration is non-blocking (no lane ever spins on another lane of its own wave): a lane
-  // that finds the slot mid-publication (state 1) simply retries the same slot next iteration.
-  bool done = false;
-  while (!done) {
-    unsigned int expect = 0u;
-    bool won = __hip_atomic_compare_exchange_strong(&tab[s].state, &expect, 1u, __ATOMIC_ACQUIRE,
-                                                    __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (won) {  // we claimed the slot: publish the key, then mark it valid
-      __hip_atomic_store(&tab[s].key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&tab[s].state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      atomicMin(&tab[s].pos, (unsigned int)i);
-      done = true;
-    } else if (expect == 2u) {
-      unsigned long long k2 = __hip_atomic_load(&tab[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k2 == key) {
-        atomicMin(&tab[s].pos, (unsigned int)i);
-        done = true;
-      } else {
-        s = (s + 1) & mask;
-      }
-    }
+  for (;;) {
+    unsigned long long old = atomicCAS(&keys[s], Q_SENT, key);
+    if (old == Q_SENT || old == key) { atomicMin(&pos[s], (unsigned int)i); return; }
+    s = (s + 1) & mask;
   }
 }
 
 __global__ void __launch_bounds__(256) k_q_lookup(const int64_t *__restrict__ query, int64_t n1,
                                                   const int64_t *__restrict__ target_idx,
-                                                  const QSlot *__restrict__ tab, uint64_t mask,
+                                                  const unsigned long long *__restrict__ keys,
+                                                  const unsigned int *__restrict__ pos, uint64_t mask,
                                                   int64_t *__restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n1) return;
   unsigned long long key = (unsigned long long)query[i];
-  uint64_t s = mix64(key) & mask;
   int64_t r = 0;
-  for (;;) {
-    QSlot q = tab[s];
-    if (q.state == 0u) break;
-    if (q.key == key) { r = target_idx[q.pos] + 1; break; }
-    s = (s + 1) & mask;
+  if (key == Q_SENT) {
+    unsigned int p = pos[mask + 1];
+    if (p != 0xFFFFFFFFu) r = target_idx[p] + 1;
+  } else {
+    uint64_t s = mix64(key) & mask;
+    for (;;) {
+      unsigned long long k = keys[s];
+      if (k == Q_SENT) break;
+      if (k == key) { r = target_idx[pos[s]] + 1; break; }
+      s = (s + 1) & mask;
+    }
   }
   out[i] = r;
 }
@@ -150,14 +142,15 @@ extern "C" int link_hash_query(const int64_t *query, int64_t n1, const int64_t *
   if (n1 == 0) return LINK_OK;
   if (!query || !out || !workspace || (n > 0 && (!target || !target_idx))) return LINK_ERR_ARG;
   uint64_t cap = query_cap(n);
-  if (workspace_bytes < cap * sizeof(QSlot)) return LINK_ERR_WORKSPACE;
-  QSlot *tab = reinterpret_cast<QSlot *>(workspace);
-  hipLaunchKernelGGL(k_q_clear, dim3(blocks_for((int64_t)cap, 256)), dim3(256), 0, S(stream), tab, cap);
+  if (workspace_bytes < link_hash_query_workspace_bytes(n)) return LINK_ERR_WORKSPACE;
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(workspace);
+  unsigned int *pos = reinterpret_cast<unsigned int *>(keys + cap);
+  hipLaunchKernelGGL(k_q_clear, dim3(blocks_for((int64_t)cap, 256)), dim3(256), 0, S(stream), keys, pos, cap);
   if (n > 0)
-    hipLaunchKernelGGL(k_q_insert, dim3(blocks_for(n, 256)), dim3(256), 0, S(stream), target, n, tab,
+    hipLaunchKernelGGL(k_q_insert, dim3(blocks_for(n, 256)), dim3(256), 0, S(stream), target, n, keys, pos,
                        cap - 1);
   hipLaunchKernelGGL(k_q_lookup, dim3(blocks_for(n1, 256)), dim3(256), 0, S(stream), query, n1,
-                     target_idx, tab, cap - 1, out);
+                     target_idx, keys, pos, cap - 1, out);
   return check_launch("link_hash_query");
 }
 

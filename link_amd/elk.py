@@ -32,9 +32,10 @@ import torch.nn.functional as TF
 
 from . import _lib as L
 from .aggregate import _AuxToVoxel, _BlockMean, link_index_of
-from .index import BlockIndex, foreign_neighbor_map
+from .functional import sphash, sphashquery
+from .index import BlockIndex, GridTooLarge, foreign_neighbor_map
 from .tensor import SparseTensor
-from .utils import make_ntuple
+from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
            "elk_core_fused", "elk_core_autograd", "ElkCorePlan"]
@@ -224,10 +225,14 @@ class Conv3d(nn.Module):
             key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
             nbr = x.kmaps.get(key)
             if nbr is None:
-                ts = x.s[0]
-                rows = x.C if ts == 1 else torch.cat(
-                    [torch.div(x.C[:, :3], ts, rounding_mode="floor").int(), x.C[:, 3:]], dim=1)
-                nbr = foreign_neighbor_map(rows, self.kernel_size[0]).long()
+                # kernel map: neighbour of voxel i at coords_i + offset*tensor_stride
+                # (nn/functional/conv.py:105-113: offsets use stride=input.stride)
+                ts = int(x.s[0])
+                try:
+                    nbr = foreign_neighbor_map(x.C, self.kernel_size[0], step=ts).long()
+                except GridTooLarge:
+                    offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=feats.device)
+                    nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous()
                 nbr = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr)   # -> zero pad row
                 x.kmaps[key] = nbr
             padded = torch.cat([feats, feats.new_zeros(1, feats.shape[1])], dim=0)

@@ -144,16 +144,17 @@ class BlockIndex:
             m = self.M
             nbr = torch.empty((m, r ** 3), dtype=torch.int32, device=self.coords.device)
             L.check(L.lib().link_neighbor_map(self.blk_coords.data_ptr(), self.cell_blk.data_ptr(),
-                                              ctypes.byref(self.grid), self.hdr.data_ptr(), m, int(r),
+                                              ctypes.byref(self.grid), self.hdr.data_ptr(), m, int(r), 1,
                                               1 if transpose else 0, nbr.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "link_neighbor_map")
             self._nbr[key] = nbr
         return self._nbr[key]
 
 
-def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False) -> torch.Tensor:
-    """Neighbour map for arbitrary block rows int32[M,4] (not produced by a BlockIndex): dense cell
-    table over the rows' bounding box (first duplicate row wins), then the same lookup kernel."""
+def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, step: int = 1) -> torch.Tensor:
+    """Neighbour map for arbitrary rows int32[M,4] (not produced by a BlockIndex): dense cell table
+    over the rows' bounding box (first duplicate row wins), then the same lookup kernel; neighbour
+    offsets are multiplied by `step`."""
     rows = rows.contiguous()
     m = rows.shape[0]
     dev = rows.device
@@ -172,5 +173,5 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False) ->
     L.check(L.lib().link_cell_table_build(rows.data_ptr(), m, ctypes.byref(grid), table.data_ptr(), None, st),
             "link_cell_table_build")
     L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
-                                      1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
+                                      int(step), 1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
     return nbr
