@@ -139,12 +139,12 @@ def main():
     stages = {
         "index_build(4 kernels)": lambda: lib.link_index_build(
             coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch, b.scratch_bytes, b.cell_blk,
-            b.vox_blk, b.idx_query, b.perm, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
+            b.vox_blk, b.idx_query, b.perm, b.vox_sorted, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
         "premix_ln": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
         "modulate_block_sum": lambda: lib.link_modulate_block_sum(
-            b.fin, b.coords, b.w_pos, b.alpha, b.perm, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
+            b.fin, b.vox_sorted, b.w_pos, b.alpha, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
         "gather_demod_ln": lambda: lib.link_gather_demod_ln(
-            b.S, b.fin, b.coords, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.perm, b.blk_start, b.blk_coords,
+            b.S, b.fin, b.vox_sorted, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.blk_start, b.blk_coords,
             b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, N, b.out, st),
     }
     k_inst = min(args.steps, 100)

@@ -136,6 +136,8 @@ size_t link_index_scratch_bytes(int64_t n, int64_t v);
  *   vox_blk    i32[N]    block id of each voxel                      (== idx_query, utils.py:50)
  *   idx_query  i64[N]    same as int64 (may be NULL)                 (reference dtype)
  *   perm       i32[N]    voxel ids grouped by block, ascending voxel id inside a block
+ *   vox_sorted i32[N,4]  (x, y, z, voxel id) of the voxel at each position of perm: the record the
+ *                        fused kernels stream instead of chasing perm -> coords (may be NULL)
  *   blk_start  i32[N+1]  start of each block's segment in perm; blk_start[M] = N
  *   blk_coords i32[N,4]  block coordinates, rows [0,M) valid         (== small_x.C, utils.py:47)
  *   counts     i32[N]    voxels per block, rows [0,M) valid          (== spcount, utils.py:51)
@@ -143,8 +145,9 @@ size_t link_index_scratch_bytes(int64_t n, int64_t v);
  * Bit-exact with the reference for small_x.C / idx_query / counts. */
 int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /* host */,
                      uint32_t *cell_counts, void *scratch, size_t scratch_bytes, int32_t *cell_blk,
-                     int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *blk_start,
-                     int32_t *blk_coords, int32_t *counts, int32_t *hdr, void *stream);
+                     int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *vox_sorted,
+                     int32_t *blk_start, int32_t *blk_coords, int32_t *counts, int32_t *hdr,
+                     void *stream);
 
 /* Neighbour map nbr i32[M,K] (K = r^3, offsets in get_kernel_offsets(r) order, nn/utils/kernel.py:
  * 11-32: odd r x fastest, even r z fastest): replaces sphash(C, offsets) + sphash + sphashquery +
@@ -218,8 +221,8 @@ int link_premix_ln(const float *feats, const float *w_pre, const float *ln_w, co
  * over the voxels of block b in ascending voxel id.  S fp[M_cap, nparts*C + 1] (block SUMS, not
  * means: mean*count of the reference re-multiplies what it just divided).  w_pos fp[cg,3]; alpha
  * fp[cg] or NULL. */
-int link_modulate_block_sum(const float *fin, const int32_t *coords, const float *w_pos,
-                            const float *alpha, const int32_t *perm, const int32_t *blk_start,
+int link_modulate_block_sum(const float *fin, const int32_t *vox_sorted, const float *w_pos,
+                            const float *alpha, const int32_t *blk_start,
                             const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
                             int64_t m_cap, float *S, void *stream);
 
@@ -229,9 +232,9 @@ int link_modulate_block_sum(const float *fin, const int32_t *coords, const float
  *   new = A_cos*cos(theta) + A_sin*sin(theta) [+ (A_lin - fin*theta)]   ('sin': A_cos*cos - A_sin*sin
  *   with X=[F sin, F cos]) ; out = LayerNorm(new)*g + b.
  * `fin` is only read for LINK_OP_COSX (may be NULL otherwise).  out fp[N,C]. */
-int link_gather_demod_ln(const float *S, const float *fin, const int32_t *coords, const float *w_pos,
-                         const float *alpha, const float *ln_w, const float *ln_b,
-                         const int32_t *perm, const int32_t *blk_start, const int32_t *blk_coords,
+int link_gather_demod_ln(const float *S, const float *fin, const int32_t *vox_sorted,
+                         const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                         const int32_t *blk_start, const int32_t *blk_coords,
                          const int32_t *cell_blk, const link_grid_t *grid /* host */,
                          const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
                          int64_t m_cap, float *out, void *stream);
@@ -247,11 +250,15 @@ typedef struct {
   const float *w_pos, *alpha;                 /* pos_weight.0.weight [cg,3]; alpha [cg] or NULL */
   const float *ln_w, *ln_b;                   /* norm.{weight,bias} [C] */
   uint32_t *cell_counts; void *scratch; size_t scratch_bytes;          /* link_index_build scratch */
-  int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *blk_start, *blk_coords, *counts, *hdr;
+  int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *vox_sorted, *blk_start, *blk_coords, *counts, *hdr;
   float *fin;                /* fp[N,C]            scratch: pre_mix output */
   float *S;                  /* fp[m_cap, P*C+4]   scratch: block table */
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
 } link_elk_buffers_t;
+
+/* Launch-geometry tuning hook for bench/profiling (key 0: modulate workgroups, 1: gather workgroups,
+ * 2: pre_mix workgroups).  Not needed for correct operation. */
+int link_set_tuning(int key, int value);
 
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,

@@ -21,6 +21,8 @@ using namespace link;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+static int g_premix_wgs_fwd();
+
 // ---------------------------------------------------------------------------------------------
 // pre_mix + LayerNorm (MFMA path, C in {16,32,48,...,128}, C % 16 == 0)
 // ---------------------------------------------------------------------------------------------
@@ -106,6 +108,108 @@ __global__ void __launch_bounds__(256) k_premix_ln_mfma(const float *__restrict_
   }
 }
 
+// Register-resident variant for C <= 64: the whole W (C*C/64 floats per lane) lives in VGPRs in exactly
+// the A-operand layout, so there is no LDS staging, no barrier, and a wave can start its MFMAs as soon
+// as its own 16 KB of W and first F tile have arrived; the next tile's rows are prefetched while the
+// current tile is in the matrix pipe.
+template <int C>
+__global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__ feats,
+                                                       const float *__restrict__ w_pre,
+                                                       const float *__restrict__ ln_w,
+                                                       const float *__restrict__ ln_b, int64_t n,
+                                                       float eps, float *__restrict__ fin) {
+  constexpr int T = C / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  float4 a[T][T];
+#pragma unroll
+  for (int tp = 0; tp < T; tp++)
+#pragma unroll
+    for (int t = 0; t < T; t++)
+      a[tp][t] = *reinterpret_cast<const float4 *>(&w_pre[(16 * tp + li) * C + 16 * t + 4 * g]);
+  float4 lw[T], lb[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    lw[t] = *reinterpret_cast<const float4 *>(&ln_w[16 * t + 4 * g]);
+    lb[t] = *reinterpret_cast<const float4 *>(&ln_b[16 * t + 4 * g]);
+  }
+  const int64_t tiles = (n + 15) / 16;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  // loads are UNCONDITIONAL on a clamped row (tail lanes re-read row n-1; their results are never
+  // stored): predicated loads would force s_waitcnt vmcnt(0) and serialise the prefetch below
+  float4 f[T];
+  {
+    int64_t v = tile * 16 + li;
+    v = (v < n) ? v : n - 1;
+#pragma unroll
+    for (int t = 0; t < T; t++) f[t] = *reinterpret_cast<const float4 *>(&feats[v * C + 16 * t + 4 * g]);
+  }
+  for (; tile < tiles; tile += stride) {
+    const int64_t v = tile * 16 + li;
+    const bool ok = v < n;
+    int64_t vn = (tile + stride) * 16 + li;
+    vn = (vn < n) ? vn : n - 1;
+    float4 fn[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) fn[t] = *reinterpret_cast<const float4 *>(&feats[vn * C + 16 * t + 4 * g]);
+    floatx4 acc[T];
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].x, f[t].x, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].y, f[t].y, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].z, f[t].z, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].w, f[t].w, acc[tp], 0, 0, 0);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) s += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float d = acc[tp][r] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    if (ok) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        float4 o;
+        o.x = (acc[tp][0] - mean) * rstd * lw[tp].x + lb[tp].x;
+        o.y = (acc[tp][1] - mean) * rstd * lw[tp].y + lb[tp].y;
+        o.z = (acc[tp][2] - mean) * rstd * lw[tp].z + lb[tp].z;
+        o.w = (acc[tp][3] - mean) * rstd * lw[tp].w + lb[tp].w;
+        *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) f[t] = fn[t];
+  }
+}
+
+template <int C>
+static int launch_premix_reg(const float *feats, const float *w_pre, const float *ln_w, const float *ln_b,
+                             int64_t n, float eps, float *fin, hipStream_t st) {
+  int64_t tiles = (n + 15) / 16;
+  int64_t wgs = (tiles + 3) / 4;
+  if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();   // default 2 waves per SIMD chip-wide; W lives in registers
+  hipLaunchKernelGGL(k_premix_ln_reg<C>, dim3((unsigned)wgs), dim3(256), 0, st, feats, w_pre, ln_w, ln_b, n,
+                     eps, fin);
+  return check_launch("link_premix_ln");
+}
+
 // generic fallback (any C <= 256): one wave per voxel, lanes = output channels, W read through L1/L2
 template <int CPL>
 __global__ void __launch_bounds__(256) k_premix_ln_generic(const float *__restrict__ feats,
@@ -170,10 +274,12 @@ extern "C" int link_premix_ln(const float *feats, const float *w_pre, const floa
   if (!feats || !w_pre || !ln_w || !ln_b || !fin) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
   switch (c) {
-    case 16: return launch_premix_mfma<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 32: return launch_premix_mfma<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 48: return launch_premix_mfma<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 64: return launch_premix_mfma<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 16: return launch_premix_reg<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 32: return launch_premix_reg<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 48: return launch_premix_reg<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 64: return launch_premix_reg<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 80: return launch_premix_mfma<80>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 112: return launch_premix_mfma<112>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     case 96: return launch_premix_mfma<96>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     case 128: return launch_premix_mfma<128>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     default: break;
@@ -198,77 +304,181 @@ __device__ __forceinline__ float theta_of(float x, float y, float z, float w0, f
   return t * alpha;
 }
 
+// sin & cos of a moderate argument: 3-term Cody-Waite reduction by pi/2 + degree-7/8 minimax
+// polynomials on [-pi/4, pi/4] (<= ~1.5 ulp for |x| < 2^15); larger or non-finite arguments take the
+// library path.  Branch-free on the fast path: ~25 VALU ops instead of the library's table walk.
+__device__ __noinline__ void sincos_slow(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
+
+__device__ __forceinline__ void sincos_fast(float x, float &sn, float &cs) {
+  if (__builtin_expect(!(fabsf(x) < 32768.0f), 0)) {
+    sincos_slow(x, &sn, &cs);     // kept out of line: the fast path is what the i-cache should hold
+    return;
+  }
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188216e-8f, r);
+  const float r2 = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? pc : ps;
+  const float c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Work partition shared by the two block kernels: the sorted block range [0,M) is cut into 8
+// contiguous slabs, one per XCD (workgroup w runs on XCD w % 8 -- observed dispatch, used for L2
+// affinity only), and each slab into equal chunks of consecutive blocks, one chunk per wave.
+// Consecutive sorted blocks are z-neighbours in the grid, so a chunk is a run along z and a slab is a
+// range of x-planes: the rows a slab gathers (its own + one halo plane each side) fit its XCD's L2.
+__device__ __forceinline__ void wave_chunk(int m, int &b0, int &b1) {
+  const int xcd = blockIdx.x & 7;
+  const int waves_per_xcd = (gridDim.x >> 3) * (blockDim.x >> 6);
+  const int wq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lo = (int)(((long long)m * xcd) >> 3), hi = (int)(((long long)m * (xcd + 1)) >> 3);
+  const int ch = (hi - lo + waves_per_xcd - 1) / waves_per_xcd;
+  b0 = lo + wq * ch;
+  b1 = b0 + ch;
+  if (b1 > hi) b1 = hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// modulate + per-block pre-aggregation
+// ---------------------------------------------------------------------------------------------
 template <int CPL, int OP>
 __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ fin,
-                                                      const int4 *__restrict__ coords,
+                                                      const int4 *__restrict__ vox_sorted,
                                                       const float *__restrict__ w_pos,
                                                       const float *__restrict__ alpha,
-                                                      const int32_t *__restrict__ perm,
                                                       const int32_t *__restrict__ blk_start,
                                                       const int32_t *__restrict__ hdr, int c, int cg,
                                                       float coord_div, float *__restrict__ S) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
-  int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (b >= hdr[LINK_HDR_M]) return;
-  const int st = blk_start[b], en = blk_start[b + 1];
+  const int lane = threadIdx.x & 63;
+  int b0, b1;
+  wave_chunk(hdr[LINK_HDR_M], b0, b1);
+  if (b0 >= b1) return;
   const int rs = P * c + 4;
   float w0[CPL], w1[CPL], w2[CPL], al[CPL];
-  float a0[CPL], a1[CPL], a2[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
     int ch = lane + 64 * q;
     int tc = (ch < c) ? ch % cg : 0;
     w0[q] = w_pos[3 * tc + 0]; w1[q] = w_pos[3 * tc + 1]; w2[q] = w_pos[3 * tc + 2];
     al[q] = alpha ? alpha[tc] : 1.0f;
-    a0[q] = a1[q] = a2[q] = 0.f;
   }
-  for (int p = st; p < en; p++) {
-    const int i = perm[p];
-    const int4 cd = coords[i];
-    float x = (float)cd.x, y = (float)cd.y, z = (float)cd.z;
-    if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+  const float inv_div = 1.0f;  (void)inv_div;
+  for (int bb = b0; bb < b1; bb += 63) {          // up to 63 blocks per pass (64 segment bounds)
+    const int nb = (b1 - bb < 63) ? (b1 - bb) : 63;
+    const int bs_l = blk_start[bb + ((lane <= nb) ? lane : nb)];
+    const int p_lo = __shfl(bs_l, 0, 64), p_hi = __shfl(bs_l, nb, 64);
+    int j = 0;                                     // current block within the pass
+    int seg_end = __shfl(bs_l, 1, 64);
+    float a0[CPL], a1[CPL], a2[CPL];
 #pragma unroll
-    for (int q = 0; q < CPL; q++) {
-      int ch = lane + 64 * q;
-      if (ch < c) {
-        float f = fin[(int64_t)i * c + ch];
-        float th = theta_of(x, y, z, w0[q], w1[q], w2[q], al[q]);
-        float sn, cs;
-        sincosf(th, &sn, &cs);
-        if (OP == LINK_OP_SIN) { a0[q] += f * sn; a1[q] += f * cs; }
-        else { a0[q] += f * cs; a1[q] += f * sn; }
-        if (OP == LINK_OP_COSX) a2[q] += f * th;
+    for (int q = 0; q < CPL; q++) a0[q] = a1[q] = a2[q] = 0.f;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+      const int pl = p0 + lane;
+      int4 vs = (pl < p_hi) ? vox_sorted[pl] : make_int4(0, 0, 0, 0);
+      const int lim = (p_hi - p0 < 64) ? (p_hi - p0) : 64;
+      for (int t = 0; t < lim; t++) {
+        const int p = p0 + t;
+        while (p >= seg_end) {                     // flush finished block(s)
+          float *row = S + (int64_t)(bb + j) * rs;
+#pragma unroll
+          for (int q = 0; q < CPL; q++) {
+            int ch = lane + 64 * q;
+            if (ch < c) {
+              row[ch] = a0[q]; row[c + ch] = a1[q];
+              if (OP == LINK_OP_COSX) row[2 * c + ch] = a2[q];
+            }
+            a0[q] = a1[q] = a2[q] = 0.f;
+          }
+          const int seg_beg = __shfl(bs_l, j, 64);          // all lanes participate in the shuffle
+          if (lane == 0) row[P * c] = (float)(seg_end - seg_beg);
+          j++;
+          seg_end = __shfl(bs_l, j + 1, 64);
+        }
+        const int i = __shfl(vs.w, t, 64);
+        float x = (float)__shfl(vs.x, t, 64), y = (float)__shfl(vs.y, t, 64), z = (float)__shfl(vs.z, t, 64);
+        if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+          int ch = lane + 64 * q;
+          if (ch < c) {
+            float f = fin[(int64_t)i * c + ch];
+            float th = theta_of(x, y, z, w0[q], w1[q], w2[q], al[q]);
+            float sn, cs;
+            sincos_fast(th, sn, cs);
+            if (OP == LINK_OP_SIN) { a0[q] += f * sn; a1[q] += f * cs; }
+            else { a0[q] += f * cs; a1[q] += f * sn; }
+            if (OP == LINK_OP_COSX) a2[q] += f * th;
+          }
+        }
       }
     }
-  }
-  float *row = S + b * (int64_t)rs;
+    // flush the remaining block(s) of the pass
+    while (j < nb) {
+      float *row = S + (int64_t)(bb + j) * rs;
 #pragma unroll
-  for (int q = 0; q < CPL; q++) {
-    int ch = lane + 64 * q;
-    if (ch < c) {
-      row[ch] = a0[q];
-      row[c + ch] = a1[q];
-      if (OP == LINK_OP_COSX) row[2 * c + ch] = a2[q];
+      for (int q = 0; q < CPL; q++) {
+        int ch = lane + 64 * q;
+        if (ch < c) {
+          row[ch] = a0[q]; row[c + ch] = a1[q];
+          if (OP == LINK_OP_COSX) row[2 * c + ch] = a2[q];
+        }
+        a0[q] = a1[q] = a2[q] = 0.f;
+      }
+      const int seg_len = __shfl(bs_l, j + 1, 64) - __shfl(bs_l, j, 64);
+      if (lane == 0) row[P * c] = (float)seg_len;
+      j++;
     }
   }
-  if (lane == 0) row[P * c] = (float)(en - st);
+}
+
+// launch geometry knobs (defaults chosen from measurements in profiles/; link_set_tuning is a
+// bench/tuning hook, not part of the functional ABI)
+static int g_modsum_wgs = 2048;   // 8 XCDs x 32 CUs x 8 workgroups of 4 waves
+static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one resident round
+static int g_premix_wgs = 512;
+static int g_use_group_path = 1;
+static int g_use_pair = 1;
+extern "C" int link_set_tuning(int key, int value) {
+  if (value <= 0) return LINK_ERR_ARG;
+  switch (key) {
+    case 0: g_modsum_wgs = (value + 7) & ~7; return LINK_OK;
+    case 1: g_gather_wgs = (value + 7) & ~7; return LINK_OK;
+    case 2: g_premix_wgs = value; return LINK_OK;
+    case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
+    case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
+    default: return LINK_ERR_ARG;
+  }
 }
 
 template <int CPL>
-static void launch_modsum(int op, dim3 grid, hipStream_t st, const float *fin, const int4 *coords,
-                          const float *w_pos, const float *alpha, const int32_t *perm,
-                          const int32_t *blk_start, const int32_t *hdr, int c, int cg, float div,
-                          float *S) {
-  dim3 block(256);
+static void launch_modsum(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
+                          const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
+                          float div, float *S) {
+  dim3 grid(g_modsum_wgs), block(256);
   if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COS>), grid, block, 0, st, fin, coords, w_pos, alpha, perm, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COS>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_SIN>), grid, block, 0, st, fin, coords, w_pos, alpha, perm, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_SIN>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
   else
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COSX>), grid, block, 0, st, fin, coords, w_pos, alpha, perm, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COSX>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
 }
 
+static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
+                              const float *w_pos, const float *alpha, const int32_t *blk_start,
+                              const int32_t *hdr, float *S_);
+static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const float *S_, const float *fin,
+                              const int4 *vox, const float *w_pos, const float *alpha, const float *ln_w,
+                              const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
+                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out);
 static int check_desc(const link_elk_desc_t *d) {
   if (!d) return LINK_ERR_ARG;
   if (d->op < 0 || d->op > 2 || d->c <= 0 || d->c > 256 || d->cg <= 0 || d->cg > d->c) return LINK_ERR_ARG;
@@ -276,84 +486,60 @@ static int check_desc(const link_elk_desc_t *d) {
   return LINK_OK;
 }
 
-extern "C" int link_modulate_block_sum(const float *fin, const int32_t *coords, const float *w_pos,
-                                       const float *alpha, const int32_t *perm,
-                                       const int32_t *blk_start, const int32_t *hdr,
+extern "C" int link_modulate_block_sum(const float *fin, const int32_t *vox_sorted, const float *w_pos,
+                                       const float *alpha, const int32_t *blk_start, const int32_t *hdr,
                                        const link_elk_desc_t *desc, int64_t n, int64_t m_cap, float *S_,
                                        void *stream) {
   if (check_desc(desc) != LINK_OK || n < 0 || m_cap < 0) return LINK_ERR_ARG;
   if (n == 0 || m_cap == 0) return LINK_OK;
-  if (!fin || !coords || !w_pos || !perm || !blk_start || !hdr || !S_) return LINK_ERR_ARG;
-  dim3 grid(blocks_for(m_cap * 64, 256));
-  const int4 *c4 = reinterpret_cast<const int4 *>(coords);
+  if (!fin || !vox_sorted || !w_pos || !blk_start || !hdr || !S_) return LINK_ERR_ARG;
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
   int cpl = (desc->c + 63) / 64;
   hipStream_t st = S(stream);
+  if (modsum_group_path(desc, st, fin, v4, w_pos, alpha, blk_start, hdr, S_)) return check_launch("link_modulate_block_sum");
   switch (cpl) {
-    case 1: launch_modsum<1>(desc->op, grid, st, fin, c4, w_pos, alpha, perm, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    case 2: launch_modsum<2>(desc->op, grid, st, fin, c4, w_pos, alpha, perm, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    case 3: launch_modsum<3>(desc->op, grid, st, fin, c4, w_pos, alpha, perm, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    default: launch_modsum<4>(desc->op, grid, st, fin, c4, w_pos, alpha, perm, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
+    case 1: launch_modsum<1>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
+    case 2: launch_modsum<2>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
+    case 3: launch_modsum<3>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
+    default: launch_modsum<4>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
   }
   return check_launch("link_modulate_block_sum");
 }
 
 // ---------------------------------------------------------------------------------------------
 // neighbour-block sum + normalise + de-modulate + LayerNorm
+//
+// The r^3 neighbourhood sum is evaluated as r "column sums" col(z') = sum over the r^2 (dx,dy)
+// neighbours at height z' (in get_kernel_offsets order within the plane), out = sum_z' col(z').
+// A wave walks a run of consecutive sorted blocks = increasing z in one (x,y) column, so when it
+// steps from z to z+1 it keeps r-1 of the r column sums in registers and gathers only r^2 new rows
+// instead of r^3 (3x fewer row reads at r=3).  Summation order is fixed (deterministic), though not
+// the k-ascending order of the reference kernel (difference ~1e-7 rel, far inside the 1e-4 gate).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void kernel_offset_d(int r, int k, int &ox, int &oy, int &oz) {
-  int lo = -((r + 1) / 2) + 1;   // nn/utils/kernel.py:21: arange(-r//2+1, r//2+1)
-  int a = k % r, b = (k / r) % r, cc = k / (r * r);
-  if ((r & 1) != 0) { ox = lo + a; oy = lo + b; oz = lo + cc; }   // odd volume: x fastest
-  else { oz = lo + a; oy = lo + b; ox = lo + cc; }                // even volume: z fastest
+template <int R>
+__device__ __forceinline__ void plane_offset(int t, int &ox, int &oy) {
+  constexpr int LO = -((R + 1) / 2) + 1;      // nn/utils/kernel.py:21
+  if ((R & 1) != 0) { ox = LO + (t % R); oy = LO + (t / R); }   // odd volume: x fastest
+  else { oy = LO + (t % R); ox = LO + (t / R); }                 // even volume: y faster than x
 }
 
-template <int CPL, int OP>
+template <int CPL, int OP, int R>
 __global__ void __launch_bounds__(256) k_gather_demod_ln(
-    const float *__restrict__ S, const float *__restrict__ fin, const int4 *__restrict__ coords,
+    const float *__restrict__ S, const float *__restrict__ fin, const int4 *__restrict__ vox_sorted,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
-    const float *__restrict__ ln_b, const int32_t *__restrict__ perm,
-    const int32_t *__restrict__ blk_start, const int4 *__restrict__ blk_coords,
-    const int32_t *__restrict__ cell_blk, link_grid_t g, const int32_t *__restrict__ hdr, int c, int cg,
-    int r, float coord_div, float eps, float *__restrict__ out) {
+    const float *__restrict__ ln_b, const int32_t *__restrict__ blk_start,
+    const int4 *__restrict__ blk_coords, const int32_t *__restrict__ cell_blk, link_grid_t g,
+    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
-  int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (b >= hdr[LINK_HDR_M]) return;
-  const int st = blk_start[b], en = blk_start[b + 1];
+  constexpr int R2 = R * R, R3 = R2 * R;
+  constexpr int ZLO = -((R + 1) / 2) + 1;
+  constexpr int SUB = (R3 <= 27) ? 16 : 8;       // blocks per pass: their neighbour ids live in LDS
+  __shared__ int32_t s_nb[4][SUB * R3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int b0, b1;
+  wave_chunk(hdr[LINK_HDR_M], b0, b1);
+  if (b0 >= b1) return;
   const int rs = P * c + 4;
-  const int K = r * r * r;
-  const int4 bc = blk_coords[b];
-  float A0[CPL], A1[CPL], A2[CPL];
-#pragma unroll
-  for (int q = 0; q < CPL; q++) A0[q] = A1[q] = A2[q] = 0.f;
-  float den = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    int kk = k0 + lane;
-    int32_t nb_l = -1;
-    if (kk < K) {
-      int ox, oy, oz;
-      kernel_offset_d(r, kk, ox, oy, oz);
-      int32_t cell = cell_of(g, bc.x + ox, bc.y + oy, bc.z + oz, bc.w);
-      if (cell >= 0) nb_l = cell_blk[cell] - 1;
-    }
-    int lim = (K - k0 < 64) ? (K - k0) : 64;
-    for (int t = 0; t < lim; t++) {
-      int32_t nb = __shfl(nb_l, t, 64);
-      if (nb >= 0) {   // wave-uniform
-        const float *row = S + (int64_t)nb * rs;
-        den += row[P * c];
-#pragma unroll
-        for (int q = 0; q < CPL; q++) {
-          int ch = lane + 64 * q;
-          if (ch < c) {
-            A0[q] += row[ch];
-            A1[q] += row[c + ch];
-            if (OP == LINK_OP_COSX) A2[q] += row[2 * c + ch];
-          }
-        }
-      }
-    }
-  }
   float w0[CPL], w1[CPL], w2[CPL], al[CPL], gw[CPL], gb[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
@@ -363,92 +549,716 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
     al[q] = alpha ? alpha[tc] : 1.0f;
     gw[q] = (ch < c) ? ln_w[ch] : 0.f;
     gb[q] = (ch < c) ? ln_b[ch] : 0.f;
-    A0[q] = A0[q] / den; A1[q] = A1[q] / den; A2[q] = A2[q] / den;   // utils.py:80
   }
-  for (int p = st; p < en; p++) {
-    const int i = perm[p];
-    const int4 cd = coords[i];
-    float x = (float)cd.x, y = (float)cd.y, z = (float)cd.z;
-    if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
-    float nv[CPL];
-    float s = 0.f;
+  // column-sum ring: slot d holds col(zc + ZLO + d) for the current centre (px,py,pw,zc)
+  float col[R][P][CPL], cden[R];
+  int px = 0, py = 0, pw = 0, pz = 0;
+  bool have = false;
+  int32_t *my_nb = s_nb[wave];
+
+  for (int bb = b0; bb < b1; bb += SUB) {
+    const int nbk = (b1 - bb < SUB) ? (b1 - bb) : SUB;
+    // ---- pass prologue (ONE memory round trip for the whole pass): block coordinates, segment
+    //      bounds, and all nbk*R^3 neighbour ids (cell table lookups, lane-parallel) -> LDS
+    const int4 bc_l = blk_coords[bb + ((lane < nbk) ? lane : nbk - 1)];
+    const int bs_l = blk_start[bb + ((lane <= nbk) ? lane : nbk)];
+    for (int e = lane; e < nbk * R3; e += 64) {
+      const int j = e / R3, k = e - j * R3;
+      const int d = k / R2, t = k - d * R2;
+      int ox, oy;
+      plane_offset<R>(t, ox, oy);
+      const int bx = __shfl(bc_l.x, j, 64), by = __shfl(bc_l.y, j, 64);
+      const int bz = __shfl(bc_l.z, j, 64), bw = __shfl(bc_l.w, j, 64);
+      const int32_t cell = cell_of(g, bx + ox, by + oy, bz + ZLO + d, bw);
+      my_nb[e] = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+    }
+    const int p_lo = __shfl(bs_l, 0, 64), p_hi = __shfl(bs_l, nbk, 64);
+    int vs_base = p_lo;
+    int4 vs = (p_lo + lane < p_hi) ? vox_sorted[p_lo + lane] : make_int4(0, 0, 0, 0);
+
+    for (int j = 0; j < nbk; j++) {
+      const int bx = __shfl(bc_l.x, j, 64), by = __shfl(bc_l.y, j, 64);
+      const int bz = __shfl(bc_l.z, j, 64), bw = __shfl(bc_l.w, j, 64);
+      const int st = __shfl(bs_l, j, 64), en = __shfl(bs_l, j + 1, 64);
+      // how many ring slots survive the move to this block
+      int keep = 0;
+      if (have && bx == px && by == py && bw == pw) {
+        int dz = bz - pz;
+        if (dz > 0 && dz < R) keep = R - dz;
+      }
+      const int shift = R - keep;
 #pragma unroll
-    for (int q = 0; q < CPL; q++) {
-      int ch = lane + 64 * q;
-      nv[q] = 0.f;
-      if (ch < c) {
-        float th = theta_of(x, y, z, w0[q], w1[q], w2[q], al[q]);
-        float sn, cs;
-        sincosf(th, &sn, &cs);
-        float v;
-        if (OP == LINK_OP_SIN) v = __fsub_rn(__fmul_rn(A0[q], cs), __fmul_rn(A1[q], sn));    // linkunet.py:148
-        else v = __fadd_rn(__fmul_rn(A0[q], cs), __fmul_rn(A1[q], sn));                       // :162
-        if (OP == LINK_OP_COSX) {
-          float f = fin[(int64_t)i * c + ch];
-          v = __fadd_rn(v, __fsub_rn(A2[q], __fmul_rn(f, th)));                               // :176
+      for (int d = 0; d < R; d++) {               // shift the surviving slots down (static indices)
+#pragma unroll
+        for (int sft = 1; sft < R; sft++) {
+          if (shift == sft && d + sft < R) {
+#pragma unroll
+            for (int pp = 0; pp < P; pp++)
+#pragma unroll
+              for (int q = 0; q < CPL; q++) col[d][pp][q] = col[d + sft][pp][q];
+            cden[d] = cden[d + sft];
+          }
         }
-        nv[q] = v;
-        s += v;
+      }
+#pragma unroll
+      for (int d = 0; d < R; d++) {
+        if (d >= keep) {                          // wave-uniform: gather plane z + ZLO + d
+          float v[R2][P][CPL], vd[R2];
+          int32_t nbv[R2];
+#pragma unroll
+          for (int t = 0; t < R2; t++) nbv[t] = my_nb[(j * R + d) * R2 + t];   // LDS broadcast reads
+#pragma unroll
+          for (int t = 0; t < R2; t++) {          // issue all row loads of the plane back to back
+            const float *row = S + (int64_t)((nbv[t] >= 0) ? nbv[t] : 0) * rs;
+            vd[t] = row[P * c];
+#pragma unroll
+            for (int pp = 0; pp < P; pp++)
+#pragma unroll
+              for (int q = 0; q < CPL; q++) {
+                int ch = lane + 64 * q;
+                v[t][pp][q] = row[pp * c + ((ch < c) ? ch : 0)];
+              }
+          }
+          float acc[P][CPL], den = 0.f;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int q = 0; q < CPL; q++) acc[pp][q] = 0.f;
+#pragma unroll
+          for (int t = 0; t < R2; t++) {          // then sum them in plane order
+            if (nbv[t] >= 0) {
+              den += vd[t];
+#pragma unroll
+              for (int pp = 0; pp < P; pp++)
+#pragma unroll
+                for (int q = 0; q < CPL; q++) acc[pp][q] += v[t][pp][q];
+            }
+          }
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int q = 0; q < CPL; q++) col[d][pp][q] = acc[pp][q];
+          cden[d] = den;
+        }
+      }
+      have = true; px = bx; py = by; pw = bw; pz = bz;
+      // out = sum of the R column sums, normalised by the summed count (utils.py:80)
+      float A[P][CPL], den = cden[0];
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int q = 0; q < CPL; q++) A[pp][q] = col[0][pp][q];
+#pragma unroll
+      for (int d = 1; d < R; d++) {
+        den += cden[d];
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+#pragma unroll
+          for (int q = 0; q < CPL; q++) A[pp][q] += col[d][pp][q];
+      }
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int q = 0; q < CPL; q++) A[pp][q] = A[pp][q] / den;
+
+      // voxels of the block (records come from the prefetched 64-wide window)
+      for (int p = st; p < en; p++) {
+        if (p - vs_base >= 64) {                  // refill the window (wave-uniform)
+          vs_base = p;
+          vs = (p + lane < p_hi) ? vox_sorted[p + lane] : make_int4(0, 0, 0, 0);
+        }
+        const int t = p - vs_base;
+        const int i = __shfl(vs.w, t, 64);
+        float x = (float)__shfl(vs.x, t, 64), y = (float)__shfl(vs.y, t, 64), z = (float)__shfl(vs.z, t, 64);
+        if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+        float nv[CPL];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+          int ch = lane + 64 * q;
+          nv[q] = 0.f;
+          if (ch < c) {
+            float th = theta_of(x, y, z, w0[q], w1[q], w2[q], al[q]);
+            float sn, cs;
+            sincos_fast(th, sn, cs);
+            float vv;
+            if (OP == LINK_OP_SIN) vv = __fsub_rn(__fmul_rn(A[0][q], cs), __fmul_rn(A[1][q], sn));   // linkunet.py:148
+            else vv = __fadd_rn(__fmul_rn(A[0][q], cs), __fmul_rn(A[1][q], sn));                      // :162
+            if (OP == LINK_OP_COSX) {
+              float f = fin[(int64_t)i * c + ch];
+              vv = __fadd_rn(vv, __fsub_rn(A[P - 1][q], __fmul_rn(f, th)));                           // :176
+            }
+            nv[q] = vv;
+            s += vv;
+          }
+        }
+        s = wave_sum(s);
+        const float mean = s / c;
+        float qq = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+          float dd = (lane + 64 * q < c) ? nv[q] - mean : 0.f;
+          qq += dd * dd;
+        }
+        qq = wave_sum(qq);
+        const float rstd = 1.0f / sqrtf(qq / c + eps);
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+          int ch = lane + 64 * q;
+          if (ch < c) out[(int64_t)i * c + ch] = (nv[q] - mean) * rstd * gw[q] + gb[q];
+        }
       }
     }
-    s = wave_sum(s);
-    const float mean = s / c;
-    float qq = 0.f;
-#pragma unroll
-    for (int q = 0; q < CPL; q++) {
-      float d = (lane + 64 * q < c) ? nv[q] - mean : 0.f;
-      qq += d * d;
-    }
-    qq = wave_sum(qq);
-    const float rstd = 1.0f / sqrtf(qq / c + eps);
-#pragma unroll
-    for (int q = 0; q < CPL; q++) {
-      int ch = lane + 64 * q;
-      if (ch < c) out[(int64_t)i * c + ch] = (nv[q] - mean) * rstd * gw[q] + gb[q];
-    }
   }
+}
+
+template <int CPL, int OP>
+static void launch_gdl_r(int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+                         const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                         const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
+                         const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
+  dim3 grid(g_gather_wgs), block(256);
+#define LINK_GDL(RR)                                                                                   \
+  hipLaunchKernelGGL((k_gather_demod_ln<CPL, OP, RR>), grid, block, 0, st, S_, fin, vox, w_pos, alpha, \
+                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+  switch (r) {
+    case 1: LINK_GDL(1); break;
+    case 2: LINK_GDL(2); break;
+    case 3: LINK_GDL(3); break;
+    case 4: LINK_GDL(4); break;
+    default: LINK_GDL(5); break;
+  }
+#undef LINK_GDL
 }
 
 template <int CPL>
-static void launch_gdl(int op, dim3 grid, hipStream_t st, const float *S_, const float *fin,
-                       const int4 *coords, const float *w_pos, const float *alpha, const float *ln_w,
-                       const float *ln_b, const int32_t *perm, const int32_t *blk_start,
-                       const int4 *blk_coords, const int32_t *cell_blk, const link_grid_t &g,
-                       const int32_t *hdr, const link_elk_desc_t &d, float *out) {
-  dim3 block(256);
+static void launch_gdl(int op, int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+                       const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                       const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
+                       const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
   if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_gather_demod_ln<CPL, LINK_OP_COS>), grid, block, 0, st, S_, fin, coords, w_pos, alpha, ln_w, ln_b, perm, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.r, d.coord_div, d.eps, out);
+    launch_gdl_r<CPL, LINK_OP_COS>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_gather_demod_ln<CPL, LINK_OP_SIN>), grid, block, 0, st, S_, fin, coords, w_pos, alpha, ln_w, ln_b, perm, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.r, d.coord_div, d.eps, out);
+    launch_gdl_r<CPL, LINK_OP_SIN>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else
-    hipLaunchKernelGGL((k_gather_demod_ln<CPL, LINK_OP_COSX>), grid, block, 0, st, S_, fin, coords, w_pos, alpha, ln_w, ln_b, perm, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.r, d.coord_div, d.eps, out);
+    launch_gdl_r<CPL, LINK_OP_COSX>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
 }
 
-extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int32_t *coords,
+extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int32_t *vox_sorted,
                                     const float *w_pos, const float *alpha, const float *ln_w,
-                                    const float *ln_b, const int32_t *perm, const int32_t *blk_start,
+                                    const float *ln_b, const int32_t *blk_start,
                                     const int32_t *blk_coords, const int32_t *cell_blk,
                                     const link_grid_t *grid, const int32_t *hdr,
                                     const link_elk_desc_t *desc, int64_t n, int64_t m_cap, float *out,
                                     void *stream) {
-  if (check_desc(desc) != LINK_OK || !grid || n < 0 || m_cap < 0) return LINK_ERR_ARG;
+  if (check_desc(desc) != LINK_OK || !grid || n < 0 || m_cap < 0 || desc->r > 5) return LINK_ERR_ARG;
   if (n == 0 || m_cap == 0) return LINK_OK;
-  if (!S_ || !coords || !w_pos || !ln_w || !ln_b || !perm || !blk_start || !blk_coords || !cell_blk ||
-      !hdr || !out)
+  if (!S_ || !vox_sorted || !w_pos || !ln_w || !ln_b || !blk_start || !blk_coords || !cell_blk || !hdr || !out)
     return LINK_ERR_ARG;
   if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
-  dim3 g3(blocks_for(m_cap * 64, 256));
-  const int4 *c4 = reinterpret_cast<const int4 *>(coords);
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   int cpl = (desc->c + 63) / 64;
+  if (gather_group_path(desc, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, out))
+    return check_launch("link_gather_demod_ln");
   switch (cpl) {
-    case 1: launch_gdl<1>(desc->op, g3, st, S_, fin, c4, w_pos, alpha, ln_w, ln_b, perm, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    case 2: launch_gdl<2>(desc->op, g3, st, S_, fin, c4, w_pos, alpha, ln_w, ln_b, perm, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    case 3: launch_gdl<3>(desc->op, g3, st, S_, fin, c4, w_pos, alpha, ln_w, ln_b, perm, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    default: launch_gdl<4>(desc->op, g3, st, S_, fin, c4, w_pos, alpha, ln_w, ln_b, perm, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 1: launch_gdl<1>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 2: launch_gdl<2>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 3: launch_gdl<3>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    default: launch_gdl<4>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
   }
   return check_launch("link_gather_demod_ln");
+}
+
+static int g_premix_wgs_fwd() { return g_premix_wgs; }
+
+// =============================================================================================
+// Sub-wave ("group") kernels: the fast path for C % 4 == 0.
+//
+// A feature row of C floats is owned by LPR = pow2ceil(C/4) adjacent lanes, 4 consecutive channels
+// (one 16-byte access) per lane, so a 256-byte row of C=64 is ONE 16-lane dwordx4 access instead of a
+// 64-lane dword access, and a 64-lane wave carries 64/LPR independent work streams ("groups"), each
+// walking its own run of consecutive blocks.  Versus lane=channel this cuts vector-memory
+// instructions 4x, quadruples the loads in flight per wave (the kernels are latency/issue bound, not
+// HBM bound, at LiDAR sizes), needs no wave-wide broadcasts, and keeps LayerNorm reductions inside
+// a 16-lane DPP row.  Groups of one wave may diverge (different segment lengths); nothing is shared
+// between them except the instruction stream.
+// =============================================================================================
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+  // butterfly over the LPR lanes of a group; steps <= 8 stay inside a 16-lane DPP row
+  if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// chunk of consecutive sorted blocks owned by this GROUP (XCD slab -> equal chunks per group)
+template <int LPR>
+__device__ __forceinline__ void group_chunk(int m, int &b0, int &b1) {
+  constexpr int G = 64 / LPR;
+  const int xcd = blockIdx.x & 7;
+  const int groups_per_xcd = (gridDim.x >> 3) * (blockDim.x >> 6) * G;
+  const int gq = ((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + ((threadIdx.x & 63) / LPR);
+  const int lo = (int)(((long long)m * xcd) >> 3), hi = (int)(((long long)m * (xcd + 1)) >> 3);
+  const int ch = (hi - lo + groups_per_xcd - 1) / groups_per_xcd;
+  b0 = lo + gq * ch;
+  b1 = b0 + ch;
+  if (b1 > hi) b1 = hi;
+  if (b0 > hi) b0 = hi;
+}
+
+// value held by the partner lane (li ^ LPR/2) of the same group: the lane owning channel ch +- C/2
+template <int LPR>
+__device__ __forceinline__ float partner(float v) {
+  if (LPR == 16)   // rotate the 16-lane DPP row by 8: swaps its halves, one VALU op
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return __shfl_xor(v, LPR / 2, 64);
+}
+
+// PAIR (channel j and j + C/2 share theta, i.e. groups == 2 and the row fills its lanes exactly):
+// a step handles TWO consecutive voxels A,B; the low half of the group evaluates sincos(theta_A), the
+// high half sincos(theta_B), and the halves swap results with one DPP op per value -- every sincos
+// evaluated once instead of twice.
+template <int LPR, int OP, bool PAIR>
+__global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict__ fin,
+                                                        const int4 *__restrict__ vox_sorted,
+                                                        const float *__restrict__ w_pos,
+                                                        const float *__restrict__ alpha,
+                                                        const int32_t *__restrict__ blk_start,
+                                                        const int32_t *__restrict__ hdr, int c, int cg,
+                                                        float coord_div, float *__restrict__ S) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int STEP = PAIR ? 2 : 1;
+  const int li = (threadIdx.x & 63) & (LPR - 1);
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;                       // lanes past C (non power-of-two widths) idle
+  const bool hi = PAIR && (li >= LPR / 2);
+  int b0, b1;
+  group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
+  if (b0 >= b1) return;
+  const int rs = P * c + 4;
+  float w0[4], w1[4], w2[4], al[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int tc = act ? (ch0 + e) % cg : 0;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+  }
+  const int p_end = blk_start[b1];
+  int p = blk_start[b0];
+  int b = b0;
+  int seg_beg = p, seg_end = blk_start[b0 + 1];
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int p_last = p_end - 1;
+  const int cofs = act ? ch0 : 0;
+  // unconditional (clamped) loads so that the compiler can keep them in flight with counted waits:
+  // records two steps ahead, feature rows one step ahead
+  auto ld_rec = [&](int q) { return vox_sorted[(q <= p_last) ? q : p_last]; };
+  auto ld_row = [&](int i) { return *reinterpret_cast<const float4 *>(&fin[(int64_t)i * c + cofs]); };
+  auto flush = [&]() {                            // block finished: one row write, no atomics
+    float *row = S + (int64_t)b * rs;
+    if (act) {
+      *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+      *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    }
+    if (li == 0) row[P * c] = (float)(seg_end - seg_beg);
+#pragma unroll
+    for (int e = 0; e < 4; e++) a0[e] = a1[e] = a2[e] = 0.f;
+    b++;
+    seg_beg = seg_end;
+    seg_end = blk_start[b + 1];
+  };
+  int4 rcA = ld_rec(p), rcB = ld_rec(p + STEP - 1);
+  int4 rnA = ld_rec(p + STEP), rnB = ld_rec(p + 2 * STEP - 1);
+  float4 fcA = ld_row(rcA.w), fcB = ld_row(rcB.w);
+  for (; p < p_end; p += STEP) {
+    const int4 r2A = ld_rec(p + 2 * STEP), r2B = ld_rec(p + 3 * STEP - 1);
+    const float4 fnA = ld_row(rnA.w), fnB = ld_row(rnB.w);
+    const bool hasB = PAIR && (p + 1 < p_end);
+    const int4 own = (hi && hasB) ? rcB : rcA;
+    float x = (float)own.x, y = (float)own.y, z = (float)own.z;
+    if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+    float snA[4], csA[4], snB[4], csB[4], thA[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float th = theta_of(x, y, z, w0[e], w1[e], w2[e], al[e]);
+      float sn, cs;
+      sincos_fast(th, sn, cs);
+      thA[e] = th;
+      if (PAIR) {
+        const float so = partner<LPR>(sn), co = partner<LPR>(cs);
+        const bool swapped = hi && hasB;          // this lane evaluated voxel B
+        snA[e] = swapped ? so : sn; csA[e] = swapped ? co : cs;
+        snB[e] = hi ? sn : so;      csB[e] = hi ? cs : co;
+      } else {
+        snA[e] = sn; csA[e] = cs; snB[e] = sn; csB[e] = cs;
+      }
+    }
+    if (p == seg_end) flush();
+    {
+      const float fv[4] = {fcA.x, fcA.y, fcA.z, fcA.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (OP == LINK_OP_SIN) { a0[e] += fv[e] * snA[e]; a1[e] += fv[e] * csA[e]; }
+        else { a0[e] += fv[e] * csA[e]; a1[e] += fv[e] * snA[e]; }
+        if (OP == LINK_OP_COSX) a2[e] += fv[e] * thA[e];
+      }
+    }
+    if (hasB) {
+      if (p + 1 == seg_end) flush();
+      const float fv[4] = {fcB.x, fcB.y, fcB.z, fcB.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (OP == LINK_OP_SIN) { a0[e] += fv[e] * snB[e]; a1[e] += fv[e] * csB[e]; }
+        else { a0[e] += fv[e] * csB[e]; a1[e] += fv[e] * snB[e]; }
+      }
+    }
+    rcA = rnA; rcB = rnB; rnA = r2A; rnB = r2B; fcA = fnA; fcB = fnB;
+  }
+  {                                               // last block of the chunk
+    float *row = S + (int64_t)b * rs;
+    if (act) {
+      *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+      *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    }
+    if (li == 0) row[P * c] = (float)(seg_end - seg_beg);
+  }
+}
+
+template <int LPR, int OP, int R, bool PAIR>
+__global__ void __launch_bounds__(256) k_gather_demod_ln_g(
+    const float *__restrict__ S, const float *__restrict__ fin, const int4 *__restrict__ vox_sorted,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
+    const float *__restrict__ ln_b, const int32_t *__restrict__ blk_start,
+    const int4 *__restrict__ blk_coords, const int32_t *__restrict__ cell_blk, link_grid_t g,
+    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int G = 64 / LPR;
+  constexpr int R2 = R * R, R3 = R2 * R;
+  constexpr int ZLO = -((R + 1) / 2) + 1;
+  constexpr int SUB = 8;                           // blocks per pass whose neighbour ids sit in LDS
+  constexpr int STEP = PAIR ? 2 : 1;
+  __shared__ int32_t s_nb[4 * G][SUB * R3];
+  __shared__ int32_t s_bs[4 * G][SUB + 1];
+  __shared__ int4 s_bc[4 * G][SUB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1), grp = wave * G + lane / LPR;
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const bool hi = PAIR && (li >= LPR / 2);
+  const int cofs = act ? ch0 : 0;
+  int b0, b1;
+  group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
+  const bool live = b0 < b1;                       // dead groups still take part in wave-level votes
+  const int rs = P * c + 4;
+  float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int ch = act ? ch0 + e : 0;
+    int tc = ch % cg;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
+  }
+  float col[R][P][4], cden[R];
+#pragma unroll
+  for (int d = 0; d < R; d++) {
+    cden[d] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < P; pp++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) col[d][pp][e] = 0.f;
+  }
+  int px = 0, py = 0, pw = 0, pz = 0;
+  bool have = false;
+  int32_t *my_nb = s_nb[grp];
+  int32_t *my_bs = s_bs[grp];
+  int4 *my_bc = s_bc[grp];
+  const float inv_c = 1.0f / (float)c;
+  const int nblk = live ? b1 - b0 : 0;
+  const int npass = (nblk + SUB - 1) / SUB;
+  int wave_pass = npass;                           // wave-uniform trip count (max over its groups)
+#pragma unroll
+  for (int o = 32; o >= LPR; o >>= 1) wave_pass = max(wave_pass, __shfl_xor(wave_pass, o, 64));
+
+  for (int ps = 0; ps < wave_pass; ps++) {
+    const int bb = b0 + ps * SUB;
+    int nbk = live ? (b1 - bb) : 0;
+    nbk = nbk < 0 ? 0 : (nbk > SUB ? SUB : nbk);
+    // ---- pass prologue: ONE round trip for block coords, segment bounds and all neighbour ids
+    for (int e = li; e < nbk; e += LPR) my_bc[e] = blk_coords[bb + e];
+    for (int e = li; e <= nbk && nbk > 0; e += LPR) my_bs[e] = blk_start[bb + e];
+    for (int e = li; e < nbk * R3; e += LPR) {
+      const int j = e / R3, k = e - j * R3;
+      const int d = k / R2, t = k - d * R2;
+      int ox, oy;
+      plane_offset<R>(t, ox, oy);
+      const int4 bc = blk_coords[bb + j];           // L1/L2 hit (same lines as above)
+      const int32_t cell = cell_of(g, bc.x + ox, bc.y + oy, bc.z + ZLO + d, bc.w);
+      my_nb[e] = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int j = 0; j < SUB; j++) {
+      const bool on = j < nbk;                      // this group still has a block in this pass
+      if (!__any(on)) break;
+      const int jj = on ? j : 0;
+      const int4 bc = on ? my_bc[jj] : make_int4(0, 0, 0, 0);
+      const int st = on ? my_bs[jj] : 0, en = on ? my_bs[jj + 1] : 0;
+      int keep = 0;
+      if (on && have && bc.x == px && bc.y == py && bc.w == pw) {
+        int dz = bc.z - pz;
+        if (dz > 0 && dz < R) keep = R - dz;
+      }
+      const int shift = R - keep;
+#pragma unroll
+      for (int d = 0; d < R; d++) {
+#pragma unroll
+        for (int sft = 1; sft < R; sft++) {
+          const bool mv = on && shift == sft && d + sft < R;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) col[d][pp][e] = mv ? col[(d + sft < R) ? d + sft : d][pp][e] : col[d][pp][e];
+          cden[d] = mv ? cden[(d + sft < R) ? d + sft : d] : cden[d];
+        }
+      }
+      // ---- missing planes, ONE plane body per iteration; each group works on ITS next missing plane
+      int dcur = on ? keep : R;
+      while (__any(dcur < R)) {
+        const bool doit = dcur < R;
+        const int d = doit ? dcur : R - 1;
+        float acc[P][4], den = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[pp][e] = 0.f;
+        float4 v[R2][P];
+        float vd[R2];
+        int32_t nbv[R2];
+#pragma unroll
+        for (int t = 0; t < R2; t++) nbv[t] = doit ? my_nb[(jj * R + d) * R2 + t] : -1;
+#pragma unroll
+        for (int t = 0; t < R2; t++) {              // all row loads of the plane issued back to back
+          const float *row = S + (int64_t)((nbv[t] >= 0) ? nbv[t] : 0) * rs;
+          vd[t] = row[P * c];
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * c + cofs]);
+        }
+#pragma unroll
+        for (int t = 0; t < R2; t++) {
+          const bool okt = nbv[t] >= 0;
+          den += okt ? vd[t] : 0.f;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            acc[pp][0] += okt ? v[t][pp].x : 0.f; acc[pp][1] += okt ? v[t][pp].y : 0.f;
+            acc[pp][2] += okt ? v[t][pp].z : 0.f; acc[pp][3] += okt ? v[t][pp].w : 0.f;
+          }
+        }
+#pragma unroll
+        for (int dd = 0; dd < R; dd++) {
+          const bool put = doit && dd == d;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) col[dd][pp][e] = put ? acc[pp][e] : col[dd][pp][e];
+          cden[dd] = put ? den : cden[dd];
+        }
+        dcur++;
+      }
+      if (on) { have = true; px = bc.x; py = bc.y; pw = bc.w; pz = bc.z; }
+      float A[P][4], den = cden[0];
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) A[pp][e] = col[0][pp][e];
+#pragma unroll
+      for (int d = 1; d < R; d++) {
+        den += cden[d];
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) A[pp][e] += col[d][pp][e];
+      }
+      const float rden = on ? den : 1.0f;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) A[pp][e] = A[pp][e] / rden;          // utils.py:80
+
+      // ---- voxels of the block, STEP at a time
+      const int p_last = (en > st) ? en - 1 : st;
+      auto ld_rec = [&](int q) { return vox_sorted[(q <= p_last) ? q : p_last]; };
+      int4 rcA = ld_rec(st), rcB = ld_rec(st + STEP - 1);
+      for (int p = st; __any(p < en); p += STEP) {
+        const bool vok = p < en;
+        const int4 rnA = ld_rec(p + STEP), rnB = ld_rec(p + 2 * STEP - 1);
+        const bool hasB = PAIR && (p + 1 < en);
+        const int4 own = (hi && hasB) ? rcB : rcA;
+        float x = (float)own.x, y = (float)own.y, z = (float)own.z;
+        if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+        float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (OP == LINK_OP_COSX) f4 = *reinterpret_cast<const float4 *>(&fin[(int64_t)rcA.w * c + cofs]);
+        const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+        float nvA[4], nvB[4];
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float th = theta_of(x, y, z, w0[e], w1[e], w2[e], al[e]);
+          float sn, cs;
+          sincos_fast(th, sn, cs);
+          float snA_ = sn, csA_ = cs, snB_ = sn, csB_ = cs;
+          if (PAIR) {
+            const float so = partner<LPR>(sn), co = partner<LPR>(cs);
+            const bool swapped = hi && hasB;
+            snA_ = swapped ? so : sn; csA_ = swapped ? co : cs;
+            snB_ = hi ? sn : so;      csB_ = hi ? cs : co;
+          }
+          float va, vb;
+          if (OP == LINK_OP_SIN) {                                            // linkunet.py:148
+            va = __fsub_rn(__fmul_rn(A[0][e], csA_), __fmul_rn(A[1][e], snA_));
+            vb = __fsub_rn(__fmul_rn(A[0][e], csB_), __fmul_rn(A[1][e], snB_));
+          } else {                                                            // :162
+            va = __fadd_rn(__fmul_rn(A[0][e], csA_), __fmul_rn(A[1][e], snA_));
+            vb = __fadd_rn(__fmul_rn(A[0][e], csB_), __fmul_rn(A[1][e], snB_));
+          }
+          if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A[P - 1][e], __fmul_rn(fv[e], th)));   // :176
+          nvA[e] = act ? va : 0.f; nvB[e] = act ? vb : 0.f;
+          sA += nvA[e]; sB += nvB[e];
+        }
+        sA = grp_sum<LPR>(sA);
+        if (PAIR) sB = grp_sum<LPR>(sB);
+        const float meanA = sA * inv_c, meanB = sB * inv_c;
+        float qA = 0.f, qB = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float dA = act ? nvA[e] - meanA : 0.f, dB = act ? nvB[e] - meanB : 0.f;
+          qA += dA * dA; qB += dB * dB;
+        }
+        qA = grp_sum<LPR>(qA);
+        if (PAIR) qB = grp_sum<LPR>(qB);
+        const float rsA = 1.0f / sqrtf(qA * inv_c + eps), rsB = 1.0f / sqrtf(qB * inv_c + eps);
+        if (act && vok) {
+          float4 o;
+          o.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0];
+          o.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
+          o.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2];
+          o.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
+          *reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]) = o;
+        }
+        if (PAIR && act && hasB) {
+          float4 o;
+          o.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0];
+          o.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
+          o.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2];
+          o.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
+          *reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]) = o;
+        }
+        rcA = rnA; rcB = rnB;
+      }
+    }
+  }
+}
+
+static inline int lanes_per_row(int c) {
+  int need = (c + 3) / 4, l = 1;
+  while (l < need) l <<= 1;
+  return l;
+}
+
+template <int LPR>
+static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
+                            const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
+                            float div, float *S) {
+  dim3 grid(g_modsum_wgs), block(256);
+  const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && op != LINK_OP_COSX;
+  if (op == LINK_OP_COS && pair)
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+  else if (op == LINK_OP_SIN && pair)
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+  else if (op == LINK_OP_COS)
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+  else if (op == LINK_OP_SIN)
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+  else
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+}
+
+template <int LPR, int OP>
+static void launch_gdl_g_r(int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+                           const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                           const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
+                           const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
+  dim3 grid(g_gather_wgs), block(256);
+  const bool pair = g_use_pair && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && OP != LINK_OP_COSX;
+#define LINK_GDLG(RR, PP)                                                                                     \
+  hipLaunchKernelGGL((k_gather_demod_ln_g<LPR, OP, RR, PP>), grid, block, 0, st, S_, fin, vox, w_pos, alpha,  \
+                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+  if (pair && OP != LINK_OP_COSX) {
+    switch (r) {
+      case 1: LINK_GDLG(1, (OP != LINK_OP_COSX)); break;
+      case 2: LINK_GDLG(2, (OP != LINK_OP_COSX)); break;
+      default: LINK_GDLG(3, (OP != LINK_OP_COSX)); break;
+    }
+  } else {
+    switch (r) {
+      case 1: LINK_GDLG(1, false); break;
+      case 2: LINK_GDLG(2, false); break;
+      default: LINK_GDLG(3, false); break;
+    }
+  }
+#undef LINK_GDLG
+}
+
+template <int LPR>
+static void launch_gdl_g(int op, int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+                         const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                         const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
+                         const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
+  if (op == LINK_OP_COS)
+    launch_gdl_g_r<LPR, LINK_OP_COS>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+  else if (op == LINK_OP_SIN)
+    launch_gdl_g_r<LPR, LINK_OP_SIN>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+  else
+    launch_gdl_g_r<LPR, LINK_OP_COSX>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+}
+
+static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
+                              const float *w_pos, const float *alpha, const int32_t *blk_start,
+                              const int32_t *hdr, float *S_) {
+  if (!g_use_group_path || (d->c & 3) != 0) return false;
+  switch (lanes_per_row(d->c)) {
+    case 1: case 2: case 4: launch_modsum_g<4>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+    case 8: launch_modsum_g<8>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+    case 16: launch_modsum_g<16>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+    case 32: launch_modsum_g<32>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+    default: launch_modsum_g<64>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+  }
+  return true;
+}
+
+static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const float *S_, const float *fin,
+                              const int4 *vox, const float *w_pos, const float *alpha, const float *ln_w,
+                              const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
+                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out) {
+  if (!g_use_group_path || (d->c & 3) != 0 || d->r > 3) return false;
+  switch (lanes_per_row(d->c)) {
+    case 1: case 2: case 4: launch_gdl_g<4>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 8: launch_gdl_g<8>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 16: launch_gdl_g<16>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 32: launch_gdl_g<32>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    default: launch_gdl_g<64>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -461,16 +1271,16 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
   int rc;
   if (build_index) {
     rc = link_index_build(b->coords, n, grid, b->cell_counts, b->scratch, b->scratch_bytes, b->cell_blk,
-                          b->vox_blk, b->idx_query, b->perm, b->blk_start, b->blk_coords, b->counts, b->hdr,
-                          stream);
+                          b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->blk_start, b->blk_coords,
+                          b->counts, b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
   rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
   if (rc != LINK_OK) return rc;
-  rc = link_modulate_block_sum(b->fin, b->coords, b->w_pos, b->alpha, b->perm, b->blk_start, b->hdr, desc, n,
+  rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
   if (rc != LINK_OK) return rc;
-  return link_gather_demod_ln(b->S, b->fin, b->coords, b->w_pos, b->alpha, b->ln_w, b->ln_b, b->perm,
+  return link_gather_demod_ln(b->S, b->fin, b->vox_sorted, b->w_pos, b->alpha, b->ln_w, b->ln_b,
                               b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, b->out,
                               stream);
 }

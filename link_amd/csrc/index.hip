@@ -307,7 +307,9 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
                                                   const int32_t *__restrict__ vox_blk,
                                                   const int32_t *__restrict__ blk_start,
                                                   const int32_t *__restrict__ hdr, int64_t n,
-                                                  int32_t *__restrict__ perm) {
+                                                  const int4 *__restrict__ coords,
+                                                  int32_t *__restrict__ perm,
+                                                  int4 *__restrict__ vox_sorted) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || p >= hdr[LINK_HDR_NVALID]) return;
   int32_t i = perm_tmp[p];
@@ -321,13 +323,17 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
     dst = st + r;
   }
   perm[dst] = i;
+  if (vox_sorted) {
+    int4 c = coords[i];
+    vox_sorted[dst] = make_int4(c.x, c.y, c.z, i);
+  }
 }
 
 extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid,
                                 uint32_t *cell_counts, void *scratch, size_t scratch_bytes,
                                 int32_t *cell_blk, int32_t *vox_blk, int64_t *idx_query, int32_t *perm,
-                                int32_t *blk_start, int32_t *blk_coords, int32_t *counts, int32_t *hdr,
-                                void *stream) {
+                                int32_t *vox_sorted, int32_t *blk_start, int32_t *blk_coords,
+                                int32_t *counts, int32_t *hdr, void *stream) {
   if (n < 0 || n >= (1LL << 31) || !grid || !hdr) return LINK_ERR_ARG;
   int64_t v = 1;
   for (int a = 0; a < 4; a++) {
@@ -353,7 +359,8 @@ extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_gri
     hipLaunchKernelGGL(k_place, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.vox_cell, sc.vox_rank, n,
                        cell_blk, blk_start, sc.perm_tmp, vox_blk, idx_query, hdr);
     hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, vox_blk,
-                       blk_start, hdr, n, perm);
+                       blk_start, hdr, n, reinterpret_cast<const int4 *>(coords), perm,
+                       reinterpret_cast<int4 *>(vox_sorted));
   }
   return check_launch("link_index_build");
 }

@@ -74,13 +74,13 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     al = alpha.contiguous().float().view(-1) if alpha is not None else None
     L.check(lib.link_premix_ln(feats.data_ptr(), w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(),
                                pre_ln_b.data_ptr(), n, c, float(eps), fin.data_ptr(), st), "link_premix_ln")
-    L.check(lib.link_modulate_block_sum(fin.data_ptr(), coords.data_ptr(), w_pos.data_ptr(),
-                                        al.data_ptr() if al is not None else None, index.perm.data_ptr(),
+    L.check(lib.link_modulate_block_sum(fin.data_ptr(), index.vox_sorted.data_ptr(), w_pos.data_ptr(),
+                                        al.data_ptr() if al is not None else None,
                                         index.blk_start.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc),
                                         n, m_cap, S.data_ptr(), st), "link_modulate_block_sum")
-    L.check(lib.link_gather_demod_ln(S.data_ptr(), fin.data_ptr(), coords.data_ptr(), w_pos.data_ptr(),
+    L.check(lib.link_gather_demod_ln(S.data_ptr(), fin.data_ptr(), index.vox_sorted.data_ptr(), w_pos.data_ptr(),
                                      al.data_ptr() if al is not None else None, ln_w.data_ptr(),
-                                     ln_b.data_ptr(), index.perm.data_ptr(), index.blk_start.data_ptr(),
+                                     ln_b.data_ptr(), index.blk_start.data_ptr(),
                                      index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
                                      ctypes.byref(index.grid), index.hdr.data_ptr(), ctypes.byref(desc), n,
                                      m_cap, out.data_ptr(), st), "link_gather_demod_ln")
@@ -110,6 +110,7 @@ class ElkCorePlan:
         self.vox_blk = torch.empty(n_cap, **i32)
         self.idx_query = torch.empty(n_cap, dtype=torch.int64, device=device)
         self.perm = torch.empty(n_cap, **i32)
+        self.vox_sorted = torch.empty((n_cap, 4), **i32)
         self.blk_start = torch.empty(n_cap + 1, **i32)
         self.blk_coords = torch.empty((n_cap, 4), **i32)
         self.counts = torch.empty(n_cap, **i32)
@@ -121,6 +122,7 @@ class ElkCorePlan:
         b.cell_counts, b.scratch, b.scratch_bytes = self.cell_counts.data_ptr(), self.scratch.data_ptr(), nbytes
         b.cell_blk, b.vox_blk, b.idx_query = self.cell_blk.data_ptr(), self.vox_blk.data_ptr(), self.idx_query.data_ptr()
         b.perm, b.blk_start, b.blk_coords = self.perm.data_ptr(), self.blk_start.data_ptr(), self.blk_coords.data_ptr()
+        b.vox_sorted = self.vox_sorted.data_ptr()
         b.counts, b.hdr = self.counts.data_ptr(), self.hdr.data_ptr()
         b.fin, b.S, b.out = self.fin.data_ptr(), self.S.data_ptr(), self.out.data_ptr()
         self._fn = L.lib().link_elk_core_forward

@@ -9,6 +9,7 @@ optional read-back of M when a caller needs exactly-sized tensors (`.M`).
 HBM layout (all int32 unless noted, N = voxels, V = cells of the dense block grid, M <= N blocks):
   cell_blk[V]  block id + 1 per cell (0 = empty)      vox_blk[N]      block of each voxel
   idx_query[N] int64 copy (reference dtype)           perm[N]         voxel ids grouped by block
+  vox_sorted[N,4] (x,y,z,voxel id) in perm order: the stream the fused kernels read
   blk_start[N+1] segment starts                       blk_coords[N,4] rows [0,M) valid
   counts[N]    rows [0,M) valid                       hdr[8]          M, status, nvalid
 """
@@ -102,6 +103,7 @@ class BlockIndex:
         self.vox_blk = torch.empty(n, **i32)
         self.idx_query = torch.empty(n, dtype=torch.int64, device=dev) if want_idx64 else None
         self.perm = torch.empty(n, **i32)
+        self.vox_sorted = torch.empty((max(n, 1), 4), **i32)
         self.blk_start = torch.empty(n + 1, **i32)
         self.blk_coords = torch.empty((max(n, 1), 4), **i32)
         self.counts_buf = torch.empty(max(n, 1), **i32)
@@ -111,7 +113,7 @@ class BlockIndex:
         L.check(L.lib().link_index_build(
             self.coords.data_ptr(), n, ctypes.byref(self.grid), cell_counts.data_ptr(), scratch.data_ptr(),
             scratch.numel(), self.cell_blk.data_ptr(), self.vox_blk.data_ptr(),
-            self.idx_query.data_ptr() if want_idx64 else None, self.perm.data_ptr(),
+            self.idx_query.data_ptr() if want_idx64 else None, self.perm.data_ptr(), self.vox_sorted.data_ptr(),
             self.blk_start.data_ptr(), self.blk_coords.data_ptr(), self.counts_buf.data_ptr(),
             self.hdr.data_ptr(), torch.cuda.current_stream().cuda_stream), "link_index_build")
 
