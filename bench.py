@@ -113,15 +113,15 @@ def main():
         step(False)
     elapsed_warm = timed(args.steps, build_index=False)
 
-    # ---- max over ranks + the trivial result gather (per-frame summaries only)
+    # ---- max over ranks + the trivial result gather (per-frame summaries only; link_amd/parallel.py)
     if world > 1:
-        mine = torch.tensor([float(N), float(M), checksum, elapsed, elapsed_warm], dtype=torch.float64, device=dev)
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rows = torch.stack(allr).cpu()
-        elapsed = float(rows[:, 3].max())
-        elapsed_warm = float(rows[:, 4].max())
-        total_vox = float(rows[:, 0].sum())
+        from link_amd.parallel import gather_frame_rows
+        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm]],
+                            dtype=torch.float64, device=dev)
+        rows = gather_frame_rows(mine).cpu()
+        elapsed = float(rows[:, 4].max())
+        elapsed_warm = float(rows[:, 5].max())
+        total_vox = float(rows[:, 1].sum())
     else:
         total_vox = float(N)
 
