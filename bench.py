@@ -45,7 +45,8 @@ def alg_bytes(n, m, c, parts=2):
     return {"total": n * 16 + 2 * n * 4 * c + 2 * table,
             "premix_ln": n * 4 * c,
             "modulate_block_sum": n * 16 + table,
-            "gather_demod_ln": table + n * 4 * c}
+            "block_gather": table,
+            "voxel_demod_ln": n * 4 * c}
 
 
 def main():
@@ -139,13 +140,15 @@ def main():
     stages = {
         "index_build(4 kernels)": lambda: lib.link_index_build(
             coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch, b.scratch_bytes, b.cell_blk,
-            b.vox_blk, b.idx_query, b.perm, b.vox_sorted, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
+            b.vox_blk, b.idx_query, b.perm, b.vox_sorted, b.pos_blk, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
         "premix_ln": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
         "modulate_block_sum": lambda: lib.link_modulate_block_sum(
             b.fin, b.vox_sorted, b.w_pos, b.alpha, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
-        "gather_demod_ln": lambda: lib.link_gather_demod_ln(
-            b.S, b.fin, b.vox_sorted, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.blk_start, b.blk_coords,
-            b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, N, b.out, st),
+        "block_gather": lambda: lib.link_block_gather(
+            b.S, b.blk_coords, b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, b.A, st),
+        "voxel_demod_ln": lambda: lib.link_voxel_demod_ln(
+            b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.hdr, ctypes.byref(desc),
+            N, b.out, st),
     }
     k_inst = min(args.steps, 100)
     evs = {name: [] for name in stages}

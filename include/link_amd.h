@@ -138,6 +138,7 @@ size_t link_index_scratch_bytes(int64_t n, int64_t v);
  *   perm       i32[N]    voxel ids grouped by block, ascending voxel id inside a block
  *   vox_sorted i32[N,4]  (x, y, z, voxel id) of the voxel at each position of perm: the record the
  *                        fused kernels stream instead of chasing perm -> coords (may be NULL)
+ *   pos_blk    i32[N]    block id of the voxel at each position of perm (may be NULL)
  *   blk_start  i32[N+1]  start of each block's segment in perm; blk_start[M] = N
  *   blk_coords i32[N,4]  block coordinates, rows [0,M) valid         (== small_x.C, utils.py:47)
  *   counts     i32[N]    voxels per block, rows [0,M) valid          (== spcount, utils.py:51)
@@ -146,8 +147,8 @@ size_t link_index_scratch_bytes(int64_t n, int64_t v);
 int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /* host */,
                      uint32_t *cell_counts, void *scratch, size_t scratch_bytes, int32_t *cell_blk,
                      int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *vox_sorted,
-                     int32_t *blk_start, int32_t *blk_coords, int32_t *counts, int32_t *hdr,
-                     void *stream);
+                     int32_t *pos_blk, int32_t *blk_start, int32_t *blk_coords, int32_t *counts,
+                     int32_t *hdr, void *stream);
 
 /* Neighbour map nbr i32[M,K] (K = r^3, offsets in get_kernel_offsets(r) order, nn/utils/kernel.py:
  * 11-32: odd r x fastest, even r z fastest): replaces sphash(C, offsets) + sphash + sphashquery +
@@ -218,9 +219,11 @@ int link_premix_ln(const float *feats, const float *w_pre, const float *ln_w, co
 /* Modulate + per-block pre-aggregation (linkunet.py:151-160 + utils.py:52,75-76 fused):
  *   theta = (float(xyz)/coord_div) @ Wpos^T (* alpha), tiled by cg;
  *   S[b] = [ sum_i fin_i*cos(theta_i), sum_i fin_i*sin(theta_i) (, sum_i fin_i*theta_i), count_b ]
- * over the voxels of block b in ascending voxel id.  S fp[M_cap, nparts*C + 1] (block SUMS, not
- * means: mean*count of the reference re-multiplies what it just divided).  w_pos fp[cg,3]; alpha
- * fp[cg] or NULL. */
+ * over the voxels of block b in ascending voxel id.  Block SUMS, not means (mean*count of the
+ * reference re-multiplies what it just divided).  S layout: m_cap rows of nparts*C floats (row =
+ * 512 B at C=64: four aligned 128-B lines), followed by the m_cap counts (fp32) at
+ * S + m_cap*nparts*C, i.e. S has m_cap*(nparts*C + 1) floats.  The SAME m_cap must be passed to every
+ * call that touches S.  w_pos fp[cg,3]; alpha fp[cg] or NULL. */
 int link_modulate_block_sum(const float *fin, const int32_t *vox_sorted, const float *w_pos,
                             const float *alpha, const int32_t *blk_start,
                             const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
@@ -239,6 +242,18 @@ int link_gather_demod_ln(const float *S, const float *fin, const int32_t *vox_so
                          const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
                          int64_t m_cap, float *out, void *stream);
 
+/* Split form of link_gather_demod_ln (same result, two simpler kernels; C % 4 == 0, r <= 3):
+ *   link_block_gather   A[m] = (sum of the r^3 neighbour rows of S) / (summed count)  -> fp[M, P*C]
+ *   link_voxel_demod_ln per voxel (loop-free, one 16-byte-per-lane group per voxel pair): read the
+ *                       block's A row, de-modulate, LayerNorm, store out[voxel]. */
+int link_block_gather(const float *S, const int32_t *blk_coords, const int32_t *cell_blk,
+                      const link_grid_t *grid /* host */, const int32_t *hdr,
+                      const link_elk_desc_t *desc /* host */, int64_t m_cap, float *A, void *stream);
+int link_voxel_demod_ln(const float *A, const float *fin, const int32_t *vox_sorted,
+                        const int32_t *pos_blk, const float *w_pos, const float *alpha, const float *ln_w,
+                        const float *ln_b, const int32_t *hdr, const link_elk_desc_t *desc /* host */,
+                        int64_t n, float *out, void *stream);
+
 /* One-call form of the whole R_core step (what bench.py times): optional index build (section B)
  * followed by the three section-C kernels, all on `stream`, from caller-owned buffers.  Exists so
  * that a host written in an interpreted language pays ONE FFI crossing per LinK block instead of one
@@ -250,9 +265,10 @@ typedef struct {
   const float *w_pos, *alpha;                 /* pos_weight.0.weight [cg,3]; alpha [cg] or NULL */
   const float *ln_w, *ln_b;                   /* norm.{weight,bias} [C] */
   uint32_t *cell_counts; void *scratch; size_t scratch_bytes;          /* link_index_build scratch */
-  int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *vox_sorted, *blk_start, *blk_coords, *counts, *hdr;
+  int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *vox_sorted, *pos_blk, *blk_start, *blk_coords, *counts, *hdr;
   float *fin;                /* fp[N,C]            scratch: pre_mix output */
-  float *S;                  /* fp[m_cap, P*C+4]   scratch: block table */
+  float *S;                  /* fp[m_cap*(P*C+1)]  scratch: block table rows + counts */
+  float *A;                  /* fp[m_cap, P*C]     scratch: normalised neighbour sums (NULL: fused gather) */
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
 } link_elk_buffers_t;
 

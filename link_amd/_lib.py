@@ -45,8 +45,8 @@ class LinkElkBuffers(Structure):
     _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha",
                                         "ln_w", "ln_b", "cell_counts", "scratch")] + \
                [("scratch_bytes", c_size_t)] + \
-               [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "blk_start", "blk_coords",
-                                        "counts", "hdr", "fin", "S", "out")]
+               [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "pos_blk", "blk_start",
+                                        "blk_coords", "counts", "hdr", "fin", "S", "A", "out")]
 
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
@@ -71,7 +71,11 @@ SIGNATURES = {
     "link_index_scratch_bytes": (c_size_t, [c_int64, c_int64]),
     "link_index_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_size_t,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_block_gather": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LinkGrid), c_void_p,
+                                  POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p]),
+    "link_voxel_demod_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p]),
     "link_neighbor_map": (c_int, [c_void_p, c_void_p, POINTER(LinkGrid), c_void_p, c_int64, c_int32,
                                   c_int32, c_int32, c_void_p, c_void_p]),
     "link_cell_table_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_void_p]),

@@ -14,7 +14,11 @@
 //                      0..K-1, broadcast with readlane, rows summed in get_kernel_offsets order),
 //                      normalise, then per voxel of the block: de-modulate + LayerNorm + store.
 //
-// S row layout: [part0 C | part1 C | (part2 C) | count, 3 pad] fp32 -> row stride P*C+4 (16-B rows).
+// S layout: m_cap rows [part0 C | part1 C | (part2 C)] fp32 (row = P*C floats: 512 B at C=64, i.e.
+// exactly 4 aligned 128-B lines -- the gather is bound by L2->L1 line requests), followed by the
+// m_cap per-block counts (fp32) at S + m_cap*P*C.
+#include <limits.h>
+
 #include "common.h"
 
 using namespace link;
@@ -356,13 +360,15 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
                                                       const float *__restrict__ alpha,
                                                       const int32_t *__restrict__ blk_start,
                                                       const int32_t *__restrict__ hdr, int c, int cg,
-                                                      float coord_div, float *__restrict__ S) {
+                                                      float coord_div, float *__restrict__ S,
+                                                      int64_t m_cap) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   const int lane = threadIdx.x & 63;
   int b0, b1;
   wave_chunk(hdr[LINK_HDR_M], b0, b1);
   if (b0 >= b1) return;
-  const int rs = P * c + 4;
+  const int rs = P * c;
+  float *__restrict__ Scnt = S + m_cap * rs;
   float w0[CPL], w1[CPL], w2[CPL], al[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
             a0[q] = a1[q] = a2[q] = 0.f;
           }
           const int seg_beg = __shfl(bs_l, j, 64);          // all lanes participate in the shuffle
-          if (lane == 0) row[P * c] = (float)(seg_end - seg_beg);
+          if (lane == 0) Scnt[bb + j] = (float)(seg_end - seg_beg);
           j++;
           seg_end = __shfl(bs_l, j + 1, 64);
         }
@@ -434,7 +440,7 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
         a0[q] = a1[q] = a2[q] = 0.f;
       }
       const int seg_len = __shfl(bs_l, j + 1, 64) - __shfl(bs_l, j, 64);
-      if (lane == 0) row[P * c] = (float)seg_len;
+      if (lane == 0) Scnt[bb + j] = (float)seg_len;
       j++;
     }
   }
@@ -447,6 +453,8 @@ static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one 
 static int g_premix_wgs = 512;
 static int g_use_group_path = 1;
 static int g_use_pair = 1;
+static int g_bgather_wgs = 1024;
+static int g_use_split = 1;
 extern "C" int link_set_tuning(int key, int value) {
   if (value <= 0) return LINK_ERR_ARG;
   switch (key) {
@@ -455,6 +463,8 @@ extern "C" int link_set_tuning(int key, int value) {
     case 2: g_premix_wgs = value; return LINK_OK;
     case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
     case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
+    case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
+    case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
     default: return LINK_ERR_ARG;
   }
 }
@@ -462,23 +472,24 @@ extern "C" int link_set_tuning(int key, int value) {
 template <int CPL>
 static void launch_modsum(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
                           const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
-                          float div, float *S) {
+                          float div, float *S, int64_t m_cap) {
   dim3 grid(g_modsum_wgs), block(256);
   if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COS>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COS>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_SIN>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_SIN>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else
-    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COSX>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum<CPL, LINK_OP_COSX>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
 }
 
 static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
                               const float *w_pos, const float *alpha, const int32_t *blk_start,
-                              const int32_t *hdr, float *S_);
+                              const int32_t *hdr, float *S_, int64_t m_cap);
 static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const float *S_, const float *fin,
                               const int4 *vox, const float *w_pos, const float *alpha, const float *ln_w,
                               const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
-                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out);
+                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out,
+                              int64_t m_cap);
 static int check_desc(const link_elk_desc_t *d) {
   if (!d) return LINK_ERR_ARG;
   if (d->op < 0 || d->op > 2 || d->c <= 0 || d->c > 256 || d->cg <= 0 || d->cg > d->c) return LINK_ERR_ARG;
@@ -496,12 +507,12 @@ extern "C" int link_modulate_block_sum(const float *fin, const int32_t *vox_sort
   const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
   int cpl = (desc->c + 63) / 64;
   hipStream_t st = S(stream);
-  if (modsum_group_path(desc, st, fin, v4, w_pos, alpha, blk_start, hdr, S_)) return check_launch("link_modulate_block_sum");
+  if (modsum_group_path(desc, st, fin, v4, w_pos, alpha, blk_start, hdr, S_, m_cap)) return check_launch("link_modulate_block_sum");
   switch (cpl) {
-    case 1: launch_modsum<1>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    case 2: launch_modsum<2>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    case 3: launch_modsum<3>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
-    default: launch_modsum<4>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_); break;
+    case 1: launch_modsum<1>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_, m_cap); break;
+    case 2: launch_modsum<2>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_, m_cap); break;
+    case 3: launch_modsum<3>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_, m_cap); break;
+    default: launch_modsum<4>(desc->op, st, fin, v4, w_pos, alpha, blk_start, hdr, desc->c, desc->cg, desc->coord_div, S_, m_cap); break;
   }
   return check_launch("link_modulate_block_sum");
 }
@@ -529,7 +540,8 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const int32_t *__restrict__ blk_start,
     const int4 *__restrict__ blk_coords, const int32_t *__restrict__ cell_blk, link_grid_t g,
-    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out) {
+    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out,
+    int64_t m_cap) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int R2 = R * R, R3 = R2 * R;
   constexpr int ZLO = -((R + 1) / 2) + 1;
@@ -539,7 +551,8 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
   int b0, b1;
   wave_chunk(hdr[LINK_HDR_M], b0, b1);
   if (b0 >= b1) return;
-  const int rs = P * c + 4;
+  const int rs = P * c;
+  const float *__restrict__ Scnt = S + m_cap * rs;
   float w0[CPL], w1[CPL], w2[CPL], al[CPL], gw[CPL], gb[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
@@ -610,7 +623,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
 #pragma unroll
           for (int t = 0; t < R2; t++) {          // issue all row loads of the plane back to back
             const float *row = S + (int64_t)((nbv[t] >= 0) ? nbv[t] : 0) * rs;
-            vd[t] = row[P * c];
+            vd[t] = Scnt[(nbv[t] >= 0) ? nbv[t] : 0];
 #pragma unroll
             for (int pp = 0; pp < P; pp++)
 #pragma unroll
@@ -713,14 +726,14 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
 }
 
 template <int CPL, int OP>
-static void launch_gdl_r(int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+static void launch_gdl_r(int r, hipStream_t st, int64_t m_cap, const float *S_, const float *fin, const int4 *vox,
                          const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                          const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
                          const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
   dim3 grid(g_gather_wgs), block(256);
 #define LINK_GDL(RR)                                                                                   \
   hipLaunchKernelGGL((k_gather_demod_ln<CPL, OP, RR>), grid, block, 0, st, S_, fin, vox, w_pos, alpha, \
-                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out, m_cap)
   switch (r) {
     case 1: LINK_GDL(1); break;
     case 2: LINK_GDL(2); break;
@@ -732,16 +745,16 @@ static void launch_gdl_r(int r, hipStream_t st, const float *S_, const float *fi
 }
 
 template <int CPL>
-static void launch_gdl(int op, int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+static void launch_gdl(int op, int r, hipStream_t st, int64_t m_cap, const float *S_, const float *fin, const int4 *vox,
                        const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                        const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
                        const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
   if (op == LINK_OP_COS)
-    launch_gdl_r<CPL, LINK_OP_COS>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_r<CPL, LINK_OP_COS>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else if (op == LINK_OP_SIN)
-    launch_gdl_r<CPL, LINK_OP_SIN>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_r<CPL, LINK_OP_SIN>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else
-    launch_gdl_r<CPL, LINK_OP_COSX>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_r<CPL, LINK_OP_COSX>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
 }
 
 extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int32_t *vox_sorted,
@@ -760,13 +773,13 @@ extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   int cpl = (desc->c + 63) / 64;
-  if (gather_group_path(desc, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, out))
+  if (gather_group_path(desc, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, out, m_cap))
     return check_launch("link_gather_demod_ln");
   switch (cpl) {
-    case 1: launch_gdl<1>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    case 2: launch_gdl<2>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    case 3: launch_gdl<3>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
-    default: launch_gdl<4>(desc->op, desc->r, st, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 1: launch_gdl<1>(desc->op, desc->r, st, m_cap, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 2: launch_gdl<2>(desc->op, desc->r, st, m_cap, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    case 3: launch_gdl<3>(desc->op, desc->r, st, m_cap, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
+    default: launch_gdl<4>(desc->op, desc->r, st, m_cap, S_, fin, v4, w_pos, alpha, ln_w, ln_b, blk_start, b4, cell_blk, *grid, hdr, *desc, out); break;
   }
   return check_launch("link_gather_demod_ln");
 }
@@ -831,7 +844,8 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
                                                         const float *__restrict__ alpha,
                                                         const int32_t *__restrict__ blk_start,
                                                         const int32_t *__restrict__ hdr, int c, int cg,
-                                                        float coord_div, float *__restrict__ S) {
+                                                        float coord_div, float *__restrict__ S,
+                                                        int64_t m_cap) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int STEP = PAIR ? 2 : 1;
   const int li = (threadIdx.x & 63) & (LPR - 1);
@@ -841,7 +855,8 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
   int b0, b1;
   group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
   if (b0 >= b1) return;
-  const int rs = P * c + 4;
+  const int rs = P * c;
+  float *__restrict__ Scnt = S + m_cap * rs;
   float w0[4], w1[4], w2[4], al[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -867,7 +882,7 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
       *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
       if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
     }
-    if (li == 0) row[P * c] = (float)(seg_end - seg_beg);
+    if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
 #pragma unroll
     for (int e = 0; e < 4; e++) a0[e] = a1[e] = a2[e] = 0.f;
     b++;
@@ -928,7 +943,7 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
       *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
       if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
     }
-    if (li == 0) row[P * c] = (float)(seg_end - seg_beg);
+    if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
   }
 }
 
@@ -938,7 +953,8 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const int32_t *__restrict__ blk_start,
     const int4 *__restrict__ blk_coords, const int32_t *__restrict__ cell_blk, link_grid_t g,
-    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out) {
+    const int32_t *__restrict__ hdr, int c, int cg, float coord_div, float eps, float *__restrict__ out,
+    int64_t m_cap) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int G = 64 / LPR;
   constexpr int R2 = R * R, R3 = R2 * R;
@@ -957,7 +973,8 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
   int b0, b1;
   group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
   const bool live = b0 < b1;                       // dead groups still take part in wave-level votes
-  const int rs = P * c + 4;
+  const int rs = P * c;
+  const float *__restrict__ Scnt = S + m_cap * rs;
   float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -1050,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
 #pragma unroll
         for (int t = 0; t < R2; t++) {              // all row loads of the plane issued back to back
           const float *row = S + (int64_t)((nbv[t] >= 0) ? nbv[t] : 0) * rs;
-          vd[t] = row[P * c];
+          vd[t] = Scnt[(nbv[t] >= 0) ? nbv[t] : 0];
 #pragma unroll
           for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * c + cofs]);
         }
@@ -1169,6 +1186,271 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split form of the gather: (a) block level -- A[m] = (sum of the r^3 neighbour rows of S) / count,
+// written once per block as a [M, P*C] table; (b) voxel level -- a loop-free streaming kernel, one
+// group per voxel (pair), that reads its block's A row (consecutive voxels share it: L1/L2 hits),
+// de-modulates, LayerNorms and stores.  (b) has no divergence and thousands of independent waves,
+// which is what hides memory latency on this chip; (a) carries only uniform block-level work.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int P, int R>
+__global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict__ S,
+                                                        const int4 *__restrict__ blk_coords,
+                                                        const int32_t *__restrict__ cell_blk, link_grid_t g,
+                                                        const int32_t *__restrict__ hdr, int c,
+                                                        int64_t m_cap, float *__restrict__ A_tab) {
+  constexpr int G = 64 / LPR;
+  constexpr int R2 = R * R, R3 = R2 * R;
+  constexpr int ZLO = -((R + 1) / 2) + 1;
+  constexpr int SUB = 8;
+  __shared__ int32_t s_nb[4 * G][SUB * R3];
+  __shared__ int4 s_bc[4 * G][SUB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1), grp = wave * G + lane / LPR;
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  int b0, b1;
+  group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
+  const bool live = b0 < b1;
+  const int rs = P * c;
+  const float *__restrict__ Scnt = S + m_cap * rs;
+  float col[R][P][4], cden[R];
+  int ph[R];                                       // height held by ring slot (slot = height mod R)
+#pragma unroll
+  for (int d = 0; d < R; d++) {
+    cden[d] = 0.f; ph[d] = INT_MIN;
+#pragma unroll
+    for (int pp = 0; pp < P; pp++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) col[d][pp][e] = 0.f;
+  }
+  int px = INT_MIN, py = 0, pw = 0;
+  int32_t *my_nb = s_nb[grp];
+  int4 *my_bc = s_bc[grp];
+  const int nblk = live ? b1 - b0 : 0;
+  int wave_pass = (nblk + SUB - 1) / SUB;
+#pragma unroll
+  for (int o = 32; o >= LPR; o >>= 1) wave_pass = max(wave_pass, __shfl_xor(wave_pass, o, 64));
+
+  for (int ps = 0; ps < wave_pass; ps++) {
+    const int bb = b0 + ps * SUB;
+    int nbk = live ? (b1 - bb) : 0;
+    nbk = nbk < 0 ? 0 : (nbk > SUB ? SUB : nbk);
+    for (int e = li; e < nbk; e += LPR) my_bc[e] = blk_coords[bb + e];
+    for (int e = li; e < nbk * R3; e += LPR) {
+      const int j = e / R3, k = e - j * R3;
+      const int d = k / R2, t = k - d * R2;
+      int ox, oy;
+      plane_offset<R>(t, ox, oy);
+      const int4 bc = blk_coords[bb + j];
+      const int32_t cell = cell_of(g, bc.x + ox, bc.y + oy, bc.z + ZLO + d, bc.w);
+      my_nb[e] = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int j = 0; j < SUB; j++) {
+      const bool on = j < nbk;
+      if (!__any(on)) break;
+      const int jj = on ? j : 0;
+      const int4 bc = on ? my_bc[jj] : make_int4(0, 0, 0, 0);
+      const bool same_col = on && bc.x == px && bc.y == py && bc.w == pw;
+      // plane d of this block is height h = z + ZLO + d and lives in ring slot (h mod R)
+      int need_mask = 0;
+#pragma unroll
+      for (int d = 0; d < R; d++) {
+        const int h = bc.z + ZLO + d;
+        const int slot = ((h % R) + R) % R;
+        bool valid = false;
+#pragma unroll
+        for (int sl = 0; sl < R; sl++) valid |= (sl == slot) && same_col && (ph[sl] == h);
+        if (on && !valid) need_mask |= 1 << d;
+      }
+      while (__any(need_mask != 0)) {              // ONE plane body per iteration, per-group plane
+        const bool doit = need_mask != 0;
+        const int d = doit ? (__ffs(need_mask) - 1) : 0;
+        const int h = bc.z + ZLO + d;
+        const int slot = ((h % R) + R) % R;
+        float acc[P][4], den = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[pp][e] = 0.f;
+        float4 v[R2][P];
+        float vd[R2];
+        int32_t nbv[R2];
+#pragma unroll
+        for (int t = 0; t < R2; t++) nbv[t] = doit ? my_nb[(jj * R + d) * R2 + t] : -1;
+#pragma unroll
+        for (int t = 0; t < R2; t++) {
+          const int32_t rid = (nbv[t] >= 0) ? nbv[t] : 0;
+          const float *row = S + (int64_t)rid * rs;
+          vd[t] = Scnt[rid];
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * c + cofs]);
+        }
+#pragma unroll
+        for (int t = 0; t < R2; t++) {
+          const bool okt = nbv[t] >= 0;
+          den += okt ? vd[t] : 0.f;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            acc[pp][0] += okt ? v[t][pp].x : 0.f; acc[pp][1] += okt ? v[t][pp].y : 0.f;
+            acc[pp][2] += okt ? v[t][pp].z : 0.f; acc[pp][3] += okt ? v[t][pp].w : 0.f;
+          }
+        }
+#pragma unroll
+        for (int sl = 0; sl < R; sl++) {
+          const bool put = doit && sl == slot;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) col[sl][pp][e] = put ? acc[pp][e] : col[sl][pp][e];
+          cden[sl] = put ? den : cden[sl];
+          ph[sl] = put ? h : ph[sl];
+        }
+        need_mask &= need_mask - 1;
+      }
+      if (on) { px = bc.x; py = bc.y; pw = bc.w; }
+      // sum the planes in ascending height order (slot of height z+ZLO+d), deterministic
+      float Av[P][4], den = 0.f;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) Av[pp][e] = 0.f;
+#pragma unroll
+      for (int d = 0; d < R; d++) {
+        const int h = bc.z + ZLO + d;
+        const int slot = ((h % R) + R) % R;
+#pragma unroll
+        for (int sl = 0; sl < R; sl++) {
+          const bool use = sl == slot;
+          den += use ? cden[sl] : 0.f;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Av[pp][e] += use ? col[sl][pp][e] : 0.f;
+        }
+      }
+      if (on && act) {
+        float *arow = A_tab + (int64_t)(bb + jj) * rs;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+          *reinterpret_cast<float4 *>(&arow[pp * c + ch0]) =
+              make_float4(Av[pp][0] / den, Av[pp][1] / den, Av[pp][2] / den, Av[pp][3] / den);   // utils.py:80
+      }
+    }
+  }
+}
+
+template <int LPR, int OP, bool PAIR>
+__global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
+    const float *__restrict__ A_tab, const float *__restrict__ fin, const int4 *__restrict__ vox_sorted,
+    const int32_t *__restrict__ pos_blk, const float *__restrict__ w_pos, const float *__restrict__ alpha,
+    const float *__restrict__ ln_w, const float *__restrict__ ln_b, const int32_t *__restrict__ hdr, int c,
+    int cg, float coord_div, float eps, float *__restrict__ out) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int G = 64 / LPR;
+  constexpr int STEP = PAIR ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (LPR - 1);
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const bool hi = PAIR && (li >= LPR / 2);
+  const int cofs = act ? ch0 : 0;
+  const int n = hdr[LINK_HDR_NVALID];
+  const int64_t gid = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / LPR;
+  const int64_t p64 = gid * STEP;
+  const bool vok = p64 < n;
+  const int p = vok ? (int)p64 : (n > 0 ? n - 1 : 0);
+  const bool hasB = PAIR && (p64 + 1 < n);
+  const int pB = hasB ? p + 1 : p;
+  const int ra = P * c;
+  // all loads of the step issued up front
+  const int4 rcA = vox_sorted[p], rcB = vox_sorted[pB];
+  const int bA = pos_blk[p], bB = pos_blk[pB];
+  float4 aA[P], aB[P];
+#pragma unroll
+  for (int pp = 0; pp < P; pp++) {
+    aA[pp] = *reinterpret_cast<const float4 *>(&A_tab[(int64_t)bA * ra + pp * c + cofs]);
+    aB[pp] = *reinterpret_cast<const float4 *>(&A_tab[(int64_t)bB * ra + pp * c + cofs]);
+  }
+  float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (OP == LINK_OP_COSX) f4 = *reinterpret_cast<const float4 *>(&fin[(int64_t)rcA.w * c + cofs]);
+  float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int ch = act ? ch0 + e : 0;
+    int tc = ch % cg;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
+  }
+  const int4 own = (hi && hasB) ? rcB : rcA;
+  float x = (float)own.x, y = (float)own.y, z = (float)own.z;
+  if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+  const float inv_c = 1.0f / (float)c;
+  const float A0a[4] = {aA[0].x, aA[0].y, aA[0].z, aA[0].w}, A1a[4] = {aA[1].x, aA[1].y, aA[1].z, aA[1].w};
+  const float A0b[4] = {aB[0].x, aB[0].y, aB[0].z, aB[0].w}, A1b[4] = {aB[1].x, aB[1].y, aB[1].z, aB[1].w};
+  const float A2a[4] = {aA[P - 1].x, aA[P - 1].y, aA[P - 1].z, aA[P - 1].w};
+  const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+  float nvA[4], nvB[4], sA = 0.f, sB = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    float th = theta_of(x, y, z, w0[e], w1[e], w2[e], al[e]);
+    float sn, cs;
+    sincos_fast(th, sn, cs);
+    float snA_ = sn, csA_ = cs, snB_ = sn, csB_ = cs;
+    if (PAIR) {
+      const float so = partner<LPR>(sn), co = partner<LPR>(cs);
+      const bool swapped = hi && hasB;
+      snA_ = swapped ? so : sn; csA_ = swapped ? co : cs;
+      snB_ = hi ? sn : so;      csB_ = hi ? cs : co;
+    }
+    float va, vb;
+    if (OP == LINK_OP_SIN) {                                                 // linkunet.py:148
+      va = __fsub_rn(__fmul_rn(A0a[e], csA_), __fmul_rn(A1a[e], snA_));
+      vb = __fsub_rn(__fmul_rn(A0b[e], csB_), __fmul_rn(A1b[e], snB_));
+    } else {                                                                 // :162
+      va = __fadd_rn(__fmul_rn(A0a[e], csA_), __fmul_rn(A1a[e], snA_));
+      vb = __fadd_rn(__fmul_rn(A0b[e], csB_), __fmul_rn(A1b[e], snB_));
+    }
+    if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A2a[e], __fmul_rn(fv[e], th)));          // :176
+    nvA[e] = act ? va : 0.f; nvB[e] = act ? vb : 0.f;
+    sA += nvA[e]; sB += nvB[e];
+  }
+  sA = grp_sum<LPR>(sA);
+  if (PAIR) sB = grp_sum<LPR>(sB);
+  const float meanA = sA * inv_c, meanB = sB * inv_c;
+  float qA = 0.f, qB = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    float dA = act ? nvA[e] - meanA : 0.f, dB = act ? nvB[e] - meanB : 0.f;
+    qA += dA * dA; qB += dB * dB;
+  }
+  qA = grp_sum<LPR>(qA);
+  if (PAIR) qB = grp_sum<LPR>(qB);
+  const float rsA = 1.0f / sqrtf(qA * inv_c + eps), rsB = 1.0f / sqrtf(qB * inv_c + eps);
+  if (act && vok) {
+    float4 o;
+    o.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0];
+    o.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
+    o.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2];
+    o.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
+    *reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]) = o;
+  }
+  if (PAIR && act && hasB) {
+    float4 o;
+    o.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0];
+    o.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
+    o.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2];
+    o.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
+    *reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]) = o;
+  }
+}
+
 static inline int lanes_per_row(int c) {
   int need = (c + 3) / 4, l = 1;
   while (l < need) l <<= 1;
@@ -1178,23 +1460,23 @@ static inline int lanes_per_row(int c) {
 template <int LPR>
 static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
                             const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
-                            float div, float *S) {
+                            float div, float *S, int64_t m_cap) {
   dim3 grid(g_modsum_wgs), block(256);
   const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && op != LINK_OP_COSX;
   if (op == LINK_OP_COS && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else if (op == LINK_OP_SIN && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
   else
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
 }
 
 template <int LPR, int OP>
-static void launch_gdl_g_r(int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+static void launch_gdl_g_r(int r, hipStream_t st, int64_t m_cap, const float *S_, const float *fin, const int4 *vox,
                            const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                            const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
                            const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
@@ -1202,7 +1484,7 @@ static void launch_gdl_g_r(int r, hipStream_t st, const float *S_, const float *
   const bool pair = g_use_pair && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && OP != LINK_OP_COSX;
 #define LINK_GDLG(RR, PP)                                                                                     \
   hipLaunchKernelGGL((k_gather_demod_ln_g<LPR, OP, RR, PP>), grid, block, 0, st, S_, fin, vox, w_pos, alpha,  \
-                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+                     ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out, m_cap)
   if (pair && OP != LINK_OP_COSX) {
     switch (r) {
       case 1: LINK_GDLG(1, (OP != LINK_OP_COSX)); break;
@@ -1220,28 +1502,102 @@ static void launch_gdl_g_r(int r, hipStream_t st, const float *S_, const float *
 }
 
 template <int LPR>
-static void launch_gdl_g(int op, int r, hipStream_t st, const float *S_, const float *fin, const int4 *vox,
+static void launch_gdl_g(int op, int r, hipStream_t st, int64_t m_cap, const float *S_, const float *fin, const int4 *vox,
                          const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                          const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
                          const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
   if (op == LINK_OP_COS)
-    launch_gdl_g_r<LPR, LINK_OP_COS>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_g_r<LPR, LINK_OP_COS>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else if (op == LINK_OP_SIN)
-    launch_gdl_g_r<LPR, LINK_OP_SIN>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_g_r<LPR, LINK_OP_SIN>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
   else
-    launch_gdl_g_r<LPR, LINK_OP_COSX>(r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+    launch_gdl_g_r<LPR, LINK_OP_COSX>(r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d, out);
+}
+
+template <int LPR, int P>
+static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
+                                const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
+                                int64_t m_cap, float *A) {
+  dim3 grid(g_bgather_wgs), block(256);
+  switch (r) {
+    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
+    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
+    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
+  }
+}
+
+extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
+                                 const link_grid_t *grid, const int32_t *hdr, const link_elk_desc_t *desc,
+                                 int64_t m_cap, float *A, void *stream) {
+  if (check_desc(desc) != LINK_OK || !grid || m_cap < 0 || desc->r > 3 || (desc->c & 3) != 0) return LINK_ERR_ARG;
+  if (m_cap == 0) return LINK_OK;
+  if (!S_ || !blk_coords || !cell_blk || !hdr || !A) return LINK_ERR_ARG;
+  const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
+  hipStream_t st = S(stream);
+  const bool p3 = desc->op == LINK_OP_COSX;
+#define LINK_BG(L)                                                                                  \
+  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A);  \
+  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A)
+  switch (lanes_per_row(desc->c)) {
+    case 1: case 2: case 4: LINK_BG(4); break;
+    case 8: LINK_BG(8); break;
+    case 16: LINK_BG(16); break;
+    case 32: LINK_BG(32); break;
+    default: LINK_BG(64); break;
+  }
+#undef LINK_BG
+  return check_launch("link_block_gather");
+}
+
+template <int LPR>
+static void launch_voxel_demod(const link_elk_desc_t &d, int64_t n, hipStream_t st, const float *A,
+                               const float *fin, const int4 *vox, const int32_t *pos_blk, const float *w_pos,
+                               const float *alpha, const float *ln_w, const float *ln_b, const int32_t *hdr,
+                               float *out) {
+  constexpr int G = 64 / LPR;
+  const bool pair = g_use_pair && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && d.op != LINK_OP_COSX;
+  const int64_t groups = pair ? (n + 1) / 2 : n;
+  const int64_t wgs = (groups + 4 * G - 1) / (4 * G);
+  dim3 grid((unsigned)wgs), block(256);
+#define LINK_VD(OPP, PP)                                                                                  \
+  hipLaunchKernelGGL((k_voxel_demod_ln_g<LPR, OPP, PP>), grid, block, 0, st, A, fin, vox, pos_blk, w_pos,  \
+                     alpha, ln_w, ln_b, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+  if (d.op == LINK_OP_COS) { if (pair) LINK_VD(LINK_OP_COS, true); else LINK_VD(LINK_OP_COS, false); }
+  else if (d.op == LINK_OP_SIN) { if (pair) LINK_VD(LINK_OP_SIN, true); else LINK_VD(LINK_OP_SIN, false); }
+  else LINK_VD(LINK_OP_COSX, false);
+#undef LINK_VD
+}
+
+extern "C" int link_voxel_demod_ln(const float *A, const float *fin, const int32_t *vox_sorted,
+                                   const int32_t *pos_blk, const float *w_pos, const float *alpha,
+                                   const float *ln_w, const float *ln_b, const int32_t *hdr,
+                                   const link_elk_desc_t *desc, int64_t n, float *out, void *stream) {
+  if (check_desc(desc) != LINK_OK || n < 0 || (desc->c & 3) != 0) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!A || !vox_sorted || !pos_blk || !w_pos || !ln_w || !ln_b || !hdr || !out) return LINK_ERR_ARG;
+  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
+  hipStream_t st = S(stream);
+  switch (lanes_per_row(desc->c)) {
+    case 1: case 2: case 4: launch_voxel_demod<4>(*desc, n, st, A, fin, v4, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, out); break;
+    case 8: launch_voxel_demod<8>(*desc, n, st, A, fin, v4, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, out); break;
+    case 16: launch_voxel_demod<16>(*desc, n, st, A, fin, v4, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, out); break;
+    case 32: launch_voxel_demod<32>(*desc, n, st, A, fin, v4, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, out); break;
+    default: launch_voxel_demod<64>(*desc, n, st, A, fin, v4, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, out); break;
+  }
+  return check_launch("link_voxel_demod_ln");
 }
 
 static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
                               const float *w_pos, const float *alpha, const int32_t *blk_start,
-                              const int32_t *hdr, float *S_) {
+                              const int32_t *hdr, float *S_, int64_t m_cap) {
   if (!g_use_group_path || (d->c & 3) != 0) return false;
   switch (lanes_per_row(d->c)) {
-    case 1: case 2: case 4: launch_modsum_g<4>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
-    case 8: launch_modsum_g<8>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
-    case 16: launch_modsum_g<16>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
-    case 32: launch_modsum_g<32>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
-    default: launch_modsum_g<64>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_); break;
+    case 1: case 2: case 4: launch_modsum_g<4>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
+    case 8: launch_modsum_g<8>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
+    case 16: launch_modsum_g<16>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
+    case 32: launch_modsum_g<32>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
+    default: launch_modsum_g<64>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
   }
   return true;
 }
@@ -1249,14 +1605,15 @@ static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const fl
 static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const float *S_, const float *fin,
                               const int4 *vox, const float *w_pos, const float *alpha, const float *ln_w,
                               const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
-                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out) {
+                              const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out,
+                              int64_t m_cap) {
   if (!g_use_group_path || (d->c & 3) != 0 || d->r > 3) return false;
   switch (lanes_per_row(d->c)) {
-    case 1: case 2: case 4: launch_gdl_g<4>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
-    case 8: launch_gdl_g<8>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
-    case 16: launch_gdl_g<16>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
-    case 32: launch_gdl_g<32>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
-    default: launch_gdl_g<64>(d->op, d->r, st, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 1: case 2: case 4: launch_gdl_g<4>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 8: launch_gdl_g<8>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 16: launch_gdl_g<16>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    case 32: launch_gdl_g<32>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
+    default: launch_gdl_g<64>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
   }
   return true;
 }
@@ -1271,8 +1628,8 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
   int rc;
   if (build_index) {
     rc = link_index_build(b->coords, n, grid, b->cell_counts, b->scratch, b->scratch_bytes, b->cell_blk,
-                          b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->blk_start, b->blk_coords,
-                          b->counts, b->hdr, stream);
+                          b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->pos_blk, b->blk_start,
+                          b->blk_coords, b->counts, b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
   rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
@@ -1280,6 +1637,12 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
   if (rc != LINK_OK) return rc;
+  if (g_use_split && b->A && b->pos_blk && (desc->c & 3) == 0 && desc->r <= 3) {
+    rc = link_block_gather(b->S, b->blk_coords, b->cell_blk, grid, b->hdr, desc, m_cap, b->A, stream);
+    if (rc != LINK_OK) return rc;
+    return link_voxel_demod_ln(b->A, b->fin, b->vox_sorted, b->pos_blk, b->w_pos, b->alpha, b->ln_w, b->ln_b,
+                               b->hdr, desc, n, b->out, stream);
+  }
   return link_gather_demod_ln(b->S, b->fin, b->vox_sorted, b->w_pos, b->alpha, b->ln_w, b->ln_b,
                               b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, b->out,
                               stream);

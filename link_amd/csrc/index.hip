@@ -309,7 +309,8 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
                                                   const int32_t *__restrict__ hdr, int64_t n,
                                                   const int4 *__restrict__ coords,
                                                   int32_t *__restrict__ perm,
-                                                  int4 *__restrict__ vox_sorted) {
+                                                  int4 *__restrict__ vox_sorted,
+                                                  int32_t *__restrict__ pos_blk) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || p >= hdr[LINK_HDR_NVALID]) return;
   int32_t i = perm_tmp[p];
@@ -327,13 +328,14 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
     int4 c = coords[i];
     vox_sorted[dst] = make_int4(c.x, c.y, c.z, i);
   }
+  if (pos_blk) pos_blk[dst] = b;
 }
 
 extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid,
                                 uint32_t *cell_counts, void *scratch, size_t scratch_bytes,
                                 int32_t *cell_blk, int32_t *vox_blk, int64_t *idx_query, int32_t *perm,
-                                int32_t *vox_sorted, int32_t *blk_start, int32_t *blk_coords,
-                                int32_t *counts, int32_t *hdr, void *stream) {
+                                int32_t *vox_sorted, int32_t *pos_blk, int32_t *blk_start,
+                                int32_t *blk_coords, int32_t *counts, int32_t *hdr, void *stream) {
   if (n < 0 || n >= (1LL << 31) || !grid || !hdr) return LINK_ERR_ARG;
   int64_t v = 1;
   for (int a = 0; a < 4; a++) {
@@ -360,7 +362,7 @@ extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_gri
                        cell_blk, blk_start, sc.perm_tmp, vox_blk, idx_query, hdr);
     hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, vox_blk,
                        blk_start, hdr, n, reinterpret_cast<const int4 *>(coords), perm,
-                       reinterpret_cast<int4 *>(vox_sorted));
+                       reinterpret_cast<int4 *>(vox_sorted), pos_blk);
   }
   return check_launch("link_index_build");
 }

@@ -66,7 +66,8 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     if m_cap is None:
         m_cap = index._m if index._m is not None else n
     fin = torch.empty((n, c), dtype=torch.float32, device=dev)
-    S = torch.empty((max(m_cap, 1), parts * c + 4), dtype=torch.float32, device=dev)
+    m_cap = max(m_cap, 1)
+    S = torch.empty(m_cap * (parts * c + 1), dtype=torch.float32, device=dev)
     out = torch.empty((n, c), dtype=torch.float32, device=dev)
     desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
     lib, st = L.lib(), _st()
@@ -78,6 +79,17 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
                                         al.data_ptr() if al is not None else None,
                                         index.blk_start.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc),
                                         n, m_cap, S.data_ptr(), st), "link_modulate_block_sum")
+    if c % 4 == 0 and r <= 3:
+        A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
+        L.check(lib.link_block_gather(S.data_ptr(), index.blk_coords.data_ptr(),
+                                      index.cell_blk.data_ptr(), ctypes.byref(index.grid), index.hdr.data_ptr(),
+                                      ctypes.byref(desc), m_cap, A.data_ptr(), st), "link_block_gather")
+        L.check(lib.link_voxel_demod_ln(A.data_ptr(), fin.data_ptr(), index.vox_sorted.data_ptr(),
+                                        index.pos_blk.data_ptr(), w_pos.data_ptr(),
+                                        al.data_ptr() if al is not None else None, ln_w.data_ptr(),
+                                        ln_b.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc), n,
+                                        out.data_ptr(), st), "link_voxel_demod_ln")
+        return out
     L.check(lib.link_gather_demod_ln(S.data_ptr(), fin.data_ptr(), index.vox_sorted.data_ptr(), w_pos.data_ptr(),
                                      al.data_ptr() if al is not None else None, ln_w.data_ptr(),
                                      ln_b.data_ptr(), index.blk_start.data_ptr(),
@@ -111,18 +123,20 @@ class ElkCorePlan:
         self.idx_query = torch.empty(n_cap, dtype=torch.int64, device=device)
         self.perm = torch.empty(n_cap, **i32)
         self.vox_sorted = torch.empty((n_cap, 4), **i32)
+        self.pos_blk = torch.empty(n_cap, **i32)
         self.blk_start = torch.empty(n_cap + 1, **i32)
         self.blk_coords = torch.empty((n_cap, 4), **i32)
         self.counts = torch.empty(n_cap, **i32)
         self.hdr = torch.zeros(L.HDR_WORDS, **i32)
         self.fin = torch.empty((n_cap, c), **f32)
-        self.S = torch.empty((n_cap, parts * c + 4), **f32)
+        self.S = torch.empty(n_cap * (parts * c + 1), **f32)
+        self.A = torch.empty((n_cap, parts * c), **f32)
         self.out = torch.empty((n_cap, c), **f32)
         b = self.buf = L.LinkElkBuffers()
         b.cell_counts, b.scratch, b.scratch_bytes = self.cell_counts.data_ptr(), self.scratch.data_ptr(), nbytes
         b.cell_blk, b.vox_blk, b.idx_query = self.cell_blk.data_ptr(), self.vox_blk.data_ptr(), self.idx_query.data_ptr()
         b.perm, b.blk_start, b.blk_coords = self.perm.data_ptr(), self.blk_start.data_ptr(), self.blk_coords.data_ptr()
-        b.vox_sorted = self.vox_sorted.data_ptr()
+        b.vox_sorted, b.pos_blk, b.A = self.vox_sorted.data_ptr(), self.pos_blk.data_ptr(), self.A.data_ptr()
         b.counts, b.hdr = self.counts.data_ptr(), self.hdr.data_ptr()
         b.fin, b.S, b.out = self.fin.data_ptr(), self.S.data_ptr(), self.out.data_ptr()
         self._fn = L.lib().link_elk_core_forward

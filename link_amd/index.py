@@ -104,6 +104,7 @@ class BlockIndex:
         self.idx_query = torch.empty(n, dtype=torch.int64, device=dev) if want_idx64 else None
         self.perm = torch.empty(n, **i32)
         self.vox_sorted = torch.empty((max(n, 1), 4), **i32)
+        self.pos_blk = torch.empty(max(n, 1), **i32)
         self.blk_start = torch.empty(n + 1, **i32)
         self.blk_coords = torch.empty((max(n, 1), 4), **i32)
         self.counts_buf = torch.empty(max(n, 1), **i32)
@@ -114,6 +115,7 @@ class BlockIndex:
             self.coords.data_ptr(), n, ctypes.byref(self.grid), cell_counts.data_ptr(), scratch.data_ptr(),
             scratch.numel(), self.cell_blk.data_ptr(), self.vox_blk.data_ptr(),
             self.idx_query.data_ptr() if want_idx64 else None, self.perm.data_ptr(), self.vox_sorted.data_ptr(),
+            self.pos_blk.data_ptr(),
             self.blk_start.data_ptr(), self.blk_coords.data_ptr(), self.counts_buf.data_ptr(),
             self.hdr.data_ptr(), torch.cuda.current_stream().cuda_stream), "link_index_build")
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert L.lib().link_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header (sizes in bytes)
     assert ctypes.sizeof(L.LinkGrid) == 36 and ctypes.sizeof(L.LinkElkDesc) == 24
-    assert ctypes.sizeof(L.LinkElkBuffers) == 24 * 8
+    assert ctypes.sizeof(L.LinkElkBuffers) == 26 * 8
 
 
 def test_argument_validation_without_gpu():

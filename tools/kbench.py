@@ -27,15 +27,19 @@ b, grid, desc = plan.buf, plan.grid, plan.desc
 stages = {
     "index": lambda: lib.link_index_build(coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch,
                                           b.scratch_bytes, b.cell_blk, b.vox_blk, b.idx_query, b.perm,
-                                          b.vox_sorted, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
+                                          b.vox_sorted, b.pos_blk, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
     "premix": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
     "modsum": lambda: lib.link_modulate_block_sum(b.fin, b.vox_sorted, b.w_pos, b.alpha, b.blk_start, b.hdr,
                                                   ctypes.byref(desc), N, N, b.S, st),
     "gather": lambda: lib.link_gather_demod_ln(b.S, b.fin, b.vox_sorted, b.w_pos, b.alpha, b.ln_w, b.ln_b,
                                                b.blk_start, b.blk_coords, b.cell_blk, ctypes.byref(grid), b.hdr,
                                                ctypes.byref(desc), N, N, b.out, st),
+    "bgather": lambda: lib.link_block_gather(b.S, b.blk_coords, b.cell_blk, ctypes.byref(grid), b.hdr,
+                                             ctypes.byref(desc), N, b.A, st),
+    "vdemod": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w,
+                                              b.ln_b, b.hdr, ctypes.byref(desc), N, b.out, st),
 }
-KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4}
+KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6}
 
 
 def time_stage(fn, k=50):
