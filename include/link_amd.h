@@ -221,9 +221,10 @@ int link_premix_ln(const float *feats, const float *w_pre, const float *ln_w, co
  *   S[b] = [ sum_i fin_i*cos(theta_i), sum_i fin_i*sin(theta_i) (, sum_i fin_i*theta_i), count_b ]
  * over the voxels of block b in ascending voxel id.  Block SUMS, not means (mean*count of the
  * reference re-multiplies what it just divided).  S layout: m_cap rows of nparts*C floats (row =
- * 512 B at C=64: four aligned 128-B lines), followed by the m_cap counts (fp32) at
- * S + m_cap*nparts*C, i.e. S has m_cap*(nparts*C + 1) floats.  The SAME m_cap must be passed to every
- * call that touches S.  w_pos fp[cg,3]; alpha fp[cg] or NULL. */
+ * 512 B at C=64: four aligned 128-B lines), one extra all-zero row (id m_cap: what absent neighbours
+ * point at), then the m_cap+1 counts (fp32) at S + (m_cap+1)*nparts*C, i.e. S has
+ * (m_cap+1)*(nparts*C + 1) floats.  The SAME m_cap must be passed to every call that touches S.
+ * w_pos fp[cg,3]; alpha fp[cg] or NULL. */
 int link_modulate_block_sum(const float *fin, const int32_t *vox_sorted, const float *w_pos,
                             const float *alpha, const int32_t *blk_start,
                             const int32_t *hdr, const link_elk_desc_t *desc /* host */, int64_t n,
@@ -267,7 +268,7 @@ typedef struct {
   uint32_t *cell_counts; void *scratch; size_t scratch_bytes;          /* link_index_build scratch */
   int32_t *cell_blk, *vox_blk; int64_t *idx_query; int32_t *perm, *vox_sorted, *pos_blk, *blk_start, *blk_coords, *counts, *hdr;
   float *fin;                /* fp[N,C]            scratch: pre_mix output */
-  float *S;                  /* fp[m_cap*(P*C+1)]  scratch: block table rows + counts */
+  float *S;                  /* fp[(m_cap+1)*(P*C+1)] scratch: block table rows + zero row + counts */
   float *A;                  /* fp[m_cap, P*C]     scratch: normalised neighbour sums (NULL: fused gather) */
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
 } link_elk_buffers_t;

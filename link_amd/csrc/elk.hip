@@ -16,7 +16,8 @@
 //
 // S layout: m_cap rows [part0 C | part1 C | (part2 C)] fp32 (row = P*C floats: 512 B at C=64, i.e.
 // exactly 4 aligned 128-B lines -- the gather is bound by L2->L1 line requests), followed by the
-// m_cap per-block counts (fp32) at S + m_cap*P*C.
+// (m_cap+1)-th all-zero row (row id m_cap: what an absent neighbour points at, so the gather needs no
+// validity selects) and then the m_cap+1 per-block counts (fp32) at S + (m_cap+1)*P*C.
 #include <limits.h>
 
 #include "common.h"
@@ -366,9 +367,14 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
   const int lane = threadIdx.x & 63;
   int b0, b1;
   wave_chunk(hdr[LINK_HDR_M], b0, b1);
-  if (b0 >= b1) return;
   const int rs = P * c;
-  float *__restrict__ Scnt = S + m_cap * rs;
+  float *__restrict__ Scnt = S + (m_cap + 1) * rs;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {       // the all-zero row absent neighbours point at
+    float *zrow = S + m_cap * rs;
+    for (int k = threadIdx.x; k < rs; k += 64) zrow[k] = 0.f;
+    if (threadIdx.x == 0) Scnt[m_cap] = 0.f;
+  }
+  if (b0 >= b1) return;
   float w0[CPL], w1[CPL], w2[CPL], al[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
@@ -552,7 +558,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
   wave_chunk(hdr[LINK_HDR_M], b0, b1);
   if (b0 >= b1) return;
   const int rs = P * c;
-  const float *__restrict__ Scnt = S + m_cap * rs;
+  const float *__restrict__ Scnt = S + (m_cap + 1) * rs;
   float w0[CPL], w1[CPL], w2[CPL], al[CPL], gw[CPL], gb[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
@@ -854,9 +860,15 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
   const bool hi = PAIR && (li >= LPR / 2);
   int b0, b1;
   group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
-  if (b0 >= b1) return;
   const int rs = P * c;
-  float *__restrict__ Scnt = S + m_cap * rs;
+  float *__restrict__ Scnt = S + (m_cap + 1) * rs;
+  if (blockIdx.x == 0 && threadIdx.x < LPR) {      // the all-zero row absent neighbours point at
+    float *zrow = S + m_cap * rs;
+    if (act)
+      for (int pp = 0; pp < P; pp++) *reinterpret_cast<float4 *>(&zrow[pp * c + ch0]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (li == 0) Scnt[m_cap] = 0.f;
+  }
+  if (b0 >= b1) return;
   float w0[4], w1[4], w2[4], al[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -974,7 +986,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
   group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
   const bool live = b0 < b1;                       // dead groups still take part in wave-level votes
   const int rs = P * c;
-  const float *__restrict__ Scnt = S + m_cap * rs;
+  const float *__restrict__ Scnt = S + (m_cap + 1) * rs;
   float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -1203,7 +1215,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
   constexpr int R2 = R * R, R3 = R2 * R;
   constexpr int ZLO = -((R + 1) / 2) + 1;
   constexpr int SUB = 8;
-  __shared__ int32_t s_nb[4 * G][SUB * R3];
+  __shared__ uint32_t s_nb[4 * G][SUB * R3];       // BYTE offsets of the neighbour rows (zero row if absent)
   __shared__ int4 s_bc[4 * G][SUB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & (LPR - 1), grp = wave * G + lane / LPR;
@@ -1214,7 +1226,10 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
   group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
   const bool live = b0 < b1;
   const int rs = P * c;
-  const float *__restrict__ Scnt = S + m_cap * rs;
+  const uint32_t row_bytes = (uint32_t)rs * 4u;
+  const char *__restrict__ Sb = reinterpret_cast<const char *>(S) + cofs * 4;        // lane's column
+  const char *__restrict__ Cb = reinterpret_cast<const char *>(S + (m_cap + 1) * rs); // counts
+  const uint32_t zero_row = (uint32_t)m_cap;
   float col[R][P][4], cden[R];
   int ph[R];                                       // height held by ring slot (slot = height mod R)
 #pragma unroll
@@ -1226,7 +1241,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
       for (int e = 0; e < 4; e++) col[d][pp][e] = 0.f;
   }
   int px = INT_MIN, py = 0, pw = 0;
-  int32_t *my_nb = s_nb[grp];
+  uint32_t *my_nb = s_nb[grp];
   int4 *my_bc = s_bc[grp];
   const int nblk = live ? b1 - b0 : 0;
   int wave_pass = (nblk + SUB - 1) / SUB;
@@ -1245,7 +1260,8 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
       plane_offset<R>(t, ox, oy);
       const int4 bc = blk_coords[bb + j];
       const int32_t cell = cell_of(g, bc.x + ox, bc.y + oy, bc.z + ZLO + d, bc.w);
-      my_nb[e] = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+      const int32_t id = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+      my_nb[e] = (id >= 0) ? (uint32_t)id : zero_row;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1273,32 +1289,25 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
         const int d = doit ? (__ffs(need_mask) - 1) : 0;
         const int h = bc.z + ZLO + d;
         const int slot = ((h % R) + R) % R;
-        float acc[P][4], den = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < P; pp++)
-#pragma unroll
-          for (int e = 0; e < 4; e++) acc[pp][e] = 0.f;
         float4 v[R2][P];
         float vd[R2];
-        int32_t nbv[R2];
 #pragma unroll
-        for (int t = 0; t < R2; t++) nbv[t] = doit ? my_nb[(jj * R + d) * R2 + t] : -1;
+        for (int t = 0; t < R2; t++) {             // all row loads of the plane back to back, 32-bit offsets
+          const uint32_t rid = doit ? my_nb[(jj * R + d) * R2 + t] : zero_row;   // idle groups: zero row
+          vd[t] = *reinterpret_cast<const float *>(Cb + rid * 4u);
 #pragma unroll
-        for (int t = 0; t < R2; t++) {
-          const int32_t rid = (nbv[t] >= 0) ? nbv[t] : 0;
-          const float *row = S + (int64_t)rid * rs;
-          vd[t] = Scnt[rid];
-#pragma unroll
-          for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * c + cofs]);
+          for (int pp = 0; pp < P; pp++)
+            v[t][pp] = *reinterpret_cast<const float4 *>(Sb + rid * row_bytes + (uint32_t)(pp * c) * 4u);
         }
+        float acc[P][4], den = vd[0];
 #pragma unroll
-        for (int t = 0; t < R2; t++) {
-          const bool okt = nbv[t] >= 0;
-          den += okt ? vd[t] : 0.f;
+        for (int pp = 0; pp < P; pp++) { acc[pp][0] = v[0][pp].x; acc[pp][1] = v[0][pp].y; acc[pp][2] = v[0][pp].z; acc[pp][3] = v[0][pp].w; }
+#pragma unroll
+        for (int t = 1; t < R2; t++) {             // absent neighbours read the zero row: no selects
+          den += vd[t];
 #pragma unroll
           for (int pp = 0; pp < P; pp++) {
-            acc[pp][0] += okt ? v[t][pp].x : 0.f; acc[pp][1] += okt ? v[t][pp].y : 0.f;
-            acc[pp][2] += okt ? v[t][pp].z : 0.f; acc[pp][3] += okt ? v[t][pp].w : 0.f;
+            acc[pp][0] += v[t][pp].x; acc[pp][1] += v[t][pp].y; acc[pp][2] += v[t][pp].z; acc[pp][3] += v[t][pp].w;
           }
         }
 #pragma unroll
@@ -1314,25 +1323,21 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
         need_mask &= need_mask - 1;
       }
       if (on) { px = bc.x; py = bc.y; pw = bc.w; }
-      // sum the planes in ascending height order (slot of height z+ZLO+d), deterministic
-      float Av[P][4], den = 0.f;
+      // all R slots now hold this block's planes: sum them in slot order (deterministic: the order
+      // is a function of z mod R only)
+      float den = cden[0];
+      float Av[P][4];
 #pragma unroll
       for (int pp = 0; pp < P; pp++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) Av[pp][e] = 0.f;
+        for (int e = 0; e < 4; e++) Av[pp][e] = col[0][pp][e];
 #pragma unroll
-      for (int d = 0; d < R; d++) {
-        const int h = bc.z + ZLO + d;
-        const int slot = ((h % R) + R) % R;
+      for (int sl = 1; sl < R; sl++) {
+        den += cden[sl];
 #pragma unroll
-        for (int sl = 0; sl < R; sl++) {
-          const bool use = sl == slot;
-          den += use ? cden[sl] : 0.f;
+        for (int pp = 0; pp < P; pp++)
 #pragma unroll
-          for (int pp = 0; pp < P; pp++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) Av[pp][e] += use ? col[sl][pp][e] : 0.f;
-        }
+          for (int e = 0; e < 4; e++) Av[pp][e] += col[sl][pp][e];
       }
       if (on && act) {
         float *arow = A_tab + (int64_t)(bb + jj) * rs;
@@ -1532,6 +1537,7 @@ extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, con
   if (check_desc(desc) != LINK_OK || !grid || m_cap < 0 || desc->r > 3 || (desc->c & 3) != 0) return LINK_ERR_ARG;
   if (m_cap == 0) return LINK_OK;
   if (!S_ || !blk_coords || !cell_blk || !hdr || !A) return LINK_ERR_ARG;
+  if ((m_cap + 1) * (int64_t)(desc->c * 3 + 1) * 4 >= (1LL << 32)) return LINK_ERR_ARG;   // 32-bit row offsets
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   const bool p3 = desc->op == LINK_OP_COSX;

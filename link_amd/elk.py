@@ -67,7 +67,7 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
         m_cap = index._m if index._m is not None else n
     fin = torch.empty((n, c), dtype=torch.float32, device=dev)
     m_cap = max(m_cap, 1)
-    S = torch.empty(m_cap * (parts * c + 1), dtype=torch.float32, device=dev)
+    S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
     out = torch.empty((n, c), dtype=torch.float32, device=dev)
     desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
     lib, st = L.lib(), _st()
@@ -129,7 +129,7 @@ class ElkCorePlan:
         self.counts = torch.empty(n_cap, **i32)
         self.hdr = torch.zeros(L.HDR_WORDS, **i32)
         self.fin = torch.empty((n_cap, c), **f32)
-        self.S = torch.empty(n_cap * (parts * c + 1), **f32)
+        self.S = torch.empty((n_cap + 1) * (parts * c + 1), **f32)
         self.A = torch.empty((n_cap, parts * c), **f32)
         self.out = torch.empty((n_cap, c), **f32)
         b = self.buf = L.LinkElkBuffers()
