@@ -277,6 +277,10 @@ typedef struct {
  * 2: pre_mix workgroups).  Not needed for correct operation. */
 int link_set_tuning(int key, int value);
 
+/* link_elk_core_forward runs pre_mix on an internal per-device side stream concurrently with the index
+ * build (fork/join with events on `stream`); link_set_overlap(0) keeps everything on `stream`. */
+int link_set_overlap(int on);
+
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           int32_t build_index, void *stream);

@@ -27,6 +27,8 @@ using namespace link;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static int g_premix_wgs_fwd();
+static int g_premix_ablate_fwd();
+static int g_premix_variant_fwd();
 
 // ---------------------------------------------------------------------------------------------
 // pre_mix + LayerNorm (MFMA path, C in {16,32,48,...,128}, C % 16 == 0)
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__
                                                        const float *__restrict__ w_pre,
                                                        const float *__restrict__ ln_w,
                                                        const float *__restrict__ ln_b, int64_t n,
-                                                       float eps, float *__restrict__ fin) {
+                                                       float eps, float *__restrict__ fin, int ablate) {
   constexpr int T = C / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -140,24 +142,108 @@ __global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__
   }
   const int64_t tiles = (n + 15) / 16;
   const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t tile0 = (int64_t)blockIdx.x * 4 + wave;
   // loads are UNCONDITIONAL on a clamped row (tail lanes re-read row n-1; their results are never
-  // stored): predicated loads would force s_waitcnt vmcnt(0) and serialise the prefetch below
-  float4 f[T];
-  {
+  // stored): predicated loads would force s_waitcnt vmcnt(0).  The loop is unrolled by two with
+  // ping-pong register sets (no register rotation): a rotation copy needs the prefetched data at the
+  // END of the iteration and the resulting vmcnt(0) also waits for the iteration's stores, which
+  // makes load, MFMA and store time purely additive (measured 10.8 + 4.1 + 4.3 us).
+  auto load_tile = [&](int64_t tile, float4 (&f)[T]) {
     int64_t v = tile * 16 + li;
     v = (v < n) ? v : n - 1;
 #pragma unroll
     for (int t = 0; t < T; t++) f[t] = *reinterpret_cast<const float4 *>(&feats[v * C + 16 * t + 4 * g]);
-  }
-  for (; tile < tiles; tile += stride) {
+  };
+  auto do_tile = [&](int64_t tile, const float4 (&f)[T]) {
     const int64_t v = tile * 16 + li;
     const bool ok = v < n;
-    int64_t vn = (tile + stride) * 16 + li;
-    vn = (vn < n) ? vn : n - 1;
-    float4 fn[T];
+    floatx4 acc[T];
 #pragma unroll
-    for (int t = 0; t < T; t++) fn[t] = *reinterpret_cast<const float4 *>(&feats[vn * C + 16 * t + 4 * g]);
+    for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){f[tp].x, f[tp].y, f[tp].z, f[tp].w};
+    if (!(ablate & 1)) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int tp = 0; tp < T; tp++) {
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].x, f[t].x, acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].y, f[t].y, acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].z, f[t].z, acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].w, f[t].w, acc[tp], 0, 0, 0);
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) s += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float d = acc[tp][r] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    if (ok && !(ablate & 2)) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        float4 o;
+        o.x = (acc[tp][0] - mean) * rstd * lw[tp].x + lb[tp].x;
+        o.y = (acc[tp][1] - mean) * rstd * lw[tp].y + lb[tp].y;
+        o.z = (acc[tp][2] - mean) * rstd * lw[tp].z + lb[tp].z;
+        o.w = (acc[tp][3] - mean) * rstd * lw[tp].w + lb[tp].w;
+        *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
+      }
+    }
+  };
+  float4 fa[T], fb[T];
+  if (tile0 < tiles) load_tile(tile0, fa);
+  for (int64_t tile = tile0; tile < tiles; tile += 2 * stride) {
+    if (tile + stride < tiles) load_tile(tile + stride, fb);       // wave-uniform
+    do_tile(tile, fa);
+    if (tile + stride < tiles) {
+      if (tile + 2 * stride < tiles) load_tile(tile + 2 * stride, fa);
+      do_tile(tile + stride, fb);
+    }
+  }
+}
+
+// TLP variant: W staged once per workgroup in LDS (padded rows: conflict-free ds_read_b128), no
+// software pipelining at all -- a wave is load -> 64 MFMA -> LayerNorm -> store per tile, and 5-6
+// resident waves per SIMD overlap each other's phases (register rotation / predication defeat the
+// compiler's counted waits on this target, occupancy does not).
+template <int C>
+__global__ void __launch_bounds__(256) k_premix_ln_tlp(const float *__restrict__ feats,
+                                                       const float *__restrict__ w_pre,
+                                                       const float *__restrict__ ln_w,
+                                                       const float *__restrict__ ln_b, int64_t n,
+                                                       float eps, float *__restrict__ fin) {
+  constexpr int T = C / 16;
+  constexpr int LDW = C + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *w_lds = reinterpret_cast<float *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  for (int e = tid * 4; e < C * C; e += 256 * 4) {
+    int r = e / C, col = e - r * C;
+    *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = *reinterpret_cast<const float4 *>(&w_pre[e]);
+  }
+  __syncthreads();
+  const int64_t tiles = (n + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t v = tile * 16 + li;
+    const bool ok = v < n;
+    const int64_t vl = ok ? v : n - 1;
+    float4 f[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) f[t] = *reinterpret_cast<const float4 *>(&feats[vl * C + 16 * t + 4 * g]);
     floatx4 acc[T];
 #pragma unroll
     for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -165,10 +251,11 @@ __global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__
     for (int t = 0; t < T; t++) {
 #pragma unroll
       for (int tp = 0; tp < T; tp++) {
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].x, f[t].x, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].y, f[t].y, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].z, f[t].z, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].w, f[t].w, acc[tp], 0, 0, 0);
+        float4 a = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * t + 4 * g]);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f[t].x, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f[t].y, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f[t].z, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f[t].w, acc[tp], 0, 0, 0);
       }
     }
     float s = 0.f;
@@ -191,17 +278,29 @@ __global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__
     if (ok) {
 #pragma unroll
       for (int tp = 0; tp < T; tp++) {
+        const float4 lw = *reinterpret_cast<const float4 *>(&ln_w[16 * tp + 4 * g]);   // L1-resident
+        const float4 lb = *reinterpret_cast<const float4 *>(&ln_b[16 * tp + 4 * g]);
         float4 o;
-        o.x = (acc[tp][0] - mean) * rstd * lw[tp].x + lb[tp].x;
-        o.y = (acc[tp][1] - mean) * rstd * lw[tp].y + lb[tp].y;
-        o.z = (acc[tp][2] - mean) * rstd * lw[tp].z + lb[tp].z;
-        o.w = (acc[tp][3] - mean) * rstd * lw[tp].w + lb[tp].w;
+        o.x = (acc[tp][0] - mean) * rstd * lw.x + lb.x;
+        o.y = (acc[tp][1] - mean) * rstd * lw.y + lb.y;
+        o.z = (acc[tp][2] - mean) * rstd * lw.z + lb.z;
+        o.w = (acc[tp][3] - mean) * rstd * lw.w + lb.w;
         *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
       }
     }
-#pragma unroll
-    for (int t = 0; t < T; t++) f[t] = fn[t];
   }
+}
+
+template <int C>
+static int launch_premix_tlp(const float *feats, const float *w_pre, const float *ln_w, const float *ln_b,
+                             int64_t n, float eps, float *fin, hipStream_t st) {
+  size_t lds = (size_t)C * (C + 4) * sizeof(float);
+  int64_t tiles = (n + 15) / 16;
+  int64_t wgs = (tiles + 3) / 4;
+  if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();
+  hipLaunchKernelGGL(k_premix_ln_tlp<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, ln_b, n,
+                     eps, fin);
+  return check_launch("link_premix_ln");
 }
 
 template <int C>
@@ -211,7 +310,7 @@ static int launch_premix_reg(const float *feats, const float *w_pre, const float
   int64_t wgs = (tiles + 3) / 4;
   if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();   // default 2 waves per SIMD chip-wide; W lives in registers
   hipLaunchKernelGGL(k_premix_ln_reg<C>, dim3((unsigned)wgs), dim3(256), 0, st, feats, w_pre, ln_w, ln_b, n,
-                     eps, fin);
+                     eps, fin, g_premix_ablate_fwd());
   return check_launch("link_premix_ln");
 }
 
@@ -279,10 +378,10 @@ extern "C" int link_premix_ln(const float *feats, const float *w_pre, const floa
   if (!feats || !w_pre || !ln_w || !ln_b || !fin) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
   switch (c) {
-    case 16: return launch_premix_reg<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 32: return launch_premix_reg<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 48: return launch_premix_reg<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 64: return launch_premix_reg<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 16: return g_premix_variant_fwd() ? launch_premix_tlp<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 32: return g_premix_variant_fwd() ? launch_premix_tlp<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 48: return g_premix_variant_fwd() ? launch_premix_tlp<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 64: return g_premix_variant_fwd() ? launch_premix_tlp<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     case 80: return launch_premix_mfma<80>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     case 112: return launch_premix_mfma<112>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     case 96: return launch_premix_mfma<96>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
@@ -459,6 +558,8 @@ static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one 
 static int g_premix_wgs = 512;
 static int g_use_group_path = 1;
 static int g_use_pair = 1;
+static int g_premix_ablate = 0;
+static int g_premix_variant = 1;   // 1 = LDS-staged W + occupancy (tlp), 0 = W in registers + ping-pong
 static int g_bgather_wgs = 1024;
 static int g_use_split = 1;
 extern "C" int link_set_tuning(int key, int value) {
@@ -470,6 +571,8 @@ extern "C" int link_set_tuning(int key, int value) {
     case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
     case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
     case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
+    case 8: g_premix_variant = value - 1; return LINK_OK;       // 1 = register-resident W, 2 = LDS-staged W (tlp)
+    case 7: g_premix_ablate = value - 1; return LINK_OK;        // debug: 1 = normal, 2 = no MFMA, 3 = no store, 4 = neither
     case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
     default: return LINK_ERR_ARG;
   }
@@ -791,6 +894,8 @@ extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int
 }
 
 static int g_premix_wgs_fwd() { return g_premix_wgs; }
+static int g_premix_ablate_fwd() { return g_premix_ablate; }
+static int g_premix_variant_fwd() { return g_premix_variant; }
 
 // =============================================================================================
 // Sub-wave ("group") kernels: the fast path for C % 4 == 0.
@@ -1339,12 +1444,13 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
 #pragma unroll
           for (int e = 0; e < 4; e++) Av[pp][e] += col[sl][pp][e];
       }
+      const float rden = 1.0f / den;                 // den is an exact small integer; x*(1/d) vs x/d: <= 1 ulp
       if (on && act) {
         float *arow = A_tab + (int64_t)(bb + jj) * rs;
 #pragma unroll
         for (int pp = 0; pp < P; pp++)
           *reinterpret_cast<float4 *>(&arow[pp * c + ch0]) =
-              make_float4(Av[pp][0] / den, Av[pp][1] / den, Av[pp][2] / den, Av[pp][3] / den);   // utils.py:80
+              make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden);   // utils.py:80
       }
     }
   }
@@ -1627,19 +1733,57 @@ static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const fl
 // ---------------------------------------------------------------------------------------------
 // one-call R_core
 // ---------------------------------------------------------------------------------------------
+// Per-device helper stream + events for the fork/join inside link_elk_core_forward: pre_mix does not
+// depend on the block index, so it runs on a side stream concurrently with the 4 latency-bound index
+// kernels (HIP streams instead of a tracing compiler; works under graph capture as a fork/join).
+// Created lazily, once per device, never destroyed (process lifetime).
+#include <mutex>
+namespace {
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream g_side[64];
+std::mutex g_side_mu;
+static int g_use_overlap = 0;   // measured: cross-stream fork/join costs more than it hides here (profiles/)
+SideStream *side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream &s = g_side[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  }
+  return &s;
+}
+}  // namespace
+
 extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_grid_t *grid,
                                      const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
                                      int32_t build_index, void *stream) {
   if (!b || !grid || check_desc(desc) != LINK_OK) return LINK_ERR_ARG;
   int rc;
+  SideStream *ss = (build_index && g_use_overlap) ? side_stream() : nullptr;
+  if (ss) {
+    // fork: pre_mix on the side stream, index build on the caller's stream, then join
+    if (hipEventRecord(ss->fork, S(stream)) != hipSuccess) return check_launch("fork record");
+    if (hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess) return check_launch("fork wait");
+    rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, ss->stream);
+    if (rc != LINK_OK) return rc;
+    if (hipEventRecord(ss->join, ss->stream) != hipSuccess) return check_launch("join record");
+  }
   if (build_index) {
     rc = link_index_build(b->coords, n, grid, b->cell_counts, b->scratch, b->scratch_bytes, b->cell_blk,
                           b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->pos_blk, b->blk_start,
                           b->blk_coords, b->counts, b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
-  rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
-  if (rc != LINK_OK) return rc;
+  if (ss) {
+    if (hipStreamWaitEvent(S(stream), ss->join, 0) != hipSuccess) return check_launch("join wait");
+  } else {
+    rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
+    if (rc != LINK_OK) return rc;
+  }
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
   if (rc != LINK_OK) return rc;
@@ -1653,3 +1797,5 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
                               b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, b->out,
                               stream);
 }
+
+extern "C" int link_set_overlap(int on) { g_use_overlap = on ? 1 : 0; return LINK_OK; }

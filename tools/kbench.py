@@ -39,7 +39,7 @@ stages = {
     "vdemod": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w,
                                               b.ln_b, b.hdr, ctypes.byref(desc), N, b.out, st),
 }
-KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6}
+KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6, "ablate": 7, "pvariant": 8}
 
 
 def time_stage(fn, k=50):
@@ -60,23 +60,55 @@ for arg in sys.argv[1:]:
     key, vals = arg.split("=")
     for v in vals.split(","):
         lib.link_set_tuning(KEYS[key], int(v))
-        if key in ("group", "pair"):
+        if key == "pvariant":
+            lib.link_set_tuning(2, 1536 if int(v) == 2 else 512)
+            for w in ((512, 1024, 1536, 2048) if int(v) == 2 else (256, 512)):
+                lib.link_set_tuning(2, w)
+                print(f"premix variant={v} wgs={w}: {time_stage(stages['premix']):.2f} us")
+        elif key == "ablate":
+            print(f"premix ablate={v}: {time_stage(stages['premix']):.2f} us")
+        elif key in ("group", "pair"):
             print(f"{key}={v}:", {k: round(time_stage(f), 2) for k, f in stages.items() if k in ("modsum", "gather")})
         else:
             print(f"{key} wgs={v}: {time_stage(stages[key]):.2f} us")
 # whole step (one FFI call), cold and warm
 import time
-for cold in (True, False):
+for ov in (0, 1):
+  lib.link_set_overlap(ov)
+  for cold in (True, False):
     for _ in range(10):
         plan.run(feats, coords, cold)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200):
         plan.run(feats, coords, cold)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("step", "cold" if cold else "warm", f"{(t1 - t0) / 200 * 1e6:.1f} us")
+    print("overlap", ov, "step", "cold" if cold else "warm", f"{(t1 - t0) / 200 * 1e6:.1f} us")
 # memory-system yardsticks: plain device copy / fill of one [N,C] fp32 tensor
 src, dst = feats, torch.empty_like(feats)
 print("torch copy [N,C] f32:", round(time_stage(lambda: dst.copy_(src)), 2), "us  (", round(2 * src.numel() * 4 / 1e6, 1), "MB moved )")
 print("torch fill [N,C] f32:", round(time_stage(lambda: dst.fill_(1.0)), 2), "us")
 big = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev); big2 = torch.empty_like(big)
 print("torch copy 256MB:", round(time_stage(lambda: big2.copy_(big), 10), 2), "us (512 MB moved)")
+# hipGraph replay of the whole step (serial and fork/join variants)
+for ov in (0, 1):
+    lib.link_set_overlap(ov)
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                plan.run(feats, coords, True)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                plan.run(feats, coords, True)
+        torch.cuda.synchronize()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200):
+            g.replay()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        print("graph replay overlap", ov, f"cold step {(t1 - t0) / 200 * 1e6:.1f} us")
+    except Exception as e:
+        print("graph capture failed (overlap", ov, "):", repr(e)[:300])
+lib.link_set_overlap(0)
