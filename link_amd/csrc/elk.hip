@@ -2,17 +2,19 @@
 // (segmentation/core/models/semantic_kitti/linkunet.py:124-185; detection/det3d/models/utils/
 // ts_elk.py:144-230) for gfx950.
 //
-//   k_premix_ln        fin = LayerNorm(F @ Wpre^T): the only GEMM-shaped step -> f32 MFMA
-//                      (v_mfma_f32_16x16x4_f32, exact f32), W staged once per workgroup in LDS
-//                      (row stride padded by 4 dwords: conflict-free ds_read_b128), D = W * F^T so
-//                      that a lane ends up holding 16t+4g+r channels of ONE voxel: the LayerNorm
-//                      reduction is 16 in-lane adds + 2 cross-lane steps, and stores are 16 B/lane.
-//   k_modulate_sum     theta / sincos / modulate / per-block pre-aggregation: one wave per block,
-//                      lanes = channels, voxels of the block visited in ascending id, sums kept in
-//                      registers, ONE non-atomic row write per block.
-//   k_gather_demod_ln  r^3 neighbour-block sum (ids looked up in the dense cell table by lanes
-//                      0..K-1, broadcast with readlane, rows summed in get_kernel_offsets order),
-//                      normalise, then per voxel of the block: de-modulate + LayerNorm + store.
+//   k_premix_ln_tlp      fin = LayerNorm(F @ Wpre^T): the only GEMM-shaped step -> f32 MFMA
+//                        (v_mfma_f32_16x16x4_f32, exact f32), W staged once per workgroup in LDS
+//                        (row stride padded by 4 dwords: conflict-free ds_read_b128), D = W * F^T so
+//                        that a lane ends up holding 16t+4g+r channels of ONE voxel: the LayerNorm
+//                        reduction is 16 in-lane adds + 2 cross-lane steps, and stores are 16 B/lane.
+//   k_modulate_sum_g     theta / sincos / modulate / per-block pre-aggregation: 16-lane groups, each
+//                        walking a run of consecutive blocks, sums in registers in ascending voxel id,
+//                        ONE non-atomic row write per block.
+//   k_block_gather_g     r^3 neighbour-block sum as r column sums with a z-sliding register ring,
+//                        neighbour ids of 8 blocks resolved into LDS in one round trip -> A table.
+//   k_voxel_demod_ln_g   loop-free per-voxel(-pair) de-modulate + LayerNorm + store.
+//   k_gather_demod_ln*   fused gather+demod forms (lane=channel generic fallback for any C / r <= 5,
+//                        and the group form used when no A scratch is supplied).
 //
 // S layout: m_cap rows [part0 C | part1 C | (part2 C)] fp32 (row = P*C floats: 512 B at C=64, i.e.
 // exactly 4 aligned 128-B lines -- the gather is bound by L2->L1 line requests), followed by the
@@ -27,194 +29,10 @@ using namespace link;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static int g_premix_wgs_fwd();
-static int g_premix_ablate_fwd();
-static int g_premix_variant_fwd();
 
 // ---------------------------------------------------------------------------------------------
-// pre_mix + LayerNorm (MFMA path, C in {16,32,48,...,128}, C % 16 == 0)
+// pre_mix + LayerNorm (MFMA path, C % 16 == 0, C <= 128)
 // ---------------------------------------------------------------------------------------------
-template <int C>
-__global__ void __launch_bounds__(256) k_premix_ln_mfma(const float *__restrict__ feats,
-                                                        const float *__restrict__ w_pre,
-                                                        const float *__restrict__ ln_w,
-                                                        const float *__restrict__ ln_b, int64_t n,
-                                                        float eps, float *__restrict__ fin) {
-  constexpr int T = C / 16;       // 16-wide tiles along channels (rows of D) and along k
-  constexpr int LDW = C + 4;      // padded LDS row stride (dwords)
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *w_lds = reinterpret_cast<float *>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  // stage W (row-major [C][C]) into LDS, 16 B per thread per step
-  for (int e = tid * 4; e < C * C; e += 256 * 4) {
-    int r = e / C, col = e - r * C;
-    *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = *reinterpret_cast<const float4 *>(&w_pre[e]);
-  }
-  // per-lane LayerNorm affine for its channels 16t+4g+r
-  float4 lw[T], lb[T];
-#pragma unroll
-  for (int t = 0; t < T; t++) {
-    lw[t] = *reinterpret_cast<const float4 *>(&ln_w[16 * t + 4 * g]);
-    lb[t] = *reinterpret_cast<const float4 *>(&ln_b[16 * t + 4 * g]);
-  }
-  __syncthreads();
-  const int64_t tiles = (n + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t v = tile * 16 + li;
-    const bool ok = v < n;
-    // B operand source: this lane's voxel row, k = 16t + 4g + e
-    float4 f[T];
-#pragma unroll
-    for (int t = 0; t < T; t++)
-      f[t] = ok ? *reinterpret_cast<const float4 *>(&feats[v * C + 16 * t + 4 * g])
-                : make_float4(0.f, 0.f, 0.f, 0.f);
-    floatx4 acc[T];
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < T; t++) {
-#pragma unroll
-      for (int tp = 0; tp < T; tp++) {
-        // A operand: W[16tp + li][16t + 4g + e]
-        float4 a = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * t + 4 * g]);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f[t].x, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f[t].y, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f[t].z, acc[tp], 0, 0, 0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f[t].w, acc[tp], 0, 0, 0);
-      }
-    }
-    // lane holds channels {16tp + 4g + r} of voxel li: LayerNorm over all C channels
-    float s = 0.f;
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) s += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int tp = 0; tp < T; tp++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float d = acc[tp][r] - mean;
-        q += d * d;
-      }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
-    if (ok) {
-#pragma unroll
-      for (int tp = 0; tp < T; tp++) {
-        float4 o;
-        o.x = (acc[tp][0] - mean) * rstd * lw[tp].x + lb[tp].x;
-        o.y = (acc[tp][1] - mean) * rstd * lw[tp].y + lb[tp].y;
-        o.z = (acc[tp][2] - mean) * rstd * lw[tp].z + lb[tp].z;
-        o.w = (acc[tp][3] - mean) * rstd * lw[tp].w + lb[tp].w;
-        *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
-      }
-    }
-  }
-}
-
-// Register-resident variant for C <= 64: the whole W (C*C/64 floats per lane) lives in VGPRs in exactly
-// the A-operand layout, so there is no LDS staging, no barrier, and a wave can start its MFMAs as soon
-// as its own 16 KB of W and first F tile have arrived; the next tile's rows are prefetched while the
-// current tile is in the matrix pipe.
-template <int C>
-__global__ void __launch_bounds__(256) k_premix_ln_reg(const float *__restrict__ feats,
-                                                       const float *__restrict__ w_pre,
-                                                       const float *__restrict__ ln_w,
-                                                       const float *__restrict__ ln_b, int64_t n,
-                                                       float eps, float *__restrict__ fin, int ablate) {
-  constexpr int T = C / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  float4 a[T][T];
-#pragma unroll
-  for (int tp = 0; tp < T; tp++)
-#pragma unroll
-    for (int t = 0; t < T; t++)
-      a[tp][t] = *reinterpret_cast<const float4 *>(&w_pre[(16 * tp + li) * C + 16 * t + 4 * g]);
-  float4 lw[T], lb[T];
-#pragma unroll
-  for (int t = 0; t < T; t++) {
-    lw[t] = *reinterpret_cast<const float4 *>(&ln_w[16 * t + 4 * g]);
-    lb[t] = *reinterpret_cast<const float4 *>(&ln_b[16 * t + 4 * g]);
-  }
-  const int64_t tiles = (n + 15) / 16;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  const int64_t tile0 = (int64_t)blockIdx.x * 4 + wave;
-  // loads are UNCONDITIONAL on a clamped row (tail lanes re-read row n-1; their results are never
-  // stored): predicated loads would force s_waitcnt vmcnt(0).  The loop is unrolled by two with
-  // ping-pong register sets (no register rotation): a rotation copy needs the prefetched data at the
-  // END of the iteration and the resulting vmcnt(0) also waits for the iteration's stores, which
-  // makes load, MFMA and store time purely additive (measured 10.8 + 4.1 + 4.3 us).
-  auto load_tile = [&](int64_t tile, float4 (&f)[T]) {
-    int64_t v = tile * 16 + li;
-    v = (v < n) ? v : n - 1;
-#pragma unroll
-    for (int t = 0; t < T; t++) f[t] = *reinterpret_cast<const float4 *>(&feats[v * C + 16 * t + 4 * g]);
-  };
-  auto do_tile = [&](int64_t tile, const float4 (&f)[T]) {
-    const int64_t v = tile * 16 + li;
-    const bool ok = v < n;
-    floatx4 acc[T];
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){f[tp].x, f[tp].y, f[tp].z, f[tp].w};
-    if (!(ablate & 1)) {
-#pragma unroll
-      for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) {
-          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].x, f[t].x, acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].y, f[t].y, acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].z, f[t].z, acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp][t].w, f[t].w, acc[tp], 0, 0, 0);
-        }
-      }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) s += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int tp = 0; tp < T; tp++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float d = acc[tp][r] - mean;
-        q += d * d;
-      }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
-    if (ok && !(ablate & 2)) {
-#pragma unroll
-      for (int tp = 0; tp < T; tp++) {
-        float4 o;
-        o.x = (acc[tp][0] - mean) * rstd * lw[tp].x + lb[tp].x;
-        o.y = (acc[tp][1] - mean) * rstd * lw[tp].y + lb[tp].y;
-        o.z = (acc[tp][2] - mean) * rstd * lw[tp].z + lb[tp].z;
-        o.w = (acc[tp][3] - mean) * rstd * lw[tp].w + lb[tp].w;
-        *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
-      }
-    }
-  };
-  float4 fa[T], fb[T];
-  if (tile0 < tiles) load_tile(tile0, fa);
-  for (int64_t tile = tile0; tile < tiles; tile += 2 * stride) {
-    if (tile + stride < tiles) load_tile(tile + stride, fb);       // wave-uniform
-    do_tile(tile, fa);
-    if (tile + stride < tiles) {
-      if (tile + 2 * stride < tiles) load_tile(tile + 2 * stride, fa);
-      do_tile(tile + stride, fb);
-    }
-  }
-}
-
 // TLP variant: W staged once per workgroup in LDS (padded rows: conflict-free ds_read_b128), no
 // software pipelining at all -- a wave is load -> 64 MFMA -> LayerNorm -> store per tile, and 5-6
 // resident waves per SIMD overlap each other's phases (register rotation / predication defeat the
@@ -298,19 +116,16 @@ static int launch_premix_tlp(const float *feats, const float *w_pre, const float
   int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 3) / 4;
   if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();
+  if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per kernel (160 KB per CU on gfx950)
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_tlp<C>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done = true;
+    }
+  }
   hipLaunchKernelGGL(k_premix_ln_tlp<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, ln_b, n,
                      eps, fin);
-  return check_launch("link_premix_ln");
-}
-
-template <int C>
-static int launch_premix_reg(const float *feats, const float *w_pre, const float *ln_w, const float *ln_b,
-                             int64_t n, float eps, float *fin, hipStream_t st) {
-  int64_t tiles = (n + 15) / 16;
-  int64_t wgs = (tiles + 3) / 4;
-  if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();   // default 2 waves per SIMD chip-wide; W lives in registers
-  hipLaunchKernelGGL(k_premix_ln_reg<C>, dim3((unsigned)wgs), dim3(256), 0, st, feats, w_pre, ln_w, ln_b, n,
-                     eps, fin, g_premix_ablate_fwd());
   return check_launch("link_premix_ln");
 }
 
@@ -356,20 +171,6 @@ __global__ void __launch_bounds__(256) k_premix_ln_generic(const float *__restri
   }
 }
 
-template <int C>
-static int launch_premix_mfma(const float *feats, const float *w_pre, const float *ln_w,
-                              const float *ln_b, int64_t n, float eps, float *fin, hipStream_t st) {
-  size_t lds = (size_t)C * (C + 4) * sizeof(float);
-  int64_t tiles = (n + 15) / 16;
-  int64_t wgs = (tiles + 3) / 4;
-  int64_t cap = 256 * 4;  // 4 workgroups per CU (LDS: 4 * 17 KB at C=64)
-  if (lds > 40 * 1024) cap = 256 * 2;
-  if (wgs > cap) wgs = cap;
-  hipLaunchKernelGGL(k_premix_ln_mfma<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w,
-                     ln_b, n, eps, fin);
-  return check_launch("link_premix_ln");
-}
-
 extern "C" int link_premix_ln(const float *feats, const float *w_pre, const float *ln_w,
                               const float *ln_b, int64_t n, int32_t c, float eps, float *fin,
                               void *stream) {
@@ -378,14 +179,14 @@ extern "C" int link_premix_ln(const float *feats, const float *w_pre, const floa
   if (!feats || !w_pre || !ln_w || !ln_b || !fin) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
   switch (c) {
-    case 16: return g_premix_variant_fwd() ? launch_premix_tlp<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 32: return g_premix_variant_fwd() ? launch_premix_tlp<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 48: return g_premix_variant_fwd() ? launch_premix_tlp<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 64: return g_premix_variant_fwd() ? launch_premix_tlp<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st) : launch_premix_reg<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 80: return launch_premix_mfma<80>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 112: return launch_premix_mfma<112>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 96: return launch_premix_mfma<96>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
-    case 128: return launch_premix_mfma<128>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 16: return launch_premix_tlp<16>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 32: return launch_premix_tlp<32>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 48: return launch_premix_tlp<48>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 64: return launch_premix_tlp<64>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 80: return launch_premix_tlp<80>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 96: return launch_premix_tlp<96>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 112: return launch_premix_tlp<112>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
+    case 128: return launch_premix_tlp<128>(feats, w_pre, ln_w, ln_b, n, eps, fin, st);
     default: break;
   }
   dim3 grid(blocks_for(n * 64, 256)), block(256);
@@ -555,11 +356,9 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
 // bench/tuning hook, not part of the functional ABI)
 static int g_modsum_wgs = 2048;   // 8 XCDs x 32 CUs x 8 workgroups of 4 waves
 static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one resident round
-static int g_premix_wgs = 512;
+static int g_premix_wgs = 1024;
 static int g_use_group_path = 1;
 static int g_use_pair = 1;
-static int g_premix_ablate = 0;
-static int g_premix_variant = 1;   // 1 = LDS-staged W + occupancy (tlp), 0 = W in registers + ping-pong
 static int g_bgather_wgs = 1024;
 static int g_use_split = 1;
 extern "C" int link_set_tuning(int key, int value) {
@@ -571,8 +370,6 @@ extern "C" int link_set_tuning(int key, int value) {
     case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
     case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
     case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
-    case 8: g_premix_variant = value - 1; return LINK_OK;       // 1 = register-resident W, 2 = LDS-staged W (tlp)
-    case 7: g_premix_ablate = value - 1; return LINK_OK;        // debug: 1 = normal, 2 = no MFMA, 3 = no store, 4 = neither
     case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
     default: return LINK_ERR_ARG;
   }
@@ -894,8 +691,6 @@ extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int
 }
 
 static int g_premix_wgs_fwd() { return g_premix_wgs; }
-static int g_premix_ablate_fwd() { return g_premix_ablate; }
-static int g_premix_variant_fwd() { return g_premix_variant; }
 
 // =============================================================================================
 // Sub-wave ("group") kernels: the fast path for C % 4 == 0.

@@ -1,0 +1,75 @@
+"""The alternative kernel paths of the C ABI must agree: split gather (link_block_gather +
+link_voxel_demod_ln) vs fused group gather vs lane=channel generic gather, and group vs generic
+modulate kernels -- selected through link_set_tuning -- on the same inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err, s_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("C,groups,baseop,s,r", [(64, 2, "cos", 7, 3), (32, 2, "sin", 3, 2), (16, 2, "cos", 7, 3),
+                                                 (128, 2, "cos", 5, 3), (48, 1, "cos_x", 4, 2), (64, 1, "cos_x", 3, 3)])
+def test_kernel_paths_agree(C, groups, baseop, s, r):
+    import link_amd as la
+    from link_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(5)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    n = 9000
+    coords = s_uniform(n, grid=80, seed=C + r).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
+    lo, hi = (0, 0, 0, 0), (79, 79, 79, 0)
+    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device)
+    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+              blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
+    outs = {}
+    try:
+        for name, settings in {"split+group+pair": {3: 1, 4: 1, 6: 1}, "fused-group": {3: 1, 4: 1, 6: 2},
+                               "no-pair": {3: 1, 4: 2, 6: 1}, "generic": {3: 2, 4: 2, 6: 2}}.items():
+            for k, v in settings.items():
+                assert lib.link_set_tuning(k, v) == 0
+            outs[name] = plan.run(feats, coords).clone()
+            assert plan.blocks() > 0
+    finally:
+        for k in (3, 4, 6):
+            lib.link_set_tuning(k, 1)
+    ref = outs["generic"].cpu().numpy()
+    for name, o in outs.items():
+        assert rel_err(o.cpu().numpy(), ref) < 2e-6, name
+    # (paths may differ in the last bit: different fma contraction / summation order per code path)
+
+
+def test_plan_matches_module_and_warm_index():
+    import link_amd as la
+    torch.manual_seed(7)
+    C, n = 64, 20000
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    coords = s_uniform(n, grid=128, seed=11).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
+    plan = la.ElkCorePlan(n, C, "cos", 32, 3, 7, ((0, 0, 0, 0), (127, 127, 127, 0)), feats.device)
+    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+              blk.norm.weight, blk.norm.bias)
+    cold = plan.run(feats, coords, build_index=True).clone()
+    warm = plan.run(feats, coords, build_index=False).clone()
+    assert torch.equal(cold, warm)
+    st = la.SparseTensor(feats, coords, 1)
+    with torch.no_grad():
+        ref = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
+    assert rel_err(cold.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    # a smaller frame through the same plan (capacity reuse), then voxels outside the plan's bounds
+    n2 = 5000
+    out2 = plan.run(feats[:n2].contiguous(), coords[:n2].contiguous())
+    st2 = la.SparseTensor(feats[:n2].contiguous(), coords[:n2].contiguous(), 1)
+    with torch.no_grad():
+        ref2 = blk._core(st2, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
+    assert rel_err(out2.cpu().numpy(), ref2.cpu().numpy()) < 2e-6
+    bad = coords.clone()
+    bad[0, 0] = 500
+    plan.run(feats, bad)
+    with pytest.raises(la._lib.LinkAmdError):
+        plan.blocks()

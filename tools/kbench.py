@@ -39,7 +39,7 @@ stages = {
     "vdemod": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w,
                                               b.ln_b, b.hdr, ctypes.byref(desc), N, b.out, st),
 }
-KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6, "ablate": 7, "pvariant": 8}
+KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6}
 
 
 def time_stage(fn, k=50):
@@ -60,14 +60,7 @@ for arg in sys.argv[1:]:
     key, vals = arg.split("=")
     for v in vals.split(","):
         lib.link_set_tuning(KEYS[key], int(v))
-        if key == "pvariant":
-            lib.link_set_tuning(2, 1536 if int(v) == 2 else 512)
-            for w in ((512, 1024, 1536, 2048) if int(v) == 2 else (256, 512)):
-                lib.link_set_tuning(2, w)
-                print(f"premix variant={v} wgs={w}: {time_stage(stages['premix']):.2f} us")
-        elif key == "ablate":
-            print(f"premix ablate={v}: {time_stage(stages['premix']):.2f} us")
-        elif key in ("group", "pair"):
+        if key in ("group", "pair"):
             print(f"{key}={v}:", {k: round(time_stage(f), 2) for k, f in stages.items() if k in ("modsum", "gather")})
         else:
             print(f"{key} wgs={v}: {time_stage(stages[key]):.2f} us")
