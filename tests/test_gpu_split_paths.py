@@ -38,9 +38,14 @@ def test_kernel_paths_agree(C, groups, baseop, s, r):
     finally:
         for k in (3, 4, 6):
             lib.link_set_tuning(k, 1)
+    # every path within the parity gate of the ORACLE (1e-4 rel), and within 5e-5 of each other
+    from oracle import link_oracle as O
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    oracle = O.elk_core_torch(feats.cpu(), coords.cpu(), params, s, r, baseop, groups, agg=O.aggregate_c).numpy()
     ref = outs["generic"].cpu().numpy()
     for name, o in outs.items():
-        assert rel_err(o.cpu().numpy(), ref) < 2e-6, name
+        assert rel_err(o.cpu().numpy(), oracle) < 1e-4, name
+        assert rel_err(o.cpu().numpy(), ref) < 5e-5, name
     # (paths may differ in the last bit: different fma contraction / summation order per code path)
 
 
