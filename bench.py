@@ -4,6 +4,10 @@
 Step      = one pass of the hot path R_core (pre_mix -> theta -> modulate ->
             voxel_to_aux -> aux_to_voxel -> de-modulate -> norm) over ONE synthetic frame, index
             structures rebuilt inside the step ("cold", as the reference does on every call).
+            Frames are independent (the unit the path shards by), so `--streams` frames are kept in
+            flight on separate HIP streams with separate buffers and NO cross-stream dependency: the
+            kernels of one frame fill the latency bubbles of another's.  `single_stream_value` is the
+            same measurement with one frame in flight.
 Workload  = BASELINE.json configs[1]: 100k unique voxels uniform in a 256^3 grid (S-uniform generator,
             seed = rank), C = 64, baseop cos, groups 2, r = 3, s = 7, fp32.
 N GPUs    = one process per GPU, one independent frame per rank per step, NO data-path collective
@@ -56,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--voxels", type=int, default=100_000)
     ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=3, help="independent frames in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -80,48 +85,56 @@ def main():
     N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
     torch.manual_seed(2)
     blk = la.ELKBlock(C, C, groups=G, baseop="cos").to(dev).eval()
-    coords = s_uniform(N, seed=rank).to(dev)
-    feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-    plan = la.ElkCorePlan(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
-    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
-              None, blk.norm.weight, blk.norm.bias)
-
-    def step(build_index=True):
-        return plan.run(feats, coords, build_index=build_index)
+    NS = max(1, args.streams)
+    frames, plans, streams = [], [], []
+    for k in range(NS):                    # NS distinct frames per rank (seeds differ per rank and slot)
+        seed = rank * 64 + k
+        frames.append((torch.randn(N, C, generator=torch.Generator().manual_seed(1 + seed)).to(dev),
+                       s_uniform(N, seed=seed).to(dev)))
+        pl = la.ElkCorePlan(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
+        pl.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+                None, blk.norm.weight, blk.norm.bias)
+        plans.append(pl)
+        streams.append(torch.cuda.Stream(device=dev))
+    feats, coords = frames[0]
+    plan = plans[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed(k, build_index=True):
+    def timed(k, build_index=True, ns=NS):
+        """EXACTLY k steps (frames), round-robin over `ns` streams; barrier + synchronize on both sides."""
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(k):
-            step(build_index)
+        for i in range(k):
+            j = i % ns
+            with torch.cuda.stream(streams[j]):
+                plans[j].run(frames[j][0], frames[j][1], build_index=build_index)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
         return t1 - t0
 
-    for _ in range(args.warmup):
-        step()
+    timed(max(args.warmup, NS))
     elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt each step)
+    elapsed_single = timed(args.steps, ns=1)         # one frame in flight
     M = plan.blocks()
-    out = step()
+    out = plan.run(feats, coords)
+    torch.cuda.synchronize()
     checksum = float(out.double().sum().item())
-    for _ in range(3):
-        step(False)
     elapsed_warm = timed(args.steps, build_index=False)
 
     # ---- max over ranks + the trivial result gather (per-frame summaries only; link_amd/parallel.py)
     if world > 1:
         from link_amd.parallel import gather_frame_rows
-        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm]],
+        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single]],
                             dtype=torch.float64, device=dev)
         rows = gather_frame_rows(mine).cpu()
         elapsed = float(rows[:, 4].max())
         elapsed_warm = float(rows[:, 5].max())
+        elapsed_single = float(rows[:, 6].max())
         total_vox = float(rows[:, 1].sum())
     else:
         total_vox = float(N)
@@ -200,8 +213,10 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: S-uniform 100k voxels in 256^3, C=64, one LinK "
                                "cos:(3x7)^3 block forward (R_core, index rebuilt every step)",
                    "voxels_per_frame": N, "blocks_per_frame": M, "channels": C, "baseop": "cos", "groups": G,
-                   "r": R, "s": S_, "frames_per_step": world, "parallelism": f"{world} independent frame(s), "
-                   "one per GPU, no data-path collective"},
+                   "r": R, "s": S_, "frames_in_flight_per_gpu": NS,
+                   "parallelism": f"{world} GPU(s) x {NS} independent frames in flight (one HIP stream each), "
+                                  "no data-path collective"},
+        "single_stream_value": round(total_vox * args.steps / elapsed_single, 1),
         "warm_index_value": round(total_vox * args.steps / elapsed_warm, 1),
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -105,3 +105,22 @@ for ov in (0, 1):
     except Exception as e:
         print("graph capture failed (overlap", ov, "):", repr(e)[:300])
 lib.link_set_overlap(0)
+# frame-level concurrency: S independent frames in flight, one plan + one stream each (no events)
+lib.link_set_overlap(0)
+for nstreams in (1, 2, 3, 4):
+    plans, streams, fr = [], [], []
+    for k in range(nstreams):
+        pl = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
+        pl.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+                blk.norm.weight, blk.norm.bias)
+        plans.append(pl); streams.append(torch.cuda.Stream())
+        fr.append((torch.randn(N, C, generator=torch.Generator().manual_seed(10 + k)).to(dev), s_uniform(N, seed=k).to(dev)))
+    torch.cuda.synchronize()
+    def run(K):
+        for it in range(K):
+            k = it % nstreams
+            with torch.cuda.stream(streams[k]):
+                plans[k].run(fr[k][0], fr[k][1], True)
+    run(4 * nstreams); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(240); torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"{nstreams} stream(s): {(t1 - t0) / 240 * 1e6:.1f} us per frame -> {N * 240 / (t1 - t0) / 1e9:.3f} Gvox/s")
