@@ -354,12 +354,13 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
 
 // launch geometry knobs (defaults chosen from measurements in profiles/; link_set_tuning is a
 // bench/tuning hook, not part of the functional ABI)
-static int g_modsum_wgs = 2048;   // 8 XCDs x 32 CUs x 8 workgroups of 4 waves
+static int g_modsum_wgs = 1024;   // chosen by sweep (tools/mstream.py): flat 512..2048, smaller grids co-run better
 static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one resident round
 static int g_premix_wgs = 1024;
 static int g_use_group_path = 1;
 static int g_use_pair = 1;
-static int g_bgather_wgs = 1024;
+static int g_coop_threshold = 4;   // mean voxels/block above which a wave's groups cooperate per block
+static int g_bgather_wgs = 512;
 static int g_use_split = 1;
 extern "C" int link_set_tuning(int key, int value) {
   if (value <= 0) return LINK_ERR_ARG;
@@ -370,6 +371,7 @@ extern "C" int link_set_tuning(int key, int value) {
     case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
     case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
     case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
+    case 7: g_coop_threshold = value; return LINK_OK;
     case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
     default: return LINK_ERR_ARG;
   }
@@ -744,14 +746,14 @@ __device__ __forceinline__ float partner(float v) {
 // high half sincos(theta_B), and the halves swap results with one DPP op per value -- every sincos
 // evaluated once instead of twice.
 template <int LPR, int OP, bool PAIR>
-__global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict__ fin,
-                                                        const int4 *__restrict__ vox_sorted,
-                                                        const float *__restrict__ w_pos,
-                                                        const float *__restrict__ alpha,
-                                                        const int32_t *__restrict__ blk_start,
-                                                        const int32_t *__restrict__ hdr, int c, int cg,
-                                                        float coord_div, float *__restrict__ S,
-                                                        int64_t m_cap) {
+__device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__ fin,
+                                                       const int4 *__restrict__ vox_sorted,
+                                                       const float *__restrict__ w_pos,
+                                                       const float *__restrict__ alpha,
+                                                       const int32_t *__restrict__ blk_start,
+                                                       const int32_t *__restrict__ hdr, int c, int cg,
+                                                       float coord_div, float *__restrict__ S,
+                                                       int64_t m_cap) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int STEP = PAIR ? 2 : 1;
   const int li = (threadIdx.x & 63) & (LPR - 1);
@@ -857,6 +859,121 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
   }
+}
+
+// Large-block mode: the G = 64/LPR groups of a wave COOPERATE on one block -- group q takes voxel
+// steps q, q+G, q+2G, ... of the block's segment (ascending), and the G partial sums are combined with
+// a fixed shuffle tree ((g0+g1)+(g2+g3)), so the result is deterministic.  Used when blocks hold many
+// voxels (LiDAR surfaces: N/M of 5..300), where one group per block would serialise long segments
+// while most groups idle; chosen on the device from N/M (the host never learns M).
+template <int LPR, int OP, bool PAIR>
+__device__ __forceinline__ void modulate_sum_cooperative(const float *__restrict__ fin,
+                                                         const int4 *__restrict__ vox_sorted,
+                                                         const float *__restrict__ w_pos,
+                                                         const float *__restrict__ alpha,
+                                                         const int32_t *__restrict__ blk_start,
+                                                         const int32_t *__restrict__ hdr, int c, int cg,
+                                                         float coord_div, float *__restrict__ S,
+                                                         int64_t m_cap) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int G = 64 / LPR;
+  constexpr int STEP = PAIR ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (LPR - 1), q = lane / LPR;
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const bool hi = PAIR && (li >= LPR / 2);
+  const int cofs = act ? ch0 : 0;
+  int b0, b1;
+  wave_chunk(hdr[LINK_HDR_M], b0, b1);
+  const int rs = P * c;
+  float *__restrict__ Scnt = S + (m_cap + 1) * rs;
+  if (blockIdx.x == 0 && threadIdx.x < LPR) {
+    float *zrow = S + m_cap * rs;
+    if (act)
+      for (int pp = 0; pp < P; pp++) *reinterpret_cast<float4 *>(&zrow[pp * c + ch0]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (li == 0) Scnt[m_cap] = 0.f;
+  }
+  if (b0 >= b1) return;
+  float w0[4], w1[4], w2[4], al[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int tc = act ? (ch0 + e) % cg : 0;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+  }
+  int st = blk_start[b0];
+  for (int b = b0; b < b1; b++) {
+    const int en = blk_start[b + 1];
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int p_last = en - 1;
+    for (int p = st + q * STEP; p < en; p += G * STEP) {        // this group's steps of the segment
+      const bool hasB = PAIR && (p + 1 < en);
+      const int4 rcA = vox_sorted[p], rcB = vox_sorted[(p + 1 <= p_last) ? p + 1 : p_last];
+      const float4 fA = *reinterpret_cast<const float4 *>(&fin[(int64_t)rcA.w * c + cofs]);
+      const float4 fB = *reinterpret_cast<const float4 *>(&fin[(int64_t)rcB.w * c + cofs]);
+      const int4 own = (hi && hasB) ? rcB : rcA;
+      float x = (float)own.x, y = (float)own.y, z = (float)own.z;
+      if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+      const float fvA[4] = {fA.x, fA.y, fA.z, fA.w}, fvB[4] = {fB.x, fB.y, fB.z, fB.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float th = theta_of(x, y, z, w0[e], w1[e], w2[e], al[e]);
+        float sn, cs;
+        sincos_fast(th, sn, cs);
+        float snA = sn, csA = cs, snB = sn, csB = cs;
+        if (PAIR) {
+          const float so = partner<LPR>(sn), co = partner<LPR>(cs);
+          const bool swapped = hi && hasB;
+          snA = swapped ? so : sn; csA = swapped ? co : cs;
+          snB = hi ? sn : so;      csB = hi ? cs : co;
+        }
+        if (OP == LINK_OP_SIN) { a0[e] += fvA[e] * snA; a1[e] += fvA[e] * csA; }
+        else { a0[e] += fvA[e] * csA; a1[e] += fvA[e] * snA; }
+        if (OP == LINK_OP_COSX) a2[e] += fvA[e] * th;
+        if (hasB) {
+          if (OP == LINK_OP_SIN) { a0[e] += fvB[e] * snB; a1[e] += fvB[e] * csB; }
+          else { a0[e] += fvB[e] * csB; a1[e] += fvB[e] * snB; }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {             // fixed combine tree over the G groups
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        a0[e] += __shfl_xor(a0[e], o, 64);
+        a1[e] += __shfl_xor(a1[e], o, 64);
+        if (OP == LINK_OP_COSX) a2[e] += __shfl_xor(a2[e], o, 64);
+      }
+    }
+    if (q == 0) {
+      float *row = S + (int64_t)b * rs;
+      if (act) {
+        *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+      }
+      if (li == 0) Scnt[b] = (float)(en - st);
+    }
+    st = en;
+  }
+}
+
+template <int LPR, int OP, bool PAIR>
+__global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict__ fin,
+                                                        const int4 *__restrict__ vox_sorted,
+                                                        const float *__restrict__ w_pos,
+                                                        const float *__restrict__ alpha,
+                                                        const int32_t *__restrict__ blk_start,
+                                                        const int32_t *__restrict__ hdr, int c, int cg,
+                                                        float coord_div, float *__restrict__ S,
+                                                        int64_t m_cap, int coop_threshold) {
+  // mean voxels per block decides the mode (grid-uniform, read from the device-side header)
+  const int m = hdr[LINK_HDR_M], nv = hdr[LINK_HDR_NVALID];
+  if (LPR < 64 && (int64_t)nv > (int64_t)coop_threshold * (m > 0 ? m : 1))
+    modulate_sum_cooperative<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap);
+  else
+    modulate_sum_per_group<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap);
 }
 
 template <int LPR, int OP, int R, bool PAIR>
@@ -1370,15 +1487,15 @@ static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4
   dim3 grid(g_modsum_wgs), block(256);
   const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && op != LINK_OP_COSX;
   if (op == LINK_OP_COS && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
   else if (op == LINK_OP_SIN && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
   else if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
   else
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
 }
 
 template <int LPR, int OP>

@@ -128,3 +128,29 @@ def test_cfg2_full_size_core():
         core2 = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
     assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
     assert torch.equal(core, core2)                     # deterministic
+
+
+@pytest.mark.parametrize("stride,baseop,groups,s,r", [(1, "cos", 2, 7, 3), (2, "cos_x", 1, 6, 2)])
+def test_core_on_lidar_like_frame(stride, baseop, groups, s, r):
+    """Surface-like sparse frame (large dense grid, few occupied cells, many voxels per block): exercises
+    the multi-tile look-back scan, the cooperative large-block modulate mode and the zero-row gather."""
+    import link_amd as la
+    from helpers import lidar_like
+    torch.manual_seed(4)
+    C = 64
+    coords = torch.from_numpy(lidar_like(40000, seed=3, stride=stride))
+    n = coords.shape[0]
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop, variant="encoder").cuda().eval()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(5))
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                           agg=O.aggregate_c)
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    with torch.no_grad():
+        core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None,
+                         C // groups, float(stride) if baseop == "cos_x" else 1.0)
+    idx = la.link_index_of(st, s)
+    assert idx.M > 0
+    if stride == 1:
+        assert n / idx.M > 4                    # large blocks: the cooperative modulate mode is what ran
+    assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
