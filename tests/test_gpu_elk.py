@@ -130,7 +130,7 @@ def test_cfg2_full_size_core():
     assert torch.equal(core, core2)                     # deterministic
 
 
-@pytest.mark.parametrize("stride,baseop,groups,s,r", [(1, "cos", 2, 7, 3), (2, "cos_x", 1, 6, 2)])
+@pytest.mark.parametrize("stride,baseop,groups,s,r", [(1, "cos", 2, 14, 3), (2, "cos_x", 1, 6, 2)])
 def test_core_on_lidar_like_frame(stride, baseop, groups, s, r):
     """Surface-like sparse frame (large dense grid, few occupied cells, many voxels per block): exercises
     the multi-tile look-back scan, the cooperative large-block modulate mode and the zero-row gather."""
