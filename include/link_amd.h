@@ -256,7 +256,8 @@ int link_voxel_demod_ln(const float *A, const float *fin, const int32_t *vox_sor
                         int64_t n, float *out, void *stream);
 
 /* One-call form of the whole R_core step (what bench.py times): optional index build (section B)
- * followed by the three section-C kernels, all on `stream`, from caller-owned buffers.  Exists so
+ * followed by the section-C kernels (pre_mix, modulate+block-sum, block gather, voxel de-modulate),
+ * all on `stream`, from caller-owned buffers.  Exists so
  * that a host written in an interpreted language pays ONE FFI crossing per LinK block instead of one
  * per kernel.  All pointers are device pointers with the meanings documented above. */
 typedef struct {
@@ -273,13 +274,11 @@ typedef struct {
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
 } link_elk_buffers_t;
 
-/* Launch-geometry tuning hook for bench/profiling (key 0: modulate workgroups, 1: gather workgroups,
- * 2: pre_mix workgroups).  Not needed for correct operation. */
+/* Tuning hook for bench/profiling (value > 0).  Keys: 0/1/2/5 = workgroups of the modulate / fused-gather /
+ * pre_mix / block-gather launches; 3 = 1 group kernels | 2 lane=channel kernels; 4 = 1 voxel-pair sincos
+ * sharing | 2 off; 6 = 1 split gather | 2 fused gather; 7 = mean voxels/block above which the modulate
+ * kernel's groups cooperate per block.  Not needed for correct operation. */
 int link_set_tuning(int key, int value);
-
-/* link_elk_core_forward runs pre_mix on an internal per-device side stream concurrently with the index
- * build (fork/join with events on `stream`); link_set_overlap(0) keeps everything on `stream`. */
-int link_set_overlap(int on);
 
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,

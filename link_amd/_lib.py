@@ -95,7 +95,6 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, POINTER(LinkGrid), c_void_p,
                                      POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
     "link_set_tuning": (c_int, [c_int, c_int]),
-    "link_set_overlap": (c_int, [c_int]),
     "link_elk_core_forward": (c_int, [POINTER(LinkElkBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc),
                                       c_int64, c_int64, c_int32, c_void_p]),
 }

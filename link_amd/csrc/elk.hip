@@ -1645,57 +1645,19 @@ static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const fl
 // ---------------------------------------------------------------------------------------------
 // one-call R_core
 // ---------------------------------------------------------------------------------------------
-// Per-device helper stream + events for the fork/join inside link_elk_core_forward: pre_mix does not
-// depend on the block index, so it runs on a side stream concurrently with the 4 latency-bound index
-// kernels (HIP streams instead of a tracing compiler; works under graph capture as a fork/join).
-// Created lazily, once per device, never destroyed (process lifetime).
-#include <mutex>
-namespace {
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-SideStream g_side[64];
-std::mutex g_side_mu;
-static int g_use_overlap = 0;   // measured: cross-stream fork/join costs more than it hides here (profiles/)
-SideStream *side_stream() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  SideStream &s = g_side[dev];
-  if (!s.stream) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
-      return nullptr;
-  }
-  return &s;
-}
-}  // namespace
-
 extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_grid_t *grid,
                                      const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
                                      int32_t build_index, void *stream) {
   if (!b || !grid || check_desc(desc) != LINK_OK) return LINK_ERR_ARG;
   int rc;
-  SideStream *ss = (build_index && g_use_overlap) ? side_stream() : nullptr;
-  if (ss) {
-    // fork: pre_mix on the side stream, index build on the caller's stream, then join
-    if (hipEventRecord(ss->fork, S(stream)) != hipSuccess) return check_launch("fork record");
-    if (hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess) return check_launch("fork wait");
-    rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, ss->stream);
-    if (rc != LINK_OK) return rc;
-    if (hipEventRecord(ss->join, ss->stream) != hipSuccess) return check_launch("join record");
-  }
   if (build_index) {
     rc = link_index_build(b->coords, n, grid, b->cell_counts, b->scratch, b->scratch_bytes, b->cell_blk,
                           b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->pos_blk, b->blk_start,
                           b->blk_coords, b->counts, b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
-  if (ss) {
-    if (hipStreamWaitEvent(S(stream), ss->join, 0) != hipSuccess) return check_launch("join wait");
-  } else {
-    rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
-    if (rc != LINK_OK) return rc;
-  }
+  rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
+  if (rc != LINK_OK) return rc;
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
   if (rc != LINK_OK) return rc;
@@ -1709,5 +1671,3 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
                               b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, b->out,
                               stream);
 }
-
-extern "C" int link_set_overlap(int on) { g_use_overlap = on ? 1 : 0; return LINK_OK; }

@@ -66,8 +66,7 @@ for arg in sys.argv[1:]:
             print(f"{key} wgs={v}: {time_stage(stages[key]):.2f} us")
 # whole step (one FFI call), cold and warm
 import time
-for ov in (0, 1):
-  lib.link_set_overlap(ov)
+for ov in (0,):
   for cold in (True, False):
     for _ in range(10):
         plan.run(feats, coords, cold)
@@ -82,31 +81,7 @@ print("torch copy [N,C] f32:", round(time_stage(lambda: dst.copy_(src)), 2), "us
 print("torch fill [N,C] f32:", round(time_stage(lambda: dst.fill_(1.0)), 2), "us")
 big = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev); big2 = torch.empty_like(big)
 print("torch copy 256MB:", round(time_stage(lambda: big2.copy_(big), 10), 2), "us (512 MB moved)")
-# hipGraph replay of the whole step (serial and fork/join variants)
-for ov in (0, 1):
-    lib.link_set_overlap(ov)
-    try:
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                plan.run(feats, coords, True)
-            side.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                plan.run(feats, coords, True)
-        torch.cuda.synchronize()
-        for _ in range(10):
-            g.replay()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(200):
-            g.replay()
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        print("graph replay overlap", ov, f"cold step {(t1 - t0) / 200 * 1e6:.1f} us")
-    except Exception as e:
-        print("graph capture failed (overlap", ov, "):", repr(e)[:300])
-lib.link_set_overlap(0)
 # frame-level concurrency: S independent frames in flight, one plan + one stream each (no events)
-lib.link_set_overlap(0)
 for nstreams in (1, 2, 3, 4):
     plans, streams, fr = [], [], []
     for k in range(nstreams):
