@@ -7,7 +7,8 @@ The HIP library (link_amd/lib/liblink_amd.so, ABI in include/link_amd.h) is mand
 CPU or eager-PyTorch fallback.
 """
 from . import _lib, backend, functional
-from .aggregate import aux_to_voxel, large_to_small, link_index_of, small_to_large_v2, voxel_to_aux
+from .aggregate import (aux_to_voxel, large_to_small, link_index_of, small_to_large_v2, upsample_voxel,
+                        voxel_to_aux)
 from .elk import (Conv3d, ELKBlock, ElkCorePlan, SparseConvTensor, TSELKBlock, elk_core_autograd, elk_core_fused, spconv2ts,
                   ts2spconv)
 from .functional import spcount, spdevoxelize, sphash, sphashquery, spvoxelize

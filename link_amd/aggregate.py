@@ -26,7 +26,8 @@ from .index import BlockIndex, GridTooLarge, foreign_neighbor_map
 from .tensor import SparseTensor
 from .utils import get_kernel_offsets
 
-__all__ = ["voxel_to_aux", "aux_to_voxel", "large_to_small", "small_to_large_v2", "link_index_of"]
+__all__ = ["voxel_to_aux", "aux_to_voxel", "large_to_small", "small_to_large_v2", "link_index_of",
+           "upsample_voxel"]
 
 
 def _st():
@@ -175,3 +176,17 @@ def large_to_small(large_x: SparseTensor, stride: int):
 def small_to_large_v2(small_x: SparseTensor, large_x: SparseTensor, idx: torch.Tensor, counts: torch.Tensor):
     """ts_elk.py:84-107: aux_to_voxel with the neighbourhood hard-wired to 3^3."""
     return aux_to_voxel(small_x, large_x, idx, counts, 3)
+
+
+def upsample_voxel(x: SparseTensor, ref_x: SparseTensor) -> SparseTensor:
+    """/root/reference/segmentation/core/models/utils.py:327-340: give every fine voxel of `ref_x` the
+    features of the coarse voxel of `x` that contains it (parent = floor(coord / x.stride)); a fine voxel
+    whose parent is absent gets x.F[-1] exactly as the reference's `x.F[idx_query]` with idx -1 does.
+    Runs on the HIP op kernels (sphash + wait-free sphashquery)."""
+    stride = x.s[0]
+    x_C = torch.cat([torch.div(x.C[:, :3], stride, rounding_mode="floor").int(), x.C[:, 3:]], dim=1)
+    ref_x_C = torch.cat([torch.div(ref_x.C[:, :3], stride, rounding_mode="floor").int(), ref_x.C[:, 3:]], dim=1)
+    idx_query = F.sphashquery(F.sphash(ref_x_C), F.sphash(x_C))
+    new_tensor = SparseTensor(x.F[idx_query], ref_x.C, ref_x.s)
+    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
+    return new_tensor

@@ -98,6 +98,8 @@ struct IndexScratch {
   int32_t *vox_cell;   // [n]
   int32_t *vox_rank;   // [n]
   int32_t *perm_tmp;   // [n]
+  int32_t *pos_tmp;    // [n]  pos_blk stand-in when the caller passes NULL
+  int32_t *cell_start; // [v]  first sorted position of each occupied cell's segment
   unsigned long long *desc;  // [tiles]
   unsigned int *ticket;      // [1] (+pad)
 };
@@ -109,7 +111,7 @@ static inline int64_t scan_tiles(int64_t v) { return (v + SCAN_TILE - 1) / SCAN_
 extern "C" size_t link_index_scratch_bytes(int64_t n, int64_t v) {
   if (n < 0) n = 0;
   if (v < 0) v = 0;
-  return 3 * align256((size_t)n * 4) + align256((size_t)scan_tiles(v) * 8) + 256;
+  return 4 * align256((size_t)n * 4) + align256((size_t)v * 4) + align256((size_t)scan_tiles(v) * 8) + 256;
 }
 
 static IndexScratch carve(void *scratch, int64_t n, int64_t v) {
@@ -118,6 +120,8 @@ static IndexScratch carve(void *scratch, int64_t n, int64_t v) {
   s.vox_cell = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
   s.vox_rank = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
   s.perm_tmp = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
+  s.pos_tmp = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
+  s.cell_start = reinterpret_cast<int32_t *>(p); p += align256((size_t)v * 4);
   s.desc = reinterpret_cast<unsigned long long *>(p); p += align256((size_t)scan_tiles(v) * 8);
   s.ticket = reinterpret_cast<unsigned int *>(p);
   return s;
@@ -148,7 +152,8 @@ __device__ __forceinline__ unsigned long long pack_desc(unsigned flag, unsigned 
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_cell_scan(
     unsigned int *cell_counts, int64_t v, link_grid_t g, unsigned long long *desc, unsigned int *ticket,
-    int64_t tiles, int32_t *__restrict__ cell_blk, int32_t *__restrict__ blk_start,
+    int64_t tiles, int32_t *__restrict__ cell_blk, int32_t *__restrict__ cell_start,
+    int32_t *__restrict__ blk_start,
     int32_t *__restrict__ blk_coords, int32_t *__restrict__ counts, int32_t *__restrict__ hdr) {
   __shared__ unsigned int s_tile;
   __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
@@ -261,6 +266,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_cell_scan(
     if (cell < v) {
       if (cnt[k] != 0u) {
         cell_blk[cell] = (int32_t)occ + 1;
+        cell_start[cell] = (int32_t)vox;
         blk_start[occ] = (int32_t)vox;
         counts[occ] = (int32_t)cnt[k];
         uint32_t cc = (uint32_t)cell;
@@ -282,8 +288,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_cell_scan(
 __global__ void __launch_bounds__(256) k_place(const int32_t *__restrict__ vox_cell,
                                                const int32_t *__restrict__ vox_rank, int64_t n,
                                                const int32_t *__restrict__ cell_blk,
-                                               const int32_t *__restrict__ blk_start,
+                                               const int32_t *__restrict__ cell_start,
                                                int32_t *__restrict__ perm_tmp,
+                                               int32_t *__restrict__ pos_blk_out,
                                                int32_t *__restrict__ vox_blk,
                                                int64_t *__restrict__ idx_query, int32_t *hdr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,8 +298,10 @@ __global__ void __launch_bounds__(256) k_place(const int32_t *__restrict__ vox_c
   int32_t cell = vox_cell[i];
   int32_t blk = -1;
   if (cell >= 0) {
-    blk = cell_blk[cell] - 1;
-    perm_tmp[blk_start[blk] + vox_rank[i]] = (int32_t)i;
+    blk = cell_blk[cell] - 1;                       // one lookup level: both come from the cell
+    const int32_t pos = cell_start[cell] + vox_rank[i];
+    perm_tmp[pos] = (int32_t)i;
+    pos_blk_out[pos] = blk;                         // block of a sorted position (constant over the segment)
   } else {
     atomicOr(&hdr[LINK_HDR_STATUS], 1);
   }
@@ -304,17 +313,16 @@ __global__ void __launch_bounds__(256) k_place(const int32_t *__restrict__ vox_c
 // each position counts its smaller neighbours directly: sum of n_b^2 loads, all L1/L2 hits.
 constexpr int SORT_MAX_SEG = 8192;
 __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ perm_tmp,
-                                                  const int32_t *__restrict__ vox_blk,
+                                                  const int32_t *__restrict__ pos_blk_in,
                                                   const int32_t *__restrict__ blk_start,
                                                   const int32_t *__restrict__ hdr, int64_t n,
                                                   const int4 *__restrict__ coords,
                                                   int32_t *__restrict__ perm,
-                                                  int4 *__restrict__ vox_sorted,
-                                                  int32_t *__restrict__ pos_blk) {
+                                                  int4 *__restrict__ vox_sorted) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || p >= hdr[LINK_HDR_NVALID]) return;
-  int32_t i = perm_tmp[p];
-  int32_t b = vox_blk[i];
+  const int32_t i = perm_tmp[p];
+  const int32_t b = pos_blk_in[p];                  // same hop as perm_tmp (no voxel -> block chase)
   int32_t st = blk_start[b], en = blk_start[b + 1];
   int32_t len = en - st;
   int64_t dst = p;
@@ -328,7 +336,6 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
     int4 c = coords[i];
     vox_sorted[dst] = make_int4(c.x, c.y, c.z, i);
   }
-  if (pos_blk) pos_blk[dst] = b;
 }
 
 extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid,
@@ -356,13 +363,14 @@ extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_gri
                      reinterpret_cast<const int4 *>(coords), n, *grid, cell_counts, sc.vox_cell,
                      sc.vox_rank, sc.desc, tiles, sc.ticket);
   hipLaunchKernelGGL(k_cell_scan, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, st, cell_counts, v,
-                     *grid, sc.desc, sc.ticket, tiles, cell_blk, blk_start, blk_coords, counts, hdr);
+                     *grid, sc.desc, sc.ticket, tiles, cell_blk, sc.cell_start, blk_start, blk_coords, counts, hdr);
   if (n > 0) {
+    int32_t *pb = pos_blk ? pos_blk : sc.pos_tmp;   // needed internally even if the caller does not want it
     hipLaunchKernelGGL(k_place, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.vox_cell, sc.vox_rank, n,
-                       cell_blk, blk_start, sc.perm_tmp, vox_blk, idx_query, hdr);
-    hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, vox_blk,
+                       cell_blk, sc.cell_start, sc.perm_tmp, pb, vox_blk, idx_query, hdr);
+    hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, pb,
                        blk_start, hdr, n, reinterpret_cast<const int4 *>(coords), perm,
-                       reinterpret_cast<int4 *>(vox_sorted), pos_blk);
+                       reinterpret_cast<int4 *>(vox_sorted));
   }
   return check_launch("link_index_build");
 }

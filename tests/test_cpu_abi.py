@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.link_premix_ln(None, None, None, None, 10, 0, 1e-6, None, None) == L.LINK_ERR_ARG
     assert lib.link_premix_ln(None, None, None, None, 10, 512, 1e-6, None, None) == L.LINK_ERR_ARG
     assert lib.link_hash_query_workspace_bytes(1000) >= 2 * 1000 * 12
-    assert lib.link_index_scratch_bytes(1000, 50000) >= 3 * 4000
+    assert lib.link_index_scratch_bytes(1000, 50000) >= 4 * 4000 + 4 * 50000
 
 
 def test_grid_from_bounds_host_logic():

@@ -115,3 +115,24 @@ def test_full_size_properties():
     # against the scalar C oracle on a channel slice
     ref = O.aggregate(x[:, :4].cpu().numpy(), coords.cpu().numpy(), 7, 3)
     assert rel_err(y[:, :4].cpu().numpy(), ref) < 1e-5
+
+
+def test_upsample_voxel():
+    """utils.py:327-340 restated with numpy: parent lookup by coordinate, -1 -> last row."""
+    import link_amd as la
+    rng = np.random.default_rng(0)
+    fine = np.unique(rng.integers(0, 40, (3000, 3)), axis=0).astype(np.int32)
+    fine = np.concatenate([fine, np.zeros((fine.shape[0], 1), np.int32)], 1)
+    stride = 4
+    parents = np.unique(fine[:, :3] // stride, axis=0)
+    keep = parents[rng.random(parents.shape[0]) < 0.8]                 # some parents absent
+    coarse = np.concatenate([keep * stride, np.zeros((keep.shape[0], 1), np.int32)], 1).astype(np.int32)
+    cf = rng.standard_normal((coarse.shape[0], 12)).astype(np.float32)
+    x = la.SparseTensor(dev(cf), dev(coarse), stride)
+    ref_x = la.SparseTensor(torch.zeros(fine.shape[0], 1, device="cuda"), dev(fine), 1)
+    out = la.upsample_voxel(x, ref_x)
+    lut = {tuple(r): i for i, r in enumerate(keep)}
+    idx = np.array([lut.get(tuple(r), -1) for r in fine[:, :3] // stride])
+    assert (idx == -1).any() and (idx >= 0).any()
+    assert np.array_equal(out.F.cpu().numpy(), cf[idx])
+    assert out.s == (1, 1, 1) and out.C is ref_x.C
