@@ -76,4 +76,22 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Output stores of the streaming kernels: write-through (sc1) so the lines leave the XCD's L2 while the
+// kernel is still running instead of waiting, dirty, for the write-back at the kernel boundary
+// (MI355X_MICROARCH.md: boundary "+ B / 6 TB/s when the predecessor leaves B bytes dirty"; "publish-large":
+// plain stores + flush 8.2 us vs sc1 write-through 3.0 us).  The next kernel runs on other XCDs anyway.
+// Inline asm stores are invisible to the compiler's vmcnt bookkeeping; that only makes its later
+// waits conservative (vmcnt retires in order), never too weak.  g_wt_stores toggles it for A/B tests.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float4 *p, float4 v) {
+  const v4f_t x = {v.x, v.y, v.z, v.w};
+  // s_nop 1: a VMEM store of more than 8 bytes needs wait states before its data VGPRs are overwritten;
+  // hipcc pads that hazard for its own instructions but cannot see inside an asm statement.
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store_out(float4 *p, float4 v, bool wt) {
+  if (wt) store_wt(p, v);
+  else *p = v;
+}
+
 }  // namespace link

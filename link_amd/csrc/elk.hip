@@ -29,6 +29,7 @@ using namespace link;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static int g_premix_wgs_fwd();
+static bool g_wt_fwd();
 
 // ---------------------------------------------------------------------------------------------
 // pre_mix + LayerNorm (MFMA path, C % 16 == 0, C <= 128)
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(256) k_premix_ln_tlp(const float *__restrict__
                                                        const float *__restrict__ w_pre,
                                                        const float *__restrict__ ln_w,
                                                        const float *__restrict__ ln_b, int64_t n,
-                                                       float eps, float *__restrict__ fin) {
+                                                       float eps, float *__restrict__ fin, bool wt) {
   constexpr int T = C / 16;
   constexpr int LDW = C + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) k_premix_ln_tlp(const float *__restrict__
         o.y = (acc[tp][1] - mean) * rstd * lw.y + lb.y;
         o.z = (acc[tp][2] - mean) * rstd * lw.z + lb.z;
         o.w = (acc[tp][3] - mean) * rstd * lw.w + lb.w;
-        *reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]) = o;
+        store_out(reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]), o, wt);
       }
     }
   }
@@ -125,7 +126,7 @@ static int launch_premix_tlp(const float *feats, const float *w_pre, const float
     }
   }
   hipLaunchKernelGGL(k_premix_ln_tlp<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, ln_b, n,
-                     eps, fin);
+                     eps, fin, g_wt_fwd());
   return check_launch("link_premix_ln");
 }
 
@@ -359,6 +360,7 @@ static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one 
 static int g_premix_wgs = 1024;
 static int g_use_group_path = 1;
 static int g_use_pair = 1;
+static int g_wt = 15;               // write-through (sc1) output stores: bit0 pre_mix, 1 modulate, 2 block gather, 3 voxel
 static int g_coop_threshold = 4;   // mean voxels/block above which a wave's groups cooperate per block
 static int g_bgather_wgs = 512;
 static int g_use_split = 1;
@@ -372,6 +374,7 @@ extern "C" int link_set_tuning(int key, int value) {
     case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
     case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
     case 7: g_coop_threshold = value; return LINK_OK;
+    case 8: g_wt = value - 1; return LINK_OK;                  // value-1 = bitmask of kernels using sc1 stores
     case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
     default: return LINK_ERR_ARG;
   }
@@ -693,6 +696,7 @@ extern "C" int link_gather_demod_ln(const float *S_, const float *fin, const int
 }
 
 static int g_premix_wgs_fwd() { return g_premix_wgs; }
+static bool g_wt_fwd() { return (g_wt & 1) != 0; }
 
 // =============================================================================================
 // Sub-wave ("group") kernels: the fast path for C % 4 == 0.
@@ -753,7 +757,7 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
                                                        const int32_t *__restrict__ blk_start,
                                                        const int32_t *__restrict__ hdr, int c, int cg,
                                                        float coord_div, float *__restrict__ S,
-                                                       int64_t m_cap) {
+                                                       int64_t m_cap, bool wt) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int STEP = PAIR ? 2 : 1;
   const int li = (threadIdx.x & 63) & (LPR - 1);
@@ -792,9 +796,9 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
   auto flush = [&]() {                            // block finished: one row write, no atomics
     float *row = S + (int64_t)b * rs;
     if (act) {
-      *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-      *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
-      if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0], a0[1], a0[2], a0[3]), wt);
+      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0], a1[1], a1[2], a1[3]), wt);
+      if (OP == LINK_OP_COSX) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0], a2[1], a2[2], a2[3]), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
 #pragma unroll
@@ -853,9 +857,9 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
   {                                               // last block of the chunk
     float *row = S + (int64_t)b * rs;
     if (act) {
-      *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-      *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
-      if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0], a0[1], a0[2], a0[3]), wt);
+      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0], a1[1], a1[2], a1[3]), wt);
+      if (OP == LINK_OP_COSX) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0], a2[1], a2[2], a2[3]), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
   }
@@ -874,7 +878,7 @@ __device__ __forceinline__ void modulate_sum_cooperative(const float *__restrict
                                                          const int32_t *__restrict__ blk_start,
                                                          const int32_t *__restrict__ hdr, int c, int cg,
                                                          float coord_div, float *__restrict__ S,
-                                                         int64_t m_cap) {
+                                                         int64_t m_cap, bool wt) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int G = 64 / LPR;
   constexpr int STEP = PAIR ? 2 : 1;
@@ -967,13 +971,13 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
                                                         const int32_t *__restrict__ blk_start,
                                                         const int32_t *__restrict__ hdr, int c, int cg,
                                                         float coord_div, float *__restrict__ S,
-                                                        int64_t m_cap, int coop_threshold) {
+                                                        int64_t m_cap, int coop_threshold, bool wt) {
   // mean voxels per block decides the mode (grid-uniform, read from the device-side header)
   const int m = hdr[LINK_HDR_M], nv = hdr[LINK_HDR_NVALID];
   if (LPR < 64 && (int64_t)nv > (int64_t)coop_threshold * (m > 0 ? m : 1))
-    modulate_sum_cooperative<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap);
+    modulate_sum_cooperative<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt);
   else
-    modulate_sum_per_group<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap);
+    modulate_sum_per_group<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt);
 }
 
 template <int LPR, int OP, int R, bool PAIR>
@@ -1227,7 +1231,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         const int4 *__restrict__ blk_coords,
                                                         const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                         const int32_t *__restrict__ hdr, int c,
-                                                        int64_t m_cap, float *__restrict__ A_tab) {
+                                                        int64_t m_cap, float *__restrict__ A_tab, bool wt) {
   constexpr int G = 64 / LPR;
   constexpr int R2 = R * R, R3 = R2 * R;
   constexpr int ZLO = -((R + 1) / 2) + 1;
@@ -1361,8 +1365,8 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
         float *arow = A_tab + (int64_t)(bb + jj) * rs;
 #pragma unroll
         for (int pp = 0; pp < P; pp++)
-          *reinterpret_cast<float4 *>(&arow[pp * c + ch0]) =
-              make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden);   // utils.py:80
+          store_out(reinterpret_cast<float4 *>(&arow[pp * c + ch0]),
+                    make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden), wt);   // utils.py:80
       }
     }
   }
@@ -1373,7 +1377,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     const float *__restrict__ A_tab, const float *__restrict__ fin, const int4 *__restrict__ vox_sorted,
     const int32_t *__restrict__ pos_blk, const float *__restrict__ w_pos, const float *__restrict__ alpha,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, const int32_t *__restrict__ hdr, int c,
-    int cg, float coord_div, float eps, float *__restrict__ out) {
+    int cg, float coord_div, float eps, float *__restrict__ out, bool wt) {
   constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
   constexpr int G = 64 / LPR;
   constexpr int STEP = PAIR ? 2 : 1;
@@ -1462,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     o.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
     o.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2];
     o.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
-    *reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]) = o;
+    store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]), o, wt);
   }
   if (PAIR && act && hasB) {
     float4 o;
@@ -1470,7 +1474,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     o.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
     o.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2];
     o.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
-    *reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]) = o;
+    store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]), o, wt);
   }
 }
 
@@ -1487,15 +1491,15 @@ static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4
   dim3 grid(g_modsum_wgs), block(256);
   const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && op != LINK_OP_COSX;
   if (op == LINK_OP_COS && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
   else if (op == LINK_OP_SIN && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
   else if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
   else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
   else
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold);
+    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
 }
 
 template <int LPR, int OP>
@@ -1543,9 +1547,9 @@ static void launch_block_gather(int r, hipStream_t st, const float *S_, const in
                                 int64_t m_cap, float *A) {
   dim3 grid(g_bgather_wgs), block(256);
   switch (r) {
-    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
-    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
-    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A); break;
+    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
+    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
+    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
   }
 }
 
@@ -1585,7 +1589,7 @@ static void launch_voxel_demod(const link_elk_desc_t &d, int64_t n, hipStream_t 
   dim3 grid((unsigned)wgs), block(256);
 #define LINK_VD(OPP, PP)                                                                                  \
   hipLaunchKernelGGL((k_voxel_demod_ln_g<LPR, OPP, PP>), grid, block, 0, st, A, fin, vox, pos_blk, w_pos,  \
-                     alpha, ln_w, ln_b, hdr, d.c, d.cg, d.coord_div, d.eps, out)
+                     alpha, ln_w, ln_b, hdr, d.c, d.cg, d.coord_div, d.eps, out, (g_wt & 8) != 0)
   if (d.op == LINK_OP_COS) { if (pair) LINK_VD(LINK_OP_COS, true); else LINK_VD(LINK_OP_COS, false); }
   else if (d.op == LINK_OP_SIN) { if (pair) LINK_VD(LINK_OP_SIN, true); else LINK_VD(LINK_OP_SIN, false); }
   else LINK_VD(LINK_OP_COSX, false);

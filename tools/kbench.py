@@ -39,7 +39,7 @@ stages = {
     "vdemod": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w,
                                               b.ln_b, b.hdr, ctypes.byref(desc), N, b.out, st),
 }
-KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6}
+KEYS = {"modsum": 0, "gather": 1, "premix": 2, "group": 3, "pair": 4, "bgather": 5, "split": 6, "wt": 8}
 
 
 def time_stage(fn, k=50):
@@ -60,7 +60,9 @@ for arg in sys.argv[1:]:
     key, vals = arg.split("=")
     for v in vals.split(","):
         lib.link_set_tuning(KEYS[key], int(v))
-        if key in ("group", "pair"):
+        if key == "wt":
+            print(f"wt={v}:", {k: round(time_stage(f), 2) for k, f in stages.items() if k in ("premix", "modsum", "bgather", "vdemod")})
+        elif key in ("group", "pair"):
             print(f"{key}={v}:", {k: round(time_stage(f), 2) for k, f in stages.items() if k in ("modsum", "gather")})
         else:
             print(f"{key} wgs={v}: {time_stage(stages[key]):.2f} us")
