@@ -154,3 +154,33 @@ def test_core_on_lidar_like_frame(stride, baseop, groups, s, r):
     if stride == 1:
         assert n / idx.M > 4                    # large blocks: the cooperative modulate mode is what ran
     assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_core_multi_frame_batch_and_repeatability():
+    """Two frames in one SparseTensor (batch column 0/1): blocks never mix frames (the batch index is part
+    of the block key, utils.py:45); per-frame results equal the frames run alone; 20 repeated runs are
+    bitwise identical (write-through stores + L2 state must not leak between launches)."""
+    import link_amd as la
+    torch.manual_seed(6)
+    C, s, r = 64, 7, 3
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    c0, c1 = s_uniform(7000, grid=64, seed=21), s_uniform(9000, grid=64, seed=22, batch=1)
+    coords = torch.cat([c0, c1], 0)
+    perm = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(1))
+    coords = coords[perm].contiguous()                      # frames interleaved
+    feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(2))
+
+    def core(f, c):
+        st = la.SparseTensor(f.cuda(), c.cuda(), 1)
+        with torch.no_grad():
+            return blk._core(st, s, r, blk.pos_weight[0].weight, None, C // 2, 1.0)
+    both = core(feats, coords)
+    for b in (0, 1):
+        sel = coords[:, 3] == b
+        alone = core(feats[sel].contiguous(), coords[sel].contiguous())
+        assert rel_err(both[sel.cuda()].cpu().numpy(), alone.cpu().numpy()) < 2e-6
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords, params, s, r, "cos", 2, agg=O.aggregate_c)
+    assert rel_err(both.cpu().numpy(), ref.numpy()) < TOL
+    for _ in range(20):
+        assert torch.equal(core(feats, coords), both)

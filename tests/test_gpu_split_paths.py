@@ -78,3 +78,34 @@ def test_plan_matches_module_and_warm_index():
     plan.run(feats, bad)
     with pytest.raises(la._lib.LinkAmdError):
         plan.blocks()
+
+
+def test_plan_is_hipgraph_capturable():
+    """The one-call step allocates nothing and never syncs, so it can be captured in a hipGraph (how a
+    serving loop would replay it) and the replay reproduces the eager result bit for bit."""
+    import link_amd as la
+    torch.manual_seed(8)
+    C, n = 64, 15000
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    coords = s_uniform(n, grid=100, seed=12).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(6)).cuda()
+    plan = la.ElkCorePlan(n, C, "cos", 32, 3, 7, ((0, 0, 0, 0), (99, 99, 99, 0)), feats.device)
+    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+              blk.norm.weight, blk.norm.bias)
+    eager = plan.run(feats, coords).clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        plan.run(feats, coords)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.run(feats, coords)
+    torch.cuda.synchronize()
+    plan.out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.out[:n], eager)
+    feats.mul_(2.0)                      # same buffers, new contents: the graph recomputes from them
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.out[:n], plan.run(feats, coords))
