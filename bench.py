@@ -75,10 +75,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in the product)")
+    # LINK_BENCH_BACKEND=gloo lets several ranks share one GPU (debugging the N>1 logic on a 1-GPU box);
+    # the real multi-GPU run uses "nccl" (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("LINK_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import link_amd as la
 
@@ -130,7 +137,7 @@ def main():
     if world > 1:
         from link_amd.parallel import gather_frame_rows
         mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single]],
-                            dtype=torch.float64, device=dev)
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         rows = gather_frame_rows(mine).cpu()
         elapsed = float(rows[:, 4].max())
         elapsed_warm = float(rows[:, 5].max())

@@ -80,16 +80,23 @@ def count_cuda(idx: torch.Tensor, s: int) -> torch.Tensor:
     return out
 
 
+_FLOAT_TYPES = (torch.float32, torch.float16, torch.bfloat16, torch.float64)
+
+
 def _f32(t, name):
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name}: fp32 features expected, got {t.dtype}")
-    return t.contiguous()
+    """Features may arrive as half / bfloat16 / double (the reference dispatches
+    AT_DISPATCH_FLOATING_TYPES_AND_HALF, voxelize_cuda.cu:52): computed in fp32 here, results are
+    returned in the caller's dtype."""
+    if t.dtype not in _FLOAT_TYPES:
+        raise ValueError(f"{name}: floating-point features expected, got {t.dtype}")
+    return t.contiguous().float()
 
 
 def voxelize_forward_cuda(inputs: torch.Tensor, idx: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     """voxelize_forward_cuda(in fp[N,c], idx i32[N], counts i32[N1]) -> fp[N1,c]
     (backend/voxelize/voxelize_cuda.cu:44-61)."""
     _need_gpu(inputs, idx, counts)
+    dt = inputs.dtype
     inputs = _f32(inputs, "voxelize_forward_cuda")
     idx, counts = idx.contiguous(), counts.contiguous()
     if idx.dtype != torch.int32 or counts.dtype != torch.int32:
@@ -99,20 +106,21 @@ def voxelize_forward_cuda(inputs: torch.Tensor, idx: torch.Tensor, counts: torch
     out = torch.empty((n1, c), dtype=torch.float32, device=inputs.device)
     L.check(L.lib().link_voxelize_forward(_p(inputs), _p(idx), _p(counts), n, c, n1, _p(out), _stream()),
             "voxelize_forward_cuda")
-    return out
+    return out.to(dt)
 
 
 def voxelize_backward_cuda(top_grad: torch.Tensor, idx: torch.Tensor, counts: torch.Tensor,
                            N: int) -> torch.Tensor:
     """voxelize_backward_cuda(top fp[N1,c], idx, counts, N) -> fp[N,c]  (voxelize_cuda.cu:63-80)."""
     _need_gpu(top_grad, idx, counts)
+    dt = top_grad.dtype
     top_grad = _f32(top_grad, "voxelize_backward_cuda")
     idx, counts = idx.contiguous(), counts.contiguous()
     c = top_grad.shape[1]
     out = torch.empty((int(N), c), dtype=torch.float32, device=top_grad.device)
     L.check(L.lib().link_voxelize_backward(_p(top_grad), _p(idx), _p(counts), int(N), c, _p(out), _stream()),
             "voxelize_backward_cuda")
-    return out
+    return out.to(dt)
 
 
 def devoxelize_forward_cuda(feat: torch.Tensor, indices: torch.Tensor, weight: torch.Tensor,
@@ -120,6 +128,7 @@ def devoxelize_forward_cuda(feat: torch.Tensor, indices: torch.Tensor, weight: t
     """devoxelize_forward_cuda(feat fp[n,c], ind i32[N,r^3], w fp[N,r^3], r) -> fp[N,c]
     (backend/devoxelize/devoxelize_cuda.cu:63-81)."""
     _need_gpu(feat, indices, weight)
+    dt = feat.dtype
     feat, weight = _f32(feat, "devoxelize_forward_cuda"), _f32(weight, "devoxelize_forward_cuda")
     indices = indices.contiguous()
     if indices.dtype != torch.int32 or indices.ndim != 2 or indices.shape[1] != int(r) ** 3:
@@ -129,13 +138,14 @@ def devoxelize_forward_cuda(feat: torch.Tensor, indices: torch.Tensor, weight: t
     out = torch.empty((nq, c), dtype=torch.float32, device=feat.device)
     L.check(L.lib().link_devoxelize_forward(_p(feat), _p(indices), _p(weight), nq, c, k, _p(out), _stream()),
             "devoxelize_forward_cuda")
-    return out
+    return out.to(dt)
 
 
 def devoxelize_backward_cuda(top_grad: torch.Tensor, indices: torch.Tensor, weight: torch.Tensor,
                              n: int, r: int) -> torch.Tensor:
     """devoxelize_backward_cuda(top fp[N,c], ind, w, n, r) -> fp[n,c]  (devoxelize_cuda.cu:85-101)."""
     _need_gpu(top_grad, indices, weight)
+    dt = top_grad.dtype
     top_grad, weight = _f32(top_grad, "devoxelize_backward_cuda"), _f32(weight, "devoxelize_backward_cuda")
     indices = indices.contiguous()
     nq, k = indices.shape
@@ -143,7 +153,7 @@ def devoxelize_backward_cuda(top_grad: torch.Tensor, indices: torch.Tensor, weig
     out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
     L.check(L.lib().link_devoxelize_backward(_p(top_grad), _p(indices), _p(weight), nq, int(n), c, k,
                                              _p(out), _stream()), "devoxelize_backward_cuda")
-    return out
+    return out.to(dt)
 
 
 __all__ = ["hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda", "voxelize_forward_cuda",

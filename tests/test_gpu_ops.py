@@ -103,3 +103,24 @@ def test_devoxelize(nq, n, c, r):
     top = rng.standard_normal((nq, c)).astype(np.float32)
     out.backward(dev(top))
     assert rel_err(f.grad.cpu().numpy(), O.spdevoxelize_bwd(top, ind, w, n)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float64])
+def test_backend_dtype_parity(dt):
+    """The backend accepts the dtypes the reference dispatches and returns the caller's dtype
+    (accumulation is always fp32)."""
+    from link_amd import backend as B
+    rng = np.random.default_rng(3)
+    n, c, n1 = 2000, 32, 200
+    idx = rng.integers(0, n1, n).astype(np.int32)
+    counts = O.spcount(idx, n1)
+    feats = rng.standard_normal((n, c)).astype(np.float32)
+    out = B.voxelize_forward_cuda(dev(feats).to(dt), dev(idx), dev(counts))
+    assert out.dtype == dt
+    ref = O.spvoxelize_fwd(dev(feats).to(dt).float().cpu().numpy(), idx, counts)
+    tol = {torch.float16: 2e-3, torch.bfloat16: 2e-2, torch.float64: 1e-6}[dt]
+    assert rel_err(out.float().cpu().numpy(), ref) < tol
+    ind = rng.integers(-1, n1, (300, 8)).astype(np.int32)
+    w = rng.random((300, 8)).astype(np.float32)
+    dv = B.devoxelize_forward_cuda(out, dev(ind), dev(w).to(dt), 2)
+    assert dv.dtype == dt and dv.shape == (300, c)
