@@ -109,3 +109,30 @@ def test_plan_is_hipgraph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(plan.out[:n], plan.run(feats, coords))
+
+
+def test_alternating_frames_through_one_plan():
+    """Stale-cache check for the write-through stores: two DIFFERENT frames alternate through the same
+    plan buffers (so every intermediate buffer changes content between launches); each result must equal
+    the one computed through a separate, fresh plan."""
+    import link_amd as la
+    torch.manual_seed(9)
+    C, n = 64, 30000
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    bounds = ((0, 0, 0, 0), (127, 127, 127, 0))
+
+    def mkplan():
+        p = la.ElkCorePlan(n, C, "cos", 32, 3, 7, bounds, torch.device("cuda"))
+        return p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+                      None, blk.norm.weight, blk.norm.bias)
+    frames = []
+    for k in range(2):
+        coords = s_uniform(n - 5000 * k, grid=128, seed=30 + k).cuda()
+        feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(40 + k)).cuda()
+        want = mkplan().run(feats, coords).clone()
+        frames.append((feats, coords, want))
+    shared = mkplan()
+    for it in range(40):
+        feats, coords, want = frames[it % 2]
+        got = shared.run(feats, coords)
+        assert torch.equal(got, want), it
