@@ -284,6 +284,34 @@ int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_g
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           int32_t build_index, void *stream);
 
+/* Training form of the middle of R_core (linkunet.py:151-176 / linkencoder.py:151-176 / ts_elk.py:166-214
+ * between `pre_mix` and `self.norm`): new = demodulate(aux_to_voxel(voxel_to_aux(modulate(fin)))).  The
+ * reference differentiates this through VoxelizeFunction.backward / DevoxelizeFunction.backward
+ * (voxelize.py:34-50, devoxelize.py:76-93; voxelize_cuda.cu:28-42, devoxelize_cuda.cu:37-59: fp
+ * atomicAdd scatter) plus torch autograd of the sin/cos/mul/cat graph; here forward and backward are
+ * three kernels each, deterministic (no atomics).  The two LayerNorms and the pre_mix Linear stay with
+ * the host framework's autograd.  Requires C % 4 == 0 and r <= 3 (LINK_ERR_ARG otherwise: the host
+ * falls back to its op-by-op differentiable composition).
+ *
+ * forward:  S scratch fp[(m_cap+1)*(P*C+1)]; A fp[m_cap, P*C] and den fp[m_cap] (region voxel counts)
+ *           are SAVED for backward; out fp[N,C] = new (before self.norm).
+ * backward: g_out fp[N,C] = d/d(new); S, gS fp[m_cap, P*C] scratch; g_fin fp[N,C]; partials
+ *           fp[link_elk_mid_partial_rows(), 4, C]: per-workgroup partial sums of
+ *           [d/d(alpha-tiled) | d/d(w_pos[:,0]) | d/d(w_pos[:,1]) | d/d(w_pos[:,2])] per channel; the host
+ *           sums rows and folds channels ch -> ch % cg (theta is tiled, linkunet.py:154). */
+int link_elk_mid_forward(const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                         const int32_t *blk_start, const int32_t *blk_coords, const int32_t *cell_blk,
+                         const link_grid_t *grid /* host */, const int32_t *hdr, const float *w_pos,
+                         const float *alpha, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
+                         float *S, float *A, float *den, float *out, void *stream);
+int32_t link_elk_mid_partial_rows(void);
+int link_elk_mid_backward(const float *g_out, const float *fin, const float *A, const float *den,
+                          const int32_t *vox_sorted, const int32_t *pos_blk, const int32_t *blk_start,
+                          const int32_t *blk_coords, const int32_t *cell_blk,
+                          const link_grid_t *grid /* host */, const int32_t *hdr, const float *w_pos,
+                          const float *alpha, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
+                          float *S, float *gS, float *g_fin, float *partials, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,11 @@ SIGNATURES = {
     "link_set_tuning": (c_int, [c_int, c_int]),
     "link_elk_core_forward": (c_int, [POINTER(LinkElkBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc),
                                       c_int64, c_int64, c_int32, c_void_p]),
+    "link_elk_mid_forward": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
+                                     POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
+    "link_elk_mid_partial_rows": (c_int32, []),
+    "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
+                                      POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }
 
 _lib = None

@@ -395,7 +395,8 @@ static void launch_modsum(int op, hipStream_t st, const float *fin, const int4 *
 
 static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
                               const float *w_pos, const float *alpha, const int32_t *blk_start,
-                              const int32_t *hdr, float *S_, int64_t m_cap);
+                              const int32_t *hdr, float *S_, int64_t m_cap, int op = -1,
+                              const float *row_den = nullptr);
 static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const float *S_, const float *fin,
                               const int4 *vox, const float *w_pos, const float *alpha, const float *ln_w,
                               const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
@@ -745,6 +746,23 @@ __device__ __forceinline__ float partner(float v) {
   return __shfl_xor(v, LPR / 2, 64);
 }
 
+// Internal op codes of the modulate kernel beyond LINK_OP_*: the BACKWARD forms.  d(new)/d(v) of the
+// de-modulation is [cos, sin] (cos), [cos, -sin] (sin), [cos, sin, 1] (cos_x), so the gradient of the
+// block table is the same segmented block sum with these factors applied to grad(new).
+#define LINK_OPI_SIN_BWD 3
+#define LINK_OPI_COSX_BWD 4
+template <int OP>
+struct op_parts { static constexpr int value = (OP == LINK_OP_COSX || OP == LINK_OPI_COSX_BWD) ? 3 : 2; };
+
+template <int OP>
+__device__ __forceinline__ void mod_accum(float &a0, float &a1, float &a2, float f, float sn, float cs, float th) {
+  if (OP == LINK_OP_SIN) { a0 += f * sn; a1 += f * cs; }
+  else if (OP == LINK_OPI_SIN_BWD) { a0 += f * cs; a1 -= f * sn; }
+  else { a0 += f * cs; a1 += f * sn; }
+  if (OP == LINK_OP_COSX) a2 += f * th;
+  if (OP == LINK_OPI_COSX_BWD) a2 += f;
+}
+
 // PAIR (channel j and j + C/2 share theta, i.e. groups == 2 and the row fills its lanes exactly):
 // a step handles TWO consecutive voxels A,B; the low half of the group evaluates sincos(theta_A), the
 // high half sincos(theta_B), and the halves swap results with one DPP op per value -- every sincos
@@ -757,8 +775,9 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
                                                        const int32_t *__restrict__ blk_start,
                                                        const int32_t *__restrict__ hdr, int c, int cg,
                                                        float coord_div, float *__restrict__ S,
-                                                       int64_t m_cap, bool wt) {
-  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+                                                       int64_t m_cap, bool wt,
+                                                       const float *__restrict__ row_den) {
+  constexpr int P = op_parts<OP>::value;
   constexpr int STEP = PAIR ? 2 : 1;
   const int li = (threadIdx.x & 63) & (LPR - 1);
   const int ch0 = 4 * li;
@@ -795,10 +814,11 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
   auto ld_row = [&](int i) { return *reinterpret_cast<const float4 *>(&fin[(int64_t)i * c + cofs]); };
   auto flush = [&]() {                            // block finished: one row write, no atomics
     float *row = S + (int64_t)b * rs;
+    const float k = row_den ? 1.0f / row_den[b] : 1.0f;    // backward: rows pre-divided by the forward's denominator
     if (act) {
-      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0], a0[1], a0[2], a0[3]), wt);
-      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0], a1[1], a1[2], a1[3]), wt);
-      if (OP == LINK_OP_COSX) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0], a2[1], a2[2], a2[3]), wt);
+      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
+      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
+      if (P == 3) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
 #pragma unroll
@@ -837,29 +857,23 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
     {
       const float fv[4] = {fcA.x, fcA.y, fcA.z, fcA.w};
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (OP == LINK_OP_SIN) { a0[e] += fv[e] * snA[e]; a1[e] += fv[e] * csA[e]; }
-        else { a0[e] += fv[e] * csA[e]; a1[e] += fv[e] * snA[e]; }
-        if (OP == LINK_OP_COSX) a2[e] += fv[e] * thA[e];
-      }
+      for (int e = 0; e < 4; e++) mod_accum<OP>(a0[e], a1[e], a2[e], fv[e], snA[e], csA[e], thA[e]);
     }
-    if (hasB) {
+    if (hasB) {                                   // PAIR forms have no third part (never cos_x)
       if (p + 1 == seg_end) flush();
       const float fv[4] = {fcB.x, fcB.y, fcB.z, fcB.w};
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (OP == LINK_OP_SIN) { a0[e] += fv[e] * snB[e]; a1[e] += fv[e] * csB[e]; }
-        else { a0[e] += fv[e] * csB[e]; a1[e] += fv[e] * snB[e]; }
-      }
+      for (int e = 0; e < 4; e++) mod_accum<OP>(a0[e], a1[e], a2[e], fv[e], snB[e], csB[e], 0.f);
     }
     rcA = rnA; rcB = rnB; rnA = r2A; rnB = r2B; fcA = fnA; fcB = fnB;
   }
   {                                               // last block of the chunk
     float *row = S + (int64_t)b * rs;
+    const float k = row_den ? 1.0f / row_den[b] : 1.0f;
     if (act) {
-      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0], a0[1], a0[2], a0[3]), wt);
-      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0], a1[1], a1[2], a1[3]), wt);
-      if (OP == LINK_OP_COSX) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0], a2[1], a2[2], a2[3]), wt);
+      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
+      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
+      if (P == 3) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
   }
@@ -878,8 +892,9 @@ __device__ __forceinline__ void modulate_sum_cooperative(const float *__restrict
                                                          const int32_t *__restrict__ blk_start,
                                                          const int32_t *__restrict__ hdr, int c, int cg,
                                                          float coord_div, float *__restrict__ S,
-                                                         int64_t m_cap, bool wt) {
-  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+                                                         int64_t m_cap, bool wt,
+                                                         const float *__restrict__ row_den) {
+  constexpr int P = op_parts<OP>::value;
   constexpr int G = 64 / LPR;
   constexpr int STEP = PAIR ? 2 : 1;
   const int lane = threadIdx.x & 63;
@@ -932,13 +947,8 @@ __device__ __forceinline__ void modulate_sum_cooperative(const float *__restrict
           snA = swapped ? so : sn; csA = swapped ? co : cs;
           snB = hi ? sn : so;      csB = hi ? cs : co;
         }
-        if (OP == LINK_OP_SIN) { a0[e] += fvA[e] * snA; a1[e] += fvA[e] * csA; }
-        else { a0[e] += fvA[e] * csA; a1[e] += fvA[e] * snA; }
-        if (OP == LINK_OP_COSX) a2[e] += fvA[e] * th;
-        if (hasB) {
-          if (OP == LINK_OP_SIN) { a0[e] += fvB[e] * snB; a1[e] += fvB[e] * csB; }
-          else { a0[e] += fvB[e] * csB; a1[e] += fvB[e] * snB; }
-        }
+        mod_accum<OP>(a0[e], a1[e], a2[e], fvA[e], snA, csA, th);
+        if (hasB) mod_accum<OP>(a0[e], a1[e], a2[e], fvB[e], snB, csB, 0.f);
       }
     }
 #pragma unroll
@@ -947,15 +957,16 @@ __device__ __forceinline__ void modulate_sum_cooperative(const float *__restrict
       for (int e = 0; e < 4; e++) {
         a0[e] += __shfl_xor(a0[e], o, 64);
         a1[e] += __shfl_xor(a1[e], o, 64);
-        if (OP == LINK_OP_COSX) a2[e] += __shfl_xor(a2[e], o, 64);
+        if (P == 3) a2[e] += __shfl_xor(a2[e], o, 64);
       }
     }
     if (q == 0) {
       float *row = S + (int64_t)b * rs;
+      const float k = row_den ? 1.0f / row_den[b] : 1.0f;
       if (act) {
-        *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-        *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
-        if (OP == LINK_OP_COSX) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+        *reinterpret_cast<float4 *>(&row[ch0]) = make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k);
+        *reinterpret_cast<float4 *>(&row[c + ch0]) = make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k);
+        if (P == 3) *reinterpret_cast<float4 *>(&row[2 * c + ch0]) = make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k);
       }
       if (li == 0) Scnt[b] = (float)(en - st);
     }
@@ -971,13 +982,14 @@ __global__ void __launch_bounds__(256) k_modulate_sum_g(const float *__restrict_
                                                         const int32_t *__restrict__ blk_start,
                                                         const int32_t *__restrict__ hdr, int c, int cg,
                                                         float coord_div, float *__restrict__ S,
-                                                        int64_t m_cap, int coop_threshold, bool wt) {
+                                                        int64_t m_cap, int coop_threshold, bool wt,
+                                                        const float *__restrict__ row_den) {
   // mean voxels per block decides the mode (grid-uniform, read from the device-side header)
   const int m = hdr[LINK_HDR_M], nv = hdr[LINK_HDR_NVALID];
   if (LPR < 64 && (int64_t)nv > (int64_t)coop_threshold * (m > 0 ? m : 1))
-    modulate_sum_cooperative<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt);
+    modulate_sum_cooperative<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt, row_den);
   else
-    modulate_sum_per_group<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt);
+    modulate_sum_per_group<LPR, OP, PAIR>(fin, vox_sorted, w_pos, alpha, blk_start, hdr, c, cg, coord_div, S, m_cap, wt, row_den);
 }
 
 template <int LPR, int OP, int R, bool PAIR>
@@ -1231,10 +1243,16 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         const int4 *__restrict__ blk_coords,
                                                         const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                         const int32_t *__restrict__ hdr, int c,
-                                                        int64_t m_cap, float *__restrict__ A_tab, bool wt) {
+                                                        int64_t m_cap, float *__restrict__ A_tab, bool wt,
+                                                        int flags, float *__restrict__ den_out) {
+  // flags bit0: TRANSPOSED neighbourhood (offsets negated: the blocks whose region contains this one --
+  // what the backward pass gathers; identical for odd r); bit1: plain sum, no division by the count.
   constexpr int G = 64 / LPR;
   constexpr int R2 = R * R, R3 = R2 * R;
-  constexpr int ZLO = -((R + 1) / 2) + 1;
+  constexpr int ZLO_F = -((R + 1) / 2) + 1;
+  const bool tr = (flags & 1) != 0;
+  const int ZLO = tr ? -(ZLO_F + R - 1) : ZLO_F;
+  const int sgn = tr ? -1 : 1;
   constexpr int SUB = 8;
   __shared__ uint32_t s_nb[4 * G][SUB * R3];       // BYTE offsets of the neighbour rows (zero row if absent)
   __shared__ int4 s_bc[4 * G][SUB];
@@ -1280,7 +1298,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
       int ox, oy;
       plane_offset<R>(t, ox, oy);
       const int4 bc = blk_coords[bb + j];
-      const int32_t cell = cell_of(g, bc.x + ox, bc.y + oy, bc.z + ZLO + d, bc.w);
+      const int32_t cell = cell_of(g, bc.x + sgn * ox, bc.y + sgn * oy, bc.z + ZLO + d, bc.w);
       const int32_t id = (cell >= 0) ? cell_blk[cell] - 1 : -1;
       my_nb[e] = (id >= 0) ? (uint32_t)id : zero_row;
     }
@@ -1360,7 +1378,8 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
 #pragma unroll
           for (int e = 0; e < 4; e++) Av[pp][e] += col[sl][pp][e];
       }
-      const float rden = 1.0f / den;                 // den is an exact small integer; x*(1/d) vs x/d: <= 1 ulp
+      const float rden = (flags & 2) ? 1.0f : 1.0f / den;   // den is an exact small integer; x*(1/d) vs x/d: <= 1 ulp
+      if (den_out && on && li == 0) den_out[bb + jj] = den;
       if (on && act) {
         float *arow = A_tab + (int64_t)(bb + jj) * rs;
 #pragma unroll
@@ -1413,7 +1432,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     int tc = ch % cg;
     w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
     al[e] = alpha ? alpha[tc] : 1.0f;
-    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
+    gw[e] = ln_w ? ln_w[ch] : 1.0f; gb[e] = ln_w ? ln_b[ch] : 0.0f;
   }
   const int4 own = (hi && hasB) ? rcB : rcA;
   float x = (float)own.x, y = (float)own.y, z = (float)own.z;
@@ -1447,6 +1466,11 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A2a[e], __fmul_rn(fv[e], th)));          // :176
     nvA[e] = act ? va : 0.f; nvB[e] = act ? vb : 0.f;
     sA += nvA[e]; sB += nvB[e];
+  }
+  if (!ln_w) {                                   // training forward: the raw de-modulated rows (no LayerNorm)
+    if (act && vok) store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]), make_float4(nvA[0], nvA[1], nvA[2], nvA[3]), wt);
+    if (PAIR && act && hasB) store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]), make_float4(nvB[0], nvB[1], nvB[2], nvB[3]), wt);
+    return;
   }
   sA = grp_sum<LPR>(sA);
   if (PAIR) sB = grp_sum<LPR>(sB);
@@ -1487,19 +1511,21 @@ static inline int lanes_per_row(int c) {
 template <int LPR>
 static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
                             const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
-                            float div, float *S, int64_t m_cap) {
+                            float div, float *S, int64_t m_cap, const float *row_den = nullptr) {
   dim3 grid(g_modsum_wgs), block(256);
-  const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && op != LINK_OP_COSX;
-  if (op == LINK_OP_COS && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
-  else if (op == LINK_OP_SIN && pair)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, true>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
-  else if (op == LINK_OP_COS)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COS, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
-  else if (op == LINK_OP_SIN)
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_SIN, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
-  else
-    hipLaunchKernelGGL((k_modulate_sum_g<LPR, LINK_OP_COSX, false>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0);
+  const bool two_part = op == LINK_OP_COS || op == LINK_OP_SIN || op == LINK_OPI_SIN_BWD;
+  const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && two_part;
+#define LINK_MS(OPP, PP)                                                                                         \
+  hipLaunchKernelGGL((k_modulate_sum_g<LPR, OPP, PP>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, \
+                     c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0, row_den)
+  switch (op) {
+    case LINK_OP_COS: if (pair) LINK_MS(LINK_OP_COS, true); else LINK_MS(LINK_OP_COS, false); break;
+    case LINK_OP_SIN: if (pair) LINK_MS(LINK_OP_SIN, true); else LINK_MS(LINK_OP_SIN, false); break;
+    case LINK_OPI_SIN_BWD: LINK_MS(LINK_OPI_SIN_BWD, false); break;
+    case LINK_OPI_COSX_BWD: LINK_MS(LINK_OPI_COSX_BWD, false); break;
+    default: LINK_MS(LINK_OP_COSX, false); break;
+  }
+#undef LINK_MS
 }
 
 template <int LPR, int OP>
@@ -1544,18 +1570,19 @@ static void launch_gdl_g(int op, int r, hipStream_t st, int64_t m_cap, const flo
 template <int LPR, int P>
 static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
                                 const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
-                                int64_t m_cap, float *A) {
+                                int64_t m_cap, float *A, int flags, float *den_out) {
   dim3 grid(g_bgather_wgs), block(256);
+  const bool wt = (g_wt & 4) != 0;
   switch (r) {
-    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
-    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
-    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, (g_wt & 4) != 0); break;
+    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
+    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
+    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
   }
 }
 
-extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
-                                 const link_grid_t *grid, const int32_t *hdr, const link_elk_desc_t *desc,
-                                 int64_t m_cap, float *A, void *stream) {
+static int block_gather_impl(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
+                             const link_grid_t *grid, const int32_t *hdr, const link_elk_desc_t *desc,
+                             int64_t m_cap, float *A, int flags, float *den_out, void *stream) {
   if (check_desc(desc) != LINK_OK || !grid || m_cap < 0 || desc->r > 3 || (desc->c & 3) != 0) return LINK_ERR_ARG;
   if (m_cap == 0) return LINK_OK;
   if (!S_ || !blk_coords || !cell_blk || !hdr || !A) return LINK_ERR_ARG;
@@ -1563,9 +1590,9 @@ extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, con
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   const bool p3 = desc->op == LINK_OP_COSX;
-#define LINK_BG(L)                                                                                  \
-  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A);  \
-  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A)
+#define LINK_BG(L)                                                                                                   \
+  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out);    \
+  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out)
   switch (lanes_per_row(desc->c)) {
     case 1: case 2: case 4: LINK_BG(4); break;
     case 8: LINK_BG(8); break;
@@ -1575,6 +1602,12 @@ extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, con
   }
 #undef LINK_BG
   return check_launch("link_block_gather");
+}
+
+extern "C" int link_block_gather(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
+                                 const link_grid_t *grid, const int32_t *hdr, const link_elk_desc_t *desc,
+                                 int64_t m_cap, float *A, void *stream) {
+  return block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, desc, m_cap, A, 0, nullptr, stream);
 }
 
 template <int LPR>
@@ -1596,13 +1629,27 @@ static void launch_voxel_demod(const link_elk_desc_t &d, int64_t n, hipStream_t 
 #undef LINK_VD
 }
 
+static int voxel_demod_impl(const float *A, const float *fin, const int32_t *vox_sorted,
+                            const int32_t *pos_blk, const float *w_pos, const float *alpha,
+                            const float *ln_w, const float *ln_b, const int32_t *hdr,
+                            const link_elk_desc_t *desc, int64_t n, float *out, void *stream);
+
 extern "C" int link_voxel_demod_ln(const float *A, const float *fin, const int32_t *vox_sorted,
                                    const int32_t *pos_blk, const float *w_pos, const float *alpha,
                                    const float *ln_w, const float *ln_b, const int32_t *hdr,
                                    const link_elk_desc_t *desc, int64_t n, float *out, void *stream) {
+  if (!ln_w || !ln_b) return LINK_ERR_ARG;
+  return voxel_demod_impl(A, fin, vox_sorted, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, desc, n, out, stream);
+}
+
+// ln_w == NULL: no LayerNorm (the training forward, whose LayerNorm is differentiated by the host)
+static int voxel_demod_impl(const float *A, const float *fin, const int32_t *vox_sorted,
+                            const int32_t *pos_blk, const float *w_pos, const float *alpha,
+                            const float *ln_w, const float *ln_b, const int32_t *hdr,
+                            const link_elk_desc_t *desc, int64_t n, float *out, void *stream) {
   if (check_desc(desc) != LINK_OK || n < 0 || (desc->c & 3) != 0) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  if (!A || !vox_sorted || !pos_blk || !w_pos || !ln_w || !ln_b || !hdr || !out) return LINK_ERR_ARG;
+  if (!A || !vox_sorted || !pos_blk || !w_pos || !hdr || !out) return LINK_ERR_ARG;
   if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
   const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
   hipStream_t st = S(stream);
@@ -1618,15 +1665,18 @@ extern "C" int link_voxel_demod_ln(const float *A, const float *fin, const int32
 
 static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
                               const float *w_pos, const float *alpha, const int32_t *blk_start,
-                              const int32_t *hdr, float *S_, int64_t m_cap) {
+                              const int32_t *hdr, float *S_, int64_t m_cap, int op, const float *row_den) {
   if (!g_use_group_path || (d->c & 3) != 0) return false;
+  if (op < 0) op = d->op;
+#define LINK_MSG(L) launch_modsum_g<L>(op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap, row_den)
   switch (lanes_per_row(d->c)) {
-    case 1: case 2: case 4: launch_modsum_g<4>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
-    case 8: launch_modsum_g<8>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
-    case 16: launch_modsum_g<16>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
-    case 32: launch_modsum_g<32>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
-    default: launch_modsum_g<64>(d->op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap); break;
+    case 1: case 2: case 4: LINK_MSG(4); break;
+    case 8: LINK_MSG(8); break;
+    case 16: LINK_MSG(16); break;
+    case 32: LINK_MSG(32); break;
+    default: LINK_MSG(64); break;
   }
+#undef LINK_MSG
   return true;
 }
 
@@ -1644,6 +1694,200 @@ static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const fl
     default: launch_gdl_g<64>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
   }
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training form of the middle of R_core:  new = demodulate(aggregate(modulate(fin, theta)), theta)
+// (linkunet.py:151-176 between pre_mix and self.norm), forward and backward.  The two LayerNorms and
+// the pre_mix Linear stay with the host framework's autograd (library GEMM + its LayerNorm).
+//
+// Backward, per part (v = A[block(i)], X = modulated features, g = grad(new)):
+//   gA[m]   = (1/den[m]) * sum_{i in m} g_i * d(new)/d(v)          -> the forward's modulate+block-sum kernel
+//             with the backward factors ([cos, sin] | [cos, -sin] | [cos, sin, 1]) and a row scale
+//   gS[n]   = sum_{m : n in region(m)} gA[m]                       -> the forward's block gather, transposed
+//             neighbourhood, no normalisation
+//   g_fin_i = gS[block(i)] . d(X)/d(fin)  (+ the -theta*g term of cos_x), and the theta gradient folded
+//             into per-workgroup partial sums of d/d(alpha) and d/d(pos_weight)  -> k_voxel_bwd_g
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int OP>
+__global__ void __launch_bounds__(256) k_voxel_bwd_g(
+    const float *__restrict__ gS, const float *__restrict__ A_tab, const float *__restrict__ fin,
+    const float *__restrict__ g_new, const int4 *__restrict__ vox_sorted, const int32_t *__restrict__ pos_blk,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, const int32_t *__restrict__ hdr, int c,
+    int cg, float coord_div, float *__restrict__ g_fin, float *__restrict__ partials) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int G = 64 / LPR;
+  __shared__ float red[4][16][LPR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1);
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  const int n = hdr[LINK_HDR_NVALID];
+  const int ra = P * c;
+  float w0[4], w1[4], w2[4], al[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int tc = act ? (ch0 + e) % cg : 0;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+  }
+  float acc[4][4];                                 // [d alpha | d w.x | d w.y | d w.z][channel of the lane]
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[q][e] = 0.f;
+  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
+  for (int64_t p = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR; p < n; p += ngroups) {
+    const int4 rc = vox_sorted[p];
+    const int b = pos_blk[p];
+    float4 gx4[P], av4[P];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+      gx4[pp] = *reinterpret_cast<const float4 *>(&gS[(int64_t)b * ra + pp * c + cofs]);
+      av4[pp] = *reinterpret_cast<const float4 *>(&A_tab[(int64_t)b * ra + pp * c + cofs]);
+    }
+    const float4 f4 = *reinterpret_cast<const float4 *>(&fin[(int64_t)rc.w * c + cofs]);
+    const float4 g4 = *reinterpret_cast<const float4 *>(&g_new[(int64_t)rc.w * c + cofs]);
+    float x = (float)rc.x, y = (float)rc.y, z = (float)rc.z;
+    if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+    const float fv[4] = {f4.x, f4.y, f4.z, f4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float gx0[4] = {gx4[0].x, gx4[0].y, gx4[0].z, gx4[0].w}, gx1[4] = {gx4[1].x, gx4[1].y, gx4[1].z, gx4[1].w};
+    const float gx2[4] = {gx4[P - 1].x, gx4[P - 1].y, gx4[P - 1].z, gx4[P - 1].w};
+    const float v0[4] = {av4[0].x, av4[0].y, av4[0].z, av4[0].w}, v1[4] = {av4[1].x, av4[1].y, av4[1].z, av4[1].w};
+    float gf[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float t = fmaf(z, w2[e], fmaf(y, w1[e], x * w0[e]));
+      const float th = t * al[e];
+      float sn, cs;
+      sincos_fast(th, sn, cs);
+      float g_cs, g_sn, gth;
+      if (OP == LINK_OP_SIN) {                     // new = v0 cos - v1 sin ; X = [f sin, f cos]
+        gf[e] = gx0[e] * sn + gx1[e] * cs;
+        g_cs = gv[e] * v0[e] + gx1[e] * fv[e];
+        g_sn = gx0[e] * fv[e] - gv[e] * v1[e];
+      } else {                                     // new = v0 cos + v1 sin (+ v2 - f theta) ; X = [f cos, f sin, (f theta)]
+        gf[e] = gx0[e] * cs + gx1[e] * sn;
+        g_cs = gv[e] * v0[e] + gx0[e] * fv[e];
+        g_sn = gv[e] * v1[e] + gx1[e] * fv[e];
+      }
+      gth = cs * g_sn - sn * g_cs;
+      if (OP == LINK_OP_COSX) {
+        const float d = gx2[e] - gv[e];
+        gf[e] = fmaf(d, th, gf[e]);
+        gth = fmaf(d, fv[e], gth);
+      }
+      if (act) {
+        acc[0][e] = fmaf(gth, t, acc[0][e]);
+        const float ga = gth * al[e];
+        acc[1][e] = fmaf(ga, x, acc[1][e]);
+        acc[2][e] = fmaf(ga, y, acc[2][e]);
+        acc[3][e] = fmaf(ga, z, acc[3][e]);
+      }
+    }
+    if (act) *reinterpret_cast<float4 *>(&g_fin[(int64_t)rc.w * c + ch0]) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+  }
+  // fixed reduction tree: groups of the wave, then the 4 waves through LDS -> one partial row per workgroup
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[q][e] += __shfl_xor(acc[q][e], o, 64);
+  if (lane < LPR)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[wave][q * 4 + e][li] = acc[q][e];
+  __syncthreads();
+  if (wave == 0 && lane < LPR && act) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float4 o;
+      o.x = (red[0][q * 4 + 0][li] + red[1][q * 4 + 0][li]) + (red[2][q * 4 + 0][li] + red[3][q * 4 + 0][li]);
+      o.y = (red[0][q * 4 + 1][li] + red[1][q * 4 + 1][li]) + (red[2][q * 4 + 1][li] + red[3][q * 4 + 1][li]);
+      o.z = (red[0][q * 4 + 2][li] + red[1][q * 4 + 2][li]) + (red[2][q * 4 + 2][li] + red[3][q * 4 + 2][li]);
+      o.w = (red[0][q * 4 + 3][li] + red[1][q * 4 + 3][li]) + (red[2][q * 4 + 3][li] + red[3][q * 4 + 3][li]);
+      *reinterpret_cast<float4 *>(&partials[((int64_t)blockIdx.x * 4 + q) * c + ch0]) = o;
+    }
+  }
+}
+
+template <int LPR>
+static void launch_voxel_bwd(const link_elk_desc_t &d, int wgs, hipStream_t st, const float *gS, const float *A,
+                             const float *fin, const float *g_new, const int4 *vox, const int32_t *pos_blk,
+                             const float *w_pos, const float *alpha, const int32_t *hdr, float *g_fin,
+                             float *partials) {
+  dim3 grid(wgs), block(256);
+#define LINK_VB(OPP)                                                                                          \
+  hipLaunchKernelGGL((k_voxel_bwd_g<LPR, OPP>), grid, block, 0, st, gS, A, fin, g_new, vox, pos_blk, w_pos,    \
+                     alpha, hdr, d.c, d.cg, d.coord_div, g_fin, partials)
+  if (d.op == LINK_OP_COS) LINK_VB(LINK_OP_COS);
+  else if (d.op == LINK_OP_SIN) LINK_VB(LINK_OP_SIN);
+  else LINK_VB(LINK_OP_COSX);
+#undef LINK_VB
+}
+
+static int train_args_ok(const link_elk_desc_t *desc, const link_grid_t *grid, int64_t n, int64_t m_cap) {
+  if (check_desc(desc) != LINK_OK || !grid || n < 0 || m_cap < 0) return LINK_ERR_ARG;
+  if ((desc->c & 3) != 0 || desc->r > 3) return LINK_ERR_ARG;      // group kernels only; callers fall back
+  return LINK_OK;
+}
+
+extern "C" int link_elk_mid_forward(const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                    const int32_t *blk_start, const int32_t *blk_coords,
+                                    const int32_t *cell_blk, const link_grid_t *grid, const int32_t *hdr,
+                                    const float *w_pos, const float *alpha, const link_elk_desc_t *desc,
+                                    int64_t n, int64_t m_cap, float *S_, float *A, float *den, float *out,
+                                    void *stream) {
+  int rc = train_args_ok(desc, grid, n, m_cap);
+  if (rc != LINK_OK) return rc;
+  if (n == 0 || m_cap == 0) return LINK_OK;
+  if (!fin || !vox_sorted || !pos_blk || !blk_start || !blk_coords || !cell_blk || !hdr || !w_pos || !S_ || !A ||
+      !den || !out)
+    return LINK_ERR_ARG;
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
+  if (!modsum_group_path(desc, S(stream), fin, v4, w_pos, alpha, blk_start, hdr, S_, m_cap)) return LINK_ERR_ARG;
+  rc = check_launch("link_elk_mid_forward");
+  if (rc != LINK_OK) return rc;
+  rc = block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, desc, m_cap, A, 0, den, stream);
+  if (rc != LINK_OK) return rc;
+  return voxel_demod_impl(A, fin, vox_sorted, pos_blk, w_pos, alpha, nullptr, nullptr, hdr, desc, n, out, stream);
+}
+
+extern "C" int32_t link_elk_mid_partial_rows(void) { return 1024; }
+
+extern "C" int link_elk_mid_backward(const float *g_out, const float *fin, const float *A, const float *den,
+                                     const int32_t *vox_sorted, const int32_t *pos_blk,
+                                     const int32_t *blk_start, const int32_t *blk_coords,
+                                     const int32_t *cell_blk, const link_grid_t *grid, const int32_t *hdr,
+                                     const float *w_pos, const float *alpha, const link_elk_desc_t *desc,
+                                     int64_t n, int64_t m_cap, float *S_, float *gS, float *g_fin,
+                                     float *partials, void *stream) {
+  int rc = train_args_ok(desc, grid, n, m_cap);
+  if (rc != LINK_OK) return rc;
+  if (n == 0 || m_cap == 0) return LINK_OK;
+  if (!g_out || !fin || !A || !den || !vox_sorted || !pos_blk || !blk_start || !blk_coords || !cell_blk || !hdr ||
+      !w_pos || !S_ || !gS || !g_fin || !partials)
+    return LINK_ERR_ARG;
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
+  hipStream_t st = S(stream);
+  const int bop = desc->op == LINK_OP_COS ? LINK_OP_COS : (desc->op == LINK_OP_SIN ? LINK_OPI_SIN_BWD : LINK_OPI_COSX_BWD);
+  if (!modsum_group_path(desc, st, g_out, v4, w_pos, alpha, blk_start, hdr, S_, m_cap, bop, den)) return LINK_ERR_ARG;
+  rc = check_launch("link_elk_mid_backward");
+  if (rc != LINK_OK) return rc;
+  rc = block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, desc, m_cap, gS, 1 | 2, nullptr, stream);
+  if (rc != LINK_OK) return rc;
+  const int wgs = link_elk_mid_partial_rows();
+  switch (lanes_per_row(desc->c)) {
+    case 1: case 2: case 4: launch_voxel_bwd<4>(*desc, wgs, st, gS, A, fin, g_out, v4, pos_blk, w_pos, alpha, hdr, g_fin, partials); break;
+    case 8: launch_voxel_bwd<8>(*desc, wgs, st, gS, A, fin, g_out, v4, pos_blk, w_pos, alpha, hdr, g_fin, partials); break;
+    case 16: launch_voxel_bwd<16>(*desc, wgs, st, gS, A, fin, g_out, v4, pos_blk, w_pos, alpha, hdr, g_fin, partials); break;
+    case 32: launch_voxel_bwd<32>(*desc, wgs, st, gS, A, fin, g_out, v4, pos_blk, w_pos, alpha, hdr, g_fin, partials); break;
+    default: launch_voxel_bwd<64>(*desc, wgs, st, gS, A, fin, g_out, v4, pos_blk, w_pos, alpha, hdr, g_fin, partials); break;
+  }
+  return check_launch("link_elk_mid_backward");
 }
 
 // ---------------------------------------------------------------------------------------------

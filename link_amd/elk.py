@@ -16,9 +16,11 @@ Two execution paths, both HIP:
   * inference (no grad): the fused R_core -- link_premix_ln -> link_modulate_block_sum ->
     link_gather_demod_ln (include/link_amd.h section C), no host sync when the index is cached or
     bounds are known;
-  * training (grad enabled): the same maths composed from differentiable pieces -- torch for the
-    dense elementwise/Linear/LayerNorm steps, the HIP autograd Functions of aggregate.py for the
-    aggregation (deterministic forward and backward).
+  * training (grad enabled): pre_mix Linear and the two LayerNorms through torch autograd, everything
+    between them (theta, modulate, block sums, r^3 gather, de-modulate) through _ElkMid, whose
+    forward and backward are three HIP kernels each (deterministic, no atomics).  Widths that are
+    not a multiple of 4, or r > 3, use the op-by-op composition elk_core_autograd (torch elementwise
+    ops + the HIP autograd Functions of aggregate.py).
 """
 from __future__ import annotations
 
@@ -38,7 +40,7 @@ from .tensor import SparseTensor
 from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
-           "elk_core_fused", "elk_core_autograd", "ElkCorePlan"]
+           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
 
@@ -204,6 +206,73 @@ def elk_core_autograd(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, al
     return TF.layer_norm(new, (c,), ln_w, ln_b, eps)
 
 
+class _ElkMid(torch.autograd.Function):
+    """new = demodulate(aggregate(modulate(fin, theta)), theta) with hand-written forward AND backward
+    (include/link_amd.h: link_elk_mid_forward / link_elk_mid_backward; 3 kernels each, no atomics).
+    Replaces, for training, the reference's VoxelizeFunction / DevoxelizeFunction autograd nodes
+    (voxelize.py:10-56, devoxelize.py:51-98) and the torch graph of sin/cos/mul/cat around them
+    (linkunet.py:151-176)."""
+
+    @staticmethod
+    def forward(ctx, fin, w_pos, alpha, index: BlockIndex, op: int, cg: int, r: int, coord_div: float):
+        n, c = fin.shape
+        dev = fin.device
+        fin = fin.contiguous().float()
+        parts = 3 if op == L.OP_COSX else 2
+        m_cap = max(index._m if index._m is not None else n, 1)
+        desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), 1e-6)
+        w_pos_c = w_pos.detach().contiguous().float()
+        al = alpha.detach().contiguous().float().view(-1) if alpha is not None else None
+        S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
+        A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
+        den = torch.empty(m_cap, dtype=torch.float32, device=dev)
+        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        L.check(L.lib().link_elk_mid_forward(
+            fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(), index.blk_start.data_ptr(),
+            index.blk_coords.data_ptr(), index.cell_blk.data_ptr(), ctypes.byref(index.grid),
+            index.hdr.data_ptr(), w_pos_c.data_ptr(), al.data_ptr() if al is not None else None,
+            ctypes.byref(desc), n, m_cap, S.data_ptr(), A.data_ptr(), den.data_ptr(), out.data_ptr(), _st()),
+            "link_elk_mid_forward")
+        ctx.save_for_backward(fin, A, den, w_pos_c, al)
+        ctx.index, ctx.desc, ctx.m_cap, ctx.S = index, desc, m_cap, S      # S: reused as backward scratch
+        ctx.alpha_shape = alpha.shape if alpha is not None else None
+        ctx.wpos_shape = w_pos.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fin, A, den, w_pos_c, al = ctx.saved_tensors
+        index, desc, m_cap = ctx.index, ctx.desc, ctx.m_cap
+        n, c = fin.shape
+        cg = desc.cg
+        dev = fin.device
+        g = g.contiguous().float()
+        rows = int(L.lib().link_elk_mid_partial_rows())
+        gS = torch.empty_like(A)
+        g_fin = torch.empty_like(fin)
+        partials = torch.empty((rows, 4, c), dtype=torch.float32, device=dev)
+        L.check(L.lib().link_elk_mid_backward(
+            g.data_ptr(), fin.data_ptr(), A.data_ptr(), den.data_ptr(), index.vox_sorted.data_ptr(),
+            index.pos_blk.data_ptr(), index.blk_start.data_ptr(), index.blk_coords.data_ptr(),
+            index.cell_blk.data_ptr(), ctypes.byref(index.grid), index.hdr.data_ptr(), w_pos_c.data_ptr(),
+            al.data_ptr() if al is not None else None, ctypes.byref(desc), n, m_cap, ctx.S.data_ptr(),
+            gS.data_ptr(), g_fin.data_ptr(), partials.data_ptr(), _st()), "link_elk_mid_backward")
+        tot = partials.sum(0).view(4, c // cg, cg).sum(1)        # theta is tiled: channel ch -> ch % cg
+        g_wpos = tot[1:4].t().contiguous().view(ctx.wpos_shape)
+        g_alpha = tot[0].view(ctx.alpha_shape) if ctx.alpha_shape is not None else None
+        return g_fin, g_wpos, g_alpha, None, None, None, None, None
+
+
+def elk_core_train(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, baseop,
+                   cg, r, coord_div=1.0, eps=1e-6):
+    """Differentiable R_core for training: pre_mix Linear + the two LayerNorms through the host
+    framework (library GEMM), everything between them through _ElkMid's fused forward/backward."""
+    c = feats.shape[1]
+    fin = TF.layer_norm(TF.linear(feats, w_pre), (c,), pre_ln_w, pre_ln_b, eps)
+    new = _ElkMid.apply(fin, w_pos, alpha, index, _OPS[baseop], cg, r, float(coord_div))
+    return TF.layer_norm(new, (c,), ln_w, ln_b, eps)
+
+
 # ------------------------------------------------------------------------------------------------
 # local 3^3 sparse convolution (row N1 of SURVEY.md section 8f, minimal form)
 # ------------------------------------------------------------------------------------------------
@@ -271,7 +340,9 @@ class _ELKBase(nn.Module):
         needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(
             p.requires_grad for p in self.parameters()))
         if needs_grad:
-            return elk_core_autograd(*args)
+            if st.F.shape[1] % 4 == 0 and r <= 3 and st.F.dtype == torch.float32:
+                return elk_core_train(*args)
+            return elk_core_autograd(*args)      # op-by-op composition: any width / r
         return elk_core_fused(*args)
 
 

@@ -234,7 +234,7 @@ def theta_torch(coords_t, pos_weight, baseop: str, groups: int, alpha=None, vari
              tiled twice ('cos'); 'sin' uses all C columns untiled (:156).
     """
     import torch
-    xyz = coords_t[:, :3].float()
+    xyz = coords_t[:, :3].to(pos_weight.dtype)     # .float() in the reference; fp64 weights -> fp64 check runs
     if variant == "encoder" and baseop == "cos_x":
         xyz = xyz / tensor_stride
     th = torch.nn.functional.linear(xyz, pos_weight)

@@ -1,0 +1,149 @@
+"""Training path of R_core: fused forward/backward of the middle (link_elk_mid_forward/backward behind
+link_amd.elk._ElkMid) against (a) the oracle's torch restatement differentiated by autograd in fp64
+and (b) the op-by-op HIP composition elk_core_autograd.  Golden reference gradients are covered by
+tests/test_gpu_elk.py::test_block_grads_vs_reference (which now runs through this path for C % 4 == 0)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import lidar_like, rel_err, s_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(C, cg, baseop, seed, dtype=torch.float32, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    p = {
+        "w_pre": torch.randn(C, C, generator=g) / C ** 0.5,
+        "pre_ln_w": 1 + 0.1 * torch.randn(C, generator=g), "pre_ln_b": 0.1 * torch.randn(C, generator=g),
+        "w_pos": 0.3 * torch.randn(cg, 3, generator=g),
+        "alpha": (1 + 0.2 * torch.randn(1, cg, generator=g)) if baseop == "cos_x" else None,
+        "ln_w": 1 + 0.1 * torch.randn(C, generator=g), "ln_b": 0.1 * torch.randn(C, generator=g),
+    }
+    return {k: (v.to(dev, dtype).requires_grad_(True) if v is not None else None) for k, v in p.items()}
+
+
+def _run(fn, feats, coords, index, p, baseop, cg, r, div, gout):
+    f = feats.detach().clone().requires_grad_(True)
+    q = {k: (v.detach().clone().requires_grad_(True) if v is not None else None) for k, v in p.items()}
+    out = fn(f, coords, index, q["w_pre"], q["pre_ln_w"], q["pre_ln_b"], q["w_pos"], q["alpha"], q["ln_w"],
+             q["ln_b"], baseop, cg, r, div, 1e-6)
+    out.backward(gout)
+    grads = {"feats": f.grad}
+    grads.update({k: v.grad for k, v in q.items() if v is not None})
+    return out.detach(), grads
+
+
+def _oracle64(feats, coords, p, s, r, baseop, groups, div, gout):
+    """fp64 autograd over the oracle's torch restatement (CPU)."""
+    from oracle import link_oracle as lo
+    f = feats.detach().cpu().double().requires_grad_(True)
+    q = {k: (v.detach().cpu().double().requires_grad_(True) if v is not None else None) for k, v in p.items()}
+    params = {"pre_mix.0.weight": q["w_pre"], "pre_mix.1.weight": q["pre_ln_w"], "pre_mix.1.bias": q["pre_ln_b"],
+              "pos_weight.0.weight": q["w_pos"], "norm.weight": q["ln_w"], "norm.bias": q["ln_b"]}
+    if q["alpha"] is not None:
+        params["alpha"] = q["alpha"]
+    variant = "encoder" if div != 1.0 else "unet"
+    out = lo.elk_core_torch(f, coords.cpu(), params, s, r, baseop, groups, variant=variant,
+                            tensor_stride=int(div), agg=lo.aggregate_torch)
+    out.backward(gout.cpu().double())
+    grads = {"feats": f.grad}
+    grads.update({k: v.grad for k, v in q.items() if v is not None})
+    return out.detach(), grads
+
+
+CASES = [
+    # C, groups, baseop, s, r, n, div, frame
+    (64, 2, "cos", 7, 3, 6000, 1.0, "uniform"),
+    (64, 2, "sin", 7, 3, 6000, 1.0, "uniform"),
+    (64, 1, "cos_x", 3, 2, 6000, 1.0, "uniform"),
+    (64, 1, "cos_x", 6, 2, 6000, 2.0, "uniform"),
+    (16, 2, "cos", 5, 3, 3000, 1.0, "uniform"),
+    (48, 1, "cos", 4, 2, 3000, 1.0, "uniform"),          # idle lanes in the 16-lane group
+    (32, 4, "sin", 3, 2, 3000, 1.0, "uniform"),
+    (128, 2, "cos", 7, 3, 3000, 1.0, "uniform"),
+    (64, 2, "cos", 14, 3, 0, 1.0, "lidar"),              # large blocks: cooperative modulate mode
+    (64, 1, "cos_x", 16, 2, 0, 1.0, "lidar"),
+]
+
+
+@pytest.mark.parametrize("C,groups,baseop,s,r,n,div,frame", CASES)
+def test_train_path_vs_fp64_oracle_and_composition(C, groups, baseop, s, r, n, div, frame):
+    import link_amd as la
+    from link_amd.elk import elk_core_autograd, elk_core_train
+    if frame == "uniform":
+        coords = s_uniform(n, grid=64, seed=5)
+        if div != 1.0:
+            coords[:, :3] *= int(div)
+    else:
+        coords = torch.from_numpy(lidar_like(20000, seed=3))
+    coords = coords.cuda()
+    n = coords.shape[0]
+    cg = C // groups
+    p = _params(C, cg, baseop, seed=11)
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(7)).cuda()
+    gout = torch.randn(n, C, generator=torch.Generator().manual_seed(8)).cuda()
+    index = la.BlockIndex(coords, s)
+    if frame == "lidar":
+        assert n / index.M > 4                     # the cooperative mode is what this case is for
+    o_t, g_t = _run(elk_core_train, feats, coords, index, p, baseop, cg, r, div, gout)
+    o_a, g_a = _run(elk_core_autograd, feats, coords, index, p, baseop, cg, r, div, gout)
+    o_r, g_r = _oracle64(feats, coords, p, s, r, baseop, groups, div, gout)
+    assert rel_err(o_t.cpu().numpy(), o_r.numpy()) < 1e-4
+    for k in g_r:
+        e_t = rel_err(g_t[k].cpu().numpy(), g_r[k].numpy())
+        e_a = rel_err(g_a[k].cpu().numpy(), g_r[k].numpy())
+        # fp32 sums over N voxels: allow what the op-by-op fp32 path itself needs, and 2e-4 absolute cap
+        assert e_t < max(2e-4, 3 * e_a), (k, e_t, e_a)
+
+
+def test_train_path_is_deterministic_and_used_by_module():
+    import link_amd as la
+    from link_amd import elk as E
+    coords = s_uniform(20000, grid=96, seed=2).cuda()
+    torch.manual_seed(0)
+    blk = la.ELKBlock(64, 64, groups=2, baseop="cos").cuda().train()
+    feats = torch.randn(20000, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    calls = []
+    orig = E._ElkMid.forward
+
+    def run():
+        f = feats.clone().requires_grad_(True)
+        st = la.SparseTensor(f, coords, 1)
+        out = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
+        blk.zero_grad()
+        out.square().sum().backward()
+        return out.detach().clone(), f.grad.clone(), blk.pos_weight[0].weight.grad.clone()
+
+    a = run()
+    b = run()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)                   # no atomics anywhere: bit-identical reruns
+    # the module's training branch is the fused one (not the op-by-op composition)
+    seen = {}
+    def spy(ctx, *args):
+        seen["hit"] = True
+        return orig(ctx, *args)
+    E._ElkMid.forward = staticmethod(spy)
+    try:
+        run()
+    finally:
+        E._ElkMid.forward = staticmethod(orig)
+    assert seen.get("hit")
+
+
+def test_train_full_size_cfg2_grad_consistency():
+    """cfg2 size: gradient of a scalar loss through the fused path vs the op-by-op HIP composition."""
+    import link_amd as la
+    from link_amd.elk import elk_core_autograd, elk_core_train
+    n, C = 100000, 64
+    coords = s_uniform(n).cuda()
+    p = _params(C, 32, "cos", seed=4)
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(1)).cuda()
+    gout = torch.randn(n, C, generator=torch.Generator().manual_seed(9)).cuda() / n
+    index = la.BlockIndex(coords, 7)
+    o_t, g_t = _run(elk_core_train, feats, coords, index, p, "cos", 32, 3, 1.0, gout)
+    o_a, g_a = _run(elk_core_autograd, feats, coords, index, p, "cos", 32, 3, 1.0, gout)
+    assert rel_err(o_t.cpu().numpy(), o_a.cpu().numpy()) < 5e-5
+    for k in g_a:
+        assert rel_err(g_t[k].cpu().numpy(), g_a[k].cpu().numpy()) < 5e-4, k
