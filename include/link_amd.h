@@ -284,33 +284,52 @@ int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_g
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           int32_t build_index, void *stream);
 
-/* Training form of the middle of R_core (linkunet.py:151-176 / linkencoder.py:151-176 / ts_elk.py:166-214
- * between `pre_mix` and `self.norm`): new = demodulate(aux_to_voxel(voxel_to_aux(modulate(fin)))).  The
- * reference differentiates this through VoxelizeFunction.backward / DevoxelizeFunction.backward
- * (voxelize.py:34-50, devoxelize.py:76-93; voxelize_cuda.cu:28-42, devoxelize_cuda.cu:37-59: fp
- * atomicAdd scatter) plus torch autograd of the sin/cos/mul/cat graph; here forward and backward are
- * three kernels each, deterministic (no atomics).  The two LayerNorms and the pre_mix Linear stay with
- * the host framework's autograd.  Requires C % 4 == 0 and r <= 3 (LINK_ERR_ARG otherwise: the host
- * falls back to its op-by-op differentiable composition).
+/* ---------------------------------------------------------------------------------------------
+ * Training form of R_core (forward with saved state + hand-written backward).
  *
- * forward:  S scratch fp[(m_cap+1)*(P*C+1)]; A fp[m_cap, P*C] and den fp[m_cap] (region voxel counts)
- *           are SAVED for backward; out fp[N,C] = new (before self.norm).
- * backward: g_out fp[N,C] = d/d(new); S, gS fp[m_cap, P*C] scratch; g_fin fp[N,C]; partials
- *           fp[link_elk_mid_partial_rows(), 4, C]: per-workgroup partial sums of
- *           [d/d(alpha-tiled) | d/d(w_pos[:,0]) | d/d(w_pos[:,1]) | d/d(w_pos[:,2])] per channel; the host
- *           sums rows and folds channels ch -> ch % cg (theta is tiled, linkunet.py:154). */
+ * The reference differentiates linkunet.py:132-178 through torch autograd: nn.Linear / nn.LayerNorm
+ * nodes, the sin/cos/mul/cat graph, and VoxelizeFunction.backward / DevoxelizeFunction.backward
+ * (voxelize.py:34-50, devoxelize.py:76-93; voxelize_cuda.cu:28-42, devoxelize_cuda.cu:37-59: fp
+ * atomicAdd scatter).  Here the forward is the inference kernels (plus the region counts `den`), and
+ * the backward is six kernels, deterministic (no atomics); the only step left to the host's GEMM library
+ * is the weight gradient g_pre^T @ F.  Group kernels only: C % 4 == 0 and r <= 3 (pre_mix backward:
+ * C % 16 == 0, C <= 128); LINK_ERR_ARG otherwise and the host falls back to its op-by-op composition.
+ *
+ * All `partials` outputs are fp[link_elk_mid_partial_rows(), Q, C] per-workgroup partial sums which the
+ * host adds up over rows (fixed grid -> deterministic).
+ *
+ * link_elk_mid_forward   fin -> out.  S scratch fp[(m_cap+1)*(P*C+1)]; A fp[m_cap, P*C] and den
+ *     fp[m_cap] are SAVED for backward.  ln_w/ln_b NULL: out = new (before self.norm); non-NULL:
+ *     out = self.norm(new) (the inference kernels unchanged).
+ * link_elk_out_ln_backward   backward of self.norm with its input recomputed from (A, fin, theta):
+ *     g_out = d/d(norm output) -> g_new = d/d(new); partials Q=2: [d norm.weight | d norm.bias].
+ * link_elk_mid_backward      g_new -> g_fin (d/d(pre_mix output)); S and gS fp[m_cap,P*C] scratch;
+ *     partials Q=4: [d alpha (tiled) | d w_pos[:,0] | d w_pos[:,1] | d w_pos[:,2]] per channel; the host
+ *     folds channels ch -> ch % cg (theta is tiled, linkunet.py:154).
+ * link_premix_ln_backward    backward of pre_mix = LayerNorm(F @ Wpre^T) with the pre-norm activations
+ *     recomputed by the forward's MFMA schedule: g_fin -> g_pre fp[N,C] (d/d(F @ Wpre^T), stored for the
+ *     weight-gradient GEMM) and g_feats fp[N,C] = g_pre @ Wpre (second MFMA pass); partials Q=2:
+ *     [d pre_mix.1.weight | d pre_mix.1.bias]. */
 int link_elk_mid_forward(const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
                          const int32_t *blk_start, const int32_t *blk_coords, const int32_t *cell_blk,
                          const link_grid_t *grid /* host */, const int32_t *hdr, const float *w_pos,
-                         const float *alpha, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
-                         float *S, float *A, float *den, float *out, void *stream);
+                         const float *alpha, const link_elk_desc_t *desc /* host */, const float *ln_w,
+                         const float *ln_b, int64_t n, int64_t m_cap, float *S, float *A, float *den,
+                         float *out, void *stream);
 int32_t link_elk_mid_partial_rows(void);
-int link_elk_mid_backward(const float *g_out, const float *fin, const float *A, const float *den,
+int link_elk_out_ln_backward(const float *g_out, const float *A, const float *fin, const int32_t *vox_sorted,
+                             const int32_t *pos_blk, const float *w_pos, const float *alpha,
+                             const float *ln_w, const int32_t *hdr, const link_elk_desc_t *desc /* host */,
+                             int64_t n, float *g_new, float *partials, void *stream);
+int link_elk_mid_backward(const float *g_new, const float *fin, const float *A, const float *den,
                           const int32_t *vox_sorted, const int32_t *pos_blk, const int32_t *blk_start,
                           const int32_t *blk_coords, const int32_t *cell_blk,
                           const link_grid_t *grid /* host */, const int32_t *hdr, const float *w_pos,
                           const float *alpha, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           float *S, float *gS, float *g_fin, float *partials, void *stream);
+int link_premix_ln_backward(const float *feats, const float *w_pre, const float *ln_w, const float *g_fin,
+                            int64_t n, int32_t c, float eps, float *g_pre, float *g_feats, float *partials,
+                            void *stream);
 
 #ifdef __cplusplus
 }

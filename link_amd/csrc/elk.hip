@@ -1829,6 +1829,340 @@ static void launch_voxel_bwd(const link_elk_desc_t &d, int wgs, hipStream_t st, 
 #undef LINK_VB
 }
 
+// Backward of self.norm fused with the recomputation of its input: new_i is rebuilt from the saved A
+// row of the voxel's block exactly as the forward's voxel kernel builds it (same operation order), its
+// LayerNorm statistics are recomputed, and g_new = rstd * (gy*w - mean(gy*w) - xhat * mean(gy*w*xhat)).
+// Per-workgroup partial sums of d/d(norm.weight) = sum gy*xhat and d/d(norm.bias) = sum gy.
+template <int LPR, int OP>
+__global__ void __launch_bounds__(256) k_out_ln_bwd_g(
+    const float *__restrict__ g_out, const float *__restrict__ A_tab, const float *__restrict__ fin,
+    const int4 *__restrict__ vox_sorted, const int32_t *__restrict__ pos_blk, const float *__restrict__ w_pos,
+    const float *__restrict__ alpha, const float *__restrict__ ln_w, const int32_t *__restrict__ hdr, int c,
+    int cg, float coord_div, float eps, float *__restrict__ g_new, float *__restrict__ partials) {
+  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
+  constexpr int G = 64 / LPR;
+  __shared__ float red[4][8][LPR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1);
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  const int n = hdr[LINK_HDR_NVALID];
+  const int ra = P * c;
+  const float inv_c = 1.0f / (float)c;
+  float w0[4], w1[4], w2[4], al[4], gw[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int ch = act ? ch0 + e : 0;
+    int tc = ch % cg;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+    gw[e] = ln_w[ch];
+  }
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
+  for (int64_t p = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR; p < n; p += ngroups) {
+    const int4 rc = vox_sorted[p];
+    const int b = pos_blk[p];
+    float4 av4[P];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) av4[pp] = *reinterpret_cast<const float4 *>(&A_tab[(int64_t)b * ra + pp * c + cofs]);
+    float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (OP == LINK_OP_COSX) f4 = *reinterpret_cast<const float4 *>(&fin[(int64_t)rc.w * c + cofs]);
+    const float4 g4 = *reinterpret_cast<const float4 *>(&g_out[(int64_t)rc.w * c + cofs]);
+    float x = (float)rc.x, y = (float)rc.y, z = (float)rc.z;
+    if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+    const float v0[4] = {av4[0].x, av4[0].y, av4[0].z, av4[0].w}, v1[4] = {av4[1].x, av4[1].y, av4[1].z, av4[1].w};
+    const float v2[4] = {av4[P - 1].x, av4[P - 1].y, av4[P - 1].z, av4[P - 1].w};
+    const float fv[4] = {f4.x, f4.y, f4.z, f4.w}, gy[4] = {g4.x, g4.y, g4.z, g4.w};
+    float nv[4], sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float th = theta_of(x, y, z, w0[e], w1[e], w2[e], al[e]);
+      float sn, cs;
+      sincos_fast(th, sn, cs);
+      float va;
+      if (OP == LINK_OP_SIN) va = __fsub_rn(__fmul_rn(v0[e], cs), __fmul_rn(v1[e], sn));
+      else va = __fadd_rn(__fmul_rn(v0[e], cs), __fmul_rn(v1[e], sn));
+      if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(v2[e], __fmul_rn(fv[e], th)));
+      nv[e] = act ? va : 0.f;
+      sm += nv[e];
+    }
+    const float mean = grp_sum<LPR>(sm) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float d = act ? nv[e] - mean : 0.f; q += d * d; }
+    const float rstd = 1.0f / sqrtf(grp_sum<LPR>(q) * inv_c + eps);
+    float xh[4], gx[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      xh[e] = act ? (nv[e] - mean) * rstd : 0.f;
+      gx[e] = act ? gy[e] * gw[e] : 0.f;
+      s1 += gx[e];
+      s2 = fmaf(gx[e], xh[e], s2);
+      if (act) { aw[e] = fmaf(gy[e], xh[e], aw[e]); ab[e] += gy[e]; }
+    }
+    const float m1 = grp_sum<LPR>(s1) * inv_c, m2 = grp_sum<LPR>(s2) * inv_c;
+    if (act) {
+      float4 o;
+      o.x = rstd * (gx[0] - m1 - xh[0] * m2);
+      o.y = rstd * (gx[1] - m1 - xh[1] * m2);
+      o.z = rstd * (gx[2] - m1 - xh[2] * m2);
+      o.w = rstd * (gx[3] - m1 - xh[3] * m2);
+      *reinterpret_cast<float4 *>(&g_new[(int64_t)rc.w * c + ch0]) = o;
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { aw[e] += __shfl_xor(aw[e], o, 64); ab[e] += __shfl_xor(ab[e], o, 64); }
+  if (lane < LPR)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { red[wave][e][li] = aw[e]; red[wave][4 + e][li] = ab[e]; }
+  __syncthreads();
+  if (wave == 0 && lane < LPR && act) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      float4 o;
+      o.x = (red[0][q * 4 + 0][li] + red[1][q * 4 + 0][li]) + (red[2][q * 4 + 0][li] + red[3][q * 4 + 0][li]);
+      o.y = (red[0][q * 4 + 1][li] + red[1][q * 4 + 1][li]) + (red[2][q * 4 + 1][li] + red[3][q * 4 + 1][li]);
+      o.z = (red[0][q * 4 + 2][li] + red[1][q * 4 + 2][li]) + (red[2][q * 4 + 2][li] + red[3][q * 4 + 2][li]);
+      o.w = (red[0][q * 4 + 3][li] + red[1][q * 4 + 3][li]) + (red[2][q * 4 + 3][li] + red[3][q * 4 + 3][li]);
+      *reinterpret_cast<float4 *>(&partials[((int64_t)blockIdx.x * 2 + q) * c + ch0]) = o;
+    }
+  }
+}
+
+template <int LPR>
+static void launch_out_ln_bwd(const link_elk_desc_t &d, int wgs, hipStream_t st, const float *g_out, const float *A,
+                              const float *fin, const int4 *vox, const int32_t *pos_blk, const float *w_pos,
+                              const float *alpha, const float *ln_w, const int32_t *hdr, float *g_new,
+                              float *partials) {
+  dim3 grid(wgs), block(256);
+#define LINK_OB(OPP)                                                                                         \
+  hipLaunchKernelGGL((k_out_ln_bwd_g<LPR, OPP>), grid, block, 0, st, g_out, A, fin, vox, pos_blk, w_pos,      \
+                     alpha, ln_w, hdr, d.c, d.cg, d.coord_div, d.eps, g_new, partials)
+  if (d.op == LINK_OP_COS) LINK_OB(LINK_OP_COS);
+  else if (d.op == LINK_OP_SIN) LINK_OB(LINK_OP_SIN);
+  else LINK_OB(LINK_OP_COSX);
+#undef LINK_OB
+}
+
+// Backward of pre_mix = LayerNorm(F @ Wpre^T): the pre-LayerNorm activations are RECOMPUTED with the
+// forward's MFMA schedule (so the statistics are bit-identical to the forward's), the LayerNorm backward
+// is applied in the accumulator layout (lane = 4 channels x 4 tiles of one voxel), and
+// g_F = g_pre @ Wpre runs as a second MFMA pass whose B operand IS that accumulator layout and whose A
+// operand is a transposed copy of W in LDS.  g_pre is also stored (the weight gradient
+// g_pre^T @ F is a plain GEMM left to the library), and per-workgroup partial sums of
+// d/d(pre_mix.1.weight) = sum g_fin*xhat and d/d(pre_mix.1.bias) = sum g_fin are written.
+template <int C>
+__global__ void __launch_bounds__(256) k_premix_ln_bwd(const float *__restrict__ feats,
+                                                       const float *__restrict__ w_pre,
+                                                       const float *__restrict__ ln_w,
+                                                       const float *__restrict__ g_fin, int64_t n, float eps,
+                                                       float *__restrict__ g_pre, float *__restrict__ g_feats,
+                                                       float *__restrict__ partials) {
+  constexpr int T = C / 16;
+  constexpr int LDW = C + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *w_lds = reinterpret_cast<float *>(smem_raw);          // W   [j][k]
+  float *wt_lds = w_lds + C * LDW;                             // W^T [k][j]
+  float *red = wt_lds + C * LDW;                               // [4 waves][2][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  for (int e = tid * 4; e < C * C; e += 256 * 4) {
+    int r = e / C, col = e - r * C;
+    const float4 w4 = *reinterpret_cast<const float4 *>(&w_pre[e]);
+    *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = w4;
+    wt_lds[(col + 0) * LDW + r] = w4.x; wt_lds[(col + 1) * LDW + r] = w4.y;
+    wt_lds[(col + 2) * LDW + r] = w4.z; wt_lds[(col + 3) * LDW + r] = w4.w;
+  }
+  __syncthreads();
+  float lw[T][4];
+#pragma unroll
+  for (int tp = 0; tp < T; tp++) {
+    const float4 l4 = *reinterpret_cast<const float4 *>(&ln_w[16 * tp + 4 * g]);
+    lw[tp][0] = l4.x; lw[tp][1] = l4.y; lw[tp][2] = l4.z; lw[tp][3] = l4.w;
+  }
+  float pw[T][4], pb[T][4];
+#pragma unroll
+  for (int tp = 0; tp < T; tp++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) pw[tp][r] = pb[tp][r] = 0.f;
+  const int64_t tiles = (n + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t v = tile * 16 + li;
+    const bool ok = v < n;
+    const int64_t vl = ok ? v : n - 1;
+    float4 f[T], gf4[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) f[t] = *reinterpret_cast<const float4 *>(&feats[vl * C + 16 * t + 4 * g]);
+#pragma unroll
+    for (int t = 0; t < T; t++) gf4[t] = *reinterpret_cast<const float4 *>(&g_fin[vl * C + 16 * t + 4 * g]);
+    floatx4 acc[T];
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        float4 a = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * t + 4 * g]);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f[t].x, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f[t].y, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f[t].z, acc[tp], 0, 0, 0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f[t].w, acc[tp], 0, 0, 0);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) s += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float d = acc[tp][r] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) {
+      const float gv[4] = {gf4[tp].x, gf4[tp].y, gf4[tp].z, gf4[tp].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float xh = (acc[tp][r] - mean) * rstd;
+        const float gx = gv[r] * lw[tp][r];
+        s1 += gx;
+        s2 = fmaf(gx, xh, s2);
+        if (ok) { pw[tp][r] = fmaf(gv[r], xh, pw[tp][r]); pb[tp][r] += gv[r]; }
+        acc[tp][r] = xh;                            // keep xhat; gx is recomputed below (saves 16 VGPRs)
+      }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) {
+      const float gv[4] = {gf4[tp].x, gf4[tp].y, gf4[tp].z, gf4[tp].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[tp][r] = rstd * (gv[r] * lw[tp][r] - m1 - acc[tp][r] * m2);   // g_pre
+      if (ok)
+        *reinterpret_cast<float4 *>(&g_pre[v * C + 16 * tp + 4 * g]) = make_float4(acc[tp][0], acc[tp][1], acc[tp][2], acc[tp][3]);
+    }
+    // g_F[v][k] = sum_j g_pre[v][j] W[j][k]:  D2[k][v] = sum_j W^T[k][j] g_pre[v][j]
+    floatx4 acc2[T];
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) acc2[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        float4 a = *reinterpret_cast<const float4 *>(&wt_lds[(16 * tp + li) * LDW + 16 * t + 4 * g]);
+        acc2[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, acc[t][0], acc2[tp], 0, 0, 0);
+        acc2[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, acc[t][1], acc2[tp], 0, 0, 0);
+        acc2[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, acc[t][2], acc2[tp], 0, 0, 0);
+        acc2[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, acc[t][3], acc2[tp], 0, 0, 0);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++)
+        *reinterpret_cast<float4 *>(&g_feats[v * C + 16 * tp + 4 * g]) = make_float4(acc2[tp][0], acc2[tp][1], acc2[tp][2], acc2[tp][3]);
+    }
+  }
+  // LayerNorm parameter gradients: sum over the 16 voxel lanes of each quarter-wave, then over waves
+#pragma unroll
+  for (int tp = 0; tp < T; tp++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      pw[tp][r] = grp_sum<16>(pw[tp][r]);
+      pb[tp][r] = grp_sum<16>(pb[tp][r]);
+    }
+  if (li == 0) {
+#pragma unroll
+    for (int tp = 0; tp < T; tp++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        red[(wave * 2 + 0) * C + 16 * tp + 4 * g + r] = pw[tp][r];
+        red[(wave * 2 + 1) * C + 16 * tp + 4 * g + r] = pb[tp][r];
+      }
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * C; e += 256) {
+    const int qq = e / C, ch = e - qq * C;
+    partials[((int64_t)blockIdx.x * 2 + qq) * C + ch] =
+        (red[(0 * 2 + qq) * C + ch] + red[(1 * 2 + qq) * C + ch]) + (red[(2 * 2 + qq) * C + ch] + red[(3 * 2 + qq) * C + ch]);
+  }
+}
+
+template <int C>
+static int launch_premix_bwd(const float *feats, const float *w_pre, const float *ln_w, const float *g_fin,
+                             int64_t n, float eps, float *g_pre, float *g_feats, float *partials, int wgs,
+                             hipStream_t st) {
+  size_t lds = ((size_t)2 * C * (C + 4) + 8 * C) * sizeof(float);
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_bwd<C>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(k_premix_ln_bwd<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, g_fin, n, eps,
+                     g_pre, g_feats, partials);
+  return check_launch("link_premix_ln_backward");
+}
+
+extern "C" int32_t link_elk_mid_partial_rows(void) { return 1024; }
+
+extern "C" int link_premix_ln_backward(const float *feats, const float *w_pre, const float *ln_w,
+                                       const float *g_fin, int64_t n, int32_t c, float eps, float *g_pre,
+                                       float *g_feats, float *partials, void *stream) {
+  if (n < 0 || c <= 0 || (c & 15) != 0 || c > 128) return LINK_ERR_ARG;     // MFMA path only; callers fall back
+  if (n == 0) return LINK_OK;
+  if (!feats || !w_pre || !ln_w || !g_fin || !g_pre || !g_feats || !partials) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const int wgs = link_elk_mid_partial_rows();
+  switch (c) {
+    case 16: return launch_premix_bwd<16>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 32: return launch_premix_bwd<32>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 48: return launch_premix_bwd<48>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 64: return launch_premix_bwd<64>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 80: return launch_premix_bwd<80>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 96: return launch_premix_bwd<96>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    case 112: return launch_premix_bwd<112>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+    default: return launch_premix_bwd<128>(feats, w_pre, ln_w, g_fin, n, eps, g_pre, g_feats, partials, wgs, st);
+  }
+}
+
+extern "C" int link_elk_out_ln_backward(const float *g_out, const float *A, const float *fin,
+                                        const int32_t *vox_sorted, const int32_t *pos_blk, const float *w_pos,
+                                        const float *alpha, const float *ln_w, const int32_t *hdr,
+                                        const link_elk_desc_t *desc, int64_t n, float *g_new, float *partials,
+                                        void *stream) {
+  if (check_desc(desc) != LINK_OK || n < 0 || (desc->c & 3) != 0) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!g_out || !A || !vox_sorted || !pos_blk || !w_pos || !ln_w || !hdr || !g_new || !partials) return LINK_ERR_ARG;
+  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
+  const int4 *v4 = reinterpret_cast<const int4 *>(vox_sorted);
+  hipStream_t st = S(stream);
+  const int wgs = link_elk_mid_partial_rows();
+  switch (lanes_per_row(desc->c)) {
+    case 1: case 2: case 4: launch_out_ln_bwd<4>(*desc, wgs, st, g_out, A, fin, v4, pos_blk, w_pos, alpha, ln_w, hdr, g_new, partials); break;
+    case 8: launch_out_ln_bwd<8>(*desc, wgs, st, g_out, A, fin, v4, pos_blk, w_pos, alpha, ln_w, hdr, g_new, partials); break;
+    case 16: launch_out_ln_bwd<16>(*desc, wgs, st, g_out, A, fin, v4, pos_blk, w_pos, alpha, ln_w, hdr, g_new, partials); break;
+    case 32: launch_out_ln_bwd<32>(*desc, wgs, st, g_out, A, fin, v4, pos_blk, w_pos, alpha, ln_w, hdr, g_new, partials); break;
+    default: launch_out_ln_bwd<64>(*desc, wgs, st, g_out, A, fin, v4, pos_blk, w_pos, alpha, ln_w, hdr, g_new, partials); break;
+  }
+  return check_launch("link_elk_out_ln_backward");
+}
+
 static int train_args_ok(const link_elk_desc_t *desc, const link_grid_t *grid, int64_t n, int64_t m_cap) {
   if (check_desc(desc) != LINK_OK || !grid || n < 0 || m_cap < 0) return LINK_ERR_ARG;
   if ((desc->c & 3) != 0 || desc->r > 3) return LINK_ERR_ARG;      // group kernels only; callers fall back
@@ -1839,8 +2173,8 @@ extern "C" int link_elk_mid_forward(const float *fin, const int32_t *vox_sorted,
                                     const int32_t *blk_start, const int32_t *blk_coords,
                                     const int32_t *cell_blk, const link_grid_t *grid, const int32_t *hdr,
                                     const float *w_pos, const float *alpha, const link_elk_desc_t *desc,
-                                    int64_t n, int64_t m_cap, float *S_, float *A, float *den, float *out,
-                                    void *stream) {
+                                    const float *ln_w, const float *ln_b, int64_t n, int64_t m_cap,
+                                    float *S_, float *A, float *den, float *out, void *stream) {
   int rc = train_args_ok(desc, grid, n, m_cap);
   if (rc != LINK_OK) return rc;
   if (n == 0 || m_cap == 0) return LINK_OK;
@@ -1853,10 +2187,9 @@ extern "C" int link_elk_mid_forward(const float *fin, const int32_t *vox_sorted,
   if (rc != LINK_OK) return rc;
   rc = block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, desc, m_cap, A, 0, den, stream);
   if (rc != LINK_OK) return rc;
-  return voxel_demod_impl(A, fin, vox_sorted, pos_blk, w_pos, alpha, nullptr, nullptr, hdr, desc, n, out, stream);
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
+  return voxel_demod_impl(A, fin, vox_sorted, pos_blk, w_pos, alpha, ln_w, ln_b, hdr, desc, n, out, stream);
 }
-
-extern "C" int32_t link_elk_mid_partial_rows(void) { return 1024; }
 
 extern "C" int link_elk_mid_backward(const float *g_out, const float *fin, const float *A, const float *den,
                                      const int32_t *vox_sorted, const int32_t *pos_blk,

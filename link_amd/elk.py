@@ -231,8 +231,8 @@ class _ElkMid(torch.autograd.Function):
             fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(), index.blk_start.data_ptr(),
             index.blk_coords.data_ptr(), index.cell_blk.data_ptr(), ctypes.byref(index.grid),
             index.hdr.data_ptr(), w_pos_c.data_ptr(), al.data_ptr() if al is not None else None,
-            ctypes.byref(desc), n, m_cap, S.data_ptr(), A.data_ptr(), den.data_ptr(), out.data_ptr(), _st()),
-            "link_elk_mid_forward")
+            ctypes.byref(desc), None, None, n, m_cap, S.data_ptr(), A.data_ptr(), den.data_ptr(), out.data_ptr(),
+            _st()), "link_elk_mid_forward")
         ctx.save_for_backward(fin, A, den, w_pos_c, al)
         ctx.index, ctx.desc, ctx.m_cap, ctx.S = index, desc, m_cap, S      # S: reused as backward scratch
         ctx.alpha_shape = alpha.shape if alpha is not None else None
@@ -263,11 +263,109 @@ class _ElkMid(torch.autograd.Function):
         return g_fin, g_wpos, g_alpha, None, None, None, None, None
 
 
+def _weight_grad(g_pre: torch.Tensor, feats: torch.Tensor) -> torch.Tensor:
+    """g_pre^T @ feats ([C,N] x [N,C]).  One GEMM with K = N runs on a handful of workgroups; cutting
+    N into 32 batches (bmm + a 32-term sum) keeps the library GEMM busy: 282 us -> 29 us on cfg2."""
+    n = g_pre.shape[0]
+    b = 32
+    if n < b * 64:
+        return g_pre.t() @ feats
+    k = n // b
+    c = g_pre.shape[1]
+    out = torch.bmm(g_pre[: b * k].view(b, k, c).transpose(1, 2), feats[: b * k].view(b, k, c)).sum(0)
+    if b * k < n:
+        out = out + g_pre[b * k:].t() @ feats[b * k:]
+    return out
+
+
+class _ElkCoreTrain(torch.autograd.Function):
+    """Whole R_core (pre_mix -> ... -> self.norm) with a hand-written backward: forward = the inference
+    kernels (+ saved A, den, fin); backward = link_elk_out_ln_backward -> link_elk_mid_backward ->
+    link_premix_ln_backward (six kernels), the weight gradient through one batched library GEMM."""
+
+    @staticmethod
+    def forward(ctx, feats, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, index: BlockIndex, op: int,
+                cg: int, r: int, coord_div: float, eps: float):
+        n, c = feats.shape
+        dev = feats.device
+        lib, st = L.lib(), _st()
+        feats = feats.detach().contiguous().float()
+        f32 = lambda t: t.detach().contiguous().float()
+        w_pre_c, pre_w, pre_b, w_pos_c, ln_w_c, ln_b_c = map(f32, (w_pre, pre_ln_w, pre_ln_b, w_pos, ln_w, ln_b))
+        al = f32(alpha).view(-1) if alpha is not None else None
+        parts = 3 if op == L.OP_COSX else 2
+        m_cap = max(index._m if index._m is not None else n, 1)
+        desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
+        fin = torch.empty((n, c), dtype=torch.float32, device=dev)
+        S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
+        A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
+        den = torch.empty(m_cap, dtype=torch.float32, device=dev)
+        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        L.check(lib.link_premix_ln(feats.data_ptr(), w_pre_c.data_ptr(), pre_w.data_ptr(), pre_b.data_ptr(), n, c,
+                                   float(eps), fin.data_ptr(), st), "link_premix_ln")
+        L.check(lib.link_elk_mid_forward(
+            fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(), index.blk_start.data_ptr(),
+            index.blk_coords.data_ptr(), index.cell_blk.data_ptr(), ctypes.byref(index.grid),
+            index.hdr.data_ptr(), w_pos_c.data_ptr(), al.data_ptr() if al is not None else None,
+            ctypes.byref(desc), ln_w_c.data_ptr(), ln_b_c.data_ptr(), n, m_cap, S.data_ptr(), A.data_ptr(),
+            den.data_ptr(), out.data_ptr(), st), "link_elk_mid_forward")
+        ctx.save_for_backward(feats, fin, A, den, w_pre_c, pre_w, w_pos_c, al, ln_w_c)
+        ctx.index, ctx.desc, ctx.m_cap, ctx.S = index, desc, m_cap, S
+        ctx.shapes = (w_pre.shape, pre_ln_w.shape, pre_ln_b.shape, w_pos.shape,
+                      alpha.shape if alpha is not None else None, ln_w.shape, ln_b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, fin, A, den, w_pre_c, pre_w, w_pos_c, al, ln_w_c = ctx.saved_tensors
+        index, desc, m_cap = ctx.index, ctx.desc, ctx.m_cap
+        n, c = fin.shape
+        cg, eps = desc.cg, desc.eps
+        dev = fin.device
+        lib, st = L.lib(), _st()
+        g = g.contiguous().float()
+        rows = int(lib.link_elk_mid_partial_rows())
+        alp = al.data_ptr() if al is not None else None
+        g_new = torch.empty_like(fin)
+        part_o = torch.empty((rows, 2, c), dtype=torch.float32, device=dev)
+        L.check(lib.link_elk_out_ln_backward(
+            g.data_ptr(), A.data_ptr(), fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
+            w_pos_c.data_ptr(), alp, ln_w_c.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc), n,
+            g_new.data_ptr(), part_o.data_ptr(), st), "link_elk_out_ln_backward")
+        gS = torch.empty_like(A)
+        g_fin = torch.empty_like(fin)
+        part_m = torch.empty((rows, 4, c), dtype=torch.float32, device=dev)
+        L.check(lib.link_elk_mid_backward(
+            g_new.data_ptr(), fin.data_ptr(), A.data_ptr(), den.data_ptr(), index.vox_sorted.data_ptr(),
+            index.pos_blk.data_ptr(), index.blk_start.data_ptr(), index.blk_coords.data_ptr(),
+            index.cell_blk.data_ptr(), ctypes.byref(index.grid), index.hdr.data_ptr(), w_pos_c.data_ptr(), alp,
+            ctypes.byref(desc), n, m_cap, ctx.S.data_ptr(), gS.data_ptr(), g_fin.data_ptr(), part_m.data_ptr(),
+            st), "link_elk_mid_backward")
+        g_pre = g_new                                   # g_new is dead from here on: reuse its storage
+        g_feats = torch.empty_like(fin)
+        part_p = torch.empty((rows, 2, c), dtype=torch.float32, device=dev)
+        L.check(lib.link_premix_ln_backward(feats.data_ptr(), w_pre_c.data_ptr(), pre_w.data_ptr(),
+                                            g_fin.data_ptr(), n, c, float(eps), g_pre.data_ptr(),
+                                            g_feats.data_ptr(), part_p.data_ptr(), st), "link_premix_ln_backward")
+        sh = ctx.shapes
+        g_w_pre = _weight_grad(g_pre, feats).view(sh[0])
+        po, pp = part_o.sum(0), part_p.sum(0)
+        tot = part_m.sum(0).view(4, c // cg, cg).sum(1)         # theta is tiled: channel ch -> ch % cg
+        g_wpos = tot[1:4].t().contiguous().view(sh[3])
+        g_alpha = tot[0].view(sh[4]) if sh[4] is not None else None
+        return (g_feats, g_w_pre, pp[0].view(sh[1]), pp[1].view(sh[2]), g_wpos, g_alpha, po[0].view(sh[5]),
+                po[1].view(sh[6]), None, None, None, None, None, None)
+
+
 def elk_core_train(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, baseop,
                    cg, r, coord_div=1.0, eps=1e-6):
-    """Differentiable R_core for training: pre_mix Linear + the two LayerNorms through the host
-    framework (library GEMM), everything between them through _ElkMid's fused forward/backward."""
+    """Differentiable R_core for training.  C % 16 == 0 (<= 128): everything hand-written
+    (_ElkCoreTrain).  Other multiples of 4: pre_mix Linear + the two LayerNorms through torch autograd,
+    the middle through _ElkMid."""
     c = feats.shape[1]
+    if c % 16 == 0 and c <= 128:
+        return _ElkCoreTrain.apply(feats, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, index,
+                                   _OPS[baseop], cg, r, float(coord_div), float(eps))
     fin = TF.layer_norm(TF.linear(feats, w_pre), (c,), pre_ln_w, pre_ln_b, eps)
     new = _ElkMid.apply(fin, w_pos, alpha, index, _OPS[baseop], cg, r, float(coord_div))
     return TF.layer_norm(new, (c,), ln_w, ln_b, eps)

@@ -61,6 +61,8 @@ CASES = [
     (16, 2, "cos", 5, 3, 3000, 1.0, "uniform"),
     (48, 1, "cos", 4, 2, 3000, 1.0, "uniform"),          # idle lanes in the 16-lane group
     (32, 4, "sin", 3, 2, 3000, 1.0, "uniform"),
+    (24, 1, "cos_x", 3, 2, 3000, 1.0, "uniform"),        # C % 16 != 0: torch LayerNorm/Linear + fused middle
+    (8, 2, "sin", 5, 3, 3000, 1.0, "uniform"),
     (128, 2, "cos", 7, 3, 3000, 1.0, "uniform"),
     (64, 2, "cos", 14, 3, 0, 1.0, "lidar"),              # large blocks: cooperative modulate mode
     (64, 1, "cos_x", 16, 2, 0, 1.0, "lidar"),
@@ -105,7 +107,7 @@ def test_train_path_is_deterministic_and_used_by_module():
     blk = la.ELKBlock(64, 64, groups=2, baseop="cos").cuda().train()
     feats = torch.randn(20000, 64, generator=torch.Generator().manual_seed(1)).cuda()
     calls = []
-    orig = E._ElkMid.forward
+    orig = E._ElkCoreTrain.forward
 
     def run():
         f = feats.clone().requires_grad_(True)
@@ -124,11 +126,11 @@ def test_train_path_is_deterministic_and_used_by_module():
     def spy(ctx, *args):
         seen["hit"] = True
         return orig(ctx, *args)
-    E._ElkMid.forward = staticmethod(spy)
+    E._ElkCoreTrain.forward = staticmethod(spy)
     try:
         run()
     finally:
-        E._ElkMid.forward = staticmethod(orig)
+        E._ElkCoreTrain.forward = staticmethod(orig)
     assert seen.get("hit")
 
 
