@@ -330,6 +330,10 @@ int link_elk_mid_backward(const float *g_new, const float *fin, const float *A, 
 int link_premix_ln_backward(const float *feats, const float *w_pre, const float *ln_w, const float *g_fin,
                             int64_t n, int32_t c, float eps, float *g_pre, float *g_feats, float *partials,
                             void *stream);
+/* Column sums of up to three partial arrays fp[rows, cols_k] (k = 0..2; cols_k == 0 skips one) into
+ * out fp[cols0+cols1+cols2], one launch, fixed summation order. */
+int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t cols1, const float *p2,
+                      int32_t cols2, int64_t rows, float *out, void *stream);
 
 #ifdef __cplusplus
 }

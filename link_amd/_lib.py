@@ -101,6 +101,8 @@ SIGNATURES = {
                                      POINTER(LinkElkDesc), c_void_p, c_void_p, c_int64, c_int64] + [c_void_p] * 5),
     "link_elk_out_ln_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p,
                                          c_void_p]),
+    "link_sum_partials": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p,
+                                  c_void_p]),
     "link_premix_ln_backward": (c_int, [c_void_p] * 4 + [c_int64, c_int32, ctypes.c_float] + [c_void_p] * 4),
     "link_elk_mid_partial_rows": (c_int32, []),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,

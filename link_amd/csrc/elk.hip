@@ -2163,6 +2163,43 @@ extern "C" int link_elk_out_ln_backward(const float *g_out, const float *A, cons
   return check_launch("link_elk_out_ln_backward");
 }
 
+// Column sums of up to three per-workgroup partial arrays [rows, cols_k] in one launch, fixed order
+// (row lanes ascending, then a fixed LDS tree): the deterministic tail of every parameter gradient.
+__global__ void __launch_bounds__(256) k_sum_partials(const float *__restrict__ p0, int c0,
+                                                      const float *__restrict__ p1, int c1,
+                                                      const float *__restrict__ p2, int c2, int64_t rows,
+                                                      float *__restrict__ out) {
+  __shared__ float red[32][8];
+  const int col = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
+  const int total = c0 + c1 + c2;
+  const float *src = nullptr;
+  int stride = 0, off = 0;
+  if (col < c0) { src = p0; stride = c0; off = col; }
+  else if (col < c0 + c1) { src = p1; stride = c1; off = col - c0; }
+  else if (col < total) { src = p2; stride = c2; off = col - c0 - c1; }
+  float acc = 0.f;
+  if (src)
+    for (int64_t r = rl; r < rows; r += 32) acc += src[r * stride + off];
+  red[rl][threadIdx.x & 7] = acc;
+  __syncthreads();
+  for (int h = 16; h >= 1; h >>= 1) {
+    if (rl < h) red[rl][threadIdx.x & 7] += red[rl + h][threadIdx.x & 7];
+    __syncthreads();
+  }
+  if (rl == 0 && col < total) out[col] = red[0][threadIdx.x & 7];
+}
+
+extern "C" int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t cols1,
+                                 const float *p2, int32_t cols2, int64_t rows, float *out, void *stream) {
+  if (cols0 < 0 || cols1 < 0 || cols2 < 0 || rows < 0 || !out) return LINK_ERR_ARG;
+  if ((cols0 && !p0) || (cols1 && !p1) || (cols2 && !p2)) return LINK_ERR_ARG;
+  const int total = cols0 + cols1 + cols2;
+  if (total == 0) return LINK_OK;
+  hipLaunchKernelGGL(k_sum_partials, dim3((total + 7) / 8), dim3(256), 0, S(stream), p0, (int)cols0, p1, (int)cols1,
+                     p2, (int)cols2, rows, out);
+  return check_launch("link_sum_partials");
+}
+
 static int train_args_ok(const link_elk_desc_t *desc, const link_grid_t *grid, int64_t n, int64_t m_cap) {
   if (check_desc(desc) != LINK_OK || !grid || n < 0 || m_cap < 0) return LINK_ERR_ARG;
   if ((desc->c & 3) != 0 || desc->r > 3) return LINK_ERR_ARG;      // group kernels only; callers fall back

@@ -326,15 +326,16 @@ class _ElkCoreTrain(torch.autograd.Function):
         g = g.contiguous().float()
         rows = int(lib.link_elk_mid_partial_rows())
         alp = al.data_ptr() if al is not None else None
-        g_new = torch.empty_like(fin)
-        part_o = torch.empty((rows, 2, c), dtype=torch.float32, device=dev)
+        work = torch.empty((3, n, c), dtype=torch.float32, device=dev)      # g_new (later g_pre) | g_fin | g_feats
+        g_new, g_fin, g_feats = work[0], work[1], work[2]
+        part = torch.empty(rows * 8 * c + 8 * c, dtype=torch.float32, device=dev)
+        part_o, part_m, part_p = part[: rows * 2 * c], part[rows * 2 * c: rows * 6 * c], part[rows * 6 * c: rows * 8 * c]
+        tot = part[rows * 8 * c:]
+        gS = torch.empty_like(A)
         L.check(lib.link_elk_out_ln_backward(
             g.data_ptr(), A.data_ptr(), fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
             w_pos_c.data_ptr(), alp, ln_w_c.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc), n,
             g_new.data_ptr(), part_o.data_ptr(), st), "link_elk_out_ln_backward")
-        gS = torch.empty_like(A)
-        g_fin = torch.empty_like(fin)
-        part_m = torch.empty((rows, 4, c), dtype=torch.float32, device=dev)
         L.check(lib.link_elk_mid_backward(
             g_new.data_ptr(), fin.data_ptr(), A.data_ptr(), den.data_ptr(), index.vox_sorted.data_ptr(),
             index.pos_blk.data_ptr(), index.blk_start.data_ptr(), index.blk_coords.data_ptr(),
@@ -342,19 +343,19 @@ class _ElkCoreTrain(torch.autograd.Function):
             ctypes.byref(desc), n, m_cap, ctx.S.data_ptr(), gS.data_ptr(), g_fin.data_ptr(), part_m.data_ptr(),
             st), "link_elk_mid_backward")
         g_pre = g_new                                   # g_new is dead from here on: reuse its storage
-        g_feats = torch.empty_like(fin)
-        part_p = torch.empty((rows, 2, c), dtype=torch.float32, device=dev)
         L.check(lib.link_premix_ln_backward(feats.data_ptr(), w_pre_c.data_ptr(), pre_w.data_ptr(),
                                             g_fin.data_ptr(), n, c, float(eps), g_pre.data_ptr(),
                                             g_feats.data_ptr(), part_p.data_ptr(), st), "link_premix_ln_backward")
+        L.check(lib.link_sum_partials(part_o.data_ptr(), 2 * c, part_m.data_ptr(), 4 * c, part_p.data_ptr(), 2 * c,
+                                      rows, tot.data_ptr(), st), "link_sum_partials")
         sh = ctx.shapes
         g_w_pre = _weight_grad(g_pre, feats).view(sh[0])
-        po, pp = part_o.sum(0), part_p.sum(0)
-        tot = part_m.sum(0).view(4, c // cg, cg).sum(1)         # theta is tiled: channel ch -> ch % cg
-        g_wpos = tot[1:4].t().contiguous().view(sh[3])
-        g_alpha = tot[0].view(sh[4]) if sh[4] is not None else None
-        return (g_feats, g_w_pre, pp[0].view(sh[1]), pp[1].view(sh[2]), g_wpos, g_alpha, po[0].view(sh[5]),
-                po[1].view(sh[6]), None, None, None, None, None, None)
+        th = tot[2 * c: 6 * c].view(4, c // cg, cg)              # theta is tiled: channel ch -> ch % cg
+        th = th.sum(1) if c != cg else th[:, 0]
+        g_wpos = th[1:4].t().contiguous().view(sh[3])
+        g_alpha = th[0].view(sh[4]) if sh[4] is not None else None
+        return (g_feats, g_w_pre, tot[6 * c: 7 * c].view(sh[1]), tot[7 * c: 8 * c].view(sh[2]), g_wpos, g_alpha,
+                tot[0: c].view(sh[5]), tot[c: 2 * c].view(sh[6]), None, None, None, None, None, None)
 
 
 def elk_core_train(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, baseop,
