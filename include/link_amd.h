@@ -335,6 +335,24 @@ int link_premix_ln_backward(const float *feats, const float *w_pre, const float 
 int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t cols1, const float *p2,
                       int32_t cols2, int64_t rows, float *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Section D -- row N1 of SURVEY.md section 8f: stride-1 submanifold sparse convolution (what
+ * ELKBlock.local_mix = spnn.Conv3d(inc, inc, 3) runs, linkunet.py:109,125).
+ * Replaces torchsparse.backend.convolution_forward_cuda (pybind_cuda.cpp:19;
+ * convolution/convolution_cuda.cu:53-165: per kernel offset gather -> cuBLAS mm -> scatter-add) for the
+ * in-place-coordinates case with ONE output-stationary kernel (accumulators in registers over all
+ * offsets, W_k staged in LDS, f32 MFMA), fed by a per-output neighbour table instead of the
+ * reference's (in,out) pair lists:
+ *   nbr  i32[N, kvol]   nbr[v,k] = input row at coords[v] + offset_k * tensor_stride, -1 absent; offsets
+ *                       in get_kernel_offsets order (nn/utils/kernel.py:9-33) -- link_neighbor_map output
+ *   w    fp[kvol, Cin, Cout]   the module's `kernel` parameter as stored (nn/modules/conv.py:34-38)
+ *   out  fp[N, Cout] = sum_k feats[nbr[:,k]] @ w[k]
+ * MFMA path for Cin == Cout, C % 16 == 0, C <= 128; any other widths <= 256 take a lane=channel kernel.
+ * The input gradient of this convolution is the same call on grad_out with w'[k] = w[kvol-1-k]^T
+ * (the neighbour relation of an odd kernel at stride 1 is symmetric). */
+int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, int64_t n, int32_t cin,
+                           int32_t cout, int32_t kvol, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ from .tensor import SparseTensor
 from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
-           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan"]
+           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
 
@@ -378,8 +378,9 @@ def elk_core_train(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha
 class Conv3d(nn.Module):
     """Stride-1 submanifold sparse convolution with the reference's parameter layout
     (`kernel` [K, Cin, Cout], torchsparse/nn/modules/conv.py:15-72; init U(+-1/sqrt(Cin*K))).
-    Neighbour map from the dense cell table (HIP), contraction as K gather + rocBLAS GEMMs.
-    Only what ELKBlock.local_mix needs: odd kernel_size, stride 1, no bias."""
+    Neighbour table from the dense cell table (HIP), contraction by the output-stationary MFMA kernel
+    link_subm_conv_forward (include/link_amd.h section D).  Only what ELKBlock.local_mix needs: odd
+    kernel_size, stride 1, no bias."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
                  dilation: int = 1, bias: bool = False, transposed: bool = False) -> None:
@@ -401,31 +402,71 @@ class Conv3d(nn.Module):
         std = 1.0 / math.sqrt(in_channels * self.kernel_volume)
         self.kernel.data.uniform_(-std, std)
 
+    def _neighbor_table(self, x: SparseTensor) -> torch.Tensor:
+        """int32[N, K] input row of every (output voxel, kernel offset), -1 absent; cached on the tensor's
+        kmaps like the reference's kernel maps (nn/functional/conv.py:103,122)."""
+        key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
+        nbr = x.kmaps.get(key)
+        if nbr is None:
+            # neighbour of voxel i at coords_i + offset*tensor_stride (conv.py:105-113: stride=input.stride)
+            ts = int(x.s[0])
+            try:
+                nbr = foreign_neighbor_map(x.C, self.kernel_size[0], step=ts)
+            except GridTooLarge:
+                offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
+                nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
+            x.kmaps[key] = nbr
+        return nbr
+
     def forward(self, x: SparseTensor) -> SparseTensor:
         feats = x.F
         if self.kernel_volume == 1:
             out = feats.matmul(self.kernel)
         else:
-            key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
-            nbr = x.kmaps.get(key)
-            if nbr is None:
-                # kernel map: neighbour of voxel i at coords_i + offset*tensor_stride
-                # (nn/functional/conv.py:105-113: offsets use stride=input.stride)
-                ts = int(x.s[0])
-                try:
-                    nbr = foreign_neighbor_map(x.C, self.kernel_size[0], step=ts).long()
-                except GridTooLarge:
-                    offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=feats.device)
-                    nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous()
-                nbr = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr)   # -> zero pad row
-                x.kmaps[key] = nbr
-            padded = torch.cat([feats, feats.new_zeros(1, feats.shape[1])], dim=0)
-            out = feats.new_zeros(feats.shape[0], self.out_channels)
-            for k in range(self.kernel_volume):
-                out = out + padded[nbr[:, k]].matmul(self.kernel[k])
+            out = _SubmConv.apply(feats, self.kernel, self._neighbor_table(x))
         y = SparseTensor(out, x.C, x.s)
         y.cmaps, y.kmaps = x.cmaps, x.kmaps
         return y
+
+
+def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+    """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd."""
+    if feats.device.type != "cuda":
+        raise L.LinkAmdError("subm_conv needs GPU tensors (HIP path; no CPU fallback)")
+    n, cin = feats.shape
+    kvol, cin2, cout = kernel.shape
+    assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
+    f = feats.detach().contiguous().float()
+    w = kernel.detach().contiguous().float()
+    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), n, cin, cout,
+                                           kvol, out.data_ptr(), _st()), "link_subm_conv_forward")
+    return out
+
+
+class _SubmConv(torch.autograd.Function):
+    """Differentiable stride-1 submanifold convolution on the HIP kernel.  Input gradient: the same
+    kernel on grad_out with w'[k] = w[K-1-k]^T (odd kernel, same coordinates: nbr[v,k] = u  <=>
+    nbr[u,K-1-k] = v).  Weight gradient: per offset gather + one batched library GEMM."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, nbr):
+        ctx.save_for_backward(feats, kernel, nbr)
+        return subm_conv(feats, kernel, nbr)
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, kernel, nbr = ctx.saved_tensors
+        g = g.contiguous().float()
+        g_feats = g_kernel = None
+        if ctx.needs_input_grad[0]:
+            g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr)
+        if ctx.needs_input_grad[1]:
+            n = feats.shape[0]
+            padded = torch.cat([feats.detach().float(), feats.new_zeros(1, feats.shape[1])], dim=0)
+            idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
+            g_kernel = torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kernel.shape[0])], 0)
+        return g_feats, g_kernel, None
 
 
 # ------------------------------------------------------------------------------------------------

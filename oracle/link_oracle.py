@@ -302,6 +302,33 @@ def aggregate_torch(x, coords, s: int, r: int):
     return new[idx_t]                                                               # utils.py:82
 
 
+def conv_neighbor_table(coords, kernel_size: int = 3, tensor_stride: int = 1) -> np.ndarray:
+    """Kernel map of a stride-1 sparse convolution as a per-output table int32[N, K]: row of
+    coords[i] + offset_k * tensor_stride, -1 absent (torchsparse/nn/functional/conv.py:103-113:
+    offsets = get_kernel_offsets(kernel_size, stride=input.stride); queries = sphash(coords, offsets);
+    results = sphashquery(queries, sphash(coords)) -> [K, N])."""
+    c = _c(coords, np.int32)
+    off = get_kernel_offsets(kernel_size) * int(tensor_stride)
+    res = sphashquery(sphash_offsets(c, off), sphash(c))             # [K, N]
+    return np.ascontiguousarray(res.T).astype(np.int32)
+
+
+def subm_conv_torch(feats, coords, kernel, tensor_stride: int = 1):
+    """Stride-1 sparse convolution forward as the reference's CPU branch computes it
+    (conv.py:47-61: per kernel offset `output[out_map] += input[in_map] @ weight[k]`), differentiable."""
+    import torch
+    k = kernel.shape[0]
+    ks = round(k ** (1 / 3))
+    nbr = torch.from_numpy(conv_neighbor_table(coords.numpy() if hasattr(coords, "numpy") else coords, ks,
+                                               tensor_stride).astype(np.int64))
+    out = torch.zeros(feats.shape[0], kernel.shape[2], dtype=feats.dtype)
+    for j in range(k):
+        out_map = torch.nonzero(nbr[:, j] >= 0).view(-1)
+        if out_map.numel():
+            out = out.index_add(0, out_map, feats[nbr[out_map, j]] @ kernel[j])
+    return out
+
+
 def aggregate_c(x, coords, s: int, r: int):
     """Same as aggregate_torch but through the scalar C oracle (no autograd)."""
     import torch

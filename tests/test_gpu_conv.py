@@ -1,0 +1,95 @@
+"""Row N1: the stride-1 submanifold convolution kernel (link_subm_conv_forward
+behind link_amd.Conv3d / link_amd.elk.subm_conv) against the oracle's restatement of the reference's
+CPU branch (oracle.subm_conv_torch, itself pinned on the reference's local_mix goldens)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import lidar_like, rel_err, s_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(kind, n, stride):
+    if kind == "lidar":
+        c = torch.from_numpy(lidar_like(n, seed=4, stride=stride))
+    else:
+        c = s_uniform(n, grid=24, seed=6)              # dense enough that most 3^3 neighbours exist
+        c[:, :3] *= stride
+    return c
+
+
+@pytest.mark.parametrize("C,kind,n,stride", [
+    (64, "lidar", 20000, 1), (64, "dense", 5000, 1), (16, "dense", 3001, 2), (128, "dense", 2000, 1),
+    (32, "lidar", 9000, 2), (48, "dense", 777, 1), (64, "dense", 7, 1),
+    (8, "dense", 3000, 1), (24, "dense", 1500, 1),                     # lane=channel kernel
+])
+def test_subm_conv_forward_vs_oracle(C, kind, n, stride):
+    import link_amd as la
+    from oracle import link_oracle as lo
+    coords = _frame(kind, n, stride)
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(n, C, generator=g)
+    conv = la.Conv3d(C, C, kernel_size=3).cuda()
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    with torch.no_grad():
+        out = conv(st).F
+    ref = lo.subm_conv_torch(feats.double(), coords, conv.kernel.detach().cpu().double(), stride)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+    # the neighbour table is the reference's kernel map (bit-exact integer work)
+    nbr = st.kmaps[("link_conv_nbr", st.C.data_ptr(), n, st.s, (3, 3, 3))]
+    assert np.array_equal(nbr.cpu().numpy(), lo.conv_neighbor_table(coords.numpy(), 3, stride))
+
+
+def test_subm_conv_rectangular_widths():
+    from link_amd.elk import subm_conv
+    from oracle import link_oracle as lo
+    coords = s_uniform(2000, grid=20, seed=1)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2000, 12, generator=g)
+    kernel = torch.randn(27, 12, 40, generator=g) * 0.1
+    nbr = torch.from_numpy(lo.conv_neighbor_table(coords.numpy(), 3, 1)).cuda()
+    out = subm_conv(feats.cuda(), kernel.cuda(), nbr)
+    ref = lo.subm_conv_torch(feats.double(), coords, kernel.double(), 1)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C,kind", [(64, "lidar"), (16, "dense"), (8, "dense")])
+def test_subm_conv_gradients_vs_oracle_autograd(C, kind):
+    import link_amd as la
+    from oracle import link_oracle as lo
+    coords = _frame(kind, 6000 if kind == "lidar" else 2500, 1)
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(8)
+    feats = torch.randn(n, C, generator=g)
+    gout = torch.randn(n, C, generator=g)
+    conv = la.Conv3d(C, C, kernel_size=3).cuda()
+    f = feats.cuda().requires_grad_(True)
+    out = conv(la.SparseTensor(f, coords.cuda(), 1)).F
+    out.backward(gout.cuda())
+    fr = feats.double().requires_grad_(True)
+    kr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    lo.subm_conv_torch(fr, coords, kr, 1).backward(gout.double())
+    assert rel_err(f.grad.cpu().numpy(), fr.grad.numpy()) < 1e-5
+    assert rel_err(conv.kernel.grad.cpu().numpy(), kr.grad.numpy()) < 1e-4
+
+
+def test_elkblock_forward_full_block_vs_oracle():
+    """R_block: whole ELKBlock.forward (local_mix on the HIP conv kernel + fused R_core + add/ReLU)."""
+    import link_amd as la
+    from oracle import link_oracle as lo
+    import torch.nn.functional as TF
+    C, s, r = 64, 7, 3
+    coords = torch.from_numpy(lidar_like(15000, seed=9))
+    n = coords.shape[0]
+    torch.manual_seed(0)
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        out = blk(la.SparseTensor(feats.cuda(), coords.cuda(), 1), s, r).F
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    core = lo.elk_core_torch(feats, coords, sd, s, r, "cos", 2)
+    local = lo.subm_conv_torch(feats, coords, sd["local_mix.0.kernel"], 1)
+    ref = torch.relu(core + TF.layer_norm(local, (C,), sd["norm_local.weight"], sd["norm_local.bias"], 1e-6))
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-4

@@ -88,6 +88,16 @@ def test_block_core_and_grads_vs_reference(name):
         assert rel_err(gr.numpy(), g["grad__" + n]) < 1e-4, n
 
 
+@pytest.mark.parametrize("name", golden_files("g_block_*.npz"))
+def test_conv_restatement_vs_reference_local_mix(name):
+    """oracle.subm_conv_torch against the reference's own local_mix output (spnn.Conv3d, CPU branch)."""
+    import torch
+    g = load_golden(name)
+    out = O.subm_conv_torch(torch.from_numpy(g["feats"]), g["coords"], torch.from_numpy(g["sd__local_mix.0.kernel"]),
+                             g["meta"]["tensor_stride"])
+    assert rel_err(out.numpy(), g["local"]) < 1e-5
+
+
 def test_size_checkpoints():
     """SURVEY.md section 8d generator checkpoints: M and sha256 of the index arrays at cfg1/cfg2."""
     import hashlib

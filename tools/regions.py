@@ -14,6 +14,7 @@ torch.manual_seed(2)
 blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev)
 x = torch.randn(N, 2 * C, generator=torch.Generator().manual_seed(1)).to(dev)
 feats = torch.randn(N, C, generator=torch.Generator().manual_seed(3)).to(dev)
+gout = torch.randn(N, C, generator=torch.Generator().manual_seed(4)).to(dev)
 
 def timeit(fn, k=50, warm=5):
     for _ in range(warm): fn()
@@ -40,5 +41,5 @@ def core_train():
     f = feats.detach().requires_grad_(True)
     st = la.SparseTensor(f, coords, 1); st.kmaps = kcache; st.cmaps = ccache
     out = blk._core(st, 7, 3, blk.pos_weight[0].weight, None, 32, 1.0)
-    out.square().mean().backward()
+    out.backward(gout)
 print(f"R_core differentiable fwd+bwd (warm index):       {timeit(core_train, 20):.1f} us")
