@@ -347,11 +347,16 @@ int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t c
  *                       in get_kernel_offsets order (nn/utils/kernel.py:9-33) -- link_neighbor_map output
  *   w    fp[kvol, Cin, Cout]   the module's `kernel` parameter as stored (nn/modules/conv.py:34-38)
  *   out  fp[N, Cout] = sum_k feats[nbr[:,k]] @ w[k]
+ *   order i32[N] or NULL: a permutation of the voxels (e.g. link_index_build's `perm`): tile t of the MFMA
+ *                       kernel computes voxels order[16t..16t+15]; spatially sorted voxels let whole tiles
+ *                       skip absent offsets.  Results do not depend on it.
  * MFMA path for Cin == Cout, C % 16 == 0, C <= 128; any other widths <= 256 take a lane=channel kernel.
  * The input gradient of this convolution is the same call on grad_out with w'[k] = w[kvol-1-k]^T
  * (the neighbour relation of an odd kernel at stride 1 is symmetric). */
-int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, int64_t n, int32_t cin,
-                           int32_t cout, int32_t kvol, float *out, void *stream);
+int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                           int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out, void *stream);
+/* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
+int link_conv_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

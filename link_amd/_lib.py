@@ -101,8 +101,9 @@ SIGNATURES = {
                                      POINTER(LinkElkDesc), c_void_p, c_void_p, c_int64, c_int64] + [c_void_p] * 5),
     "link_elk_out_ln_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p,
                                          c_void_p]),
-    "link_subm_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
-                                       c_void_p]),
+    "link_subm_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                       c_void_p, c_void_p]),
+    "link_conv_set_tuning": (c_int, [c_int, c_int]),
     "link_sum_partials": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p,
                                   c_void_p]),
     "link_premix_ln_backward": (c_int, [c_void_p] * 4 + [c_int64, c_int32, ctypes.c_float] + [c_void_p] * 4),

@@ -9,7 +9,11 @@
 // workgroup stages W_k (transposed, padded) in LDS once for all its 4*NT tiles, each lane gathers the
 // neighbour row of its voxel straight into the MFMA B-operand layout (one dwordx4 per 16-channel
 // tile), and v_mfma_f32_16x16x4_f32 accumulates D[co][voxel] += W_k^T[co][ci] * F[nbr][ci] (exact f32).
-// Tiles in which no voxel has the offset's neighbour skip the MFMAs.  Output is written once.
+// The offset loop is software-pipelined: W_next travels global -> registers -> the other LDS buffer
+// while W_k feeds the MFMAs (one barrier per offset), and the wave's 27 x 16 x NT neighbour ids sit in LDS.
+// Tiles in which no voxel has the offset's neighbour skip the MFMAs, and an offset no tile of the
+// workgroup needs skips the W_k staging too; `order` (optional) lists the voxels in a spatially coherent
+// order so that the 16 voxels of a tile share their present/absent pattern.  Output is written once.
 //
 // out[v, co] = sum_k sum_ci feats[nbr[v, k], ci] * w[k, ci, co]          (nbr < 0: absent)
 #include "common.h"
@@ -21,69 +25,138 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int C, int NT>
 __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict__ feats,
                                                         const int32_t *__restrict__ nbr,
-                                                        const float *__restrict__ w, int64_t n, int kvol,
-                                                        float *__restrict__ out) {
+                                                        const float *__restrict__ w,
+                                                        const int32_t *__restrict__ order, int64_t n,
+                                                        int kvol, float *__restrict__ out) {
   constexpr int T = C / 16;
   constexpr int LDW = C + 4;
+  constexpr int WREG = (C * C + 1023) / 1024;       // float4 of W_k per thread (last one guarded)
+  constexpr int KMAX = 27;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *wt_lds = reinterpret_cast<float *>(smem_raw);          // W_k^T [co][ci], row stride LDW
+  float *wt_lds = reinterpret_cast<float *>(smem_raw);          // 2 x W_k^T [co][ci], row stride LDW
+  int32_t *nb_lds = reinterpret_cast<int32_t *>(wt_lds + 2 * C * LDW);   // [4 waves][KMAX][NT*16] neighbour ids
+  __shared__ uint32_t wg_mask;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
+  int32_t *my_nb = nb_lds + wave * (KMAX * NT * 16);
   const int64_t tiles = (n + 15) / 16;
   const int64_t tiles_per_pass = (int64_t)gridDim.x * 4 * NT;
   for (int64_t base = 0; base < tiles; base += tiles_per_pass) {
     const int64_t tile0 = base + ((int64_t)blockIdx.x * 4 + wave) * NT;
     floatx4 acc[NT][T];
+    int64_t vox[NT];                                // this lane's output voxel of each tile (-1: past the end)
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+    for (int j = 0; j < NT; j++) {
+      const int64_t q = (tile0 + j) * 16 + li;
+      vox[j] = (q < n) ? (order ? (int64_t)order[q] : q) : -1;
 #pragma unroll
       for (int tp = 0; tp < T; tp++) acc[j][tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid == 0) wg_mask = 0u;
+    // the wave's neighbour ids -> LDS in one round trip (the 4 quarter-waves split the offsets)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      for (int k = g; k < kvol; k += 4)
+        my_nb[(k * NT + j) * 16 + li] = (vox[j] >= 0) ? nbr[vox[j] * kvol + k] : -1;
+    __syncthreads();                                // ids visible; wg_mask zeroed; previous pass done with LDS
+    uint32_t wmask = 0u;                            // offsets for which some voxel of this wave has a neighbour
     for (int k = 0; k < kvol; k++) {
-      __syncthreads();                              // every wave is done with the previous W_k
-      const float *wk = w + (int64_t)k * C * C;     // [ci][co]
-      for (int e = tid * 4; e < C * C; e += 256 * 4) {
-        const int ci = e / C, co = e - ci * C;
-        const float4 w4 = *reinterpret_cast<const float4 *>(&wk[e]);
-        wt_lds[(co + 0) * LDW + ci] = w4.x; wt_lds[(co + 1) * LDW + ci] = w4.y;
-        wt_lds[(co + 2) * LDW + ci] = w4.z; wt_lds[(co + 3) * LDW + ci] = w4.w;
-      }
+      bool need = false;
+#pragma unroll
+      for (int j = 0; j < NT; j++) need |= my_nb[(k * NT + j) * 16 + li] >= 0;
+      if (__any(need)) wmask |= 1u << k;
+    }
+    if (lane == 0 && wmask) atomicOr(&wg_mask, wmask);
+    __syncthreads();
+    uint32_t m = wg_mask;                           // offsets the workgroup computes; all others skipped outright
+    if (m == 0u) {                                  // (uniform) nothing to do: rows of zeros
       __syncthreads();
-      int id[NT];
+    } else {
+      // software pipeline over the needed offsets: W_next travels global -> registers while W_k is used
+      float4 wreg[WREG];
+      int k = __ffs(m) - 1;
+      m &= m - 1;
+      {
+        const float *wk = w + (int64_t)k * C * C;
 #pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int64_t v = (tile0 + j) * 16 + li;
-        id[j] = (v < n) ? nbr[v * kvol + k] : -1;
+        for (int q = 0; q < WREG; q++)
+          if ((q * 256 + tid) * 4 < C * C) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
       }
-      float4 f[NT][T];
+      int buf = 0;
+      {
+        float *dst = wt_lds;
 #pragma unroll
-      for (int j = 0; j < NT; j++) {                // all gathers of the step back to back
-        const int64_t row = (id[j] >= 0) ? id[j] : 0;
-#pragma unroll
-        for (int t = 0; t < T; t++) f[j][t] = *reinterpret_cast<const float4 *>(&feats[row * C + 16 * t + 4 * g]);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const bool has = id[j] >= 0;
-        if (!__any(has)) continue;                  // wave-uniform: no voxel of the tile has neighbour k
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-          const float fx = has ? f[j][t].x : 0.f, fy = has ? f[j][t].y : 0.f;
-          const float fz = has ? f[j][t].z : 0.f, fw = has ? f[j][t].w : 0.f;
-#pragma unroll
-          for (int tp = 0; tp < T; tp++) {
-            const float4 a = *reinterpret_cast<const float4 *>(&wt_lds[(16 * tp + li) * LDW + 16 * t + 4 * g]);
-            acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, fx, acc[j][tp], 0, 0, 0);
-            acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, fy, acc[j][tp], 0, 0, 0);
-            acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, fz, acc[j][tp], 0, 0, 0);
-            acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, fw, acc[j][tp], 0, 0, 0);
+        for (int q = 0; q < WREG; q++) {
+          const int e = (q * 256 + tid) * 4, ci = e / C, co = e - ci * C;
+          if (e < C * C) {
+            dst[(co + 0) * LDW + ci] = wreg[q].x; dst[(co + 1) * LDW + ci] = wreg[q].y;
+            dst[(co + 2) * LDW + ci] = wreg[q].z; dst[(co + 3) * LDW + ci] = wreg[q].w;
           }
         }
       }
+      __syncthreads();
+      while (true) {
+        const int kn = m ? (__ffs(m) - 1) : -1;      // next needed offset (uniform)
+        m &= m - 1;
+        if (kn >= 0) {
+          const float *wk = w + (int64_t)kn * C * C;
+#pragma unroll
+          for (int q = 0; q < WREG; q++)
+          if ((q * 256 + tid) * 4 < C * C) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
+        }
+        if ((wmask >> k) & 1u) {                     // wave-uniform: this wave has work at offset k
+          const float *wt = wt_lds + buf * (C * LDW);
+          int id[NT];
+#pragma unroll
+          for (int j = 0; j < NT; j++) id[j] = my_nb[(k * NT + j) * 16 + li];
+          float4 f[NT][T];
+#pragma unroll
+          for (int j = 0; j < NT; j++) {            // all gathers of the step back to back
+            const int64_t row = (id[j] >= 0) ? id[j] : 0;
+#pragma unroll
+            for (int t = 0; t < T; t++) f[j][t] = *reinterpret_cast<const float4 *>(&feats[row * C + 16 * t + 4 * g]);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; j++) {
+            const bool has = id[j] >= 0;
+            if (!__any(has)) continue;              // wave-uniform: no voxel of the tile has neighbour k
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+              const float fx = has ? f[j][t].x : 0.f, fy = has ? f[j][t].y : 0.f;
+              const float fz = has ? f[j][t].z : 0.f, fw = has ? f[j][t].w : 0.f;
+#pragma unroll
+              for (int tp = 0; tp < T; tp++) {
+                const float4 a = *reinterpret_cast<const float4 *>(&wt[(16 * tp + li) * LDW + 16 * t + 4 * g]);
+                acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, fx, acc[j][tp], 0, 0, 0);
+                acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, fy, acc[j][tp], 0, 0, 0);
+                acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, fz, acc[j][tp], 0, 0, 0);
+                acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, fw, acc[j][tp], 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (kn < 0) break;
+        {                                            // W_next -> the other LDS buffer (nobody reads it now)
+          float *dst = wt_lds + (buf ^ 1) * (C * LDW);
+#pragma unroll
+          for (int q = 0; q < WREG; q++) {
+            const int e = (q * 256 + tid) * 4, ci = e / C, co = e - ci * C;
+            if (e < C * C) {
+              dst[(co + 0) * LDW + ci] = wreg[q].x; dst[(co + 1) * LDW + ci] = wreg[q].y;
+              dst[(co + 2) * LDW + ci] = wreg[q].z; dst[(co + 3) * LDW + ci] = wreg[q].w;
+            }
+          }
+        }
+        __syncthreads();                             // ONE barrier per offset
+        buf ^= 1;
+        k = kn;
+      }
+      __syncthreads();                               // LDS free for the next pass
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const int64_t v = (tile0 + j) * 16 + li;
-      if (v < n) {
+      const int64_t v = vox[j];
+      if (v >= 0) {
 #pragma unroll
         for (int tp = 0; tp < T; tp++)
           *reinterpret_cast<float4 *>(&out[v * C + 16 * tp + 4 * g]) =
@@ -126,13 +199,18 @@ __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restri
   }
 }
 
-static int g_conv_wgs = 512;   // 2 workgroups per CU: one stages W_k while the other runs MFMAs
+static int g_conv_wgs = 1024;  // cap (sweep: tools/convsweep.py)
+static int g_conv_nt = 0;      // 0 = by size; 1/2/4 forced (tuning)
+extern "C" int link_conv_set_tuning(int key, int value) {
+  if (key == 0 && value > 0) { g_conv_wgs = value; return LINK_OK; }
+  if (key == 1 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_conv_nt = value; return LINK_OK; }
+  return LINK_ERR_ARG;
+}
 
-template <int C>
-static int launch_conv_mfma(const float *feats, const int32_t *nbr, const float *w, int64_t n, int kvol,
-                            float *out, hipStream_t st) {
-  constexpr int NT = 4;
-  const size_t lds = (size_t)C * (C + 4) * sizeof(float);
+template <int C, int NT>
+static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                               int64_t n, int kvol, float *out, hipStream_t st) {
+  const size_t lds = ((size_t)2 * C * (C + 4) + (size_t)4 * 27 * NT * 16) * sizeof(float);
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -144,26 +222,42 @@ static int launch_conv_mfma(const float *feats, const int32_t *nbr, const float 
   const int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 4 * NT - 1) / (4 * NT);
   if (wgs > g_conv_wgs) wgs = g_conv_wgs;
-  hipLaunchKernelGGL((k_subm_conv_mfma<C, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, n, kvol, out);
+  hipLaunchKernelGGL((k_subm_conv_mfma<C, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out);
   return check_launch("link_subm_conv_forward");
 }
 
-extern "C" int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, int64_t n,
-                                      int32_t cin, int32_t cout, int32_t kvol, float *out, void *stream) {
+// tiles per wave: as few as still fills the chip (more workgroups = more latency hiding; fewer = less
+// W_k staging traffic); C = 128 is capped at 2 by the 160 KB of LDS
+template <int C>
+static int launch_conv_mfma(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                            int64_t n, int kvol, float *out, hipStream_t st) {
+  const int64_t tiles = (n + 15) / 16;
+  if (g_conv_nt == 4 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, st);
+  if (g_conv_nt == 2 || g_conv_nt == 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, st);
+  if (g_conv_nt == 1) return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, st);
+  if (tiles > (int64_t)g_conv_wgs * 4 * 2 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, st);
+  if (tiles > (int64_t)g_conv_wgs * 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, st);
+  return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, st);
+}
+
+extern "C" int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w,
+                                      const int32_t *order, int64_t n, int32_t cin, int32_t cout,
+                                      int32_t kvol, float *out, void *stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || cin > 256 || cout > 256 || kvol <= 0) return LINK_ERR_ARG;
+  const bool mfma_ok = cin == cout && (cin & 15) == 0 && cin <= 128 && kvol <= 27;
   if (n == 0) return LINK_OK;
   if (!feats || !nbr || !w || !out) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  if (cin == cout && (cin & 15) == 0 && cin <= 128) {
+  if (mfma_ok) {
     switch (cin) {
-      case 16: return launch_conv_mfma<16>(feats, nbr, w, n, kvol, out, st);
-      case 32: return launch_conv_mfma<32>(feats, nbr, w, n, kvol, out, st);
-      case 48: return launch_conv_mfma<48>(feats, nbr, w, n, kvol, out, st);
-      case 64: return launch_conv_mfma<64>(feats, nbr, w, n, kvol, out, st);
-      case 80: return launch_conv_mfma<80>(feats, nbr, w, n, kvol, out, st);
-      case 96: return launch_conv_mfma<96>(feats, nbr, w, n, kvol, out, st);
-      case 112: return launch_conv_mfma<112>(feats, nbr, w, n, kvol, out, st);
-      default: return launch_conv_mfma<128>(feats, nbr, w, n, kvol, out, st);
+      case 16: return launch_conv_mfma<16>(feats, nbr, w, order, n, kvol, out, st);
+      case 32: return launch_conv_mfma<32>(feats, nbr, w, order, n, kvol, out, st);
+      case 48: return launch_conv_mfma<48>(feats, nbr, w, order, n, kvol, out, st);
+      case 64: return launch_conv_mfma<64>(feats, nbr, w, order, n, kvol, out, st);
+      case 80: return launch_conv_mfma<80>(feats, nbr, w, order, n, kvol, out, st);
+      case 96: return launch_conv_mfma<96>(feats, nbr, w, order, n, kvol, out, st);
+      case 112: return launch_conv_mfma<112>(feats, nbr, w, order, n, kvol, out, st);
+      default: return launch_conv_mfma<128>(feats, nbr, w, order, n, kvol, out, st);
     }
   }
   dim3 grid(blocks_for(n * 64, 256)), block(256);

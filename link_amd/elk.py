@@ -415,6 +415,13 @@ class Conv3d(nn.Module):
             except GridTooLarge:
                 offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
                 nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
+            # spatially coherent voxel order for the kernel's tile-level skipping: voxels grouped by
+            # (4*stride)^3 blocks of the dense block grid (the LinK index with a small block edge)
+            try:
+                order = BlockIndex(x.C, 4 * ts, want_idx64=False).perm
+            except GridTooLarge:
+                order = None
+            nbr = (nbr, order)
             x.kmaps[key] = nbr
         return nbr
 
@@ -423,13 +430,15 @@ class Conv3d(nn.Module):
         if self.kernel_volume == 1:
             out = feats.matmul(self.kernel)
         else:
-            out = _SubmConv.apply(feats, self.kernel, self._neighbor_table(x))
+            nbr, order = self._neighbor_table(x)
+            out = _SubmConv.apply(feats, self.kernel, nbr, order)
         y = SparseTensor(out, x.C, x.s)
         y.cmaps, y.kmaps = x.cmaps, x.kmaps
         return y
 
 
-def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
+              order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd."""
     if feats.device.type != "cuda":
         raise L.LinkAmdError("subm_conv needs GPU tensors (HIP path; no CPU fallback)")
@@ -439,7 +448,8 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor) -> t
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
-    L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), n, cin, cout,
+    L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(),
+                                           order.data_ptr() if order is not None else None, n, cin, cout,
                                            kvol, out.data_ptr(), _st()), "link_subm_conv_forward")
     return out
 
@@ -450,9 +460,10 @@ class _SubmConv(torch.autograd.Function):
     nbr[u,K-1-k] = v).  Weight gradient: per offset gather + one batched library GEMM."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, nbr):
+    def forward(ctx, feats, kernel, nbr, order=None):
         ctx.save_for_backward(feats, kernel, nbr)
-        return subm_conv(feats, kernel, nbr)
+        ctx.order = order
+        return subm_conv(feats, kernel, nbr, order)
 
     @staticmethod
     def backward(ctx, g):
@@ -460,13 +471,13 @@ class _SubmConv(torch.autograd.Function):
         g = g.contiguous().float()
         g_feats = g_kernel = None
         if ctx.needs_input_grad[0]:
-            g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr)
+            g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr, ctx.order)
         if ctx.needs_input_grad[1]:
             n = feats.shape[0]
             padded = torch.cat([feats.detach().float(), feats.new_zeros(1, feats.shape[1])], dim=0)
             idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
             g_kernel = torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kernel.shape[0])], 0)
-        return g_feats, g_kernel, None
+        return g_feats, g_kernel, None, None
 
 
 # ------------------------------------------------------------------------------------------------
