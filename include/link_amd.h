@@ -355,6 +355,13 @@ int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t c
  * (the neighbour relation of an odd kernel at stride 1 is symmetric). */
 int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
                            int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out, void *stream);
+/* Row N2 (fused epilogue): out = relu(addend + LayerNorm(conv(feats)) * ln_w + ln_b) in the convolution's
+ * store phase -- `st.F = self.activate(new_st_F + self.norm_local(st_local.F))` (linkunet.py:183,
+ * ts_elk.py:228) with addend = the R_core output.  addend may be NULL, relu 0/1; eps of norm_local. */
+int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                               int64_t n, int32_t cin, int32_t cout, int32_t kvol, const float *ln_w,
+                               const float *ln_b, float eps, const float *addend, int32_t relu, float *out,
+                               void *stream);
 /* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
 int link_conv_set_tuning(int key, int value);
 

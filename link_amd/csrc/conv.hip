@@ -22,12 +22,20 @@ using namespace link;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// optional fused epilogue (row N2 of SURVEY.md section 8f; linkunet.py:183 / ts_elk.py:228):
+// out = relu(addend + LayerNorm(conv) * ln_w + ln_b); ln_w == NULL -> plain convolution output
+struct conv_epilogue {
+  const float *ln_w, *ln_b, *addend;
+  float eps;
+  int relu;
+};
+
 template <int C, int NT>
 __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict__ feats,
                                                         const int32_t *__restrict__ nbr,
                                                         const float *__restrict__ w,
                                                         const int32_t *__restrict__ order, int64_t n,
-                                                        int kvol, float *__restrict__ out) {
+                                                        int kvol, float *__restrict__ out, conv_epilogue ep) {
   constexpr int T = C / 16;
   constexpr int LDW = C + 4;
   constexpr int WREG = (C * C + 1023) / 1024;       // float4 of W_k per thread (last one guarded)
@@ -156,7 +164,47 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const int64_t v = vox[j];
-      if (v >= 0) {
+      if (ep.ln_w) {
+        // row N2: out = relu(addend + LayerNorm(conv)) -- the accumulator layout holds 16 channels of ONE
+        // voxel per lane (the quarter-waves hold the other 48), so the statistics are 16 in-lane adds + 2
+        // cross-lane steps, exactly as in the pre_mix kernel
+        float sm = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < T; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float mean = sm * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < T; tp++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float d = acc[j][tp][r] - mean;
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / C) + ep.eps);
+        if (v >= 0) {
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) {
+            const int ch = 16 * tp + 4 * g;
+            const float4 lw = *reinterpret_cast<const float4 *>(&ep.ln_w[ch]);
+            const float4 lb = *reinterpret_cast<const float4 *>(&ep.ln_b[ch]);
+            float4 o;
+            o.x = (acc[j][tp][0] - mean) * rstd * lw.x + lb.x;
+            o.y = (acc[j][tp][1] - mean) * rstd * lw.y + lb.y;
+            o.z = (acc[j][tp][2] - mean) * rstd * lw.z + lb.z;
+            o.w = (acc[j][tp][3] - mean) * rstd * lw.w + lb.w;
+            if (ep.addend) {
+              const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * C + ch]);
+              o.x = a4.x + o.x; o.y = a4.y + o.y; o.z = a4.z + o.z; o.w = a4.w + o.w;
+            }
+            if (ep.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4 *>(&out[v * C + ch]) = o;
+          }
+        }
+      } else if (v >= 0) {
 #pragma unroll
         for (int tp = 0; tp < T; tp++)
           *reinterpret_cast<float4 *>(&out[v * C + 16 * tp + 4 * g]) =
@@ -171,7 +219,8 @@ template <int CPL>
 __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restrict__ feats,
                                                            const int32_t *__restrict__ nbr,
                                                            const float *__restrict__ w, int64_t n, int cin,
-                                                           int cout, int kvol, float *__restrict__ out) {
+                                                           int cout, int kvol, float *__restrict__ out,
+                                                           conv_epilogue ep) {
   const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (v >= n) return;
@@ -192,6 +241,30 @@ __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restri
       }
     }
   }
+  if (ep.ln_w) {
+    float sm = 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; q++) sm += (lane + 64 * q < cout) ? acc[q] : 0.f;
+    const float mean = wave_sum(sm) / cout;
+    float qq = 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+      const float d = (lane + 64 * q < cout) ? acc[q] - mean : 0.f;
+      qq += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(qq) / cout + ep.eps);
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+      const int co = lane + 64 * q;
+      if (co < cout) {
+        float o = (acc[q] - mean) * rstd * ep.ln_w[co] + ep.ln_b[co];
+        if (ep.addend) o = ep.addend[v * cout + co] + o;
+        if (ep.relu) o = fmaxf(o, 0.f);
+        out[v * cout + co] = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < CPL; q++) {
     const int co = lane + 64 * q;
@@ -209,7 +282,7 @@ extern "C" int link_conv_set_tuning(int key, int value) {
 
 template <int C, int NT>
 static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
-                               int64_t n, int kvol, float *out, hipStream_t st) {
+                               int64_t n, int kvol, float *out, const conv_epilogue &ep, hipStream_t st) {
   const size_t lds = ((size_t)2 * C * (C + 4) + (size_t)4 * 27 * NT * 16) * sizeof(float);
   if (lds > 64 * 1024) {
     static bool done = false;
@@ -222,7 +295,7 @@ static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const flo
   const int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 4 * NT - 1) / (4 * NT);
   if (wgs > g_conv_wgs) wgs = g_conv_wgs;
-  hipLaunchKernelGGL((k_subm_conv_mfma<C, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out);
+  hipLaunchKernelGGL((k_subm_conv_mfma<C, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
   return check_launch("link_subm_conv_forward");
 }
 
@@ -230,19 +303,39 @@ static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const flo
 // W_k staging traffic); C = 128 is capped at 2 by the 160 KB of LDS
 template <int C>
 static int launch_conv_mfma(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
-                            int64_t n, int kvol, float *out, hipStream_t st) {
+                            int64_t n, int kvol, float *out, const conv_epilogue &ep, hipStream_t st) {
   const int64_t tiles = (n + 15) / 16;
-  if (g_conv_nt == 4 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, st);
-  if (g_conv_nt == 2 || g_conv_nt == 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, st);
-  if (g_conv_nt == 1) return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, st);
-  if (tiles > (int64_t)g_conv_wgs * 4 * 2 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, st);
-  if (tiles > (int64_t)g_conv_wgs * 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, st);
-  return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, st);
+  if (g_conv_nt == 4 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (g_conv_nt == 2 || g_conv_nt == 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (g_conv_nt == 1) return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (tiles > (int64_t)g_conv_wgs * 4 * 2 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (tiles > (int64_t)g_conv_wgs * 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
+  return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
 }
+
+static int subm_conv_impl(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                          int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out,
+                          const conv_epilogue &ep, void *stream);
 
 extern "C" int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w,
                                       const int32_t *order, int64_t n, int32_t cin, int32_t cout,
                                       int32_t kvol, float *out, void *stream) {
+  const conv_epilogue ep = {nullptr, nullptr, nullptr, 0.f, 0};
+  return subm_conv_impl(feats, nbr, w, order, n, cin, cout, kvol, out, ep, stream);
+}
+
+extern "C" int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const float *w,
+                                          const int32_t *order, int64_t n, int32_t cin, int32_t cout,
+                                          int32_t kvol, const float *ln_w, const float *ln_b, float eps,
+                                          const float *addend, int32_t relu, float *out, void *stream) {
+  if (!ln_w || !ln_b) return LINK_ERR_ARG;
+  const conv_epilogue ep = {ln_w, ln_b, addend, eps, relu ? 1 : 0};
+  return subm_conv_impl(feats, nbr, w, order, n, cin, cout, kvol, out, ep, stream);
+}
+
+static int subm_conv_impl(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
+                          int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out,
+                          const conv_epilogue &ep, void *stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || cin > 256 || cout > 256 || kvol <= 0) return LINK_ERR_ARG;
   const bool mfma_ok = cin == cout && (cin & 15) == 0 && cin <= 128 && kvol <= 27;
   if (n == 0) return LINK_OK;
@@ -250,21 +343,21 @@ extern "C" int link_subm_conv_forward(const float *feats, const int32_t *nbr, co
   hipStream_t st = S(stream);
   if (mfma_ok) {
     switch (cin) {
-      case 16: return launch_conv_mfma<16>(feats, nbr, w, order, n, kvol, out, st);
-      case 32: return launch_conv_mfma<32>(feats, nbr, w, order, n, kvol, out, st);
-      case 48: return launch_conv_mfma<48>(feats, nbr, w, order, n, kvol, out, st);
-      case 64: return launch_conv_mfma<64>(feats, nbr, w, order, n, kvol, out, st);
-      case 80: return launch_conv_mfma<80>(feats, nbr, w, order, n, kvol, out, st);
-      case 96: return launch_conv_mfma<96>(feats, nbr, w, order, n, kvol, out, st);
-      case 112: return launch_conv_mfma<112>(feats, nbr, w, order, n, kvol, out, st);
-      default: return launch_conv_mfma<128>(feats, nbr, w, order, n, kvol, out, st);
+      case 16: return launch_conv_mfma<16>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 32: return launch_conv_mfma<32>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 48: return launch_conv_mfma<48>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 64: return launch_conv_mfma<64>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 80: return launch_conv_mfma<80>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 96: return launch_conv_mfma<96>(feats, nbr, w, order, n, kvol, out, ep, st);
+      case 112: return launch_conv_mfma<112>(feats, nbr, w, order, n, kvol, out, ep, st);
+      default: return launch_conv_mfma<128>(feats, nbr, w, order, n, kvol, out, ep, st);
     }
   }
   dim3 grid(blocks_for(n * 64, 256)), block(256);
   const int cpl = (cout + 63) / 64;
-  if (cpl == 1) hipLaunchKernelGGL(k_subm_conv_generic<1>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out);
-  else if (cpl == 2) hipLaunchKernelGGL(k_subm_conv_generic<2>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out);
-  else if (cpl == 3) hipLaunchKernelGGL(k_subm_conv_generic<3>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out);
-  else hipLaunchKernelGGL(k_subm_conv_generic<4>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out);
+  if (cpl == 1) hipLaunchKernelGGL(k_subm_conv_generic<1>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out, ep);
+  else if (cpl == 2) hipLaunchKernelGGL(k_subm_conv_generic<2>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out, ep);
+  else if (cpl == 3) hipLaunchKernelGGL(k_subm_conv_generic<3>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out, ep);
+  else hipLaunchKernelGGL(k_subm_conv_generic<4>, grid, block, 0, st, feats, nbr, w, n, (int)cin, (int)cout, (int)kvol, out, ep);
   return check_launch("link_subm_conv_forward");
 }

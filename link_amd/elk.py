@@ -40,7 +40,7 @@ from .tensor import SparseTensor
 from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
-           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv"]
+           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv", "subm_conv_ln_add_relu"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
 
@@ -454,6 +454,26 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     return out
 
 
+def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
+                          order: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float,
+                          addend: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+    """relu(addend + LayerNorm(subm_conv(feats))): the block's tail (linkunet.py:183) fused into the
+    convolution's store phase (include/link_amd.h: link_subm_conv_ln_add_relu).  No autograd."""
+    n, cin = feats.shape
+    kvol, cin2, cout = kernel.shape
+    assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
+    f = feats.detach().contiguous().float()
+    w = kernel.detach().contiguous().float()
+    add = addend.detach().contiguous().float() if addend is not None else None
+    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    L.check(L.lib().link_subm_conv_ln_add_relu(
+        f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), order.data_ptr() if order is not None else None,
+        n, cin, cout, kvol, ln_w.detach().contiguous().float().data_ptr(),
+        ln_b.detach().contiguous().float().data_ptr(), float(eps), add.data_ptr() if add is not None else None,
+        1 if relu else 0, out.data_ptr(), _st()), "link_subm_conv_ln_add_relu")
+    return out
+
+
 class _SubmConv(torch.autograd.Function):
     """Differentiable stride-1 submanifold convolution on the HIP kernel.  Input gradient: the same
     kernel on grad_out with w'[k] = w[K-1-k]^T (odd kernel, same coordinates: nbr[v,k] = u  <=>
@@ -496,6 +516,26 @@ class _ELKBase(nn.Module):
             return elk_core_autograd(*args)      # op-by-op composition: any width / r
         return elk_core_fused(*args)
 
+    def _finish(self, st: SparseTensor, core_fn):
+        """st.F = relu(core + norm_local(local_mix(st).F))  (linkunet.py:125,183 / ts_elk.py:146,228).
+        Inference: the LayerNorm + add + ReLU run in the convolution kernel's store phase (row N2); with
+        grad enabled, or when forward hooks observe local_mix / norm_local, the modules run one by one."""
+        conv = self.local_mix[0]
+        needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(
+            p.requires_grad for p in self.parameters()))
+        hooked = any(m._forward_hooks or m._forward_pre_hooks
+                     for m in (self.local_mix, conv, self.norm_local, self.activate))
+        if needs_grad or hooked or conv.kernel_volume == 1 or st.F.dtype != torch.float32:
+            local = self.local_mix(st)
+            new = core_fn()
+            st.F = self.activate(new + self.norm_local(local.F))
+            return st
+        new = core_fn()
+        nbr, order = conv._neighbor_table(st)
+        st.F = subm_conv_ln_add_relu(st.F, conv.kernel, nbr, order, self.norm_local.weight, self.norm_local.bias,
+                                     self.norm_local.eps, new, relu=True)
+        return st
+
 
 class ELKBlock(_ELKBase):
     def __init__(self, inc, outc, groups=1, baseop="cos_x", variant="unet"):
@@ -518,13 +558,11 @@ class ELKBlock(_ELKBase):
         if self.baseop == "cos_x" and self.groups != 1:
             # linkunet.py:165 does not tile theta for cos_x: only groups == 1 is shape-consistent
             raise ValueError("baseop='cos_x' requires groups == 1 (as in the reference configs)")
-        local = self.local_mix(st)
         alpha = self.alpha if self.baseop == "cos_x" else None
         coord_div = float(st.s[0]) if (self.variant == "encoder" and self.baseop == "cos_x") else 1.0
         cg = self.inc // self.groups
-        new = self._core(st, int(s), int(r), self.pos_weight[0].weight, alpha, cg, coord_div)
-        st.F = self.activate(new + self.norm_local(local.F))
-        return st
+        return self._finish(st, lambda: self._core(st, int(s), int(r), self.pos_weight[0].weight, alpha, cg,
+                                                   coord_div))
 
 
 class SparseConvTensor:
@@ -587,11 +625,8 @@ class TSELKBlock(_ELKBase):
         return ts2spconv(self.forward_(st, stride), save)
 
     def forward_(self, st: SparseTensor, stride):
-        local = self.local_mix(st)
         if self.baseop == "cos":      # ts_elk.py:168: first C/2 columns, tiled twice
             w_pos, cg = self.pos_weight[0].weight[: self.inc // 2], self.inc // 2
         else:                          # 'sin' (ts_elk.py:155-156): all C columns, untiled
             w_pos, cg = self.pos_weight[0].weight, self.inc
-        new = self._core(st, int(stride), 3, w_pos, None, cg, 1.0)
-        st.F = self.activate(new + self.norm_local(local.F))
-        return st
+        return self._finish(st, lambda: self._core(st, int(stride), 3, w_pos, None, cg, 1.0))

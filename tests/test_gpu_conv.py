@@ -94,3 +94,29 @@ def test_elkblock_forward_full_block_vs_oracle():
     local = lo.subm_conv_torch(feats, coords, sd["local_mix.0.kernel"], 1)
     ref = torch.relu(core + TF.layer_norm(local, (C,), sd["norm_local.weight"], sd["norm_local.bias"], 1e-6))
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("C,baseop,groups", [(64, "cos", 2), (8, "sin", 2), (32, "cos_x", 1)])
+def test_fused_epilogue_equals_module_by_module(C, baseop, groups):
+    """Row N2: the conv kernel's fused LayerNorm + add + ReLU tail against the same block run module by
+    module (a forward hook on local_mix switches the block to that path)."""
+    import link_amd as la
+    coords = torch.from_numpy(lidar_like(12000, seed=5)).cuda()
+    n = coords.shape[0]
+    torch.manual_seed(1)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    with torch.no_grad():
+        blk.norm_local.weight.uniform_(0.5, 1.5); blk.norm_local.bias.uniform_(-0.5, 0.5)
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(2)).cuda()
+    s, r = (7, 3) if baseop != "cos_x" else (3, 2)
+    with torch.no_grad():
+        fused = blk(la.SparseTensor(feats.clone(), coords, 1), s, r).F
+        seen = []
+        h = blk.local_mix.register_forward_hook(lambda m, i, o: seen.append(o.F))
+        try:
+            plain = blk(la.SparseTensor(feats.clone(), coords, 1), s, r).F
+        finally:
+            h.remove()
+    assert len(seen) == 1                           # the hooked run went module by module
+    assert rel_err(fused.cpu().numpy(), plain.cpu().numpy()) < 2e-6
+    assert float(fused.min()) >= 0.0
