@@ -191,6 +191,16 @@ int link_aux_to_voxel_backward(const float *g_out, const int32_t *perm, const in
                                const int32_t *counts, const int32_t *nbr_t, const float *denom,
                                int64_t n, int64_t m, int64_t c, int64_t k, float *g_new,
                                float *g_small, void *stream);
+/* aux_to_voxel forward on the dense block grid (same results as link_aux_to_voxel_forward, which takes an
+ * explicit neighbour table): means -> sum table, r^3 neighbour sum by the fused path's z-sliding block
+ * gather, float4 row gather to voxels.  Needs the index that produced `small_f`'s row order
+ * (blk_coords, cell_blk, grid, hdr from link_index_build), w % 8 == 0 or w % 12 == 0, r <= 3
+ * (LINK_ERR_ARG otherwise).  S scratch fp[(m+1)*(w+1)]; new_feat fp[m,w]; denom fp[m]; out fp[n,w]. */
+int link_aux_to_voxel_forward_grid(const float *small_f, const int32_t *counts, const int32_t *blk_coords,
+                                   const int32_t *cell_blk, const link_grid_t *grid /* host */,
+                                   const int32_t *hdr, const int64_t *idx, int64_t n, int64_t m, int32_t w,
+                                   int32_t r, float *S, float *new_feat, float *denom, float *out,
+                                   void *stream);
 
 /* =============================================================================================
  * C. Fused ELKBlock core (R_core of SURVEY.md section 8d)

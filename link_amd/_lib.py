@@ -103,6 +103,8 @@ SIGNATURES = {
                                          c_void_p]),
     "link_subm_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                        c_void_p, c_void_p]),
+    "link_aux_to_voxel_forward_grid": (c_int, [c_void_p] * 4 + [POINTER(LinkGrid), c_void_p, c_void_p, c_int64,
+                                               c_int64, c_int32, c_int32] + [c_void_p] * 5),
     "link_conv_set_tuning": (c_int, [c_int, c_int]),
     "link_subm_conv_ln_add_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                            c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -69,15 +69,25 @@ class _AuxToVoxel(Function):
         small_f = small_f.contiguous().float()
         m, c = small_f.shape
         n = idx.shape[0]
-        k = nbr.shape[1]
+        k = r ** 3
         dev = small_f.device
         new_feat = torch.empty((m, c), dtype=torch.float32, device=dev)
         denom = torch.empty(m, dtype=torch.float32, device=dev)
         out = torch.empty((n, c), dtype=torch.float32, device=dev)
-        L.check(L.lib().link_aux_to_voxel_forward(small_f.data_ptr(), counts.data_ptr(), nbr.data_ptr(),
-                                                  idx.data_ptr(), n, m, c, k, new_feat.data_ptr(),
-                                                  denom.data_ptr(), out.data_ptr(), _st()),
-                "link_aux_to_voxel_forward")
+        if (c % 8 == 0 or c % 12 == 0) and r <= 3 and c <= 512 and m > 0 and (m + 1) * (c + 1) * 4 < 2 ** 32:
+            # dense-grid form: the fused path's block-gather kernel (no neighbour table needed)
+            S = torch.empty((m + 1) * (c + 1), dtype=torch.float32, device=dev)
+            L.check(L.lib().link_aux_to_voxel_forward_grid(
+                small_f.data_ptr(), counts.data_ptr(), index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
+                ctypes.byref(index.grid), index.hdr.data_ptr(), idx.data_ptr(), n, m, c, r, S.data_ptr(),
+                new_feat.data_ptr(), denom.data_ptr(), out.data_ptr(), _st()), "link_aux_to_voxel_forward_grid")
+        else:
+            nbr = index.neighbor_map(r)
+            k = nbr.shape[1]
+            L.check(L.lib().link_aux_to_voxel_forward(small_f.data_ptr(), counts.data_ptr(), nbr.data_ptr(),
+                                                      idx.data_ptr(), n, m, c, k, new_feat.data_ptr(),
+                                                      denom.data_ptr(), out.data_ptr(), _st()),
+                    "link_aux_to_voxel_forward")
         ctx.index, ctx.r = index, r
         ctx.save_for_backward(counts, denom)
         ctx.shape = (n, m, c, k)
@@ -150,8 +160,7 @@ def aux_to_voxel(small_x: SparseTensor, large_x: SparseTensor, idx: torch.Tensor
     r = int(r)
     index = getattr(small_x, "_link_index", None)
     if index is not None and idx is index.idx_query and small_x.C.data_ptr() == index.blk_coords.data_ptr():
-        nbr = index.neighbor_map(r)
-        large_x.F = _AuxToVoxel.apply(small_x.F, counts.contiguous().int(), nbr, idx, index, r)
+        large_x.F = _AuxToVoxel.apply(small_x.F, counts.contiguous().int(), None, idx, index, r)
         return large_x
     # foreign inputs: reference algorithm on the op kernels (neighbour map from the dense table when the
     # rows fit, else hash queries)

@@ -2261,6 +2261,67 @@ extern "C" int link_elk_mid_backward(const float *g_out, const float *fin, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// aux_to_voxel on the block-gather kernel (the drop-in surface's R_agg):
+// utils.py:75-82 multiplies the block MEANS by their counts again and sums r^3 neighbours; here the
+// means are turned into the S layout (sum rows + zero row + count column) in one pass, the fused
+// path's k_block_gather_g produces new_feat = sum/count-sum (and the denominators the backward needs),
+// and a float4 row gather expands blocks to voxels.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_means_to_table(const float *__restrict__ mean,
+                                                        const int32_t *__restrict__ counts, int64_t m, int w,
+                                                        float *__restrict__ S) {
+  const int w4 = w >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of one row
+  if (e < (m + 1) * w4) {
+    const int64_t row = e / w4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                          // row m: the all-zero row
+    if (row < m) {
+      const float cnt = (float)counts[row];
+      v = *reinterpret_cast<const float4 *>(&mean[e * 4]);
+      v.x *= cnt; v.y *= cnt; v.z *= cnt; v.w *= cnt;
+    }
+    *reinterpret_cast<float4 *>(&S[e * 4]) = v;
+  }
+  if (e <= m) S[(m + 1) * (int64_t)w + e] = (e < m) ? (float)counts[e] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_row_gather4(const float *__restrict__ tab,
+                                                     const int64_t *__restrict__ idx, int64_t n, int w,
+                                                     float *__restrict__ out) {
+  const int w4 = w >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w4) return;
+  const int64_t i = e / w4;
+  const int j = (int)(e - i * w4);
+  *reinterpret_cast<float4 *>(&out[e * 4]) = *reinterpret_cast<const float4 *>(&tab[idx[i] * w + 4 * j]);
+}
+
+extern "C" int link_aux_to_voxel_forward_grid(const float *small_f, const int32_t *counts,
+                                              const int32_t *blk_coords, const int32_t *cell_blk,
+                                              const link_grid_t *grid, const int32_t *hdr, const int64_t *idx,
+                                              int64_t n, int64_t m, int32_t w, int32_t r, float *S_,
+                                              float *new_feat, float *denom, float *out, void *stream) {
+  if (n < 0 || m < 0 || w <= 0 || r <= 0 || r > 3 || !grid) return LINK_ERR_ARG;
+  int parts = 0;
+  if (w % 8 == 0 && w / 2 <= 256) parts = 2;
+  else if (w % 12 == 0 && w / 3 <= 256) parts = 3;
+  if (!parts) return LINK_ERR_ARG;                   // callers fall back to link_aux_to_voxel_forward
+  if (m == 0) return LINK_OK;
+  if (!small_f || !counts || !blk_coords || !cell_blk || !hdr || !S_ || !new_feat || !denom) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  hipLaunchKernelGGL(k_means_to_table, dim3(blocks_for((m + 1) * (w / 4), 256)), dim3(256), 0, st, small_f, counts,
+                     m, (int)w, S_);
+  link_elk_desc_t d = {parts == 3 ? LINK_OP_COSX : LINK_OP_COS, w / parts, w / parts, r, 1.0f, 1e-6f};
+  int rc = block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, &d, m, new_feat, 0, denom, stream);
+  if (rc != LINK_OK) return rc;
+  if (n > 0) {
+    if (!idx || !out) return LINK_ERR_ARG;
+    hipLaunchKernelGGL(k_row_gather4, dim3(blocks_for(n * (w / 4), 256)), dim3(256), 0, st, new_feat, idx, n, (int)w, out);
+  }
+  return check_launch("link_aux_to_voxel_forward_grid");
+}
+
+// ---------------------------------------------------------------------------------------------
 // one-call R_core
 // ---------------------------------------------------------------------------------------------
 extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_grid_t *grid,

@@ -177,7 +177,7 @@ class ElkCorePlan:
 # ------------------------------------------------------------------------------------------------
 def _aggregate(x: torch.Tensor, index: BlockIndex, r: int) -> torch.Tensor:
     mean = _BlockMean.apply(x, index)
-    return _AuxToVoxel.apply(mean, index.counts, index.neighbor_map(r), index.idx_query, index, r)
+    return _AuxToVoxel.apply(mean, index.counts, None, index.idx_query, index, r)
 
 
 def elk_core_autograd(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b, baseop,
