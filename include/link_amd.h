@@ -372,6 +372,14 @@ int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const flo
                                int64_t n, int32_t cin, int32_t cout, int32_t kvol, const float *ln_w,
                                const float *ln_b, float eps, const float *addend, int32_t relu, float *out,
                                void *stream);
+/* Weight gradient of the convolution above: g_w[k][ci][co] = sum_v feats[nbr[v,k]][ci] * g_out[v][co]
+ * (replaces the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278: per offset gather +
+ * cuBLAS mm(in^T, grad)).  nbr_t i32[kvol, N] is the TRANSPOSED neighbour table (coalesced column
+ * reads); C = Cin = Cout <= 64, C % 4 == 0.  partial fp[link_subm_conv_wgrad_chunks(), kvol, C, C]: the
+ * host sums the chunk axis (fixed grid -> deterministic). */
+int32_t link_subm_conv_wgrad_chunks(void);
+int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c,
+                         int32_t kvol, float *partial, void *stream);
 /* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
 int link_conv_set_tuning(int key, int value);
 

@@ -272,6 +272,119 @@ __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient  g_w[k][ci][co] = sum_v feats[nbr[v,k]][ci] * g_out[v][co]   (C <= 64, C % 4 == 0)
+//
+// The reduction runs over voxels, so voxels are the MFMA k-dimension: a step takes 4 (input row,
+// output row) pairs, lane (li, g) loads ONE float4 of pair g's input row (channels 4li..4li+3) and one
+// of its grad row, and the 16 products {r, q} of v_mfma_f32_16x16x4_f32 give
+// D_{r,q}[i][j] = sum_pairs F[4i + r] * G[4j + q] -- all 64 x 64 entries from two 16-byte loads per
+// lane.  Workgroup (k, chunk): its 4 waves walk the chunk's voxels 64 at a time, read the offset's
+// column of the transposed neighbour table (coalesced), compact the present (in, out) pairs with a
+// ballot into a per-wave LDS queue (exact sparsity skipping), and consume them 16 at a time; the
+// waves' accumulators are summed through LDS in a fixed order and written as one [C x C] partial per
+// (chunk, k): deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_subm_conv_wgrad(const float *__restrict__ feats,
+                                                         const float *__restrict__ gout,
+                                                         const int32_t *__restrict__ nbr_t, int64_t n, int c,
+                                                         int kvol, int chunks, float *__restrict__ partial) {
+  __shared__ int2 queue[4][96];                     // per wave: pending (in row, out row) pairs
+  __shared__ float red[4][16][4][64];               // [wave][r*4+q][e][lane]  (64 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x % kvol, chunk = blockIdx.x / kvol;
+  const bool act = 4 * li < c;
+  const int cofs = act ? 4 * li : 0;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[r][q] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  // voxel range of this wave: the chunk's range cut in 4, in units of 64 voxels
+  const int64_t units = (n + 63) / 64;
+  const int64_t per_chunk = (units + chunks - 1) / chunks;
+  const int64_t u0 = (int64_t)chunk * per_chunk, u1 = (u0 + per_chunk < units) ? u0 + per_chunk : units;
+  const int32_t *col = nbr_t + (int64_t)k * n;
+  int2 *my_q = queue[wave];
+  int qn = 0;                                       // pairs waiting in the queue (wave-uniform)
+  auto consume = [&](int base, int cnt) {           // cnt <= 16 pairs starting at queue[base]: 4 MFMA steps
+    float4 fa[4], ga[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int qi = 4 * s + g;
+      const bool ok = qi < cnt;
+      const int2 pr = my_q[base + (ok ? qi : 0)];
+      fa[s] = *reinterpret_cast<const float4 *>(&feats[(int64_t)pr.x * c + cofs]);
+      ga[s] = *reinterpret_cast<const float4 *>(&gout[(int64_t)pr.y * c + cofs]);
+      if (!ok || !act) fa[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!act) ga[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      if (4 * s >= cnt) break;                      // wave-uniform
+      const float fv[4] = {fa[s].x, fa[s].y, fa[s].z, fa[s].w}, gv[4] = {ga[s].x, ga[s].y, ga[s].z, ga[s].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[r], gv[q], acc[r][q], 0, 0, 0);
+    }
+  };
+  for (int64_t u = u0 + wave; u < u1; u += 4) {
+    const int64_t v = u * 64 + lane;
+    const int id = (v < n) ? col[v] : -1;
+    const uint64_t m = __ballot(id >= 0);
+    if (id >= 0) my_q[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(id, (int)v);
+    qn += __popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int done = 0;
+    while (qn - done >= 16) { consume(done, 16); done += 16; }
+    if (done) {                                     // move the < 16 leftovers to the front
+      const int left = qn - done;
+      int2 keep = make_int2(0, 0);
+      if (lane < left) keep = my_q[done + lane];
+      __builtin_amdgcn_wave_barrier();
+      if (lane < left) my_q[lane] = keep;
+      qn = left;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (qn > 0) consume(0, qn);                       // tail (qn < 16)
+  // fixed-order sum of the 4 waves, then one [C x C] partial per (chunk, k)
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[wave][r * 4 + q][e][lane] = acc[r][q][e];
+  __syncthreads();
+  float *dst = partial + ((int64_t)chunk * kvol + k) * c * c;
+  for (int idx = tid; idx < 16 * 4 * 64; idx += 256) {
+    const int l = idx & 63, e = (idx >> 6) & 3, rq = idx >> 8;
+    const int r = rq >> 2, q = rq & 3;
+    const int ci = 4 * (4 * (l >> 4) + e) + r, co = 4 * (l & 15) + q;   // D[i = 4g+e][j = li] of product (r, q)
+    if (ci < c && co < c)
+      dst[ci * c + co] = (red[0][rq][e][l] + red[1][rq][e][l]) + (red[2][rq][e][l] + red[3][rq][e][l]);
+  }
+}
+
+extern "C" int32_t link_subm_conv_wgrad_chunks(void) { return 16; }
+
+extern "C" int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n,
+                                    int32_t c, int32_t kvol, float *partial, void *stream) {
+  if (n < 0 || c <= 0 || c > 64 || (c & 3) != 0 || kvol <= 0) return LINK_ERR_ARG;
+  if (!partial) return LINK_ERR_ARG;
+  if (n > 0 && (!feats || !gout || !nbr_t)) return LINK_ERR_ARG;
+  const int chunks = link_subm_conv_wgrad_chunks();
+  hipLaunchKernelGGL(k_subm_conv_wgrad, dim3((unsigned)(kvol * chunks)), dim3(256), 0, S(stream), feats, gout, nbr_t, n,
+                     (int)c, (int)kvol, chunks, partial);
+  return check_launch("link_subm_conv_wgrad");
+}
+
 static int g_conv_wgs = 1024;  // cap (sweep: tools/convsweep.py)
 static int g_conv_nt = 0;      // 0 = by size; 1/2/4 forced (tuning)
 extern "C" int link_conv_set_tuning(int key, int value) {

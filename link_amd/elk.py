@@ -493,10 +493,24 @@ class _SubmConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr, ctx.order)
         if ctx.needs_input_grad[1]:
-            n = feats.shape[0]
-            padded = torch.cat([feats.detach().float(), feats.new_zeros(1, feats.shape[1])], dim=0)
-            idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
-            g_kernel = torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kernel.shape[0])], 0)
+            n, cin = feats.shape
+            kvol, _, cout = kernel.shape
+            if cin == cout and cin <= 64 and cin % 4 == 0:
+                lib = L.lib()
+                chunks = int(lib.link_subm_conv_wgrad_chunks())
+                nbr_t = getattr(nbr, "_link_t", None)     # transposed table cached on the (kmaps-cached) tensor
+                if nbr_t is None:
+                    nbr_t = nbr.t().contiguous()
+                    nbr._link_t = nbr_t
+                part = torch.empty((chunks, kvol, cin, cout), dtype=torch.float32, device=g.device)
+                f = feats.detach().contiguous().float()
+                L.check(lib.link_subm_conv_wgrad(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n, cin, kvol,
+                                                 part.data_ptr(), _st()), "link_subm_conv_wgrad")
+                g_kernel = part.sum(0)
+            else:                                   # wide / rectangular: per offset gather + batched library GEMM
+                padded = torch.cat([feats.detach().float(), feats.new_zeros(1, cin)], dim=0)
+                idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
+                g_kernel = torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kvol)], 0)
         return g_feats, g_kernel, None, None
 
 

@@ -56,7 +56,7 @@ def test_subm_conv_rectangular_widths():
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("C,kind", [(64, "lidar"), (16, "dense"), (8, "dense")])
+@pytest.mark.parametrize("C,kind", [(64, "lidar"), (16, "dense"), (8, "dense"), (48, "dense"), (80, "dense")])
 def test_subm_conv_gradients_vs_oracle_autograd(C, kind):
     import link_amd as la
     from oracle import link_oracle as lo

@@ -46,3 +46,16 @@ for name, coords, s in (("lidar-like", torch.from_numpy(lidar_like(120000, seed=
     t_blk = timeit(block)
     print(f"{name}: N={n} neighbours/voxel={present:.1f}  conv HIP {t_hip:.1f} us (unordered tiles {t_hip0:.1f}) ({flops/t_hip/1e6:.1f} TFLOP/s useful) | "
           f"torch loop {t_loop:.1f} us | whole ELKBlock.forward (warm maps) {t_blk:.1f} us")
+
+# training: conv forward + backward (input + weight gradients)
+for name, coords in (("lidar-like", torch.from_numpy(lidar_like(120000, seed=0))), ("cfg2 S-uniform", s_uniform(100000))):
+    coords = coords.to(dev); n = coords.shape[0]
+    conv = la.Conv3d(C, C, 3).to(dev)
+    feats = torch.randn(n, C, device=dev)
+    st = la.SparseTensor(feats, coords, 1); conv._neighbor_table(st)
+    gout = torch.randn(n, C, device=dev)
+    def step():
+        f = feats.detach().requires_grad_(True)
+        x = la.SparseTensor(f, coords, 1); x.kmaps = st.kmaps; x.cmaps = st.cmaps
+        conv(x).F.backward(gout)
+    print(f"{name}: conv fwd+bwd (d feats, d kernel) {timeit(step, k=20):.1f} us")
