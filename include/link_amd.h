@@ -340,6 +340,15 @@ int link_elk_mid_backward(const float *g_new, const float *fin, const float *A, 
 int link_premix_ln_backward(const float *feats, const float *w_pre, const float *ln_w, const float *g_fin,
                             int64_t n, int32_t c, float eps, float *g_pre, float *g_feats, float *partials,
                             void *stream);
+/* The block's tail for training: y = relu(addend + LayerNorm(x) * ln_w + ln_b)
+ * (`st.F = self.activate(new_st_F + self.norm_local(st_local.F))`, linkunet.py:183 / ts_elk.py:228) and its
+ * backward: g_addend = g_y * (y > 0); g_x = LayerNorm backward of that (statistics recomputed from x);
+ * partials fp[link_elk_mid_partial_rows(), 2, C] = per-workgroup sums of [d ln_w | d ln_b].  C % 4 == 0,
+ * C <= 256.  (Inference fuses the tail into the convolution: link_subm_conv_ln_add_relu.) */
+int link_ln_add_relu_forward(const float *x, const float *addend, const float *ln_w, const float *ln_b,
+                             int64_t n, int32_t c, float eps, float *y, void *stream);
+int link_ln_add_relu_backward(const float *g_y, const float *y, const float *x, const float *ln_w, int64_t n,
+                              int32_t c, float eps, float *g_addend, float *g_x, float *partials, void *stream);
 /* Column sums of up to three partial arrays fp[rows, cols_k] (k = 0..2; cols_k == 0 skips one) into
  * out fp[cols0+cols1+cols2], one launch, fixed summation order. */
 int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t cols1, const float *p2,

@@ -2163,6 +2163,152 @@ extern "C" int link_elk_out_ln_backward(const float *g_out, const float *A, cons
   return check_launch("link_elk_out_ln_backward");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The block's tail for training (linkunet.py:183 / ts_elk.py:228): y = relu(addend + LayerNorm(x)),
+// forward and backward, one 16-byte-per-lane group per row (persistent grid).  Inference fuses this
+// tail into the convolution kernel instead (conv.hip, row N2).
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(256) k_ln_add_relu_fwd_g(const float *__restrict__ x,
+                                                           const float *__restrict__ addend,
+                                                           const float *__restrict__ ln_w,
+                                                           const float *__restrict__ ln_b, int64_t n, int c,
+                                                           float eps, float *__restrict__ y) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1), ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  const float inv_c = 1.0f / (float)c;
+  const float4 w4 = *reinterpret_cast<const float4 *>(&ln_w[cofs]), b4 = *reinterpret_cast<const float4 *>(&ln_b[cofs]);
+  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
+  for (int64_t i = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR; i < n; i += ngroups) {
+    float4 v = *reinterpret_cast<const float4 *>(&x[i * c + cofs]);
+    const float4 a = *reinterpret_cast<const float4 *>(&addend[i * c + cofs]);
+    if (!act) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float mean = grp_sum<LPR>((v.x + v.y) + (v.z + v.w)) * inv_c;
+    const float dx = act ? v.x - mean : 0.f, dy = act ? v.y - mean : 0.f, dz = act ? v.z - mean : 0.f, dw = act ? v.w - mean : 0.f;
+    const float rstd = 1.0f / sqrtf(grp_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * inv_c + eps);
+    if (act) {
+      float4 o;
+      o.x = fmaxf(a.x + (dx * rstd * w4.x + b4.x), 0.f);
+      o.y = fmaxf(a.y + (dy * rstd * w4.y + b4.y), 0.f);
+      o.z = fmaxf(a.z + (dz * rstd * w4.z + b4.z), 0.f);
+      o.w = fmaxf(a.w + (dw * rstd * w4.w + b4.w), 0.f);
+      *reinterpret_cast<float4 *>(&y[i * c + ch0]) = o;
+    }
+  }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(256) k_ln_add_relu_bwd_g(const float *__restrict__ g_y,
+                                                           const float *__restrict__ y,
+                                                           const float *__restrict__ x,
+                                                           const float *__restrict__ ln_w, int64_t n, int c,
+                                                           float eps, float *__restrict__ g_addend,
+                                                           float *__restrict__ g_x, float *__restrict__ partials) {
+  constexpr int G = 64 / LPR;
+  __shared__ float red[4][8][LPR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1), ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  const float inv_c = 1.0f / (float)c;
+  const float4 w4 = *reinterpret_cast<const float4 *>(&ln_w[cofs]);
+  const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
+  for (int64_t i = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR; i < n; i += ngroups) {
+    const float4 v4 = *reinterpret_cast<const float4 *>(&x[i * c + cofs]);
+    const float4 y4 = *reinterpret_cast<const float4 *>(&y[i * c + cofs]);
+    const float4 g4 = *reinterpret_cast<const float4 *>(&g_y[i * c + cofs]);
+    const float xv[4] = {v4.x, v4.y, v4.z, v4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) sm += act ? xv[e] : 0.f;
+    const float mean = grp_sum<LPR>(sm) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float d = act ? xv[e] - mean : 0.f; q += d * d; }
+    const float rstd = 1.0f / sqrtf(grp_sum<LPR>(q) * inv_c + eps);
+    float g[4], xh[4], gx[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      g[e] = (act && yv[e] > 0.f) ? gv[e] : 0.f;              // ReLU mask from the saved output
+      xh[e] = act ? (xv[e] - mean) * rstd : 0.f;
+      gx[e] = g[e] * gw[e];
+      s1 += gx[e];
+      s2 = fmaf(gx[e], xh[e], s2);
+      aw[e] = fmaf(g[e], xh[e], aw[e]);
+      ab[e] += g[e];
+    }
+    const float m1 = grp_sum<LPR>(s1) * inv_c, m2 = grp_sum<LPR>(s2) * inv_c;
+    if (act) {
+      *reinterpret_cast<float4 *>(&g_addend[i * c + ch0]) = make_float4(g[0], g[1], g[2], g[3]);
+      *reinterpret_cast<float4 *>(&g_x[i * c + ch0]) =
+          make_float4(rstd * (gx[0] - m1 - xh[0] * m2), rstd * (gx[1] - m1 - xh[1] * m2),
+                      rstd * (gx[2] - m1 - xh[2] * m2), rstd * (gx[3] - m1 - xh[3] * m2));
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { aw[e] += __shfl_xor(aw[e], o, 64); ab[e] += __shfl_xor(ab[e], o, 64); }
+  if (lane < LPR)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { red[wave][e][li] = aw[e]; red[wave][4 + e][li] = ab[e]; }
+  __syncthreads();
+  if (wave == 0 && lane < LPR && act) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      float4 o;
+      o.x = (red[0][q * 4 + 0][li] + red[1][q * 4 + 0][li]) + (red[2][q * 4 + 0][li] + red[3][q * 4 + 0][li]);
+      o.y = (red[0][q * 4 + 1][li] + red[1][q * 4 + 1][li]) + (red[2][q * 4 + 1][li] + red[3][q * 4 + 1][li]);
+      o.z = (red[0][q * 4 + 2][li] + red[1][q * 4 + 2][li]) + (red[2][q * 4 + 2][li] + red[3][q * 4 + 2][li]);
+      o.w = (red[0][q * 4 + 3][li] + red[1][q * 4 + 3][li]) + (red[2][q * 4 + 3][li] + red[3][q * 4 + 3][li]);
+      *reinterpret_cast<float4 *>(&partials[((int64_t)blockIdx.x * 2 + q) * c + ch0]) = o;
+    }
+  }
+}
+
+extern "C" int32_t link_elk_mid_partial_rows(void);
+
+extern "C" int link_ln_add_relu_forward(const float *x, const float *addend, const float *ln_w,
+                                        const float *ln_b, int64_t n, int32_t c, float eps, float *y,
+                                        void *stream) {
+  if (n < 0 || c <= 0 || (c & 3) != 0 || c > 256) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!x || !addend || !ln_w || !ln_b || !y) return LINK_ERR_ARG;
+  dim3 grid(1024), block(256);
+  hipStream_t st = S(stream);
+  switch (lanes_per_row(c)) {
+    case 1: case 2: case 4: hipLaunchKernelGGL(k_ln_add_relu_fwd_g<4>, grid, block, 0, st, x, addend, ln_w, ln_b, n, (int)c, eps, y); break;
+    case 8: hipLaunchKernelGGL(k_ln_add_relu_fwd_g<8>, grid, block, 0, st, x, addend, ln_w, ln_b, n, (int)c, eps, y); break;
+    case 16: hipLaunchKernelGGL(k_ln_add_relu_fwd_g<16>, grid, block, 0, st, x, addend, ln_w, ln_b, n, (int)c, eps, y); break;
+    case 32: hipLaunchKernelGGL(k_ln_add_relu_fwd_g<32>, grid, block, 0, st, x, addend, ln_w, ln_b, n, (int)c, eps, y); break;
+    default: hipLaunchKernelGGL(k_ln_add_relu_fwd_g<64>, grid, block, 0, st, x, addend, ln_w, ln_b, n, (int)c, eps, y); break;
+  }
+  return check_launch("link_ln_add_relu_forward");
+}
+
+extern "C" int link_ln_add_relu_backward(const float *g_y, const float *y, const float *x, const float *ln_w,
+                                         int64_t n, int32_t c, float eps, float *g_addend, float *g_x,
+                                         float *partials, void *stream) {
+  if (n < 0 || c <= 0 || (c & 3) != 0 || c > 256) return LINK_ERR_ARG;
+  if (!partials) return LINK_ERR_ARG;
+  if (n > 0 && (!g_y || !y || !x || !ln_w || !g_addend || !g_x)) return LINK_ERR_ARG;
+  dim3 grid(link_elk_mid_partial_rows()), block(256);
+  hipStream_t st = S(stream);
+  switch (lanes_per_row(c)) {
+    case 1: case 2: case 4: hipLaunchKernelGGL(k_ln_add_relu_bwd_g<4>, grid, block, 0, st, g_y, y, x, ln_w, n, (int)c, eps, g_addend, g_x, partials); break;
+    case 8: hipLaunchKernelGGL(k_ln_add_relu_bwd_g<8>, grid, block, 0, st, g_y, y, x, ln_w, n, (int)c, eps, g_addend, g_x, partials); break;
+    case 16: hipLaunchKernelGGL(k_ln_add_relu_bwd_g<16>, grid, block, 0, st, g_y, y, x, ln_w, n, (int)c, eps, g_addend, g_x, partials); break;
+    case 32: hipLaunchKernelGGL(k_ln_add_relu_bwd_g<32>, grid, block, 0, st, g_y, y, x, ln_w, n, (int)c, eps, g_addend, g_x, partials); break;
+    default: hipLaunchKernelGGL(k_ln_add_relu_bwd_g<64>, grid, block, 0, st, g_y, y, x, ln_w, n, (int)c, eps, g_addend, g_x, partials); break;
+  }
+  return check_launch("link_ln_add_relu_backward");
+}
+
 // Column sums of up to three per-workgroup partial arrays [rows, cols_k] in one launch, fixed order
 // (row lanes ascending, then a fixed LDS tree): the deterministic tail of every parameter gradient.
 __global__ void __launch_bounds__(256) k_sum_partials(const float *__restrict__ p0, int c0,

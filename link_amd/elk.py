@@ -474,6 +474,40 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     return out
 
 
+class _Tail(torch.autograd.Function):
+    """relu(addend + LayerNorm(x)) with a hand-written backward (link_ln_add_relu_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, x, addend, ln_w, ln_b, eps):
+        n, c = x.shape
+        x = x.detach().contiguous().float()
+        a = addend.detach().contiguous().float()
+        w, b = ln_w.detach().contiguous().float(), ln_b.detach().contiguous().float()
+        y = torch.empty_like(x)
+        L.check(L.lib().link_ln_add_relu_forward(x.data_ptr(), a.data_ptr(), w.data_ptr(), b.data_ptr(), n, c,
+                                                 float(eps), y.data_ptr(), _st()), "link_ln_add_relu_forward")
+        ctx.save_for_backward(x, y, w)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w = ctx.saved_tensors
+        n, c = x.shape
+        lib = L.lib()
+        rows = int(lib.link_elk_mid_partial_rows())
+        g = g.contiguous().float()
+        g_add, g_x = torch.empty_like(x), torch.empty_like(x)
+        part = torch.empty(rows * 2 * c + 2 * c, dtype=torch.float32, device=x.device)
+        L.check(lib.link_ln_add_relu_backward(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), n, c, ctx.eps,
+                                              g_add.data_ptr(), g_x.data_ptr(), part.data_ptr(), _st()),
+                "link_ln_add_relu_backward")
+        tot = part[rows * 2 * c:]
+        L.check(lib.link_sum_partials(part.data_ptr(), 2 * c, None, 0, None, 0, rows, tot.data_ptr(), _st()),
+                "link_sum_partials")
+        return g_x, g_add, tot[:c].view_as(w), tot[c:].view_as(w), None
+
+
 class _SubmConv(torch.autograd.Function):
     """Differentiable stride-1 submanifold convolution on the HIP kernel.  Input gradient: the same
     kernel on grad_out with w'[k] = w[K-1-k]^T (odd kernel, same coordinates: nbr[v,k] = u  <=>
@@ -542,7 +576,12 @@ class _ELKBase(nn.Module):
         if needs_grad or hooked or conv.kernel_volume == 1 or st.F.dtype != torch.float32:
             local = self.local_mix(st)
             new = core_fn()
-            st.F = self.activate(new + self.norm_local(local.F))
+            nl = self.norm_local
+            if (needs_grad and not hooked and st.F.dtype == torch.float32 and new.shape[1] % 4 == 0
+                    and new.shape[1] <= 256 and new.is_cuda):
+                st.F = _Tail.apply(local.F, new, nl.weight, nl.bias, nl.eps)     # fused tail, fused backward
+            else:
+                st.F = self.activate(new + nl(local.F))
             return st
         new = core_fn()
         nbr, order = conv._neighbor_table(st)

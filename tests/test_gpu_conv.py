@@ -120,3 +120,52 @@ def test_fused_epilogue_equals_module_by_module(C, baseop, groups):
     assert len(seen) == 1                           # the hooked run went module by module
     assert rel_err(fused.cpu().numpy(), plain.cpu().numpy()) < 2e-6
     assert float(fused.min()) >= 0.0
+
+
+@pytest.mark.parametrize("C,baseop,groups,s,r", [(64, "cos", 2, 7, 3), (32, "cos_x", 1, 3, 2), (16, "sin", 2, 5, 3)])
+def test_elkblock_training_step_vs_fp64_oracle(C, baseop, groups, s, r):
+    """Whole ELKBlock forward+backward in training mode (fused core backward, HIP conv + its gradients,
+    fused tail backward) against fp64 autograd over the oracle restatements."""
+    import link_amd as la
+    from oracle import link_oracle as lo
+    import torch.nn.functional as TF
+    # 0.2 m voxels: coordinates stay below ~500, so theta keeps the fp32 precision the 1e-4 gate assumes
+    coords = torch.from_numpy(lidar_like(9000, seed=11, voxel=0.2))
+    n = coords.shape[0]
+    torch.manual_seed(3)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().train()
+    with torch.no_grad():
+        for nm, p in blk.named_parameters():
+            if "norm" in nm or nm.endswith("pre_mix.1.weight") or nm.endswith("pre_mix.1.bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    gout = torch.randn(n, C, generator=torch.Generator().manual_seed(4))
+    f = feats.cuda().requires_grad_(True)
+    out = blk(la.SparseTensor(f, coords.cuda(), 1), s, r).F
+    out.backward(gout.cuda())
+    # fp64 oracle
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    fr = feats.double().requires_grad_(True)
+    core = lo.elk_core_torch(fr, coords, sd, s, r, baseop, groups)
+    local = lo.subm_conv_torch(fr, coords, sd["local_mix.0.kernel"], 1)
+    z = core + TF.layer_norm(local, (C,), sd["norm_local.weight"], sd["norm_local.bias"], 1e-6)
+    # ReLU is discontinuous: differentiate the oracle with the GPU run's activation mask (the two masks may
+    # only disagree where the pre-activation is within rounding of zero), else one flipped element moves
+    # sums of random-sign gradients by percents
+    mask = (out.detach().cpu() > 0)
+    flips = (z.detach() > 0) != mask
+    assert float(z.detach().abs()[flips].max()) < 1e-3 if bool(flips.any()) else True
+    ref = z * mask.double()
+    ref.backward(gout.double())
+    # forward: the 1e-4 gate is against the fp32 restatement (theta of LiDAR-sized coordinates carries
+    # ~1e-4 of fp32 rounding that an fp64 oracle does not have); fp64 bounds the gradients
+    sd32 = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    z32 = lo.elk_core_torch(feats, coords, sd32, s, r, baseop, groups) + TF.layer_norm(
+        lo.subm_conv_torch(feats, coords, sd32["local_mix.0.kernel"], 1), (C,), sd32["norm_local.weight"],
+        sd32["norm_local.bias"], 1e-6)
+    assert rel_err(out.detach().cpu().numpy(), torch.relu(z32).numpy()) < 1e-4
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 5e-4
+    assert rel_err(f.grad.cpu().numpy(), fr.grad.numpy()) < 5e-4
+    for nm, p in blk.named_parameters():
+        assert p.grad is not None, nm
+        assert rel_err(p.grad.cpu().numpy(), sd[nm].grad.numpy()) < 5e-4, nm

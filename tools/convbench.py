@@ -59,3 +59,18 @@ for name, coords in (("lidar-like", torch.from_numpy(lidar_like(120000, seed=0))
         x = la.SparseTensor(f, coords, 1); x.kmaps = st.kmaps; x.cmaps = st.cmaps
         conv(x).F.backward(gout)
     print(f"{name}: conv fwd+bwd (d feats, d kernel) {timeit(step, k=20):.1f} us")
+
+# whole ELKBlock training step (fwd+bwd), warm maps
+for name, coords, s in (("lidar-like", torch.from_numpy(lidar_like(120000, seed=0)), 7), ("cfg2 S-uniform", s_uniform(100000), 7)):
+    coords = coords.to(dev); n = coords.shape[0]
+    torch.manual_seed(0)
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev).train()
+    feats = torch.randn(n, C, device=dev); gout = torch.randn(n, C, device=dev)
+    st = la.SparseTensor(feats, coords, 1)
+    with torch.no_grad(): blk(la.SparseTensor(feats.clone(), coords, 1), s, 3)
+    st0 = la.SparseTensor(feats.clone(), coords, 1); blk.local_mix[0]._neighbor_table(st0); la.voxel_to_aux(st0, s)
+    def step():
+        f = feats.detach().clone().requires_grad_(True)
+        x = la.SparseTensor(f, coords, 1); x.kmaps = st0.kmaps; x.cmaps = st0.cmaps
+        blk(x, s, 3).F.backward(gout)
+    print(f"{name}: whole ELKBlock training step (fwd+bwd, warm maps) {timeit(step, k=20):.1f} us")
