@@ -11,8 +11,9 @@ from .aggregate import (aux_to_voxel, large_to_small, link_index_of, small_to_la
                         voxel_to_aux)
 from .elk import (Conv3d, ELKBlock, ElkCorePlan, SparseConvTensor, TSELKBlock, elk_core_autograd, elk_core_fused, spconv2ts,
                   ts2spconv)
-from .functional import spcount, spdevoxelize, sphash, sphashquery, spvoxelize
+from .functional import calc_ti_weights, spcount, spdevoxelize, sphash, sphashquery, spvoxelize
 from .index import BlockIndex, coords_bounds
+from .pointvoxel import initial_voxelize, point_to_voxel, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 from .utils import get_kernel_offsets, make_ntuple
 

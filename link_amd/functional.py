@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from . import backend
 
-__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize"]
+__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights"]
 
 
 def sphash(coords: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -87,3 +87,27 @@ def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) 
 
 def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor, r: int = 2) -> torch.Tensor:
     return DevoxelizeFunction.apply(feats, coords, weights, r)
+
+
+def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float = 1) -> torch.Tensor:
+    """Trilinear interpolation weights [8, P] of the corner voxels (corner k = 4*dx + 2*dy + dz, the order of
+    get_kernel_offsets(2)), zero for absent corners, renormalised to sum to one (+1e-8)."""
+    with torch.no_grad():
+        p = coords[:, :3]
+        lo = (torch.floor(p / scale) * scale if scale != 1 else torch.floor(p)).float()
+        hi = lo + scale
+        near, far = hi - p, p - lo                       # weight of the low / high corner per axis
+        cols = []
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    wx = far[:, 0] if dx else near[:, 0]
+                    wy = far[:, 1] if dy else near[:, 1]
+                    wz = far[:, 2] if dz else near[:, 2]
+                    cols.append(wx * wy * wz)
+        w = torch.stack(cols, 0).contiguous()
+        if scale != 1:
+            w /= scale ** 3
+        w[idx_query == -1] = 0
+        w /= w.sum(0) + 1e-8
+    return w

@@ -333,3 +333,65 @@ def aggregate_c(x, coords, s: int, r: int):
     """Same as aggregate_torch but through the scalar C oracle (no autograd)."""
     import torch
     return torch.from_numpy(aggregate(x.detach().numpy(), coords.numpy(), s, r))
+
+
+# ------------------------------------------------------------------------------ point <-> voxel (row N4)
+def calc_ti_weights_np(points, idx_query, scale=1):
+    """torchsparse/nn/functional/devoxelize.py:10-48: trilinear weights [8, P]; idx_query int64[8, P]."""
+    p = np.asarray(points, np.float32)[:, :3]
+    pf = (np.floor(p / np.float32(scale)) * np.float32(scale)).astype(np.float32) if scale != 1 else np.floor(p)
+    pc = pf + np.float32(scale)
+    near, far = pc - p, p - pf
+    rows = []
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                rows.append((far[:, 0] if dx else near[:, 0]) * (far[:, 1] if dy else near[:, 1])
+                            * (far[:, 2] if dz else near[:, 2]))
+    w = np.stack(rows, 0).astype(np.float32)
+    if scale != 1:
+        w /= np.float32(scale ** 3)
+    w[np.asarray(idx_query) == -1] = 0
+    w /= w.sum(0) + np.float32(1e-8)
+    return w
+
+
+def _voxel_keys_np(points, stride):
+    pts = np.asarray(points, np.float32)
+    return np.concatenate([(np.floor(pts[:, :3] / np.float32(stride)).astype(np.int32) * stride),
+                           pts[:, 3:].astype(np.int32)], 1).astype(np.int32)
+
+
+def initial_voxelize_np(points, feats, init_res, after_res):
+    """segmentation/core/models/utils.py:234-254.  Returns (vox_F, vox_C int32, idx_query int64, counts
+    int32, z_C) -- voxels numbered by ascending coordinate hash (torch.unique of the hashes)."""
+    pts = np.asarray(points, np.float32)
+    scaled = np.concatenate([(pts[:, :3] * np.float32(init_res)) / np.float32(after_res), pts[:, 3:]], 1).astype(np.float32)
+    cell = np.floor(scaled)
+    pc_hash = sphash(cell.astype(np.int32))
+    vox_hash = np.unique(pc_hash)
+    idx = sphashquery(pc_hash, vox_hash)
+    counts = spcount(idx.astype(np.int32), len(vox_hash))
+    vox_c = np.round(spvoxelize_fwd(cell, idx.astype(np.int32), counts)).astype(np.int32)
+    vox_f = spvoxelize_fwd(np.asarray(feats, np.float32), idx.astype(np.int32), counts)
+    return vox_f, vox_c, idx, counts, scaled
+
+
+def point_to_voxel_np(points_scaled, feats, vox_c, stride=1):
+    """utils.py:259-281 (uncached branch)."""
+    idx = sphashquery(sphash(_voxel_keys_np(points_scaled, stride)), sphash(vox_c))
+    counts = spcount(idx.astype(np.int32), vox_c.shape[0])
+    return spvoxelize_fwd(np.asarray(feats, np.float32), idx.astype(np.int32), counts), idx, counts
+
+
+def voxel_to_point_np(vox_f, vox_c, stride, points_scaled, nearest=False):
+    """utils.py:286-324 (uncached branch).  Returns (point feats, idx_query int64[P,8], weights fp32[P,8])."""
+    off = get_kernel_offsets(2) * int(stride)
+    idx = sphashquery(sphash_offsets(_voxel_keys_np(points_scaled, stride), off), sphash(vox_c))      # [8, P]
+    w = calc_ti_weights_np(points_scaled, idx, stride).T.copy()
+    idx = np.ascontiguousarray(idx.T)
+    if nearest:
+        w[:, 1:] = 0.0
+        idx[:, 1:] = -1
+    return spdevoxelize_fwd(np.asarray(vox_f, np.float32), idx.astype(np.int32), w), idx, w
+

@@ -98,6 +98,27 @@ def test_conv_restatement_vs_reference_local_mix(name):
     assert rel_err(out.numpy(), g["local"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", golden_files("g_pointvoxel_*.npz"))
+def test_pointvoxel_restatements_vs_reference(name):
+    """Row N4: oracle restatements of initial_voxelize / point_to_voxel / voxel_to_point against the
+    reference's own outputs (tests/golden/make_golden_pointvoxel.py)."""
+    g = load_golden(name)
+    m = g["meta"]
+    vf, vc, idx, counts, zc = O.initial_voxelize_np(g["points"], g["feats"], m["init_res"], m["after_res"])
+    assert np.array_equal(vc, g["vox_C"]) and np.array_equal(idx, g["idx_query"])
+    assert np.array_equal(counts, g["counts"]) and np.array_equal(zc, g["z_C"])
+    assert rel_err(vf, g["vox_F"]) < 1e-6
+    p2v, _, _ = O.point_to_voxel_np(zc, g["p2v_feats_in"], vc, 1)
+    assert rel_err(p2v, g["p2v_F"]) < 1e-6
+    if "v2p1_F" in g:
+        f1, i1, w1 = O.voxel_to_point_np(g["v2p1_F_in"], vc, 1, zc)
+        assert np.array_equal(i1, g["v2p1_idx"]) and rel_err(w1, g["v2p1_w"]) < 1e-6 and rel_err(f1, g["v2p1_F"]) < 1e-6
+        f2, i2, w2 = O.voxel_to_point_np(g["v2p2_F_in"], g["v2p2_C"], 2, zc)
+        assert np.array_equal(i2, g["v2p2_idx"]) and rel_err(w2, g["v2p2_w"]) < 1e-6 and rel_err(f2, g["v2p2_F"]) < 1e-6
+        fn, _, _ = O.voxel_to_point_np(g["v2p1_F_in"], vc, 1, zc, nearest=True)
+        assert rel_err(fn, g["v2p1_nearest_F"]) < 1e-6
+
+
 def test_size_checkpoints():
     """SURVEY.md section 8d generator checkpoints: M and sha256 of the index arrays at cfg1/cfg2."""
     import hashlib
