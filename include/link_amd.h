@@ -369,7 +369,11 @@ int link_sum_partials(const float *p0, int32_t cols0, const float *p1, int32_t c
  *   order i32[N] or NULL: a permutation of the voxels (e.g. link_index_build's `perm`): tile t of the MFMA
  *                       kernel computes voxels order[16t..16t+15]; spatially sorted voxels let whole tiles
  *                       skip absent offsets.  Results do not depend on it.
- * MFMA path for Cin == Cout, C % 16 == 0, C <= 128; any other widths <= 256 take a lane=channel kernel.
+ * The table is per OUTPUT row, so the same entry serves down-sampling (kernel 2 / stride 2: N = coarse rows,
+ * entries = fine rows) and transposed convolutions (N = fine rows, one non-absent entry = the parent);
+ * feats may have any number of rows.  MFMA path for Cin, Cout multiples of 16 up to 128 (the square
+ * widths and the channel changes of the reference encoders are instantiated); other widths <= 256 take a
+ * lane=channel kernel.
  * The input gradient of this convolution is the same call on grad_out with w'[k] = w[kvol-1-k]^T
  * (the neighbour relation of an odd kernel at stride 1 is symmetric). */
 int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,

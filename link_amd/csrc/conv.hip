@@ -30,19 +30,19 @@ struct conv_epilogue {
   int relu;
 };
 
-template <int C, int NT>
+template <int CI, int CO, int NT>
 __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict__ feats,
                                                         const int32_t *__restrict__ nbr,
                                                         const float *__restrict__ w,
                                                         const int32_t *__restrict__ order, int64_t n,
                                                         int kvol, float *__restrict__ out, conv_epilogue ep) {
-  constexpr int T = C / 16;
-  constexpr int LDW = C + 4;
-  constexpr int WREG = (C * C + 1023) / 1024;       // float4 of W_k per thread (last one guarded)
+  constexpr int TI = CI / 16, TO = CO / 16;         // 16-channel tiles of the input (MFMA k-steps) / output rows
+  constexpr int LDW = CI + 4;
+  constexpr int WREG = (CI * CO + 1023) / 1024;     // float4 of W_k per thread (last one guarded)
   constexpr int KMAX = 27;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *wt_lds = reinterpret_cast<float *>(smem_raw);          // 2 x W_k^T [co][ci], row stride LDW
-  int32_t *nb_lds = reinterpret_cast<int32_t *>(wt_lds + 2 * C * LDW);   // [4 waves][KMAX][NT*16] neighbour ids
+  int32_t *nb_lds = reinterpret_cast<int32_t *>(wt_lds + 2 * CO * LDW);   // [4 waves][KMAX][NT*16] neighbour ids
   __shared__ uint32_t wg_mask;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -51,14 +51,14 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
   const int64_t tiles_per_pass = (int64_t)gridDim.x * 4 * NT;
   for (int64_t base = 0; base < tiles; base += tiles_per_pass) {
     const int64_t tile0 = base + ((int64_t)blockIdx.x * 4 + wave) * NT;
-    floatx4 acc[NT][T];
+    floatx4 acc[NT][TO];
     int64_t vox[NT];                                // this lane's output voxel of each tile (-1: past the end)
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const int64_t q = (tile0 + j) * 16 + li;
       vox[j] = (q < n) ? (order ? (int64_t)order[q] : q) : -1;
 #pragma unroll
-      for (int tp = 0; tp < T; tp++) acc[j][tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      for (int tp = 0; tp < TO; tp++) acc[j][tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
     }
     if (tid == 0) wg_mask = 0u;
     // the wave's neighbour ids -> LDS in one round trip (the 4 quarter-waves split the offsets)
@@ -85,18 +85,18 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
       int k = __ffs(m) - 1;
       m &= m - 1;
       {
-        const float *wk = w + (int64_t)k * C * C;
+        const float *wk = w + (int64_t)k * CI * CO;
 #pragma unroll
         for (int q = 0; q < WREG; q++)
-          if ((q * 256 + tid) * 4 < C * C) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
+          if ((q * 256 + tid) * 4 < CI * CO) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
       }
       int buf = 0;
       {
         float *dst = wt_lds;
 #pragma unroll
         for (int q = 0; q < WREG; q++) {
-          const int e = (q * 256 + tid) * 4, ci = e / C, co = e - ci * C;
-          if (e < C * C) {
+          const int e = (q * 256 + tid) * 4, ci = e / CO, co = e - ci * CO;
+          if (e < CI * CO) {
             dst[(co + 0) * LDW + ci] = wreg[q].x; dst[(co + 1) * LDW + ci] = wreg[q].y;
             dst[(co + 2) * LDW + ci] = wreg[q].z; dst[(co + 3) * LDW + ci] = wreg[q].w;
           }
@@ -107,33 +107,33 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
         const int kn = m ? (__ffs(m) - 1) : -1;      // next needed offset (uniform)
         m &= m - 1;
         if (kn >= 0) {
-          const float *wk = w + (int64_t)kn * C * C;
+          const float *wk = w + (int64_t)kn * CI * CO;
 #pragma unroll
           for (int q = 0; q < WREG; q++)
-          if ((q * 256 + tid) * 4 < C * C) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
+          if ((q * 256 + tid) * 4 < CI * CO) wreg[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
         }
         if ((wmask >> k) & 1u) {                     // wave-uniform: this wave has work at offset k
-          const float *wt = wt_lds + buf * (C * LDW);
+          const float *wt = wt_lds + buf * (CO * LDW);
           int id[NT];
 #pragma unroll
           for (int j = 0; j < NT; j++) id[j] = my_nb[(k * NT + j) * 16 + li];
-          float4 f[NT][T];
+          float4 f[NT][TI];
 #pragma unroll
           for (int j = 0; j < NT; j++) {            // all gathers of the step back to back
             const int64_t row = (id[j] >= 0) ? id[j] : 0;
 #pragma unroll
-            for (int t = 0; t < T; t++) f[j][t] = *reinterpret_cast<const float4 *>(&feats[row * C + 16 * t + 4 * g]);
+            for (int t = 0; t < TI; t++) f[j][t] = *reinterpret_cast<const float4 *>(&feats[row * CI + 16 * t + 4 * g]);
           }
 #pragma unroll
           for (int j = 0; j < NT; j++) {
             const bool has = id[j] >= 0;
             if (!__any(has)) continue;              // wave-uniform: no voxel of the tile has neighbour k
 #pragma unroll
-            for (int t = 0; t < T; t++) {
+            for (int t = 0; t < TI; t++) {
               const float fx = has ? f[j][t].x : 0.f, fy = has ? f[j][t].y : 0.f;
               const float fz = has ? f[j][t].z : 0.f, fw = has ? f[j][t].w : 0.f;
 #pragma unroll
-              for (int tp = 0; tp < T; tp++) {
+              for (int tp = 0; tp < TO; tp++) {
                 const float4 a = *reinterpret_cast<const float4 *>(&wt[(16 * tp + li) * LDW + 16 * t + 4 * g]);
                 acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, fx, acc[j][tp], 0, 0, 0);
                 acc[j][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, fy, acc[j][tp], 0, 0, 0);
@@ -145,11 +145,11 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
         }
         if (kn < 0) break;
         {                                            // W_next -> the other LDS buffer (nobody reads it now)
-          float *dst = wt_lds + (buf ^ 1) * (C * LDW);
+          float *dst = wt_lds + (buf ^ 1) * (CO * LDW);
 #pragma unroll
           for (int q = 0; q < WREG; q++) {
-            const int e = (q * 256 + tid) * 4, ci = e / C, co = e - ci * C;
-            if (e < C * C) {
+            const int e = (q * 256 + tid) * 4, ci = e / CO, co = e - ci * CO;
+            if (e < CI * CO) {
               dst[(co + 0) * LDW + ci] = wreg[q].x; dst[(co + 1) * LDW + ci] = wreg[q].y;
               dst[(co + 2) * LDW + ci] = wreg[q].z; dst[(co + 3) * LDW + ci] = wreg[q].w;
             }
@@ -170,13 +170,13 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
         // cross-lane steps, exactly as in the pre_mix kernel
         float sm = 0.f;
 #pragma unroll
-        for (int tp = 0; tp < T; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
+        for (int tp = 0; tp < TO; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
         sm += __shfl_xor(sm, 16, 64);
         sm += __shfl_xor(sm, 32, 64);
-        const float mean = sm * (1.0f / C);
+        const float mean = sm * (1.0f / CO);
         float q = 0.f;
 #pragma unroll
-        for (int tp = 0; tp < T; tp++)
+        for (int tp = 0; tp < TO; tp++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float d = acc[j][tp][r] - mean;
@@ -184,10 +184,10 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
           }
         q += __shfl_xor(q, 16, 64);
         q += __shfl_xor(q, 32, 64);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / C) + ep.eps);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / CO) + ep.eps);
         if (v >= 0) {
 #pragma unroll
-          for (int tp = 0; tp < T; tp++) {
+          for (int tp = 0; tp < TO; tp++) {
             const int ch = 16 * tp + 4 * g;
             const float4 lw = *reinterpret_cast<const float4 *>(&ep.ln_w[ch]);
             const float4 lb = *reinterpret_cast<const float4 *>(&ep.ln_b[ch]);
@@ -197,17 +197,17 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
             o.z = (acc[j][tp][2] - mean) * rstd * lw.z + lb.z;
             o.w = (acc[j][tp][3] - mean) * rstd * lw.w + lb.w;
             if (ep.addend) {
-              const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * C + ch]);
+              const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * CO + ch]);
               o.x = a4.x + o.x; o.y = a4.y + o.y; o.z = a4.z + o.z; o.w = a4.w + o.w;
             }
             if (ep.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            *reinterpret_cast<float4 *>(&out[v * C + ch]) = o;
+            *reinterpret_cast<float4 *>(&out[v * CO + ch]) = o;
           }
         }
       } else if (v >= 0) {
 #pragma unroll
-        for (int tp = 0; tp < T; tp++)
-          *reinterpret_cast<float4 *>(&out[v * C + 16 * tp + 4 * g]) =
+        for (int tp = 0; tp < TO; tp++)
+          *reinterpret_cast<float4 *>(&out[v * CO + 16 * tp + 4 * g]) =
               make_float4(acc[j][tp][0], acc[j][tp][1], acc[j][tp][2], acc[j][tp][3]);
       }
     }
@@ -393,14 +393,14 @@ extern "C" int link_conv_set_tuning(int key, int value) {
   return LINK_ERR_ARG;
 }
 
-template <int C, int NT>
+template <int CI, int CO, int NT>
 static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
                                int64_t n, int kvol, float *out, const conv_epilogue &ep, hipStream_t st) {
-  const size_t lds = ((size_t)2 * C * (C + 4) + (size_t)4 * 27 * NT * 16) * sizeof(float);
+  const size_t lds = ((size_t)2 * CO * (CI + 4) + (size_t)4 * 27 * NT * 16) * sizeof(float);
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<C, NT>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       done = true;
     }
@@ -408,22 +408,23 @@ static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const flo
   const int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 4 * NT - 1) / (4 * NT);
   if (wgs > g_conv_wgs) wgs = g_conv_wgs;
-  hipLaunchKernelGGL((k_subm_conv_mfma<C, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
+  hipLaunchKernelGGL((k_subm_conv_mfma<CI, CO, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
   return check_launch("link_subm_conv_forward");
 }
 
 // tiles per wave: as few as still fills the chip (more workgroups = more latency hiding; fewer = less
-// W_k staging traffic); C = 128 is capped at 2 by the 160 KB of LDS
-template <int C>
+// W_k staging traffic); the widest layers are capped at 2 by the 160 KB of LDS
+template <int CI, int CO>
 static int launch_conv_mfma(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
                             int64_t n, int kvol, float *out, const conv_epilogue &ep, hipStream_t st) {
   const int64_t tiles = (n + 15) / 16;
-  if (g_conv_nt == 4 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
-  if (g_conv_nt == 2 || g_conv_nt == 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
-  if (g_conv_nt == 1) return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
-  if (tiles > (int64_t)g_conv_wgs * 4 * 2 && C <= 112) return launch_conv_mfma_nt<C, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
-  if (tiles > (int64_t)g_conv_wgs * 4) return launch_conv_mfma_nt<C, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
-  return launch_conv_mfma_nt<C, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
+  constexpr bool nt4_fits = ((size_t)2 * CO * (CI + 4) + (size_t)4 * 27 * 4 * 16) * sizeof(float) <= 160 * 1024 && CO <= 112;
+  if (g_conv_nt == 4 && nt4_fits) return launch_conv_mfma_nt<CI, CO, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (g_conv_nt == 2 || g_conv_nt == 4) return launch_conv_mfma_nt<CI, CO, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (g_conv_nt == 1) return launch_conv_mfma_nt<CI, CO, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (tiles > (int64_t)g_conv_wgs * 4 * 2 && nt4_fits) return launch_conv_mfma_nt<CI, CO, 4>(feats, nbr, w, order, n, kvol, out, ep, st);
+  if (tiles > (int64_t)g_conv_wgs * 4) return launch_conv_mfma_nt<CI, CO, 2>(feats, nbr, w, order, n, kvol, out, ep, st);
+  return launch_conv_mfma_nt<CI, CO, 1>(feats, nbr, w, order, n, kvol, out, ep, st);
 }
 
 static int subm_conv_impl(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
@@ -450,21 +451,19 @@ static int subm_conv_impl(const float *feats, const int32_t *nbr, const float *w
                           int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out,
                           const conv_epilogue &ep, void *stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || cin > 256 || cout > 256 || kvol <= 0) return LINK_ERR_ARG;
-  const bool mfma_ok = cin == cout && (cin & 15) == 0 && cin <= 128 && kvol <= 27;
+  const bool mfma_ok = (cin & 15) == 0 && (cout & 15) == 0 && cin <= 128 && cout <= 128 && kvol <= 27;
   if (n == 0) return LINK_OK;
   if (!feats || !nbr || !w || !out) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
   if (mfma_ok) {
-    switch (cin) {
-      case 16: return launch_conv_mfma<16>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 32: return launch_conv_mfma<32>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 48: return launch_conv_mfma<48>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 64: return launch_conv_mfma<64>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 80: return launch_conv_mfma<80>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 96: return launch_conv_mfma<96>(feats, nbr, w, order, n, kvol, out, ep, st);
-      case 112: return launch_conv_mfma<112>(feats, nbr, w, order, n, kvol, out, ep, st);
-      default: return launch_conv_mfma<128>(feats, nbr, w, order, n, kvol, out, ep, st);
-    }
+#define LINK_CONV(I, O) if (cin == I && cout == O) return launch_conv_mfma<I, O>(feats, nbr, w, order, n, kvol, out, ep, st)
+    LINK_CONV(16, 16); LINK_CONV(32, 32); LINK_CONV(48, 48); LINK_CONV(64, 64); LINK_CONV(80, 80); LINK_CONV(96, 96);
+    LINK_CONV(112, 112); LINK_CONV(128, 128);
+    // the channel changes of the reference encoders (cs = [32,32,64,128,256,256,128,96,96] x cr, linkunet.py:262)
+    LINK_CONV(16, 32); LINK_CONV(32, 16); LINK_CONV(32, 64); LINK_CONV(64, 32); LINK_CONV(64, 128); LINK_CONV(128, 64);
+    LINK_CONV(96, 128); LINK_CONV(128, 96); LINK_CONV(64, 96); LINK_CONV(96, 64); LINK_CONV(32, 96); LINK_CONV(96, 32);
+    LINK_CONV(16, 64); LINK_CONV(64, 16); LINK_CONV(32, 128); LINK_CONV(128, 32);
+#undef LINK_CONV
   }
   dim3 grid(blocks_for(n * 64, 256)), block(256);
   const int cpl = (cout + 63) / 64;

@@ -271,8 +271,8 @@ def _weight_grad(g_pre: torch.Tensor, feats: torch.Tensor) -> torch.Tensor:
     if n < b * 64:
         return g_pre.t() @ feats
     k = n // b
-    c = g_pre.shape[1]
-    out = torch.bmm(g_pre[: b * k].view(b, k, c).transpose(1, 2), feats[: b * k].view(b, k, c)).sum(0)
+    out = torch.bmm(g_pre[: b * k].view(b, k, g_pre.shape[1]).transpose(1, 2),
+                    feats[: b * k].view(b, k, feats.shape[1])).sum(0)
     if b * k < n:
         out = out + g_pre[b * k:].t() @ feats[b * k:]
     return out
@@ -375,36 +375,53 @@ def elk_core_train(feats, coords, index, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha
 # ------------------------------------------------------------------------------------------------
 # local 3^3 sparse convolution (row N1 of SURVEY.md section 8f, minimal form)
 # ------------------------------------------------------------------------------------------------
+class _StridedMap:
+    """Kernel map of a kernel-2 stride-2 convolution: coarse coordinates + the per-output table of the
+    down direction [N_coarse, 8] and of the transposed direction [N_fine, 8] (one parent per fine voxel)."""
+
+    def __init__(self, out_coords, nbr_down, nbr_up):
+        self.out_coords, self.nbr_down, self.nbr_up = out_coords, nbr_down, nbr_up
+
+
 class Conv3d(nn.Module):
-    """Stride-1 submanifold sparse convolution with the reference's parameter layout
-    (`kernel` [K, Cin, Cout], torchsparse/nn/modules/conv.py:15-72; init U(+-1/sqrt(Cin*K))).
-    Neighbour table from the dense cell table (HIP), contraction by the output-stationary MFMA kernel
-    link_subm_conv_forward (include/link_amd.h section D).  Only what ELKBlock.local_mix needs: odd
-    kernel_size, stride 1, no bias."""
+    """Sparse convolution with the reference's parameter layout (`kernel` [K, Cin, Cout], optional `bias`;
+    torchsparse/nn/modules/conv.py:15-72; init U(+-1/sqrt(Cin*K)), or Cout*K when transposed) for the forms
+    the LinK networks use (linkunet.py:40-92,109): odd cubic kernels at stride 1 (submanifold), and
+    kernel 2 / stride 2 down-sampling and transposed up-sampling.  Kernel maps are per-output neighbour
+    tables from the dense cell table (HIP) -- the same relation the reference builds with sphash ->
+    sphashquery -> nonzero (nn/functional/conv.py:103-122) -- cached on the tensor's kmaps under the
+    reference's key; contraction by the output-stationary MFMA kernel (include/link_amd.h section D)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
                  dilation: int = 1, bias: bool = False, transposed: bool = False) -> None:
         super().__init__()
-        if make_ntuple(stride, 3) != (1, 1, 1) or transposed or bias:
-            raise NotImplementedError("link_amd.Conv3d implements the stride-1, bias-free form used by "
-                                      "ELKBlock.local_mix")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size = make_ntuple(kernel_size, 3)
-        if len(set(self.kernel_size)) != 1 or self.kernel_size[0] % 2 != 1:
-            raise NotImplementedError("cubic odd kernel sizes only")
-        self.stride, self.dilation, self.transposed = (1, 1, 1), dilation, False
-        self.kernel_volume = self.kernel_size[0] ** 3
+        self.stride = make_ntuple(stride, 3)
+        self.dilation, self.transposed = dilation, transposed
+        if len(set(self.kernel_size)) != 1 or len(set(self.stride)) != 1:
+            raise NotImplementedError("cubic kernels / isotropic strides only")
+        ks, st = self.kernel_size[0], self.stride[0]
+        if not ((st == 1 and ks % 2 == 1 and not transposed) or (st == 2 and ks == 2)):
+            raise NotImplementedError("link_amd.Conv3d implements odd kernels at stride 1 and kernel 2 / stride 2 "
+                                      "(down-sampling or transposed)")
+        self.kernel_volume = ks ** 3
         if self.kernel_volume > 1:
             self.kernel = nn.Parameter(torch.zeros(self.kernel_volume, in_channels, out_channels))
         else:
             self.kernel = nn.Parameter(torch.zeros(in_channels, out_channels))
-        self.register_parameter("bias", None)
-        std = 1.0 / math.sqrt(in_channels * self.kernel_volume)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        std = 1.0 / math.sqrt((out_channels if transposed else in_channels) * self.kernel_volume)
         self.kernel.data.uniform_(-std, std)
+        if self.bias is not None:
+            self.bias.data.uniform_(-std, std)
 
-    def _neighbor_table(self, x: SparseTensor) -> torch.Tensor:
-        """int32[N, K] input row of every (output voxel, kernel offset), -1 absent; cached on the tensor's
-        kmaps like the reference's kernel maps (nn/functional/conv.py:103,122)."""
+    def _neighbor_table(self, x: SparseTensor):
+        """(int32[N, K] input row of every (output voxel, kernel offset), -1 absent; spatial voxel order or
+        None), cached on the tensor's kmaps like the reference's kernel maps (nn/functional/conv.py:103,122)."""
         key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
         nbr = x.kmaps.get(key)
         if nbr is None:
@@ -425,15 +442,53 @@ class Conv3d(nn.Module):
             x.kmaps[key] = nbr
         return nbr
 
+    def _strided_map(self, x: SparseTensor) -> _StridedMap:
+        """Down-sampling kernel map, cached under the reference's key (conv.py:103): output coordinates =
+        unique(floor(c / (stride*ts)) * (stride*ts)) ordered by (batch, x, y, z) as spdownsample does
+        (downsample.py:26-49), table[j,k] = input row at out_coords[j] + offset_k * ts."""
+        key = (x.s, self.kernel_size, self.stride, self.dilation)
+        km = x.kmaps.get(key)
+        if km is None:
+            ts = int(x.s[0])
+            ss = ts * self.stride[0]
+            c = x.C.clone()
+            c[:, :3] = torch.div(c[:, :3], ss, rounding_mode="floor") * ss
+            out_c = torch.unique(c[:, [3, 0, 1, 2]], dim=0)[:, [1, 2, 3, 0]].contiguous()
+            try:
+                down = foreign_neighbor_map(out_c, 2, step=ts, table_rows=x.C)
+            except GridTooLarge:
+                offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
+                down = sphashquery(sphash(out_c, offs), sphash(x.C)).t().contiguous().int()
+            jj, kk = torch.nonzero(down >= 0, as_tuple=True)
+            up = torch.full((x.C.shape[0], down.shape[1]), -1, dtype=torch.int32, device=x.C.device)
+            up[down[jj, kk].long(), kk] = jj.int()
+            km = _StridedMap(out_c, down, up)
+            x.kmaps[key] = km
+        return km
+
     def forward(self, x: SparseTensor) -> SparseTensor:
         feats = x.F
-        if self.kernel_volume == 1:
-            out = feats.matmul(self.kernel)
+        if self.stride[0] == 1:
+            if self.kernel_volume == 1:
+                out = feats.matmul(self.kernel)
+            else:
+                nbr, order = self._neighbor_table(x)
+                out = _SubmConv.apply(feats, self.kernel, nbr, order)
+            coords, stride = x.C, x.s
+        elif not self.transposed:
+            km = self._strided_map(x)
+            out = _GatherConv.apply(feats, self.kernel, km.nbr_down, km.nbr_up)
+            coords, stride = km.out_coords, tuple(x.s[k] * self.stride[k] for k in range(3))
         else:
-            nbr, order = self._neighbor_table(x)
-            out = _SubmConv.apply(feats, self.kernel, nbr, order)
-        y = SparseTensor(out, x.C, x.s)
+            stride = tuple(x.s[k] // self.stride[k] for k in range(3))
+            km = x.kmaps[(stride, self.kernel_size, self.stride, self.dilation)]   # the matching down-conv's map
+            out = _GatherConv.apply(feats, self.kernel, km.nbr_up, km.nbr_down)
+            coords = x.cmaps[stride]
+        if self.bias is not None:
+            out = out + self.bias
+        y = SparseTensor(out, coords, stride)
         y.cmaps, y.kmaps = x.cmaps, x.kmaps
+        y.cmaps.setdefault(y.stride, y.coords)
         return y
 
 
@@ -442,8 +497,9 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd."""
     if feats.device.type != "cuda":
         raise L.LinkAmdError("subm_conv needs GPU tensors (HIP path; no CPU fallback)")
-    n, cin = feats.shape
+    cin = feats.shape[1]
     kvol, cin2, cout = kernel.shape
+    n = nbr.shape[0]                                   # output rows (== input rows for the submanifold form)
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
@@ -508,6 +564,50 @@ class _Tail(torch.autograd.Function):
         return g_x, g_add, tot[:c].view_as(w), tot[c:].view_as(w), None
 
 
+def _conv_weight_grad(feats, g, nbr, kernel_shape):
+    """g_w[k] = feats[nbr[:,k]]^T @ g: the MFMA kernel for square widths <= 64, else per offset gather +
+    batched library GEMM."""
+    kvol, cin, cout = kernel_shape
+    n_out = nbr.shape[0]
+    if cin == cout and cin <= 64 and cin % 4 == 0:
+        lib = L.lib()
+        chunks = int(lib.link_subm_conv_wgrad_chunks())
+        nbr_t = getattr(nbr, "_link_t", None)          # transposed table cached on the (kmaps-cached) tensor
+        if nbr_t is None:
+            nbr_t = nbr.t().contiguous()
+            nbr._link_t = nbr_t
+        part = torch.empty((chunks, kvol, cin, cout), dtype=torch.float32, device=g.device)
+        f = feats.detach().contiguous().float()
+        L.check(lib.link_subm_conv_wgrad(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n_out, cin, kvol,
+                                         part.data_ptr(), _st()), "link_subm_conv_wgrad")
+        return part.sum(0)
+    padded = torch.cat([feats.detach().float(), feats.new_zeros(1, cin)], dim=0)
+    idx = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr).long()
+    return torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kvol)], 0)
+
+
+class _GatherConv(torch.autograd.Function):
+    """out[j] = sum_k feats[table[j,k]] @ kernel[k] for any per-output table (strided / transposed
+    convolutions).  Input gradient: the same kernel on grad_out with kernel[k]^T and the opposite
+    direction's table; weight gradient as for the submanifold form."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, table, table_back):
+        ctx.save_for_backward(feats, kernel, table, table_back)
+        return subm_conv(feats, kernel, table, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, kernel, table, table_back = ctx.saved_tensors
+        g = g.contiguous().float()
+        g_feats = g_kernel = None
+        if ctx.needs_input_grad[0]:
+            g_feats = subm_conv(g, kernel.detach().transpose(1, 2).contiguous(), table_back, None)
+        if ctx.needs_input_grad[1]:
+            g_kernel = _conv_weight_grad(feats, g, table, kernel.shape)
+        return g_feats, g_kernel, None, None
+
+
 class _SubmConv(torch.autograd.Function):
     """Differentiable stride-1 submanifold convolution on the HIP kernel.  Input gradient: the same
     kernel on grad_out with w'[k] = w[K-1-k]^T (odd kernel, same coordinates: nbr[v,k] = u  <=>
@@ -527,24 +627,7 @@ class _SubmConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr, ctx.order)
         if ctx.needs_input_grad[1]:
-            n, cin = feats.shape
-            kvol, _, cout = kernel.shape
-            if cin == cout and cin <= 64 and cin % 4 == 0:
-                lib = L.lib()
-                chunks = int(lib.link_subm_conv_wgrad_chunks())
-                nbr_t = getattr(nbr, "_link_t", None)     # transposed table cached on the (kmaps-cached) tensor
-                if nbr_t is None:
-                    nbr_t = nbr.t().contiguous()
-                    nbr._link_t = nbr_t
-                part = torch.empty((chunks, kvol, cin, cout), dtype=torch.float32, device=g.device)
-                f = feats.detach().contiguous().float()
-                L.check(lib.link_subm_conv_wgrad(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n, cin, kvol,
-                                                 part.data_ptr(), _st()), "link_subm_conv_wgrad")
-                g_kernel = part.sum(0)
-            else:                                   # wide / rectangular: per offset gather + batched library GEMM
-                padded = torch.cat([feats.detach().float(), feats.new_zeros(1, cin)], dim=0)
-                idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
-                g_kernel = torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kvol)], 0)
+            g_kernel = _conv_weight_grad(feats, g, nbr, kernel.shape)
         return g_feats, g_kernel, None, None
 
 

@@ -155,17 +155,22 @@ class BlockIndex:
         return self._nbr[key]
 
 
-def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, step: int = 1) -> torch.Tensor:
+def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, step: int = 1,
+                         table_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Neighbour map for arbitrary rows int32[M,4] (not produced by a BlockIndex): dense cell table
-    over the rows' bounding box (first duplicate row wins), then the same lookup kernel; neighbour
-    offsets are multiplied by `step`."""
+    over the bounding box of `table_rows` (default: the rows themselves; first duplicate row wins), then
+    the same lookup kernel; neighbour offsets are multiplied by `step`.  With `table_rows`, entry [i,k] is
+    the index in table_rows of rows[i] + offset_k*step (the kernel map of a strided convolution)."""
     rows = rows.contiguous()
     m = rows.shape[0]
     dev = rows.device
     nbr = torch.empty((m, r ** 3), dtype=torch.int32, device=dev)
     if m == 0:
         return nbr
-    lo, hi = coords_bounds(rows)
+    src = rows if table_rows is None else table_rows.contiguous()
+    if src.shape[0] == 0:
+        return nbr.fill_(-1)
+    lo, hi = coords_bounds(src)
     try:
         grid = L.grid_from_bounds(lo, hi, 1)
     except L.LinkAmdError as e:
@@ -174,8 +179,8 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, st
         raise GridTooLarge(f"dense block grid would need {grid.cells} cells")
     table = torch.zeros(grid.cells, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    L.check(L.lib().link_cell_table_build(rows.data_ptr(), m, ctypes.byref(grid), table.data_ptr(), None, st),
-            "link_cell_table_build")
+    L.check(L.lib().link_cell_table_build(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), None,
+                                          st), "link_cell_table_build")
     L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
                                       int(step), 1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
     return nbr

@@ -395,3 +395,45 @@ def voxel_to_point_np(vox_f, vox_c, stride, points_scaled, nearest=False):
         idx[:, 1:] = -1
     return spdevoxelize_fwd(np.asarray(vox_f, np.float32), idx.astype(np.int32), w), idx, w
 
+
+
+# ------------------------------------------------------------------------------ strided sparse conv (row N1)
+def downsample_coords(coords, stride: int = 2, tensor_stride: int = 1) -> np.ndarray:
+    """torchsparse/nn/functional/downsample.py:26-49 for kernel_size == stride: floor to multiples of
+    stride*tensor_stride, unique rows ordered by (batch, x, y, z)."""
+    c = _c(coords, np.int32).copy()
+    ss = int(stride) * int(tensor_stride)
+    c[:, :3] = np.floor_divide(c[:, :3], ss) * ss
+    u = np.unique(c[:, [3, 0, 1, 2]], axis=0)
+    return np.ascontiguousarray(u[:, [1, 2, 3, 0]]).astype(np.int32)
+
+
+def strided_conv_table(in_coords, out_coords, kernel_size: int = 2, tensor_stride: int = 1) -> np.ndarray:
+    """conv.py:105-113 for a down-sampling convolution: int32[N_out, K], entry = input row at
+    out_coords[j] + offset_k * tensor_stride (offsets of get_kernel_offsets(kernel_size, stride=input.stride))."""
+    off = get_kernel_offsets(kernel_size) * int(tensor_stride)
+    res = sphashquery(sphash_offsets(_c(out_coords, np.int32), off), sphash(_c(in_coords, np.int32)))   # [K, N_out]
+    return np.ascontiguousarray(res.T).astype(np.int32)
+
+
+def gather_conv_torch(feats, table, kernel, n_out=None, transposed_of=None):
+    """conv.py:47-61 (`output[out_map] += input[in_map] @ weight[k]`).  `table` int[N_out,K] per-output table.
+    transposed_of: the down-conv's table [N_coarse,K] -- computes the TRANSPOSED convolution (in/out maps
+    swapped, conv.py:56-57) producing n_out fine rows from coarse `feats`."""
+    import torch
+    k = kernel.shape[0]
+    if transposed_of is not None:
+        t = torch.from_numpy(np.asarray(transposed_of).astype(np.int64))
+        out = torch.zeros(int(n_out), kernel.shape[2], dtype=feats.dtype)
+        for j in range(k):
+            rows = torch.nonzero(t[:, j] >= 0).view(-1)                     # coarse rows having a fine child at offset j
+            if rows.numel():
+                out = out.index_add(0, t[rows, j], feats[rows] @ kernel[j])
+        return out
+    t = torch.from_numpy(np.asarray(table).astype(np.int64))
+    out = torch.zeros(t.shape[0], kernel.shape[2], dtype=feats.dtype)
+    for j in range(k):
+        rows = torch.nonzero(t[:, j] >= 0).view(-1)
+        if rows.numel():
+            out = out.index_add(0, rows, feats[t[rows, j]] @ kernel[j])
+    return out

@@ -119,6 +119,29 @@ def test_pointvoxel_restatements_vs_reference(name):
         assert rel_err(fn, g["v2p1_nearest_F"]) < 1e-6
 
 
+@pytest.mark.parametrize("name", golden_files("g_stridedconv_*.npz"))
+def test_strided_conv_restatement_vs_reference(name):
+    """Row N1 (strided part): oracle restatements of spdownsample + the k2-s2 / transposed convolution against
+    the reference's spnn.Conv3d chain (tests/golden/make_golden_stridedconv.py)."""
+    import torch
+    g = load_golden(name)
+    c0 = g["coords"]
+    c2 = O.downsample_coords(c0, 2, 1)
+    assert np.array_equal(c2, g["x2_C"]) and np.array_equal(c0, g["x4_C"])
+    if not g["meta"]["features_valid"]:
+        return
+    t = lambda a: torch.from_numpy(a)
+    x1 = O.subm_conv_torch(t(g["feats"]), c0, t(g["k1"]), 1)
+    assert rel_err(x1.numpy(), g["x1_F"]) < 1e-5
+    down = O.strided_conv_table(c0, c2, 2, 1)
+    x2 = O.gather_conv_torch(x1, down, t(g["k2"]))
+    assert rel_err(x2.numpy(), g["x2_F"]) < 1e-5
+    x3 = O.subm_conv_torch(x2, c2, t(g["k3"]), 2)
+    assert rel_err(x3.numpy(), g["x3_F"]) < 1e-5
+    x4 = O.gather_conv_torch(x3, None, t(g["k4"]), n_out=c0.shape[0], transposed_of=down)
+    assert rel_err(x4.numpy(), g["x4_F"]) < 1e-5
+
+
 def test_size_checkpoints():
     """SURVEY.md section 8d generator checkpoints: M and sha256 of the index arrays at cfg1/cfg2."""
     import hashlib
