@@ -13,6 +13,7 @@ from .elk import (Conv3d, ELKBlock, ElkCorePlan, SparseConvTensor, TSELKBlock, e
                   ts2spconv)
 from .functional import calc_ti_weights, spcount, spdevoxelize, sphash, sphashquery, spvoxelize
 from .index import BlockIndex, coords_bounds
+from .modules import BatchNorm, LeakyReLU, ReLU, fapply
 from .pointvoxel import initial_voxelize, point_to_voxel, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 from .utils import get_kernel_offsets, make_ntuple
@@ -30,10 +31,11 @@ def install_as_torchsparse() -> None:
     ts = types.ModuleType("torchsparse")
     ts.SparseTensor, ts.PointTensor, ts.cat = SparseTensor, PointTensor, cat
     nn_mod = types.ModuleType("torchsparse.nn")
-    nn_mod.Conv3d = Conv3d
+    nn_mod.Conv3d, nn_mod.BatchNorm, nn_mod.ReLU, nn_mod.LeakyReLU = Conv3d, BatchNorm, ReLU, LeakyReLU
     nn_mod.functional = functional
     nn_utils = types.ModuleType("torchsparse.nn.utils")
     nn_utils.get_kernel_offsets = get_kernel_offsets
+    nn_utils.fapply = fapply
     nn_mod.utils = nn_utils
     utils_mod = types.ModuleType("torchsparse.utils")
     utils_mod.make_ntuple = make_ntuple

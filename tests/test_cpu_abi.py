@@ -136,3 +136,39 @@ def test_install_as_torchsparse():
         assert callable(getattr(B, name))
     for k in [k for k in sys.modules if k == "torchsparse" or k.startswith("torchsparse.")]:
         del sys.modules[k]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/segmentation/core/models"),
+                    reason="needs the reference checkout (build container only)")
+def test_reference_network_classes_build_on_the_aliased_surface():
+    """Level-0 integration: with link_amd registered under the torchsparse module names, the
+    reference's OWN network classes (segmentation/core/models/semantic_kitti/link{encoder,unet}.py, imported
+    from where they lie, unmodified) construct on top of link_amd.Conv3d / BatchNorm / ReLU and their
+    ELKBlock parameters carry the reference's state_dict names.  Construction only: running them needs a GPU,
+    and the reference checkout does not travel to the GPU box."""
+    import importlib
+    import sys
+    import link_amd as la
+    la.install_as_torchsparse()
+    sys.path.insert(0, "/root/reference/segmentation")
+    try:
+        enc = importlib.import_module("core.models.semantic_kitti.linkencoder")
+        net = enc.ELKEncoder(num_classes=19, cr=1.0, baseop="cos_x", groups=1, s=3, r=2)
+        assert isinstance(net.stem[0], la.Conv3d) and isinstance(net.down1[0].net[1], la.BatchNorm)
+        keys = set(net.state_dict().keys())
+        for k in ("elk1.alpha", "elk1.pos_weight.0.weight", "elk1.pre_mix.0.weight", "elk1.pre_mix.1.weight",
+                  "elk1.local_mix.0.kernel", "elk1.norm_local.weight", "elk1.norm.bias", "stem.0.kernel",
+                  "down1.0.net.0.kernel"):
+            assert k in keys, k
+        # our ELKBlock exposes exactly the parameter names/shapes of the reference's
+        ref_blk = {k[len("elk1."):]: v.shape for k, v in net.state_dict().items() if k.startswith("elk1.")}
+        ours = {k: v.shape for k, v in la.ELKBlock(64, 64, 1, baseop="cos_x", variant="encoder").state_dict().items()}
+        assert ref_blk == ours
+        unet = importlib.import_module("core.models.semantic_kitti.linkunet")
+        net2 = unet.ELKUNet(num_classes=19, cr=0.5, baseop="cos", groups=2, s=7, r=3)
+        assert any(isinstance(m, la.Conv3d) and m.transposed for m in net2.modules())      # the up-sampling path
+    finally:
+        sys.path.remove("/root/reference/segmentation")
+        for k in [k for k in sys.modules if k == "torchsparse" or k.startswith("torchsparse.") or k == "core"
+                  or k.startswith("core.")]:
+            del sys.modules[k]
