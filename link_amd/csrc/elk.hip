@@ -364,6 +364,7 @@ static int g_wt = 15;               // write-through (sc1) output stores: bit0 p
 static int g_coop_threshold = 4;   // mean voxels/block above which a wave's groups cooperate per block
 static int g_bgather_wgs = 512;
 static int g_use_split = 1;
+static int g_use_dense = 1;        // dense-grid block gather for occupied grids (device-side regime switch)
 extern "C" int link_set_tuning(int key, int value) {
   if (value <= 0) return LINK_ERR_ARG;
   switch (key) {
@@ -376,6 +377,7 @@ extern "C" int link_set_tuning(int key, int value) {
     case 7: g_coop_threshold = value; return LINK_OK;
     case 8: g_wt = value - 1; return LINK_OK;                  // value-1 = bitmask of kernels using sc1 stores
     case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
+    case 9: g_use_dense = (value == 1); return LINK_OK;        // 1 = dense-grid block gather allowed, 2 = never
     default: return LINK_ERR_ARG;
   }
 }
@@ -1231,6 +1233,142 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
   }
 }
 
+// Regime switch of the block gather: the dense-grid kernel walks CELLS (tiles of the block grid), which pays
+// off when most cells are occupied (cfg2: 85 %) and is hopeless when almost none are (LiDAR block grids:
+// ~1 %).  Both kernels read the same device-side header, so the choice needs no host sync.
+constexpr int DENSE_RATIO = 3;          // dense regime: V <= DENSE_RATIO * M
+__device__ __forceinline__ bool dense_regime(const link_grid_t &g, int m) {
+  const long long v = (long long)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
+  return v <= (long long)DENSE_RATIO * m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense-grid block gather (r = 3).  A wave owns a tile of G = 64/LPR adjacent y-columns x TZ cells along z
+// at fixed (x, batch); its G groups march z in LOCKSTEP.  Per z-step group q loads the three x-neighbour
+// rows of ITS column (the two edge groups also those of the halo column next to the tile), adds them (x-sum),
+// swaps x-sums with the neighbouring groups through the lane crossbar (y-sum), and keeps the last three
+// yx-planes in a register ring whose slot is the (compile-time) step number -- no selects, no per-group
+// height bookkeeping.  A tile of G x TZ cells fetches 3 (G+2)(TZ+2) rows: 6.75 per cell at G = TZ = 4
+// against ~17 per block for the column-walking kernel, and the neighbour ids come from ONE round trip
+// (cell arithmetic + cell_blk) instead of two.  Same summation order on every run: deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int P>
+__global__ void __launch_bounds__(256) k_block_gather_dense(const float *__restrict__ S,
+                                                            const int32_t *__restrict__ cell_blk, link_grid_t g,
+                                                            const int32_t *__restrict__ hdr, int c, int64_t m_cap,
+                                                            float *__restrict__ A_tab, bool wt, int flags,
+                                                            float *__restrict__ den_out, int tiles_y, int tiles_z) {
+  constexpr int G = 64 / LPR;
+  constexpr int TZ = 4;
+  constexpr int NY = G + 2, NZ = TZ + 2, NCELL = 3 * NY * NZ;
+  static_assert(G >= 2, "needs at least two columns per wave");
+  __shared__ uint32_t s_id[4][NCELL];
+  if (!dense_regime(g, hdr[LINK_HDR_M])) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & (LPR - 1), q = lane / LPR;
+  const int ch0 = 4 * li;
+  const bool act = ch0 < c;
+  const int cofs = act ? ch0 : 0;
+  // wave -> tile; x is the slowest tile coordinate and the workgroup range is cut into 8 XCD slabs
+  const long long tiles = (long long)g.dim[0] * g.dim[3] * tiles_y * tiles_z;
+  const long long wtiles = (tiles + 3) / 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long long lo = (wtiles * xcd) >> 3, hi = (wtiles * (xcd + 1)) >> 3;
+  const long long wgt = lo + slot;
+  if (wgt >= hi) return;
+  const long long tile = wgt * 4 + wave;
+  if (tile >= tiles) return;
+  const int zs = (int)(tile % tiles_z);
+  long long t2 = tile / tiles_z;
+  const int yq = (int)(t2 % tiles_y);
+  t2 /= tiles_y;
+  const int bb = g.lo[3] + (int)(t2 % g.dim[3]);
+  const int bx = g.lo[0] + (int)(t2 / g.dim[3]);
+  const int by0 = g.lo[1] + yq * G, bz0 = g.lo[2] + zs * TZ;
+  const int rs = P * c;
+  const uint32_t row_bytes = (uint32_t)rs * 4u;
+  const uint32_t zero_row = (uint32_t)m_cap;
+  uint32_t *ids = s_id[wave];
+  bool any_out = false;
+  for (int e = lane; e < NCELL; e += 64) {          // ids of the tile's input cells: one round trip
+    const int ix = e / (NY * NZ), rem = e - ix * (NY * NZ);
+    const int iy = rem / NZ, iz = rem - iy * NZ;
+    const int32_t cell = cell_of(g, bx + ix - 1, by0 + iy - 1, bz0 + iz - 1, bb);
+    const int32_t id = (cell >= 0) ? cell_blk[cell] - 1 : -1;
+    ids[e] = (id >= 0) ? (uint32_t)id : zero_row;
+    any_out |= (id >= 0) && ix == 1 && iy >= 1 && iy <= G && iz >= 1 && iz <= TZ;
+  }
+  if (!__any(any_out)) return;                      // no block in this tile
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const char *__restrict__ Sb = reinterpret_cast<const char *>(S) + cofs * 4;
+  const char *__restrict__ Cb = reinterpret_cast<const char *>(S + (m_cap + 1) * rs);
+  const int own = q + 1;                            // this group's column inside the (G+2)-wide input window
+  const int halo = (q == 0) ? 0 : ((q == G - 1) ? G + 1 : -1);
+  float ring[3][P][4], rden[3];
+#pragma unroll
+  for (int t = 0; t < NZ; t++) {                    // fully unrolled: the ring slot t % 3 is a constant
+    uint32_t r[3], h[3];
+#pragma unroll
+    for (int ix = 0; ix < 3; ix++) {
+      r[ix] = ids[(ix * NY + own) * NZ + t];
+      h[ix] = (halo >= 0) ? ids[(ix * NY + (halo >= 0 ? halo : 0)) * NZ + t] : zero_row;
+    }
+    float4 v[3][P], w[3][P];
+    float vd[3], wd[3];
+#pragma unroll
+    for (int ix = 0; ix < 3; ix++) {                // 6 rows (3 own, 3 halo / zero row), all loads back to back
+      vd[ix] = *reinterpret_cast<const float *>(Cb + r[ix] * 4u);
+      wd[ix] = *reinterpret_cast<const float *>(Cb + h[ix] * 4u);
+#pragma unroll
+      for (int pp = 0; pp < P; pp++) {
+        v[ix][pp] = *reinterpret_cast<const float4 *>(Sb + r[ix] * row_bytes + (uint32_t)(pp * c) * 4u);
+        w[ix][pp] = *reinterpret_cast<const float4 *>(Sb + h[ix] * row_bytes + (uint32_t)(pp * c) * 4u);
+      }
+    }
+    float cx[P][4], hx[P][4];
+    const float cd = (vd[0] + vd[1]) + vd[2], hd = (wd[0] + wd[1]) + wd[2];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+      cx[pp][0] = (v[0][pp].x + v[1][pp].x) + v[2][pp].x; cx[pp][1] = (v[0][pp].y + v[1][pp].y) + v[2][pp].y;
+      cx[pp][2] = (v[0][pp].z + v[1][pp].z) + v[2][pp].z; cx[pp][3] = (v[0][pp].w + v[1][pp].w) + v[2][pp].w;
+      hx[pp][0] = (w[0][pp].x + w[1][pp].x) + w[2][pp].x; hx[pp][1] = (w[0][pp].y + w[1][pp].y) + w[2][pp].y;
+      hx[pp][2] = (w[0][pp].z + w[1][pp].z) + w[2][pp].z; hx[pp][3] = (w[0][pp].w + w[1][pp].w) + w[2][pp].w;
+    }
+    // y-sum: x-sums of the left and right neighbour columns (the edge groups use their halo column)
+    {
+      const float ld = __shfl_up(cd, LPR, 64), rd = __shfl_down(cd, LPR, 64);
+      rden[t % 3] = ((q == 0 ? hd : ld) + cd) + (q == G - 1 ? hd : rd);
+    }
+#pragma unroll
+    for (int pp = 0; pp < P; pp++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float l = __shfl_up(cx[pp][e], LPR, 64), rr = __shfl_down(cx[pp][e], LPR, 64);
+        ring[t % 3][pp][e] = ((q == 0 ? hx[pp][e] : l) + cx[pp][e]) + (q == G - 1 ? hx[pp][e] : rr);
+      }
+    if (t >= 2) {                                   // planes z-1, z, z+1 of output cell iz = t-1 are in the ring
+      const uint32_t oid = ids[(1 * NY + own) * NZ + (t - 1)];
+      if (oid != zero_row) {
+        const float den = (rden[0] + rden[1]) + rden[2];
+        const float k = (flags & 2) ? 1.0f : 1.0f / den;
+        if (den_out && li == 0) den_out[oid] = den;
+        if (act) {
+          float *arow = A_tab + (int64_t)oid * rs;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++)
+            store_out(reinterpret_cast<float4 *>(&arow[pp * c + ch0]),
+                      make_float4(((ring[0][pp][0] + ring[1][pp][0]) + ring[2][pp][0]) * k,
+                                  ((ring[0][pp][1] + ring[1][pp][1]) + ring[2][pp][1]) * k,
+                                  ((ring[0][pp][2] + ring[1][pp][2]) + ring[2][pp][2]) * k,
+                                  ((ring[0][pp][3] + ring[1][pp][3]) + ring[2][pp][3]) * k), wt);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Split form of the gather: (a) block level -- A[m] = (sum of the r^3 neighbour rows of S) / count,
 // written once per block as a [M, P*C] table; (b) voxel level -- a loop-free streaming kernel, one
@@ -1245,6 +1383,9 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         const int32_t *__restrict__ hdr, int c,
                                                         int64_t m_cap, float *__restrict__ A_tab, bool wt,
                                                         int flags, float *__restrict__ den_out) {
+  // flags bit2: a dense-grid launch (k_block_gather_dense) accompanies this one and takes the frame when the
+  // block grid is at least 1/DENSE_RATIO occupied -- then this kernel has nothing to do
+  if ((flags & 4) && dense_regime(g, hdr[LINK_HDR_M])) return;
   // flags bit0: TRANSPOSED neighbourhood (offsets negated: the blocks whose region contains this one --
   // what the backward pass gathers; identical for odd r); bit1: plain sum, no division by the count.
   constexpr int G = 64 / LPR;
@@ -1573,6 +1714,20 @@ static void launch_block_gather(int r, hipStream_t st, const float *S_, const in
                                 int64_t m_cap, float *A, int flags, float *den_out) {
   dim3 grid(g_bgather_wgs), block(256);
   const bool wt = (g_wt & 4) != 0;
+  if constexpr (LPR <= 32) {
+    if (r == 3 && g_use_dense) {                    // dense-grid kernel rides along; one of the two exits at once
+      constexpr int G = 64 / LPR, TZ = 4;
+      const int tiles_y = (g.dim[1] + G - 1) / G, tiles_z = (g.dim[2] + TZ - 1) / TZ;
+      const long long tiles = (long long)g.dim[0] * g.dim[3] * tiles_y * tiles_z;
+      const long long wtiles = (tiles + 3) / 4;
+      if (wtiles < (1LL << 22)) {
+        const unsigned wgs = (unsigned)(((wtiles + 7) / 8 + 1) * 8);
+        hipLaunchKernelGGL((k_block_gather_dense<LPR, P>), dim3(wgs), block, 0, st, S_, cell_blk, g, hdr, c, m_cap, A,
+                           wt, flags, den_out, tiles_y, tiles_z);
+        flags |= 4;
+      }
+    }
+  }
   switch (r) {
     case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
     case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
