@@ -727,10 +727,11 @@ __device__ __forceinline__ float grp_sum(float v) {
 
 // chunk of consecutive sorted blocks owned by this GROUP (XCD slab -> equal chunks per group)
 template <int LPR>
-__device__ __forceinline__ void group_chunk(int m, int &b0, int &b1) {
+__device__ __forceinline__ void group_chunk(int m, int &b0, int &b1, int nwg = 0) {
   constexpr int G = 64 / LPR;
   const int xcd = blockIdx.x & 7;
-  const int groups_per_xcd = (gridDim.x >> 3) * (blockDim.x >> 6) * G;
+  if (nwg == 0) nwg = gridDim.x;                  // workgroups taking part (a launch may be wider: block gather)
+  const int groups_per_xcd = (nwg >> 3) * (blockDim.x >> 6) * G;
   const int gq = ((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + ((threadIdx.x & 63) / LPR);
   const int lo = (int)(((long long)m * xcd) >> 3), hi = (int)(((long long)m * (xcd + 1)) >> 3);
   const int ch = (hi - lo + groups_per_xcd - 1) / groups_per_xcd;
@@ -1252,18 +1253,16 @@ __device__ __forceinline__ bool dense_regime(const link_grid_t &g, int m) {
 // against ~17 per block for the column-walking kernel, and the neighbour ids come from ONE round trip
 // (cell arithmetic + cell_blk) instead of two.  Same summation order on every run: deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int P>
-__global__ void __launch_bounds__(256) k_block_gather_dense(const float *__restrict__ S,
+template <int LPR, int P, int TZ>
+__device__ __forceinline__ void block_gather_dense_body(const float *__restrict__ S,
                                                             const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                             const int32_t *__restrict__ hdr, int c, int64_t m_cap,
                                                             float *__restrict__ A_tab, bool wt, int flags,
                                                             float *__restrict__ den_out, int tiles_y, int tiles_z) {
   constexpr int G = 64 / LPR;
-  constexpr int TZ = 4;
   constexpr int NY = G + 2, NZ = TZ + 2, NCELL = 3 * NY * NZ;
   static_assert(G >= 2, "needs at least two columns per wave");
   __shared__ uint32_t s_id[4][NCELL];
-  if (!dense_regime(g, hdr[LINK_HDR_M])) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & (LPR - 1), q = lane / LPR;
   const int ch0 = 4 * li;
@@ -1382,10 +1381,17 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                         const int32_t *__restrict__ hdr, int c,
                                                         int64_t m_cap, float *__restrict__ A_tab, bool wt,
-                                                        int flags, float *__restrict__ den_out) {
-  // flags bit2: a dense-grid launch (k_block_gather_dense) accompanies this one and takes the frame when the
-  // block grid is at least 1/DENSE_RATIO occupied -- then this kernel has nothing to do
-  if ((flags & 4) && dense_regime(g, hdr[LINK_HDR_M])) return;
+                                                        int flags, float *__restrict__ den_out, int sparse_wgs,
+                                                        int tiles_y, int tiles_z) {
+  // flags bit2: the launch is wide enough for the dense-grid form, which takes the frame when the block grid
+  // is at least 1/DENSE_RATIO occupied (device-side decision: the host never learns M)
+  if constexpr (R == 3 && LPR <= 32) {
+    if ((flags & 4) && dense_regime(g, hdr[LINK_HDR_M])) {
+      block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z);
+      return;
+    }
+  }
+  if ((int)blockIdx.x >= sparse_wgs) return;        // column-walking form: the first sparse_wgs workgroups
   // flags bit0: TRANSPOSED neighbourhood (offsets negated: the blocks whose region contains this one --
   // what the backward pass gathers; identical for odd r); bit1: plain sum, no division by the count.
   constexpr int G = 64 / LPR;
@@ -1403,7 +1409,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
   const bool act = ch0 < c;
   const int cofs = act ? ch0 : 0;
   int b0, b1;
-  group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1);
+  group_chunk<LPR>(hdr[LINK_HDR_M], b0, b1, sparse_wgs);
   const bool live = b0 < b1;
   const int rs = P * c;
   const uint32_t row_bytes = (uint32_t)rs * 4u;
@@ -1712,26 +1718,26 @@ template <int LPR, int P>
 static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
                                 const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
                                 int64_t m_cap, float *A, int flags, float *den_out) {
-  dim3 grid(g_bgather_wgs), block(256);
   const bool wt = (g_wt & 4) != 0;
-  if constexpr (LPR <= 32) {
-    if (r == 3 && g_use_dense) {                    // dense-grid kernel rides along; one of the two exits at once
-      constexpr int G = 64 / LPR, TZ = 4;
-      const int tiles_y = (g.dim[1] + G - 1) / G, tiles_z = (g.dim[2] + TZ - 1) / TZ;
-      const long long tiles = (long long)g.dim[0] * g.dim[3] * tiles_y * tiles_z;
-      const long long wtiles = (tiles + 3) / 4;
-      if (wtiles < (1LL << 22)) {
-        const unsigned wgs = (unsigned)(((wtiles + 7) / 8 + 1) * 8);
-        hipLaunchKernelGGL((k_block_gather_dense<LPR, P>), dim3(wgs), block, 0, st, S_, cell_blk, g, hdr, c, m_cap, A,
-                           wt, flags, den_out, tiles_y, tiles_z);
-        flags |= 4;
-      }
+  unsigned wgs = (unsigned)g_bgather_wgs;
+  int tiles_y = 0, tiles_z = 0;
+  if (LPR <= 32 && r == 3 && g_use_dense) {         // widen the launch for the dense-grid form (same kernel)
+    constexpr int G = 64 / LPR, TZ = 4;
+    tiles_y = (g.dim[1] + G - 1) / G;
+    tiles_z = (g.dim[2] + TZ - 1) / TZ;
+    const long long tiles = (long long)g.dim[0] * g.dim[3] * tiles_y * tiles_z;
+    const long long wtiles = (tiles + 3) / 4;
+    if (wtiles < (1LL << 22)) {
+      const unsigned dw = (unsigned)(((wtiles + 7) / 8 + 1) * 8);
+      if (dw > wgs) wgs = dw;
+      flags |= 4;
     }
   }
+  dim3 grid(wgs), block(256);
   switch (r) {
-    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
-    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
-    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out); break;
+    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
+    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
+    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
   }
 }
 
