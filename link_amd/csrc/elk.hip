@@ -1317,13 +1317,25 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
     float4 v[3][P], w[3][P];
     float vd[3], wd[3];
 #pragma unroll
-    for (int ix = 0; ix < 3; ix++) {                // 6 rows (3 own, 3 halo / zero row), all loads back to back
+    for (int ix = 0; ix < 3; ix++) {                // 3 own rows, all loads back to back
       vd[ix] = *reinterpret_cast<const float *>(Cb + r[ix] * 4u);
-      wd[ix] = *reinterpret_cast<const float *>(Cb + h[ix] * 4u);
 #pragma unroll
-      for (int pp = 0; pp < P; pp++) {
+      for (int pp = 0; pp < P; pp++)
         v[ix][pp] = *reinterpret_cast<const float4 *>(Sb + r[ix] * row_bytes + (uint32_t)(pp * c) * 4u);
-        w[ix][pp] = *reinterpret_cast<const float4 *>(Sb + h[ix] * row_bytes + (uint32_t)(pp * c) * 4u);
+    }
+#pragma unroll
+    for (int ix = 0; ix < 3; ix++) {                // halo rows: only the two edge groups issue them (exec-masked)
+      wd[ix] = 0.f;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++) w[ix][pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (halo >= 0) {
+#pragma unroll
+      for (int ix = 0; ix < 3; ix++) {
+        wd[ix] = *reinterpret_cast<const float *>(Cb + h[ix] * 4u);
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+          w[ix][pp] = *reinterpret_cast<const float4 *>(Sb + h[ix] * row_bytes + (uint32_t)(pp * c) * 4u);
       }
     }
     float cx[P][4], hx[P][4];
@@ -1375,7 +1387,7 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
 // de-modulates, LayerNorms and stores.  (b) has no divergence and thousands of independent waves,
 // which is what hides memory latency on this chip; (a) carries only uniform block-level work.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int P, int R>
+template <int LPR, int P, int R, bool DENSE>
 __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict__ S,
                                                         const int4 *__restrict__ blk_coords,
                                                         const int32_t *__restrict__ cell_blk, link_grid_t g,
@@ -1385,7 +1397,7 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         int tiles_y, int tiles_z) {
   // flags bit2: the launch is wide enough for the dense-grid form, which takes the frame when the block grid
   // is at least 1/DENSE_RATIO occupied (device-side decision: the host never learns M)
-  if constexpr (R == 3 && LPR <= 32) {
+  if constexpr (DENSE && R == 3 && LPR <= 32) {
     if ((flags & 4) && dense_regime(g, hdr[LINK_HDR_M])) {
       block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z);
       return;
@@ -1725,20 +1737,27 @@ static void launch_block_gather(int r, hipStream_t st, const float *S_, const in
     constexpr int G = 64 / LPR, TZ = 4;
     tiles_y = (g.dim[1] + G - 1) / G;
     tiles_z = (g.dim[2] + TZ - 1) / TZ;
+    const long long cells = (long long)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
     const long long tiles = (long long)g.dim[0] * g.dim[3] * tiles_y * tiles_z;
     const long long wtiles = (tiles + 3) / 4;
-    if (wtiles < (1LL << 22)) {
+    // M <= m_cap: a grid with more than DENSE_RATIO * m_cap cells can never be in the dense regime, and the
+    // column-walking-only instantiation (fewer registers, 4 waves/SIMD) is launched instead
+    if (wtiles < (1LL << 22) && cells <= (long long)DENSE_RATIO * m_cap) {
       const unsigned dw = (unsigned)(((wtiles + 7) / 8 + 1) * 8);
       if (dw > wgs) wgs = dw;
       flags |= 4;
     }
   }
   dim3 grid(wgs), block(256);
+#define LINK_BGK(RR, DD)                                                                                          \
+  hipLaunchKernelGGL((k_block_gather_g<LPR, P, RR, DD>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, \
+                     m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z)
   switch (r) {
-    case 1: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 1>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
-    case 2: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 2>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
-    default: hipLaunchKernelGGL((k_block_gather_g<LPR, P, 3>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z); break;
+    case 1: LINK_BGK(1, false); break;
+    case 2: LINK_BGK(2, false); break;
+    default: if (flags & 4) LINK_BGK(3, true); else LINK_BGK(3, false); break;
   }
+#undef LINK_BGK
 }
 
 static int block_gather_impl(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
