@@ -187,12 +187,12 @@ def main():
     achieved = ab[dom] / (core[dom] * 1e-6) / 1e9
     # memory-side bytes per launch from rocprofv3 PMC passes over this workload (not collectable from inside
     # the timed process): 2*FETCH_SIZE + WRITE_SIZE with the gfx950 wide-read correction, cfg2 only
-    pmc_traffic = {"block_gather": 56.2e6, "premix_ln": 51.4e6, "modulate_block_sum": 49.9e6,
+    pmc_traffic = {"block_gather": 53.8e6, "premix_ln": 51.4e6, "modulate_block_sum": 49.9e6,
                    "voxel_demod_ln": 50.8e6}
     traffic = pmc_traffic.get(dom) if (N, C) == (100000, 64) else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_v5_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                "traffic_source": "profiles/r01_v6_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes; Infinity-Cache hits are counted by these counters)",
                 "alg_bytes_per_launch": ab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
                 "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / args.steps, 2),

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG:-run}
 rm -rf $OUT; mkdir -p $OUT
-timeout ${TMO:-150} rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-50} --warmup 5 --no-cpu-baseline > $OUT/bench.log 2>&1
+timeout ${TMO:-150} rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-50} --warmup ${WARM:-5} --no-cpu-baseline ${ARGS:-} > $OUT/bench.log 2>&1
 echo "rocprof rc=$?"
 grep '^{' $OUT/bench.log | cut -c1-1200
 db=$(find $OUT -name "*.db" | head -1)
