@@ -1254,7 +1254,7 @@ __device__ __forceinline__ bool dense_regime(const link_grid_t &g, int m) {
 // (cell arithmetic + cell_blk) instead of two.  Same summation order on every run: deterministic.
 // ---------------------------------------------------------------------------------------------
 template <int LPR, int P, int TZ>
-__device__ __forceinline__ void block_gather_dense_body(const float *__restrict__ S,
+__device__ __forceinline__ bool block_gather_dense_body(const float *__restrict__ S,
                                                             const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                             const int32_t *__restrict__ hdr, int c, int64_t m_cap,
                                                             float *__restrict__ A_tab, bool wt, int flags,
@@ -1263,6 +1263,7 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
   constexpr int NY = G + 2, NZ = TZ + 2, NCELL = 3 * NY * NZ;
   static_assert(G >= 2, "needs at least two columns per wave");
   __shared__ uint32_t s_id[4][NCELL];
+  const int m_now = hdr[LINK_HDR_M];                // regime check below; its load overlaps the id loads
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & (LPR - 1), q = lane / LPR;
   const int ch0 = 4 * li;
@@ -1274,9 +1275,9 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const long long lo = (wtiles * xcd) >> 3, hi = (wtiles * (xcd + 1)) >> 3;
   const long long wgt = lo + slot;
-  if (wgt >= hi) return;
+  if (wgt >= hi) return dense_regime(g, m_now);
   const long long tile = wgt * 4 + wave;
-  if (tile >= tiles) return;
+  if (tile >= tiles) return dense_regime(g, m_now);
   const int zs = (int)(tile % tiles_z);
   long long t2 = tile / tiles_z;
   const int yq = (int)(t2 % tiles_y);
@@ -1297,7 +1298,8 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
     ids[e] = (id >= 0) ? (uint32_t)id : zero_row;
     any_out |= (id >= 0) && ix == 1 && iy >= 1 && iy <= G && iz >= 1 && iz <= TZ;
   }
-  if (!__any(any_out)) return;                      // no block in this tile
+  if (!dense_regime(g, m_now)) return false;        // sparse block grid: the column-walking form takes over
+  if (!__any(any_out)) return true;                 // no block in this tile
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1378,6 +1380,7 @@ __device__ __forceinline__ void block_gather_dense_body(const float *__restrict_
       }
     }
   }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1398,10 +1401,9 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
   // flags bit2: the launch is wide enough for the dense-grid form, which takes the frame when the block grid
   // is at least 1/DENSE_RATIO occupied (device-side decision: the host never learns M)
   if constexpr (DENSE && R == 3 && LPR <= 32) {
-    if ((flags & 4) && dense_regime(g, hdr[LINK_HDR_M])) {
-      block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z);
+    if ((flags & 4) &&
+        block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z))
       return;
-    }
   }
   if ((int)blockIdx.x >= sparse_wgs) return;        // column-walking form: the first sparse_wgs workgroups
   // flags bit0: TRANSPOSED neighbourhood (offsets negated: the blocks whose region contains this one --
