@@ -396,6 +396,78 @@ int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *n
 /* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
 int link_conv_set_tuning(int key, int value);
 
+/* =============================================================================================
+ * E. Dense-cell form of R_core (the fast path when the block grid is mostly occupied)
+ *
+ * Same result as section C (linkunet.py:124-185 / ts_elk.py:144-230, R_core of SURVEY.md section 8d), but
+ * built for frames whose dense block grid is about as large as the frame itself (V <~ 2 N: cfg1/cfg2
+ * S-uniform).  There the reference's hash tables, torch.unique and scatter-add (utils.py:45-52,65-82) and
+ * section B's count/scan/place index all disappear: the block table is indexed by GRID CELL, a voxel
+ * finds its block by arithmetic, and the only index structure is a per-cell slot list filled by the pre_mix
+ * kernel itself (one atomic per voxel).  Three or four launches per step, no scan, no sort, no host sync:
+ *   link_dc_premix_insert  fin = LayerNorm(F Wpre^T) (f32 MFMA, software-pipelined) + rank = cnt[cell]++,
+ *                          slots[cell][rank] = (x,y,z,id)
+ *   link_dc_modsum         per cell: sort the slot list by voxel id (<= 4: network; more: selection), modulate,
+ *                          sum -> S[cell] (every interior cell written, empty ones as zero rows); resets cnt
+ *   link_dc_gather         r^3 box sum over the padded grid: LDS-DMA plane ring, xy sum from LDS, z ring in
+ *                          registers -> A[cell]
+ *   link_voxel_demod_ln    (section C kernel, fed with vrec/vcell) per voxel de-modulate + LayerNorm
+ * The grid is padded by one empty cell on every spatial side (rows stay zero: the caller zero-fills S, Scnt
+ * and A ONCE), so neighbour addressing needs no bounds checks.  Cell id =
+ * ((b*pdim0 + x+1)*pdim1 + y+1)*pdim2 + z+1 with (x,y,z,b) the block coordinate minus grid.lo.
+ * Slot capacity k = s^3 covers every frame with unique voxel coordinates; a voxel that finds its cell full
+ * (duplicate coordinates) or lies outside the grid is dropped and flagged in hdr[LINK_HDR_STATUS]
+ * (bit0 outside, bit1 slot overflow) -- callers that cannot rule that out use section C.
+ * Supported: C in {16,32,64,128}, r in {2,3}; LINK_ERR_ARG otherwise.
+ * ============================================================================================= */
+typedef struct {
+  int32_t s;        /* block edge in voxel-coordinate units */
+  int32_t lo[4];    /* block-coordinate lower bound (x,y,z,b) */
+  int32_t dim[4];   /* interior extent in blocks (x,y,z,b) */
+  int32_t pdim[3];  /* padded spatial extent = dim + 2 */
+  int32_t k;        /* slots per cell */
+  int64_t vp;       /* padded cells = pdim0*pdim1*pdim2*dim3 */
+} link_dc_grid_t;
+/* Host helper: padded grid + slot capacity from a link_grid_t.  k <= 0 selects s^3.  Returns vp or -1
+ * (vp*k must stay below 2^31 slots). */
+int64_t link_dc_grid_from(const link_grid_t *grid, int32_t k, link_dc_grid_t *out);
+
+#define LINK_HDR_STATUS_ACC 3   /* status bits being collected by the running step (dense-cell path) */
+
+typedef struct {
+  const float *feats;        /* fp[N,C] */
+  const int32_t *coords;     /* i32[N,4] */
+  const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;   /* as link_elk_buffers_t */
+  uint32_t *cnt;             /* u32[vp]     voxels per cell; all-zero on entry and on exit (self-cleaning) */
+  int32_t *slots;            /* i32[vp*k,4] (x,y,z,id) records; no initialisation needed */
+  int32_t *vrec;             /* i32[N,4]    (x,y,z,id) per voxel, original order */
+  int32_t *vcell;            /* i32[N]      padded cell id per voxel (0 for dropped voxels) */
+  int32_t *cell_n;           /* i32[vp]     voxels per cell of the last indexed frame (zero-filled once) */
+  int32_t *hdr;              /* i32[8]      LINK_HDR_*; zero-filled once */
+  float *fin;                /* fp[N,C] */
+  float *S;                  /* fp[(vp+1), P*C] block table, zero-filled once (border rows stay zero) */
+  float *A;                  /* fp[(vp+1), P*C] normalised neighbour sums, zero-filled once */
+  float *out;                /* fp[N,C] */
+} link_dc_buffers_t;
+
+int link_dc_premix_insert(const float *feats, const int32_t *coords, const float *w_pre, const float *ln_w,
+                          const float *ln_b, int64_t n, int32_t c, float eps, const link_dc_grid_t *g /* host */,
+                          int32_t insert, float *fin, uint32_t *cnt, int32_t *slots, int32_t *vrec,
+                          int32_t *vcell, int32_t *hdr, void *stream);
+int link_dc_modsum(const float *fin, const int32_t *slots, uint32_t *cnt, int32_t *cell_n, const float *w_pos,
+                   const float *alpha, const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */,
+                   int32_t warm, float *S, int32_t *hdr, void *stream);
+int link_dc_gather(const float *S, const int32_t *cell_n, const link_elk_desc_t *desc /* host */,
+                   const link_dc_grid_t *g /* host */, float *A, void *stream);
+/* One call = one R_core step on the dense-cell path (build_index = 0 reuses slots/cell_n of the previous
+ * call on the same coordinates: the "warm" figure). */
+int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
+                                const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
+                                void *stream);
+/* Tuning hook (bench only): key 0 premix workgroups, 1 modsum workgroups, 2 gather z-splits, 3 write-through
+ * mask (bit0 fin, bit1 S, bit2 A). */
+int link_dc_set_tuning(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
 
 LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
-HDR_M, HDR_STATUS, HDR_NVALID, HDR_WORDS = 0, 1, 2, 8
+HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LinkGrid(Structure):
@@ -47,6 +47,26 @@ class LinkElkBuffers(Structure):
                [("scratch_bytes", c_size_t)] + \
                [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "pos_blk", "blk_start",
                                         "blk_coords", "counts", "hdr", "fin", "S", "A", "out")]
+
+
+class LinkDcGrid(Structure):
+    """link_dc_grid_t (dense-cell path: padded grid + slot capacity)"""
+    _fields_ = [("s", c_int32), ("lo", c_int32 * 4), ("dim", c_int32 * 4), ("pdim", c_int32 * 3),
+                ("k", c_int32), ("vp", c_int64)]
+
+    @property
+    def interior_cells(self) -> int:
+        v = 1
+        for d in self.dim:
+            v *= int(d)
+        return v
+
+
+class LinkDcBuffers(Structure):
+    """link_dc_buffers_t"""
+    _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha",
+                                        "ln_w", "ln_b", "cnt", "slots", "vrec", "vcell", "cell_n", "hdr", "fin",
+                                        "S", "A", "out")]
 
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
@@ -116,6 +136,15 @@ SIGNATURES = {
                                   c_void_p]),
     "link_premix_ln_backward": (c_int, [c_void_p] * 4 + [c_int64, c_int32, ctypes.c_float] + [c_void_p] * 4),
     "link_elk_mid_partial_rows": (c_int32, []),
+    "link_dc_grid_from": (c_int64, [POINTER(LinkGrid), c_int32, POINTER(LinkDcGrid)]),
+    "link_dc_premix_insert": (c_int, [c_void_p] * 5 + [c_int64, c_int32, c_float, POINTER(LinkDcGrid), c_int32] +
+                              [c_void_p] * 7),
+    "link_dc_modsum": (c_int, [c_void_p] * 6 + [POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_int32, c_void_p,
+                               c_void_p, c_void_p]),
+    "link_dc_gather": (c_int, [c_void_p, c_void_p, POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_void_p, c_void_p]),
+    "link_elk_core_dense_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
+                                            c_int64, c_int32, c_void_p]),
+    "link_dc_set_tuning": (c_int, [c_int, c_int]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }
@@ -164,3 +193,11 @@ def grid_from_bounds(lo, hi, s: int) -> LinkGrid:
         raise LinkAmdError(f"grid_from_bounds({list(lo)}, {list(hi)}, s={s}): bounds invalid or grid "
                            ">= 2^30 cells")
     return g
+
+
+def dc_grid_from(grid: LinkGrid, k: int = 0):
+    """Padded dense-cell grid of `grid` (slot capacity k, 0 = s^3), or None when the dense-cell path cannot
+    address it (>= 2^30 cells or >= 2^31 slots)."""
+    g = LinkDcGrid()
+    v = lib().link_dc_grid_from(ctypes.byref(grid), int(k), ctypes.byref(g))
+    return g if v > 0 else None

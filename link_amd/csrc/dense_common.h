@@ -1,0 +1,54 @@
+// link_amd/csrc/dense_common.h -- helpers shared by the dense-cell kernels (dense.hip, dense_fused.hip).
+#pragma once
+#include <limits.h>
+
+#include "elk_common.h"
+
+namespace link {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// All table stores go through buffer descriptors: write-through (sc1: the lines leave the XCD's L2 while the
+// kernel runs; the consumer kernel runs on other XCDs anyway), and -- the point -- a lane that must NOT
+// store passes an out-of-range offset, which the hardware drops.  No branch around any store, so every
+// s_waitcnt vmcnt the compiler emits is an exact count instead of the vmcnt(0) a conditional VMEM op forces.
+// Tables handled here are < 4 GiB (checked by the launchers).
+#define DC_OOB 0xFFFFFFF0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_rsrc(const void *base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float4 v) {
+  const v4i_t x = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z),
+                   __builtin_bit_cast(int, v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void st16i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int4 v) {
+  const v4i_t x = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void st4i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, 0);
+}
+
+__device__ __forceinline__ int dc_cell(const link_dc_grid_t &g, int ux, int uy, int uz, int ub) {
+  return ((ub * g.pdim[0] + ux + 1) * g.pdim[1] + uy + 1) * g.pdim[2] + uz + 1;
+}
+
+// Slot lists.  `slots` holds vp*k records (x,y,z,id): first the INLINE region, DC_INL records per cell
+// (64 contiguous bytes: what the per-cell kernels stream), then the overflow region with the remaining
+// k - DC_INL records per cell (touched only by cells with more than DC_INL voxels).
+#define DC_INL 4
+__device__ __forceinline__ uint32_t dc_slot(const link_dc_grid_t &g, int pcell, int rank) {     // record index
+  return rank < DC_INL ? (uint32_t)pcell * DC_INL + (uint32_t)rank
+                       : (uint32_t)g.vp * DC_INL + (uint32_t)pcell * (uint32_t)(g.k - DC_INL) + (uint32_t)(rank - DC_INL);
+}
+
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+static inline bool dc_width_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
+
+}  // namespace link

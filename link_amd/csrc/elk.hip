@@ -22,11 +22,9 @@
 // validity selects) and then the m_cap+1 per-block counts (fp32) at S + (m_cap+1)*P*C.
 #include <limits.h>
 
-#include "common.h"
+#include "elk_common.h"
 
 using namespace link;
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static int g_premix_wgs_fwd();
 static bool g_wt_fwd();
@@ -199,42 +197,6 @@ extern "C" int link_premix_ln(const float *feats, const float *w_pre, const floa
   return check_launch("link_premix_ln");
 }
 
-// ---------------------------------------------------------------------------------------------
-// theta for one channel of one voxel.  theta = ((x/div)*w0 + (y/div)*w1) + (z/div)*w2 evaluated as an
-// fma chain in x,y,z order (nn.Linear(3, cg, bias=False) on float coords, linkunet.py:151), then
-// * alpha for cos_x (linkunet.py:165).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float theta_of(float x, float y, float z, float w0, float w1, float w2,
-                                          float alpha) {
-  float t = fmaf(z, w2, fmaf(y, w1, x * w0));
-  return t * alpha;
-}
-
-// sin & cos of a moderate argument: 3-term Cody-Waite reduction by pi/2 + degree-7/8 minimax
-// polynomials on [-pi/4, pi/4] (<= ~1.5 ulp for |x| < 2^15); larger or non-finite arguments take the
-// library path.  Branch-free on the fast path: ~25 VALU ops instead of the library's table walk.
-__device__ __noinline__ void sincos_slow(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
-
-__device__ __forceinline__ void sincos_fast(float x, float &sn, float &cs) {
-  if (__builtin_expect(!(fabsf(x) < 32768.0f), 0)) {
-    sincos_slow(x, &sn, &cs);     // kept out of line: the fast path is what the i-cache should hold
-    return;
-  }
-  const float k = rintf(x * 0.63661977236758134f);
-  float r = fmaf(-k, 1.5703125f, x);
-  r = fmaf(-k, 4.837512969970703125e-4f, r);
-  r = fmaf(-k, 7.54978995489188216e-8f, r);
-  const float r2 = r * r;
-  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
-  ps = fmaf(ps * r2, r, r);
-  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
-  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
-  const int q = (int)k;
-  const float s0 = (q & 1) ? pc : ps;
-  const float c0 = (q & 1) ? ps : pc;
-  sn = (q & 2) ? -s0 : s0;
-  cs = ((q + 1) & 2) ? -c0 : c0;
-}
 
 // Work partition shared by the two block kernels: the sorted block range [0,M) is cut into 8
 // contiguous slabs, one per XCD (workgroup w runs on XCD w % 8 -- observed dispatch, used for L2
@@ -713,17 +675,6 @@ static bool g_wt_fwd() { return (g_wt & 1) != 0; }
 // a 16-lane DPP row.  Groups of one wave may diverge (different segment lengths); nothing is shared
 // between them except the instruction stream.
 // =============================================================================================
-template <int LPR>
-__device__ __forceinline__ float grp_sum(float v) {
-  // butterfly over the LPR lanes of a group; steps <= 8 stay inside a 16-lane DPP row
-  if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
-  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
-  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
-  return v;
-}
 
 // chunk of consecutive sorted blocks owned by this GROUP (XCD slab -> equal chunks per group)
 template <int LPR>
@@ -741,30 +692,7 @@ __device__ __forceinline__ void group_chunk(int m, int &b0, int &b1, int nwg = 0
   if (b0 > hi) b0 = hi;
 }
 
-// value held by the partner lane (li ^ LPR/2) of the same group: the lane owning channel ch +- C/2
-template <int LPR>
-__device__ __forceinline__ float partner(float v) {
-  if (LPR == 16)   // rotate the 16-lane DPP row by 8: swaps its halves, one VALU op
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-  return __shfl_xor(v, LPR / 2, 64);
-}
 
-// Internal op codes of the modulate kernel beyond LINK_OP_*: the BACKWARD forms.  d(new)/d(v) of the
-// de-modulation is [cos, sin] (cos), [cos, -sin] (sin), [cos, sin, 1] (cos_x), so the gradient of the
-// block table is the same segmented block sum with these factors applied to grad(new).
-#define LINK_OPI_SIN_BWD 3
-#define LINK_OPI_COSX_BWD 4
-template <int OP>
-struct op_parts { static constexpr int value = (OP == LINK_OP_COSX || OP == LINK_OPI_COSX_BWD) ? 3 : 2; };
-
-template <int OP>
-__device__ __forceinline__ void mod_accum(float &a0, float &a1, float &a2, float f, float sn, float cs, float th) {
-  if (OP == LINK_OP_SIN) { a0 += f * sn; a1 += f * cs; }
-  else if (OP == LINK_OPI_SIN_BWD) { a0 += f * cs; a1 -= f * sn; }
-  else { a0 += f * cs; a1 += f * sn; }
-  if (OP == LINK_OP_COSX) a2 += f * th;
-  if (OP == LINK_OPI_COSX_BWD) a2 += f;
-}
 
 // PAIR (channel j and j + C/2 share theta, i.e. groups == 2 and the row fills its lanes exactly):
 // a step handles TWO consecutive voxels A,B; the low half of the group evaluates sincos(theta_A), the

@@ -1,0 +1,116 @@
+// link_amd/csrc/elk_common.h -- device helpers shared by elk.hip (general path) and dense.hip (dense-cell path).
+#pragma once
+#include "common.h"
+
+namespace link {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// theta for one channel of one voxel.  theta = ((x/div)*w0 + (y/div)*w1) + (z/div)*w2 evaluated as an
+// fma chain in x,y,z order (nn.Linear(3, cg, bias=False) on float coords, linkunet.py:151), then
+// * alpha for cos_x (linkunet.py:165).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float theta_of(float x, float y, float z, float w0, float w1, float w2,
+                                          float alpha) {
+  float t = fmaf(z, w2, fmaf(y, w1, x * w0));
+  return t * alpha;
+}
+
+// sin & cos of a moderate argument: 3-term Cody-Waite reduction by pi/2 + degree-7/8 minimax
+// polynomials on [-pi/4, pi/4] (<= ~1.5 ulp for |x| < 2^15); larger or non-finite arguments take the
+// library path.  Branch-free on the fast path: ~25 VALU ops instead of the library's table walk.
+static __device__ __noinline__ void sincos_slow(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
+
+__device__ __forceinline__ void sincos_fast(float x, float &sn, float &cs) {
+  if (__builtin_expect(!(fabsf(x) < 32768.0f), 0)) {
+    sincos_slow(x, &sn, &cs);     // kept out of line: the fast path is what the i-cache should hold
+    return;
+  }
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188216e-8f, r);
+  const float r2 = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? pc : ps;
+  const float c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Call-free variant used by the dense-cell kernels (a call to the out-of-line libm path costs every kernel
+// that contains it the callee's registers and a scratch frame).  |x| < 2^15: the same float path as
+// sincos_fast, bit for bit.  Larger arguments: the reduction is done in double (k = rint(x * 2/pi),
+// r = x - k * pi/2 with a two-term pi/2 and fma): exact to float precision for |x| < 2^50, far beyond any
+// theta = coords . w a voxel grid produces; non-finite x gives NaN like sinf / cosf.
+__device__ __forceinline__ void sincos_nocall(float x, float &sn, float &cs) {
+  float r;
+  int q;
+  if (__builtin_expect(fabsf(x) < 32768.0f, 1)) {
+    const float k = rintf(x * 0.63661977236758134f);
+    r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    q = (int)k;
+  } else {
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);
+    double rd = fma(-kd, 1.57079632679489655800e+00, xd);
+    rd = fma(-kd, 6.12323399573676603587e-17, rd);
+    r = (float)rd;
+    q = (int)(kd - 4.0 * floor(kd * 0.25));
+  }
+  const float r2 = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const float s0 = (q & 1) ? pc : ps;
+  const float c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+  // butterfly over the LPR lanes of a group; steps <= 8 stay inside a 16-lane DPP row
+  if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// value held by the partner lane (li ^ LPR/2) of the same group: the lane owning channel ch +- C/2
+template <int LPR>
+__device__ __forceinline__ float partner(float v) {
+  if (LPR == 16)   // rotate the 16-lane DPP row by 8: swaps its halves, one VALU op
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return __shfl_xor(v, LPR / 2, 64);
+}
+
+// Internal op codes of the modulate kernel beyond LINK_OP_*: the BACKWARD forms.  d(new)/d(v) of the
+// de-modulation is [cos, sin] (cos), [cos, -sin] (sin), [cos, sin, 1] (cos_x), so the gradient of the
+// block table is the same segmented block sum with these factors applied to grad(new).
+#define LINK_OPI_SIN_BWD 3
+#define LINK_OPI_COSX_BWD 4
+template <int OP>
+struct op_parts { static constexpr int value = (OP == LINK_OP_COSX || OP == LINK_OPI_COSX_BWD) ? 3 : 2; };
+
+template <int OP>
+__device__ __forceinline__ void mod_accum(float &a0, float &a1, float &a2, float f, float sn, float cs, float th) {
+  if (OP == LINK_OP_SIN) { a0 += f * sn; a1 += f * cs; }
+  else if (OP == LINK_OPI_SIN_BWD) { a0 += f * cs; a1 -= f * sn; }
+  else { a0 += f * cs; a1 += f * sn; }
+  if (OP == LINK_OP_COSX) a2 += f * th;
+  if (OP == LINK_OPI_COSX_BWD) a2 += f;
+}
+
+}  // namespace link

@@ -103,18 +103,66 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
 
 class ElkCorePlan:
     """Preallocated arena for repeated R_core steps (what bench.py times and what a serving loop would
-    hold per stream): every buffer of link_elk_buffers_t is allocated once for frames of <= n_cap
-    voxels inside fixed coordinate `bounds`, so one step = ONE FFI call = 7 kernel launches (4 index +
-    3 core) with no allocation and no host sync.  `run(..., build_index=False)` reuses the index of
-    the previous call (same coords): the "warm" number of SURVEY.md section 8d."""
+    hold per stream): every buffer is allocated once for frames of <= n_cap voxels inside fixed
+    coordinate `bounds`, so one step = ONE FFI call with no allocation and no host sync.
+
+    Two layouts, chosen here on the host from what is known before the frame arrives:
+      * dense-cell (include/link_amd.h section E): block table indexed by grid cell, the index is a
+        per-cell slot list filled by the pre_mix kernel -- 4 launches.  Taken when the padded grid has
+        at most `dense_ratio` x n_cap cells (a mostly occupied grid: cfg1/cfg2), C in {16,32,64,128},
+        r in {2,3}.  Slot capacity s^3 covers every frame with unique coordinates; duplicates beyond
+        it are dropped and reported by blocks().
+      * general (sections B + C): count/scan/place index + block-id table -- 8 launches; any grid.
+    `run(..., build_index=False)` reuses the index of the previous call (same coords): the "warm"
+    number of SURVEY.md section 8d."""
 
     def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
-                 coord_div: float = 1.0, eps: float = 1e-6):
+                 coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0):
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
-        v = self.grid.cells
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
-        parts = 3 if baseop == "cos_x" else 2
+        self.parts = 3 if baseop == "cos_x" else 2
+        self.device = device
+        if layout not in ("auto", "dense", "general"):
+            raise ValueError(f"layout must be auto|dense|general, got {layout!r}")
+        dcg = L.dc_grid_from(self.grid) if layout != "general" else None
+        ok = (dcg is not None and c in (16, 32, 64, 128) and r in (2, 3)
+              and (dcg.vp + 1) * self.parts * c * 4 < 2 ** 32 and n_cap * c * 4 < 2 ** 32)
+        if layout == "dense" and not ok:
+            raise L.LinkAmdError("ElkCorePlan(layout='dense'): width / r / grid size not supported by the "
+                                 "dense-cell path (include/link_amd.h section E)")
+        self.dense = ok and (layout == "dense" or dcg.vp <= dense_ratio * max(n_cap, 1))
+        self.dcg = dcg if self.dense else None
+        self.out = torch.empty((n_cap, c), dtype=torch.float32, device=device)
+        self.fin = torch.empty((n_cap, c), dtype=torch.float32, device=device)
+        self.hdr = torch.zeros(L.HDR_WORDS, dtype=torch.int32, device=device)
+        if self.dense:
+            self._init_dense()
+        else:
+            self._init_general()
+
+    def _init_dense(self):
+        g, dev, n_cap, c = self.dcg, self.device, self.n_cap, self.c
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        vp, w = int(g.vp), self.parts * c
+        self.cnt = torch.zeros(vp, **i32)                              # self-cleaning
+        self.slots = torch.empty((vp * int(g.k), 4), **i32)           # touched only where voxels land
+        self.vrec = torch.empty((n_cap, 4), **i32)
+        self.vcell = torch.empty(n_cap, **i32)
+        self.cell_n = torch.zeros(vp, **i32)
+        self.S = torch.zeros((vp + 1, w), **f32)                       # border rows stay zero
+        self.A = torch.zeros((vp + 1, w), **f32)
+        b = self.buf = L.LinkDcBuffers()
+        b.cnt, b.slots, b.vrec, b.vcell = self.cnt.data_ptr(), self.slots.data_ptr(), self.vrec.data_ptr(), self.vcell.data_ptr()
+        b.cell_n, b.hdr, b.fin = self.cell_n.data_ptr(), self.hdr.data_ptr(), self.fin.data_ptr()
+        b.S, b.A, b.out = self.S.data_ptr(), self.A.data_ptr(), self.out.data_ptr()
+        self._fn = L.lib().link_elk_core_dense_forward
+        self.m_cap = vp
+
+    def _init_general(self):
+        device, n_cap, c = self.device, self.n_cap, self.c
+        v = self.grid.cells
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.cell_counts = torch.zeros(max(v, 1), **i32)            # self-cleaning
@@ -129,11 +177,8 @@ class ElkCorePlan:
         self.blk_start = torch.empty(n_cap + 1, **i32)
         self.blk_coords = torch.empty((n_cap, 4), **i32)
         self.counts = torch.empty(n_cap, **i32)
-        self.hdr = torch.zeros(L.HDR_WORDS, **i32)
-        self.fin = torch.empty((n_cap, c), **f32)
-        self.S = torch.empty((n_cap + 1) * (parts * c + 1), **f32)
-        self.A = torch.empty((n_cap, parts * c), **f32)
-        self.out = torch.empty((n_cap, c), **f32)
+        self.S = torch.empty((n_cap + 1) * (self.parts * c + 1), **f32)
+        self.A = torch.empty((n_cap, self.parts * c), **f32)
         b = self.buf = L.LinkElkBuffers()
         b.cell_counts, b.scratch, b.scratch_bytes = self.cell_counts.data_ptr(), self.scratch.data_ptr(), nbytes
         b.cell_blk, b.vox_blk, b.idx_query = self.cell_blk.data_ptr(), self.vox_blk.data_ptr(), self.idx_query.data_ptr()
@@ -158,17 +203,26 @@ class ElkCorePlan:
         assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype == torch.float32
         assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
         self.buf.feats, self.buf.coords = feats.data_ptr(), coords.data_ptr()
-        rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
-                      min(self.m_cap, n), 1 if build_index else 0, torch.cuda.current_stream().cuda_stream)
+        st = torch.cuda.current_stream().cuda_stream
+        if self.dense:
+            rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
+                          1 if build_index else 0, st)
+        else:
+            rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
+                          min(self.m_cap, n), 1 if build_index else 0, st)
         if rc != 0:
-            L.check(rc, "link_elk_core_forward")
+            L.check(rc, "link_elk_core_dense_forward" if self.dense else "link_elk_core_forward")
         return self.out[:n]
 
     def blocks(self) -> int:
-        """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds."""
+        """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds (or, on
+        the dense-cell layout, found its cell's slot list full: duplicate coordinates)."""
         h = self.hdr.tolist()
         if h[L.HDR_STATUS] != 0:
-            raise L.LinkAmdError("ElkCorePlan: voxels outside the plan's bounds")
+            raise L.LinkAmdError("ElkCorePlan: voxels outside the plan's bounds" if h[L.HDR_STATUS] & 1 else
+                                 "ElkCorePlan: more voxels in a block than its slot list holds (duplicate coordinates)")
+        if self.dense:
+            return int((self.cell_n > 0).sum().item())
         return int(h[L.HDR_M])
 
 

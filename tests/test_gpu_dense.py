@@ -1,0 +1,131 @@
+"""Dense-cell layout of R_core (include/link_amd.h section E, link_amd/csrc/dense.hip) against the oracle
+restatement of linkunet.py:124-185 and against the general layout (sections B + C) on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err, s_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(la, blk, n, C, groups, baseop, r, s, bounds, layout, coord_div=1.0):
+    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, torch.device("cuda"), coord_div=coord_div,
+                          layout=layout)
+    plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+              blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
+    return plan
+
+
+def _oracle(blk, feats, coords, s, r, baseop, groups):
+    from oracle import link_oracle as O
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    return O.elk_core_torch(feats.cpu(), coords.cpu(), params, s, r, baseop, groups, agg=O.aggregate_c).numpy()
+
+
+@pytest.mark.parametrize("C,groups,baseop,s,r,grid,n", [
+    (64, 2, "cos", 7, 3, 80, 9000), (32, 2, "sin", 3, 2, 40, 6000), (16, 2, "cos", 7, 3, 256, 10000),
+    (128, 2, "cos", 5, 3, 60, 7000), (64, 1, "cos_x", 3, 2, 36, 5000), (64, 1, "cos_x", 3, 3, 30, 4000),
+    (32, 1, "cos", 4, 3, 50, 8000), (16, 1, "cos_x", 2, 2, 24, 3000), (128, 1, "cos_x", 4, 2, 40, 3000)])
+def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n):
+    import link_amd as la
+    torch.manual_seed(5)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    coords = s_uniform(n, grid=grid, seed=C + r).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
+    bounds = ((0, 0, 0, 0), (grid - 1, grid - 1, grid - 1, 0))
+    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    general = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "general")
+    assert dense.dense and not general.dense
+    od = dense.run(feats, coords).clone()
+    og = general.run(feats, coords).clone()
+    assert dense.blocks() == general.blocks() > 0
+    ref = _oracle(blk, feats, coords, s, r, baseop, groups)
+    assert rel_err(od.cpu().numpy(), ref) < 1e-4            # the parity gate (fp32, BASELINE.json)
+    assert rel_err(od.cpu().numpy(), og.cpu().numpy()) < 1e-4     # both sit on the oracle within the gate
+    # warm (index reused) == cold, bitwise; and a second cold run is bitwise identical (no fp atomics,
+    # slot order removed by the id sort)
+    warm = dense.run(feats, coords, build_index=False).clone()
+    assert torch.equal(od, warm)
+    for _ in range(3):
+        assert torch.equal(od, dense.run(feats, coords))
+    assert int(dense.cnt.abs().sum().item()) == 0           # the counters cleaned themselves
+
+
+def test_dense_large_cells_negative_coords_batches():
+    """Cells with many voxels (selection path, > 4 per cell), negative coordinates, two batch items."""
+    import link_amd as la
+    torch.manual_seed(9)
+    C, groups, baseop, s, r = 64, 2, "cos", 7, 3
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    a = s_uniform(5000, grid=24, seed=1)                     # ~ 80 voxels per 7^3 block
+    b = s_uniform(3000, grid=24, seed=2, batch=1)
+    coords = torch.cat([a, b])
+    coords[:, :3] -= 11                                      # blocks straddle zero: floor division
+    perm = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(0))
+    coords = coords[perm].contiguous().cuda()
+    n = coords.shape[0]
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
+    bounds = ((-11, -11, -11, 0), (12, 12, 12, 1))
+    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    od = dense.run(feats, coords).clone()
+    assert dense.blocks() > 0
+    assert int(dense.cell_n.max().item()) > 4
+    ref = _oracle(blk, feats, coords, s, r, baseop, groups)
+    assert rel_err(od.cpu().numpy(), ref) < 1e-4
+    for _ in range(3):
+        assert torch.equal(od, dense.run(feats, coords))
+
+
+def test_dense_status_word_and_capacity_reuse():
+    import link_amd as la
+    torch.manual_seed(7)
+    C, n = 64, 20000
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    coords = s_uniform(n, grid=128, seed=11).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
+    bounds = ((0, 0, 0, 0), (127, 127, 127, 0))
+    plan = _plan(la, blk, n, C, 2, "cos", 3, 7, bounds, "auto")
+    assert plan.dense                                        # 21^3 padded cells <= 4 n
+    out = plan.run(feats, coords).clone()
+    ref = _oracle(blk, feats, coords, 7, 3, "cos", 2)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-4
+    n2 = 5000                                                # a smaller frame through the same plan
+    out2 = plan.run(feats[:n2].contiguous(), coords[:n2].contiguous()).clone()
+    ref2 = _oracle(blk, feats[:n2], coords[:n2], 7, 3, "cos", 2)
+    assert rel_err(out2.cpu().numpy(), ref2) < 1e-4
+    assert plan.blocks() > 0
+    bad = coords.clone()
+    bad[0, 0] = 500                                          # outside the plan's bounds -> status bit 0
+    plan.run(feats, bad)
+    with pytest.raises(la._lib.LinkAmdError):
+        plan.blocks()
+    plan.run(feats, coords)                                  # the status word is per step
+    assert plan.blocks() > 0
+    dup = coords.clone()                                     # 400 copies of one voxel: > 7^3 slots -> bit 1
+    dup[:400] = dup[0]
+    plan.run(feats, dup)
+    with pytest.raises(la._lib.LinkAmdError):
+        plan.blocks()
+    assert torch.equal(out, plan.run(feats, coords))
+
+
+def test_dense_cfg2_full_size():
+    """BASELINE.json configs[1] at full size: dense-cell vs general layout vs oracle; M = 43 334."""
+    import link_amd as la
+    torch.manual_seed(2)
+    N, C = 100_000, 64
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    coords = s_uniform(N, seed=0).cuda()
+    feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1)).cuda()
+    bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
+    dense = _plan(la, blk, N, C, 2, "cos", 3, 7, bounds, "auto")
+    general = _plan(la, blk, N, C, 2, "cos", 3, 7, bounds, "general")
+    assert dense.dense
+    od, og = dense.run(feats, coords).clone(), general.run(feats, coords).clone()
+    assert dense.blocks() == general.blocks() == 43334
+    assert rel_err(od.cpu().numpy(), og.cpu().numpy()) < 1e-4     # both sit on the oracle within the gate
+    ref = _oracle(blk, feats, coords, 7, 3, "cos", 2)
+    assert rel_err(od.cpu().numpy(), ref) < 1e-4
+    for _ in range(5):
+        assert torch.equal(od, dense.run(feats, coords))
