@@ -67,7 +67,17 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -156,20 +166,36 @@ def main():
     from link_amd import _lib as L
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
-    b, grid, desc = plan.buf, plan.grid, plan.desc
-    stages = {
-        "index_build(4 kernels)": lambda: lib.link_index_build(
-            coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch, b.scratch_bytes, b.cell_blk,
-            b.vox_blk, b.idx_query, b.perm, b.vox_sorted, b.pos_blk, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
-        "premix_ln": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
-        "modulate_block_sum": lambda: lib.link_modulate_block_sum(
-            b.fin, b.vox_sorted, b.w_pos, b.alpha, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
-        "block_gather": lambda: lib.link_block_gather(
-            b.S, b.blk_coords, b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, b.A, st),
-        "voxel_demod_ln": lambda: lib.link_voxel_demod_ln(
-            b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.hdr, ctypes.byref(desc),
-            N, b.out, st),
-    }
+    b, desc = plan.buf, plan.desc
+    ab = alg_bytes(N, M, C)
+    if plan.dense:
+        g = plan.dcg
+        stages = {
+            "index": lambda: lib.link_dc_index(coords.data_ptr(), N, ctypes.byref(g), b.cnt, b.slots, b.vcell, b.hdr, st),
+            "premix_modsum": lambda: lib.link_dc_premix_modsum(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, 0, st),
+            "gather": lambda: lib.link_dc_gather(b.S, b.cell_n, ctypes.byref(desc), ctypes.byref(g), b.A, st),
+            "demod": lambda: lib.link_dc_demod(b.A, b.fin, coords.data_ptr(), b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b,
+                                               ctypes.byref(desc), ctypes.byref(g), N, b.out, st),
+        }
+        table = ab["block_gather"]
+        kab = {"index": N * 16, "premix_modsum": N * 4 * C + table, "gather": table, "demod": N * 4 * C}
+    else:
+        grid = plan.grid
+        stages = {
+            "index_build(4 kernels)": lambda: lib.link_index_build(
+                coords.data_ptr(), N, ctypes.byref(grid), b.cell_counts, b.scratch, b.scratch_bytes, b.cell_blk,
+                b.vox_blk, b.idx_query, b.perm, b.vox_sorted, b.pos_blk, b.blk_start, b.blk_coords, b.counts, b.hdr, st),
+            "premix_ln": lambda: lib.link_premix_ln(b.feats, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6, b.fin, st),
+            "modulate_block_sum": lambda: lib.link_modulate_block_sum(
+                b.fin, b.vox_sorted, b.w_pos, b.alpha, b.blk_start, b.hdr, ctypes.byref(desc), N, N, b.S, st),
+            "block_gather": lambda: lib.link_block_gather(
+                b.S, b.blk_coords, b.cell_blk, ctypes.byref(grid), b.hdr, ctypes.byref(desc), N, b.A, st),
+            "voxel_demod_ln": lambda: lib.link_voxel_demod_ln(
+                b.A, b.fin, b.vox_sorted, b.pos_blk, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.hdr, ctypes.byref(desc),
+                N, b.out, st),
+        }
+        kab = {k: ab[k] for k in ("premix_ln", "modulate_block_sum", "block_gather", "voxel_demod_ln")}
+    assert abs(sum(kab.values()) - ab["total"]) <= 16 * N, "per-kernel split must add up to B_alg"
     k_inst = min(args.steps, 100)
     evs = {name: [] for name in stages}
     for _ in range(k_inst):
@@ -180,23 +206,38 @@ def main():
             e1.record()
             evs[name].append((e0, e1))
     torch.cuda.synchronize()
-    kern_us = {name: 1e3 * sum(a.elapsed_time(b_) for a, b_ in v) / len(v) for name, v in evs.items()}
-    ab = alg_bytes(N, M, C)
-    core = {k: v for k, v in kern_us.items() if k in ab}
+    kern_us = {name: 1e3 * sum(x.elapsed_time(y) for x, y in v) / len(v) for name, v in evs.items()}
+    # whole single-frame steps, device-event timed one by one: median and mean
+    step_ev = []
+    for _ in range(max(50, min(args.steps, 200))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plan.run(feats, coords)
+        e1.record()
+        step_ev.append((e0, e1))
+    torch.cuda.synchronize()
+    step_us = sorted(1e3 * x.elapsed_time(y) for x, y in step_ev)
+    core = {k: v for k, v in kern_us.items() if k in kab}
     dom = max(core, key=core.get)
-    achieved = ab[dom] / (core[dom] * 1e-6) / 1e9
-    # memory-side bytes per launch from rocprofv3 PMC passes over this workload (not collectable from inside
-    # the timed process): 2*FETCH_SIZE + WRITE_SIZE with the gfx950 wide-read correction, cfg2 only
-    pmc_traffic = {"block_gather": 53.8e6, "premix_ln": 51.4e6, "modulate_block_sum": 49.9e6,
-                   "voxel_demod_ln": 50.8e6}
-    traffic = pmc_traffic.get(dom) if (N, C) == (100000, 64) else None
+    achieved = kab[dom] / (core[dom] * 1e-6) / 1e9
+    # memory-side bytes per launch: rocprofv3 PMC passes over this workload (tools/pmc_dc.sh -> profiles/traffic.json;
+    # they cannot be collected from inside the timed process)
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj) and (N, C) == (100000, 64):
+        tdb = json.load(open(tj))
+        traffic = tdb.get("kernels", {}).get(dom)
+        traffic_src = tdb.get("source")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_v6_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                  "separate passes; Infinity-Cache hits are counted by these counters)",
-                "alg_bytes_per_launch": ab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
+                "traffic_source": traffic_src,
+                "alg_bytes_per_launch": kab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
+                "layout": "dense-cell" if plan.dense else "general",
                 "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / args.steps, 2),
-                               "frac": round(ab["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+                               "frac": round(ab["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                "single_frame_step": {"median_us": round(step_us[len(step_us) // 2], 2),
+                                      "mean_us": round(sum(step_us) / len(step_us), 2), "n": len(step_us),
+                                      "frac": round(ab["total"] / (step_us[len(step_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     # ---- CPU baseline: the oracle port on this host (rank 0, N=1 only) ---------------------------
     cpu = None

@@ -459,14 +459,31 @@ int link_dc_modsum(const float *fin, const int32_t *slots, uint32_t *cnt, int32_
                    int32_t warm, float *S, int32_t *hdr, void *stream);
 int link_dc_gather(const float *S, const int32_t *cell_n, const link_elk_desc_t *desc /* host */,
                    const link_dc_grid_t *g /* host */, float *A, void *stream);
+/* Fused forms (link_amd/csrc/dense_fused.hip) -- what link_elk_core_dense_forward runs by default:
+ *   link_dc_index          the slot insert alone: coords -> cnt / slots / vcell (status bits as above)
+ *   link_dc_premix_modsum  pre_mix + LayerNorm + theta + modulate + per-cell sum in ONE kernel: a wave owns a
+ *                          range of cells, lays their voxels out id-ordered in LDS, and runs them through MFMA
+ *                          tiles of 16 voxels, so `fin` never leaves registers (it is written, for the
+ *                          de-modulation, only when op == LINK_OP_COSX); C in {16,32,64}, k <= 384
+ *   link_dc_demod          per-voxel de-modulate + LayerNorm in original voxel order from A[vcell] */
+int link_dc_index(const int32_t *coords, int64_t n, const link_dc_grid_t *g /* host */, uint32_t *cnt,
+                  int32_t *slots, int32_t *vcell, int32_t *hdr, void *stream);
+int link_dc_premix_modsum(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
+                          const link_elk_desc_t *desc /* host */, int64_t n, int32_t warm, void *stream);
+int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const int32_t *vcell,
+                  const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                  const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */, int64_t n, float *out,
+                  void *stream);
 /* One call = one R_core step on the dense-cell path (build_index = 0 reuses slots/cell_n of the previous
  * call on the same coordinates: the "warm" figure). */
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
-/* Tuning hook (bench only): key 0 premix workgroups, 1 modsum workgroups, 2 gather z-splits, 3 write-through
- * mask (bit0 fin, bit1 S, bit2 A). */
+/* Tuning hooks (bench only).  link_dc_set_tuning: key 0 premix workgroups, 1 modsum workgroups, 2 gather
+ * z-splits, 3 kernel selection (bit0 fused pre_mix+modsum, bit1 dense-cell demod kernel; default 3).
+ * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups. */
 int link_dc_set_tuning(int key, int value);
+int link_dc_set_tuning2(int key, int value);
 
 #ifdef __cplusplus
 }

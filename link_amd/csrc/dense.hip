@@ -23,7 +23,7 @@ using namespace link;
 static int g_dc_premix_wgs = 512;
 static int g_dc_modsum_wgs = 768;
 static int g_dc_zsplit = 0;          // 0 = auto
-static int g_dc_wt = 7;
+static int g_dc_mode = 3;          // bit0: fused pre_mix+modsum kernel, bit1: dense-cell demod kernel
 
 extern "C" int link_dc_set_tuning(int key, int value) {
   if (value < 0) return LINK_ERR_ARG;
@@ -31,7 +31,7 @@ extern "C" int link_dc_set_tuning(int key, int value) {
     case 0: g_dc_premix_wgs = value > 0 ? value : 512; break;
     case 1: g_dc_modsum_wgs = value > 0 ? value : 768; break;
     case 2: g_dc_zsplit = value; break;
-    case 3: g_dc_wt = value; break;
+    case 3: g_dc_mode = value; break;
     default: return LINK_ERR_ARG;
   }
   return LINK_OK;
@@ -86,20 +86,22 @@ __global__ void __launch_bounds__(256) k_dc_premix_insert(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, gq = lane >> 4;
   {                                                  // stage W: all loads first, one wait
-    constexpr int NV = (C * C / 4 + 255) / 256;
+    // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
+    // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
+    constexpr int NF4 = C * C / 4;                     // float4 pieces of W
+    constexpr int NV = (NF4 + 255) / 256;
     float4 wv[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int e = (i * 256 + tid) * 4;
-      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[e < C * C ? e : 0]);
+      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[(NF4 % 256 == 0 || e < C * C) ? e : 0]);
     }
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-      const int e = (i * 256 + tid) * 4;
-      if (e < C * C) {
-        const int r = e / C, col = e - r * C;
-        *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = wv[i];
-      }
+      int e = (i * 256 + tid) * 4;
+      if (NF4 % 256 != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
+      const int r = e / C, col = e - r * C;
+      *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = (NF4 % 256 == 0 || (i * 256 + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
     }
     if (tid < C) ln_lds[tid] = ln_w[tid];
     else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
@@ -845,19 +847,43 @@ extern "C" int link_dc_gather(const float *S_, const int32_t *cell_n, const link
 // ---------------------------------------------------------------------------------------------
 // one-call R_core on the dense-cell path
 // ---------------------------------------------------------------------------------------------
+extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_grid_t *g, uint32_t *cnt, int32_t *slots,
+                             int32_t *vcell, int32_t *hdr, void *stream);
+extern "C" int link_dc_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d,
+                                     int64_t n, int32_t warm, void *stream);
+extern "C" int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const int32_t *vcell,
+                             const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                             const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, float *out, void *stream);
+
 extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const link_dc_grid_t *g,
                                            const link_elk_desc_t *desc, int64_t n, int32_t build_index,
                                            void *stream) {
   if (!b || dc_desc_ok(desc, g) != LINK_OK || n < 0) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  int rc = link_dc_premix_insert(b->feats, b->coords, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, g,
-                                 build_index, b->fin, b->cnt, b->slots, b->vrec, b->vcell, b->hdr, stream);
-  if (rc != LINK_OK) return rc;
-  rc = link_dc_modsum(b->fin, b->slots, b->cnt, b->cell_n, b->w_pos, b->alpha, desc, g, build_index ? 0 : 1, b->S,
-                      b->hdr, stream);
-  if (rc != LINK_OK) return rc;
+  int rc;
+  const bool fused = (g_dc_mode & 1) && desc->c <= 64 && g->k <= 384;
+  if (fused) {
+    // index -> fused pre_mix + modulate + per-cell sum -> box gather -> per-voxel de-modulate
+    if (build_index) {
+      rc = link_dc_index(b->coords, n, g, b->cnt, b->slots, b->vcell, b->hdr, stream);
+      if (rc != LINK_OK) return rc;
+    }
+    rc = link_dc_premix_modsum(b, g, desc, n, build_index ? 0 : 1, stream);
+    if (rc != LINK_OK) return rc;
+  } else {
+    rc = link_dc_premix_insert(b->feats, b->coords, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, g,
+                               build_index, b->fin, b->cnt, b->slots, b->vrec, b->vcell, b->hdr, stream);
+    if (rc != LINK_OK) return rc;
+    rc = link_dc_modsum(b->fin, b->slots, b->cnt, b->cell_n, b->w_pos, b->alpha, desc, g, build_index ? 0 : 1, b->S,
+                        b->hdr, stream);
+    if (rc != LINK_OK) return rc;
+  }
   rc = link_dc_gather(b->S, b->cell_n, desc, g, b->A, stream);
   if (rc != LINK_OK) return rc;
+  if (g_dc_mode & 2)
+    return link_dc_demod(b->A, b->fin, b->coords, b->vcell, b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, g, n, b->out,
+                         stream);
+  if (fused && build_index) return LINK_ERR_ARG;       // section C's kernel needs vrec, which only pre_mix+insert writes
   return link_voxel_demod_ln(b->A, b->fin, b->vrec, b->vcell, b->w_pos, b->alpha, b->ln_w, b->ln_b, b->hdr, desc, n,
                              b->out, stream);
 }

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=100_000)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--unfused", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda")
     N, C = a.voxels, a.channels
@@ -70,15 +71,24 @@ def main():
     p = plans["dense"]
     b, g, d = p.buf, p.dcg, p.desc
     st = torch.cuda.current_stream().cuda_stream
-    stages = {
+    unfused = {
         "premix_insert": lambda: lib.link_dc_premix_insert(b.feats, b.coords, b.w_pre, b.pre_ln_w, b.pre_ln_b, N, C, 1e-6,
                                                            ctypes.byref(g), 1, b.fin, b.cnt, b.slots, b.vrec, b.vcell, b.hdr, st),
         "modsum": lambda: lib.link_dc_modsum(b.fin, b.slots, b.cnt, b.cell_n, b.w_pos, b.alpha, ctypes.byref(d), ctypes.byref(g),
                                              0, b.S, b.hdr, st),
         "gather": lambda: lib.link_dc_gather(b.S, b.cell_n, ctypes.byref(d), ctypes.byref(g), b.A, st),
-        "demod": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vrec, b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.hdr,
-                                                 ctypes.byref(d), N, b.out, st),
+        "demod_c": lambda: lib.link_voxel_demod_ln(b.A, b.fin, b.vrec, b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b, b.hdr,
+                                                   ctypes.byref(d), N, b.out, st),
     }
+    stages = {
+        "index": lambda: lib.link_dc_index(b.coords, N, ctypes.byref(g), b.cnt, b.slots, b.vcell, b.hdr, st),
+        "premix_modsum": lambda: lib.link_dc_premix_modsum(ctypes.byref(b), ctypes.byref(g), ctypes.byref(d), N, 0, st),
+        "gather": unfused["gather"],
+        "demod": lambda: lib.link_dc_demod(b.A, b.fin, b.coords, b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b,
+                                           ctypes.byref(d), ctypes.byref(g), N, b.out, st),
+    }
+    if a.unfused:
+        stages = unfused
 
     def chain():
         for f in stages.values():
@@ -106,19 +116,19 @@ def main():
         return res
 
     report("default   ")
-    if a.sweep:
-        for wgs in (256, 384, 512, 768, 1024, 1536):
-            lib.link_dc_set_tuning(0, wgs); report(f"premix wgs={wgs:5d}")
-        lib.link_dc_set_tuning(0, 512)
+    if a.sweep and not a.unfused:
+        for wgs in (256, 384, 512, 768, 1024):
+            lib.link_dc_set_tuning2(0, wgs); report(f"k1 wgs={wgs:5d}")
+        lib.link_dc_set_tuning2(0, 512)
         for wgs in (256, 512, 1024, 2048, 4096):
-            lib.link_dc_set_tuning(1, wgs); report(f"modsum wgs={wgs:5d}")
-        lib.link_dc_set_tuning(1, 1024)
-        for zs in (1, 2, 3, 4, 5, 6, 8, 10):
+            lib.link_dc_set_tuning2(1, wgs); report(f"demod wgs={wgs:5d}")
+        lib.link_dc_set_tuning2(1, 1024)
+        for wgs in (128, 256, 512):
+            lib.link_dc_set_tuning2(2, wgs); report(f"index wgs={wgs:5d}")
+        lib.link_dc_set_tuning2(2, 0)
+        for zs in (2, 3, 4, 5):
             lib.link_dc_set_tuning(2, zs); report(f"gather zsplit={zs:3d}")
         lib.link_dc_set_tuning(2, 0)
-        for wt in (0, 1, 2, 4, 7):
-            lib.link_dc_set_tuning(3, wt); report(f"write-through mask={wt}")
-        lib.link_dc_set_tuning(3, 7)
     # frames in flight
     for ns in (1, 2, 3, 4):
         ps, ss = [], []
