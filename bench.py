@@ -170,15 +170,20 @@ def main():
     ab = alg_bytes(N, M, C)
     if plan.dense:
         g = plan.dcg
+        # the three launches of one step (index -> pre_mix+modulate+cell sums -> box sum+de-modulate); C = 64
         stages = {
             "index": lambda: lib.link_dc_index(coords.data_ptr(), N, ctypes.byref(g), b.cnt, b.slots, b.vcell, b.hdr, st),
             "premix_modsum": lambda: lib.link_dc_premix_modsum(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, 0, st),
-            "gather": lambda: lib.link_dc_gather(b.S, b.cell_n, ctypes.byref(desc), ctypes.byref(g), b.A, st),
-            "demod": lambda: lib.link_dc_demod(b.A, b.fin, coords.data_ptr(), b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b,
-                                               ctypes.byref(desc), ctypes.byref(g), N, b.out, st),
+            "gather_demod": lambda: lib.link_dc_gather_demod(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, st),
         }
         table = ab["block_gather"]
-        kab = {"index": N * 16, "premix_modsum": N * 4 * C + table, "gather": table, "demod": N * 4 * C}
+        kab = {"index": N * 16, "premix_modsum": N * 4 * C + table, "gather_demod": table + N * 4 * C}
+        if C != 64:                                   # other widths: box sum and de-modulation are two kernels
+            del stages["gather_demod"], kab["gather_demod"]
+            stages["gather"] = lambda: lib.link_dc_gather(b.S, b.cell_n, ctypes.byref(desc), ctypes.byref(g), b.A, st)
+            stages["demod"] = lambda: lib.link_dc_demod(b.A, b.fin, coords.data_ptr(), b.vcell, b.w_pos, b.alpha, b.ln_w,
+                                                        b.ln_b, ctypes.byref(desc), ctypes.byref(g), N, b.out, st)
+            kab.update({"gather": table, "demod": N * 4 * C})
     else:
         grid = plan.grid
         stages = {

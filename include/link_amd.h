@@ -464,7 +464,7 @@ int link_dc_gather(const float *S, const int32_t *cell_n, const link_elk_desc_t 
  *   link_dc_premix_modsum  pre_mix + LayerNorm + theta + modulate + per-cell sum in ONE kernel: a wave owns a
  *                          range of cells, lays their voxels out id-ordered in LDS, and runs them through MFMA
  *                          tiles of 16 voxels, so `fin` never leaves registers (it is written, for the
- *                          de-modulation, only when op == LINK_OP_COSX); C in {16,32,64}, k <= 384
+ *                          de-modulation, only when op == LINK_OP_COSX); C in {16,32,64}, k <= 352
  *   link_dc_demod          per-voxel de-modulate + LayerNorm in original voxel order from A[vcell] */
 int link_dc_index(const int32_t *coords, int64_t n, const link_dc_grid_t *g /* host */, uint32_t *cnt,
                   int32_t *slots, int32_t *vcell, int32_t *hdr, void *stream);
@@ -474,16 +474,24 @@ int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const
                   const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                   const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */, int64_t n, float *out,
                   void *stream);
+/*   link_dc_gather_demod   box sum + de-modulate + LayerNorm in ONE kernel (C = 64): the normalised neighbour sums
+ *                          of a z-plane live in LDS only and the plane's voxels are dealt out to the workgroup's
+ *                          16 lane groups as pairs; neither the A table nor its per-voxel gather exists */
+int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
+                         const link_elk_desc_t *desc /* host */, int64_t n, void *stream);
 /* One call = one R_core step on the dense-cell path (build_index = 0 reuses slots/cell_n of the previous
  * call on the same coordinates: the "warm" figure). */
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
 /* Tuning hooks (bench only).  link_dc_set_tuning: key 0 premix workgroups, 1 modsum workgroups, 2 gather
- * z-splits, 3 kernel selection (bit0 fused pre_mix+modsum, bit1 dense-cell demod kernel; default 3).
- * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups. */
+ * z-splits, 3 kernel selection (bit0 fused pre_mix+modsum, bit1 dense-cell demod kernel, bit2 fused gather+demod; default 7).
+ * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups, 3 z-splits of the fused gather+demod. */
 int link_dc_set_tuning(int key, int value);
 int link_dc_set_tuning2(int key, int value);
+/* Bench only: device buffer u64[waves*8] that the fused kernel fills with per-wave phase timings (s_memtime
+ * deltas: W staging, cell section, pipeline fill, tile bodies, per-cell sums, total, tiles, start); NULL = off. */
+int link_dc_set_debug_buffer(void *device_ptr);
 
 #ifdef __cplusplus
 }

@@ -146,9 +146,11 @@ SIGNATURES = {
                                             c_int64, c_int32, c_void_p]),
     "link_dc_set_tuning": (c_int, [c_int, c_int]),
     "link_dc_set_tuning2": (c_int, [c_int, c_int]),
+    "link_dc_set_debug_buffer": (c_int, [c_void_p]),
     "link_dc_index": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_premix_modsum": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64,
                                       c_int32, c_void_p]),
+    "link_dc_gather_demod": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64, c_void_p]),
     "link_dc_demod": (c_int, [c_void_p] * 8 + [POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_int64, c_void_p, c_void_p]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),

@@ -76,6 +76,25 @@ __device__ __forceinline__ void sincos_nocall(float x, float &sn, float &cs) {
   cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// The |x| < 2^15 body of sincos_nocall alone, branch-free (bit-identical there): for code that has already
+// established the range for the whole wave and must stay one basic block.
+__device__ __forceinline__ void sincos_small(float x, float &sn, float &cs) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188216e-8f, r);
+  const int q = (int)k;
+  const float r2 = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const float s0 = (q & 1) ? pc : ps;
+  const float c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 template <int LPR>
 __device__ __forceinline__ float grp_sum(float v) {
   // butterfly over the LPR lanes of a group; steps <= 8 stay inside a 16-lane DPP row

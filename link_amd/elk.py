@@ -108,7 +108,8 @@ class ElkCorePlan:
 
     Two layouts, chosen here on the host from what is known before the frame arrives:
       * dense-cell (include/link_amd.h section E): block table indexed by grid cell, the index is a
-        per-cell slot list filled by the pre_mix kernel -- 4 launches.  Taken when the padded grid has
+        per-cell slot list -- 3 launches (slot insert; fused pre_mix + modulate + cell sums; fused box
+        sum + de-modulate).  Taken when the padded grid has
         at most `dense_ratio` x n_cap cells (a mostly occupied grid: cfg1/cfg2), C in {16,32,64,128},
         r in {2,3}.  Slot capacity s^3 covers every frame with unique coordinates; duplicates beyond
         it are dropped and reported by blocks().

@@ -7,6 +7,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 
 import link_amd as la
@@ -45,6 +46,8 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--unfused", action="store_true")
+    ap.add_argument("--split", action="store_true", help="separate gather + demod kernels instead of the fused one")
+    ap.add_argument("--phases", action="store_true", help="per-wave phase timing of the fused kernel (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     N, C = a.voxels, a.channels
@@ -89,6 +92,9 @@ def main():
     }
     if a.unfused:
         stages = unfused
+    elif not a.split and C == 64:
+        stages = {"index": stages["index"], "premix_modsum": stages["premix_modsum"],
+                  "gather_demod": lambda: lib.link_dc_gather_demod(ctypes.byref(b), ctypes.byref(g), ctypes.byref(d), N, st)}
 
     def chain():
         for f in stages.values():
@@ -116,6 +122,22 @@ def main():
         return res
 
     report("default   ")
+    if a.phases and not a.unfused:
+        dbg = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+        lib.link_dc_set_debug_buffer(dbg.data_ptr())
+        for _ in range(3):
+            chain()
+        torch.cuda.synchronize()
+        lib.link_dc_set_debug_buffer(None)
+        d = dbg.view(-1, 8).cpu().numpy()
+        d = d[d[:, 5] > 0]
+        names = ["W staging", "cell section", "pipeline fill", "tile bodies", "per-cell sums", "total"]
+        print(f"fused kernel, {len(d)} waves; cycles per wave (mean / p50 / max), tiles per wave {d[:, 6].mean():.2f}")
+        for i, nm in enumerate(names):
+            print(f"  {nm:14s} {d[:, i].mean():9.0f} {np.median(d[:, i]):9.0f} {d[:, i].max():9.0f}")
+        print(f"  per tile: body {d[:, 3].sum() / d[:, 6].sum():.0f}  sums {d[:, 4].sum() / d[:, 6].sum():.0f}")
+        span = (d[:, 7] + d[:, 5]).max() - d[:, 7].min()
+        print(f"  first start -> last end: {span} cycles; start skew p50 {np.median(d[:, 7] - d[:, 7].min()):.0f} max {(d[:, 7] - d[:, 7].min()).max()}")
     if a.sweep and not a.unfused:
         for wgs in (256, 384, 512, 768, 1024):
             lib.link_dc_set_tuning2(0, wgs); report(f"k1 wgs={wgs:5d}")
@@ -127,8 +149,8 @@ def main():
             lib.link_dc_set_tuning2(2, wgs); report(f"index wgs={wgs:5d}")
         lib.link_dc_set_tuning2(2, 0)
         for zs in (2, 3, 4, 5):
-            lib.link_dc_set_tuning(2, zs); report(f"gather zsplit={zs:3d}")
-        lib.link_dc_set_tuning(2, 0)
+            lib.link_dc_set_tuning(2, zs); lib.link_dc_set_tuning2(3, zs); report(f"gather zsplit={zs:3d}")
+        lib.link_dc_set_tuning(2, 0); lib.link_dc_set_tuning2(3, 0)
     # frames in flight
     for ns in (1, 2, 3, 4):
         ps, ss = [], []

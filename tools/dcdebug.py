@@ -5,37 +5,28 @@ import numpy as np, torch
 import link_amd as la
 from link_amd import _lib as L
 from helpers import rel_err, s_uniform
-C, groups, baseop, s, r, grid, n = 64, 2, "cos", 7, 3, 80, 9000
+C, groups, baseop, s, r, grid, n = 64, 1, "cos_x", 3, 3, 30, 4000
 torch.manual_seed(5)
 blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
 coords = s_uniform(n, grid=grid, seed=C + r).cuda()
 feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
 bounds = ((0, 0, 0, 0), (grid - 1,) * 3 + (0,))
 lib = L.lib()
-res = {}
-for mode in (0, 2, 3):
-    lib.link_dc_set_tuning(3, mode)
+for mode, single in ((7, 0), (7, 1)):
+    lib.link_dc_set_tuning(3, mode); lib.link_dc_set_tuning2(4, single)
     p = la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, torch.device("cuda"), layout="dense")
-    p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight, blk.norm.bias)
-    out = p.run(feats, coords).clone()
-    torch.cuda.synchronize()
-    res[mode] = dict(out=out.cpu().numpy(), S=p.S.clone().cpu().numpy(), A=p.A.clone().cpu().numpy(), cell_n=p.cell_n.clone().cpu().numpy(), vcell=p.vcell.clone().cpu().numpy())
-for mode in (2, 3):
-    for k in ("S", "A", "out"):
-        a, b = res[mode][k], res[0][k]
-        print("mode", mode, k, "rel err vs mode 0:", rel_err(a, b))
-    print("cell_n equal", np.array_equal(res[mode]["cell_n"], res[0]["cell_n"]), "vcell equal", np.array_equal(res[mode]["vcell"], res[0]["vcell"]))
-S3, S0 = res[3]["S"], res[0]["S"]
-bad = np.where(np.abs(S3 - S0).max(1) > 1e-4)[0]
-print("bad S rows", len(bad), bad[:20], "counts there", res[0]["cell_n"][bad[:20]])
-if len(bad):
-    r0 = bad[0]; print(S3[r0][:8], S0[r0][:8]); print(S3[r0][64:72], S0[r0][64:72])
-o2, o0 = res[2]["out"], res[0]["out"]
-d = np.abs(o2 - o0).max(1)
-print("rows wrong:", (d > 1e-3).sum(), "of", len(d), "first wrong rows", np.where(d > 1e-3)[0][:16])
-i = int(np.where(d > 1e-3)[0][0]) if (d > 1e-3).any() else 0
-print("row", i, o2[i][:8], o0[i][:8])
-print("chan err profile", np.abs(o2 - o0).max(0)[:64].round(3))
-# is o2 row i equal to o0 row j for some neighbour?
-for j in (i - 1, i + 1, i ^ 1):
-    if 0 <= j < len(d): print("vs row", j, np.abs(o2[i] - o0[j]).max())
+    p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, blk.alpha, blk.norm.weight, blk.norm.bias)
+    o0 = p.run(feats, coords).clone()
+    fin0 = p.fin.clone()
+    bad = 0
+    for it in range(6):
+        o = p.run(feats, coords).clone()
+        d = (o != o0).any(1)
+        fd = (p.fin != fin0).any(1)
+        if d.any() or fd.any():
+            bad += 1
+            idx = torch.nonzero(d).flatten()[:8].tolist()
+            cn = p.cell_n[p.vcell[idx].long()].tolist() if idx else []
+            print("mode", mode, "iter", it, "rows differing", int(d.sum()), "fin rows differing", int(fd.sum()), idx, "cell counts", cn,
+                  "max abs diff", float((o - o0).abs().max()))
+    print("mode", mode, "single", single, "bad iterations", bad)
