@@ -53,6 +53,114 @@ def alg_bytes(n, m, c, parts=2):
             "voxel_demod_ln": n * 4 * c}
 
 
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or os.cpu_count() or 1)
+
+
+def cpu_baseline(blk, feats, coords, out, N, C, S_, R, G):
+    """SURVEY.md section 8d CPU baseline on this host: R_core through oracle/ (baseline only; the roofline
+    fraction is the quality measure).  Bounded: the OpenMP leg runs a sub-frame sized for ~10 s."""
+    import torch
+    from oracle import link_oracle as O
+    model, phys = _cpu_info()
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    fc, cc = feats.cpu(), coords.cpu()
+    torch.set_num_threads(1)
+    reps, t_cpu, ref = 0, 0.0, None
+    while reps < 20 and t_cpu < 8.0:                     # scalar port, one core, full frame
+        t0 = time.perf_counter()
+        ref = O.elk_core_torch(fc, cc, params, S_, R, "cos", G, agg=O.aggregate_c)
+        t_cpu += time.perf_counter() - t0
+        reps += 1
+    err = float((out.cpu() - ref).abs().max() / ref.abs().max())
+    one_core = N * reps / t_cpu
+    # OpenMP leg: all physical cores, the reference's pragma placement (a parallel region per voxel in
+    # spvoxelize) -- first a 4k-voxel probe, then a sample sized for about 10 s
+    os.environ["OMP_NUM_THREADS"] = str(phys)
+    torch.set_num_threads(phys)
+    O.set_omp(True)
+    try:
+        def omp_pass(nv):
+            t0 = time.perf_counter()
+            O.elk_core_torch(fc[:nv], cc[:nv], params, S_, R, "cos", G, agg=O.aggregate_c)
+            return time.perf_counter() - t0
+        probe = omp_pass(min(N, 4000))
+        nv = int(min(N, max(4000, 4000 * 10.0 / max(probe, 1e-3))))
+        t_omp = omp_pass(nv)
+    finally:
+        O.set_omp(False)
+        torch.set_num_threads(1)
+    return {"value": round(nv / t_omp, 1), "unit": "voxels/s", "cores": phys, "kind": "port", "cpu_model": model,
+            "sample": f"R_core on the first {nv} voxels of the same frame (C={C}) through oracle/'s OpenMP twin: pragmas at "
+                      f"the reference's loop placement (voxelize_cpu.cpp:17, devoxelize_cpu.cpp:16), OMP_NUM_THREADS={phys}, "
+                      f"torch threads={phys}; {t_omp:.1f} s",
+            "single_core_port": {"value": round(one_core, 1), "cores": 1,
+                                 "sample": f"{reps} full passes (N={N}) through the scalar C restatement + single-thread "
+                                           f"torch dense ops, {t_cpu:.1f} s"},
+            "host_cpus": os.cpu_count(), "gpu_vs_oracle_max_rel_err": err}
+
+
+def timed_regions(la, blk, feats, coords, C, s, r, iters=30):
+    """The other timed regions of SURVEY.md section 8d on the same frame, device-event medians in us:
+    R_agg = voxel_to_aux + aux_to_voxel through the drop-in surface on X[N,2C]; R_block = ELKBlock.forward
+    (local_mix + R_core + norm_local/add/ReLU).  cold = fresh SparseTensor (nothing cached), warm = the
+    tensor's kmaps/cmaps carried over (what the 2nd..4th block of a network stage sees)."""
+    import torch
+    dev = feats.device
+    x = torch.randn(feats.shape[0], 2 * C, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def med(fn):
+        for _ in range(3):
+            fn()
+        ev = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        v = sorted(1e3 * a.elapsed_time(b) for a, b in ev)
+        return round(v[len(v) // 2], 1)
+
+    st0 = la.SparseTensor(x, coords, 1)
+    la.voxel_to_aux(st0, s)
+
+    def r_agg(warm):
+        st = la.SparseTensor(x, coords, 1)
+        if warm:
+            st.kmaps, st.cmaps = st0.kmaps, st0.cmaps
+        small, idx, counts = la.voxel_to_aux(st, s)
+        return la.aux_to_voxel(small, st, idx, counts, r).F
+
+    stb = la.SparseTensor(feats, coords, 1)
+    with torch.no_grad():
+        blk(stb, s, r)
+
+    def r_block(warm):
+        st = la.SparseTensor(feats, coords, 1)
+        if warm:
+            st.kmaps, st.cmaps = stb.kmaps, stb.cmaps
+        with torch.no_grad():
+            return blk(st, s, r).F
+
+    return {"R_agg_cold_us": med(lambda: r_agg(False)), "R_agg_warm_us": med(lambda: r_agg(True)),
+            "R_block_cold_us": med(lambda: r_block(False)), "R_block_warm_us": med(lambda: r_block(True)),
+            "note": "host-inclusive device-event medians through the Python module surface (allocating path); "
+                    "R_core cold/warm are `value`/`warm_index_value` (arena path, one FFI call per step)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,26 +352,15 @@ def main():
                                       "mean_us": round(sum(step_us) / len(step_us), 2), "n": len(step_us),
                                       "frac": round(ab["total"] / (step_us[len(step_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
-    # ---- CPU baseline: the oracle port on this host (rank 0, N=1 only) ---------------------------
+    # ---- CPU baseline: the oracle on this host (rank 0, N=1 only) -------------------------------------
+    # (1) the OpenMP twin of the C restatement -- pragmas exactly where the reference's CPU ops have them
+    #     (voxelize_cpu.cpp:17 inner loop, devoxelize_cpu.cpp:16 outer loop), OMP_NUM_THREADS = physical
+    #     cores -- on a bounded sample of the same frame; (2) the same code scalar, one core, full frame.
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import link_oracle as O
-        torch.set_num_threads(1)
-        params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
-        fc, cc = feats.cpu(), coords.cpu()
-        reps, t_cpu = 0, 0.0
-        ref = None
-        while reps < 20 and t_cpu < 12.0:
-            t0 = time.perf_counter()
-            ref = O.elk_core_torch(fc, cc, params, S_, R, "cos", G, agg=O.aggregate_c)
-            t_cpu += time.perf_counter() - t0
-            reps += 1
-        err = float((out.cpu() - ref).abs().max() / ref.abs().max())
-        cpu = {"value": round(N * reps / t_cpu, 1), "unit": "voxels/s", "cores": 1, "kind": "port",
-               "sample": f"{reps} full passes of the same workload (R_core, N={N}, C={C}) through oracle/ "
-                         f"(scalar C aggregation + single-thread torch dense ops), {t_cpu:.1f} s",
-               "host_cpus": os.cpu_count(), "gpu_vs_oracle_max_rel_err": err}
+        cpu = cpu_baseline(blk, feats, coords, out, N, C, S_, R, G)
 
+    regions = timed_regions(la, blk, feats, coords, C, S_, R) if world == 1 else None
     ms = 1e3 * elapsed / args.steps
     line = {
         "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
@@ -278,7 +375,7 @@ def main():
                                   "no data-path collective"},
         "single_stream_value": round(total_vox * args.steps / elapsed_single, 1),
         "warm_index_value": round(total_vox * args.steps / elapsed_warm, 1),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
     }
     print(json.dumps(line))
     if world > 1:

@@ -127,8 +127,10 @@ class ElkCorePlan:
         if layout not in ("auto", "dense", "general"):
             raise ValueError(f"layout must be auto|dense|general, got {layout!r}")
         dcg = L.dc_grid_from(self.grid) if layout != "general" else None
+        # 32-bit byte offsets in every table, and a slot arena (vp * k records of 16 B) of at most 1 GiB
         ok = (dcg is not None and c in (16, 32, 64, 128) and r in (2, 3)
-              and (dcg.vp + 1) * self.parts * c * 4 < 2 ** 32 and n_cap * c * 4 < 2 ** 32)
+              and (dcg.vp + 1) * self.parts * c * 4 < 2 ** 32 and n_cap * c * 4 < 2 ** 32
+              and dcg.vp * dcg.k * 16 <= 2 ** 30)
         if layout == "dense" and not ok:
             raise L.LinkAmdError("ElkCorePlan(layout='dense'): width / r / grid size not supported by the "
                                  "dense-cell path (include/link_amd.h section E)")
@@ -199,11 +201,17 @@ class ElkCorePlan:
             None if t is None else t.data_ptr() for t in self._params]
         return self
 
-    def run(self, feats: torch.Tensor, coords: torch.Tensor, build_index: bool = True) -> torch.Tensor:
+    def run(self, feats: torch.Tensor, coords: torch.Tensor, build_index: bool = True,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One R_core step.  `out` (fp32 [n, C], contiguous): write the result there instead of the plan's
+        own buffer (what the module path does: the block's output tensor must outlive the plan)."""
         n = feats.shape[0]
         assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype == torch.float32
         assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
         self.buf.feats, self.buf.coords = feats.data_ptr(), coords.data_ptr()
+        if out is not None:
+            assert out.shape == (n, self.c) and out.dtype == torch.float32 and out.is_contiguous()
+        self.buf.out = (out if out is not None else self.out).data_ptr()
         st = torch.cuda.current_stream().cuda_stream
         if self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
@@ -213,7 +221,7 @@ class ElkCorePlan:
                           min(self.m_cap, n), 1 if build_index else 0, st)
         if rc != 0:
             L.check(rc, "link_elk_core_dense_forward" if self.dense else "link_elk_core_forward")
-        return self.out[:n]
+        return out if out is not None else self.out[:n]
 
     def blocks(self) -> int:
         """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds (or, on
@@ -690,7 +698,52 @@ class _SubmConv(torch.autograd.Function):
 # modules
 # ------------------------------------------------------------------------------------------------
 class _ELKBase(nn.Module):
+    def _core_dense(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
+        """Inference R_core on the dense-cell layout (ElkCorePlan), or None when the frame's block grid is
+        too sparse / the width unsupported: then the general layout below runs.  Plans (arena + slot lists)
+        are cached per module and grid; the slot index of a coordinate tensor is reused while that tensor
+        lives (the reference recomputes everything per call, utils.py:45-51)."""
+        feats, coords = st.F, st.C
+        n, c = feats.shape
+        if n == 0 or c not in (16, 32, 64, 128) or r not in (2, 3) or not feats.is_cuda:
+            return None
+        bkey = ("link_bounds", coords.data_ptr(), n)
+        bounds = st.cmaps.get(bkey)
+        if bounds is None:
+            from .index import coords_bounds
+            bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
+        cache = self.__dict__.setdefault("_dc_plans", {})
+        n_cap = 1 << max(10, (n - 1).bit_length())
+        key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, bounds, float(coord_div))
+        plan = cache.get(key, False)
+        if plan is False:
+            try:
+                plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, bounds, feats.device, coord_div=coord_div)
+                if not plan.dense:
+                    plan = None
+            except L.LinkAmdError:
+                plan = None
+            if len(cache) >= 8:                              # arenas are large: keep the cache small
+                cache.pop(next(iter(cache)))
+            cache[key] = plan
+        if plan is None:
+            return None
+        plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
+                  self.norm.weight, self.norm.bias)
+        ikey = (coords.data_ptr(), n, coords._version)
+        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
+        plan._indexed = ikey
+        plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
+        return out
+
     def _core(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
+        needs_grad0 = torch.is_grad_enabled() and (st.F.requires_grad or any(
+            p.requires_grad for p in self.parameters()))
+        if not needs_grad0 and st.F.dtype == torch.float32 and st.C.dtype == torch.int32:
+            out = self._core_dense(st, s_eff, r, w_pos, alpha, cg, coord_div)
+            if out is not None:
+                return out
         index = link_index_of(st, s_eff)
         args = (st.F, st.C, index, self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias,
                 w_pos, alpha, self.norm.weight, self.norm.bias, self.baseop, cg, r, coord_div, 1e-6)

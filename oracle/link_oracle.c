@@ -29,6 +29,15 @@ extern "C" {
  * sphash: 64-bit FNV-1a over the four 32-bit words of a coordinate row, folded to 60 bits.
  * Follows backend/hash/hash_cpu.cpp:7-18 (== backend/hash/hash_cuda.cu:10-23).
  * ------------------------------------------------------------------------------------------- */
+/* OpenMP build (-fopenmp -DLINK_ORACLE_OMP -> liblink_oracle_omp.so): the pragmas sit exactly where the
+ * reference's CPU ops have them (voxelize: inner channel loop; devoxelize forward: outer row loop), so that
+ * the all-cores CPU baseline of bench.py times the reference's parallel structure, not a better one. */
+#ifdef LINK_ORACLE_OMP
+#define LINK_OMP_FOR _Pragma("omp parallel for")
+#else
+#define LINK_OMP_FOR
+#endif
+
 static inline int64_t fnv_row(const int32_t c[4]) {
   uint64_t h = 14695981039346656037ULL;
   for (int j = 0; j < 4; j++) {
@@ -125,6 +134,7 @@ void oracle_voxelize_fwd(int64_t n, int64_t c, const float *in, const int32_t *i
     int32_t pos = idx[i];
     if (pos < 0 || counts[pos] == 0) continue;
     float cnt = (float)counts[pos];
+    LINK_OMP_FOR                                   /* voxelize_cpu.cpp:17: the INNER loop is the parallel one */
     for (int64_t j = 0; j < c; j++) out[pos * c + j] += in[i * c + j] / cnt;
   }
 }
@@ -137,6 +147,7 @@ void oracle_voxelize_bwd(int64_t n, int64_t c, const float *top, const int32_t *
     int32_t pos = idx[i];
     if (pos < 0 || counts[pos] == 0) continue;
     float cnt = (float)counts[pos];
+    LINK_OMP_FOR                                   /* voxelize_cpu.cpp:36 */
     for (int64_t j = 0; j < c; j++) bottom[i * c + j] = top[pos * c + j] / cnt;
   }
 }
@@ -149,6 +160,7 @@ void oracle_voxelize_bwd(int64_t n, int64_t c, const float *top, const int32_t *
  * ------------------------------------------------------------------------------------------- */
 void oracle_devoxelize_fwd(int64_t nq, int64_t c, int64_t K, const int32_t *ind, const float *w,
                            const float *feat, float *out) {
+  LINK_OMP_FOR                                     /* devoxelize_cpu.cpp:16: the OUTER loop is the parallel one */
   for (int64_t i = 0; i < nq; i++) {
     for (int64_t j = 0; j < c; j++) {
       float acc = 0.f;
@@ -172,6 +184,7 @@ void oracle_devoxelize_bwd(int64_t nq, int64_t n, int64_t c, int64_t K, const in
     for (int64_t k = 0; k < K; k++) {
       int32_t q = ind[i * K + k];
       if (q < 0) continue;
+      LINK_OMP_FOR                                 /* devoxelize_cpu.cpp:49 */
       for (int64_t j = 0; j < c; j++) bottom[(int64_t)q * c + j] += w[i * K + k] * top[i * c + j];
     }
 }

@@ -24,22 +24,32 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblink_oracle.so")
+_SO_OMP = os.path.join(_HERE, "liblink_oracle_omp.so")
 _SRC = os.path.join(_HERE, "link_oracle.c")
-_lib = None
+_libs = {False: None, True: None}
+_omp = False
 
 
 def build(force: bool = False) -> str:
-    """Compile oracle/link_oracle.c with gcc (seconds)."""
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
+    """Compile oracle/link_oracle.c with gcc (seconds): the scalar checker and its OpenMP twin (same source,
+    -fopenmp -DLINK_ORACLE_OMP: pragmas at the reference's loop placement; bench.py's all-cores baseline)."""
+    for so, extra in ((_SO, []), (_SO_OMP, ["-fopenmp", "-DLINK_ORACLE_OMP"])):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(_SRC):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared"] + extra + ["-o", so, _SRC, "-lm"])
     return _SO
 
 
+def set_omp(flag: bool) -> None:
+    """Route the native-op layer through the OpenMP build (bench.py's cpu_baseline leg only)."""
+    global _omp
+    _omp = bool(flag)
+
+
 def lib() -> ctypes.CDLL:
-    global _lib
+    _lib = _libs[_omp]
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_SO)
+        _lib = _libs[_omp] = ctypes.CDLL(_SO_OMP if _omp else _SO)
         i64, p = ctypes.c_int64, ctypes.c_void_p
         _lib.oracle_hash.argtypes = [i64, p, p]
         _lib.oracle_kernel_hash.argtypes = [i64, i64, p, p, p, ctypes.c_int]
