@@ -51,3 +51,62 @@ def test_encoder_stages_forward_backward_vs_oracle(baseop, groups, s, r, c, n_st
         assert _l2(p.grad.cpu().numpy(), sd[name].grad.numpy()) < 5e-3, name
         checked += 1
     assert checked > 40
+
+
+def test_cfg3_full_size_s_kitti_encoder():
+    """BASELINE.json configs[2] at full size: the S-kitti frame of SURVEY.md section 8d (seed 0, ~113k voxels),
+    C = 64, four stages, cos_x (2x3)^3 -- forward per stage against the oracle graph (coordinates bit-exact,
+    features by the max-norm metric), backward by properties (finite, non-zero, input gradient within relative
+    L2 of the oracle's autograd).  Prints N and M per stage."""
+    import link_amd as la
+    from link_amd import synth
+    from oracle import link_oracle as lo
+    coords_np, feats_np = synth.s_kitti(0)
+    coords, feats = torch.from_numpy(coords_np), torch.from_numpy(feats_np)
+    torch.manual_seed(5)
+    net = LE.build_stages(la, 4, 64, "cos_x", 1, 4).cuda().train()
+    f = feats.cuda().requires_grad_(True)
+    outs = net(la.SparseTensor(f, coords.cuda(), 1), 3, 2)
+    outs[-1].F.square().sum().backward()                       # the cfg3 loss: sum of squares on stage 4
+    sd = {k: (v.detach().cpu().requires_grad_(False)) for k, v in net.state_dict().items()}
+    fr = feats.clone().requires_grad_(True)
+    ref = LE.oracle_stages(lo, sd, fr, coords, 3, 2, "cos_x", 1, 4, 64)
+    ref[-1][0].square().sum().backward()
+    report = []
+    for i, (o, (ro, rc)) in enumerate(zip(outs, ref)):
+        assert np.array_equal(o.C.cpu().numpy(), rc), f"stage {i} coordinates"
+        err = rel_err(o.F.detach().cpu().numpy(), ro.detach().numpy())
+        assert err < 5e-4, f"stage {i} output {err}"
+        ts = 2 ** (i + 1)
+        m = np.unique(np.concatenate([rc[:, :3] // (ts * 3), rc[:, 3:]], 1), axis=0).shape[0]
+        report.append((ts, rc.shape[0], m, round(rc.shape[0] / m, 2), err))
+    print("cfg3 S-kitti seed 0: N =", coords.shape[0], "| per stage (stride, N, M at s_eff = 3*stride, N/M, rel err):", report)
+    g = f.grad.cpu().numpy()
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    assert _l2(g, fr.grad.numpy()) < 2e-2                      # fp32 on both sides through ~60 layers with ReLUs
+    for name, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+
+
+def test_encoder_vs_reference_network_fixture():
+    """Network-level parity: the encoder half of the REFERENCE's ELKEncoder, run by
+    the imported reference on its CPU path (tests/golden/make_golden_encoder.py; r = 2, every number reference
+    output), against the same graph on link_amd modules with the reference's state_dict loaded strict=True:
+    spdownsample coordinate order, kmaps reuse across stages, the in-place st.F contract of ELKBlock and the
+    encoder variant's coords/stride theta all have to line up for the four stage outputs to match."""
+    import link_amd as la
+    from helpers import load_golden
+    g = load_golden("g_encoder_cosx_s3_r2.npz")
+    net = LE.build_reference_shaped_encoder(la, 16, "cos_x", 1)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    missing, unexpected = net.load_state_dict(sd, strict=True), None
+    net = net.cuda().eval()
+    x = la.SparseTensor(torch.from_numpy(g["feats"]).cuda(), torch.from_numpy(g["coords"]).cuda(), 1)
+    with torch.no_grad():
+        x0, outs = net(x, 3, 2)
+    assert rel_err(x0.F.cpu().numpy(), g["x0_F"]) < 1e-5
+    for i, o in enumerate(outs, 1):
+        assert np.array_equal(o.C.cpu().numpy(), g[f"x{i}_C"]), f"stage {i} coordinates (spdownsample order)"
+        assert o.s == (2 ** i,) * 3
+        assert rel_err(o.F.cpu().numpy(), g[f"x{i}_F"]) < 1e-4, f"stage {i} features"

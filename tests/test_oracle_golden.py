@@ -65,6 +65,37 @@ def test_aggregate_vs_reference(name):
     assert rel_err(out, g["out"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", golden_files("g_agg_*.npz"))
+def test_aggregate_fixture_is_the_region_mean(name):
+    """Independent pin of the aggregation fixtures -- above all the r = 3 ones, whose spdevoxelize call went
+    through a restatement of the CUDA kernel because the reference's CPU op hard-wires 8 neighbours (SURVEY.md
+    section 8a "aggregate identity"): out_i must be the plain mean of X over every voxel whose block
+    lies in the r^3 neighbourhood of voxel i's block (offsets of get_kernel_offsets(r): {-1,0,1}^3 for r = 3,
+    {0,1}^3 for r = 2), computed here by brute force in fp64 from the fixture's own inputs, nothing else."""
+    g = load_golden(name)
+    s, r = g["meta"]["s"], g["meta"]["r"]
+    coords, x = g["coords"].astype(np.int64), g["feats"].astype(np.float64)
+    blk = np.concatenate([np.floor_divide(coords[:, :3], s), coords[:, 3:]], 1)
+    lo, hi = (-1, 1) if r == 3 else (0, 1)
+    keys, inv = np.unique(blk, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    sums = np.zeros((keys.shape[0], x.shape[1]))
+    np.add.at(sums, inv, x)
+    cnt = np.bincount(inv, minlength=keys.shape[0]).astype(np.float64)
+    lut = {tuple(k): j for j, k in enumerate(keys.tolist())}
+    tot, den = np.zeros_like(sums), np.zeros(keys.shape[0])
+    for j, k in enumerate(keys.tolist()):
+        for dx in range(lo, hi + 1):
+            for dy in range(lo, hi + 1):
+                for dz in range(lo, hi + 1):
+                    q = lut.get((k[0] + dx, k[1] + dy, k[2] + dz, k[3]))
+                    if q is not None:
+                        tot[j] += sums[q]
+                        den[j] += cnt[q]
+    brute = (tot / den[:, None])[inv]
+    assert rel_err(g["out"], brute) < 2e-6
+
+
 @pytest.mark.parametrize("name", golden_files("g_block_*.npz"))
 def test_block_core_and_grads_vs_reference(name):
     import torch
