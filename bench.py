@@ -41,16 +41,17 @@ def s_uniform(n, grid=256, seed=0):
     return torch.stack([lin % grid, (lin // grid) % grid, lin // (grid * grid), torch.zeros_like(lin)], 1).int()
 
 
-def alg_bytes(n, m, c, parts=2):
+def alg_bytes(n, m, c, parts=2, esz=4):
     """B_alg = N*16 + N*4C + N*4C + 2*M*4*(W+1), and its per-kernel split
-    (each term charged once, to the kernel that must move it)."""
+    (each term charged once, to the kernel that must move it).  esz = bytes per feature element at the
+    boundary (fp16 / bf16 rows: 2C instead of 4C; the block table stays fp32)."""
     w = parts * c
     table = m * 4 * (w + 1)
-    return {"total": n * 16 + 2 * n * 4 * c + 2 * table,
-            "premix_ln": n * 4 * c,
+    return {"total": n * 16 + 2 * n * esz * c + 2 * table,
+            "premix_ln": n * esz * c,
             "modulate_block_sum": n * 16 + table,
             "block_gather": table,
-            "voxel_demod_ln": n * 4 * c}
+            "voxel_demod_ln": n * esz * c}
 
 
 def _cpu_info():
@@ -170,6 +171,8 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--streams", type=int, default=3, help="independent frames in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
+                    help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
     args = ap.parse_args()
 
     import torch
@@ -214,7 +217,8 @@ def main():
     frames, plans, streams = [], [], []
     for k in range(NS):                    # NS distinct frames per rank (seeds differ per rank and slot)
         seed = rank * 64 + k
-        frames.append((torch.randn(N, C, generator=torch.Generator().manual_seed(1 + seed)).to(dev),
+        io_t = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
+        frames.append((torch.randn(N, C, generator=torch.Generator().manual_seed(1 + seed)).to(dev).to(io_t),
                        s_uniform(N, seed=seed).to(dev)))
         pl = la.ElkCorePlan(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
         pl.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
@@ -275,7 +279,8 @@ def main():
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
     b, desc = plan.buf, plan.desc
-    ab = alg_bytes(N, M, C)
+    esz = 4 if args.io == "f32" else 2
+    ab = alg_bytes(N, M, C, esz=esz)
     if plan.dense:
         g = plan.dcg
         # the three launches of one step (index -> pre_mix+modulate+cell sums -> box sum+de-modulate); C = 64
@@ -285,13 +290,13 @@ def main():
             "gather_demod": lambda: lib.link_dc_gather_demod(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, st),
         }
         table = ab["block_gather"]
-        kab = {"index": N * 16, "premix_modsum": N * 4 * C + table, "gather_demod": table + N * 4 * C}
+        kab = {"index": N * 16, "premix_modsum": N * esz * C + table, "gather_demod": table + N * esz * C}
         if C != 64:                                   # other widths: box sum and de-modulation are two kernels
             del stages["gather_demod"], kab["gather_demod"]
             stages["gather"] = lambda: lib.link_dc_gather(b.S, b.cell_n, ctypes.byref(desc), ctypes.byref(g), b.A, st)
             stages["demod"] = lambda: lib.link_dc_demod(b.A, b.fin, coords.data_ptr(), b.vcell, b.w_pos, b.alpha, b.ln_w,
-                                                        b.ln_b, ctypes.byref(desc), ctypes.byref(g), N, b.out, st)
-            kab.update({"gather": table, "demod": N * 4 * C})
+                                                        b.ln_b, ctypes.byref(desc), ctypes.byref(g), N, b.out, 0, st)
+            kab.update({"gather": table, "demod": N * esz * C})
     else:
         grid = plan.grid
         stages = {
@@ -358,15 +363,17 @@ def main():
     #     cores -- on a bounded sample of the same frame; (2) the same code scalar, one core, full frame.
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(blk, feats, coords, out, N, C, S_, R, G)
+        cpu = cpu_baseline(blk, feats.float(), coords, out.float(), N, C, S_, R, G)
 
-    regions = timed_regions(la, blk, feats, coords, C, S_, R) if world == 1 else None
+    regions = timed_regions(la, blk, feats.float(), coords, C, S_, R) if (world == 1 and args.io == "f32") else None
     ms = 1e3 * elapsed / args.steps
     line = {
         "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
         "value": round(total_vox * args.steps / elapsed, 1), "unit": "voxels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.io == "f32" else f"{args.io} rows at the boundary, f32 contraction / block table / statistics",
+        "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: S-uniform 100k voxels in 256^3, C=64, one LinK "
                                "cos:(3x7)^3 block forward (R_core, index rebuilt every step)",
                    "voxels_per_frame": N, "blocks_per_frame": M, "channels": C, "baseop": "cos", "groups": G,

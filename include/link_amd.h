@@ -434,8 +434,11 @@ int64_t link_dc_grid_from(const link_grid_t *grid, int32_t k, link_dc_grid_t *ou
 
 #define LINK_HDR_STATUS_ACC 3   /* status bits being collected by the running step (dense-cell path) */
 
+#define LINK_IO_F32 0
+#define LINK_IO_F16 1
+#define LINK_IO_BF16 2
 typedef struct {
-  const float *feats;        /* fp[N,C] */
+  const void *feats;         /* [N,C] in io_dtype */
   const int32_t *coords;     /* i32[N,4] */
   const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;   /* as link_elk_buffers_t */
   uint32_t *cnt;             /* u32[vp]     voxels per cell; all-zero on entry and on exit (self-cleaning) */
@@ -447,7 +450,13 @@ typedef struct {
   float *fin;                /* fp[N,C] */
   float *S;                  /* fp[(vp+1), P*C] block table, zero-filled once (border rows stay zero) */
   float *A;                  /* fp[(vp+1), P*C] normalised neighbour sums, zero-filled once */
-  float *out;                /* fp[N,C] */
+  void *out;                 /* [N,C] in io_dtype */
+  int32_t io_dtype;          /* LINK_IO_*: type of feats and out at the kernel boundary.  fp16 / bf16 are honoured
+                                by the fused kernels (link_dc_premix_modsum, link_dc_gather_demod, link_dc_demod):
+                                rows are converted on load / store, the contraction, theta, the block table and the
+                                LayerNorm statistics stay fp32 -- the reference's AMP contract (custom_fwd(cast_inputs
+                                = torch.half) on voxelize / devoxelize, nn/functional/voxelize.py:13, devoxelize.py:54,
+                                fp32 accumulation) */
 } link_dc_buffers_t;
 
 int link_dc_premix_insert(const float *feats, const int32_t *coords, const float *w_pre, const float *ln_w,
@@ -472,8 +481,8 @@ int link_dc_premix_modsum(const link_dc_buffers_t *buf /* host */, const link_dc
                           const link_elk_desc_t *desc /* host */, int64_t n, int32_t warm, void *stream);
 int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const int32_t *vcell,
                   const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
-                  const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */, int64_t n, float *out,
-                  void *stream);
+                  const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */, int64_t n, void *out,
+                  int32_t io_dtype, void *stream);
 /*   link_dc_gather_demod   box sum + de-modulate + LayerNorm in ONE kernel (C = 64): the normalised neighbour sums
  *                          of a z-plane live in LDS only and the plane's voxels are dealt out to the workgroup's
  *                          16 lane groups as pairs; neither the A table nor its per-voxel gather exists */

@@ -16,7 +16,8 @@ SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
 LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
-ABI_VERSION = 2
+IO_F32, IO_F16, IO_BF16 = 0, 1, 2
+ABI_VERSION = 3
 
 
 class LinkGrid(Structure):
@@ -66,7 +67,7 @@ class LinkDcBuffers(Structure):
     """link_dc_buffers_t"""
     _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha",
                                         "ln_w", "ln_b", "cnt", "slots", "vrec", "vcell", "cell_n", "hdr", "fin",
-                                        "S", "A", "out")]
+                                        "S", "A", "out")] + [("io_dtype", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
@@ -151,7 +152,8 @@ SIGNATURES = {
     "link_dc_premix_modsum": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64,
                                       c_int32, c_void_p]),
     "link_dc_gather_demod": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64, c_void_p]),
-    "link_dc_demod": (c_int, [c_void_p] * 8 + [POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_int64, c_void_p, c_void_p]),
+    "link_dc_demod": (c_int, [c_void_p] * 8 + [POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_int64, c_void_p, c_int32,
+                              c_void_p]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }

@@ -758,7 +758,8 @@ extern "C" int link_dc_gather_demod(const link_dc_buffers_t *b, const link_dc_gr
                                     int64_t n, void *stream);
 extern "C" int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const int32_t *vcell,
                              const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
-                             const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, float *out, void *stream);
+                             const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, void *out, int32_t io_dtype,
+                             void *stream);
 
 extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const link_dc_grid_t *g,
                                            const link_elk_desc_t *desc, int64_t n, int32_t build_index,
@@ -767,6 +768,7 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
   if (n == 0) return LINK_OK;
   int rc;
   const bool fused = (g_dc_mode & 1) && desc->c <= 64 && g->k <= 352;
+  if (b->io_dtype != LINK_IO_F32 && (!fused || !(g_dc_mode & 2))) return LINK_ERR_ARG;   // half rows: fused kernels only
   if (fused) {
     // index -> fused pre_mix + modulate + per-cell sum -> box gather -> per-voxel de-modulate
     if (build_index) {
@@ -776,7 +778,7 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
     rc = link_dc_premix_modsum(b, g, desc, n, build_index ? 0 : 1, stream);
     if (rc != LINK_OK) return rc;
   } else {
-    rc = link_dc_premix_insert(b->feats, b->coords, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, g,
+    rc = link_dc_premix_insert(reinterpret_cast<const float *>(b->feats), b->coords, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, g,
                                build_index, b->fin, b->cnt, b->slots, b->vrec, b->vcell, b->hdr, stream);
     if (rc != LINK_OK) return rc;
     rc = link_dc_modsum(b->fin, b->slots, b->cnt, b->cell_n, b->w_pos, b->alpha, desc, g, build_index ? 0 : 1, b->S,
@@ -789,8 +791,8 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
   if (rc != LINK_OK) return rc;
   if (g_dc_mode & 2)
     return link_dc_demod(b->A, b->fin, b->coords, b->vcell, b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, g, n, b->out,
-                         stream);
+                         b->io_dtype, stream);
   if (fused && build_index) return LINK_ERR_ARG;       // section C's kernel needs vrec, which only pre_mix+insert writes
   return link_voxel_demod_ln(b->A, b->fin, b->vrec, b->vcell, b->w_pos, b->alpha, b->ln_w, b->ln_b, b->hdr, desc, n,
-                             b->out, stream);
+                             reinterpret_cast<float *>(b->out), stream);
 }

@@ -13,18 +13,34 @@
 //                         is ever idle, whatever the cell sizes), X tile -> LDS -> per-cell sums -> S rows
 //   k_dc_demod            per voxel pair, original order, persistent + software-pipelined: A[cell] row,
 //                         de-modulate, LayerNorm, store
-#include <type_traits>
-
-#include "dense_common.h"
+#define DC_IO 0
+#define DC_IO_NS dcio_f32
+#include "dense_fused_impl.h"
 
 using namespace link;
 
-static int g_k1_wgs = 512;
-static int g_demod_wgs = 1024;
+namespace link {
+int g_k1_wgs = 512;
+int g_demod_wgs = 1024;
+int g_k2_zsplit = 0;
+int g_k2_single = 0;
+unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
+}
 static int g_index_wgs = 0;
-static int g_k2_zsplit = 0;
-static int g_k2_single = 0;
-static unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
+
+// the fp16 / bf16 instantiations live in their own translation units (dense_fused_f16.hip, dense_fused_bf16.hip)
+#define DC_DECL_IO(NS)                                                                                                    \
+  namespace NS {                                                                                                           \
+  int run_premix_modsum(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, bool,        \
+                        hipStream_t);                                                                                      \
+  int run_demod(const float *, const float *, const int32_t *, const int32_t *, const float *, const float *,             \
+                const float *, const float *, const link_elk_desc_t &, const link_dc_grid_t &, int64_t, void *,            \
+                hipStream_t);                                                                                              \
+  int run_gather_demod(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, hipStream_t); \
+  }
+DC_DECL_IO(dcio_f16)
+DC_DECL_IO(dcio_bf16)
+#undef DC_DECL_IO
 
 extern "C" int link_dc_set_debug_buffer(void *p) {
   g_k1_dbg = reinterpret_cast<unsigned long long *>(p);
@@ -83,1005 +99,62 @@ extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_gri
   return check_launch("link_dc_index");
 }
 
-// ---------------------------------------------------------------------------------------------
-// pre_mix + LayerNorm + modulate + per-cell sum
-// ---------------------------------------------------------------------------------------------
-template <int C, int OP>
-struct dc_k1_cfg {
-  static constexpr int T = C / 16;
-  static constexpr int P = op_parts<OP>::value;
-  static constexpr int LDW = C + 4;
-  static constexpr int RB = P * C * 4;                 // bytes of one X / S row
-  static constexpr int XROW = RB + 16;                 // LDS row stride: +4 dwords -> conflict-free b128 writes
-  static constexpr int RGL = P * C / 4;                // lanes holding one row (16 B each)
-  static constexpr int RGS = RGL <= 8 ? 8 : (RGL <= 16 ? 16 : (RGL <= 32 ? 32 : 64));
-  static constexpr int RG = 64 / RGS;                  // rows summed side by side per wave
-  static constexpr int LCAP = 352;                     // records of one cell range kept in LDS (>= 7^3; two workgroups must fit 160 KB)
-  static constexpr int W_BYTES = (C * LDW + 2 * C) * 4;
-  static constexpr int LIST_OFF = 0;
-  static constexpr int SCELL_OFF = LCAP * 16;          // padded cell id of every list slot
-  static constexpr int X_OFF = SCELL_OFF + LCAP * 4;
-  static constexpr int WAVE_BYTES = X_OFF + 16 * XROW;
-  static constexpr int LDS_BYTES = W_BYTES + 4 * WAVE_BYTES;
-};
-
-// NB = number of distinct 16-channel theta blocks of a voxel: channel ch uses theta[ch % cg]; when cg is a
-// multiple of 16 the MFMA channel block tp (channels 16 tp + 4 g + r of lane group g) uses theta block
-// tp % (cg/16), so a lane evaluates 4*NB sincos per voxel instead of 4*T; otherwise NB = T.
-template <int C, int OP, int NB>
-__global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
-    const float *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
-    int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
-    const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
-    float coord_div, float eps, int64_t n, link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_,
-    float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg) {
-  using K = dc_k1_cfg<C, OP>;
-  // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime deltas
-  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_fill = 0, tq_body = 0, tq_sum = 0;
-  int tq_tiles = 0;
-  constexpr int T = K::T, P = K::P, LDW = K::LDW;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *w_lds = reinterpret_cast<float *>(smem_raw);
-  float *ln_lds = w_lds + C * LDW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, gq = lane >> 4;
-  char *wbase = smem_raw + K::W_BYTES + wave * K::WAVE_BYTES;
-  int4 *list = reinterpret_cast<int4 *>(wbase + K::LIST_OFF);
-  int *scell = reinterpret_cast<int *>(wbase + K::SCELL_OFF);
-  char *xbuf = wbase + K::X_OFF;
-  {                                                    // stage W and the LayerNorm parameters
-    // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
-    // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
-    constexpr int NF4 = C * C / 4;                     // float4 pieces of W
-    constexpr int NV = (NF4 + 255) / 256;
-    float4 wv[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int e = (i * 256 + tid) * 4;
-      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[(NF4 % 256 == 0 || e < C * C) ? e : 0]);
-    }
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      int e = (i * 256 + tid) * 4;
-      if (NF4 % 256 != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
-      const int r = e / C, col = e - r * C;
-      *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = (NF4 % 256 == 0 || (i * 256 + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
-    }
-    if (tid < C) ln_lds[tid] = ln_w[tid];
-    else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
-  }
-  if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
-    hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
-    hdr[LINK_HDR_STATUS_ACC] = 0;
-  }
-  __syncthreads();
-  if (dbg) tq1 = __builtin_amdgcn_s_memtime();
-  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
-  const int Vi = Dx * Dy * Dz * g.dim[3];
-  const int wid = blockIdx.x * 4 + wave;
-  const int c_begin = wid * cpw;
-  const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
-  if (c_begin >= c_end) return;
-  const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * K::RB));
-  const __amdgpu_buffer_rsrc_t r_fin = dc_rsrc(fin, (uint32_t)(n * C * 4));     // written for cos_x only
-  const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
-  const __amdgpu_buffer_rsrc_t r_n = dc_rsrc(cell_n, (uint32_t)(g.vp * 4));
-  const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
-  const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
-  // theta weights of this lane's channels
-  float w0[NB][4], w1[NB][4], w2[NB][4], al[NB][4];
-#pragma unroll
-  for (int tb = 0; tb < NB; tb++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int tc = (16 * tb + 4 * gq + r) % cg;
-      w0[tb][r] = w_pos[3 * tc + 0]; w1[tb][r] = w_pos[3 * tc + 1]; w2[tb][r] = w_pos[3 * tc + 2];
-      al[tb][r] = alpha ? alpha[tc] : 1.0f;
-    }
-  const int rl = lane;                                 // lane's 16-byte piece of an X / S row
-  const bool ract = rl < K::RGL;
-
-  for (int chunk = c_begin; chunk < c_end;) {
-    const int nrem = (c_end - chunk < 64) ? c_end - chunk : 64;
-    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    // ---- cell lanes: count, padded cell id, inline records (all requested before anything is consumed) ----
-    int pc = 0, nv = 0;
-    {
-      const int q = chunk + (lane < nrem ? lane : 0);
-      const int z = q % Dz;
-      int t = q / Dz;
-      const int y = t % Dy;
-      t /= Dy;
-      pc = dc_cell(g, t % Dx, y, z, t / Dx);
-    }
-    const int4 r0 = slots[(int64_t)pc * DC_INL + 0], r1 = slots[(int64_t)pc * DC_INL + 1];
-    const int4 r2 = slots[(int64_t)pc * DC_INL + 2], r3 = slots[(int64_t)pc * DC_INL + 3];
-    nv = (int)csrc[pc];
-    nv = nv < g.k ? nv : g.k;
-    nv = nv < K::LCAP ? nv : K::LCAP;
-    if (lane >= nrem) nv = 0;
-    int incl = nv;                                      // inclusive prefix over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    const unsigned long long fit = __ballot(lane < nrem && incl <= K::LCAP);
-    const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
-    const int Ttot = __builtin_amdgcn_readfirstlane(__shfl(incl, nfit - 1, 64));
-    if (lane < nfit) {
-      const int excl = incl - nv;
-      // order the inline records by voxel id: keys id*4+slot through a 5-exchange network
-      int k0 = nv > 0 ? r0.w * 4 + 0 : INT_MAX, k1 = nv > 1 ? r1.w * 4 + 1 : INT_MAX;
-      int k2 = nv > 2 ? r2.w * 4 + 2 : INT_MAX, k3 = nv > 3 ? r3.w * 4 + 3 : INT_MAX;
-      int a, bb;
-      a = min(k0, k1); bb = max(k0, k1); k0 = a; k1 = bb;
-      a = min(k2, k3); bb = max(k2, k3); k2 = a; k3 = bb;
-      a = min(k0, k2); bb = max(k0, k2); k0 = a; k2 = bb;
-      a = min(k1, k3); bb = max(k1, k3); k1 = a; k3 = bb;
-      a = min(k1, k2); bb = max(k1, k2); k1 = a; k2 = bb;
-      const int ks[4] = {k0, k1, k2, k3};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int s = ks[j] & 3;
-        int4 r;
-        r.x = s == 0 ? r0.x : (s == 1 ? r1.x : (s == 2 ? r2.x : r3.x));
-        r.y = s == 0 ? r0.y : (s == 1 ? r1.y : (s == 2 ? r2.y : r3.y));
-        r.z = s == 0 ? r0.z : (s == 1 ? r1.z : (s == 2 ? r2.z : r3.z));
-        r.w = ks[j] >> 2;
-        if (j < nv) { list[excl + j] = r; scell[excl + j] = pc; }
-        // the id-ordered records go back to the slot list: the fused gather+demod walks it and must pair the
-        // same voxels in every run (rank order from the atomics is not reproducible)
-        st16i(r_slots, (j < nv && nv <= DC_INL && !warm) ? ((uint32_t)pc * DC_INL + j) * 16u : DC_OOB, r);
-      }
-      for (int k = DC_INL; k < nv; k++) {               // overflow records: insertion by id (rare)
-        const int4 r = slots[dc_slot(g, pc, k)];
-        scell[excl + k] = pc;
-        int pos = k;
-        while (pos > 0 && list[excl + pos - 1].w > r.w) {
-          list[excl + pos] = list[excl + pos - 1];
-          pos--;
-        }
-        list[excl + pos] = r;
-      }
-      if (nv > DC_INL && !warm)
-        for (int k = 0; k < nv; k++) slots[dc_slot(g, pc, k)] = list[excl + k];
-    }
-    {                                                   // publish the counts, reset the counters
-      const uint32_t coff = (lane < nfit && !warm) ? (uint32_t)pc * 4u : DC_OOB;
-      st4i(r_n, coff, nv);
-      st4i(r_cnt, coff, 0);
-    }
-    for (unsigned long long em = __ballot(lane < nfit && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
-      const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
-      st16(r_S, ract ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_cell += tqb - tqa; tqa = tqb; }
-    // ---- tiles of 16 voxels, software-pipelined: while tile t's accumulators go through LayerNorm /
-    // theta / sincos / modulate on the VALU, the 64 MFMAs of tile t+1 are issued from the same instruction
-    // stream (one basic block: nothing in it depends on them), and the rows of tile t+2 are in flight ----
-    const int ntile = (Ttot + 15) >> 4;
-    const int nloop = ntile;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld_rows = [&](int tile_idx, int4 &rr, float4 (&ff)[T]) {
-      int sl = 16 * tile_idx + li;
-      sl = sl < Ttot ? sl : Ttot - 1;
-      rr = list[sl];
-#pragma unroll
-      for (int tt = 0; tt < T; tt++)
-        ff[tt] = *reinterpret_cast<const float4 *>(&feats[(int64_t)rr.w * C + 16 * tt + 4 * gq]);
-    };
-    auto mfma_tile = [&](const float4 (&ff)[T], floatx4 (&cc)[T]) {
-#pragma unroll
-      for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tt = 0; tt < T; tt++) {
-        float4 a[T];
-#pragma unroll
-        for (int tp = 0; tp < T; tp++)
-          a[tp] = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * tt + 4 * gq]);
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].x, ff[tt].x, cc[tp], 0, 0, 0);
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].y, ff[tt].y, cc[tp], 0, 0, 0);
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].z, ff[tt].z, cc[tp], 0, 0, 0);
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].w, ff[tt].w, cc[tp], 0, 0, 0);
-      }
-    };
-    // Two register sets (A/B) for the records, rows and accumulators, used alternately by the two halves of
-    // the unrolled loop: nothing is ever copied, so no instruction of a step waits for the loads it issued.
-    int4 recA = make_int4(0, 0, 0, 0), recB = recA, recC = recA;
-    float4 fA[T], fB[T];
-    floatx4 acA[T], acB[T];
-    if (ntile > 0) {                                    // pipeline fill: tile 0 multiplied, tile 1 requested
-      ld_rows(0, recA, fB);
-      ld_rows(ntile > 1 ? 1 : 0, recB, fA);
-      mfma_tile(fB, acA);
-    }
-    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_fill += tqb - tqa; tqa = tqb; }
-    // step t: finishes tile t (record rec, accumulators ac), multiplies tile t+1 (record recn, rows fn) into
-    // acn, requests tile t+2 (record rec2, rows f2)
-    auto step = [&](int t, const int4 &rec, const int4 &recn, int4 &rec2, const float4 (&fn)[T], float4 (&f2)[T],
-                    const floatx4 (&ac)[T], floatx4 (&acn)[T]) {
-      if (ntile > 0) {
-        const int slot = 16 * t + li;
-        // theta of this voxel's blocks; a wave whose arguments all sit below 2^15 takes the branch-free body
-        float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
-        if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
-        float th[NB][4];
-        bool big = false;
-#pragma unroll
-        for (int tb = 0; tb < NB; tb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            th[tb][r] = theta_of(x, y, z, w0[tb][r], w1[tb][r], w2[tb][r], al[tb][r]);
-            big |= !(fabsf(th[tb][r]) < 32768.0f);
-          }
-        const bool slow = __any(big);
-        const bool more = t + 1 < ntile;
-        (void)recn;
-        auto body = [&](auto more_tag, auto slow_tag) {
-          constexpr bool MORE = decltype(more_tag)::value, SLOW = decltype(slow_tag)::value;
-          if constexpr (MORE) mfma_tile(fn, acn);
-          if constexpr (MORE) ld_rows(t + 2 < ntile ? t + 2 : t + 1, rec2, f2);
-          float sn[NB][4], cs[NB][4];
-#pragma unroll
-          for (int tb = 0; tb < NB; tb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              if constexpr (SLOW) sincos_nocall(th[tb][r], sn[tb][r], cs[tb][r]);
-              else sincos_small(th[tb][r], sn[tb][r], cs[tb][r]);
-            }
-          // LayerNorm over the voxel's C channels: 16 in-lane values + the 4 lane groups
-          float s = 0.f;
-#pragma unroll
-          for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
-          const float mean = s * (1.0f / C);
-          float qq = 0.f;
-#pragma unroll
-          for (int tp = 0; tp < T; tp++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const float d = ac[tp][r] - mean;
-              qq += d * d;
-            }
-          qq += __shfl_xor(qq, 16, 64);
-          qq += __shfl_xor(qq, 32, 64);
-          const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
-#pragma unroll
-          for (int tp = 0; tp < T; tp++) {
-            const float4 lw = *reinterpret_cast<const float4 *>(&ln_lds[16 * tp + 4 * gq]);
-            const float4 lb = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * tp + 4 * gq]);
-            const float fv[4] = {(ac[tp][0] - mean) * rstd * lw.x + lb.x, (ac[tp][1] - mean) * rstd * lw.y + lb.y,
-                                 (ac[tp][2] - mean) * rstd * lw.z + lb.z, (ac[tp][3] - mean) * rstd * lw.w + lb.w};
-            if (OP == LINK_OP_COSX)                     // the de-modulation of cos_x needs fin (linkunet.py:176)
-              st16(r_fin, slot < Ttot ? (uint32_t)rec.w * (uint32_t)(C * 4) + (uint32_t)((16 * tp + 4 * gq) * 4) : DC_OOB,
-                   make_float4(fv[0], fv[1], fv[2], fv[3]));
-            const int tb = tp % NB;
-            float p0[4], p1[4], p2[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              if (OP == LINK_OP_SIN) { p0[r] = fv[r] * sn[tb][r]; p1[r] = fv[r] * cs[tb][r]; }
-              else { p0[r] = fv[r] * cs[tb][r]; p1[r] = fv[r] * sn[tb][r]; }
-              p2[r] = fv[r] * th[tb][r];
-            }
-            char *xr = xbuf + li * K::XROW + (16 * tp + 4 * gq) * 4;
-            *reinterpret_cast<float4 *>(xr) = make_float4(p0[0], p0[1], p0[2], p0[3]);
-            *reinterpret_cast<float4 *>(xr + C * 4) = make_float4(p1[0], p1[1], p1[2], p1[3]);
-            if (P == 3) *reinterpret_cast<float4 *>(xr + 2 * C * 4) = make_float4(p2[0], p2[1], p2[2], p2[3]);
-          }
-          if constexpr (MORE && !SLOW) {
-#pragma unroll
-            for (int i = 0; i < T * T * 4; i++) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // six VALU
-            }
-          }
-        };
-        if (__builtin_expect(slow, 0)) {                // never on sane inputs: no overlap, smallest code
-          if (more) {
-            mfma_tile(fn, acn);
-            ld_rows(t + 2 < ntile ? t + 2 : t + 1, rec2, f2);
-          }
-          body(std::false_type{}, std::true_type{});
-        } else {
-          if (more) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{});
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_body += tqb - tqa; tqa = tqb; tq_tiles++; }
-      // ---- per-cell sums of this tile: ONE stream over the 16 rows in slot order (ascending voxel id inside a
-      // cell), every lane owning 16 bytes of the row; a row that closes its cell (the next slot belongs to
-      // another cell) is followed by the cell's S row store.  All rows are requested up front, the close
-      // flags are a 16-bit ballot, the closing cell's id comes by v_readlane: no dependent LDS round trips. ----
-      {
-        const int slot = 16 * t + li;
-        const int myc = slot < Ttot ? scell[slot] : -1;
-        const int nxc = slot + 1 < Ttot ? scell[slot + 1] : -2;
-        const unsigned closes = (unsigned)__ballot(gq == 0 && slot < Ttot && myc != nxc);
-        const char *xrow = xbuf + (ract ? rl : 0) * 16;
-#pragma unroll
-        for (int h = 0; h < 16; h += 8) {
-          float4 v[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const float4 *>(xrow + (h + k) * K::XROW);
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            if (16 * t + h + k < Ttot) {                // wave-uniform
-              acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w;
-              if ((closes >> (h + k)) & 1u) {           // wave-uniform
-                const int pcs = __builtin_amdgcn_readlane(myc, h + k);
-                st16(r_S, ract ? (uint32_t)pcs * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, acc);
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-              }
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_sum += tqb - tqa; tqa = tqb; }
-    };
-    // rows of tile t+1 sit in fA for even t and fB for odd t, accumulators of tile t in acA / acB likewise;
-    // the three records rotate by plain copies (they come from LDS: no VMEM wait is involved)
-    for (int t = 0; t < nloop; t += 2) {
-      step(t, recA, recB, recC, fA, fB, acA, acB);
-      recA = recB; recB = recC;
-      if (t + 1 < nloop) {
-        step(t + 1, recA, recB, recC, fB, fA, acB, acA);
-        recA = recB; recB = recC;
-      }
-    }
-    chunk += nfit;
-  }
-  if (dbg && lane == 0) {
-    unsigned long long *d = dbg + (size_t)wid * 8;
-    const unsigned long long te = __builtin_amdgcn_s_memtime();
-    d[0] = tq1 - tq0; d[1] = tq_cell; d[2] = tq_fill; d[3] = tq_body; d[4] = tq_sum; d[5] = te - tq0; d[6] = tq_tiles; d[7] = tq0;
-  }
-}
-
-template <int C, int OP, int NB>
-static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                     bool warm, hipStream_t st) {
-  using K = dc_k1_cfg<C, OP>;
-  const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
-  int64_t waves = (int64_t)g_k1_wgs * 4;
-  int cpw = (int)((vi + waves - 1) / waves);
-  if (cpw < 1) cpw = 1;
-  const int64_t wgs = (vi + (int64_t)cpw * 4 - 1) / ((int64_t)cpw * 4);
-  if (K::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB>), dim3((unsigned)wgs), dim3(256), K::LDS_BYTES, st, b->feats,
-                     reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
-                     b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr, g_k1_dbg);
-  return check_launch("link_dc_premix_modsum");
-}
-
-template <int C, int OP>
-static int dispatch_k1_nb(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                          bool warm, hipStream_t st) {
-  constexpr int T = C / 16;
-  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
-  if (nb > T) nb = T;
-  if (nb == T) return launch_k1<C, OP, T>(b, g, d, n, warm, st);
-  if (T >= 2 && nb == T / 2) return launch_k1<C, OP, (T >= 2 ? T / 2 : 1)>(b, g, d, n, warm, st);
-  if (T >= 4 && nb == T / 4) return launch_k1<C, OP, (T >= 4 ? T / 4 : 1)>(b, g, d, n, warm, st);
-  return launch_k1<C, OP, T>(b, g, d, n, warm, st);    // any other grouping: every block evaluates its own theta
-}
-
-template <int C>
-static int dispatch_k1_op(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                          bool warm, hipStream_t st) {
-  switch (d.op) {
-    case LINK_OP_COS: return dispatch_k1_nb<C, LINK_OP_COS>(b, g, d, n, warm, st);
-    case LINK_OP_SIN: return dispatch_k1_nb<C, LINK_OP_SIN>(b, g, d, n, warm, st);
-    default: return dispatch_k1_nb<C, LINK_OP_COSX>(b, g, d, n, warm, st);
-  }
+static int dc_common_ok(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d, int64_t n) {
+  if (!b || !g || !d || n < 0) return LINK_ERR_ARG;
+  if (b->io_dtype < 0 || b->io_dtype > 2) return LINK_ERR_ARG;
+  if (d->op < 0 || d->op > 2 || d->cg <= 0 || d->c % d->cg != 0 || g->k < DC_INL) return LINK_ERR_ARG;
+  const int parts = d->op == LINK_OP_COSX ? 3 : 2;
+  if ((g->vp + 1) * (int64_t)parts * d->c * 4 >= (1LL << 32) || g->vp * (int64_t)g->k * 16 >= (1LL << 32)) return LINK_ERR_ARG;
+  if (n * (int64_t)d->c * 4 >= (1LL << 32)) return LINK_ERR_ARG;
+  return LINK_OK;
 }
 
 extern "C" int link_dc_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d,
                                      int64_t n, int32_t warm, void *stream) {
-  if (!b || !g || !d || n < 0) return LINK_ERR_ARG;
+  if (dc_common_ok(b, g, d, n) != LINK_OK) return LINK_ERR_ARG;
   if (d->c != 16 && d->c != 32 && d->c != 64) return LINK_ERR_ARG;
-  if (d->op < 0 || d->op > 2 || d->cg <= 0 || d->c % d->cg != 0 || g->k < DC_INL) return LINK_ERR_ARG;
   if (g->k > 352) return LINK_ERR_ARG;                 // a cell's records must fit the wave's LDS list (LCAP)
-  if (n * (int64_t)d->c * 4 >= (1LL << 32) || (d->op == LINK_OP_COSX && !b->fin)) return LINK_ERR_ARG;
-  const int parts = d->op == LINK_OP_COSX ? 3 : 2;
-  if ((g->vp + 1) * (int64_t)parts * d->c * 4 >= (1LL << 32) || g->vp * (int64_t)g->k * 16 >= (1LL << 32)) return LINK_ERR_ARG;
+  if (d->op == LINK_OP_COSX && !b->fin) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   if (!b->feats || !b->slots || !b->cnt || !b->cell_n || !b->w_pre || !b->pre_ln_w || !b->pre_ln_b || !b->w_pos ||
       !b->S || !b->hdr)
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  switch (d->c) {
-    case 16: return dispatch_k1_op<16>(b, *g, *d, n, warm != 0, st);
-    case 32: return dispatch_k1_op<32>(b, *g, *d, n, warm != 0, st);
-    default: return dispatch_k1_op<64>(b, *g, *d, n, warm != 0, st);
+  switch (b->io_dtype) {
+    case 1: return dcio_f16::run_premix_modsum(b, *g, *d, n, warm != 0, st);
+    case 2: return dcio_bf16::run_premix_modsum(b, *g, *d, n, warm != 0, st);
+    default: return dcio_f32::run_premix_modsum(b, *g, *d, n, warm != 0, st);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-voxel de-modulate + LayerNorm, original voxel order
-// ---------------------------------------------------------------------------------------------
-// A group of LPR lanes (row of C floats = LPR x float4) per voxel PAIR (2p, 2p+1); a group walks pairs p,
-// p + #groups, ... as a three-stage pipeline -- meta(p+2): the two coordinate rows and cell ids; rows(p+1):
-// the two A rows (buffer loads, 32-bit offsets); out(p): theta / sincos (shared between channels j and
-// j + C/2 when PAIR) / de-modulate / LayerNorm / store.  All parameters live in registers for the whole
-// kernel; invalid lanes store to an out-of-range offset.
-template <int LPR, int OP, bool PAIR, bool DIV>
-__global__ void __launch_bounds__(256) k_dc_demod(const float *__restrict__ A_, const float *__restrict__ fin,
-                                                  const int4 *__restrict__ coords, const int32_t *__restrict__ vcell,
-                                                  const float *__restrict__ w_pos, const float *__restrict__ alpha,
-                                                  const float *__restrict__ ln_w, const float *__restrict__ ln_b, int c,
-                                                  int cg, float coord_div, float eps, int64_t n, int64_t a_rows,
-                                                  float *__restrict__ out) {
-  constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
-  constexpr int G = 64 / LPR;
-  const int lane = threadIdx.x & 63;
-  const int li = lane & (LPR - 1);
-  const int ch0 = 4 * li;
-  const bool hi = PAIR && (li >= LPR / 2);
-  const int ra = P * c * 4;                            // A row bytes
-  const __amdgpu_buffer_rsrc_t r_A = dc_rsrc(A_, (uint32_t)(a_rows * ra));
-  const __amdgpu_buffer_rsrc_t r_fin = dc_rsrc(fin, (uint32_t)(n * c * 4));
-  const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * c * 4));
-  float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int ch = ch0 + e, tc = ch % cg;
-    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
-    al[e] = alpha ? alpha[tc] : 1.0f;
-    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
-  }
-  const float inv_c = 1.0f / (float)c;
-  const int64_t npair = (n + 1) >> 1;
-  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
-  int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
-  if (p >= npair) return;
-  auto ld_meta = [&](int64_t pp, int4 &ca, int4 &cb, int &va, int &vb) {
-    const int64_t q = pp < npair ? pp : npair - 1;
-    const int64_t ia = 2 * q, ib = (2 * q + 1 < n) ? 2 * q + 1 : 2 * q;
-    ca = coords[ia]; cb = coords[ib];
-    va = vcell[ia]; vb = vcell[ib];
-  };
-  auto ld_rows = [&](int va, int vb, v4i_t (&ra_)[P], v4i_t (&rb_)[P]) {
-#pragma unroll
-    for (int pp = 0; pp < P; pp++) {
-      ra_[pp] = __builtin_amdgcn_raw_buffer_load_b128(r_A, (uint32_t)va * (uint32_t)ra + (uint32_t)((pp * c + ch0) * 4), 0, 0);
-      rb_[pp] = __builtin_amdgcn_raw_buffer_load_b128(r_A, (uint32_t)vb * (uint32_t)ra + (uint32_t)((pp * c + ch0) * 4), 0, 0);
-    }
-  };
-  int4 c0a, c0b, c1a, c1b;
-  int v0a, v0b, v1a, v1b;
-  // NOTE: elements of these vectors are converted with __int_as_float (by value); __builtin_bit_cast on a
-  // vector-element lvalue reads element 0 whatever the index (clang, ROCm 7.2)
-  v4i_t a0[P], b0[P];
-  ld_meta(p, c0a, c0b, v0a, v0b);
-  ld_rows(v0a, v0b, a0, b0);
-  ld_meta(p + ngroups, c1a, c1b, v1a, v1b);
-  for (; p < npair; p += ngroups) {
-    v4i_t a1[P], b1[P];
-    ld_rows(v1a, v1b, a1, b1);
-    int4 c2a, c2b;
-    int v2a, v2b;
-    ld_meta(p + 2 * ngroups, c2a, c2b, v2a, v2b);
-    const bool hasB = 2 * p + 1 < n;
-    v4i_t fx = {0, 0, 0, 0}, fy = {0, 0, 0, 0};
-    if (OP == LINK_OP_COSX) {
-      fx = __builtin_amdgcn_raw_buffer_load_b128(r_fin, (uint32_t)(2 * p) * (uint32_t)(c * 4) + (uint32_t)(ch0 * 4), 0, 0);
-      fy = __builtin_amdgcn_raw_buffer_load_b128(r_fin, hasB ? (uint32_t)(2 * p + 1) * (uint32_t)(c * 4) + (uint32_t)(ch0 * 4) : DC_OOB, 0, 0);
-    }
-    float nvA[4], nvB[4], sA = 0.f, sB = 0.f;
-    // theta first; a wave whose arguments all sit below 2^15 (always, on sane inputs) evaluates the branch-free
-    // float sincos -- left as one `if` inside sincos_nocall, hipcc if-converts the double-precision path and
-    // executes its f64 instructions on every iteration
-    float thA[4], thB[4];
-    bool big = false;
-    {
-      const bool swapped = PAIR && hi && hasB;
-      float xa = (float)(swapped ? c0b.x : c0a.x), ya = (float)(swapped ? c0b.y : c0a.y), za = (float)(swapped ? c0b.z : c0a.z);
-      float xb = (float)c0b.x, yb = (float)c0b.y, zb = (float)c0b.z;
-      if (DIV) { xa = xa / coord_div; ya = ya / coord_div; za = za / coord_div; xb = xb / coord_div; yb = yb / coord_div; zb = zb / coord_div; }
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        thA[e] = theta_of(xa, ya, za, w0[e], w1[e], w2[e], al[e]);
-        thB[e] = PAIR ? thA[e] : theta_of(xb, yb, zb, w0[e], w1[e], w2[e], al[e]);
-        big |= !(fabsf(thA[e]) < 32768.0f) || !(fabsf(thB[e]) < 32768.0f);
-      }
-    }
-    float snA[4], csA[4], snB[4], csB[4];
-    if (__builtin_expect(__any(big), 0)) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        sincos_nocall(thA[e], snA[e], csA[e]);
-        if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_nocall(thB[e], snB[e], csB[e]);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        sincos_small(thA[e], snA[e], csA[e]);
-        if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_small(thB[e], snB[e], csB[e]);
-      }
-    }
-    if (PAIR) {                                        // this lane evaluated ONE voxel's theta: swap with the partner half
-      const bool swapped = hi && hasB;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const float sn = snA[e], cs = csA[e];
-        const float so = partner<LPR>(sn), co = partner<LPR>(cs);
-        snA[e] = swapped ? so : sn; csA[e] = swapped ? co : cs;
-        snB[e] = hi ? sn : so;      csB[e] = hi ? cs : co;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const float A0 = __int_as_float(a0[0][e]), A1 = __int_as_float(a0[1][e]);
-      const float B0 = __int_as_float(b0[0][e]), B1 = __int_as_float(b0[1][e]);
-      if (OP == LINK_OP_SIN) {                                                   // linkunet.py:148
-        nvA[e] = __fsub_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
-        nvB[e] = __fsub_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
-      } else {                                                                   // :162
-        nvA[e] = __fadd_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
-        nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
-      }
-      if (OP == LINK_OP_COSX) {                                                  // :176
-        nvA[e] = __fadd_rn(nvA[e], __fsub_rn(__int_as_float(a0[P - 1][e]), __fmul_rn(__int_as_float(fx[e]), thA[e])));
-        nvB[e] = __fadd_rn(nvB[e], __fsub_rn(__int_as_float(b0[P - 1][e]), __fmul_rn(__int_as_float(fy[e]), thB[e])));
-      }
-      sA += nvA[e]; sB += nvB[e];
-    }
-    sA = grp_sum<LPR>(sA);
-    sB = grp_sum<LPR>(sB);
-    const float meanA = sA * inv_c, meanB = sB * inv_c;
-    float qA = 0.f, qB = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const float dA = nvA[e] - meanA, dB = nvB[e] - meanB;
-      qA += dA * dA; qB += dB * dB;
-    }
-    qA = grp_sum<LPR>(qA);
-    qB = grp_sum<LPR>(qB);
-    const float rsA = __builtin_amdgcn_rsqf(qA * inv_c + eps), rsB = __builtin_amdgcn_rsqf(qB * inv_c + eps);
-    float4 oa, ob;
-    oa.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0]; oa.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
-    oa.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2]; oa.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
-    ob.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0]; ob.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
-    ob.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2]; ob.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
-    const uint32_t offA = (uint32_t)(2 * p) * (uint32_t)(c * 4) + (uint32_t)(ch0 * 4);
-    st16(r_out, offA, oa);
-    st16(r_out, hasB ? offA + (uint32_t)(c * 4) : DC_OOB, ob);
-    c0a = c1a; c0b = c1b; v0a = v1a; v0b = v1b;
-    c1a = c2a; c1b = c2b; v1a = v2a; v1b = v2b;
-#pragma unroll
-    for (int pp = 0; pp < P; pp++) { a0[pp] = a1[pp]; b0[pp] = b1[pp]; }
-  }
-}
-
-template <int LPR>
-static void launch_dc_demod(const link_elk_desc_t &d, int64_t n, int64_t a_rows, hipStream_t st, const float *A,
-                            const float *fin, const int32_t *coords, const int32_t *vcell, const float *w_pos,
-                            const float *alpha, const float *ln_w, const float *ln_b, float *out) {
-  constexpr int G = 64 / LPR;
-  const int64_t npair = (n + 1) / 2;
-  int64_t wgs = (npair + 4 * G - 1) / (4 * G);
-  if (wgs > g_demod_wgs) wgs = g_demod_wgs;
-  const bool two_part = d.op == LINK_OP_COS || d.op == LINK_OP_SIN;
-  const bool pair = LPR >= 2 && d.c == 2 * d.cg && two_part;
-  const int4 *co = reinterpret_cast<const int4 *>(coords);
-#define LINK_DCDM2(OPP, PP, DD)                                                                                             \
-  hipLaunchKernelGGL((k_dc_demod<LPR, OPP, PP, DD>), dim3((unsigned)wgs), dim3(256), 0, st, A, fin, co, vcell, w_pos, alpha, \
-                     ln_w, ln_b, d.c, d.cg, d.coord_div, d.eps, n, a_rows, out)
-#define LINK_DCDM(OPP, PP)                                        \
-  do {                                                            \
-    if (d.coord_div != 1.0f) LINK_DCDM2(OPP, PP, true);           \
-    else LINK_DCDM2(OPP, PP, false);                              \
-  } while (0)
-  switch (d.op) {
-    case LINK_OP_COS: if (pair) LINK_DCDM(LINK_OP_COS, true); else LINK_DCDM(LINK_OP_COS, false); break;
-    case LINK_OP_SIN: if (pair) LINK_DCDM(LINK_OP_SIN, true); else LINK_DCDM(LINK_OP_SIN, false); break;
-    default: LINK_DCDM(LINK_OP_COSX, false); break;
-  }
-#undef LINK_DCDM
-#undef LINK_DCDM2
 }
 
 extern "C" int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const int32_t *vcell,
                              const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
-                             const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, float *out, void *stream) {
+                             const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, void *out, int32_t io_dtype,
+                             void *stream) {
   if (!d || !g || n < 0 || !dc_width_ok(d->c) || d->op < 0 || d->op > 2 || d->cg <= 0 || d->c % d->cg != 0) return LINK_ERR_ARG;
+  if (io_dtype < 0 || io_dtype > 2) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   if (!A || !coords || !vcell || !w_pos || !ln_w || !ln_b || !out || (d->op == LINK_OP_COSX && !fin)) return LINK_ERR_ARG;
   const int parts = d->op == LINK_OP_COSX ? 3 : 2;
   if ((g->vp + 1) * (int64_t)parts * d->c * 4 >= (1LL << 32) || n * (int64_t)d->c * 4 >= (1LL << 32)) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  switch (d->c) {
-    case 16: launch_dc_demod<4>(*d, n, g->vp + 1, st, A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, out); break;
-    case 32: launch_dc_demod<8>(*d, n, g->vp + 1, st, A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, out); break;
-    case 64: launch_dc_demod<16>(*d, n, g->vp + 1, st, A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, out); break;
-    default: launch_dc_demod<32>(*d, n, g->vp + 1, st, A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, out); break;
+  switch (io_dtype) {
+    case 1: return dcio_f16::run_demod(A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, *d, *g, n, out, st);
+    case 2: return dcio_bf16::run_demod(A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, *d, *g, n, out, st);
+    default: return dcio_f32::run_demod(A, fin, coords, vcell, w_pos, alpha, ln_w, ln_b, *d, *g, n, out, st);
   }
-  return check_launch("link_dc_demod");
-}
-
-// ---------------------------------------------------------------------------------------------
-// r^3 box sum + per-voxel de-modulate + LayerNorm in one kernel (C = 64)
-// ---------------------------------------------------------------------------------------------
-// Counters on cfg2: k_dc_gather and k_dc_demod each move ~75 MB (the A table written, then gathered row by
-// row per voxel) and run at memory speed.  Fused, the A rows live for one z-plane in LDS: the workgroup's 16
-// groups (4 x 4 columns, dense.hip's plane ring unchanged) put their normalised neighbour sums into an 8 KB
-// LDS image, and the plane's voxels -- about 32, whatever their distribution over the 16 cells -- are dealt
-// out to the 16 groups as PAIRS: pair p = voxels 2p, 2p+1 of the plane's concatenated slot lists.  A voxel
-// finds its cell by a 16-lane ballot against the row-scanned counts (lane li of every DPP row holds cell
-// li), its record and A row come from LDS (the inline slot records of the plane's cells travel with the
-// plane by LDS-DMA).  Every LDS access is inline asm (dense_gather.h explains why); out rows leave through
-// buffer stores, whose unknown number the plane ring's counted wait tolerates by construction.
-#include "dense_gather.h"
-
-template <int OP, int R>
-struct dc_k2_cfg {
-  static constexpr int C = 64, LPR = 16, NG = 16;
-  static constexpr int P = (OP == LINK_OP_COSX) ? 3 : 2;
-  using G = dc_gather_cfg<C, P, R>;
-  static constexpr int RB = P * C * 4;
-  static constexpr int REC_OFF = G::PLANE_BYTES + G::CNT_BYTES;
-  static constexpr int REC_BYTES = NG * DC_INL * 16;
-  static constexpr int BUF_BYTES = REC_OFF + REC_BYTES;
-  static constexpr int ABUF_OFF = 3 * BUF_BYTES;
-  static constexpr int NCNT_OFF = ABUF_OFF + NG * RB;
-  static constexpr int LDS_BYTES = NCNT_OFF + NG * 4;
-  static constexpr int NI = G::PASSES + 2;            // DMA instructions per plane and wave
-  static_assert(G::NG == NG && G::TX * G::TY == NG, "16 columns");
-};
-
-__device__ __forceinline__ void lds_rd2_b128(uint32_t a0, uint32_t a1, v4f_t &x0, v4f_t &x1) {
-  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1) : "memory");
-}
-__device__ __forceinline__ int lds_rd_b32(uint32_t a) {
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_wr_b128(uint32_t a, float4 v) {
-  const v4f_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(x) : "memory");
-}
-__device__ __forceinline__ void lds_wr_b32(uint32_t a, int v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
-
-template <int OP, int R, bool PAIR, bool DIV>
-__global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
-    const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
-    const float *__restrict__ fin, const float *__restrict__ w_pos, const float *__restrict__ alpha,
-    const float *__restrict__ ln_w, const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n,
-    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, float *__restrict__ out, int single) {
-  using K2 = dc_k2_cfg<OP, R>;
-  using K = typename K2::G;
-  constexpr int C = 64, P = K2::P, LPR = 16, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
-  constexpr int RB = P * C * 4;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int per = (nwg + 7) >> 3;
-  const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (L >= nwg) return;
-  int t = L;
-  const int zseg = t % zsplit; t /= zsplit;
-  const int ty = t % tyn; t /= tyn;
-  const int tx = t % txn;
-  const int b = t / txn;
-  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
-  const int PDx = g.pdim[0], PDy = g.pdim[1], PDz = g.pdim[2];
-  const int x0 = tx * TX, y0 = ty * TY;
-  const int zs = (int)(((long long)Dz * zseg) / zsplit), ze = (int)(((long long)Dz * (zseg + 1)) / zsplit);
-  if (zs >= ze) return;
-  const int nplanes = (ze - zs) + R - 1;
-  const int pz0 = zs + 1 - HLO;
-  auto col_cell0 = [&](int hx, int hy) {             // padded cell id of (haloed column, z = 0), clamped into the grid
-    int px = x0 + 1 - HLO + hx, py = y0 + 1 - HLO + hy;
-    px = px < PDx - 1 ? px : PDx - 1;
-    py = py < PDy - 1 ? py : PDy - 1;
-    return (uint32_t)(((b * PDx + px) * PDy + py) * PDz);
-  };
-  uint32_t src_off[K::PASSES];
-#pragma unroll
-  for (int i = 0; i < K::PASSES; i++) {
-    int pid = i * 256 + tid;
-    if (pid >= K::NPC) pid = K::NPC - 1;
-    const int col = pid / K::RP, pcs = pid % K::RP;
-    src_off[i] = col_cell0(col / HY, col % HY) * (uint32_t)RB + (uint32_t)pcs * 16u;
-  }
-  uint32_t cnt_cell0;
-  {
-    int e = wave * 64 + lane;
-    if (e >= K::NCOL) e = K::NCOL - 1;
-    cnt_cell0 = col_cell0(e / HY, e % HY);
-  }
-  // inline slot records of the 16 interior cells of an output plane: wave w, lane l < 16 -> piece w*16 + l
-  uint32_t rec_cell0;
-  int rec_k;
-  {
-    const int piece = wave * 16 + (lane & 15);
-    const int col = piece >> 2;
-    rec_k = piece & 3;
-    rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
-  }
-  const char *Sb = reinterpret_cast<const char *>(S_);
-  auto issue = [&](int plane) {
-    int pz = pz0 + plane;
-    pz = pz < PDz - 1 ? pz : PDz - 1;
-    char *buf = lds + (plane % 3) * K2::BUF_BYTES;
-#pragma unroll
-    for (int i = 0; i < K::PASSES; i++) {
-      const char *src = Sb + (size_t)src_off[i] + (size_t)pz * RB;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(buf + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
-    const int32_t *csrc = cell_n + cnt_cell0 + pz;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
-                                     (__attribute__((address_space(3))) void *)(buf + K::PLANE_BYTES + wave * 256), 4, 0, 0);
-    int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
-    po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
-    const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
-    if (lane < 16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rsrc,
-                                       (__attribute__((address_space(3))) void *)(buf + K2::REC_OFF + wave * 256), 16, 0, 0);
-  };
-  // ---- this group's column ----
-  const int grp = tid >> 4, li = tid & 15;
-  const int ix = grp / TY, iy = grp % TY;
-  const bool col_ok = (x0 + ix < Dx) && (y0 + iy < Dy);
-  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)lds;
-  const uint32_t row_lane = (uint32_t)((ix * HY + iy) * RB + li * 16);
-  const uint32_t cnt_lane = (uint32_t)((ix * HY + iy) * 4);
-  const uint32_t abuf = lds_base + K2::ABUF_OFF, ncnt = lds_base + K2::NCNT_OFF;
-  const int rowbase = lane & ~15;                      // first lane of this group's DPP row
-  const int ch0 = 4 * li;
-  const bool hi = PAIR && li >= 8;
-  const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * C * 4));
-  float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int ch = ch0 + e, tc = ch % cg;
-    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
-    al[e] = alpha ? alpha[tc] : 1.0f;
-    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
-  }
-  float4 r0[P], r1[P];
-  float c0 = 0.f, c1 = 0.f;
-  int n_prev = 0;                                      // voxels in this group's cell of the previous plane
-#pragma unroll
-  for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-  issue(0);
-  if (nplanes > 1) issue(1);
-  for (int i = 0; i < nplanes; i++) {
-    if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");
-    if (i + 2 < nplanes) issue(i + 2);
-    const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::BUF_BYTES);
-    float4 cur[P];
-    float cc = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K::PLANE_BYTES + cnt_lane;
-      dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
-      dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
-      if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
-    }
-    const int n_here = lds_rd_b32(bufa + (uint32_t)K::PLANE_BYTES + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
-    if (i >= R - 1) {
-      const int po = pz0 + i - (R - 1) + HLO;
-      float4 a[P];
-      float den;
-      if (R == 3) {
-        den = (c0 + c1) + cc;
-#pragma unroll
-        for (int pp = 0; pp < P; pp++) {
-          a[pp].x = (r0[pp].x + r1[pp].x) + cur[pp].x; a[pp].y = (r0[pp].y + r1[pp].y) + cur[pp].y;
-          a[pp].z = (r0[pp].z + r1[pp].z) + cur[pp].z; a[pp].w = (r0[pp].w + r1[pp].w) + cur[pp].w;
-        }
-      } else {
-        den = c1 + cc;
-#pragma unroll
-        for (int pp = 0; pp < P; pp++) {
-          a[pp].x = r1[pp].x + cur[pp].x; a[pp].y = r1[pp].y + cur[pp].y;
-          a[pp].z = r1[pp].z + cur[pp].z; a[pp].w = r1[pp].w + cur[pp].w;
-        }
-      }
-      const float inv = den > 0.f ? 1.0f / den : 0.f;
-      // ---- A rows + counts of the plane's 16 cells -> LDS ----
-#pragma unroll
-      for (int pp = 0; pp < P; pp++)
-        lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
-                    make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
-      const int n_cell = (R == 3) ? n_prev : n_prev;   // the plane that closed is the previous one for both R
-      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_cell : 0);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // ---- deal the plane's voxels out as pairs ----
-      const int nli = lds_rd_b32(ncnt + (uint32_t)(li * 4));          // lane li of every row: cell li
-      int incl = nli;
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
-      const int Tv = __shfl(incl, rowbase + 15, 64);
-      const int npair = single ? Tv : (Tv + 1) >> 1;
-      const uint32_t recb = lds_base + (uint32_t)(((i % 3) * K2::BUF_BYTES) + K2::REC_OFF);
-      for (int p = grp; p < npair; p += 16) {
-        const int vA = single ? p : 2 * p, vB = (!single && 2 * p + 1 < Tv) ? 2 * p + 1 : vA;
-        const bool hasB = !single && 2 * p + 1 < Tv;
-        const unsigned long long mA = __ballot(incl <= vA), mB = __ballot(incl <= vB);
-        const int cA = __popc((unsigned)(mA >> rowbase) & 0xFFFFu), cB = __popc((unsigned)(mB >> rowbase) & 0xFFFFu);
-        const int eA = cA ? __shfl(incl, rowbase + cA - 1, 64) : 0, eB = cB ? __shfl(incl, rowbase + cB - 1, 64) : 0;
-        const int kA = vA - eA, kB = vB - eB;
-        v4f_t qa, qb;
-        lds_rd2_b128(recb + (uint32_t)((cA * DC_INL + (kA < DC_INL ? kA : 0)) * 16),
-                     recb + (uint32_t)((cB * DC_INL + (kB < DC_INL ? kB : 0)) * 16), qa, qb);
-        int4 recA = make_int4(__float_as_int(qa.x), __float_as_int(qa.y), __float_as_int(qa.z), __float_as_int(qa.w));
-        int4 recB = make_int4(__float_as_int(qb.x), __float_as_int(qb.y), __float_as_int(qb.z), __float_as_int(qb.w));
-        if (kA >= DC_INL || kB >= DC_INL) {             // overflow records: rare, ordinary loads
-          const int pcA = ((b * PDx + x0 + cA / TY + 1) * PDy + y0 + cA % TY + 1) * PDz + po;
-          const int pcB = ((b * PDx + x0 + cB / TY + 1) * PDy + y0 + cB % TY + 1) * PDz + po;
-          if (kA >= DC_INL) recA = slots[dc_slot(g, pcA, kA)];
-          if (kB >= DC_INL) recB = slots[dc_slot(g, pcB, kB)];
-        }
-        v4f_t A0v, A1v, B0v, B1v, A2v = {0.f, 0.f, 0.f, 0.f}, B2v = {0.f, 0.f, 0.f, 0.f};
-        lds_rd2_b128(abuf + (uint32_t)(cA * RB + li * 16), abuf + (uint32_t)(cA * RB + C * 4 + li * 16), A0v, A1v);
-        lds_rd2_b128(abuf + (uint32_t)(cB * RB + li * 16), abuf + (uint32_t)(cB * RB + C * 4 + li * 16), B0v, B1v);
-        float4 fx = make_float4(0.f, 0.f, 0.f, 0.f), fy = fx;
-        if (OP == LINK_OP_COSX) {
-          lds_rd2_b128(abuf + (uint32_t)(cA * RB + 2 * C * 4 + li * 16), abuf + (uint32_t)(cB * RB + 2 * C * 4 + li * 16), A2v, B2v);
-          fx = *reinterpret_cast<const float4 *>(&fin[(int64_t)recA.w * C + ch0]);
-          fy = *reinterpret_cast<const float4 *>(&fin[(int64_t)recB.w * C + ch0]);
-        }
-        // ---- theta / sincos / de-modulate / LayerNorm / store (k_dc_demod's body) ----
-        float thA[4], thB[4];
-        bool big = false;
-        {
-          const bool swapped = PAIR && hi && hasB;
-          float xa = (float)(swapped ? recB.x : recA.x), ya = (float)(swapped ? recB.y : recA.y), za = (float)(swapped ? recB.z : recA.z);
-          float xb = (float)recB.x, yb = (float)recB.y, zb = (float)recB.z;
-          if (DIV) { xa = xa / coord_div; ya = ya / coord_div; za = za / coord_div; xb = xb / coord_div; yb = yb / coord_div; zb = zb / coord_div; }
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            thA[e] = theta_of(xa, ya, za, w0[e], w1[e], w2[e], al[e]);
-            thB[e] = PAIR ? thA[e] : theta_of(xb, yb, zb, w0[e], w1[e], w2[e], al[e]);
-            big |= !(fabsf(thA[e]) < 32768.0f) || !(fabsf(thB[e]) < 32768.0f);
-          }
-        }
-        float snA[4], csA[4], snB[4], csB[4];
-        if (__builtin_expect(__any(big), 0)) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            sincos_nocall(thA[e], snA[e], csA[e]);
-            if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_nocall(thB[e], snB[e], csB[e]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            sincos_small(thA[e], snA[e], csA[e]);
-            if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_small(thB[e], snB[e], csB[e]);
-          }
-        }
-        if (PAIR) {
-          const bool swapped = hi && hasB;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const float sn = snA[e], cs = csA[e];
-            const float so = partner<LPR>(sn), co = partner<LPR>(cs);
-            snA[e] = swapped ? so : sn; csA[e] = swapped ? co : cs;
-            snB[e] = hi ? sn : so;      csB[e] = hi ? cs : co;
-          }
-        }
-        const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
-        float nvA[4], nvB[4], sA = 0.f, sB = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float A0 = A0v[e], A1 = A1v[e], B0 = B0v[e], B1 = B1v[e];
-          if (OP == LINK_OP_SIN) {                                                   // linkunet.py:148
-            nvA[e] = __fsub_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
-            nvB[e] = __fsub_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
-          } else {                                                                   // :162
-            nvA[e] = __fadd_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
-            nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
-          }
-          if (OP == LINK_OP_COSX) {                                                  // :176
-            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], __fmul_rn(fxa[e], thA[e])));
-            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], __fmul_rn(fya[e], thB[e])));
-          }
-          sA += nvA[e]; sB += nvB[e];
-        }
-        sA = grp_sum<LPR>(sA);
-        sB = grp_sum<LPR>(sB);
-        const float meanA = sA * (1.0f / C), meanB = sB * (1.0f / C);
-        float qA = 0.f, qB = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float dA = nvA[e] - meanA, dB = nvB[e] - meanB;
-          qA += dA * dA; qB += dB * dB;
-        }
-        qA = grp_sum<LPR>(qA);
-        qB = grp_sum<LPR>(qB);
-        const float rsA = __builtin_amdgcn_rsqf(qA * (1.0f / C) + eps), rsB = __builtin_amdgcn_rsqf(qB * (1.0f / C) + eps);
-        float4 oa, ob;
-        oa.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0]; oa.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
-        oa.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2]; oa.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
-        ob.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0]; ob.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
-        ob.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2]; ob.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
-        st16(r_out, (uint32_t)recA.w * (uint32_t)(C * 4) + (uint32_t)(ch0 * 4), oa);
-        st16(r_out, hasB ? (uint32_t)recB.w * (uint32_t)(C * 4) + (uint32_t)(ch0 * 4) : DC_OOB, ob);
-      }
-    }
-#pragma unroll
-    for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
-    c0 = c1; c1 = cc;
-    n_prev = n_here;
-  }
-}
-
-template <int OP, int R>
-static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                     hipStream_t st) {
-  using K2 = dc_k2_cfg<OP, R>;
-  using K = typename K2::G;
-  const int txn = (g.dim[0] + K::TX - 1) / K::TX, tyn = (g.dim[1] + K::TY - 1) / K::TY;
-  int zsplit = g_k2_zsplit;
-  if (zsplit <= 0) {
-    const int64_t tiles = (int64_t)txn * tyn * g.dim[3];
-    zsplit = (int)(512 / tiles);
-    if (zsplit < 1) zsplit = 1;
-  }
-  if (zsplit > g.dim[2]) zsplit = g.dim[2];
-  const int64_t nwg = (int64_t)txn * tyn * g.dim[3] * zsplit;
-  const int64_t grid = (nwg + 7) / 8 * 8;
-  const bool two_part = d.op == LINK_OP_COS || d.op == LINK_OP_SIN;
-  const bool pair = d.c == 2 * d.cg && two_part;
-  const bool div = d.coord_div != 1.0f;
-#define LINK_K2(PP, DD)                                                                                               \
-  do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod<OP, R, PP, DD>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::LDS_BYTES);                             \
-    hipLaunchKernelGGL((k_dc_gather_demod<OP, R, PP, DD>), dim3((unsigned)grid), dim3(256), K2::LDS_BYTES, st, b->S,  \
-                       b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w,      \
-                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, g_k2_single);     \
-  } while (0)
-  if (pair) { if (div) LINK_K2(true, true); else LINK_K2(true, false); }
-  else { if (div) LINK_K2(false, true); else LINK_K2(false, false); }
-#undef LINK_K2
-  return check_launch("link_dc_gather_demod");
 }
 
 extern "C" int link_dc_gather_demod(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d,
                                     int64_t n, void *stream) {
-  if (!b || !g || !d || n < 0 || d->c != 64 || (d->r != 2 && d->r != 3) || d->op < 0 || d->op > 2 || d->cg <= 0 ||
-      d->c % d->cg != 0 || g->k < DC_INL)
-    return LINK_ERR_ARG;
-  const int parts = d->op == LINK_OP_COSX ? 3 : 2;
-  if ((g->vp + 1) * (int64_t)parts * d->c * 4 >= (1LL << 32) || n * (int64_t)d->c * 4 >= (1LL << 32) ||
-      g->vp * (int64_t)g->k * 16 >= (1LL << 32))
-    return LINK_ERR_ARG;
+  if (dc_common_ok(b, g, d, n) != LINK_OK || d->c != 64 || (d->r != 2 && d->r != 3)) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   if (!b->S || !b->cell_n || !b->slots || !b->w_pos || !b->ln_w || !b->ln_b || !b->out || (d->op == LINK_OP_COSX && !b->fin))
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  if (d->r == 3) {
-    switch (d->op) {
-      case LINK_OP_COS: return launch_k2<LINK_OP_COS, 3>(b, *g, *d, n, st);
-      case LINK_OP_SIN: return launch_k2<LINK_OP_SIN, 3>(b, *g, *d, n, st);
-      default: return launch_k2<LINK_OP_COSX, 3>(b, *g, *d, n, st);
-    }
-  }
-  switch (d->op) {
-    case LINK_OP_COS: return launch_k2<LINK_OP_COS, 2>(b, *g, *d, n, st);
-    case LINK_OP_SIN: return launch_k2<LINK_OP_SIN, 2>(b, *g, *d, n, st);
-    default: return launch_k2<LINK_OP_COSX, 2>(b, *g, *d, n, st);
+  switch (b->io_dtype) {
+    case 1: return dcio_f16::run_gather_demod(b, *g, *d, n, st);
+    case 2: return dcio_bf16::run_gather_demod(b, *g, *d, n, st);
+    default: return dcio_f32::run_gather_demod(b, *g, *d, n, st);
   }
 }

@@ -43,6 +43,7 @@ __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "Sparse
            "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv", "subm_conv_ln_add_relu"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
+_IO_DTYPES = {torch.float32: L.IO_F32, torch.float16: L.IO_F16, torch.bfloat16: L.IO_BF16}
 
 
 def _st():
@@ -206,12 +207,23 @@ class ElkCorePlan:
         """One R_core step.  `out` (fp32 [n, C], contiguous): write the result there instead of the plan's
         own buffer (what the module path does: the block's output tensor must outlive the plan)."""
         n = feats.shape[0]
-        assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype == torch.float32
+        assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype in _IO_DTYPES
         assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
         self.buf.feats, self.buf.coords = feats.data_ptr(), coords.data_ptr()
+        own = self.out
+        if feats.dtype != torch.float32:
+            # fp16 / bf16 rows at the kernel boundary (AMP): fused dense-cell kernels only
+            if not (self.dense and self.c <= 64 and int(self.dcg.k) <= 352):
+                raise L.LinkAmdError("ElkCorePlan: fp16/bf16 feature rows need the fused dense-cell kernels "
+                                     "(dense layout, C <= 64, s^3 <= 352)")
+            own = self.__dict__.setdefault("_out_half", {}).get(feats.dtype)
+            if own is None and out is None:
+                own = self._out_half[feats.dtype] = torch.empty((self.n_cap, self.c), dtype=feats.dtype, device=self.device)
+        if self.dense:
+            self.buf.io_dtype = _IO_DTYPES[feats.dtype]
         if out is not None:
-            assert out.shape == (n, self.c) and out.dtype == torch.float32 and out.is_contiguous()
-        self.buf.out = (out if out is not None else self.out).data_ptr()
+            assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
+        self.buf.out = (out if out is not None else own).data_ptr()
         st = torch.cuda.current_stream().cuda_stream
         if self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
@@ -221,7 +233,7 @@ class ElkCorePlan:
                           min(self.m_cap, n), 1 if build_index else 0, st)
         if rc != 0:
             L.check(rc, "link_elk_core_dense_forward" if self.dense else "link_elk_core_forward")
-        return out if out is not None else self.out[:n]
+        return out if out is not None else own[:n]
 
     def blocks(self) -> int:
         """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds (or, on
@@ -707,6 +719,9 @@ class _ELKBase(nn.Module):
         n, c = feats.shape
         if n == 0 or c not in (16, 32, 64, 128) or r not in (2, 3) or not feats.is_cuda:
             return None
+        half = feats.dtype != torch.float32
+        if half and (c > 64 or s_eff ** 3 > 352):            # half rows: fused kernels only
+            return None
         bkey = ("link_bounds", coords.data_ptr(), n)
         bounds = st.cmaps.get(bkey)
         if bounds is None:
@@ -731,7 +746,7 @@ class _ELKBase(nn.Module):
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
         ikey = (coords.data_ptr(), n, coords._version)
-        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        out = torch.empty((n, c), dtype=feats.dtype, device=feats.device)
         plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
         plan._indexed = ikey
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
@@ -740,7 +755,7 @@ class _ELKBase(nn.Module):
     def _core(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         needs_grad0 = torch.is_grad_enabled() and (st.F.requires_grad or any(
             p.requires_grad for p in self.parameters()))
-        if not needs_grad0 and st.F.dtype == torch.float32 and st.C.dtype == torch.int32:
+        if not needs_grad0 and st.F.dtype in _IO_DTYPES and st.C.dtype == torch.int32:
             out = self._core_dense(st, s_eff, r, w_pos, alpha, cg, coord_div)
             if out is not None:
                 return out

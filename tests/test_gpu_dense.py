@@ -129,3 +129,34 @@ def test_dense_cfg2_full_size():
     assert rel_err(od.cpu().numpy(), ref) < 1e-4
     for _ in range(5):
         assert torch.equal(od, dense.run(feats, coords))
+
+
+@pytest.mark.parametrize("dtype,tol_round,tol_oracle", [(torch.float16, 1.2e-3, 6e-3), (torch.bfloat16, 9e-3, 5e-2)])
+@pytest.mark.parametrize("C,groups,baseop,s,r,grid,n", [(64, 2, "cos", 7, 3, 80, 9000), (32, 1, "cos_x", 3, 2, 40, 6000),
+                                                       (64, 1, "cos_x", 3, 2, 36, 5000)])
+def test_dense_half_rows(dtype, tol_round, tol_oracle, C, groups, baseop, s, r, grid, n):
+    """fp16 / bf16 feature rows at the kernel boundary (SURVEY.md section 8b "AMP": the reference wraps its
+    voxelize / devoxelize ops in custom_fwd(cast_inputs=torch.half), fp32 accumulation).  Everything inside is
+    fp32, so (a) against the fp32 path fed the SAME rounded inputs only the output rounding remains (half an ulp
+    of the row maximum: 2^-11 fp16, 2^-8 bf16), and (b) against the fp32 oracle on the unrounded inputs the
+    stated looser gate holds."""
+    import link_amd as la
+    torch.manual_seed(5)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    coords = s_uniform(n, grid=grid, seed=C + r).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
+    bounds = ((0, 0, 0, 0), (grid - 1, grid - 1, grid - 1, 0))
+    plan = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    fh = feats.to(dtype)
+    oh = plan.run(fh, coords).clone()
+    assert oh.dtype == dtype and oh.shape == (n, C)
+    o32 = plan.run(fh.float(), coords).clone()
+    assert rel_err(oh.float().cpu().numpy(), o32.cpu().numpy()) < tol_round
+    ref = _oracle(blk, feats, coords, s, r, baseop, groups)
+    assert rel_err(oh.float().cpu().numpy(), ref) < tol_oracle
+    assert torch.equal(oh, plan.run(fh, coords))                 # reproducible
+    # the module path keeps the row type (what a caller under torch.autocast hands over)
+    st = la.SparseTensor(fh, coords, 1)
+    with torch.no_grad():
+        core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None, C // groups, 1.0)
+    assert core.dtype == dtype and rel_err(core.float().cpu().numpy(), o32.cpu().numpy()) < tol_round

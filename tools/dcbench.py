@@ -88,7 +88,7 @@ def main():
         "premix_modsum": lambda: lib.link_dc_premix_modsum(ctypes.byref(b), ctypes.byref(g), ctypes.byref(d), N, 0, st),
         "gather": unfused["gather"],
         "demod": lambda: lib.link_dc_demod(b.A, b.fin, b.coords, b.vcell, b.w_pos, b.alpha, b.ln_w, b.ln_b,
-                                           ctypes.byref(d), ctypes.byref(g), N, b.out, st),
+                                           ctypes.byref(d), ctypes.byref(g), N, b.out, 0, st),
     }
     if a.unfused:
         stages = unfused
