@@ -209,6 +209,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import link_amd as la
+    from link_amd import _lib as L
 
     N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
     torch.manual_seed(2)
@@ -232,8 +233,16 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def geometry(ns):
+        """Launch geometry for the number of frames kept in flight (dense-cell layout): one frame alone wants
+        every kernel spread over 2 workgroups per CU; with several frames in flight half that per kernel lets
+        the kernels of different frames share the CUs (tools/mstream_dc.py)."""
+        if plan.dense:
+            L.lib().link_dc_set_tuning2(0, 512 if ns == 1 else 256)
+
     def timed(k, build_index=True, ns=NS):
         """EXACTLY k steps (frames), round-robin over `ns` streams; barrier + synchronize on both sides."""
+        geometry(ns)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -275,8 +284,8 @@ def main():
 
     # ---- instrumented replay: per-kernel durations with HIP events on the launch stream ---------
     import ctypes
-    from link_amd import _lib as L
     lib = L.lib()
+    geometry(1)
     st = torch.cuda.current_stream().cuda_stream
     b, desc = plan.buf, plan.desc
     esz = 4 if args.io == "f32" else 2
@@ -342,7 +351,7 @@ def main():
     # they cannot be collected from inside the timed process)
     traffic, traffic_src = None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj) and (N, C) == (100000, 64):
+    if os.path.exists(tj) and (N, C) == (100000, 64) and args.io == "f32":
         tdb = json.load(open(tj))
         traffic = tdb.get("kernels", {}).get(dom)
         traffic_src = tdb.get("source")

@@ -24,6 +24,7 @@ int g_k1_wgs = 512;
 int g_demod_wgs = 1024;
 int g_k2_zsplit = 0;
 int g_k2_single = 0;
+int g_k1_pipe = 0;
 unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
 }
 static int g_index_wgs = 0;
@@ -55,6 +56,7 @@ extern "C" int link_dc_set_tuning2(int key, int value) {
     case 2: g_index_wgs = value; break;
     case 3: g_k2_zsplit = value; break;
     case 4: g_k2_single = value; break;
+    case 5: g_k1_pipe = value; break;
     default: return LINK_ERR_ARG;
   }
   return LINK_OK;

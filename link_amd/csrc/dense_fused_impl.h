@@ -10,7 +10,7 @@
 #include "dense_gather.h"
 
 namespace link {
-extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single;
+extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe;
 extern unsigned long long *g_k1_dbg;
 }
 
@@ -84,8 +84,12 @@ struct dc_k1_cfg {
 // NB = number of distinct 16-channel theta blocks of a voxel: channel ch uses theta[ch % cg]; when cg is a
 // multiple of 16 the MFMA channel block tp (channels 16 tp + 4 g + r of lane group g) uses theta block
 // tp % (cg/16), so a lane evaluates 4*NB sincos per voxel instead of 4*T; otherwise NB = T.
-template <int C, int OP, int NB>
-__global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
+// PIPE: software-pipelined tiles (MFMAs of tile t+1 issued inside tile t's VALU block; two accumulator and
+// row sets: ~256 registers, 2 waves per SIMD and nothing else fits beside them) or plain tiles (rows of t+1 in
+// flight while t is multiplied, then finished: ~130 registers, so that a second frame's kernels can share the
+// SIMDs).  Same arithmetic, bit for bit.
+template <int C, int OP, int NB, bool PIPE>
+__global__ void __launch_bounds__(256, PIPE ? 2 : 3) k_dc_premix_modsum(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
     int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
     int4 recA = make_int4(0, 0, 0, 0), recB = recA, recC = recA;
     float4 fA[T], fB[T];
     floatx4 acA[T], acB[T];
-    if (ntile > 0) {                                    // pipeline fill: tile 0 multiplied, tile 1 requested
+    if (PIPE && ntile > 0) {                            // pipeline fill: tile 0 multiplied, tile 1 requested
       ld_rows(0, recA, fB);
       ld_rows(ntile > 1 ? 1 : 0, recB, fA);
       mfma_tile(fB, acA);
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
             big |= !(fabsf(th[tb][r]) < 32768.0f);
           }
         const bool slow = __any(big);
-        const bool more = t + 1 < ntile;
+        const bool more = PIPE && t + 1 < ntile;
         (void)recn;
         auto body = [&](auto more_tag, auto slow_tag) {
           constexpr bool MORE = decltype(more_tag)::value, SLOW = decltype(slow_tag)::value;
@@ -406,12 +410,27 @@ __global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
     };
     // rows of tile t+1 sit in fA for even t and fB for odd t, accumulators of tile t in acA / acB likewise;
     // the three records rotate by plain copies (they come from LDS: no VMEM wait is involved)
-    for (int t = 0; t < nloop; t += 2) {
-      step(t, recA, recB, recC, fA, fB, acA, acB);
-      recA = recB; recB = recC;
-      if (t + 1 < nloop) {
-        step(t + 1, recA, recB, recC, fB, fA, acB, acA);
+    if constexpr (PIPE) {
+      for (int t = 0; t < nloop; t += 2) {
+        step(t, recA, recB, recC, fA, fB, acA, acB);
         recA = recB; recB = recC;
+        if (t + 1 < nloop) {
+          step(t + 1, recA, recB, recC, fB, fA, acB, acA);
+          recA = recB; recB = recC;
+        }
+      }
+    } else {
+      // plain tiles: rows of tile t in fA (even t) / fB (odd t), the other set receives tile t+1 meanwhile
+      if (ntile > 0) ld_rows(0, recA, fA);
+      for (int t = 0; t < nloop; t += 2) {
+        if (t + 1 < ntile) ld_rows(t + 1, recB, fB);
+        mfma_tile(fA, acA);
+        step(t, recA, recB, recC, fB, fB, acA, acB);
+        if (t + 1 < nloop) {
+          if (t + 2 < ntile) ld_rows(t + 2, recA, fA);
+          mfma_tile(fB, acA);
+          step(t + 1, recB, recA, recC, fA, fA, acA, acB);
+        }
       }
     }
     chunk += nfit;
@@ -423,8 +442,8 @@ __global__ void __launch_bounds__(256, 2) k_dc_premix_modsum(
   }
 }
 
-template <int C, int OP, int NB>
-static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+template <int C, int OP, int NB, bool PIPE>
+static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                      bool warm, hipStream_t st) {
   using K = dc_k1_cfg<C, OP>;
   const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
@@ -433,12 +452,18 @@ static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   if (cpw < 1) cpw = 1;
   const int64_t wgs = (vi + (int64_t)cpw * 4 - 1) / ((int64_t)cpw * 4);
   if (K::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB>), dim3((unsigned)wgs), dim3(256), K::LDS_BYTES, st, b->feats,
+  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(256), K::LDS_BYTES, st, b->feats,
                      reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
                      b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr, g_k1_dbg);
   return check_launch("link_dc_premix_modsum");
+}
+
+template <int C, int OP, int NB>
+static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                     bool warm, hipStream_t st) {
+  return g_k1_pipe ? launch_k1p<C, OP, NB, true>(b, g, d, n, warm, st) : launch_k1p<C, OP, NB, false>(b, g, d, n, warm, st);
 }
 
 template <int C, int OP>

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--unfused", action="store_true")
     ap.add_argument("--split", action="store_true", help="separate gather + demod kernels instead of the fused one")
+    ap.add_argument("--pipecmp", action="store_true", help="fused kernel: software-pipelined vs plain tiles")
     ap.add_argument("--phases", action="store_true", help="per-wave phase timing of the fused kernel (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -151,6 +152,27 @@ def main():
         for zs in (2, 3, 4, 5):
             lib.link_dc_set_tuning(2, zs); lib.link_dc_set_tuning2(3, zs); report(f"gather zsplit={zs:3d}")
         lib.link_dc_set_tuning(2, 0); lib.link_dc_set_tuning2(3, 0)
+    if a.pipecmp:
+        for pipe in (1, 0):
+            lib.link_dc_set_tuning2(5, pipe)
+            report(f"k1 pipe={pipe}")
+            for ns in (1, 3):
+                ps, ss = [], []
+                for k in range(ns):
+                    q = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense")
+                    q.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+                           blk.norm.weight, blk.norm.bias)
+                    ps.append(q); ss.append(torch.cuda.Stream())
+                cnt = [0]
+
+                def step():
+                    j = cnt[0] % ns
+                    cnt[0] += 1
+                    with torch.cuda.stream(ss[j]):
+                        ps[j].run(feats, coords)
+                print(f"   pipe={pipe}, {ns} frames in flight: {wall(step, iters=300):6.2f} us/frame")
+        lib.link_dc_set_tuning2(5, 1)
+        return
     # frames in flight
     for ns in (1, 2, 3, 4):
         ps, ss = [], []
