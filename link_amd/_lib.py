@@ -18,6 +18,9 @@ HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
 ABI_VERSION = 3
+# LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
+# raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
+DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
 
 
 class LinkGrid(Structure):

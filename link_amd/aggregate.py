@@ -119,6 +119,9 @@ def link_index_of(st: SparseTensor, s: int) -> BlockIndex:
     if idx is None:
         bounds = st.cmaps.get(("link_bounds", st.C.data_ptr(), st.C.shape[0]))
         idx = BlockIndex(st.C, int(s), bounds=bounds)
+        # bounds computed from these coordinates (coords_bounds) cannot drop a voxel; bounds from the caller's
+        # metadata can (hdr[STATUS]) -- consumers then zero-fill their output rows
+        idx.rows_checked = bounds is None or not st.cmaps.get(("link_bounds_unchecked", st.C.data_ptr(), st.C.shape[0]))
         st.cmaps.setdefault(("link_bounds", st.C.data_ptr(), st.C.shape[0]), idx.bounds)
         st.kmaps[key] = idx
     return idx

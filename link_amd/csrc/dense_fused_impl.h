@@ -636,8 +636,8 @@ __global__ void __launch_bounds__(256) k_dc_demod(const float *__restrict__ A_, 
     ob.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0]; ob.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
     ob.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2]; ob.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
     const uint32_t offA = (uint32_t)(2 * p) * (uint32_t)c + (uint32_t)ch0;       // element offset
-    io_st4(r_out, offA, true, oa);
-    io_st4(r_out, offA + (uint32_t)c, hasB, ob);
+    io_st4(r_out, offA, v0a != 0, oa);                   // a voxel the index dropped (cell 0) keeps its row untouched
+    io_st4(r_out, offA + (uint32_t)c, hasB && v0b != 0, ob);
     c0a = c1a; c0b = c1b; v0a = v1a; v0b = v1b;
     c1a = c2a; c1b = c2b; v1a = v2a; v1b = v2b;
 #pragma unroll

@@ -71,7 +71,7 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     fin = torch.empty((n, c), dtype=torch.float32, device=dev)
     m_cap = max(m_cap, 1)
     S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
-    out = torch.empty((n, c), dtype=torch.float32, device=dev)
+    out = _alloc_out(index, (n, c), dev)
     desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
     lib, st = L.lib(), _st()
     w_pos = w_pos.contiguous().float()
@@ -100,6 +100,15 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
                                      ctypes.byref(index.grid), index.hdr.data_ptr(), ctypes.byref(desc), n,
                                      m_cap, out.data_ptr(), st), "link_gather_demod_ln")
     return out
+
+
+def _alloc_out(index: BlockIndex, shape, dev) -> torch.Tensor:
+    """Output rows of a core call.  The kernels write the rows of every *indexed* voxel; a voxel outside
+    caller-supplied bounds is dropped by the index (hdr[STATUS] bit 0), so when the bounds were not derived
+    from the coordinates themselves the rows start as zeros instead of uninitialised memory."""
+    if getattr(index, "rows_checked", True):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    return torch.zeros(shape, dtype=torch.float32, device=dev)
 
 
 class ElkCorePlan:
@@ -233,15 +242,24 @@ class ElkCorePlan:
                           min(self.m_cap, n), 1 if build_index else 0, st)
         if rc != 0:
             L.check(rc, "link_elk_core_dense_forward" if self.dense else "link_elk_core_forward")
+        if L.DEBUG:
+            self.check()
         return out if out is not None else own[:n]
+
+    def check(self) -> None:
+        """Read the device status word of the last step (one 32-byte D2H sync) and raise if a voxel was
+        dropped: outside the plan's bounds (its `out` row was not written), or in a cell whose slot list was
+        full.  Runs after every step under LINK_AMD_DEBUG=1; INTEGRATION.md states the contract."""
+        st = int(self.hdr[L.HDR_STATUS].item())
+        if st != 0:
+            raise L.LinkAmdError("ElkCorePlan: voxels outside the plan's bounds" if st & 1 else
+                                 "ElkCorePlan: more voxels in a block than its slot list holds (duplicate coordinates)")
 
     def blocks(self) -> int:
         """M of the last indexed frame (D2H sync); raises if a voxel fell outside the plan's bounds (or, on
         the dense-cell layout, found its cell's slot list full: duplicate coordinates)."""
+        self.check()
         h = self.hdr.tolist()
-        if h[L.HDR_STATUS] != 0:
-            raise L.LinkAmdError("ElkCorePlan: voxels outside the plan's bounds" if h[L.HDR_STATUS] & 1 else
-                                 "ElkCorePlan: more voxels in a block than its slot list holds (duplicate coordinates)")
         if self.dense:
             return int((self.cell_n > 0).sum().item())
         return int(h[L.HDR_M])
@@ -301,7 +319,7 @@ class _ElkMid(torch.autograd.Function):
         S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
         A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
         den = torch.empty(m_cap, dtype=torch.float32, device=dev)
-        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        out = _alloc_out(index, (n, c), dev)
         L.check(L.lib().link_elk_mid_forward(
             fin.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(), index.blk_start.data_ptr(),
             index.blk_coords.data_ptr(), index.cell_blk.data_ptr(), ctypes.byref(index.grid),
@@ -375,7 +393,7 @@ class _ElkCoreTrain(torch.autograd.Function):
         S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
         A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
         den = torch.empty(m_cap, dtype=torch.float32, device=dev)
-        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        out = _alloc_out(index, (n, c), dev)
         L.check(lib.link_premix_ln(feats.data_ptr(), w_pre_c.data_ptr(), pre_w.data_ptr(), pre_b.data_ptr(), n, c,
                                    float(eps), fin.data_ptr(), st), "link_premix_ln")
         L.check(lib.link_elk_mid_forward(
@@ -746,7 +764,10 @@ class _ELKBase(nn.Module):
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
         ikey = (coords.data_ptr(), n, coords._version)
-        out = torch.empty((n, c), dtype=feats.dtype, device=feats.device)
+        # bounds taken from the caller's metadata (TSELKBlock: spatial_shape) are not verified without a sync:
+        # rows of voxels outside them are never written, so they start as zeros (status word)
+        alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
+        out = alloc((n, c), dtype=feats.dtype, device=feats.device)
         plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
         plan._indexed = ikey
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
@@ -764,6 +785,8 @@ class _ELKBase(nn.Module):
                 w_pos, alpha, self.norm.weight, self.norm.bias, self.baseop, cg, r, coord_div, 1e-6)
         needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(
             p.requires_grad for p in self.parameters()))
+        if L.DEBUG:
+            index.M                              # validates hdr[STATUS] (one D2H sync)
         if needs_grad:
             if st.F.shape[1] % 4 == 0 and r <= 3 and st.F.dtype == torch.float32:
                 return elk_core_train(*args)
@@ -880,7 +903,8 @@ class TSELKBlock(_ELKBase):
         if shape is not None and save.get("batch_size") is not None:   # bounds for free: no bbox sync
             z, y, x = [int(v) for v in shape]
             bounds = ((0, 0, 0, 0), (x - 1, y - 1, z - 1, int(save["batch_size"]) - 1))
-            st.cmaps.setdefault(("link_bounds", st.C.data_ptr(), st.C.shape[0]), bounds)
+            if st.cmaps.setdefault(("link_bounds", st.C.data_ptr(), st.C.shape[0]), bounds) is bounds:
+                st.cmaps[("link_bounds_unchecked", st.C.data_ptr(), st.C.shape[0])] = True
         return ts2spconv(self.forward_(st, stride), save)
 
     def forward_(self, st: SparseTensor, stride):

@@ -83,6 +83,9 @@ class BlockIndex:
         self.s = s
         self.n = n = coords.shape[0]
         dev = coords.device
+        # bounds handed in by the caller (spatial_shape) are trusted without a sync: a voxel outside them is
+        # dropped and reported in hdr[STATUS]; consumers zero-fill their outputs in that case (rows_checked)
+        self.rows_checked = bounds is None
         if bounds is None:
             if n == 0:
                 bounds = ((0, 0, 0, 0), (0, 0, 0, 0))

@@ -112,6 +112,41 @@ def test_tselk_block_vs_oracle():
     assert rel_err(out.features.cpu().numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("grid,n", [(80, 6000), (56, 60000)])      # general layout / dense-cell layout
+def test_tselk_wrong_spatial_shape_contract(grid, n):
+    """spatial_shape smaller than the data (caller error): voxels outside it are dropped by the index.  The
+    contract: their core rows are zeros -- never uninitialised memory -- rows of the other
+    voxels are finite, and the status word reports it (ElkCorePlan.check / BlockIndex.M raise)."""
+    import link_amd as la
+    import link_amd._lib as L
+    torch.manual_seed(3)
+    C, stride = 32, 7
+    blk = la.TSELKBlock(C, C, baseop="cos").cuda().eval()
+    coords = s_uniform(n, grid=grid, seed=9)
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
+    indices = coords[:, [3, 2, 1, 0]].contiguous().cuda()
+    half = grid // 2
+    # the block grid covers whole blocks: a voxel is dropped when its BLOCK lies beyond the last block of the shape
+    outside = (torch.div(coords[:, :3], stride, rounding_mode="floor") > (half - 1) // stride).any(1)
+    assert outside.any() and (~outside).any()
+    cap = {}
+    orig = blk._core
+    blk._core = lambda *a, **k: cap.setdefault("core", orig(*a, **k))
+    for _ in range(2):          # twice: a recycled allocation holds the previous (non-zero) result
+        cap.clear()
+        sct = la.SparseConvTensor(feats, indices, spatial_shape=[half, half, half], batch_size=1)
+        with torch.no_grad():
+            blk(sct, stride)
+        core = cap["core"].cpu()
+        assert torch.isfinite(core).all()
+        assert (core[outside] == 0).all()
+        assert (core[~outside].abs().sum(1) > 0).all()
+    plans = [p for p in blk.__dict__.get("_dc_plans", {}).values() if p is not None]
+    if plans:
+        with pytest.raises(L.LinkAmdError):
+            plans[0].check()
+
+
 def test_cfg2_full_size_core():
     """BASELINE cfg2: N=100k, C=64, cos g=2, r=3, s=7 through the fused core vs the oracle (a few s)."""
     import link_amd as la
