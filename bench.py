@@ -162,6 +162,95 @@ def timed_regions(la, blk, feats, coords, C, s, r, iters=30):
                     "R_core cold/warm are `value`/`warm_index_value` (arena path, one FFI call per step)"}
 
 
+def cfg3_mode(args, la, dev, rank, world, dist):
+    """BASELINE.json configs[2] shape (labelled, NOT the headline): the encoder common to both segmentation models
+    (stem -> 4 x [k2-s2 down, 2 residual blocks + tail || ELKBlock cos_x (2x3)^3 + tail, add/ReLU],
+    linkencoder.py:186-368; assembled in tests/link_encoder.py from link_amd modules) on one S-kitti frame per
+    rank (link_amd/synth.py, seed = rank; full size, ~113k voxels), warm kernel maps.  A step = one eval
+    forward; the line also carries forward+backward (sum-of-squares loss on stage 4) and the time inside the
+    four ELK blocks."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import link_encoder as LE
+    from link_amd.synth import s_kitti, block_stats
+    co, fe = s_kitti(seed=rank)
+    coords, feats = torch.from_numpy(co).to(dev), torch.from_numpy(fe).to(dev)
+    n = coords.shape[0]
+    torch.manual_seed(0)
+    net = LE.build_stages(la, 4, 64, "cos_x", 1, 4).to(dev)
+    st0 = la.SparseTensor(feats, coords, 1)
+    with torch.no_grad():
+        sizes = [o.C.shape[0] for o in net.eval()(st0, 3, 2)]
+
+    def step(train):
+        f = feats.detach().requires_grad_(train)
+        x = la.SparseTensor(f, coords, 1)
+        x.kmaps, x.cmaps = st0.kmaps, st0.cmaps
+        if train:
+            net(x, 3, 2)[-1].F.square().sum().backward()
+        else:
+            with torch.no_grad():
+                net(x, 3, 2)
+
+    def timed(train, k, w):
+        net.train(train)
+        for _ in range(w):
+            step(train)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(train)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    k = min(args.steps, 50)
+    w = min(args.warmup, 5)
+    t_fwd = timed(False, k, w)
+    t_tr = timed(True, max(1, k // 4), 2)
+    # time inside the ELK blocks (eval), stream-synchronised per call: an upper bound of their share
+    elk_t = [0.0]
+    saved = [m.forward for m in net.elk]
+
+    def wrap(f0):
+        def fwd(*a, **kw):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            o = f0(*a, **kw)
+            torch.cuda.synchronize(); elk_t[0] += time.perf_counter() - t0
+            return o
+        return fwd
+    for m in net.elk:
+        m.forward = wrap(m.forward)
+    net.eval()
+    for _ in range(5):
+        step(False)
+    for m, f0 in zip(net.elk, saved):
+        m.forward = f0
+    nv = torch.tensor([float(n)], device=dev)
+    if world > 1:
+        dist.all_reduce(nv)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "voxels_per_second", "value": float(nv.item()) * k / t_fwd, "unit": "voxels/s", "n_gpus": world,
+            "steps": k, "warmup": w, "ms_per_step": 1e3 * t_fwd / k, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (S-kitti ray-cast frame, SURVEY.md 8d; random-init weights)",
+            "headline": False,
+            "config": {"workload": "cfg3 (labelled secondary mode): LinK encoder stages, eval forward, C=64 cos_x (2x3)^3 "
+                                   "r=2, one S-kitti frame per GPU, warm kernel maps",
+                       "voxels": n, "stage_voxels": sizes, "blocks_s6_on_input_voxels": int(block_stats(co, 6)[1]),
+                       "parallelism": f"dp{world}"},
+            "fwd_bwd_ms": 1e3 * t_tr / max(1, k // 4), "elk_blocks_fwd_ms": 1e3 * elk_t[0] / 5,
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +262,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
                     help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3"), default="cfg2",
+                    help="cfg2 = the headline (R_core, S-uniform); cfg3 = labelled secondary mode: forward and "
+                         "forward+backward of the LinK encoder stages on one S-kitti frame per rank")
     args = ap.parse_args()
 
     import torch
@@ -210,6 +302,9 @@ def main():
 
     import link_amd as la
     from link_amd import _lib as L
+
+    if args.workload == "cfg3":
+        return cfg3_mode(args, la, dev, rank, world, dist)
 
     N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
     torch.manual_seed(2)
