@@ -396,6 +396,37 @@ int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *n
 /* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
 int link_conv_set_tuning(int key, int value);
 
+/* Pair-list form of the same convolution, for sparse frames (few of the K neighbours present per voxel).
+ * The kernel map is the reference's own: per kernel offset the list of (input row, output row) pairs
+ * (nbmaps / nbsizes, nn/functional/conv.py:109-122; consumed offset by offset in convolution_cuda.cu:90-165
+ * as gather -> cuBLAS -> scatter-add).  Here ONE MFMA launch computes every pair's contribution row and ONE
+ * output-stationary launch adds them per voxel in a fixed order (no atomics, deterministic) with the optional
+ * bias / LayerNorm + add + ReLU epilogue.
+ *   rows_pad     contribution rows, a multiple of 128.  Rows are grouped by kernel offset, each group padded to
+ *                a 128-row granule; pair_in i32[rows_pad] = input row of the pair (-1: padding);
+ *                wg_k i32[rows_pad/128] = kernel offset of each granule (-1: skip).
+ *   contrib      fp32[rows_pad, cout] scratch: contrib[p] = feats[pair_in[p]] . w[wg_k[p/128]].
+ *   n_direct     output voxels i < n_direct take contrib[i] as their first term (submanifold: the centre
+ *                offset's pairs are the identity and occupy rows [0, n)); 0 for strided / transposed maps.
+ *   ext_start i32[n+1], ext_list i32[...]: CSR list of the other contribution rows of every output voxel,
+ *                ascending kernel offset.
+ * Widths: link_conv_pairs_supported(cin, cout) (multiples of 16 the LinK networks use, <= 128). */
+int link_conv_pairs_supported(int32_t cin, int32_t cout);
+int link_conv_pairs_gemm(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
+                         const float *w, int32_t cin, int32_t cout, float *contrib, void *stream);
+int link_conv_pairs_sum(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                        int64_t n_direct, int32_t cout, const float *bias, const float *ln_w, const float *ln_b,
+                        float eps, const float *addend, int32_t relu, float *out, void *stream);
+/* Submanifold tables (odd kernel, identical input and output coordinates: nbr[i, centre] == i): the centre
+ * offset's GEMM runs on the output rows themselves and the voxel is finished in the accumulators --
+ * out[i] = epilogue(feats[i] . w[centre] + sum of contrib[ext_list[ext_start[i] .. ext_start[i+1])]) with the
+ * same epilogue as link_conv_pairs_sum.  contrib (contrib_rows rows, < 4 GiB) then holds only the OTHER offsets' rows (link_conv_pairs_gemm
+ * over a pair list without the centre), so the centre term never travels through HBM. */
+int link_conv_centre_sum(const float *feats, const float *w, int32_t centre, const float *contrib,
+                         int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
+                         const float *bias, const float *ln_w, const float *ln_b, float eps, const float *addend,
+                         int32_t relu, float *out, void *stream);
+
 /* =============================================================================================
  * E. Dense-cell form of R_core (the fast path when the block grid is mostly occupied)
  *

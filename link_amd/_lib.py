@@ -130,6 +130,12 @@ SIGNATURES = {
     "link_aux_to_voxel_forward_grid": (c_int, [c_void_p] * 4 + [POINTER(LinkGrid), c_void_p, c_void_p, c_int64,
                                                c_int64, c_int32, c_int32] + [c_void_p] * 5),
     "link_conv_set_tuning": (c_int, [c_int, c_int]),
+    "link_conv_pairs_supported": (c_int, [c_int32, c_int32]),
+    "link_conv_pairs_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "link_conv_pairs_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                    c_float, c_void_p, c_int32, c_void_p, c_void_p]),
+    "link_conv_centre_sum": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p]),
     "link_subm_conv_wgrad_chunks": (c_int32, []),
     "link_subm_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "link_subm_conv_ln_add_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,

@@ -1,0 +1,351 @@
+// link_amd/csrc/conv_pairs.hip -- the sparse-frame form of the sparse convolution (row N1).
+//
+// conv.hip's output-stationary kernel walks all K offsets for every tile of 16 output voxels; that is the right
+// shape when a voxel has most of its 27 neighbours.  On sparse frames (cfg2: 1.2 of 27 present, LiDAR sweeps:
+// ~6) nearly every (tile, offset) step finds one or two of its 16 voxels with work, and the f32 MFMA issues at
+// tile granularity -- 15/16 of the matrix pipe's time multiplies zeros.  The reference's gather-GEMM-scatter
+// (convolution_cuda.cu:90-165) is dense by construction because it runs over the *pair list* of each offset.
+// This file keeps that property without its 27 x 3 launches, its scatter atomics or its intermediate copies:
+//
+//   k_conv_pairs_gemm   rows = pairs (input row j -> contribution row p), grouped by kernel offset and padded
+//                       to 128-row granules; a workgroup owns one granule, stages W_k once in LDS and its 8
+//                       waves run one dense 16-pair MFMA tile each: contrib[p] = feats[pair_in[p]] . W_k
+//                       (v_mfma_f32_16x16x4_f32, exact f32).
+//   k_conv_pairs_sum    output-stationary and deterministic: voxel i adds the rows of its CSR list (ascending
+//                       offset) in registers, then bias / LayerNorm + add + ReLU epilogue (the block's tail,
+//                       linkunet.py:183) and ONE store.  No atomics anywhere.  (Strided / transposed maps.)
+//   k_conv_centre_sum   submanifold maps: the centre offset's pairs are the identity, so its GEMM runs on the
+//                       output tile itself and the same epilogue finishes the voxel in the MFMA accumulators;
+//                       the pair list then holds only the other offsets.
+//
+// The pair lists are the kernel map (the reference's nbmaps/nbsizes, nn/functional/conv.py:109-122): built once
+// per coordinate set on the host side (link_amd/elk.py::_pair_plan) and cached with it.
+#include "common.h"
+
+using namespace link;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int CI, int CO>
+__global__ void __launch_bounds__(512) k_conv_pairs_gemm(const float *__restrict__ feats,
+                                                         const int32_t *__restrict__ pair_in,
+                                                         const int32_t *__restrict__ wg_k,
+                                                         const float *__restrict__ w, float *__restrict__ contrib) {
+  constexpr int TI = CI / 16, TO = CO / 16;
+  constexpr int LD = CO + 4;                 // row stride of W_k in LDS: 4*LD = 16 (mod 32) -> the two 16-lane
+                                             // rows of a half-wave read disjoint banks
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *w_lds = reinterpret_cast<float *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = wg_k[blockIdx.x];
+  if (k < 0) return;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  // the wave's 16 input rows first: their latency hides behind the W_k staging
+  const int j0 = pair_in[row0 + li];
+  float4 f0[TI];
+  {
+    const float *r0 = feats + (int64_t)(j0 < 0 ? 0 : j0) * CI + 4 * g;
+#pragma unroll
+    for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const float4 *>(r0 + 16 * t);
+  }
+  const float *wk = w + (int64_t)k * CI * CO;
+  for (int e = tid * 4; e < CI * CO; e += 512 * 4) {
+    const int r = e / CO, col = e - r * CO;
+    *reinterpret_cast<float4 *>(&w_lds[r * LD + col]) = *reinterpret_cast<const float4 *>(&wk[e]);
+  }
+  __syncthreads();
+  if (__all(j0 < 0)) return;                           // granule padding
+  floatx4 a0[TO];
+#pragma unroll
+  for (int tp = 0; tp < TO; tp++) a0[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < TI; t++) {
+    const float *wr = &w_lds[(16 * t + 4 * g) * LD + li];
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) {
+      // A operand: W_k^T[co = 16tp + li][ci = 16t + 4g + j]
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * tp], f0[t].x, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[LD + 16 * tp], f0[t].y, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2 * LD + 16 * tp], f0[t].z, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * LD + 16 * tp], f0[t].w, a0[tp], 0, 0, 0);
+    }
+  }
+  // D[co = 16tp + 4g + r][pair li]: a lane holds 4 consecutive channels of its pair's row per output tile
+  float *o0 = contrib + (row0 + li) * CO + 4 * g;
+  if (j0 >= 0) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++)
+      *reinterpret_cast<float4 *>(o0 + 16 * tp) = make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]);
+  }
+}
+
+// Submanifold tables: the centre offset's pairs are the identity, so its GEMM needs no gather and no
+// contribution rows -- this kernel runs it per tile of 16 output voxels and finishes the voxel in the MFMA
+// accumulator layout (a lane holds 4 channels x CO/16 tiles of ONE voxel): + the voxel's CSR rows of the other
+// offsets (computed before by k_conv_pairs_gemm), + bias, LayerNorm as in-lane adds + 2 cross-lane steps,
+// + addend, ReLU, one store.  On cfg2 (0.15 other neighbours per voxel) the whole convolution is this kernel
+// plus a 17k-row GEMM.
+template <int CI, int CO, bool TAIL>
+__global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict__ feats, const float *__restrict__ w,
+                                                         int centre, const float *__restrict__ contrib,
+                                                         uint32_t contrib_bytes, const int32_t *__restrict__ ext_start,
+                                                         const int32_t *__restrict__ ext_list, int64_t n,
+                                                         const float *__restrict__ bias, const float *__restrict__ ln_w,
+                                                         const float *__restrict__ ln_b, float eps,
+                                                         const float *__restrict__ addend, int relu,
+                                                         float *__restrict__ out) {
+  constexpr int TI = CI / 16, TO = CO / 16;
+  constexpr int LD = CO + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *w_lds = reinterpret_cast<float *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int64_t v0 = row0 + li;
+  const bool ok0 = v0 < n;
+  const int64_t c0 = ok0 ? v0 : n - 1;
+  float4 f0[TI];
+#pragma unroll
+  for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const float4 *>(feats + c0 * CI + 16 * t + 4 * g);
+  const int s0 = ext_start[c0], e0 = ok0 ? ext_start[c0 + 1] : s0;
+  const float *wk = w + (int64_t)centre * CI * CO;
+  for (int e = tid * 4; e < CI * CO; e += 512 * 4) {
+    const int r = e / CO, col = e - r * CO;
+    *reinterpret_cast<float4 *>(&w_lds[r * LD + col]) = *reinterpret_cast<const float4 *>(&wk[e]);
+  }
+  const int pf0 = s0 < e0 ? ext_list[s0] : -1, pf1 = s0 + 1 < e0 ? ext_list[s0 + 1] : -1;
+  __syncthreads();
+  if (row0 >= n) return;
+  floatx4 a0[TO];
+#pragma unroll
+  for (int tp = 0; tp < TO; tp++) a0[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < TI; t++) {
+    const float *wr = &w_lds[(16 * t + 4 * g) * LD + li];
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) {
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * tp], f0[t].x, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[LD + 16 * tp], f0[t].y, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2 * LD + 16 * tp], f0[t].z, a0[tp], 0, 0, 0);
+      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * LD + 16 * tp], f0[t].w, a0[tp], 0, 0, 0);
+    }
+  }
+  // the other offsets' rows, ascending kernel offset (fixed summation order), two per trip: the lists are
+  // short but the trip count of a wave is the maximum over its 16 voxels, and a trip is two dependent round
+  // trips.  Absent rows read through an out-of-range buffer offset (returns 0): no branch around the loads.
+  if (__any(s0 < e0)) {
+    const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(contrib), 0, contrib_bytes, 0x00020000);
+    int p0 = pf0, p1 = pf1;                            // first trip's row ids were fetched before the MFMAs
+    for (int q0 = s0; __any(q0 < e0); q0 += 2) {
+      floatx4 c[2][TO];
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        const uint32_t o0 = p0 >= 0 ? (uint32_t)p0 * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
+        const uint32_t o1 = p1 >= 0 ? (uint32_t)p1 * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
+        c[0][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, o0, 0, 0));
+        c[1][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, o1, 0, 0));
+      }
+      p0 = q0 + 2 < e0 ? ext_list[q0 + 2] : -1;
+      p1 = q0 + 3 < e0 ? ext_list[q0 + 3] : -1;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) { a0[tp] += c[0][tp]; a0[tp] += c[1][tp]; }
+    }
+  }
+  if (bias) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) {
+      const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * tp + 4 * g);
+      a0[tp][0] += b.x; a0[tp][1] += b.y; a0[tp][2] += b.z; a0[tp][3] += b.w;
+    }
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (TAIL) {
+    float sm = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) sm += (a0[tp][0] + a0[tp][1]) + (a0[tp][2] + a0[tp][3]);
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    mean = sm * (1.0f / CO);
+    float qv = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const float d = a0[tp][r] - mean; qv += d * d; }
+    qv += __shfl_xor(qv, 16, 64);
+    qv += __shfl_xor(qv, 32, 64);
+    rstd = 1.0f / sqrtf(qv * (1.0f / CO) + eps);
+  }
+  if (!ok0) return;
+#pragma unroll
+  for (int tp = 0; tp < TO; tp++) {
+    float4 o = make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]);
+    if (TAIL) {
+      const float4 lw = *reinterpret_cast<const float4 *>(ln_w + 16 * tp + 4 * g);
+      const float4 lb = *reinterpret_cast<const float4 *>(ln_b + 16 * tp + 4 * g);
+      o.x = (o.x - mean) * rstd * lw.x + lb.x; o.y = (o.y - mean) * rstd * lw.y + lb.y;
+      o.z = (o.z - mean) * rstd * lw.z + lb.z; o.w = (o.w - mean) * rstd * lw.w + lb.w;
+      if (addend) {
+        const float4 ad = *reinterpret_cast<const float4 *>(addend + v0 * CO + 16 * tp + 4 * g);
+        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+      }
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    }
+    *reinterpret_cast<float4 *>(out + v0 * CO + 16 * tp + 4 * g) = o;
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ float cp_grp_sum(float v) {
+  if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+// one LPR-lane group per output voxel, a lane owns 4 channels (C = 4 * LPR)
+template <int LPR, bool TAIL>
+__global__ void __launch_bounds__(256) k_conv_pairs_sum(const float *__restrict__ contrib,
+                                                        const int32_t *__restrict__ ext_start,
+                                                        const int32_t *__restrict__ ext_list, int64_t n,
+                                                        int64_t n_direct, const float *__restrict__ bias,
+                                                        const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                        float eps, const float *__restrict__ addend, int relu,
+                                                        float *__restrict__ out) {
+  constexpr int C = 4 * LPR, G = 64 / LPR;
+  const int lane = threadIdx.x & 63, li = lane & (LPR - 1);
+  const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gw = bv, gb = bv;
+  if (bias) bv = *reinterpret_cast<const float4 *>(bias + 4 * li);
+  if (TAIL) { gw = *reinterpret_cast<const float4 *>(ln_w + 4 * li); gb = *reinterpret_cast<const float4 *>(ln_b + 4 * li); }
+  for (int64_t v = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR; v < n; v += ngroups) {
+    const int s = ext_start[v], e = ext_start[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < n_direct) acc = *reinterpret_cast<const float4 *>(contrib + v * C + 4 * li);
+    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TAIL && addend) ad = *reinterpret_cast<const float4 *>(addend + v * C + 4 * li);
+    int q = s;
+    for (; q + 1 < e; q += 2) {                       // two rows in flight per trip
+      const int p0 = ext_list[q], p1 = ext_list[q + 1];
+      const float4 c0 = *reinterpret_cast<const float4 *>(contrib + (int64_t)p0 * C + 4 * li);
+      const float4 c1 = *reinterpret_cast<const float4 *>(contrib + (int64_t)p1 * C + 4 * li);
+      acc.x += c0.x; acc.y += c0.y; acc.z += c0.z; acc.w += c0.w;
+      acc.x += c1.x; acc.y += c1.y; acc.z += c1.z; acc.w += c1.w;
+    }
+    if (q < e) {
+      const float4 c0 = *reinterpret_cast<const float4 *>(contrib + (int64_t)ext_list[q] * C + 4 * li);
+      acc.x += c0.x; acc.y += c0.y; acc.z += c0.z; acc.w += c0.w;
+    }
+    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+    if (TAIL) {
+      const float mean = cp_grp_sum<LPR>((acc.x + acc.y) + (acc.z + acc.w)) * (1.0f / C);
+      const float dx = acc.x - mean, dy = acc.y - mean, dz = acc.z - mean, dw = acc.w - mean;
+      const float var = cp_grp_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / C);
+      const float rstd = 1.0f / sqrtf(var + eps);
+      acc.x = dx * rstd * gw.x + gb.x + ad.x; acc.y = dy * rstd * gw.y + gb.y + ad.y;
+      acc.z = dz * rstd * gw.z + gb.z + ad.z; acc.w = dw * rstd * gw.w + gb.w + ad.w;
+      if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    }
+    *reinterpret_cast<float4 *>(out + v * C + 4 * li) = acc;
+  }
+}
+
+template <int CI, int CO>
+static int launch_pairs_gemm(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
+                             const float *w, float *contrib, hipStream_t st) {
+  const size_t lds = (size_t)CI * (CO + 4) * sizeof(float);
+  if (lds > 64 * 1024)      // per device and cheap: no process-wide "done" flag
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_pairs_gemm<CI, CO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_conv_pairs_gemm<CI, CO>), dim3((unsigned)granules), dim3(512), lds, st, feats, pair_in, wg_k, w, contrib);
+  return check_launch("link_conv_pairs_gemm");
+}
+
+extern "C" int link_conv_pairs_supported(int32_t cin, int32_t cout) {
+  const bool sq = cin == cout && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
+  const bool rect = (cin == 16 && cout == 32) || (cin == 32 && cout == 16) || (cin == 32 && cout == 64) ||
+                    (cin == 64 && cout == 32) || (cin == 64 && cout == 128) || (cin == 128 && cout == 64);
+  return (sq || rect) ? 1 : 0;
+}
+
+extern "C" int link_conv_pairs_gemm(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
+                                    const float *w, int32_t cin, int32_t cout, float *contrib, void *stream) {
+  if (rows_pad < 0 || (rows_pad & 127) || rows_pad >= (1LL << 31) || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
+  if (rows_pad == 0) return LINK_OK;
+  if (!feats || !pair_in || !wg_k || !w || !contrib) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const int64_t gr = rows_pad / 128;
+#define LINK_CP(I, O) if (cin == I && cout == O) return launch_pairs_gemm<I, O>(feats, pair_in, wg_k, gr, w, contrib, st)
+  LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
+  LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
+#undef LINK_CP
+  return LINK_ERR_ARG;
+}
+
+extern "C" int link_conv_pairs_sum(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                   int64_t n_direct, int32_t cout, const float *bias, const float *ln_w,
+                                   const float *ln_b, float eps, const float *addend, int32_t relu, float *out,
+                                   void *stream) {
+  if (n < 0 || n_direct < 0 || n_direct > n) return LINK_ERR_ARG;
+  if (cout != 16 && cout != 32 && cout != 64 && cout != 128) return LINK_ERR_ARG;   // power-of-two lane groups
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!contrib || !ext_start || !ext_list || !out) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const bool tail = ln_w != nullptr;
+  const int lpr = cout / 4, gpw = 64 / lpr;
+  int64_t wgs = (n + 4 * gpw - 1) / (4 * gpw);
+  if (wgs > 4096) wgs = 4096;
+#define LINK_CS(LPRV)                                                                                                  \
+  if (lpr == LPRV) {                                                                                                   \
+    if (tail) hipLaunchKernelGGL((k_conv_pairs_sum<LPRV, true>), dim3((unsigned)wgs), dim3(256), 0, st, contrib, ext_start,  \
+                                 ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out);                \
+    else hipLaunchKernelGGL((k_conv_pairs_sum<LPRV, false>), dim3((unsigned)wgs), dim3(256), 0, st, contrib, ext_start,      \
+                            ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out);                     \
+    return check_launch("link_conv_pairs_sum");                                                                        \
+  }
+  LINK_CS(4) LINK_CS(8) LINK_CS(16) LINK_CS(32)
+#undef LINK_CS
+  return LINK_ERR_ARG;
+}
+
+template <int CI, int CO>
+static int launch_centre_sum(const float *feats, const float *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
+                             const int32_t *ext_list, int64_t n, const float *bias, const float *ln_w, const float *ln_b,
+                             float eps, const float *addend, int relu, float *out, hipStream_t st) {
+  const size_t lds = (size_t)CI * (CO + 4) * sizeof(float);
+  const unsigned wgs = (unsigned)((n + 127) / 128);
+  if (ln_w) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, true>), dim3(wgs), dim3(512), lds, st, feats, w, centre, contrib, cbytes, ext_start,
+                       ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, false>), dim3(wgs), dim3(512), lds, st, feats, w, centre, contrib, cbytes, ext_start,
+                       ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
+  }
+  return check_launch("link_conv_centre_sum");
+}
+
+extern "C" int link_conv_centre_sum(const float *feats, const float *w, int32_t centre, const float *contrib,
+                                    int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin,
+                                    int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                                    const float *addend, int32_t relu, float *out, void *stream) {
+  if (n < 0 || centre < 0 || !link_conv_pairs_supported(cin, cout) || (ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
+  if (contrib_rows < 0 || contrib_rows * (int64_t)cout * 4 >= 0xFFFFFFF0LL) return LINK_ERR_ARG;   // 32-bit row offsets
+  const uint32_t cbytes = (uint32_t)(contrib_rows * cout * 4);
+  if (n == 0) return LINK_OK;
+  if (!feats || !w || !ext_start || !out || (contrib_rows > 0 && (!contrib || !ext_list))) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+#define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O>(feats, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
+  LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
+  LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
+#undef LINK_CC
+  return LINK_ERR_ARG;
+}

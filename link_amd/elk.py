@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
@@ -585,9 +585,104 @@ class Conv3d(nn.Module):
         return y
 
 
+# a voxel with more neighbours than this runs on the output-stationary table kernel (conv.hip): measured
+# cross-over of the two forms on MI355X (tools/convbench.py)
+PAIR_DENSITY_MAX = 17.0
+
+
+class _PairPlan:
+    """Pair-list kernel map of one per-output neighbour table (include/link_amd.h: link_conv_pairs_*): the
+    reference's nbmaps / nbsizes (nn/functional/conv.py:109-122) regrouped for one launch -- contribution rows
+    grouped by kernel offset in 128-row granules (`pair_in`, `wg_k`), and the CSR list of every output voxel's
+    rows in ascending offset order (`ext_start`, `ext_list`).  For a submanifold table (odd kernel, same
+    coordinates in and out) the centre pairs are the identity and occupy rows [0, n)."""
+
+    def __init__(self, nbr: torch.Tensor):
+        n, kvol = nbr.shape
+        dev = nbr.device
+        valid = nbr >= 0
+        centre = kvol // 2
+        direct = bool(kvol % 2 == 1 and n > 0 and
+                      torch.equal(nbr[:, centre], torch.arange(n, dtype=nbr.dtype, device=dev)))
+        if direct:
+            valid = valid.clone()
+            valid[:, centre] = False
+        ii, kk = torch.nonzero(valid, as_tuple=True)                   # row-major: (voxel, offset) ascending
+        cnt_k = torch.bincount(kk, minlength=kvol)
+        self.pairs = int(ii.numel())
+        self.n, self.kvol, self.direct = n, kvol, direct
+        self.density = (self.pairs + (n if direct else 0)) / max(n, 1)
+        n_dir_pad = 0                                   # centre rows of a submanifold table: link_conv_centre_sum
+        pad_k = (cnt_k + 127) // 128 * 128
+        base_k = n_dir_pad + torch.cumsum(pad_k, 0) - pad_k
+        start_k = torch.cumsum(cnt_k, 0) - cnt_k
+        order = torch.sort(kk, stable=True).indices                    # pairs grouped by offset, voxel ascending
+        kk_s = kk[order]
+        p_sorted = base_k[kk_s] + (torch.arange(self.pairs, device=dev) - start_k[kk_s])
+        self.rows_pad = int(n_dir_pad + int(pad_k.sum().item()))
+        pair_in = torch.full((max(self.rows_pad, 1),), -1, dtype=torch.int32, device=dev)
+        pair_in[p_sorted] = nbr[ii[order], kk_s]
+        ext_list = torch.empty(max(self.pairs, 1), dtype=torch.int32, device=dev)
+        ext_list[order] = p_sorted.int()
+        ext_start = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        ext_start[1:] = torch.cumsum(valid.sum(1), 0).int()
+        wg_k = torch.cat([torch.full((n_dir_pad // 128,), centre, dtype=torch.int32, device=dev),
+                          torch.repeat_interleave(torch.arange(kvol, dtype=torch.int32, device=dev), pad_k // 128)])
+        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, wg_k, ext_start, ext_list
+        self._contrib: Dict[int, torch.Tensor] = {}
+
+    def contrib(self, cout: int) -> torch.Tensor:
+        buf = self._contrib.get(cout)
+        if buf is None:
+            if len(self._contrib) >= 2:
+                self._contrib.clear()
+            buf = self._contrib[cout] = torch.empty((max(self.rows_pad, 1), cout), dtype=torch.float32,
+                                                    device=self.pair_in.device)
+        return buf
+
+
+def _pair_plan(nbr: torch.Tensor, cin: int, cout: int) -> Optional[_PairPlan]:
+    """The table's pair plan when the pair-list kernels should run it (sparse neighbourhoods, supported
+    widths), else None; built once per table and cached on the (kmaps-cached) table tensor."""
+    if not L.lib().link_conv_pairs_supported(cin, cout):
+        return None
+    plan = getattr(nbr, "_link_pairs", False)
+    if plan is False:
+        plan = _PairPlan(nbr)
+        nbr._link_pairs = plan
+    return plan if plan.density <= PAIR_DENSITY_MAX else None
+
+
+def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False):
+    lib, st = L.lib(), _st()
+    contrib = plan.contrib(cout)
+    L.check(lib.link_conv_pairs_gemm(f.data_ptr(), plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+                                     w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
+    ln_w, ln_b, eps = ln if ln is not None else (None, None, 0.0)
+    if plan.direct:
+        L.check(lib.link_conv_centre_sum(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
+                                         plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
+                                         bias.data_ptr() if bias is not None else None,
+                                         ln_w.data_ptr() if ln_w is not None else None,
+                                         ln_b.data_ptr() if ln_b is not None else None, float(eps),
+                                         addend.data_ptr() if addend is not None else None, 1 if relu else 0,
+                                         out.data_ptr(), st), "link_conv_centre_sum")
+        return out
+    L.check(lib.link_conv_pairs_sum(contrib.data_ptr(), plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n,
+                                    0, cout,
+                                    bias.data_ptr() if bias is not None else None,
+                                    ln_w.data_ptr() if ln_w is not None else None,
+                                    ln_b.data_ptr() if ln_b is not None else None, float(eps),
+                                    addend.data_ptr() if addend is not None else None, 1 if relu else 0,
+                                    out.data_ptr(), st), "link_conv_pairs_sum")
+    return out
+
+
 def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
-              order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd."""
+              order: Optional[torch.Tensor] = None, form: str = "auto") -> torch.Tensor:
+    """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd.  `form`:
+    "auto" picks the pair-list kernels on sparse neighbourhoods and the output-stationary table kernel on
+    dense ones; "table" / "pairs" force one (tests, benches)."""
     if feats.device.type != "cuda":
         raise L.LinkAmdError("subm_conv needs GPU tensors (HIP path; no CPU fallback)")
     cin = feats.shape[1]
@@ -597,6 +692,13 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
+    if form == "pairs" and plan is None:
+        plan = getattr(nbr, "_link_pairs", None)
+        if plan is None:
+            raise L.LinkAmdError(f"subm_conv(form='pairs'): widths {cin}->{cout} not supported by the pair-list kernels")
+    if plan is not None:
+        return _conv_pairs(plan, f, w, cin, cout, out)
     L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(),
                                            order.data_ptr() if order is not None else None, n, cin, cout,
                                            kvol, out.data_ptr(), _st()), "link_subm_conv_forward")
@@ -605,9 +707,10 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
 
 def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
                           order: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float,
-                          addend: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+                          addend: Optional[torch.Tensor], relu: bool = True, form: str = "auto") -> torch.Tensor:
     """relu(addend + LayerNorm(subm_conv(feats))): the block's tail (linkunet.py:183) fused into the
-    convolution's store phase (include/link_amd.h: link_subm_conv_ln_add_relu).  No autograd."""
+    convolution's store phase (include/link_amd.h: link_subm_conv_ln_add_relu, or the epilogue of
+    link_conv_pairs_sum on sparse neighbourhoods).  No autograd."""
     n, cin = feats.shape
     kvol, cin2, cout = kernel.shape
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
@@ -615,10 +718,15 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     w = kernel.detach().contiguous().float()
     add = addend.detach().contiguous().float() if addend is not None else None
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    lw, lb = ln_w.detach().contiguous().float(), ln_b.detach().contiguous().float()
+    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
+    if form == "pairs" and plan is None:
+        plan = getattr(nbr, "_link_pairs", None)
+    if plan is not None:
+        return _conv_pairs(plan, f, w, cin, cout, out, ln=(lw, lb, eps), addend=add, relu=relu)
     L.check(L.lib().link_subm_conv_ln_add_relu(
         f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), order.data_ptr() if order is not None else None,
-        n, cin, cout, kvol, ln_w.detach().contiguous().float().data_ptr(),
-        ln_b.detach().contiguous().float().data_ptr(), float(eps), add.data_ptr() if add is not None else None,
+        n, cin, cout, kvol, lw.data_ptr(), lb.data_ptr(), float(eps), add.data_ptr() if add is not None else None,
         1 if relu else 0, out.data_ptr(), _st()), "link_subm_conv_ln_add_relu")
     return out
 
