@@ -380,7 +380,12 @@ int link_subm_conv_forward(const float *feats, const int32_t *nbr, const float *
                            int64_t n, int32_t cin, int32_t cout, int32_t kvol, float *out, void *stream);
 /* Row N2 (fused epilogue): out = relu(addend + LayerNorm(conv(feats)) * ln_w + ln_b) in the convolution's
  * store phase -- `st.F = self.activate(new_st_F + self.norm_local(st_local.F))` (linkunet.py:183,
- * ts_elk.py:228) with addend = the R_core output.  addend may be NULL, relu 0/1; eps of norm_local. */
+ * ts_elk.py:228) with addend = the R_core output.  addend may be NULL; eps of norm_local.
+ * `relu` is a flag word: bit 0 = ReLU; bit 1 = ln_w / ln_b are a plain per-channel affine out = conv * ln_w + ln_b
+ * (an inference-mode BatchNorm folded to scale / shift, with the convolution's bias folded into the shift) instead
+ * of LayerNorm weights -- the BN (+ residual) (+ ReLU) epilogues of the detection stages (scn.py:83-107,482-489)
+ * and of the encoders' conv blocks (linkunet.py:18-92,217-224).  Same flag word in link_conv_pairs_sum and
+ * link_conv_centre_sum. */
 int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
                                int64_t n, int32_t cin, int32_t cout, int32_t kvol, const float *ln_w,
                                const float *ln_b, float eps, const float *addend, int32_t relu, float *out,

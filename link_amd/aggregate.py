@@ -31,7 +31,7 @@ __all__ = ["voxel_to_aux", "aux_to_voxel", "large_to_small", "small_to_large_v2"
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return L.current_stream_handle()
 
 
 class _BlockMean(Function):

@@ -13,7 +13,7 @@ from . import _lib as L
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return L.current_stream_handle()
 
 
 def _need_gpu(*ts):

@@ -168,23 +168,26 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
         // row N2: out = relu(addend + LayerNorm(conv)) -- the accumulator layout holds 16 channels of ONE
         // voxel per lane (the quarter-waves hold the other 48), so the statistics are 16 in-lane adds + 2
         // cross-lane steps, exactly as in the pre_mix kernel
-        float sm = 0.f;
+        float mean = 0.f, rstd = 1.f;               // bit 1 of ep.relu: ln_w / ln_b are a plain per-channel affine
+        if (!(ep.relu & 2)) {                       // (folded BatchNorm, scn.py:486-489), no statistics
+          float sm = 0.f;
 #pragma unroll
-        for (int tp = 0; tp < TO; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
-        sm += __shfl_xor(sm, 16, 64);
-        sm += __shfl_xor(sm, 32, 64);
-        const float mean = sm * (1.0f / CO);
-        float q = 0.f;
+          for (int tp = 0; tp < TO; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
+          sm += __shfl_xor(sm, 16, 64);
+          sm += __shfl_xor(sm, 32, 64);
+          mean = sm * (1.0f / CO);
+          float q = 0.f;
 #pragma unroll
-        for (int tp = 0; tp < TO; tp++)
+          for (int tp = 0; tp < TO; tp++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float d = acc[j][tp][r] - mean;
-            q += d * d;
-          }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / CO) + ep.eps);
+            for (int r = 0; r < 4; r++) {
+              const float d = acc[j][tp][r] - mean;
+              q += d * d;
+            }
+          q += __shfl_xor(q, 16, 64);
+          q += __shfl_xor(q, 32, 64);
+          rstd = 1.0f / sqrtf(q * (1.0f / CO) + ep.eps);
+        }
         if (v >= 0) {
 #pragma unroll
           for (int tp = 0; tp < TO; tp++) {
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
               const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * CO + ch]);
               o.x = a4.x + o.x; o.y = a4.y + o.y; o.z = a4.z + o.z; o.w = a4.w + o.w;
             }
-            if (ep.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (ep.relu & 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4 *>(&out[v * CO + ch]) = o;
           }
         }
@@ -242,24 +245,27 @@ __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restri
     }
   }
   if (ep.ln_w) {
-    float sm = 0.f;
+    float mean = 0.f, rstd = 1.f;
+    if (!(ep.relu & 2)) {
+      float sm = 0.f;
 #pragma unroll
-    for (int q = 0; q < CPL; q++) sm += (lane + 64 * q < cout) ? acc[q] : 0.f;
-    const float mean = wave_sum(sm) / cout;
-    float qq = 0.f;
+      for (int q = 0; q < CPL; q++) sm += (lane + 64 * q < cout) ? acc[q] : 0.f;
+      mean = wave_sum(sm) / cout;
+      float qq = 0.f;
 #pragma unroll
-    for (int q = 0; q < CPL; q++) {
-      const float d = (lane + 64 * q < cout) ? acc[q] - mean : 0.f;
-      qq += d * d;
+      for (int q = 0; q < CPL; q++) {
+        const float d = (lane + 64 * q < cout) ? acc[q] - mean : 0.f;
+        qq += d * d;
+      }
+      rstd = 1.0f / sqrtf(wave_sum(qq) / cout + ep.eps);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(qq) / cout + ep.eps);
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
       const int co = lane + 64 * q;
       if (co < cout) {
         float o = (acc[q] - mean) * rstd * ep.ln_w[co] + ep.ln_b[co];
         if (ep.addend) o = ep.addend[v * cout + co] + o;
-        if (ep.relu) o = fmaxf(o, 0.f);
+        if (ep.relu & 1) o = fmaxf(o, 0.f);
         out[v * cout + co] = o;
       }
     }
@@ -443,7 +449,7 @@ extern "C" int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr
                                           int32_t kvol, const float *ln_w, const float *ln_b, float eps,
                                           const float *addend, int32_t relu, float *out, void *stream) {
   if (!ln_w || !ln_b) return LINK_ERR_ARG;
-  const conv_epilogue ep = {ln_w, ln_b, addend, eps, relu ? 1 : 0};
+  const conv_epilogue ep = {ln_w, ln_b, addend, eps, relu & 3};
   return subm_conv_impl(feats, nbr, w, order, n, cin, cout, kvol, out, ep, stream);
 }
 

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict
     }
   }
   float mean = 0.f, rstd = 1.f;
-  if (TAIL) {
+  if (TAIL && !(relu & 2)) {                         // bit 1: ln_w / ln_b are a per-channel affine (folded BatchNorm)
     float sm = 0.f;
 #pragma unroll
     for (int tp = 0; tp < TO; tp++) sm += (a0[tp][0] + a0[tp][1]) + (a0[tp][2] + a0[tp][3]);
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict
         const float4 ad = *reinterpret_cast<const float4 *>(addend + v0 * CO + 16 * tp + 4 * g);
         o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
       }
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (relu & 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     }
     *reinterpret_cast<float4 *>(out + v0 * CO + 16 * tp + 4 * g) = o;
   }
@@ -240,13 +240,16 @@ __global__ void __launch_bounds__(256) k_conv_pairs_sum(const float *__restrict_
     }
     acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
     if (TAIL) {
-      const float mean = cp_grp_sum<LPR>((acc.x + acc.y) + (acc.z + acc.w)) * (1.0f / C);
+      float mean = 0.f, rstd = 1.f;
+      if (!(relu & 2)) {
+        mean = cp_grp_sum<LPR>((acc.x + acc.y) + (acc.z + acc.w)) * (1.0f / C);
+        const float ex = acc.x - mean, ey = acc.y - mean, ez = acc.z - mean, ew = acc.w - mean;
+        rstd = 1.0f / sqrtf(cp_grp_sum<LPR>((ex * ex + ey * ey) + (ez * ez + ew * ew)) * (1.0f / C) + eps);
+      }
       const float dx = acc.x - mean, dy = acc.y - mean, dz = acc.z - mean, dw = acc.w - mean;
-      const float var = cp_grp_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / C);
-      const float rstd = 1.0f / sqrtf(var + eps);
       acc.x = dx * rstd * gw.x + gb.x + ad.x; acc.y = dy * rstd * gw.y + gb.y + ad.y;
       acc.z = dz * rstd * gw.z + gb.z + ad.z; acc.w = dw * rstd * gw.w + gb.w + ad.w;
-      if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+      if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
     }
     *reinterpret_cast<float4 *>(out + v * C + 4 * li) = acc;
   }

@@ -47,7 +47,7 @@ _IO_DTYPES = {torch.float32: L.IO_F32, torch.float16: L.IO_F16, torch.bfloat16: 
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return L.current_stream_handle()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -204,6 +204,11 @@ class ElkCorePlan:
 
     def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
         """Bind the block's parameters (fp32, contiguous, on the plan's device)."""
+        key = tuple((p.data_ptr(), p._version, tuple(p.shape), p.dtype) if p is not None else None
+                    for p in (w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b))
+        if self.__dict__.get("_bound") == key:              # same storage, unmodified since the last bind
+            return self
+        self._bound = key
         self._params = tuple(None if t is None else t.detach().contiguous().float().view(-1)
                              for t in (w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b))
         b = self.buf
@@ -233,7 +238,7 @@ class ElkCorePlan:
         if out is not None:
             assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
         self.buf.out = (out if out is not None else own).data_ptr()
-        st = torch.cuda.current_stream().cuda_stream
+        st = L.current_stream_handle()
         if self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
                           1 if build_index else 0, st)
@@ -476,6 +481,30 @@ class _StridedMap:
         self.out_coords, self.nbr_down, self.nbr_up = out_coords, nbr_down, nbr_up
 
 
+def neighbor_table_of(x: SparseTensor, kernel_size):
+    """Per-output neighbour table of a stride-1 convolution over x's voxels: (int32[N, K], spatial tile order or
+    None), cached on the tensor's kmaps (every convolution with this kernel size over these coordinates shares it)."""
+    key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, tuple(kernel_size))
+    nbr = x.kmaps.get(key)
+    if nbr is None:
+        # neighbour of voxel i at coords_i + offset*tensor_stride (conv.py:105-113: stride=input.stride)
+        ts = int(x.s[0])
+        try:
+            nbr = foreign_neighbor_map(x.C, kernel_size[0], step=ts)
+        except GridTooLarge:
+            offs = get_kernel_offsets(kernel_size, stride=x.s, device=x.F.device)
+            nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
+        # spatially coherent voxel order for the table kernel's tile-level skipping: voxels grouped by
+        # (4*stride)^3 blocks of the dense block grid (the LinK index with a small block edge)
+        try:
+            order = BlockIndex(x.C, 4 * ts, want_idx64=False).perm
+        except GridTooLarge:
+            order = None
+        nbr = (nbr, order)
+        x.kmaps[key] = nbr
+    return nbr
+
+
 class Conv3d(nn.Module):
     """Sparse convolution with the reference's parameter layout (`kernel` [K, Cin, Cout], optional `bias`;
     torchsparse/nn/modules/conv.py:15-72; init U(+-1/sqrt(Cin*K)), or Cout*K when transposed) for the forms
@@ -515,25 +544,7 @@ class Conv3d(nn.Module):
     def _neighbor_table(self, x: SparseTensor):
         """(int32[N, K] input row of every (output voxel, kernel offset), -1 absent; spatial voxel order or
         None), cached on the tensor's kmaps like the reference's kernel maps (nn/functional/conv.py:103,122)."""
-        key = ("link_conv_nbr", x.C.data_ptr(), x.C.shape[0], x.s, self.kernel_size)
-        nbr = x.kmaps.get(key)
-        if nbr is None:
-            # neighbour of voxel i at coords_i + offset*tensor_stride (conv.py:105-113: stride=input.stride)
-            ts = int(x.s[0])
-            try:
-                nbr = foreign_neighbor_map(x.C, self.kernel_size[0], step=ts)
-            except GridTooLarge:
-                offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
-                nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
-            # spatially coherent voxel order for the kernel's tile-level skipping: voxels grouped by
-            # (4*stride)^3 blocks of the dense block grid (the LinK index with a small block edge)
-            try:
-                order = BlockIndex(x.C, 4 * ts, want_idx64=False).perm
-            except GridTooLarge:
-                order = None
-            nbr = (nbr, order)
-            x.kmaps[key] = nbr
-        return nbr
+        return neighbor_table_of(x, self.kernel_size)
 
     def _strided_map(self, x: SparseTensor) -> _StridedMap:
         """Down-sampling kernel map, cached under the reference's key (conv.py:103): output coordinates =
@@ -665,7 +676,7 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
                                          bias.data_ptr() if bias is not None else None,
                                          ln_w.data_ptr() if ln_w is not None else None,
                                          ln_b.data_ptr() if ln_b is not None else None, float(eps),
-                                         addend.data_ptr() if addend is not None else None, 1 if relu else 0,
+                                         addend.data_ptr() if addend is not None else None, int(relu),
                                          out.data_ptr(), st), "link_conv_centre_sum")
         return out
     L.check(lib.link_conv_pairs_sum(contrib.data_ptr(), plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n,
@@ -673,7 +684,7 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
                                     bias.data_ptr() if bias is not None else None,
                                     ln_w.data_ptr() if ln_w is not None else None,
                                     ln_b.data_ptr() if ln_b is not None else None, float(eps),
-                                    addend.data_ptr() if addend is not None else None, 1 if relu else 0,
+                                    addend.data_ptr() if addend is not None else None, int(relu),
                                     out.data_ptr(), st), "link_conv_pairs_sum")
     return out
 
@@ -707,10 +718,13 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
 
 def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
                           order: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float,
-                          addend: Optional[torch.Tensor], relu: bool = True, form: str = "auto") -> torch.Tensor:
+                          addend: Optional[torch.Tensor], relu: bool = True, form: str = "auto",
+                          affine: bool = False) -> torch.Tensor:
     """relu(addend + LayerNorm(subm_conv(feats))): the block's tail (linkunet.py:183) fused into the
     convolution's store phase (include/link_amd.h: link_subm_conv_ln_add_relu, or the epilogue of
-    link_conv_pairs_sum on sparse neighbourhoods).  No autograd."""
+    link_conv_pairs_sum on sparse neighbourhoods).  `affine=True`: ln_w / ln_b are a per-channel scale / shift
+    (an inference BatchNorm folded with the convolution's bias) and no statistics are taken:
+    relu(addend + conv * ln_w + ln_b) -- the BN / residual / ReLU epilogues of the detection stages.  No autograd."""
     n, cin = feats.shape
     kvol, cin2, cout = kernel.shape
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
@@ -722,12 +736,13 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
     if form == "pairs" and plan is None:
         plan = getattr(nbr, "_link_pairs", None)
+    flags = (1 if relu else 0) | (2 if affine else 0)
     if plan is not None:
-        return _conv_pairs(plan, f, w, cin, cout, out, ln=(lw, lb, eps), addend=add, relu=relu)
+        return _conv_pairs(plan, f, w, cin, cout, out, ln=(lw, lb, eps), addend=add, relu=flags)
     L.check(L.lib().link_subm_conv_ln_add_relu(
         f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), order.data_ptr() if order is not None else None,
         n, cin, cout, kvol, lw.data_ptr(), lb.data_ptr(), float(eps), add.data_ptr() if add is not None else None,
-        1 if relu else 0, out.data_ptr(), _st()), "link_subm_conv_ln_add_relu")
+        flags, out.data_ptr(), _st()), "link_subm_conv_ln_add_relu")
     return out
 
 
@@ -970,17 +985,35 @@ class SparseConvTensor:
 
 def spconv2ts(sct):
     """ts_elk.py:10-33: (batch,z,y,x) indices -> (x,y,z,batch) coords, stride 1; keep spconv metadata."""
-    coords = sct.indices[:, [3, 2, 1, 0]].contiguous()
+    # the converted coordinates and the maps built on them are kept in the tensor's indice_dict (the dict spconv
+    # itself shares between the tensors of one coordinate set), so the blocks and convolutions of a stage reuse
+    # one neighbour table / block index instead of rebuilding them per call; the entry holds `indices` alive,
+    # which keeps its address -- part of the key -- from being reused
+    ind = sct.indices
+    ent = None
+    if isinstance(getattr(sct, "indice_dict", None), dict):
+        key = ("link_ts", ind.data_ptr(), ind.shape[0], ind._version)
+        ent = sct.indice_dict.get(key)
+        if ent is None:
+            ent = sct.indice_dict[key] = (ind[:, [3, 2, 1, 0]].contiguous(), ind, {}, {})
+    coords = ent[0] if ent is not None else ind[:, [3, 2, 1, 0]].contiguous()
     st = SparseTensor(sct.features, coords, 1)
+    if ent is not None:
+        st.cmaps, st.kmaps = ent[2], ent[3]
     save = {k: getattr(sct, k, None) for k in ("batch_size", "benchmark", "benchmark_record", "grid",
                                                "indice_dict", "spatial_shape", "voxel_num")}
     save["_cls"] = type(sct)
+    save["_ind"] = (coords, ind)
     return st, save
 
 
 def ts2spconv(st: SparseTensor, sct_save: dict):
     """ts_elk.py:36-59."""
-    indices = st.coords[:, [3, 2, 1, 0]].contiguous()
+    src = sct_save.get("_ind")
+    if src is not None and st.coords is src[0]:
+        indices = src[1]                               # coordinates untouched: hand the caller's indices back
+    else:
+        indices = st.coords[:, [3, 2, 1, 0]].contiguous()
     cls = sct_save.get("_cls", SparseConvTensor)
     sct = cls(st.feats, indices, spatial_shape=sct_save["spatial_shape"], batch_size=sct_save["batch_size"],
               grid=sct_save["grid"], voxel_num=sct_save["voxel_num"], indice_dict=sct_save["indice_dict"],

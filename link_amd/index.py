@@ -47,7 +47,7 @@ _workspaces: Dict[Tuple[int, int], _Workspace] = {}
 
 def _workspace(device) -> _Workspace:
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+           L.current_stream_handle())
     ws = _workspaces.get(key)
     if ws is None:
         ws = _workspaces[key] = _Workspace(device)
@@ -59,7 +59,7 @@ def coords_bounds(coords: torch.Tensor) -> Tuple[Tuple[int, ...], Tuple[int, ...
     imax, imin = 2 ** 31 - 1, -2 ** 31
     bbox = torch.tensor([imax] * 4 + [imin] * 4, dtype=torch.int32, device=coords.device)
     L.check(L.lib().link_coords_bbox(coords.data_ptr(), coords.shape[0], bbox.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream), "link_coords_bbox")
+                                     L.current_stream_handle()), "link_coords_bbox")
     b = bbox.tolist()
     return tuple(b[:4]), tuple(b[4:])
 
@@ -120,7 +120,7 @@ class BlockIndex:
             self.idx_query.data_ptr() if want_idx64 else None, self.perm.data_ptr(), self.vox_sorted.data_ptr(),
             self.pos_blk.data_ptr(),
             self.blk_start.data_ptr(), self.blk_coords.data_ptr(), self.counts_buf.data_ptr(),
-            self.hdr.data_ptr(), torch.cuda.current_stream().cuda_stream), "link_index_build")
+            self.hdr.data_ptr(), L.current_stream_handle()), "link_index_build")
 
     # -- lazily synchronised facts ------------------------------------------------------------------
     @property
@@ -153,7 +153,7 @@ class BlockIndex:
             L.check(L.lib().link_neighbor_map(self.blk_coords.data_ptr(), self.cell_blk.data_ptr(),
                                               ctypes.byref(self.grid), self.hdr.data_ptr(), m, int(r), 1,
                                               1 if transpose else 0, nbr.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "link_neighbor_map")
+                                              L.current_stream_handle()), "link_neighbor_map")
             self._nbr[key] = nbr
         return self._nbr[key]
 
@@ -181,7 +181,7 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, st
     if grid.cells > MAX_CELLS:
         raise GridTooLarge(f"dense block grid would need {grid.cells} cells")
     table = torch.zeros(grid.cells, dtype=torch.int32, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
+    st = L.current_stream_handle()
     L.check(L.lib().link_cell_table_build(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), None,
                                           st), "link_cell_table_build")
     L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
