@@ -83,11 +83,20 @@ __device__ __forceinline__ float group_sum(float v) {
 // Inline asm stores are invisible to the compiler's vmcnt bookkeeping; that only makes its later
 // waits conservative (vmcnt retires in order), never too weak.  g_wt_stores toggles it for A/B tests.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+// The asm form below was validated (repeat-bitwise tests + stale-cache tests) with the toolchain of ROCm 7.2
+// (clang 22).  It carries a hand-placed hazard pad the compiler cannot see, so any OTHER compiler major falls
+// back to an ordinary store until it has been re-validated -- the dense-cell kernels (dense_common.h) already
+// use the compiler-visible form, __builtin_amdgcn_raw_buffer_store_b128 with aux = sc1.
+#define LINK_STORE_WT_VALIDATED_CLANG 22
 __device__ __forceinline__ void store_wt(float4 *p, float4 v) {
+#if defined(__clang_major__) && __clang_major__ == LINK_STORE_WT_VALIDATED_CLANG
   const v4f_t x = {v.x, v.y, v.z, v.w};
   // s_nop 1: a VMEM store of more than 8 bytes needs wait states before its data VGPRs are overwritten;
   // hipcc pads that hazard for its own instructions but cannot see inside an asm statement.
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+#else
+  *p = v;
+#endif
 }
 __device__ __forceinline__ void store_out(float4 *p, float4 v, bool wt) {
   if (wt) store_wt(p, v);

@@ -404,12 +404,10 @@ static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const flo
                                int64_t n, int kvol, float *out, const conv_epilogue &ep, hipStream_t st) {
   const size_t lds = ((size_t)2 * CO * (CI + 4) + (size_t)4 * 27 * NT * 16) * sizeof(float);
   if (lds > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
+    // per device and cheap (a host-side table write): no process-wide once-flag, which a second GPU or a
+    // device reset would never pass again
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 4 * NT - 1) / (4 * NT);

@@ -116,12 +116,10 @@ static int launch_premix_tlp(const float *feats, const float *w_pre, const float
   int64_t wgs = (tiles + 3) / 4;
   if (wgs > g_premix_wgs_fwd()) wgs = g_premix_wgs_fwd();
   if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per kernel (160 KB per CU on gfx950)
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_tlp<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
+    // per device and cheap (a host-side table write): no process-wide once-flag, which a second GPU or a
+    // device reset would never pass again
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_tlp<C>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_premix_ln_tlp<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, ln_b, n,
                      eps, fin, g_wt_fwd());
@@ -2217,12 +2215,10 @@ static int launch_premix_bwd(const float *feats, const float *w_pre, const float
                              hipStream_t st) {
   size_t lds = ((size_t)2 * C * (C + 4) + 8 * C) * sizeof(float);
   if (lds > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_bwd<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
+    // per device and cheap (a host-side table write): no process-wide once-flag, which a second GPU or a
+    // device reset would never pass again
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_premix_ln_bwd<C>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_premix_ln_bwd<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, g_fin, n, eps,
                      g_pre, g_feats, partials);

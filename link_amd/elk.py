@@ -82,7 +82,9 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
                                         al.data_ptr() if al is not None else None,
                                         index.blk_start.data_ptr(), index.hdr.data_ptr(), ctypes.byref(desc),
                                         n, m_cap, S.data_ptr(), st), "link_modulate_block_sum")
-    if c % 4 == 0 and r <= 3:
+    # the block-gather kernel addresses the table with 32-bit byte offsets: beyond 4 GiB (C = 256 above ~1.4 M
+    # voxels when M is not known) the one-kernel gather + de-modulate with 64-bit row addressing takes over
+    if c % 4 == 0 and r <= 3 and (m_cap + 1) * (parts * c + 1) * 4 < 2 ** 32:
         A = torch.empty((m_cap, parts * c), dtype=torch.float32, device=dev)
         L.check(lib.link_block_gather(S.data_ptr(), index.blk_coords.data_ptr(),
                                       index.cell_blk.data_ptr(), ctypes.byref(index.grid), index.hdr.data_ptr(),
@@ -896,6 +898,39 @@ class _ELKBase(nn.Module):
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
         return out
 
+    def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
+        """R_core as the reference writes it (linkunet.py:124-176), op by op on voxel_to_aux / aux_to_voxel:
+        any grid extent, any width; differentiable through the ops' autograd Functions."""
+        from .aggregate import aux_to_voxel, voxel_to_aux
+        c = st.F.shape[1]
+        fin = self.pre_mix(st.F.float())
+        xyz = st.C[:, :3].float()
+        if coord_div != 1.0:
+            xyz = xyz / coord_div
+        th = TF.linear(xyz, w_pos)
+        if alpha is not None:
+            th = th * alpha
+        if c != cg:
+            th = th.repeat([1, c // cg])
+        sin, cos = torch.sin(th), torch.cos(th)
+        if self.baseop == "sin":
+            x = torch.cat([fin * sin, fin * cos], dim=1)
+        elif self.baseop == "cos":
+            x = torch.cat([fin * cos, fin * sin], dim=1)
+        else:
+            x = torch.cat([fin * cos, fin * sin, fin * th], dim=1)
+        big = SparseTensor(x, st.C, st.s)
+        big.cmaps, big.kmaps = st.cmaps, st.kmaps
+        small, idx, counts = voxel_to_aux(big, s_eff)
+        v = aux_to_voxel(small, big, idx, counts, r).F
+        if self.baseop == "sin":
+            new = v[:, :c] * cos - v[:, c:] * sin
+        elif self.baseop == "cos":
+            new = v[:, :c] * cos + v[:, c:] * sin
+        else:
+            new = v[:, :c] * cos + v[:, c:2 * c] * sin + (v[:, 2 * c:] - fin * th)
+        return self.norm(new)
+
     def _core(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         needs_grad0 = torch.is_grad_enabled() and (st.F.requires_grad or any(
             p.requires_grad for p in self.parameters()))
@@ -903,7 +938,12 @@ class _ELKBase(nn.Module):
             out = self._core_dense(st, s_eff, r, w_pos, alpha, cg, coord_div)
             if out is not None:
                 return out
-        index = link_index_of(st, s_eff)
+        try:
+            index = link_index_of(st, s_eff)
+        except GridTooLarge:
+            # coordinates spread over more cells than the dense block grid may hold: the reference algorithm on
+            # the op kernels (hash / unique / query), as voxel_to_aux does on its own for such inputs
+            return self._core_generic(st, s_eff, r, w_pos, alpha, cg, coord_div)
         args = (st.F, st.C, index, self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias,
                 w_pos, alpha, self.norm.weight, self.norm.bias, self.baseop, cg, r, coord_div, 1e-6)
         needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(

@@ -147,6 +147,32 @@ def test_tselk_wrong_spatial_shape_contract(grid, n):
             plans[0].check()
 
 
+def test_core_on_coordinates_beyond_the_dense_grid_limit():
+    """Two clusters 40 000 cells apart in every axis: the dense block grid would need > 2^28 cells, so the block
+    core takes the reference algorithm on the op kernels (hash / unique / query) -- same result as the oracle,
+    forward and backward."""
+    import link_amd as la
+    torch.manual_seed(5)
+    C, s, r = 16, 3, 2
+    blk = la.ELKBlock(C, C, groups=1, baseop="cos_x").cuda()
+    a = s_uniform(1500, grid=24, seed=1)
+    b = s_uniform(1500, grid=24, seed=2)
+    b[:, :3] += 40000
+    coords = torch.cat([a, b]).contiguous()
+    feats = torch.randn(3000, C, generator=torch.Generator().manual_seed(3))
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords, params, s, r, "cos_x", 1, agg=O.aggregate_c)
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), 1)
+    with torch.no_grad():
+        core = blk.eval()._core(st, s, r, blk.pos_weight[0].weight, blk.alpha, C, 1.0)
+    assert rel_err(core.cpu().numpy(), ref.numpy()) < TOL
+    f = feats.cuda().requires_grad_(True)
+    out = blk.train()._core(la.SparseTensor(f, coords.cuda(), 1), s, r, blk.pos_weight[0].weight, blk.alpha, C, 1.0)
+    assert rel_err(out.detach().cpu().numpy(), ref.numpy()) < TOL
+    out.square().sum().backward()
+    assert torch.isfinite(f.grad).all() and f.grad.abs().sum() > 0
+
+
 def test_cfg2_full_size_core():
     """BASELINE cfg2: N=100k, C=64, cos g=2, r=3, s=7 through the fused core vs the oracle (a few s)."""
     import link_amd as la
