@@ -131,25 +131,31 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict
       a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * LD + 16 * tp], f0[t].w, a0[tp], 0, 0, 0);
     }
   }
-  // the other offsets' rows, ascending kernel offset (fixed summation order), two per trip: the lists are
+  // the other offsets' rows, ascending kernel offset (fixed summation order), NQ per trip: the lists are
   // short but the trip count of a wave is the maximum over its 16 voxels, and a trip is two dependent round
   // trips.  Absent rows read through an out-of-range buffer offset (returns 0): no branch around the loads.
   if (__any(s0 < e0)) {
+    constexpr int NQ = (TO <= 4) ? 4 : 2;              // rows in flight per trip (register budget: NQ * TO dwordx4)
     const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(contrib), 0, contrib_bytes, 0x00020000);
-    int p0 = pf0, p1 = pf1;                            // first trip's row ids were fetched before the MFMAs
-    for (int q0 = s0; __any(q0 < e0); q0 += 2) {
-      floatx4 c[2][TO];
+    int p[NQ];
+    p[0] = pf0; p[1] = pf1;                            // the first trip's row ids were fetched before the MFMAs
 #pragma unroll
-      for (int tp = 0; tp < TO; tp++) {
-        const uint32_t o0 = p0 >= 0 ? (uint32_t)p0 * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
-        const uint32_t o1 = p1 >= 0 ? (uint32_t)p1 * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
-        c[0][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, o0, 0, 0));
-        c[1][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, o1, 0, 0));
-      }
-      p0 = q0 + 2 < e0 ? ext_list[q0 + 2] : -1;
-      p1 = q0 + 3 < e0 ? ext_list[q0 + 3] : -1;
+    for (int j = 2; j < NQ; j++) p[j] = s0 + j < e0 ? ext_list[s0 + j] : -1;
+    for (int q0 = s0; __any(q0 < e0); q0 += NQ) {
+      floatx4 c[NQ][TO];
 #pragma unroll
-      for (int tp = 0; tp < TO; tp++) { a0[tp] += c[0][tp]; a0[tp] += c[1][tp]; }
+      for (int j = 0; j < NQ; j++)
+#pragma unroll
+        for (int tp = 0; tp < TO; tp++) {
+          const uint32_t off = p[j] >= 0 ? (uint32_t)p[j] * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
+          c[j][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, off, 0, 0));
+        }
+#pragma unroll
+      for (int j = 0; j < NQ; j++) p[j] = q0 + NQ + j < e0 ? ext_list[q0 + NQ + j] : -1;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++)
+#pragma unroll
+        for (int j = 0; j < NQ; j++) a0[tp] += c[j][tp];
     }
   }
   if (bias) {

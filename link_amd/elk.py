@@ -852,6 +852,20 @@ class _SubmConv(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # modules
 # ------------------------------------------------------------------------------------------------
+DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take
+
+
+def _dense_occupancy_ok(coords: torch.Tensor, s: int) -> bool:
+    """True when the frame's blocks are small enough for the dense-cell layout (one D2H sync; see _core_dense)."""
+    b = torch.div(coords[:, :3], s, rounding_mode="floor").long()
+    b -= b.min(0).values
+    ext = b.max(0).values + 1
+    lin = ((coords[:, 3].long() * ext[0] + b[:, 0]) * ext[1] + b[:, 1]) * ext[2] + b[:, 2]
+    cnt = torch.unique(lin, return_counts=True)[1]
+    m, mx = int(cnt.numel()), int(cnt.max().item())
+    return coords.shape[0] <= DENSE_MAX_MEAN * m and mx <= DENSE_MAX_CELL
+
+
 class _ELKBase(nn.Module):
     def _core_dense(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         """Inference R_core on the dense-cell layout (ElkCorePlan), or None when the frame's block grid is
@@ -864,6 +878,22 @@ class _ELKBase(nn.Module):
             return None
         half = feats.dtype != torch.float32
         if half and (c > 64 or s_eff ** 3 > 352):            # half rows: fused kernels only
+            return None
+        # The dense-cell kernels are built for frames whose occupied cells hold a handful of voxels each (cfg1 / cfg2:
+        # ~2); a cell is one wave's serial work there.  LiDAR-like frames (20+ voxels per occupied block, 100+
+        # in the densest) belong to the general layout, whose kernels split big blocks over lanes.  The bounds
+        # alone cannot tell the two apart, so the occupancy is measured once per coordinate set (cached in cmaps;
+        # one small sync, like coords_bounds).  Caller-supplied bounds (TSELKBlock + spatial_shape) promise a
+        # sync-free call, so those frames use the general layout unless the module opts in (dense_layout = True).
+        okey = ("link_dense_ok", coords.data_ptr(), n, s_eff)
+        ok = st.cmaps.get(okey)
+        if ok is None:
+            if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) and not getattr(self, "dense_layout", False):
+                ok = False
+            else:
+                ok = _dense_occupancy_ok(coords, s_eff)
+            st.cmaps[okey] = ok
+        if not ok:
             return None
         bkey = ("link_bounds", coords.data_ptr(), n)
         bounds = st.cmaps.get(bkey)

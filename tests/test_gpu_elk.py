@@ -112,16 +112,17 @@ def test_tselk_block_vs_oracle():
     assert rel_err(out.features.cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("grid,n", [(80, 6000), (56, 60000)])      # general layout / dense-cell layout
-def test_tselk_wrong_spatial_shape_contract(grid, n):
+@pytest.mark.parametrize("dense", [False, True])                     # general layout / dense-cell layout (opt-in)
+def test_tselk_wrong_spatial_shape_contract(dense):
     """spatial_shape smaller than the data (caller error): voxels outside it are dropped by the index.  The
     contract: their core rows are zeros -- never uninitialised memory -- rows of the other
     voxels are finite, and the status word reports it (ElkCorePlan.check / BlockIndex.M raise)."""
     import link_amd as la
     import link_amd._lib as L
     torch.manual_seed(3)
-    C, stride = 32, 7
+    C, stride, grid, n = 32, 7, 80, 6000
     blk = la.TSELKBlock(C, C, baseop="cos").cuda().eval()
+    blk.dense_layout = dense           # caller-supplied bounds use the general layout unless the module opts in
     coords = s_uniform(n, grid=grid, seed=9)
     feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
     indices = coords[:, [3, 2, 1, 0]].contiguous().cuda()
@@ -142,6 +143,7 @@ def test_tselk_wrong_spatial_shape_contract(grid, n):
         assert (core[outside] == 0).all()
         assert (core[~outside].abs().sum(1) > 0).all()
     plans = [p for p in blk.__dict__.get("_dc_plans", {}).values() if p is not None]
+    assert bool(plans) == dense
     if plans:
         with pytest.raises(L.LinkAmdError):
             plans[0].check()
