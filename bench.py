@@ -177,17 +177,20 @@ def cfg3_mode(args, la, dev, rank, world, dist):
     coords, feats = torch.from_numpy(co).to(dev), torch.from_numpy(fe).to(dev)
     n = coords.shape[0]
     torch.manual_seed(0)
-    net = LE.build_stages(la, 4, 64, "cos_x", 1, 4).to(dev)
+    # the reference's ELKEncoder encoder half, class by class (tests/link_encoder.py mirrors linkencoder.py:186-290
+    # with the reference's attribute names), its Conv3d -> BatchNorm -> ReLU runs fused for inference
+    net = la.fuse_for_inference(LE.build_reference_shaped_encoder(la, 64, "cos_x", 1)).to(dev)
+    net.elk = [getattr(net, f"elk{i}") for i in (1, 2, 3, 4)]
     st0 = la.SparseTensor(feats, coords, 1)
     with torch.no_grad():
-        sizes = [o.C.shape[0] for o in net.eval()(st0, 3, 2)]
+        sizes = [o.C.shape[0] for o in net.eval()(st0, 3, 2)[1]]
 
     def step(train):
         f = feats.detach().requires_grad_(train)
         x = la.SparseTensor(f, coords, 1)
         x.kmaps, x.cmaps = st0.kmaps, st0.cmaps
         if train:
-            net(x, 3, 2)[-1].F.square().sum().backward()
+            net(x, 3, 2)[1][-1].F.square().sum().backward()
         else:
             with torch.no_grad():
                 net(x, 3, 2)
@@ -241,8 +244,8 @@ def cfg3_mode(args, la, dev, rank, world, dist):
             "steps": k, "warmup": w, "ms_per_step": 1e3 * t_fwd / k, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (S-kitti ray-cast frame, SURVEY.md 8d; random-init weights)",
             "headline": False,
-            "config": {"workload": "cfg3 (labelled secondary mode): LinK encoder stages, eval forward, C=64 cos_x (2x3)^3 "
-                                   "r=2, one S-kitti frame per GPU, warm kernel maps",
+            "config": {"workload": "cfg3 (labelled secondary mode): encoder half of ELKEncoder (stem + 4 stages), eval forward, "
+                                   "C=64 cos_x (2x3)^3 r=2, Conv-BN-ReLU runs fused, one S-kitti frame per GPU, warm kernel maps",
                        "voxels": n, "stage_voxels": sizes, "blocks_s6_on_input_voxels": int(block_stats(co, 6)[1]),
                        "parallelism": f"dp{world}"},
             "fwd_bwd_ms": 1e3 * t_tr / max(1, k // 4), "elk_blocks_fwd_ms": 1e3 * elk_t[0] / 5,

@@ -14,7 +14,7 @@ from .elk import (Conv3d, ELKBlock, ElkCorePlan, SparseConvTensor, TSELKBlock, e
 from .detstage import ELKv3Stage, SparseBasicBlock, SubMConv3d
 from .functional import calc_ti_weights, spcount, spdevoxelize, sphash, sphashquery, spvoxelize
 from .index import BlockIndex, coords_bounds
-from .modules import BatchNorm, LeakyReLU, ReLU, fapply
+from .modules import BatchNorm, LeakyReLU, ReLU, fapply, fuse_for_inference
 from .pointvoxel import initial_voxelize, point_to_voxel, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 from .utils import get_kernel_offsets, make_ntuple

@@ -14,13 +14,16 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // s_waitcnt vmcnt the compiler emits is an exact count instead of the vmcnt(0) a conditional VMEM op forces.
 // Tables handled here are < 4 GiB (checked by the launchers).
 #define DC_OOB 0xFFFFFFF0u
+#ifndef DC_ST_AUX
+#define DC_ST_AUX 16      /* sc1: write-through; 0 = ordinary write-back stores (A/B: LINK_AMD_CXXFLAGS=-DDC_ST_AUX=0) */
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_rsrc(const void *base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float4 v) {
   const v4i_t x = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z),
                    __builtin_bit_cast(int, v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, byte_off, 0, 16 /* sc1 */);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, byte_off, 0, DC_ST_AUX);
 }
 __device__ __forceinline__ void st16i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int4 v) {
   const v4i_t x = {v.x, v.y, v.z, v.w};

@@ -55,7 +55,7 @@ __device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_o
       x.x = (int)(bf16_rne(v.x) | (bf16_rne(v.y) << 16));
       x.y = (int)(bf16_rne(v.z) | (bf16_rne(v.w) << 16));
     }
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, valid ? elem_off * 2u : DC_OOB, 0, 16 /* sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, valid ? elem_off * 2u : DC_OOB, 0, DC_ST_AUX);
   }
 }
 

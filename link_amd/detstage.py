@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .elk import (SparseConvTensor, TSELKBlock, _SubmConv, neighbor_table_of, spconv2ts, subm_conv,
+from .elk import (SparseConvTensor, TSELKBlock, _SubmConv, fold_batchnorm, neighbor_table_of, spconv2ts, subm_conv,
                   subm_conv_ln_add_relu)
 from .utils import get_kernel_offsets
 
@@ -99,18 +99,7 @@ class SubMConv3d(nn.Module):
 
 def _fold(conv: SubMConv3d, bn: nn.BatchNorm1d):
     """(scale, shift) of BatchNorm (running statistics) applied to conv + bias: y = conv * scale + shift."""
-    ver = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
-        ((conv.bias._version,) if conv.bias is not None else ()) + (bn.weight.device,)
-    hit = bn.__dict__.get("_link_fold")
-    if hit is not None and hit[0] == ver:              # eight tiny torch launches per call otherwise
-        return hit[1], hit[2]
-    sc = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-    sh = bn.bias.detach().float() - bn.running_mean.float() * sc
-    if conv.bias is not None:
-        sh = sh + conv.bias.detach().float() * sc
-    sc, sh = sc.contiguous(), sh.contiguous()
-    bn.__dict__["_link_fold"] = (ver, sc, sh)
-    return sc, sh
+    return fold_batchnorm(bn, conv.bias)
 
 
 def _conv_bn(conv: SubMConv3d, bn: nn.BatchNorm1d, feats, nbr, order, addend=None, relu=False):

@@ -597,6 +597,33 @@ class Conv3d(nn.Module):
         y.cmaps.setdefault(y.stride, y.coords)
         return y
 
+    def forward_affine(self, x: SparseTensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool) -> SparseTensor:
+        """Inference only: relu?(conv(x) * scale + shift) in ONE launch -- the convolution with a following
+        BatchNorm (running statistics, folded to scale / shift together with this module's bias by the caller)
+        and ReLU in its finish phase (linkunet.py:23-92: BasicConvolutionBlock / ResidualBlock / *_tail)."""
+        feats = x.F
+        if self.stride[0] == 1:
+            coords, stride = x.C, x.s
+            table, order = (None, None) if self.kernel_volume == 1 else self._neighbor_table(x)
+        elif not self.transposed:
+            km = self._strided_map(x)
+            table, order = km.nbr_down, None
+            coords, stride = km.out_coords, tuple(x.s[k] * self.stride[k] for k in range(3))
+        else:
+            stride = tuple(x.s[k] // self.stride[k] for k in range(3))
+            km = x.kmaps[(stride, self.kernel_size, self.stride, self.dilation)]
+            table, order = km.nbr_up, None
+            coords = x.cmaps[stride]
+        if table is None:                               # 1x1x1: a dense GEMM on the rows
+            out = torch.addcmul(shift, feats.float().matmul(self.kernel.detach()), scale)
+            out = torch.relu_(out) if relu else out
+        else:
+            out = subm_conv_ln_add_relu(feats, self.kernel, table, order, scale, shift, 0.0, None, relu=relu, affine=True)
+        y = SparseTensor(out, coords, stride)
+        y.cmaps, y.kmaps = x.cmaps, x.kmaps
+        y.cmaps.setdefault(y.stride, y.coords)
+        return y
+
 
 # a voxel with more neighbours than this runs on the output-stationary table kernel (conv.hip): measured
 # cross-over of the two forms on MI355X (tools/convbench.py)
@@ -691,6 +718,24 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
     return out
 
 
+def fold_batchnorm(bn: nn.BatchNorm1d, conv_bias: Optional[torch.Tensor] = None):
+    """(scale, shift) with bn(y + conv_bias) == y * scale + shift for a BatchNorm in inference mode (running
+    statistics); cached on the module and refreshed when any of its tensors changes (eight tiny launches
+    otherwise, per call)."""
+    ver = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+        ((conv_bias._version, conv_bias.data_ptr()) if conv_bias is not None else ()) + (bn.weight.device,)
+    hit = bn.__dict__.get("_link_fold")
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    sc = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    sh = bn.bias.detach().float() - bn.running_mean.float() * sc
+    if conv_bias is not None:
+        sh = sh + conv_bias.detach().float() * sc
+    sc, sh = sc.contiguous(), sh.contiguous()
+    bn.__dict__["_link_fold"] = (ver, sc, sh)
+    return sc, sh
+
+
 def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
               order: Optional[torch.Tensor] = None, form: str = "auto") -> torch.Tensor:
     """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd.  `form`:
@@ -727,9 +772,11 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     link_conv_pairs_sum on sparse neighbourhoods).  `affine=True`: ln_w / ln_b are a per-channel scale / shift
     (an inference BatchNorm folded with the convolution's bias) and no statistics are taken:
     relu(addend + conv * ln_w + ln_b) -- the BN / residual / ReLU epilogues of the detection stages.  No autograd."""
-    n, cin = feats.shape
+    cin = feats.shape[1]
     kvol, cin2, cout = kernel.shape
+    n = nbr.shape[0]                                   # output rows (the table is per output row)
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
+    assert addend is None or addend.shape == (n, cout)
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
     add = addend.detach().contiguous().float() if addend is not None else None

@@ -110,3 +110,37 @@ def test_encoder_vs_reference_network_fixture():
         assert np.array_equal(o.C.cpu().numpy(), g[f"x{i}_C"]), f"stage {i} coordinates (spdownsample order)"
         assert o.s == (2 ** i,) * 3
         assert rel_err(o.F.cpu().numpy(), g[f"x{i}_F"]) < 1e-4, f"stage {i} features"
+
+
+def test_fused_conv_bn_relu_equals_module_by_module_and_reference_fixture():
+    """link_amd.fuse_for_inference: the [Conv3d, BatchNorm, ReLU] runs of the reference-shaped encoder collapse to
+    one launch each (BatchNorm folded into the convolution's finish phase).  Same state_dict keys, same outputs as
+    the unfused modules and as the imported reference's own forward (fixture); training mode is untouched."""
+    import link_amd as la
+    from helpers import load_golden
+    g = load_golden("g_encoder_cosx_s3_r2.npz")
+    net = LE.build_reference_shaped_encoder(la, 16, "cos_x", 1)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    keys = list(net.state_dict().keys())
+    feats, coords = torch.from_numpy(g["feats"]).cuda(), torch.from_numpy(g["coords"]).cuda()
+    with torch.no_grad():
+        x0a, outs_a = net(la.SparseTensor(feats, coords, 1), 3, 2)
+    la.fuse_for_inference(net)
+    n_fused = sum(1 for m in net.modules() if type(m).__name__ == "_FusedSequential")
+    assert n_fused == 1 + 4 * 5 and list(net.state_dict().keys()) == keys      # stem + per stage: down, 2 residual nets, 2 tails
+    with torch.no_grad():
+        x0b, outs_b = net(la.SparseTensor(feats, coords, 1), 3, 2)
+    assert rel_err(x0b.F.cpu().numpy(), x0a.F.cpu().numpy()) < 1e-5
+    assert rel_err(x0b.F.cpu().numpy(), g["x0_F"]) < 1e-5
+    for i, (a, b) in enumerate(zip(outs_a, outs_b), 1):
+        assert torch.equal(a.C, b.C) and a.s == b.s
+        assert rel_err(b.F.cpu().numpy(), a.F.cpu().numpy()) < 2e-5
+        assert rel_err(b.F.cpu().numpy(), g[f"x{i}_F"]) < 1e-4
+    # training mode: plain nn.Sequential semantics (batch statistics, autograd)
+    net.train()
+    f = feats.clone().requires_grad_(True)
+    _, outs = net(la.SparseTensor(f, coords, 1), 3, 2)
+    outs[-1].F.square().sum().backward()
+    assert torch.isfinite(f.grad).all() and net.stem[0].kernel.grad is not None
