@@ -34,7 +34,7 @@ from .elk import (SparseConvTensor, TSELKBlock, _SubmConv, fold_batchnorm, neigh
                   subm_conv_ln_add_relu)
 from .utils import get_kernel_offsets
 
-__all__ = ["SubMConv3d", "SparseBasicBlock", "ELKv3Stage"]
+__all__ = ["SubMConv3d", "SparseConv3d", "SparseBasicBlock", "ELKv3Stage", "SpMiddleResNetFHDELKv3", "to_dense"]
 
 
 def _replace_feature(sct, feats):
@@ -130,6 +130,42 @@ class SparseBasicBlock(nn.Module):
         return _conv_bn(self.conv2, self.bn2, h, nbr, order, addend=feats, relu=True)
 
 
+def _needs_modules(mod: nn.Module, feats: torch.Tensor) -> bool:
+    """True when the modules must run one by one (autograd, or training-mode BatchNorm statistics)."""
+    if not feats.is_cuda:
+        raise L.LinkAmdError("the detection stages need GPU tensors (HIP path; no CPU fallback)")
+    return mod.training or (torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in mod.parameters())))
+
+
+def _seq_conv_bn(seq, sct, relu: bool):
+    """[conv, BatchNorm(, ReLU)] module by module."""
+    t = seq[0](sct)
+    f = seq[1](t.features)
+    return _replace_feature(t, torch.relu(f) if relu else f)
+
+
+def _stage_modules(conv, conv_tail, elk, elk_tail, act, sct, block_sz):
+    """scn.py:586-590 one module at a time (the differentiable path)."""
+    x_conv = _seq_conv_bn(conv_tail, conv(sct), False)
+    x_lk = _seq_conv_bn(elk_tail, elk(sct, block_sz), False)
+    return _replace_feature(x_conv, act(x_conv.features + x_lk.features))
+
+
+def _stage_fused(conv, conv_tail, elk, elk_tail, sct, block_sz):
+    """scn.py:586-590 at inference: six convolutions with BatchNorm / residual / ReLU in their finish phase + the
+    fused TSELKBlock, one neighbour table for all of them."""
+    feats = sct.features
+    io_dtype = feats.dtype
+    nbr, order = _site_table(sct)
+    x = feats.float().contiguous()
+    for blk in conv:
+        x = blk.fused(x, nbr, order)
+    x_conv = _conv_bn(conv_tail[0], conv_tail[1], x, nbr, order)
+    x_lk = elk(_replace_feature(sct, feats.float()), block_sz).features
+    out = _conv_bn(elk_tail[0], elk_tail[1], x_lk, nbr, order, addend=x_conv, relu=True)
+    return _replace_feature(sct, out if io_dtype == torch.float32 else out.to(io_dtype))
+
+
 class ELKv3Stage(nn.Module):
     """Stage K of SpMiddleResNetFHDELKv3 (scn.py:477-494 constructor, :586-590 forward); attribute names
     `conv`, `conv_tail`, `elk`, `elk_tail` stand for the backbone's convK, convK_tail, elkK, elkK_tail
@@ -156,27 +192,202 @@ class ELKv3Stage(nn.Module):
         return self.load_state_dict(sd, strict=strict)
 
     def _modules_path(self, sct):
-        x_conv = self.conv(sct)
-        t = self.conv_tail[0](x_conv)
-        x_conv = _replace_feature(t, self.conv_tail[1](t.features))
-        x_lk = self.elk(sct, self.block_sz)
-        t = self.elk_tail[0](x_lk)
-        x_lk = _replace_feature(t, self.elk_tail[1](t.features))
-        return _replace_feature(x_conv, self.act(x_conv.features + x_lk.features))
+        return _stage_modules(self.conv, self.conv_tail, self.elk, self.elk_tail, self.act, sct, self.block_sz)
 
     def forward(self, sct):
-        feats = sct.features
-        needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad or self.training or not feats.is_cuda:
-            if not feats.is_cuda:
-                raise L.LinkAmdError("ELKv3Stage needs GPU tensors (HIP path; no CPU fallback)")
+        if _needs_modules(self, sct.features):
             return self._modules_path(sct)
-        io_dtype = feats.dtype
-        nbr, order = _site_table(sct)
-        x = feats.float().contiguous()
-        for blk in self.conv:
-            x = blk.fused(x, nbr, order)
-        x_conv = _conv_bn(self.conv_tail[0], self.conv_tail[1], x, nbr, order)
-        x_lk = self.elk(_replace_feature(sct, feats.float()), self.block_sz).features
-        out = _conv_bn(self.elk_tail[0], self.elk_tail[1], x_lk, nbr, order, addend=x_conv, relu=True)
-        return _replace_feature(sct, out if io_dtype == torch.float32 else out.to(io_dtype))
+        return _stage_fused(self.conv, self.conv_tail, self.elk, self.elk_tail, sct, self.block_sz)
+
+
+# ------------------------------------------------------------------------------------------------
+# the rest of the backbone's sparse half: strided convolutions between the stages, extra_conv, dense()
+# ------------------------------------------------------------------------------------------------
+def _ntuple3(v):
+    return tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+class SparseConv3d(nn.Module):
+    """Regular (site-creating) sparse convolution with spconv 2.x's layout, for the forms the backbone uses
+    (scn.py:496-502,518-524,540-546,562-568): kernel 3 or 1 per axis, stride 2 or 1 per axis, per-axis padding,
+    axes in (z, y, x) order.  Output sites are all positions o inside the output shape
+    floor((in + 2 pad - k) / stride) + 1 that have at least one active input under the kernel,
+    out[o] = sum_taps W[:, a, b, c, :] . in[o * stride - pad + (a, b, c)].  The kernel map is a per-output table
+    (dense cell table of the input sites), cached in the tensor's indice_dict; contraction on the table / pair-list
+    convolution kernels with the BatchNorm + ReLU of the surrounding SparseSequential folded in at inference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=0, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _ntuple3(kernel_size), _ntuple3(stride), _ntuple3(padding)
+        if any(k not in (1, 3) for k in self.kernel_size) or any(s not in (1, 2) for s in self.stride):
+            raise NotImplementedError("SparseConv3d: kernel 1 or 3 and stride 1 or 2 per axis")
+        kz, ky, kx = self.kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, kz, ky, kx, in_channels))
+        nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
+        if bias:
+            bound = 1.0 / (kz * ky * kx * in_channels) ** 0.5
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._kio = None
+
+    def _taps(self):
+        return [(a, b, c) for a in range(self.kernel_size[0]) for b in range(self.kernel_size[1])
+                for c in range(self.kernel_size[2])]
+
+    def kernel_kio(self) -> torch.Tensor:
+        """[taps, Cin, Cout], taps in (a, b, c) row-major order (the table's column order)."""
+        ver = (self.weight._version, self.weight.device)
+        live = torch.is_grad_enabled() and self.weight.requires_grad
+        if self._kio is None or self._kio[0] != ver or live:
+            kio = self.weight.reshape(self.out_channels, -1, self.in_channels).permute(1, 2, 0).contiguous()
+            if live:
+                return kio
+            self._kio = (ver, kio.detach())
+        return self._kio[1]
+
+    def out_shape(self, shape):
+        return [(int(shape[d]) + 2 * self.padding[d] - self.kernel_size[d]) // self.stride[d] + 1 for d in range(3)]
+
+    def _map(self, sct):
+        """(output indices int32[M,4] (b,z,y,x) sorted, table int32[M, taps] of input rows, transposed-direction
+        table for the input gradient), cached per (input coordinate set, geometry)."""
+        key = ("link_sparse_conv", sct.indices.data_ptr(), sct.indices.shape[0], self.kernel_size, self.stride, self.padding)
+        hit = sct.indice_dict.get(key)
+        if hit is not None:
+            return hit[0], hit[1], hit[2]
+        dev = sct.indices.device
+        oshape = self.out_shape(sct.spatial_shape)
+        k, s, p = self.kernel_size, self.stride, self.padding
+        cst = self.__dict__.setdefault("_const", {}).get(dev)
+        if cst is None:                                  # small constant tensors: one H2D each, once per device
+            offs = get_kernel_offsets(3, device="cpu").tolist()
+            col = {(o3[2] + 1, o3[1] + 1, o3[0] + 1): j for j, o3 in enumerate(offs)}      # window position (a,b,c)
+            sel = [col[(a if k[0] == 3 else 1, b if k[1] == 3 else 1, c if k[2] == 3 else 1)] for a, b, c in self._taps()]
+            cst = self._const[dev] = (torch.tensor(self._taps(), device=dev), torch.tensor(p, device=dev),
+                                      torch.tensor(s, device=dev), torch.tensor([1 if kk == 3 else 0 for kk in k], device=dev),
+                                      torch.tensor(sel, device=dev))
+        taps, p_t, st, centre, sel_t = cst
+        # output sites: o with o * s = i + p - tap for some active input i and tap, inside the output shape;
+        # deduplicated on a linear key (ascending key = lexicographic (b, z, y, x)).  (A per-axis candidate product
+        # -- at most 8 instead of 27 candidates per input -- was measured slower: more, smaller torch launches.)
+        ind = sct.indices.long()
+        num = ind[:, None, 1:] + p_t - taps[None]
+        o = torch.div(num, st, rounding_mode="floor")
+        ok = (num == o * st).all(-1) & (o >= 0).all(-1) & (o[..., 0] < oshape[0]) & (o[..., 1] < oshape[1]) & (o[..., 2] < oshape[2])
+        lin = ((ind[:, None, 0] * oshape[0] + o[..., 0]) * oshape[1] + o[..., 1]) * oshape[2] + o[..., 2]
+        uk = torch.unique(lin[ok])
+        ox = uk % oshape[2]; r1 = torch.div(uk, oshape[2], rounding_mode="floor")
+        oy = r1 % oshape[1]; r2 = torch.div(r1, oshape[1], rounding_mode="floor")
+        oz = r2 % oshape[0]; ob = torch.div(r2, oshape[0], rounding_mode="floor")
+        out_ind = torch.stack([ob, oz, oy, ox], 1)
+        # table[j, t] = input row at out_ind[j] * s - p + tap_t  (dense cell table of the input sites).  A 3-wide
+        # window per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its one tap
+        # sits at o*s - p, the window centre
+        from .index import foreign_neighbor_map
+        in_xyzb = sct.indices[:, [3, 2, 1, 0]].contiguous().int()
+        base = out_ind[:, 1:] * st - p_t + centre
+        rows = torch.cat([base[:, [2, 1, 0]], out_ind[:, :1]], 1).int().contiguous()      # (x, y, z, b)
+        full = foreign_neighbor_map(rows, 3, table_rows=in_xyzb)                           # [M, 27], offsets (dx,dy,dz)
+        sel = sel_t
+        table = full[:, sel].contiguous()
+        jj, tt = torch.nonzero(table >= 0, as_tuple=True)
+        back = torch.full((sct.indices.shape[0], table.shape[1]), -1, dtype=torch.int32, device=dev)
+        back[table[jj, tt].long(), tt] = jj.int()
+        hit = sct.indice_dict[key] = (out_ind.int().contiguous(), table, back, sct.indices)
+        return hit[0], hit[1], hit[2]
+
+    def _out_tensor(self, sct, out_ind, feats):
+        out = SparseConvTensor(feats, out_ind, self.out_shape(sct.spatial_shape), sct.batch_size, None, None,
+                               sct.indice_dict, sct.benchmark)
+        return out
+
+    def forward(self, sct):
+        out_ind, table, back = self._map(sct)
+        w = self.kernel_kio()
+        if torch.is_grad_enabled() and (sct.features.requires_grad or self.weight.requires_grad):
+            from .elk import _GatherConv
+            out = _GatherConv.apply(sct.features.float(), w, table, back)
+        else:
+            out = subm_conv(sct.features, w, table, None)
+        if self.bias is not None:
+            out = out + self.bias
+        return self._out_tensor(sct, out_ind, out)
+
+    def fused(self, sct, bn, relu=True):
+        out_ind, table, _ = self._map(sct)
+        sc, sh = fold_batchnorm(bn, self.bias)
+        out = subm_conv_ln_add_relu(sct.features, self.kernel_kio(), table, None, sc, sh, 0.0, None, relu=relu, affine=True)
+        return self._out_tensor(sct, out_ind, out)
+
+
+def to_dense(sct) -> torch.Tensor:
+    """spconv's SparseConvTensor.dense(): [B, C, D, H, W] with zeros at inactive sites."""
+    d, h, w = [int(v) for v in sct.spatial_shape]
+    ind = sct.indices.long()
+    out = torch.zeros((int(sct.batch_size), d, h, w, sct.features.shape[1]), dtype=sct.features.dtype,
+                      device=sct.features.device)
+    out[ind[:, 0], ind[:, 1], ind[:, 2], ind[:, 3]] = sct.features
+    return out.permute(0, 4, 1, 2, 3).contiguous()
+
+
+class SpMiddleResNetFHDELKv3(nn.Module):
+    """The sparse half of the detection backbone (scn.py:452-626), attribute names as the reference's
+    (conv_input, conv{k}, conv{k}_tail, elk{k}, elk{k}_tail, act{k}, down{k}, extra_conv), on the SparseConvTensor
+    shim.  forward(voxel_features, coors, batch_size, input_shape) returns (BEV tensor [B, 128 * D, H, W],
+    {'conv1'..'conv4': SparseConvTensor}) exactly as scn.py:570-626.  Inference: every convolution carries its
+    BatchNorm / residual / ReLU in its finish phase; training / autograd: module by module."""
+
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHDELKv3", **kwargs):
+        super().__init__()
+        self.name = name
+        eps, mom = (norm_cfg or {}).get("eps", 1e-3), (norm_cfg or {}).get("momentum", 0.01)
+        bn = lambda c: nn.BatchNorm1d(c, eps=eps, momentum=mom)
+        self.planes = [16, 32, 64, 128]
+        self.block_sz = 7
+        p = self.planes
+        self.conv_input = nn.Sequential(SubMConv3d(num_input_features, p[0], 3, bias=False), bn(p[0]), nn.ReLU(inplace=True))
+        pads = {2: 1, 3: 1, 4: [0, 1, 1]}
+        for k in (1, 2, 3, 4):
+            c = p[k - 1]
+            if k > 1:
+                setattr(self, f"down{k}", nn.Sequential(SparseConv3d(p[k - 2], c, 3, 2, padding=pads[k], bias=False), bn(c),
+                                                        nn.ReLU(inplace=True)))
+            setattr(self, f"conv{k}", nn.Sequential(SparseBasicBlock(c, eps, mom), SparseBasicBlock(c, eps, mom)))
+            setattr(self, f"conv{k}_tail", nn.Sequential(SubMConv3d(c, c, 3, bias=False), bn(c)))
+            setattr(self, f"elk{k}", TSELKBlock(c, c))
+            setattr(self, f"elk{k}_tail", nn.Sequential(SubMConv3d(c, c, 3, bias=False), bn(c)))
+            setattr(self, f"act{k}", nn.ReLU(inplace=True))
+        self.extra_conv = nn.Sequential(SparseConv3d(p[3], p[3], (3, 1, 1), (2, 1, 1), bias=False), bn(p[3]), nn.ReLU())
+
+    def forward(self, voxel_features, coors, batch_size, input_shape, indice_dict=None):
+        """`indice_dict` (not in the reference's signature): a dict kept by the caller to reuse the kernel maps of a
+        coordinate set across calls (benchmarks of the kernels alone; a static scene).  Default: maps are built
+        per call, as the reference does."""
+        sparse_shape = [int(v) for v in list(input_shape)[::-1]]
+        sparse_shape[0] += 1                                           # scn.py:573
+        x = SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size, indice_dict=indice_dict)
+        fused = not _needs_modules(self, voxel_features)
+        if fused:
+            nbr, order = _site_table(x)
+            sc, sh = fold_batchnorm(self.conv_input[1], self.conv_input[0].bias)
+            x = _replace_feature(x, subm_conv_ln_add_relu(x.features, self.conv_input[0].kernel_kio(), nbr, order, sc, sh,
+                                                          0.0, None, relu=True, affine=True))
+        else:
+            x = _seq_conv_bn(self.conv_input, x, True)
+        scales = {}
+        for k in (1, 2, 3, 4):
+            if k > 1:
+                down = getattr(self, f"down{k}")
+                x = down[0].fused(x, down[1], relu=True) if fused else _seq_conv_bn(down, x, True)
+            parts = [getattr(self, f"{n}{k}{s}") for n, s in (("conv", ""), ("conv", "_tail"), ("elk", ""), ("elk", "_tail"))]
+            if fused:
+                x = _stage_fused(*parts, x, self.block_sz)
+            else:
+                x = _stage_modules(*parts, getattr(self, f"act{k}"), x, self.block_sz)
+            scales[f"conv{k}"] = x
+        ret = self.extra_conv[0].fused(x, self.extra_conv[1], relu=True) if fused else _seq_conv_bn(self.extra_conv, x, True)
+        ret = to_dense(ret)
+        n, c, d, h, w = ret.shape
+        return ret.view(n, c * d, h, w), scales

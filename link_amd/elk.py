@@ -642,32 +642,40 @@ class _PairPlan:
         dev = nbr.device
         valid = nbr >= 0
         centre = kvol // 2
-        direct = bool(kvol % 2 == 1 and n > 0 and
-                      torch.equal(nbr[:, centre], torch.arange(n, dtype=nbr.dtype, device=dev)))
+        # ONE host round trip for everything the plan needs on the host: is the centre column the identity, and
+        # the number of pairs per kernel offset (granule padding, wg_k)
+        ident = (nbr[:, centre] == torch.arange(n, dtype=nbr.dtype, device=dev)).all() if (kvol % 2 == 1 and n > 0) \
+            else torch.zeros((), dtype=torch.bool, device=dev)
+        host = torch.cat([valid.sum(0), ident.view(1).long()]).tolist()
+        direct = bool(host[-1])
+        cnt_k = host[:-1]
         if direct:
             valid = valid.clone()
             valid[:, centre] = False
-        ii, kk = torch.nonzero(valid, as_tuple=True)                   # row-major: (voxel, offset) ascending
-        cnt_k = torch.bincount(kk, minlength=kvol)
-        self.pairs = int(ii.numel())
+            cnt_k[centre] = 0
+        self.pairs = int(sum(cnt_k))
         self.n, self.kvol, self.direct = n, kvol, direct
         self.density = (self.pairs + (n if direct else 0)) / max(n, 1)
-        n_dir_pad = 0                                   # centre rows of a submanifold table: link_conv_centre_sum
-        pad_k = (cnt_k + 127) // 128 * 128
-        base_k = n_dir_pad + torch.cumsum(pad_k, 0) - pad_k
-        start_k = torch.cumsum(cnt_k, 0) - cnt_k
-        order = torch.sort(kk, stable=True).indices                    # pairs grouped by offset, voxel ascending
-        kk_s = kk[order]
-        p_sorted = base_k[kk_s] + (torch.arange(self.pairs, device=dev) - start_k[kk_s])
-        self.rows_pad = int(n_dir_pad + int(pad_k.sum().item()))
+        pad_k = [(c + 127) // 128 * 128 for c in cnt_k]
+        base_k, start_k, acc_b, acc_s = [], [], 0, 0
+        for c, pk in zip(cnt_k, pad_k):
+            base_k.append(acc_b); start_k.append(acc_s)
+            acc_b += pk; acc_s += c
+        self.rows_pad = acc_b
+        # pairs grouped by offset, voxel ascending inside an offset: row-major nonzero of the transposed mask
+        kk_s, ii_s = torch.nonzero(valid.t(), as_tuple=True)
+        shift = torch.tensor([b - s for b, s in zip(base_k, start_k)], dtype=torch.int64, device=dev)
+        p_sorted = torch.arange(self.pairs, device=dev) + shift[kk_s]          # contribution row of every pair
         pair_in = torch.full((max(self.rows_pad, 1),), -1, dtype=torch.int32, device=dev)
-        pair_in[p_sorted] = nbr[ii[order], kk_s]
-        ext_list = torch.empty(max(self.pairs, 1), dtype=torch.int32, device=dev)
-        ext_list[order] = p_sorted.int()
+        pair_in[p_sorted] = nbr[ii_s, kk_s]
+        pmat = torch.empty((n, kvol), dtype=torch.int32, device=dev)
+        pmat[ii_s, kk_s] = p_sorted.int()
+        ext_list = pmat[valid] if self.pairs else torch.zeros(1, dtype=torch.int32, device=dev)   # voxel-major, offset ascending
         ext_start = torch.zeros(n + 1, dtype=torch.int32, device=dev)
         ext_start[1:] = torch.cumsum(valid.sum(1), 0).int()
-        wg_k = torch.cat([torch.full((n_dir_pad // 128,), centre, dtype=torch.int32, device=dev),
-                          torch.repeat_interleave(torch.arange(kvol, dtype=torch.int32, device=dev), pad_k // 128)])
+        import numpy as _np
+        wg = _np.repeat(_np.arange(kvol, dtype=_np.int32), [pk // 128 for pk in pad_k])
+        wg_k = torch.from_numpy(wg).to(dev) if wg.size else torch.zeros(0, dtype=torch.int32, device=dev)
         self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, wg_k, ext_start, ext_list
         self._contrib: Dict[int, torch.Tensor] = {}
 

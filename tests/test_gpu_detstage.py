@@ -123,3 +123,107 @@ def test_submconv_weight_layout_and_state_dict_mapping():
     dst.load_backbone_stage(sd, 2)
     for (k1, v1), (k2, v2) in zip(src.state_dict().items(), dst.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole sparse half of the backbone: conv_input, 4 stages, 3 site-creating k3-s2 convolutions, extra_conv, dense()
+# ------------------------------------------------------------------------------------------------
+def dense_regular(feats, indices, shape, weight, k, stride, pad, batch):
+    """Regular sparse convolution by definition: dense conv3d of the zero-filled grid; active output sites = those
+    with at least one active input under the kernel (occupancy convolved with ones).  Returns (out indices sorted
+    like torch.unique(dim=0), features float64, out shape)."""
+    d, h, w = shape
+    vol = torch.zeros(batch, feats.shape[1], d, h, w, dtype=torch.float64)
+    occ = torch.zeros(batch, 1, d, h, w, dtype=torch.float64)
+    bi, zi, yi, xi = [indices[:, j].long() for j in range(4)]
+    vol[bi, :, zi, yi, xi] = feats.double()
+    occ[bi, 0, zi, yi, xi] = 1.0
+    out = torch.nn.functional.conv3d(vol, weight.double().permute(0, 4, 1, 2, 3), None, stride=stride, padding=pad)
+    act = torch.nn.functional.conv3d(occ, torch.ones(1, 1, *k, dtype=torch.float64), None, stride=stride, padding=pad) > 0.5
+    oi = torch.nonzero(act[:, 0])                                   # (b, z, y, x), row-major = lexicographic
+    return oi.int(), out[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]], list(out.shape[2:])
+
+
+def test_sparse_conv3d_sites_and_values_vs_dense_definition():
+    import link_amd as la
+    torch.manual_seed(0)
+    shape = [21, 30, 26]
+    coords = s_uniform(3000, grid=20, seed=4)                       # x, y, z < 20
+    indices = coords[:, [3, 2, 1, 0]].contiguous().int()
+    feats = torch.randn(3000, 32)
+    sct = la.SparseConvTensor(feats.cuda(), indices.cuda(), shape, 1)
+    for k, s, p in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        conv = la.SparseConv3d(32, 64, k, s, padding=p, bias=False).cuda()
+        with torch.no_grad():
+            out = conv(sct)
+        ri, rf, rshape = dense_regular(feats, indices, shape, conv.weight.detach().cpu(), k, s, p, 1)
+        assert list(out.spatial_shape) == rshape
+        assert torch.equal(out.indices.cpu(), ri), (k, s, p)
+        assert rel_err(out.features.cpu().numpy(), rf.numpy()) < 1e-5
+
+
+def test_backbone_sparse_half_vs_dense_oracle():
+    """SpMiddleResNetFHDELKv3.forward (scn.py:570-626) on a small grid: every active-site set, the four multi-scale
+    outputs and the BEV tensor against the dense definitions + the oracle's TSELKBlock; fused inference and the
+    module-by-module path agree."""
+    import link_amd as la
+    from oracle import link_oracle as O
+    torch.manual_seed(1)
+    net = la.SpMiddleResNetFHDELKv3(num_input_features=5).cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.6)
+            m.weight.data.uniform_(0.6, 1.4); m.bias.data.uniform_(-0.2, 0.2)
+    net.eval()
+    input_shape = [32, 32, 40]                                      # (x, y, z) -> sparse shape (41, 32, 32)
+    g = torch.Generator().manual_seed(3)
+    lin = torch.randperm(32 * 32 * 40, generator=g)[:5000]
+    x, y, z = lin % 32, (lin // 32) % 32, lin // 1024
+    indices = torch.stack([torch.zeros_like(x), z, y, x], 1).int()
+    feats = torch.randn(5000, 5, generator=g)
+    with torch.no_grad():
+        bev, scales = net(feats.cuda(), indices.cuda(), 1, input_shape)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+
+    def bn(pre, v):
+        return (v - sd[pre + ".running_mean"].double()) / torch.sqrt(sd[pre + ".running_var"].double() + 1e-3) \
+            * sd[pre + ".weight"].double() + sd[pre + ".bias"].double()
+
+    shape = [41, 32, 32]
+    f = torch.relu(bn("conv_input.1", dense_subm(feats, indices, shape, sd["conv_input.0.weight"], None)))
+    ind = indices
+    pads = {2: (1, 1, 1), 3: (1, 1, 1), 4: (0, 1, 1)}
+    for k in (1, 2, 3, 4):
+        if k > 1:
+            ind, f, shape = dense_regular(f, ind, shape, sd[f"down{k}.0.weight"], (3, 3, 3), (2, 2, 2), pads[k], 1)
+            f = torch.relu(bn(f"down{k}.1", f))
+        xx = f
+        for i in range(2):
+            h = torch.relu(bn(f"conv{k}.{i}.bn1", dense_subm(xx, ind, shape, sd[f"conv{k}.{i}.conv1.weight"], sd[f"conv{k}.{i}.conv1.bias"])))
+            xx = torch.relu(bn(f"conv{k}.{i}.bn2", dense_subm(h, ind, shape, sd[f"conv{k}.{i}.conv2.weight"], sd[f"conv{k}.{i}.conv2.bias"])) + xx)
+        x_conv = bn(f"conv{k}_tail.1", dense_subm(xx, ind, shape, sd[f"conv{k}_tail.0.weight"], None))
+        coords = ind[:, [3, 2, 1, 0]].contiguous()
+        elk = {kk[len(f"elk{k}."):]: v for kk, v in sd.items() if kk.startswith(f"elk{k}.")}
+        c = f.shape[1]
+        core = O.elk_core_torch(f.float(), coords, elk, 7, 3, "cos", 1, variant="det", agg=O.aggregate_c).double()
+        local = O.subm_conv_torch(f, coords, elk["local_mix.0.kernel"].double(), 1)
+        local = torch.nn.functional.layer_norm(local, (c,), elk["norm_local.weight"].double(), elk["norm_local.bias"].double(), 1e-6)
+        e = torch.relu(core + local)
+        x_lk = bn(f"elk{k}_tail.1", dense_subm(e, ind, shape, sd[f"elk{k}_tail.0.weight"], None))
+        f = torch.relu(x_conv + x_lk)
+        got = scales[f"conv{k}"]
+        assert torch.equal(got.indices.cpu(), ind) and list(got.spatial_shape) == shape, f"stage {k} sites"
+        assert rel_err(got.features.cpu().numpy(), f.numpy()) < 1e-4, f"stage {k} features"
+    ind, f, shape = dense_regular(f, ind, shape, sd["extra_conv.0.weight"], (3, 1, 1), (2, 1, 1), (0, 0, 0), 1)
+    f = torch.relu(bn("extra_conv.1", f))
+    ref = torch.zeros(1, shape[0], shape[1], shape[2], 128, dtype=torch.float64)
+    ref[ind[:, 0].long(), ind[:, 1].long(), ind[:, 2].long(), ind[:, 3].long()] = f
+    ref = ref.permute(0, 4, 1, 2, 3).reshape(1, 128 * shape[0], shape[1], shape[2])
+    assert tuple(bev.shape) == tuple(ref.shape)
+    assert rel_err(bev.cpu().numpy(), ref.numpy()) < 1e-4
+    # module-by-module (autograd) path: same outputs, gradients flow to the input and to a strided convolution
+    fin = feats.cuda().requires_grad_(True)
+    bev2, _ = net(fin, indices.cuda(), 1, input_shape)
+    assert rel_err(bev2.detach().cpu().numpy(), ref.numpy()) < 1e-4
+    bev2.square().sum().backward()
+    assert torch.isfinite(fin.grad).all() and net.down3[0].weight.grad.abs().sum() > 0

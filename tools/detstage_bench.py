@@ -37,3 +37,27 @@ for planes, ds in ((16, 1), (32, 2), (64, 4), (128, 8)):
         t_f = ev(lambda: stage(sct))
         t_m = ev(lambda: stage._modules_path(sct))
     print(f"stage C={planes:3d}: N={n:6d} neighbours/voxel={dens:5.2f}  fused {t_f:7.1f} us   module-by-module {t_m:7.1f} us")
+
+# whole sparse half of the backbone (scn.py:570-626) on the full S-nusc frame: 5 input features, grid 1440 x 1440 x 40
+net = la.SpMiddleResNetFHDELKv3(num_input_features=5).to(dev).eval()
+indices = torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int().to(dev)
+feats = torch.from_numpy(fe).to(dev)
+with torch.no_grad():
+    bev, scales = net(feats, indices, 1, [1440, 1440, 40])
+    sizes = [scales[f"conv{k}"].features.shape[0] for k in (1, 2, 3, 4)]
+    t_f = ev(lambda: net(feats, indices, 1, [1440, 1440, 40]), k=10)
+    maps = {}
+    t_w = ev(lambda: net(feats, indices, 1, [1440, 1440, 40], indice_dict=maps), k=10)
+net.train(False)
+def mods():
+    with torch.no_grad():
+        x = la.SparseConvTensor(feats, indices, [41, 1440, 1440], 1)
+        from link_amd import detstage as D
+        x = D._seq_conv_bn(net.conv_input, x, True)
+        for k in (1, 2, 3, 4):
+            if k > 1: x = D._seq_conv_bn(getattr(net, f"down{k}"), x, True)
+            x = D._stage_modules(getattr(net, f"conv{k}"), getattr(net, f"conv{k}_tail"), getattr(net, f"elk{k}"),
+                                 getattr(net, f"elk{k}_tail"), getattr(net, f"act{k}"), x, 7)
+        return D.to_dense(D._seq_conv_bn(net.extra_conv, x, True))
+t_m = ev(mods, k=10)
+print(f"backbone sparse half: stage voxels {sizes}, BEV {tuple(bev.shape)}: fused {t_f / 1e3:.2f} ms with the kernel maps built per call (as the reference does), {t_w / 1e3:.2f} ms on warm maps; module-by-module {t_m / 1e3:.2f} ms (maps per call)")
