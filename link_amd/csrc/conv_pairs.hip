@@ -358,3 +358,89 @@ extern "C" int link_conv_centre_sum(const float *feats, const float *w, int32_t 
 #undef LINK_CC
   return LINK_ERR_ARG;
 }
+
+// ---------------------------------------------------------------------------------------------
+// building the pair plan from a per-output neighbour table (what link_amd/elk.py::_PairPlan holds)
+// ---------------------------------------------------------------------------------------------
+// Two passes over the table with one host round trip between them (the host needs the per-offset pair counts
+// to lay out the 128-row granules and to size the contribution buffer -- the same numbers the reference's
+// nbsizes holds on the host, nn/functional/conv.py:114-116):
+//   k_pair_count   stats[k] = pairs of offset k, stats[kvol] = rows whose centre entry is not the row itself
+//                  (0 <=> submanifold table); row_info[i] = (#valid entries) | (centre valid) << 16
+//   k_pair_fill    contribution row p of every pair: base_k[k] + a rank inside the offset handed out by ONE
+//                  atomic per wave and offset (ballot + prefix); pair_in[p] = input row, and the voxel's CSR
+//                  list in ascending offset order.  Ranks depend on the schedule, results do not: the output
+//                  kernels sum a voxel's rows in CSR order, wherever the rows live.
+// The workgroup stages its 256 table rows through LDS (coalesced reads; row stride kvol is odd for every
+// kernel the networks use, so the per-lane walk is conflict-free).
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ nbr, int64_t n, int kvol, int centre,
+                                                   int skip_centre, const int32_t *__restrict__ base_k,
+                                                   const int32_t *__restrict__ ext_start, int32_t *__restrict__ counters,
+                                                   int32_t *__restrict__ row_info, int32_t *__restrict__ pair_in,
+                                                   int32_t *__restrict__ ext_list) {
+  extern __shared__ int32_t tile[];                    // [256][kvol]
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const int rows = (int)((n - row0 < 256) ? n - row0 : 256);
+  const int tot = rows * kvol;
+  const int32_t *src = nbr + row0 * kvol;
+  for (int e = threadIdx.x; e < tot; e += 256) tile[e] = src[e];
+  __syncthreads();
+  const int r = threadIdx.x;
+  const bool live = r < rows;
+  const int32_t *mine = tile + (live ? r : 0) * kvol;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int q = (FILL && live) ? ext_start[row0 + r] : 0;
+  int nvalid = 0, cvalid = 0;
+  for (int k = 0; k < kvol; k++) {
+    const int v = live ? mine[k] : -1;
+    bool valid = v >= 0;
+    if (k == centre) {
+      cvalid = valid ? 1 : 0;
+      if (!FILL) {
+        const unsigned long long bad = __ballot(live && v != (int)(row0 + r));
+        if (bad && lane == 0) atomicAdd(&counters[kvol], __popcll(bad));
+      }
+      if (FILL && skip_centre) valid = false;
+    }
+    const unsigned long long m = __ballot(valid);
+    if (m) {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(&counters[k], __popcll(m));
+      if (FILL) {
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (valid) {
+          const int p = base_k[k] + b + __popcll(m & lt);
+          pair_in[p] = v;
+          ext_list[q++] = p;
+        }
+      }
+    }
+    nvalid += valid ? 1 : 0;
+  }
+  if (!FILL && live) row_info[row0 + r] = nvalid | (cvalid << 16);
+}
+
+extern "C" int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *stats, int32_t *row_info,
+                                    void *stream) {
+  if (n < 0 || kvol <= 0 || kvol > 64) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!nbr || !stats || !row_info) return LINK_ERR_ARG;
+  const unsigned wgs = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_pair_plan<false>, dim3(wgs), dim3(256), (size_t)256 * kvol * 4, S(stream), nbr, n, (int)kvol, (int)(kvol / 2), 0,
+                     (const int32_t *)nullptr, (const int32_t *)nullptr, stats, row_info, (int32_t *)nullptr, (int32_t *)nullptr);
+  return check_launch("link_pair_plan_count");
+}
+
+extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
+                                   const int32_t *ext_start, int32_t *counters, int32_t *pair_in, int32_t *ext_list,
+                                   void *stream) {
+  if (n < 0 || kvol <= 0 || kvol > 64) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!nbr || !base_k || !ext_start || !counters || !pair_in || !ext_list) return LINK_ERR_ARG;
+  const unsigned wgs = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_pair_plan<true>, dim3(wgs), dim3(256), (size_t)256 * kvol * 4, S(stream), nbr, n, (int)kvol, (int)(kvol / 2),
+                     (int)skip_centre, base_k, ext_start, counters, (int32_t *)nullptr, pair_in, ext_list);
+  return check_launch("link_pair_plan_fill");
+}

@@ -491,20 +491,47 @@ def neighbor_table_of(x: SparseTensor, kernel_size):
     if nbr is None:
         # neighbour of voxel i at coords_i + offset*tensor_stride (conv.py:105-113: stride=input.stride)
         ts = int(x.s[0])
+        bkey = ("link_bounds", x.C.data_ptr(), x.C.shape[0])
+        bounds = x.cmaps.get(bkey)
+        if bounds is None or x.cmaps.get(("link_bounds_unchecked", x.C.data_ptr(), x.C.shape[0])):
+            # one bounding-box pass per coordinate set, shared with the block index; bounds that came from the
+            # caller's metadata are not trusted here (the cell table is addressed with them)
+            from .index import coords_bounds
+            fresh = coords_bounds(x.C.contiguous())
+            if bounds is None and x.C.is_contiguous():
+                x.cmaps[bkey] = fresh
+            bounds = fresh
         try:
-            nbr = foreign_neighbor_map(x.C, kernel_size[0], step=ts)
+            nbr = foreign_neighbor_map(x.C, kernel_size[0], step=ts, bounds=bounds)
         except GridTooLarge:
             offs = get_kernel_offsets(kernel_size, stride=x.s, device=x.F.device)
             nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
-        # spatially coherent voxel order for the table kernel's tile-level skipping: voxels grouped by
-        # (4*stride)^3 blocks of the dense block grid (the LinK index with a small block edge)
-        try:
-            order = BlockIndex(x.C, 4 * ts, want_idx64=False).perm
-        except GridTooLarge:
-            order = None
-        nbr = (nbr, order)
+        nbr = (nbr, _TileOrder(x.C, 4 * ts))
         x.kmaps[key] = nbr
     return nbr
+
+
+class _TileOrder:
+    """Spatially coherent voxel order for the TABLE kernel's tile-level skipping: voxels grouped by (4*stride)^3
+    blocks of the dense block grid (the LinK index with a small block edge).  Built on first use -- frames that
+    run the pair-list kernels never need it."""
+
+    def __init__(self, coords: torch.Tensor, edge: int):
+        self._coords, self._edge, self._perm, self._done = coords, edge, None, False
+
+    def tensor(self) -> Optional[torch.Tensor]:
+        """The permutation int32[N] (None beyond the dense-grid limit)."""
+        self.data_ptr()
+        return self._perm
+
+    def data_ptr(self):
+        if not self._done:
+            try:
+                self._perm = BlockIndex(self._coords, self._edge, want_idx64=False).perm
+            except GridTooLarge:
+                self._perm = None
+            self._done, self._coords = True, None
+        return self._perm.data_ptr() if self._perm is not None else None
 
 
 class Conv3d(nn.Module):
@@ -640,43 +667,45 @@ class _PairPlan:
     def __init__(self, nbr: torch.Tensor):
         n, kvol = nbr.shape
         dev = nbr.device
-        valid = nbr >= 0
         centre = kvol // 2
-        # ONE host round trip for everything the plan needs on the host: is the centre column the identity, and
-        # the number of pairs per kernel offset (granule padding, wg_k)
-        ident = (nbr[:, centre] == torch.arange(n, dtype=nbr.dtype, device=dev)).all() if (kvol % 2 == 1 and n > 0) \
-            else torch.zeros((), dtype=torch.bool, device=dev)
-        host = torch.cat([valid.sum(0), ident.view(1).long()]).tolist()
-        direct = bool(host[-1])
-        cnt_k = host[:-1]
+        lib, st = L.lib(), _st()
+        nbr = nbr.contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        # pass 1 on the device, then ONE host round trip for what the layout needs: pairs per kernel offset and
+        # whether the centre column is the identity (include/link_amd.h: link_pair_plan_count / _fill)
+        stats = torch.zeros(kvol + 1, **i32)
+        row_info = torch.empty(max(n, 1), **i32)
+        L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, stats.data_ptr(), row_info.data_ptr(), st),
+                "link_pair_plan_count")
+        host = stats.tolist()
+        direct = bool(kvol % 2 == 1 and n > 0 and host[kvol] == 0)
+        cnt_k = host[:kvol]
         if direct:
-            valid = valid.clone()
-            valid[:, centre] = False
             cnt_k[centre] = 0
         self.pairs = int(sum(cnt_k))
         self.n, self.kvol, self.direct = n, kvol, direct
         self.density = (self.pairs + (n if direct else 0)) / max(n, 1)
-        pad_k = [(c + 127) // 128 * 128 for c in cnt_k]
-        base_k, start_k, acc_b, acc_s = [], [], 0, 0
-        for c, pk in zip(cnt_k, pad_k):
-            base_k.append(acc_b); start_k.append(acc_s)
-            acc_b += pk; acc_s += c
-        self.rows_pad = acc_b
-        # pairs grouped by offset, voxel ascending inside an offset: row-major nonzero of the transposed mask
-        kk_s, ii_s = torch.nonzero(valid.t(), as_tuple=True)
-        shift = torch.tensor([b - s for b, s in zip(base_k, start_k)], dtype=torch.int64, device=dev)
-        p_sorted = torch.arange(self.pairs, device=dev) + shift[kk_s]          # contribution row of every pair
-        pair_in = torch.full((max(self.rows_pad, 1),), -1, dtype=torch.int32, device=dev)
-        pair_in[p_sorted] = nbr[ii_s, kk_s]
-        pmat = torch.empty((n, kvol), dtype=torch.int32, device=dev)
-        pmat[ii_s, kk_s] = p_sorted.int()
-        ext_list = pmat[valid] if self.pairs else torch.zeros(1, dtype=torch.int32, device=dev)   # voxel-major, offset ascending
-        ext_start = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-        ext_start[1:] = torch.cumsum(valid.sum(1), 0).int()
+        base_k, gran, acc = [], [], 0
+        for c in cnt_k:
+            base_k.append(acc)
+            gran.append((c + 127) // 128)
+            acc += gran[-1] * 128
+        self.rows_pad = acc
+        ext_cnt = (row_info[:n] & 0xFFFF) - (row_info[:n] >> 16) if direct else row_info[:n] & 0xFFFF
+        ext_start = torch.zeros(n + 1, **i32)
+        torch.cumsum(ext_cnt, 0, out=ext_start[1:])
+        pair_in = torch.full((max(self.rows_pad, 1),), -1, **i32)
+        ext_list = torch.empty(max(self.pairs, 1), **i32)
         import numpy as _np
-        wg = _np.repeat(_np.arange(kvol, dtype=_np.int32), [pk // 128 for pk in pad_k])
-        wg_k = torch.from_numpy(wg).to(dev) if wg.size else torch.zeros(0, dtype=torch.int32, device=dev)
-        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, wg_k, ext_start, ext_list
+        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), _np.zeros(kvol, dtype=_np.int32),
+                                _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
+        meta = torch.from_numpy(meta).to(dev)                      # base_k | counters (zero) | wg_k: one H2D
+        if self.pairs:
+            L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), ext_start.data_ptr(),
+                                            meta[kvol:].data_ptr(), pair_in.data_ptr(), ext_list.data_ptr(), st),
+                    "link_pair_plan_fill")
+        self._meta = meta
+        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[2 * kvol:], ext_start, ext_list
         self._contrib: Dict[int, torch.Tensor] = {}
 
     def contrib(self, cout: int) -> torch.Tensor:
@@ -910,17 +939,6 @@ class _SubmConv(torch.autograd.Function):
 DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take
 
 
-def _dense_occupancy_ok(coords: torch.Tensor, s: int) -> bool:
-    """True when the frame's blocks are small enough for the dense-cell layout (one D2H sync; see _core_dense)."""
-    b = torch.div(coords[:, :3], s, rounding_mode="floor").long()
-    b -= b.min(0).values
-    ext = b.max(0).values + 1
-    lin = ((coords[:, 3].long() * ext[0] + b[:, 0]) * ext[1] + b[:, 1]) * ext[2] + b[:, 2]
-    cnt = torch.unique(lin, return_counts=True)[1]
-    m, mx = int(cnt.numel()), int(cnt.max().item())
-    return coords.shape[0] <= DENSE_MAX_MEAN * m and mx <= DENSE_MAX_CELL
-
-
 class _ELKBase(nn.Module):
     def _core_dense(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         """Inference R_core on the dense-cell layout (ElkCorePlan), or None when the frame's block grid is
@@ -942,13 +960,10 @@ class _ELKBase(nn.Module):
         # sync-free call, so those frames use the general layout unless the module opts in (dense_layout = True).
         okey = ("link_dense_ok", coords.data_ptr(), n, s_eff)
         ok = st.cmaps.get(okey)
-        if ok is None:
-            if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) and not getattr(self, "dense_layout", False):
-                ok = False
-            else:
-                ok = _dense_occupancy_ok(coords, s_eff)
-            st.cmaps[okey] = ok
-        if not ok:
+        unchecked = st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n))
+        if ok is None and unchecked and not getattr(self, "dense_layout", False):
+            ok = st.cmaps[okey] = False
+        if ok is False:
             return None
         bkey = ("link_bounds", coords.data_ptr(), n)
         bounds = st.cmaps.get(bkey)
@@ -970,7 +985,21 @@ class _ELKBase(nn.Module):
                 cache.pop(next(iter(cache)))
             cache[key] = plan
         if plan is None:
+            st.cmaps[okey] = False
             return None
+        if ok is None:
+            # first visit of this coordinate set: the slot-insert kernel alone fills the per-cell counters; their
+            # maximum and the number of occupied cells decide (two tiny reductions, one host round trip)
+            cc = coords.contiguous()
+            L.check(L.lib().link_dc_index(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.slots.data_ptr(),
+                                          plan.vcell.data_ptr(), plan.hdr.data_ptr(), _st()), "link_dc_index")
+            mx, m, n_in = torch.stack([plan.cnt.max(), (plan.cnt > 0).sum(), plan.cnt.sum()]).tolist()
+            plan.cnt.zero_()                                   # the step below inserts again
+            plan._indexed = None
+            ok = st.cmaps[okey] = bool(m > 0 and n_in <= DENSE_MAX_MEAN * m and mx <= DENSE_MAX_CELL)
+            if not ok:
+                plan.hdr.zero_()                               # nothing of this frame stays behind in the shared plan
+                return None
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
         ikey = (coords.data_ptr(), n, coords._version)

@@ -54,10 +54,16 @@ def _workspace(device) -> _Workspace:
     return ws
 
 
+_BBOX_INIT: Dict[torch.device, torch.Tensor] = {}
+
+
 def coords_bounds(coords: torch.Tensor) -> Tuple[Tuple[int, ...], Tuple[int, ...]]:
     """Inclusive (lo, hi) of int32 coords[N,4] via the HIP bbox kernel (one 32-byte D2H sync)."""
-    imax, imin = 2 ** 31 - 1, -2 ** 31
-    bbox = torch.tensor([imax] * 4 + [imin] * 4, dtype=torch.int32, device=coords.device)
+    init = _BBOX_INIT.get(coords.device)
+    if init is None:                                   # one H2D per device; per call a device-side copy
+        imax, imin = 2 ** 31 - 1, -2 ** 31
+        init = _BBOX_INIT[coords.device] = torch.tensor([imax] * 4 + [imin] * 4, dtype=torch.int32, device=coords.device)
+    bbox = init.clone()
     L.check(L.lib().link_coords_bbox(coords.data_ptr(), coords.shape[0], bbox.data_ptr(),
                                      L.current_stream_handle()), "link_coords_bbox")
     b = bbox.tolist()
@@ -159,7 +165,7 @@ class BlockIndex:
 
 
 def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, step: int = 1,
-                         table_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         table_rows: Optional[torch.Tensor] = None, bounds=None) -> torch.Tensor:
     """Neighbour map for arbitrary rows int32[M,4] (not produced by a BlockIndex): dense cell table
     over the bounding box of `table_rows` (default: the rows themselves; first duplicate row wins), then
     the same lookup kernel; neighbour offsets are multiplied by `step`.  With `table_rows`, entry [i,k] is
@@ -173,7 +179,7 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, st
     src = rows if table_rows is None else table_rows.contiguous()
     if src.shape[0] == 0:
         return nbr.fill_(-1)
-    lo, hi = coords_bounds(src)
+    lo, hi = bounds if bounds is not None else coords_bounds(src)      # bounds of `src`, when the caller has them
     try:
         grid = L.grid_from_bounds(lo, hi, 1)
     except L.LinkAmdError as e:

@@ -39,7 +39,7 @@ def test_subm_conv_forward_vs_oracle(C, kind, n, stride):
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
     # the neighbour table is the reference's kernel map (bit-exact integer work)
     nbr, order = st.kmaps[("link_conv_nbr", st.C.data_ptr(), n, st.s, (3, 3, 3))]
-    assert order is not None and sorted(order.cpu().tolist()) == list(range(n))
+    assert order is not None and sorted(order.tensor().cpu().tolist()) == list(range(n))     # built on first use
     assert np.array_equal(nbr.cpu().numpy(), lo.conv_neighbor_table(coords.numpy(), 3, stride))
 
 
