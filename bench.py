@@ -336,7 +336,7 @@ def main():
         every kernel spread over 2 workgroups per CU; with several frames in flight half that per kernel lets
         the kernels of different frames share the CUs (tools/mstream_dc.py)."""
         if plan.dense:
-            L.lib().link_dc_set_tuning2(0, 512 if ns == 1 else 256)
+            L.lib().link_dc_set_tuning2(0, int(os.environ.get("LINK_BENCH_K1_WGS", "0")) or (512 if ns == 1 else 256))
 
     def timed(k, build_index=True, ns=NS):
         """EXACTLY k steps (frames), round-robin over `ns` streams; barrier + synchronize on both sides."""

@@ -88,8 +88,11 @@ struct dc_k1_cfg {
 // row sets: ~256 registers, 2 waves per SIMD and nothing else fits beside them) or plain tiles (rows of t+1 in
 // flight while t is multiplied, then finished: ~130 registers, so that a second frame's kernels can share the
 // SIMDs).  Same arithmetic, bit for bit.
+#ifndef DC_K1_WAVES
+#define DC_K1_WAVES 2     /* register budget = 512 / this; LDS (80 KB per workgroup) allows 2 workgroups per CU anyway, and at 3 the tile body spills (A/B: LINK_AMD_CXXFLAGS=-DDC_K1_WAVES=3) */
+#endif
 template <int C, int OP, int NB, bool PIPE>
-__global__ void __launch_bounds__(256, PIPE ? 2 : 3) k_dc_premix_modsum(
+__global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsum(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
     int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
@@ -109,6 +112,29 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : 3) k_dc_premix_modsum(
   int4 *list = reinterpret_cast<int4 *>(wbase + K::LIST_OFF);
   int *scell = reinterpret_cast<int *>(wbase + K::SCELL_OFF);
   char *xbuf = wbase + K::X_OFF;
+  // the first chunk's cell records and counts are requested BEFORE W is staged: the two latencies overlap
+  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
+  const int Vi = Dx * Dy * Dz * g.dim[3];
+  const int wid = blockIdx.x * 4 + wave;
+  const int c_begin = wid * cpw;
+  const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
+  const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
+  auto cell_of = [&](int chunk, int nrem) {
+    const int q = chunk + (lane < nrem ? lane : 0);
+    const int z = q % Dz;
+    int t = q / Dz;
+    const int y = t % Dy;
+    t /= Dy;
+    return dc_cell(g, t % Dx, y, z, t / Dx);
+  };
+  int pc_f = 0, nv_f = 0;
+  int4 rf0 = make_int4(0, 0, 0, 0), rf1 = rf0, rf2 = rf0, rf3 = rf0;
+  if (c_begin < c_end) {
+    pc_f = cell_of(c_begin, (c_end - c_begin < 64) ? c_end - c_begin : 64);
+    rf0 = slots[(int64_t)pc_f * DC_INL + 0]; rf1 = slots[(int64_t)pc_f * DC_INL + 1];
+    rf2 = slots[(int64_t)pc_f * DC_INL + 2]; rf3 = slots[(int64_t)pc_f * DC_INL + 3];
+    nv_f = (int)csrc[pc_f];
+  }
   {                                                    // stage W and the LayerNorm parameters
     // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
     // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
@@ -136,18 +162,12 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : 3) k_dc_premix_modsum(
   }
   __syncthreads();
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
-  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
-  const int Vi = Dx * Dy * Dz * g.dim[3];
-  const int wid = blockIdx.x * 4 + wave;
-  const int c_begin = wid * cpw;
-  const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   if (c_begin >= c_end) return;
   const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * K::RB));
   const __amdgpu_buffer_rsrc_t r_fin = dc_rsrc(fin, (uint32_t)(n * C * 4));     // written for cos_x only
   const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   const __amdgpu_buffer_rsrc_t r_n = dc_rsrc(cell_n, (uint32_t)(g.vp * 4));
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
-  const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
   // theta weights of this lane's channels
   float w0[NB][4], w1[NB][4], w2[NB][4], al[NB][4];
 #pragma unroll
@@ -165,18 +185,16 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : 3) k_dc_premix_modsum(
     const int nrem = (c_end - chunk < 64) ? c_end - chunk : 64;
     unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
     // ---- cell lanes: count, padded cell id, inline records (all requested before anything is consumed) ----
-    int pc = 0, nv = 0;
-    {
-      const int q = chunk + (lane < nrem ? lane : 0);
-      const int z = q % Dz;
-      int t = q / Dz;
-      const int y = t % Dy;
-      t /= Dy;
-      pc = dc_cell(g, t % Dx, y, z, t / Dx);
+    int pc, nv;
+    int4 r0, r1, r2, r3;
+    if (chunk == c_begin) {                             // wave-uniform: the first chunk was requested before the staging
+      pc = pc_f; nv = nv_f; r0 = rf0; r1 = rf1; r2 = rf2; r3 = rf3;
+    } else {
+      pc = cell_of(chunk, nrem);
+      r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
+      r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
+      nv = (int)csrc[pc];
     }
-    const int4 r0 = slots[(int64_t)pc * DC_INL + 0], r1 = slots[(int64_t)pc * DC_INL + 1];
-    const int4 r2 = slots[(int64_t)pc * DC_INL + 2], r3 = slots[(int64_t)pc * DC_INL + 3];
-    nv = (int)csrc[pc];
     nv = nv < g.k ? nv : g.k;
     nv = nv < K::LCAP ? nv : K::LCAP;
     if (lane >= nrem) nv = 0;
