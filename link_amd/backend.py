@@ -158,3 +158,52 @@ def devoxelize_backward_cuda(top_grad: torch.Tensor, indices: torch.Tensor, weig
 
 __all__ = ["hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda", "voxelize_forward_cuda",
            "voxelize_backward_cuda", "devoxelize_forward_cuda", "devoxelize_backward_cuda"]
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution_{forward,backward}_cuda (pybind_cuda.cpp:19-21; convolution_cuda.cu:53-278)
+# ------------------------------------------------------------------------------------------------
+def _tables_of(neighbor_map: torch.Tensor, neighbor_offset: torch.Tensor, n_in: int, n_out: int, transpose: bool):
+    """The reference's kernel map -- pairs (in, out) int32[L, 2] grouped by kernel offset, sizes int32[K] on the
+    host (nn/functional/conv.py:109-122) -- as link_amd's per-output tables: fwd[out, k] = in, back[in, k] = out
+    (cached on the map tensor; `transpose` swaps the roles of the two columns, convolution_cuda.cu:117-131)."""
+    key = "_link_tables_t" if transpose else "_link_tables"
+    hit = getattr(neighbor_map, key, None)
+    if hit is None:
+        sizes = neighbor_offset.to(device=neighbor_map.device, dtype=torch.int64)
+        k = sizes.numel()
+        kk = torch.repeat_interleave(torch.arange(k, device=neighbor_map.device), sizes)
+        src = neighbor_map[:, 1 if transpose else 0].long()
+        dst = neighbor_map[:, 0 if transpose else 1].long()
+        fwd = torch.full((n_out, k), -1, dtype=torch.int32, device=neighbor_map.device)
+        fwd[dst, kk] = src.int()
+        back = torch.full((n_in, k), -1, dtype=torch.int32, device=neighbor_map.device)
+        back[src, kk] = dst.int()
+        hit = (fwd, back)
+        setattr(neighbor_map, key, hit)
+    return hit
+
+
+def convolution_forward_cuda(in_feat: torch.Tensor, out_feat: torch.Tensor, kernel: torch.Tensor,
+                             neighbor_map: torch.Tensor, neighbor_offset: torch.Tensor, transpose: bool) -> None:
+    """out_feat += sum_k in_feat[in_k] @ kernel[k] scattered to out_k: the reference's gather / GEMM / scatter-add
+    loop as ONE pass of the table or pair-list kernel (include/link_amd.h section D)."""
+    from .elk import subm_conv
+    _need_gpu(in_feat, out_feat, kernel, neighbor_map)
+    if in_feat.shape[1] != kernel.shape[1]:
+        raise ValueError("Input feature size and kernel size mismatch")          # convolution_cuda.cu:57-59
+    fwd, _ = _tables_of(neighbor_map, neighbor_offset, in_feat.shape[0], out_feat.shape[0], bool(transpose))
+    out_feat += subm_conv(in_feat, kernel, fwd).to(out_feat.dtype)
+
+
+def convolution_backward_cuda(in_feat: torch.Tensor, grad_in_feat: torch.Tensor, grad_out_feat: torch.Tensor,
+                              kernel: torch.Tensor, grad_kernel: torch.Tensor, neighbor_map: torch.Tensor,
+                              neighbor_offset: torch.Tensor, transpose: bool) -> None:
+    """grad_in_feat += grad_out[out_k] @ kernel[k]^T scattered to in_k; grad_kernel[k] += in[in_k]^T @ grad_out[out_k]
+    (convolution_cuda.cu:167-278)."""
+    from .elk import _conv_weight_grad, subm_conv
+    _need_gpu(in_feat, grad_in_feat, grad_out_feat, kernel, grad_kernel, neighbor_map)
+    fwd, back = _tables_of(neighbor_map, neighbor_offset, in_feat.shape[0], grad_out_feat.shape[0], bool(transpose))
+    g = grad_out_feat.contiguous().float()
+    grad_in_feat += subm_conv(g, kernel.detach().transpose(1, 2).contiguous(), back).to(grad_in_feat.dtype)
+    grad_kernel += _conv_weight_grad(in_feat, g, fwd, tuple(kernel.shape)).to(grad_kernel.dtype)

@@ -652,6 +652,44 @@ class Conv3d(nn.Module):
         return y
 
 
+def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optional[torch.Tensor] = None, stride=1,
+           dilation=1, transposed: bool = False) -> SparseTensor:
+    """Functional form of the sparse convolution (torchsparse/nn/functional/conv.py:83-147: same arguments, same
+    kmaps / cmaps contract) on the kernels behind link_amd.Conv3d; forms as the module's (odd kernels at stride 1,
+    kernel 2 / stride 2 down and transposed)."""
+    ks, st = make_ntuple(kernel_size, 3), make_ntuple(stride, 3)
+    shell = Conv3d.__new__(Conv3d)                     # the module's forward with the caller's tensors as parameters
+    nn.Module.__init__(shell)
+    shell.kernel_size, shell.stride, shell.dilation, shell.transposed = ks, st, dilation, transposed
+    if len(set(ks)) != 1 or len(set(st)) != 1 or not ((st[0] == 1 and ks[0] % 2 == 1 and not transposed) or
+                                                      (st[0] == 2 and ks[0] == 2)):
+        raise NotImplementedError("link_amd conv3d: odd cubic kernels at stride 1, kernel 2 / stride 2 (down or transposed)")
+    shell.kernel_volume = ks[0] ** 3
+    shell.in_channels, shell.out_channels = weight.shape[-2], weight.shape[-1]
+    shell.__dict__["kernel"], shell.__dict__["bias"] = weight, bias
+    return Conv3d.forward(shell, input)
+
+
+def spdownsample(coords: torch.Tensor, stride=2, kernel_size=2, tensor_stride=1) -> torch.Tensor:
+    """Output coordinates of a strided convolution (torchsparse/nn/functional/downsample.py:11-51): with
+    stride in {1, kernel_size} per axis the coordinates are floored to multiples of stride * tensor_stride;
+    otherwise every position input + offset that lies on the coarse lattice (and not below the inputs' minimum)
+    is an output.  Rows unique, ordered by (batch, x, y, z)."""
+    stride, ks, ts = make_ntuple(stride, 3), make_ntuple(kernel_size, 3), make_ntuple(tensor_stride, 3)
+    ss = torch.tensor([stride[k] * ts[k] for k in range(3)], dtype=torch.int32, device=coords.device)
+    if all(stride[k] in (1, ks[k]) for k in range(3)):
+        c = coords.clone()
+        c[:, :3] = torch.div(c[:, :3], ss, rounding_mode="floor") * ss
+    else:
+        offs = get_kernel_offsets(ks, ts, device=coords.device)
+        lo = coords[:, :3].min(0, keepdim=True).values
+        x = (coords[:, None, :3] + offs[None]).reshape(-1, 3)
+        b = coords[:, 3:].repeat_interleave(offs.shape[0], 0)
+        keep = ((x % ss == 0) & (x >= lo)).all(1)
+        c = torch.cat([x, b], 1)[keep]
+    return torch.unique(c[:, [3, 0, 1, 2]], dim=0)[:, [1, 2, 3, 0]].contiguous()
+
+
 # a voxel with more neighbours than this runs on the output-stationary table kernel (conv.hip): measured
 # cross-over of the two forms on MI355X (tools/convbench.py)
 PAIR_DENSITY_MAX = 17.0

@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from . import backend
 
-__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights"]
+__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights", "conv3d", "spdownsample"]
 
 
 def sphash(coords: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -111,3 +111,15 @@ def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float 
         w[idx_query == -1] = 0
         w /= w.sum(0) + 1e-8
     return w
+
+
+def conv3d(*args, **kwargs):
+    """torchsparse.nn.functional.conv3d (nn/functional/conv.py:83) -- see link_amd.elk.conv3d."""
+    from .elk import conv3d as _impl
+    return _impl(*args, **kwargs)
+
+
+def spdownsample(*args, **kwargs):
+    """torchsparse.nn.functional.spdownsample (nn/functional/downsample.py:11) -- see link_amd.elk.spdownsample."""
+    from .elk import spdownsample as _impl
+    return _impl(*args, **kwargs)

@@ -132,8 +132,10 @@ def test_install_as_torchsparse():
     assert get_kernel_offsets is la.get_kernel_offsets and make_ntuple is la.make_ntuple
     import torchsparse.backend as B
     for name in ("hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda", "voxelize_forward_cuda",
-                 "voxelize_backward_cuda", "devoxelize_forward_cuda", "devoxelize_backward_cuda"):
+                 "voxelize_backward_cuda", "devoxelize_forward_cuda", "devoxelize_backward_cuda",
+                 "convolution_forward_cuda", "convolution_backward_cuda"):
         assert callable(getattr(B, name))
+    assert callable(F.conv3d) and callable(F.spdownsample)      # nn/functional/conv.py:83, downsample.py:11
     for k in [k for k in sys.modules if k == "torchsparse" or k.startswith("torchsparse.")]:
         del sys.modules[k]
 

@@ -304,3 +304,90 @@ def test_pair_form_strided_tables_and_tail():
     a0 = subm_conv_ln_add_relu(feats, conv.kernel.detach(), nbr, order, lw, lb, 1e-6, None, relu=False, form="pairs")
     ref = torch.nn.functional.layer_norm(subm_conv(feats, conv.kernel.detach(), nbr, order, form="table"), (C,), lw, lb, 1e-6)
     assert rel_err(a0.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# functional / backend forms (torchsparse.nn.functional.conv3d, spdownsample; backend.convolution_*_cuda)
+# ------------------------------------------------------------------------------------------------
+def test_functional_conv3d_and_spdownsample():
+    import link_amd as la
+    import link_amd.functional as F
+    from oracle import link_oracle as lo
+    coords = torch.from_numpy(lidar_like(9000, seed=7))
+    n = coords.shape[0]
+    feats = torch.randn(n, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    mod = la.Conv3d(32, 32, 3, bias=True).cuda()
+    with torch.no_grad():
+        a = mod(la.SparseTensor(feats, coords.cuda(), 1))
+        b = F.conv3d(la.SparseTensor(feats, coords.cuda(), 1), mod.kernel, 3, mod.bias)
+    assert torch.equal(a.F, b.F) and torch.equal(a.C, b.C) and a.s == b.s
+    down = la.Conv3d(32, 64, 2, stride=2).cuda()
+    up = la.Conv3d(64, 32, 2, stride=2, transposed=True).cuda()
+    with torch.no_grad():
+        x = la.SparseTensor(feats, coords.cuda(), 1)
+        x.cmaps.setdefault(x.s, x.C)                    # a stride-1 layer would have registered them (conv.py:144)
+        d1 = down(x)
+        u1 = up(d1)
+        y = la.SparseTensor(feats, coords.cuda(), 1)
+        y.cmaps.setdefault(y.s, y.C)
+        d2 = F.conv3d(y, down.kernel, 2, None, stride=2)
+        u2 = F.conv3d(d2, up.kernel, 2, None, stride=2, transposed=True)
+    assert torch.equal(d1.F, d2.F) and torch.equal(d1.C, d2.C) and d2.s == (2, 2, 2)
+    assert torch.equal(u1.F, u2.F) and torch.equal(u2.C, coords.cuda())
+    # spdownsample: the k2-s2 branch is the module's coordinate set; the general branch (k3-s2) by brute force
+    c2 = F.spdownsample(coords.cuda(), 2, 2, 1)
+    assert torch.equal(c2, d1.C)
+    assert np.array_equal(c2.cpu().numpy(), lo.downsample_coords(coords.numpy(), 2, 1))
+    small = s_uniform(400, grid=12, seed=2).cuda()
+    c3 = F.spdownsample(small, 2, 3, 1).cpu().numpy()
+    cn = small.cpu().numpy()
+    cand = set()
+    lo3 = cn[:, :3].min(0)
+    for row in cn:
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    p = row[:3] + (dx, dy, dz)
+                    if (p % 2 == 0).all() and (p >= lo3).all():
+                        cand.add((int(row[3]), int(p[0]), int(p[1]), int(p[2])))
+    ref = np.array(sorted(cand), dtype=np.int32)[:, [1, 2, 3, 0]]
+    assert np.array_equal(c3, ref)
+
+
+def test_backend_convolution_names_with_reference_kmap_layout():
+    """torchsparse.backend.convolution_forward_cuda / convolution_backward_cuda with the reference's kernel map
+    (pairs grouped by offset + per-offset sizes on the host, conv.py:109-122), against a torch loop over offsets."""
+    import link_amd as la
+    import link_amd.backend as B
+    coords = torch.from_numpy(lidar_like(8000, seed=9)).cuda()
+    n, cin, cout = coords.shape[0], 32, 64
+    conv = la.Conv3d(cin, cout, 3).cuda()
+    st = la.SparseTensor(torch.randn(n, cin, device="cuda"), coords, 1)
+    nbr, _ = conv._neighbor_table(st)
+    res = nbr.t().contiguous()                                  # [K, N_out] like sphashquery's result
+    nbsizes = (res != -1).sum(1)
+    nz = torch.nonzero(res != -1)
+    nbmaps = torch.stack([res[nz[:, 0], nz[:, 1]].long(), nz[:, 1]], 1).int()   # (in, out) grouped by offset
+    w = conv.kernel.detach()
+    out = torch.zeros(n, cout, device="cuda")
+    B.convolution_forward_cuda(st.F, out, w, nbmaps, nbsizes.cpu().int(), False)
+    ref = torch.zeros(n, cout, device="cuda", dtype=torch.float64)
+    cur = 0
+    for k in range(27):
+        m = nbmaps[cur:cur + int(nbsizes[k])].long()
+        ref.index_add_(0, m[:, 1], st.F[m[:, 0]].double() @ w[k].double())
+        cur += int(nbsizes[k])
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    g = torch.randn(n, cout, device="cuda")
+    gi, gw = torch.zeros(n, cin, device="cuda"), torch.zeros_like(w)
+    B.convolution_backward_cuda(st.F, gi, g, w, gw, nbmaps, nbsizes.cpu().int(), False)
+    gi_ref = torch.zeros(n, cin, device="cuda", dtype=torch.float64)
+    gw_ref = torch.zeros(27, cin, cout, device="cuda", dtype=torch.float64)
+    cur = 0
+    for k in range(27):
+        m = nbmaps[cur:cur + int(nbsizes[k])].long()
+        gi_ref.index_add_(0, m[:, 0], g[m[:, 1]].double() @ w[k].double().t())
+        gw_ref[k] = st.F[m[:, 0]].double().t() @ g[m[:, 1]].double()
+        cur += int(nbsizes[k])
+    assert rel_err(gi.cpu().numpy(), gi_ref.cpu().numpy()) < 1e-5
+    assert rel_err(gw.cpu().numpy(), gw_ref.cpu().numpy()) < 1e-5
