@@ -254,6 +254,64 @@ def cfg3_mode(args, la, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def cfg5_mode(args, la, dev, rank, world, dist):
+    """BASELINE.json configs[4] shape (labelled, NOT the headline): the sparse half of the detection backbone
+    SpMiddleResNetFHDELKv3 (scn.py:452-626: conv_input, 4 x [2 SparseBasicBlocks + tail || TSELKBlock (3x7)^3 + tail],
+    3 k3-s2 SparseConv3d, extra_conv, dense -> BEV [1, 256, 180, 180]) on one S-nusc frame per rank
+    (link_amd/synth.py, seed = rank; ~150k voxels, 5 features, grid 1440 x 1440 x 40), eval forward, fp32, random-init
+    weights.  A step builds every kernel map of the frame (as the reference does per frame); the line also carries
+    the warm-map time.  The dense BEV half (RPN, CenterHead) is plain torch in the reference and not timed."""
+    import torch
+    from link_amd.synth import s_nusc
+    co, fe = s_nusc(seed=rank)
+    indices = torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int().to(dev)
+    feats = torch.from_numpy(fe).to(dev)
+    n = indices.shape[0]
+    torch.manual_seed(0)
+    net = la.SpMiddleResNetFHDELKv3(num_input_features=5).to(dev).eval()
+    shape = [1440, 1440, 40]
+
+    def timed(k, w, maps):
+        with torch.no_grad():
+            for _ in range(w):
+                net(feats, indices, 1, shape, indice_dict=maps)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                net(feats, indices, 1, shape, indice_dict=maps)
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    k, w = min(args.steps, 30), min(args.warmup, 3)
+    t_cold = timed(k, w, None)
+    t_warm = timed(k, w, {})
+    with torch.no_grad():
+        bev, scales = net(feats, indices, 1, shape)
+    nv = torch.tensor([float(n)], device=dev)
+    if world > 1:
+        dist.all_reduce(nv)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "voxels_per_second", "value": float(nv.item()) * k / t_cold, "unit": "voxels/s", "n_gpus": world,
+            "steps": k, "warmup": w, "ms_per_step": 1e3 * t_cold / k, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (S-nusc ray-cast frame, SURVEY.md 8d; random-init weights)",
+            "headline": False,
+            "config": {"workload": "cfg5 (labelled secondary mode): sparse half of SpMiddleResNetFHDELKv3, eval forward, kernel "
+                                   "maps built per frame, one S-nusc frame per GPU",
+                       "voxels": n, "stage_voxels": [scales[f"conv{i}"].features.shape[0] for i in (1, 2, 3, 4)],
+                       "bev": list(bev.shape), "parallelism": f"dp{world}"},
+            "warm_maps_ms": 1e3 * t_warm / k, "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,9 +323,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
                     help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
                     help="cfg2 = the headline (R_core, S-uniform); cfg3 = labelled secondary mode: forward and "
-                         "forward+backward of the LinK encoder stages on one S-kitti frame per rank")
+                         "forward+backward of the LinK encoder stages on one S-kitti frame per rank; cfg5 = labelled: "
+                         "sparse half of the detection backbone (SpMiddleResNetFHDELKv3) on one S-nusc frame per rank")
     args = ap.parse_args()
 
     import torch
@@ -308,6 +367,8 @@ def main():
 
     if args.workload == "cfg3":
         return cfg3_mode(args, la, dev, rank, world, dist)
+    if args.workload == "cfg5":
+        return cfg5_mode(args, la, dev, rank, world, dist)
 
     N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
     torch.manual_seed(2)
