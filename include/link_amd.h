@@ -427,19 +427,28 @@ int link_conv_pairs_sum(const float *contrib, const int32_t *ext_start, const in
  * out[i] = epilogue(feats[i] . w[centre] + sum of contrib[ext_list[ext_start[i] .. ext_start[i+1])]) with the
  * same epilogue as link_conv_pairs_sum.  contrib (contrib_rows rows, < 4 GiB) then holds only the OTHER offsets' rows (link_conv_pairs_gemm
  * over a pair list without the centre), so the centre term never travels through HBM. */
+/* Output sites of a site-creating sparse convolution (spconv's SparseConv3d as the detection backbone uses it,
+ * scn.py:496-502: kernel 3 or 1, stride 2 or 1, padding per axis; axes (z, y, x), indices i32[n,4] = (b, z, y, x)):
+ * cand i32[n * link_conv_out_candidate_count(kernel, stride), 4] receives every candidate site of every input, rows
+ * of -1 where a combination is invalid or outside out_shape.  Sorted unique rows = link_index_build with block
+ * edge 1 over `cand` (out-of-range rows are dropped there). */
+int32_t link_conv_out_candidate_count(const int32_t *kernel, const int32_t *stride);
+int link_conv_out_candidates(const int32_t *indices, int64_t n, const int32_t *kernel, const int32_t *stride,
+                             const int32_t *padding, const int32_t *out_shape, int32_t *cand, void *stream);
 /* Building the pair plan from a per-output neighbour table nbr i32[n, kvol] (-1 absent), kvol <= 64 -- the device
- * half of what nn/functional/conv.py:109-122 does with nonzero / sum on the host side:
- *   link_pair_plan_count   stats i32[kvol + 1] (zero on entry): stats[k] += pairs of offset k, stats[kvol] += rows
- *                          whose centre entry nbr[i, kvol/2] != i (0 <=> submanifold table); row_info i32[n] =
- *                          (#valid entries of the row) | (centre entry valid) << 16.
- *   link_pair_plan_fill    (after the host laid out base_k i32[kvol] = first contribution row of every offset's
- *                          granules, and ext_start i32[n+1] = exclusive scan of the rows' list lengths):
- *                          pair_in[p] = input row of pair p (pair_in pre-filled with -1), ext_list = every row's
- *                          contribution rows in ascending offset order; counters i32[kvol] zero on entry;
- *                          skip_centre != 0 leaves the centre offset out (link_conv_centre_sum computes it). */
-int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *stats, int32_t *row_info, void *stream);
+ * half of what nn/functional/conv.py:109-122 does with nonzero / sum on the host side.  G = ceil(n / 256) workgroups:
+ *   link_pair_plan_count   wg_counts i32[G, kvol + 1]: per workgroup, pairs of every offset, and (last column) rows
+ *                          whose centre entry nbr[i, kvol/2] != i (column sum 0 <=> submanifold table);
+ *                          row_info i32[n] = (#valid entries of the row) | (centre entry valid) << 16.
+ *   link_pair_plan_fill    after the host laid out base_k i32[kvol] (first contribution row of every offset's
+ *                          128-row granules), wg_base i32[G, kvol] (exclusive scan of wg_counts over the workgroups)
+ *                          and ext_start i32[n+1] (exclusive scan of the rows' list lengths): pair_in[p] = input row
+ *                          of pair p (pair_in pre-filled with -1), ext_list = every row's contribution rows in
+ *                          ascending offset order.  No atomics: placement is deterministic.  skip_centre != 0 leaves
+ *                          the centre offset out (link_conv_centre_sum computes it). */
+int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *wg_counts, int32_t *row_info, void *stream);
 int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
-                        const int32_t *ext_start, int32_t *counters, int32_t *pair_in, int32_t *ext_list, void *stream);
+                        const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *ext_list, void *stream);
 int link_conv_centre_sum(const float *feats, const float *w, int32_t centre, const float *contrib,
                          int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
                          const float *bias, const float *ln_w, const float *ln_b, float eps, const float *addend,

@@ -275,7 +275,8 @@ static int launch_pairs_gemm(const float *feats, const int32_t *pair_in, const i
 extern "C" int link_conv_pairs_supported(int32_t cin, int32_t cout) {
   const bool sq = cin == cout && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
   const bool rect = (cin == 16 && cout == 32) || (cin == 32 && cout == 16) || (cin == 32 && cout == 64) ||
-                    (cin == 64 && cout == 32) || (cin == 64 && cout == 128) || (cin == 128 && cout == 64);
+                    (cin == 64 && cout == 32) || (cin == 64 && cout == 128) || (cin == 128 && cout == 64) ||
+                    (cin == 16 && cout == 64) || (cin == 64 && cout == 16);
   return (sq || rect) ? 1 : 0;
 }
 
@@ -289,6 +290,7 @@ extern "C" int link_conv_pairs_gemm(const float *feats, const int32_t *pair_in, 
 #define LINK_CP(I, O) if (cin == I && cout == O) return launch_pairs_gemm<I, O>(feats, pair_in, wg_k, gr, w, contrib, st)
   LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
   LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
+  LINK_CP(16, 64); LINK_CP(64, 16);
 #undef LINK_CP
   return LINK_ERR_ARG;
 }
@@ -355,6 +357,7 @@ extern "C" int link_conv_centre_sum(const float *feats, const float *w, int32_t 
 #define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O>(feats, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
   LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
   LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
+  LINK_CC(16, 64); LINK_CC(64, 16);
 #undef LINK_CC
   return LINK_ERR_ARG;
 }
@@ -365,21 +368,23 @@ extern "C" int link_conv_centre_sum(const float *feats, const float *w, int32_t 
 // Two passes over the table with one host round trip between them (the host needs the per-offset pair counts
 // to lay out the 128-row granules and to size the contribution buffer -- the same numbers the reference's
 // nbsizes holds on the host, nn/functional/conv.py:114-116):
-//   k_pair_count   stats[k] = pairs of offset k, stats[kvol] = rows whose centre entry is not the row itself
-//                  (0 <=> submanifold table); row_info[i] = (#valid entries) | (centre valid) << 16
-//   k_pair_fill    contribution row p of every pair: base_k[k] + a rank inside the offset handed out by ONE
-//                  atomic per wave and offset (ballot + prefix); pair_in[p] = input row, and the voxel's CSR
-//                  list in ascending offset order.  Ranks depend on the schedule, results do not: the output
-//                  kernels sum a voxel's rows in CSR order, wherever the rows live.
+//   count pass     per workgroup (256 table rows): pairs of every offset, and rows whose centre entry is not the
+//                  row itself (0 in total <=> submanifold table); row_info[i] = (#valid entries) | (centre valid) << 16
+//   fill pass      contribution row p of every pair = first row of its offset's granules + pairs of that offset in
+//                  earlier workgroups (the host's scan of the count pass) + in earlier waves / lanes (LDS, ballot):
+//                  no atomics, placement is deterministic; pair_in[p] = input row, and the voxel's CSR list in
+//                  ascending offset order.
 // The workgroup stages its 256 table rows through LDS (coalesced reads; row stride kvol is odd for every
 // kernel the networks use, so the per-lane walk is conflict-free).
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ nbr, int64_t n, int kvol, int centre,
                                                    int skip_centre, const int32_t *__restrict__ base_k,
-                                                   const int32_t *__restrict__ ext_start, int32_t *__restrict__ counters,
-                                                   int32_t *__restrict__ row_info, int32_t *__restrict__ pair_in,
-                                                   int32_t *__restrict__ ext_list) {
-  extern __shared__ int32_t tile[];                    // [256][kvol]
+                                                   const int32_t *__restrict__ wg_base, const int32_t *__restrict__ ext_start,
+                                                   int32_t *__restrict__ wg_counts, int32_t *__restrict__ row_info,
+                                                   int32_t *__restrict__ pair_in, int32_t *__restrict__ ext_list) {
+  extern __shared__ int32_t smem[];
+  int32_t *tile = smem;                                // [256][kvol]
+  int32_t *wcnt = smem + 256 * kvol;                   // [4][kvol + 1]: pairs per wave and offset (+ identity misses)
   const int64_t row0 = (int64_t)blockIdx.x * 256;
   const int rows = (int)((n - row0 < 256) ? n - row0 : 256);
   const int tot = rows * kvol;
@@ -389,58 +394,137 @@ __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ n
   const int r = threadIdx.x;
   const bool live = r < rows;
   const int32_t *mine = tile + (live ? r : 0) * kvol;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  int q = (FILL && live) ? ext_start[row0 + r] : 0;
   int nvalid = 0, cvalid = 0;
+  // pass A: this wave's pair count per offset -> LDS (no global atomics: 27 counters shared by every wave of the
+  // grid serialise in the L2 and made this kernel the longest of a cold frame)
   for (int k = 0; k < kvol; k++) {
     const int v = live ? mine[k] : -1;
     bool valid = v >= 0;
     if (k == centre) {
       cvalid = valid ? 1 : 0;
-      if (!FILL) {
-        const unsigned long long bad = __ballot(live && v != (int)(row0 + r));
-        if (bad && lane == 0) atomicAdd(&counters[kvol], __popcll(bad));
-      }
+      const unsigned long long bad = __ballot(live && v != (int)(row0 + r));
+      if (lane == 0) wcnt[wave * (kvol + 1) + kvol] = __popcll(bad);
       if (FILL && skip_centre) valid = false;
     }
     const unsigned long long m = __ballot(valid);
-    if (m) {
-      int b = 0;
-      if (lane == 0) b = atomicAdd(&counters[k], __popcll(m));
-      if (FILL) {
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (valid) {
-          const int p = base_k[k] + b + __popcll(m & lt);
-          pair_in[p] = v;
-          ext_list[q++] = p;
-        }
-      }
-    }
+    if (lane == 0) wcnt[wave * (kvol + 1) + k] = __popcll(m);
     nvalid += valid ? 1 : 0;
   }
-  if (!FILL && live) row_info[row0 + r] = nvalid | (cvalid << 16);
+  __syncthreads();
+  if (!FILL) {
+    if (live) row_info[row0 + r] = nvalid | (cvalid << 16);
+    if (threadIdx.x <= kvol) {                         // per-workgroup totals; the host sums / scans them
+      const int k = threadIdx.x;
+      wg_counts[(int64_t)blockIdx.x * (kvol + 1) + k] =
+          wcnt[k] + wcnt[(kvol + 1) + k] + wcnt[2 * (kvol + 1) + k] + wcnt[3 * (kvol + 1) + k];
+    }
+    return;
+  }
+  // pass B: contribution row = first row of the offset's granules + pairs of earlier workgroups + earlier waves of
+  // this workgroup + earlier lanes of this wave: deterministic placement, voxel ascending inside an offset
+  int q = live ? ext_start[row0 + r] : 0;
+  for (int k = 0; k < kvol; k++) {
+    if (skip_centre && k == centre) continue;
+    const int v = live ? mine[k] : -1;
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (valid) {
+      int before = 0;
+      for (int w = 0; w < wave; w++) before += wcnt[w * (kvol + 1) + k];
+      const int p = base_k[k] + wg_base[(int64_t)blockIdx.x * kvol + k] + before + __popcll(m & lt);
+      pair_in[p] = v;
+      ext_list[q++] = p;
+    }
+  }
 }
 
-extern "C" int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *stats, int32_t *row_info,
+extern "C" int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *wg_counts, int32_t *row_info,
                                     void *stream) {
   if (n < 0 || kvol <= 0 || kvol > 64) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  if (!nbr || !stats || !row_info) return LINK_ERR_ARG;
+  if (!nbr || !wg_counts || !row_info) return LINK_ERR_ARG;
   const unsigned wgs = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_pair_plan<false>, dim3(wgs), dim3(256), (size_t)256 * kvol * 4, S(stream), nbr, n, (int)kvol, (int)(kvol / 2), 0,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr, stats, row_info, (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(k_pair_plan<false>, dim3(wgs), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
+                     (int)kvol, (int)(kvol / 2), 0, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                     wg_counts, row_info, (int32_t *)nullptr, (int32_t *)nullptr);
   return check_launch("link_pair_plan_count");
 }
 
 extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
-                                   const int32_t *ext_start, int32_t *counters, int32_t *pair_in, int32_t *ext_list,
+                                   const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *ext_list,
                                    void *stream) {
   if (n < 0 || kvol <= 0 || kvol > 64) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  if (!nbr || !base_k || !ext_start || !counters || !pair_in || !ext_list) return LINK_ERR_ARG;
+  if (!nbr || !base_k || !wg_base || !ext_start || !pair_in || !ext_list) return LINK_ERR_ARG;
   const unsigned wgs = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_pair_plan<true>, dim3(wgs), dim3(256), (size_t)256 * kvol * 4, S(stream), nbr, n, (int)kvol, (int)(kvol / 2),
-                     (int)skip_centre, base_k, ext_start, counters, (int32_t *)nullptr, pair_in, ext_list);
+  hipLaunchKernelGGL(k_pair_plan<true>, dim3(wgs), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
+                     (int)kvol, (int)(kvol / 2), (int)skip_centre, base_k, wg_base, ext_start, (int32_t *)nullptr,
+                     (int32_t *)nullptr, pair_in, ext_list);
   return check_launch("link_pair_plan_fill");
+}
+
+// ---------------------------------------------------------------------------------------------
+// output sites of a site-creating (regular) sparse convolution: candidate rows
+// ---------------------------------------------------------------------------------------------
+// A site o exists when some active input i and tap a satisfy o * s = i + p - a (per axis).  Per axis an input
+// offers few candidates: kernel 3 / stride 2 -> floor((i+p)/2) and, when i+p is even, one less; otherwise one
+// per tap whose numerator divides.  Thread (input, combination) writes its candidate row (b, z, y, x) -- or a
+// row of -1 when a factor is invalid or outside the output shape; duplicates and the -1 rows are what the
+// dense-grid block index (link_index_build with block edge 1) is built to drop, and its sorted unique rows are
+// the output sites.
+struct conv_geom { int k[3], s[3], p[3], oshape[3], slots[3]; };
+
+__global__ void __launch_bounds__(256) k_conv_out_candidates(const int4 *__restrict__ ind, int64_t n, conv_geom g, int ncomb,
+                                                             int4 *__restrict__ cand) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * ncomb) return;
+  const int64_t i = t / ncomb;
+  int c = (int)(t - i * ncomb);
+  const int4 r = ind[i];                               // (b, z, y, x)
+  const int pos[3] = {r.y, r.z, r.w};
+  int o[3];
+  bool ok = true;
+#pragma unroll
+  for (int d = 2; d >= 0; d--) {
+    const int j = c % g.slots[d];
+    c /= g.slots[d];
+    const int v = pos[d] + g.p[d];
+    if (g.k[d] == 3 && g.s[d] == 2) {
+      o[d] = (v >> 1) - j;
+      ok &= (j == 0) || ((v & 1) == 0);
+    } else {
+      const int num = v - j;                           // tap j
+      o[d] = num / g.s[d];
+      ok &= num >= 0 && num % g.s[d] == 0;
+    }
+    ok &= o[d] >= 0 && o[d] < g.oshape[d];
+  }
+  cand[t] = ok ? make_int4(r.x, o[0], o[1], o[2]) : make_int4(-1, -1, -1, -1);
+}
+
+extern "C" int link_conv_out_candidates(const int32_t *indices, int64_t n, const int32_t *kernel, const int32_t *stride,
+                                        const int32_t *padding, const int32_t *out_shape, int32_t *cand, void *stream) {
+  if (n < 0 || !kernel || !stride || !padding || !out_shape) return LINK_ERR_ARG;
+  conv_geom g;
+  int ncomb = 1;
+  for (int d = 0; d < 3; d++) {
+    g.k[d] = kernel[d]; g.s[d] = stride[d]; g.p[d] = padding[d]; g.oshape[d] = out_shape[d];
+    if ((g.k[d] != 1 && g.k[d] != 3) || (g.s[d] != 1 && g.s[d] != 2) || g.p[d] < 0 || g.oshape[d] <= 0) return LINK_ERR_ARG;
+    g.slots[d] = (g.k[d] == 3 && g.s[d] == 2) ? 2 : g.k[d];
+    ncomb *= g.slots[d];
+  }
+  if (n == 0) return LINK_OK;
+  if (!indices || !cand || n * ncomb >= (1LL << 31)) return LINK_ERR_ARG;
+  const int64_t total = n * ncomb;
+  hipLaunchKernelGGL(k_conv_out_candidates, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(indices), n, g, ncomb, reinterpret_cast<int4 *>(cand));
+  return check_launch("link_conv_out_candidates");
+}
+
+extern "C" int32_t link_conv_out_candidate_count(const int32_t *kernel, const int32_t *stride) {
+  int ncomb = 1;
+  for (int d = 0; d < 3; d++) ncomb *= (kernel[d] == 3 && stride[d] == 2) ? 2 : kernel[d];
+  return ncomb;
 }

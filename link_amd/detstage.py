@@ -24,6 +24,7 @@ The k3-s2 SparseConv3d between the stages (it creates new active sites) is not p
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -260,42 +261,42 @@ class SparseConv3d(nn.Module):
         dev = sct.indices.device
         oshape = self.out_shape(sct.spatial_shape)
         k, s, p = self.kernel_size, self.stride, self.padding
+        n = sct.indices.shape[0]
+        lib, stream = L.lib(), L.current_stream_handle()
         cst = self.__dict__.setdefault("_const", {}).get(dev)
         if cst is None:                                  # small constant tensors: one H2D each, once per device
             offs = get_kernel_offsets(3, device="cpu").tolist()
             col = {(o3[2] + 1, o3[1] + 1, o3[0] + 1): j for j, o3 in enumerate(offs)}      # window position (a,b,c)
             sel = [col[(a if k[0] == 3 else 1, b if k[1] == 3 else 1, c if k[2] == 3 else 1)] for a, b, c in self._taps()]
-            cst = self._const[dev] = (torch.tensor(self._taps(), device=dev), torch.tensor(p, device=dev),
-                                      torch.tensor(s, device=dev), torch.tensor([1 if kk == 3 else 0 for kk in k], device=dev),
-                                      torch.tensor(sel, device=dev))
-        taps, p_t, st, centre, sel_t = cst
-        # output sites: o with o * s = i + p - tap for some active input i and tap, inside the output shape;
-        # deduplicated on a linear key (ascending key = lexicographic (b, z, y, x)).  (A per-axis candidate product
-        # -- at most 8 instead of 27 candidates per input -- was measured slower: more, smaller torch launches.)
-        ind = sct.indices.long()
-        num = ind[:, None, 1:] + p_t - taps[None]
-        o = torch.div(num, st, rounding_mode="floor")
-        ok = (num == o * st).all(-1) & (o >= 0).all(-1) & (o[..., 0] < oshape[0]) & (o[..., 1] < oshape[1]) & (o[..., 2] < oshape[2])
-        lin = ((ind[:, None, 0] * oshape[0] + o[..., 0]) * oshape[1] + o[..., 1]) * oshape[2] + o[..., 2]
-        uk = torch.unique(lin[ok])
-        ox = uk % oshape[2]; r1 = torch.div(uk, oshape[2], rounding_mode="floor")
-        oy = r1 % oshape[1]; r2 = torch.div(r1, oshape[1], rounding_mode="floor")
-        oz = r2 % oshape[0]; ob = torch.div(r2, oshape[0], rounding_mode="floor")
-        out_ind = torch.stack([ob, oz, oy, ox], 1)
-        # table[j, t] = input row at out_ind[j] * s - p + tap_t  (dense cell table of the input sites).  A 3-wide
-        # window per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its one tap
-        # sits at o*s - p, the window centre
-        from .index import foreign_neighbor_map
-        in_xyzb = sct.indices[:, [3, 2, 1, 0]].contiguous().int()
-        base = out_ind[:, 1:] * st - p_t + centre
-        rows = torch.cat([base[:, [2, 1, 0]], out_ind[:, :1]], 1).int().contiguous()      # (x, y, z, b)
-        full = foreign_neighbor_map(rows, 3, table_rows=in_xyzb)                           # [M, 27], offsets (dx,dy,dz)
-        sel = sel_t
-        table = full[:, sel].contiguous()
-        jj, tt = torch.nonzero(table >= 0, as_tuple=True)
-        back = torch.full((sct.indices.shape[0], table.shape[1]), -1, dtype=torch.int32, device=dev)
-        back[table[jj, tt].long(), tt] = jj.int()
-        hit = sct.indice_dict[key] = (out_ind.int().contiguous(), table, back, sct.indices)
+            cst = self._const[dev] = (torch.tensor(sel, device=dev),
+                                      torch.tensor([s[2], s[1], s[0], 1], dtype=torch.int32, device=dev),
+                                      torch.tensor([(1 if k[2] == 3 else 0) - p[2], (1 if k[1] == 3 else 0) - p[1],
+                                                    (1 if k[0] == 3 else 0) - p[0], 0], dtype=torch.int32, device=dev))
+        sel_t, mul_t, add_t = cst
+        # output sites: candidates of every input (HIP), then their sorted unique rows through the dense-grid block
+        # index with block edge 1 (rows of -1 = invalid combinations, dropped there); columns are (b, z, y, x), so the
+        # index's lexicographic row order is the site order
+        i3 = ctypes.c_int32 * 3
+        ka, sa, pa, oa = i3(*k), i3(*s), i3(*p), i3(*oshape)
+        ncomb = int(lib.link_conv_out_candidate_count(ka, sa))
+        ind = sct.indices.contiguous()
+        cand = torch.empty((max(n * ncomb, 1), 4), dtype=torch.int32, device=dev)
+        L.check(lib.link_conv_out_candidates(ind.data_ptr(), n, ka, sa, pa, oa, cand.data_ptr(), stream), "link_conv_out_candidates")
+        from .index import BlockIndex, foreign_neighbor_map
+        hi = (int(sct.batch_size) - 1, oshape[0] - 1, oshape[1] - 1, oshape[2] - 1)
+        idx = BlockIndex(cand[: n * ncomb], 1, bounds=((0, 0, 0, 0), hi), want_idx64=False)
+        m = int(idx.hdr[L.HDR_M].item())                 # the one host round trip of this map
+        out_ind = idx.blk_coords[:m]
+        # table[j, t] = input row at out_ind[j] * s - p + tap_t (dense cell table of the input sites).  A 3-wide window
+        # per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its tap is the centre
+        rows = out_ind[:, [3, 2, 1, 0]] * mul_t + add_t                                    # (x, y, z, b) window centres
+        in_xyzb = ind[:, [3, 2, 1, 0]].contiguous()
+        shp = [int(v) for v in sct.spatial_shape]
+        full = foreign_neighbor_map(rows.contiguous(), 3, table_rows=in_xyzb,
+                                    bounds=((0, 0, 0, 0), (shp[2] - 1, shp[1] - 1, shp[0] - 1, int(sct.batch_size) - 1)))
+        table = full[:, sel_t].contiguous()
+        back = None                                      # transposed direction: built on the first backward
+        hit = sct.indice_dict[key] = [out_ind.contiguous(), table, back, sct.indices]
         return hit[0], hit[1], hit[2]
 
     def _out_tensor(self, sct, out_ind, feats):
@@ -308,6 +309,12 @@ class SparseConv3d(nn.Module):
         w = self.kernel_kio()
         if torch.is_grad_enabled() and (sct.features.requires_grad or self.weight.requires_grad):
             from .elk import _GatherConv
+            if back is None:                             # back[i, t] = output row that reads input i through tap t
+                key = ("link_sparse_conv", sct.indices.data_ptr(), sct.indices.shape[0], self.kernel_size, self.stride, self.padding)
+                jj, tt = torch.nonzero(table >= 0, as_tuple=True)
+                back = torch.full((sct.indices.shape[0], table.shape[1]), -1, dtype=torch.int32, device=table.device)
+                back[table[jj, tt].long(), tt] = jj.int()
+                sct.indice_dict[key][2] = back
             out = _GatherConv.apply(sct.features.float(), w, table, back)
         else:
             out = subm_conv(sct.features, w, table, None)

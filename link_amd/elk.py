@@ -139,10 +139,7 @@ class ElkCorePlan:
         if layout not in ("auto", "dense", "general"):
             raise ValueError(f"layout must be auto|dense|general, got {layout!r}")
         dcg = L.dc_grid_from(self.grid) if layout != "general" else None
-        # 32-bit byte offsets in every table, and a slot arena (vp * k records of 16 B) of at most 1 GiB
-        ok = (dcg is not None and c in (16, 32, 64, 128) and r in (2, 3)
-              and (dcg.vp + 1) * self.parts * c * 4 < 2 ** 32 and n_cap * c * 4 < 2 ** 32
-              and dcg.vp * dcg.k * 16 <= 2 ** 30)
+        ok = dcg is not None and self._dense_supported(dcg, n_cap, c, r, self.parts)
         if layout == "dense" and not ok:
             raise L.LinkAmdError("ElkCorePlan(layout='dense'): width / r / grid size not supported by the "
                                  "dense-cell path (include/link_amd.h section E)")
@@ -155,6 +152,21 @@ class ElkCorePlan:
             self._init_dense()
         else:
             self._init_general()
+
+    @staticmethod
+    def _dense_supported(dcg, n_cap: int, c: int, r: int, parts: int) -> bool:
+        # 32-bit byte offsets in every table, and a slot arena (vp * k records of 16 B) of at most 1 GiB
+        return (c in (16, 32, 64, 128) and r in (2, 3) and (dcg.vp + 1) * parts * c * 4 < 2 ** 32
+                and n_cap * c * 4 < 2 ** 32 and dcg.vp * dcg.k * 16 <= 2 ** 30)
+
+    @classmethod
+    def would_be_dense(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, dense_ratio: float = 4.0) -> bool:
+        """What layout='auto' would choose, without allocating anything."""
+        try:
+            dcg = L.dc_grid_from(L.grid_from_bounds(bounds[0], bounds[1], int(s)))
+        except L.LinkAmdError:
+            return False
+        return cls._dense_supported(dcg, n_cap, c, r, 3 if baseop == "cos_x" else 2) and dcg.vp <= dense_ratio * max(n_cap, 1)
 
     def _init_dense(self):
         g, dev, n_cap, c = self.dcg, self.device, self.n_cap, self.c
@@ -709,13 +721,14 @@ class _PairPlan:
         lib, st = L.lib(), _st()
         nbr = nbr.contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
-        # pass 1 on the device, then ONE host round trip for what the layout needs: pairs per kernel offset and
-        # whether the centre column is the identity (include/link_amd.h: link_pair_plan_count / _fill)
-        stats = torch.zeros(kvol + 1, **i32)
+        # pass 1 on the device (per-workgroup counts), then ONE host round trip for what the layout needs: pairs per
+        # kernel offset and whether the centre column is the identity (include/link_amd.h: link_pair_plan_count / _fill)
+        nwg = (n + 255) // 256
+        wg_counts = torch.empty((max(nwg, 1), kvol + 1), **i32)
         row_info = torch.empty(max(n, 1), **i32)
-        L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, stats.data_ptr(), row_info.data_ptr(), st),
+        L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, wg_counts.data_ptr(), row_info.data_ptr(), st),
                 "link_pair_plan_count")
-        host = stats.tolist()
+        host = wg_counts[:nwg].sum(0).tolist() if n else [0] * (kvol + 1)
         direct = bool(kvol % 2 == 1 and n > 0 and host[kvol] == 0)
         cnt_k = host[:kvol]
         if direct:
@@ -735,15 +748,16 @@ class _PairPlan:
         pair_in = torch.full((max(self.rows_pad, 1),), -1, **i32)
         ext_list = torch.empty(max(self.pairs, 1), **i32)
         import numpy as _np
-        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), _np.zeros(kvol, dtype=_np.int32),
-                                _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
-        meta = torch.from_numpy(meta).to(dev)                      # base_k | counters (zero) | wg_k: one H2D
+        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
+        meta = torch.from_numpy(meta).to(dev)                      # base_k | wg_k: one H2D
         if self.pairs:
-            L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), ext_start.data_ptr(),
-                                            meta[kvol:].data_ptr(), pair_in.data_ptr(), ext_list.data_ptr(), st),
+            per_wg = wg_counts[:nwg, :kvol]
+            wg_base = (torch.cumsum(per_wg, 0, dtype=torch.int32) - per_wg).contiguous()    # exclusive scan over workgroups
+            L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), wg_base.data_ptr(),
+                                            ext_start.data_ptr(), pair_in.data_ptr(), ext_list.data_ptr(), st),
                     "link_pair_plan_fill")
         self._meta = meta
-        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[2 * kvol:], ext_start, ext_list
+        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[kvol:], ext_start, ext_list
         self._contrib: Dict[int, torch.Tensor] = {}
 
     def contrib(self, cout: int) -> torch.Tensor:
@@ -766,6 +780,25 @@ def _pair_plan(nbr: torch.Tensor, cin: int, cout: int) -> Optional[_PairPlan]:
         plan = _PairPlan(nbr)
         nbr._link_pairs = plan
     return plan if plan.density <= PAIR_DENSITY_MAX else None
+
+
+def _pad_in_channels(f: torch.Tensor, w: torch.Tensor, kernel: torch.Tensor, cin: int, cout: int):
+    """Few input channels (the networks' first layers: 4 or 5 point features) run the MFMA kernels with the rows
+    zero-padded to 16 channels (the weight's extra rows are zero; cached per kernel version): (f, w, cin)."""
+    cin_p = (cin + 15) // 16 * 16
+    if cin_p == cin or cin > 16 or not L.lib().link_conv_pairs_supported(cin_p, cout):
+        return f, w, cin
+    hit = getattr(kernel, "_link_padded", None)
+    ver = (kernel._version, kernel.data_ptr())
+    if hit is None or hit[0] != ver:
+        wp = torch.zeros((w.shape[0], cin_p, cout), dtype=torch.float32, device=w.device)
+        wp[:, :cin] = w
+        hit = (ver, wp)
+        try:
+            kernel._link_padded = hit
+        except AttributeError:
+            pass
+    return TF.pad(f, (0, cin_p - cin)), hit[1], cin_p
 
 
 def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False):
@@ -825,6 +858,8 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
+    if form != "table" and w.ndim == 3:
+        f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
     plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
     if form == "pairs" and plan is None:
         plan = getattr(nbr, "_link_pairs", None)
@@ -857,6 +892,8 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     add = addend.detach().contiguous().float() if addend is not None else None
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     lw, lb = ln_w.detach().contiguous().float(), ln_b.detach().contiguous().float()
+    if form != "table":
+        f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
     plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
     if form == "pairs" and plan is None:
         plan = getattr(nbr, "_link_pairs", None)
@@ -996,6 +1033,8 @@ class _ELKBase(nn.Module):
         # alone cannot tell the two apart, so the occupancy is measured once per coordinate set (cached in cmaps;
         # one small sync, like coords_bounds).  Caller-supplied bounds (TSELKBlock + spatial_shape) promise a
         # sync-free call, so those frames use the general layout unless the module opts in (dense_layout = True).
+        if getattr(self, "dense_layout", None) is False:     # TSELKBlock: LiDAR detection frames, clumpy by nature
+            return None
         okey = ("link_dense_ok", coords.data_ptr(), n, s_eff)
         ok = st.cmaps.get(okey)
         unchecked = st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n))
@@ -1013,12 +1052,13 @@ class _ELKBase(nn.Module):
         key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, bounds, float(coord_div))
         plan = cache.get(key, False)
         if plan is False:
-            try:
-                plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, bounds, feats.device, coord_div=coord_div)
-                if not plan.dense:
+            plan = None
+            if ElkCorePlan.would_be_dense(n_cap, c, self.baseop, r, s_eff, bounds):
+                try:
+                    plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, bounds, feats.device, coord_div=coord_div,
+                                       layout="dense")
+                except L.LinkAmdError:
                     plan = None
-            except L.LinkAmdError:
-                plan = None
             if len(cache) >= 8:                              # arenas are large: keep the cache small
                 cache.pop(next(iter(cache)))
             cache[key] = plan
@@ -1217,6 +1257,8 @@ def ts2spconv(st: SparseTensor, sct_save: dict):
 class TSELKBlock(_ELKBase):
     """ts_elk.py:110-230 ('cos' and 'sin' base ops; the other branches of the reference are dead or
     reference an undefined self.alpha)."""
+
+    dense_layout = False          # opt in per instance (True) for frames with small blocks; None = measure per frame
 
     def __init__(self, inc, outc, baseop="cos"):
         super().__init__()
