@@ -149,6 +149,13 @@ int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /
                      int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *vox_sorted,
                      int32_t *pos_blk, int32_t *blk_start, int32_t *blk_coords, int32_t *counts,
                      int32_t *hdr, void *stream);
+/* The cell half of link_index_build alone (no voxel placement): sorted unique block coordinates blk_coords i32[.,4],
+ * counts, cell table and hdr[LINK_HDR_M] of the rows `coords` -- rows outside the grid are dropped (status word).
+ * Same scratch / cell_counts contract as link_index_build.  Used for the output-site set of site-creating
+ * convolutions, whose candidate rows are mostly duplicates. */
+int link_index_cells(const int32_t *coords, int64_t n, const link_grid_t *grid, uint32_t *cell_counts, void *scratch,
+                     size_t scratch_bytes, int32_t *cell_blk, int32_t *blk_start, int32_t *blk_coords, int32_t *counts,
+                     int32_t *hdr, void *stream);
 
 /* Neighbour map nbr i32[M,K] (K = r^3, offsets in get_kernel_offsets(r) order, nn/utils/kernel.py:
  * 11-32: odd r x fastest, even r z fastest): replaces sphash(C, offsets) + sphash + sphashquery +

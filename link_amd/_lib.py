@@ -134,6 +134,8 @@ SIGNATURES = {
     "link_conv_pairs_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "link_conv_pairs_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_int32, c_void_p, c_void_p]),
+    "link_index_cells": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
     "link_conv_out_candidate_count": (c_int32, [c_void_p, c_void_p]),
     "link_conv_out_candidates": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -375,6 +375,35 @@ extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_gri
   return check_launch("link_index_build");
 }
 
+// The first half of link_index_build alone: which cells of the grid are occupied, in cell order -- sorted unique
+// block coordinates, their counts and the cell table, without placing / ordering the voxels.  (Output sites of a
+// site-creating convolution: the "voxels" are candidate rows with many duplicates, only the set matters.)
+extern "C" int link_index_cells(const int32_t *coords, int64_t n, const link_grid_t *grid, uint32_t *cell_counts,
+                                void *scratch, size_t scratch_bytes, int32_t *cell_blk, int32_t *blk_start,
+                                int32_t *blk_coords, int32_t *counts, int32_t *hdr, void *stream) {
+  if (n < 0 || n >= (1LL << 31) || !grid || !hdr) return LINK_ERR_ARG;
+  int64_t v = 1;
+  for (int a = 0; a < 4; a++) {
+    if (grid->dim[a] <= 0) return LINK_ERR_ARG;
+    v *= grid->dim[a];
+    if (v >= (1LL << 30)) return LINK_ERR_ARG;
+  }
+  if (grid->s <= 0) return LINK_ERR_ARG;
+  if (!cell_counts || !scratch || !cell_blk || !blk_start || !blk_coords || !counts || (n > 0 && !coords)) return LINK_ERR_ARG;
+  if (scratch_bytes < link_index_scratch_bytes(n, v)) return LINK_ERR_WORKSPACE;
+  IndexScratch sc = carve(scratch, n, v);
+  const int64_t tiles = scan_tiles(v);
+  hipStream_t st = S(stream);
+  int64_t cc_threads = n > tiles ? n : tiles;
+  if (cc_threads > (1 << 22)) cc_threads = (n > (1 << 22)) ? n : (1 << 22);
+  hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(cc_threads, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const int4 *>(coords), n, *grid, cell_counts, sc.vox_cell,
+                     sc.vox_rank, sc.desc, tiles, sc.ticket);
+  hipLaunchKernelGGL(k_cell_scan, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, st, cell_counts, v,
+                     *grid, sc.desc, sc.ticket, tiles, cell_blk, sc.cell_start, blk_start, blk_coords, counts, hdr);
+  return check_launch("link_index_cells");
+}
+
 // ---------------------------------------------------------------------------------------------
 // neighbour map
 // ---------------------------------------------------------------------------------------------

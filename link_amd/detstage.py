@@ -273,8 +273,8 @@ class SparseConv3d(nn.Module):
                                       torch.tensor([(1 if k[2] == 3 else 0) - p[2], (1 if k[1] == 3 else 0) - p[1],
                                                     (1 if k[0] == 3 else 0) - p[0], 0], dtype=torch.int32, device=dev))
         sel_t, mul_t, add_t = cst
-        # output sites: candidates of every input (HIP), then their sorted unique rows through the dense-grid block
-        # index with block edge 1 (rows of -1 = invalid combinations, dropped there); columns are (b, z, y, x), so the
+        # output sites: candidates of every input (HIP), then their sorted unique rows through the dense cell
+        # grid (link_index_cells; rows of -1 = invalid combinations, dropped there); columns are (b, z, y, x), so the
         # index's lexicographic row order is the site order
         i3 = ctypes.c_int32 * 3
         ka, sa, pa, oa = i3(*k), i3(*s), i3(*p), i3(*oshape)
@@ -282,11 +282,11 @@ class SparseConv3d(nn.Module):
         ind = sct.indices.contiguous()
         cand = torch.empty((max(n * ncomb, 1), 4), dtype=torch.int32, device=dev)
         L.check(lib.link_conv_out_candidates(ind.data_ptr(), n, ka, sa, pa, oa, cand.data_ptr(), stream), "link_conv_out_candidates")
-        from .index import BlockIndex, foreign_neighbor_map
+        from .index import foreign_neighbor_map, unique_cells
         hi = (int(sct.batch_size) - 1, oshape[0] - 1, oshape[1] - 1, oshape[2] - 1)
-        idx = BlockIndex(cand[: n * ncomb], 1, bounds=((0, 0, 0, 0), hi), want_idx64=False)
-        m = int(idx.hdr[L.HDR_M].item())                 # the one host round trip of this map
-        out_ind = idx.blk_coords[:m]
+        sites, hdr = unique_cells(cand[: n * ncomb], ((0, 0, 0, 0), hi))
+        m = int(hdr[L.HDR_M].item())                     # the one host round trip of this map
+        out_ind = sites[:m]
         # table[j, t] = input row at out_ind[j] * s - p + tap_t (dense cell table of the input sites).  A 3-wide window
         # per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its tap is the centre
         rows = out_ind[:, [3, 2, 1, 0]] * mul_t + add_t                                    # (x, y, z, b) window centres

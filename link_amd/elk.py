@@ -728,7 +728,9 @@ class _PairPlan:
         row_info = torch.empty(max(n, 1), **i32)
         L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, wg_counts.data_ptr(), row_info.data_ptr(), st),
                 "link_pair_plan_count")
-        host = wg_counts[:nwg].sum(0).tolist() if n else [0] * (kvol + 1)
+        import numpy as _np
+        per_wg = wg_counts[:nwg].cpu().numpy() if n else _np.zeros((0, kvol + 1), dtype=_np.int32)   # G x (kvol+1) ints
+        host = per_wg.sum(0).tolist()
         direct = bool(kvol % 2 == 1 and n > 0 and host[kvol] == 0)
         cnt_k = host[:kvol]
         if direct:
@@ -747,17 +749,18 @@ class _PairPlan:
         torch.cumsum(ext_cnt, 0, out=ext_start[1:])
         pair_in = torch.full((max(self.rows_pad, 1),), -1, **i32)
         ext_list = torch.empty(max(self.pairs, 1), **i32)
-        import numpy as _np
-        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
-        meta = torch.from_numpy(meta).to(dev)                      # base_k | wg_k: one H2D
+        pk = per_wg[:, :kvol].astype(_np.int32)
+        wg_base = (_np.cumsum(pk, 0, dtype=_np.int32) - pk).reshape(-1)              # exclusive scan over workgroups
+        nwk = wg_base.size
+        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), wg_base,
+                                _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
+        meta = torch.from_numpy(meta).to(dev)                      # base_k | wg_base | wg_k: one H2D
         if self.pairs:
-            per_wg = wg_counts[:nwg, :kvol]
-            wg_base = (torch.cumsum(per_wg, 0, dtype=torch.int32) - per_wg).contiguous()    # exclusive scan over workgroups
-            L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), wg_base.data_ptr(),
-                                            ext_start.data_ptr(), pair_in.data_ptr(), ext_list.data_ptr(), st),
-                    "link_pair_plan_fill")
+            L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(),
+                                            meta[kvol:].data_ptr(), ext_start.data_ptr(), pair_in.data_ptr(),
+                                            ext_list.data_ptr(), st), "link_pair_plan_fill")
         self._meta = meta
-        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[kvol:], ext_start, ext_list
+        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[kvol + nwk:], ext_start, ext_list
         self._contrib: Dict[int, torch.Tensor] = {}
 
     def contrib(self, cout: int) -> torch.Tensor:

@@ -164,6 +164,32 @@ class BlockIndex:
         return self._nbr[key]
 
 
+def unique_cells(rows: torch.Tensor, bounds) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Sorted unique rows of int32 `rows`[n,4] inside `bounds` (rows outside are dropped), lexicographic over the four
+    columns, through the dense cell grid (include/link_amd.h: link_index_cells).  Returns (rows buffer int32[n,4] of
+    which the first M are valid, hdr): M = hdr[HDR_M] stays on the device until the caller reads it."""
+    rows = rows.contiguous()
+    n, dev = rows.shape[0], rows.device
+    try:
+        grid = L.grid_from_bounds(bounds[0], bounds[1], 1)
+    except L.LinkAmdError as e:
+        raise GridTooLarge(str(e))
+    v = grid.cells
+    if v > MAX_CELLS:
+        raise GridTooLarge(f"dense grid would need {v} cells (> {MAX_CELLS})")
+    cell_counts, scratch = _workspace(dev).ensure(n, v)
+    i32 = dict(dtype=torch.int32, device=dev)
+    cell_blk = torch.empty(v, **i32)
+    blk_start = torch.empty(n + 1, **i32)
+    blk_coords = torch.empty((max(n, 1), 4), **i32)
+    counts = torch.empty(max(n, 1), **i32)
+    hdr = torch.empty(L.HDR_WORDS, **i32)
+    L.check(L.lib().link_index_cells(rows.data_ptr(), n, ctypes.byref(grid), cell_counts.data_ptr(), scratch.data_ptr(),
+                                     scratch.numel(), cell_blk.data_ptr(), blk_start.data_ptr(), blk_coords.data_ptr(),
+                                     counts.data_ptr(), hdr.data_ptr(), L.current_stream_handle()), "link_index_cells")
+    return blk_coords, hdr
+
+
 def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, step: int = 1,
                          table_rows: Optional[torch.Tensor] = None, bounds=None) -> torch.Tensor:
     """Neighbour map for arbitrary rows int32[M,4] (not produced by a BlockIndex): dense cell table
