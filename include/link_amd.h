@@ -450,12 +450,23 @@ int link_conv_out_candidates(const int32_t *indices, int64_t n, const int32_t *k
  *   link_pair_plan_fill    after the host laid out base_k i32[kvol] (first contribution row of every offset's
  *                          128-row granules), wg_base i32[G, kvol] (exclusive scan of wg_counts over the workgroups)
  *                          and ext_start i32[n+1] (exclusive scan of the rows' list lengths): pair_in[p] = input row
- *                          of pair p (pair_in pre-filled with -1), ext_list = every row's contribution rows in
+ *                          of pair p, pair_out[p] = its output row (both pre-filled with -1), ext_list = every row's contribution rows in
  *                          ascending offset order.  No atomics: placement is deterministic.  skip_centre != 0 leaves
  *                          the centre offset out (link_conv_centre_sum computes it). */
 int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *wg_counts, int32_t *row_info, void *stream);
 int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
-                        const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *ext_list, void *stream);
+                        const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,
+                        int32_t *ext_list, void *stream);
+/* Weight gradient over the pair list (the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278):
+ * gw[k] = sum over the pairs p of offset k of feats[pair_in[p]]^T . gout[pair_out[p]]   (fp32 [kvol, cin, cout]).
+ * One MFMA workgroup per 128-pair granule writes partial fp32[rows_pad/128, cin, cout]; the per-offset sums run in
+ * granule order (gran_start i32[kvol+1] = first granule of every offset): deterministic, no atomics.  pair_out
+ * i32[rows_pad] as written by link_pair_plan_fill (pre-filled with -1).  n_direct > 0 (a plan built with skip_centre
+ * over n_direct voxels): the centre offset's identity pairs i -> i run as ceil(n_direct / 128) further granules, so
+ * partial needs rows_pad/128 + ceil(n_direct/128) slots. */
+int link_conv_pairs_wgrad(const float *feats, const float *gout, const int32_t *pair_in, const int32_t *pair_out,
+                          const int32_t *wg_k, const int32_t *gran_start, int64_t rows_pad, int32_t kvol, int64_t n_direct,
+                          int32_t cin, int32_t cout, float *partial, float *gw, void *stream);
 int link_conv_centre_sum(const float *feats, const float *w, int32_t centre, const float *contrib,
                          int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
                          const float *bias, const float *ln_w, const float *ln_b, float eps, const float *addend,

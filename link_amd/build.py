@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=9) as ex:
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(one, SOURCES))
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
     with open(stamp_file, "w") as f:

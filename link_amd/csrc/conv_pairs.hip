@@ -381,7 +381,8 @@ __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ n
                                                    int skip_centre, const int32_t *__restrict__ base_k,
                                                    const int32_t *__restrict__ wg_base, const int32_t *__restrict__ ext_start,
                                                    int32_t *__restrict__ wg_counts, int32_t *__restrict__ row_info,
-                                                   int32_t *__restrict__ pair_in, int32_t *__restrict__ ext_list) {
+                                                   int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out,
+                                                   int32_t *__restrict__ ext_list) {
   extern __shared__ int32_t smem[];
   int32_t *tile = smem;                                // [256][kvol]
   int32_t *wcnt = smem + 256 * kvol;                   // [4][kvol + 1]: pairs per wave and offset (+ identity misses)
@@ -435,6 +436,7 @@ __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ n
       for (int w = 0; w < wave; w++) before += wcnt[w * (kvol + 1) + k];
       const int p = base_k[k] + wg_base[(int64_t)blockIdx.x * kvol + k] + before + __popcll(m & lt);
       pair_in[p] = v;
+      pair_out[p] = (int)(row0 + r);
       ext_list[q++] = p;
     }
   }
@@ -448,20 +450,20 @@ extern "C" int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol,
   const unsigned wgs = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_pair_plan<false>, dim3(wgs), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
                      (int)kvol, (int)(kvol / 2), 0, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                     wg_counts, row_info, (int32_t *)nullptr, (int32_t *)nullptr);
+                     wg_counts, row_info, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
   return check_launch("link_pair_plan_count");
 }
 
 extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
-                                   const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *ext_list,
-                                   void *stream) {
+                                   const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,
+                                   int32_t *ext_list, void *stream) {
   if (n < 0 || kvol <= 0 || kvol > 64) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  if (!nbr || !base_k || !wg_base || !ext_start || !pair_in || !ext_list) return LINK_ERR_ARG;
+  if (!nbr || !base_k || !wg_base || !ext_start || !pair_in || !pair_out || !ext_list) return LINK_ERR_ARG;
   const unsigned wgs = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_pair_plan<true>, dim3(wgs), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
                      (int)kvol, (int)(kvol / 2), (int)skip_centre, base_k, wg_base, ext_start, (int32_t *)nullptr,
-                     (int32_t *)nullptr, pair_in, ext_list);
+                     (int32_t *)nullptr, pair_in, pair_out, ext_list);
   return check_launch("link_pair_plan_fill");
 }
 
@@ -527,4 +529,134 @@ extern "C" int32_t link_conv_out_candidate_count(const int32_t *kernel, const in
   int ncomb = 1;
   for (int d = 0; d < 3; d++) ncomb *= (kernel[d] == 3 && stride[d] == 2) ? 2 : kernel[d];
   return ncomb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient over the pair list: g_w[k] = sum over the pairs of offset k of feats[in]^T . g_out[out]
+// ---------------------------------------------------------------------------------------------
+// (the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278: per offset gather + cuBLAS mm(in^T,
+// grad)).  A workgroup walks WGRAD_RUN consecutive 128-pair granules: both row sets of a granule are staged in LDS
+// (padding pairs as zero rows), wave w accumulates the 16-row strip ci in [16w, 16w+16) of the [CI x CO] product with
+// the pairs as the MFMA k-dimension, and a strip goes to a partial slot whenever the offset changes or the walk ends
+// -- the per-offset sums are formed afterwards in slot order by k_conv_pairs_wgrad_sum: fixed order, no atomics, any
+// width pair the forward kernels take.
+constexpr int WGRAD_RUN = 4;                           // granules one workgroup folds into a partial (same offset only)
+
+template <int CI, int CO>
+__global__ void __launch_bounds__(64 * (CI / 16)) k_conv_pairs_wgrad(const float *__restrict__ feats, const float *__restrict__ gout,
+                                                                     const int32_t *__restrict__ pair_in,
+                                                                     const int32_t *__restrict__ pair_out,
+                                                                     const int32_t *__restrict__ wg_k, int64_t granules,
+                                                                     int64_t plan_granules, int centre, int64_t n_rows,
+                                                                     float *__restrict__ partial) {
+  // granules [plan_granules, granules): the identity pairs (i -> i) of a submanifold table's centre offset
+  constexpr int NW = CI / 16, NT = 64 * NW, TO = CO / 16;
+  constexpr int LDF = CI + 16, LDG = CO + 16;          // row strides: 16 (mod 32) banks apart for the 4 pairs of a k-step
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *fl = reinterpret_cast<float *>(smem_raw);     // [128][LDF]
+  float *gl = fl + 128 * LDF;                          // [128][LDG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g4 = lane >> 4;
+  floatx4 acc[TO];
+#pragma unroll
+  for (int tt = 0; tt < TO; tt++) acc[tt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const float *fa = fl + g4 * LDF + 16 * wave + li;    // A[ci = 16 wave + li][pair = 4 q + g4]
+  const float *gb = gl + g4 * LDG + li;                // B[pair = 4 q + g4][co = 16 tt + li]
+  auto flush = [&](int64_t slot) {                     // D[ci = 16 wave + 4 g4 + r][co = 16 tt + li]
+    float *dst = partial + slot * CI * CO + (16 * wave + 4 * g4) * CO + li;
+#pragma unroll
+    for (int tt = 0; tt < TO; tt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) dst[r * CO + 16 * tt] = acc[tt][r];
+      acc[tt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  const int64_t g0 = (int64_t)blockIdx.x * WGRAD_RUN;
+  int64_t run = g0;                                    // first granule of the run being accumulated = its partial slot
+  int cur = g0 < plan_granules ? wg_k[g0] : centre;
+  for (int64_t gi = g0; gi < g0 + WGRAD_RUN && gi < granules; gi++) {
+    const bool ident = gi >= plan_granules;
+    const int k = ident ? centre : wg_k[gi];
+    if (k != cur || gi == plan_granules) { if (gi != g0) flush(run); run = gi; cur = k; }
+    const int64_t row0 = gi * 128;
+    const int64_t id0 = (gi - plan_granules) * 128;
+    __syncthreads();                                   // the previous granule's operands are consumed
+    for (int e = tid; e < 128 * (CI / 4); e += NT) {
+      const int pr = e / (CI / 4), c4 = e - pr * (CI / 4);
+      const int j = ident ? (id0 + pr < n_rows ? (int)(id0 + pr) : -1) : pair_in[row0 + pr];
+      const float4 v = j >= 0 ? *reinterpret_cast<const float4 *>(feats + (int64_t)j * CI + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&fl[pr * LDF + 4 * c4]) = v;
+    }
+    for (int e = tid; e < 128 * (CO / 4); e += NT) {
+      const int pr = e / (CO / 4), c4 = e - pr * (CO / 4);
+      const int j = ident ? (id0 + pr < n_rows ? (int)(id0 + pr) : -1) : pair_out[row0 + pr];
+      const float4 v = j >= 0 ? *reinterpret_cast<const float4 *>(gout + (int64_t)j * CO + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&gl[pr * LDG + 4 * c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < 32; q++) {
+      const float a = fa[4 * q * LDF];
+#pragma unroll
+      for (int tt = 0; tt < TO; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gb[4 * q * LDG + 16 * tt], acc[tt], 0, 0, 0);
+    }
+  }
+  flush(run);
+}
+
+// g_w[k][e] = sum of the partial slots of offset k in granule order: a slot exists at the offset's first granule and at
+// every later multiple of WGRAD_RUN (where a workgroup started a run); gran_start i32[kvol + 1]
+__global__ void __launch_bounds__(256) k_conv_pairs_wgrad_sum(const float *__restrict__ partial, const int32_t *__restrict__ gran_start,
+                                                              int kvol, int elems, int id_k, int id_first, int id_end,
+                                                              float *__restrict__ gw) {
+  const int k = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.f;
+  const int first = gran_start[k], end = gran_start[k + 1];
+  for (int gi = first; gi < end; gi = (gi == first) ? (first / WGRAD_RUN + 1) * WGRAD_RUN : gi + WGRAD_RUN)
+    s += partial[(int64_t)gi * elems + e];
+  if (k == id_k)                                       // the identity granules of the centre offset (their own slot range)
+    for (int gi = id_first; gi < id_end; gi = (gi == id_first) ? (id_first / WGRAD_RUN + 1) * WGRAD_RUN : gi + WGRAD_RUN)
+      s += partial[(int64_t)gi * elems + e];
+  gw[(int64_t)k * elems + e] = s;
+}
+
+template <int CI, int CO>
+static int launch_pairs_wgrad(const float *feats, const float *gout, const int32_t *pair_in, const int32_t *pair_out,
+                              const int32_t *wg_k, int64_t granules, int64_t plan_granules, int centre, int64_t n_rows,
+                              float *partial, hipStream_t st) {
+  const size_t lds = (size_t)128 * ((CI + 16) + (CO + 16)) * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_pairs_wgrad<CI, CO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_conv_pairs_wgrad<CI, CO>), dim3((unsigned)((granules + WGRAD_RUN - 1) / WGRAD_RUN)), dim3(64 * (CI / 16)), lds,
+                     st, feats, gout, pair_in, pair_out, wg_k, granules, plan_granules, centre, n_rows, partial);
+  return check_launch("link_conv_pairs_wgrad");
+}
+
+extern "C" int link_conv_pairs_wgrad(const float *feats, const float *gout, const int32_t *pair_in, const int32_t *pair_out,
+                                     const int32_t *wg_k, const int32_t *gran_start, int64_t rows_pad, int32_t kvol,
+                                     int64_t n_direct, int32_t cin, int32_t cout, float *partial, float *gw, void *stream) {
+  if (rows_pad < 0 || (rows_pad & 127) || kvol <= 0 || n_direct < 0 || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
+  if (!gw || !gran_start) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const int64_t pg = rows_pad / 128;
+  const int64_t gr = pg + (n_direct + 127) / 128;      // + identity granules of the centre offset (submanifold tables)
+  int rc = LINK_OK;
+  if (gr > 0) {
+    if (!feats || !gout || !partial || (pg > 0 && (!pair_in || !pair_out || !wg_k))) return LINK_ERR_ARG;
+    rc = LINK_ERR_ARG;
+#define LINK_CW(I, O) \
+  if (cin == I && cout == O) rc = launch_pairs_wgrad<I, O>(feats, gout, pair_in, pair_out, wg_k, gr, pg, (int)(kvol / 2), n_direct, partial, st)
+    LINK_CW(16, 16); LINK_CW(32, 32); LINK_CW(64, 64); LINK_CW(128, 128);
+    LINK_CW(16, 32); LINK_CW(32, 16); LINK_CW(32, 64); LINK_CW(64, 32); LINK_CW(64, 128); LINK_CW(128, 64);
+    LINK_CW(16, 64); LINK_CW(64, 16);
+#undef LINK_CW
+    if (rc != LINK_OK) return rc;
+  }
+  const int elems = cin * cout;
+  hipLaunchKernelGGL(k_conv_pairs_wgrad_sum, dim3((unsigned)((elems + 255) / 256), (unsigned)kvol), dim3(256), 0, st, partial, gran_start,
+                     (int)kvol, elems, n_direct > 0 ? (int)(kvol / 2) : -1, (int)pg, (int)gr, gw);
+  return check_launch("link_conv_pairs_wgrad_sum");
 }

@@ -747,20 +747,23 @@ class _PairPlan:
         ext_cnt = (row_info[:n] & 0xFFFF) - (row_info[:n] >> 16) if direct else row_info[:n] & 0xFFFF
         ext_start = torch.zeros(n + 1, **i32)
         torch.cumsum(ext_cnt, 0, out=ext_start[1:])
-        pair_in = torch.full((max(self.rows_pad, 1),), -1, **i32)
+        pair_io = torch.full((2, max(self.rows_pad, 1)), -1, **i32)      # input row | output row of every pair
+        pair_in, pair_out = pair_io[0], pair_io[1]
         ext_list = torch.empty(max(self.pairs, 1), **i32)
         pk = per_wg[:, :kvol].astype(_np.int32)
         wg_base = (_np.cumsum(pk, 0, dtype=_np.int32) - pk).reshape(-1)              # exclusive scan over workgroups
         nwk = wg_base.size
-        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), wg_base,
+        gstart = _np.concatenate([[0], _np.cumsum(gran)]).astype(_np.int32)          # first granule of every offset
+        meta = _np.concatenate([_np.asarray(base_k, dtype=_np.int32), wg_base, gstart,
                                 _np.repeat(_np.arange(kvol, dtype=_np.int32), gran)])
-        meta = torch.from_numpy(meta).to(dev)                      # base_k | wg_base | wg_k: one H2D
+        meta = torch.from_numpy(meta).to(dev)                      # base_k | wg_base | gran_start | wg_k: one H2D
         if self.pairs:
             L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(),
                                             meta[kvol:].data_ptr(), ext_start.data_ptr(), pair_in.data_ptr(),
-                                            ext_list.data_ptr(), st), "link_pair_plan_fill")
+                                            pair_out.data_ptr(), ext_list.data_ptr(), st), "link_pair_plan_fill")
         self._meta = meta
-        self.pair_in, self.wg_k, self.ext_start, self.ext_list = pair_in, meta[kvol + nwk:], ext_start, ext_list
+        self.pair_in, self.pair_out, self.ext_start, self.ext_list = pair_in, pair_out, ext_start, ext_list
+        self.gran_start, self.wg_k = meta[kvol + nwk: kvol + nwk + kvol + 1], meta[kvol + nwk + kvol + 1:]
         self._contrib: Dict[int, torch.Tensor] = {}
 
     def contrib(self, cout: int) -> torch.Tensor:
@@ -860,6 +863,11 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
     f = feats.detach().contiguous().float()
     w = kernel.detach().contiguous().float()
+    if form != "table" and w.ndim == 3 and cout < 16 and n > 0 and L.lib().link_conv_pairs_supported((cin + 15) // 16 * 16, 16):
+        # few OUTPUT channels (the input gradient of a network's first layer): zero columns up to 16, slice afterwards
+        wp = torch.zeros((kvol, cin, 16), dtype=torch.float32, device=w.device)
+        wp[:, :, :cout] = w
+        return subm_conv(f, wp, nbr, order, form)[:, :cout].contiguous()
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     if form != "table" and w.ndim == 3:
         f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
@@ -949,6 +957,22 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
     batched library GEMM."""
     kvol, cin, cout = kernel_shape
     n_out = nbr.shape[0]
+    # square widths <= 64 keep the table kernel below (measured equal on the kernels, and it needs no second launch for
+    # the centre); every other width pair the forward kernels take -- wide and rectangular layers -- runs the pair list
+    square_small = cin == cout and cin <= 64 and cin % 4 == 0
+    plan = _pair_plan(nbr, cin, cout) if (n_out > 0 and len(kernel_shape) == 3 and not square_small) else None
+    if plan is not None:
+        # pair-list form: one MFMA pass over the 128-pair granules + per-offset sums in granule order; the centre
+        # offset of a submanifold table (identity pairs, not in the plan) is the plain feats^T . g
+        lib = L.lib()
+        f = feats.detach().contiguous().float()
+        gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=g.device)
+        n_dir = plan.n if plan.direct else 0
+        part = torch.empty((max(plan.rows_pad // 128 + (n_dir + 127) // 128, 1), cin, cout), dtype=torch.float32, device=g.device)
+        L.check(lib.link_conv_pairs_wgrad(f.data_ptr(), g.data_ptr(), plan.pair_in.data_ptr(), plan.pair_out.data_ptr(),
+                                          plan.wg_k.data_ptr(), plan.gran_start.data_ptr(), plan.rows_pad, kvol, n_dir, cin, cout,
+                                          part.data_ptr(), gw.data_ptr(), _st()), "link_conv_pairs_wgrad")
+        return gw
     if cin == cout and cin <= 64 and cin % 4 == 0:
         lib = L.lib()
         chunks = int(lib.link_subm_conv_wgrad_chunks())

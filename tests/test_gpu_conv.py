@@ -391,3 +391,31 @@ def test_backend_convolution_names_with_reference_kmap_layout():
         cur += int(nbsizes[k])
     assert rel_err(gi.cpu().numpy(), gi_ref.cpu().numpy()) < 1e-5
     assert rel_err(gw.cpu().numpy(), gw_ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,kind", [(128, 128, "lidar"), (32, 64, "lidar"), (64, 128, "uniform"), (128, 64, "dense")])
+def test_pair_list_weight_gradient_wide_and_rectangular(cin, cout, kind):
+    """link_conv_pairs_wgrad (widths the table weight-gradient kernel does not take) against fp64 per-offset GEMMs:
+    submanifold table (centre offset as identity granules) and a strided table; bitwise reproducible."""
+    import link_amd as la
+    from link_amd.elk import _conv_weight_grad
+    coords = s_uniform(6000, grid=40, seed=5) if kind == "uniform" else _frame(kind, 6000, 1)
+    n = coords.shape[0]
+    conv = la.Conv3d(cin, cout, 3).cuda()
+    st = la.SparseTensor(torch.randn(n, cin, device="cuda"), coords.cuda(), 1)
+    nbr, _ = conv._neighbor_table(st)
+    g = torch.randn(n, cout, device="cuda")
+    a = _conv_weight_grad(st.F, g, nbr, (27, cin, cout))
+    b = _conv_weight_grad(st.F, g, nbr, (27, cin, cout))
+    assert torch.equal(a, b)
+    pad = torch.cat([st.F.double(), torch.zeros(1, cin, device="cuda", dtype=torch.float64)])
+    idx = torch.where(nbr < 0, torch.full_like(nbr, n), nbr).long()
+    ref = torch.stack([pad[idx[:, k]].t() @ g.double() for k in range(27)])
+    assert rel_err(a.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    down = la.Conv3d(cin, cout, 2, stride=2).cuda()
+    km = down._strided_map(st)
+    gd = torch.randn(km.nbr_down.shape[0], cout, device="cuda")
+    a = _conv_weight_grad(st.F, gd, km.nbr_down, (8, cin, cout))
+    idx = torch.where(km.nbr_down < 0, torch.full_like(km.nbr_down, n), km.nbr_down).long()
+    ref = torch.stack([pad[idx[:, k]].t() @ gd.double() for k in range(8)])
+    assert rel_err(a.cpu().numpy(), ref.cpu().numpy()) < 1e-5
