@@ -303,9 +303,15 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsu
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_fill += tqb - tqa; tqa = tqb; }
     // step t: finishes tile t (record rec, accumulators ac), multiplies tile t+1 (record recn, rows fn) into
     // acn, requests tile t+2 (record rec2, rows f2)
-    auto step = [&](int t, const int4 &rec, const int4 &recn, int4 &rec2, const float4 (&fn)[T], float4 (&f2)[T],
+    // `phase`: 0 = finish the tile and form its sums (pipelined variant); 1 = finish only; 2 = sums only.  The plain
+    // loop runs the sums of tile t-1 AFTER the MFMAs of tile t were issued: the row stores of a tile are then old by
+    // the time the next row loads are waited for (s_waitcnt vmcnt counts stores too, and waiting on just-issued
+    // write-through stores every tile was the largest stall of this kernel), and the matrix pipe works through
+    // tile t while the VALU adds up tile t-1.
+    auto step = [&](auto phase_tag, int t, const int4 &rec, const int4 &recn, int4 &rec2, const float4 (&fn)[T], float4 (&f2)[T],
                     const floatx4 (&ac)[T], floatx4 (&acn)[T]) {
-      if (ntile > 0) {
+      constexpr int PHASE = decltype(phase_tag)::value;
+      if (PHASE != 2 && ntile > 0) {
         const int slot = 16 * t + li;
         // theta of this voxel's blocks; a wave whose arguments all sit below 2^15 takes the branch-free body
         float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
@@ -394,7 +400,8 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsu
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_body += tqb - tqa; tqa = tqb; tq_tiles++; }
+      if (PHASE != 2 && dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_body += tqb - tqa; tqa = tqb; tq_tiles++; }
+      if (PHASE == 1) return;
       // ---- per-cell sums of this tile: ONE stream over the 16 rows in slot order (ascending voxel id inside a
       // cell), every lane owning 16 bytes of the row; a row that closes its cell (the next slot belongs to
       // another cell) is followed by the cell's S row store.  All rows are requested up front, the close
@@ -430,26 +437,31 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsu
     // the three records rotate by plain copies (they come from LDS: no VMEM wait is involved)
     if constexpr (PIPE) {
       for (int t = 0; t < nloop; t += 2) {
-        step(t, recA, recB, recC, fA, fB, acA, acB);
+        step(std::integral_constant<int, 0>{}, t, recA, recB, recC, fA, fB, acA, acB);
         recA = recB; recB = recC;
         if (t + 1 < nloop) {
-          step(t + 1, recA, recB, recC, fB, fA, acB, acA);
+          step(std::integral_constant<int, 0>{}, t + 1, recA, recB, recC, fB, fA, acB, acA);
           recA = recB; recB = recC;
         }
       }
     } else {
       // plain tiles: rows of tile t in fA (even t) / fB (odd t), the other set receives tile t+1 meanwhile
+      using body_only = std::integral_constant<int, 1>;
+      using sums_only = std::integral_constant<int, 2>;
       if (ntile > 0) ld_rows(0, recA, fA);
       for (int t = 0; t < nloop; t += 2) {
         if (t + 1 < ntile) ld_rows(t + 1, recB, fB);
         mfma_tile(fA, acA);
-        step(t, recA, recB, recC, fB, fB, acA, acB);
+        if (t > 0) step(sums_only{}, t - 1, recB, recB, recC, fB, fB, acA, acB);
+        step(body_only{}, t, recA, recB, recC, fB, fB, acA, acB);
         if (t + 1 < nloop) {
           if (t + 2 < ntile) ld_rows(t + 2, recA, fA);
-          mfma_tile(fB, acA);
-          step(t + 1, recB, recA, recC, fA, fA, acA, acB);
+          mfma_tile(fB, acA);                          // acA is free again: tile t was finished above
+          step(sums_only{}, t, recA, recA, recC, fA, fA, acA, acB);
+          step(body_only{}, t + 1, recB, recA, recC, fA, fA, acA, acB);
         }
       }
+      if (nloop > 0) step(sums_only{}, nloop - 1, recA, recA, recC, fA, fA, acA, acB);
     }
     chunk += nfit;
   }
