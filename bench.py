@@ -398,6 +398,8 @@ def main():
         the kernels of different frames share the CUs (tools/mstream_dc.py)."""
         if plan.dense:
             L.lib().link_dc_set_tuning2(0, int(os.environ.get("LINK_BENCH_K1_WGS", "0")) or (512 if ns == 1 else 256))
+            if os.environ.get("LINK_BENCH_K2_SPLIT") is not None:
+                L.lib().link_dc_set_tuning2(6, int(os.environ["LINK_BENCH_K2_SPLIT"]))
 
     def timed(k, build_index=True, ns=NS):
         """EXACTLY k steps (frames), round-robin over `ns` streams; barrier + synchronize on both sides."""

@@ -25,6 +25,7 @@ int g_demod_wgs = 1024;
 int g_k2_zsplit = 0;
 int g_k2_single = 0;
 int g_k1_pipe = 0;
+int g_k2_split = 1;         // producer / consumer form of the fused gather + de-modulate kernel (where two workgroups fit a CU)
 unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
 }
 static int g_index_wgs = 0;
@@ -57,6 +58,7 @@ extern "C" int link_dc_set_tuning2(int key, int value) {
     case 3: g_k2_zsplit = value; break;
     case 4: g_k2_single = value; break;
     case 5: g_k1_pipe = value; break;
+    case 6: g_k2_split = value; break;
     default: return LINK_ERR_ARG;
   }
   return LINK_OK;

@@ -10,7 +10,7 @@
 #include "dense_gather.h"
 
 namespace link {
-extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe;
+extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe, g_k2_split;
 extern unsigned long long *g_k1_dbg;
 }
 
@@ -728,6 +728,15 @@ struct dc_k2_cfg {
   static constexpr int ABUF_OFF = 3 * BUF_BYTES;
   static constexpr int NCNT_OFF = ABUF_OFF + NG * RB;
   static constexpr int LDS_BYTES = NCNT_OFF + NG * 4;
+  // producer / consumer form: two A images (ABUF_OFF, 2 * NG * RB), two count images, a ring of 4 record images
+  // (plane-ring slots without the record image: 2 workgroups of 79 KB per CU)
+  static constexpr int SPLIT_PLANE = G::NPC * 16;      // no padding pass: surplus DMA lanes re-load pass 0's pieces
+  static constexpr int SPLIT_BUF_BYTES = SPLIT_PLANE + G::CNT_BYTES;
+  static constexpr int SPLIT_ABUF_OFF = 3 * SPLIT_BUF_BYTES;
+  static constexpr int SPLIT_NCNT_OFF = SPLIT_ABUF_OFF + 2 * NG * RB;
+  static constexpr int SPLIT_REC_OFF = SPLIT_NCNT_OFF + 2 * NG * 4;
+  static constexpr int SPLIT_LDS_BYTES = SPLIT_REC_OFF + 4 * REC_BYTES;
+  static constexpr bool SPLIT_FITS = 2 * SPLIT_LDS_BYTES <= 160 * 1024;      // two workgroups per CU (not cos_x: 3-part rows)
   static constexpr int NI = G::PASSES + 2;            // DMA instructions per plane and wave
   static_assert(G::NG == NG && G::TX * G::TY == NG, "16 columns");
 };
@@ -1018,6 +1027,304 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
   }
 }
 
+template <int OP, int R, bool PAIR, bool DIV>
+__global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
+    const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
+    const float *__restrict__ fin, const float *__restrict__ w_pos, const float *__restrict__ alpha,
+    const float *__restrict__ ln_w, const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n,
+    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, void *__restrict__ out, int single) {
+  using K2 = dc_k2_cfg<OP, R>;
+  using K = typename K2::G;
+  constexpr int C = 64, P = K2::P, LPR = 16, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
+  constexpr int RB = P * C * 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  // Producer / consumer form: waves 0-3 run the plane ring and the box sums exactly as k_dc_gather_demod does and
+  // leave the A rows + counts of output plane j in LDS buffer j & 1; waves 4-7 deal plane j's voxels out as pairs
+  // and finish them ONE STEP LATER, while the producers already sum plane j+1.  One barrier per step instead of
+  // two, the two halves of a step overlap instead of adding up, and the producers issue no stores, so their
+  // counted DMA waits are exact.  The inline slot records get their own ring of 4 (a plane-ring slot is reused
+  // while the consumers still read the records that travelled with it).
+  const bool producer = threadIdx.x < 256;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x & 255) >> 6);
+  const int per = (nwg + 7) >> 3;
+  const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (L >= nwg) return;
+  int t = L;
+  const int zseg = t % zsplit; t /= zsplit;
+  const int ty = t % tyn; t /= tyn;
+  const int tx = t % txn;
+  const int b = t / txn;
+  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
+  const int PDx = g.pdim[0], PDy = g.pdim[1], PDz = g.pdim[2];
+  const int x0 = tx * TX, y0 = ty * TY;
+  const int zs = (int)(((long long)Dz * zseg) / zsplit), ze = (int)(((long long)Dz * (zseg + 1)) / zsplit);
+  if (zs >= ze) return;
+  const int nplanes = (ze - zs) + R - 1;
+  const int pz0 = zs + 1 - HLO;
+  auto col_cell0 = [&](int hx, int hy) {             // padded cell id of (haloed column, z = 0), clamped into the grid
+    int px = x0 + 1 - HLO + hx, py = y0 + 1 - HLO + hy;
+    px = px < PDx - 1 ? px : PDx - 1;
+    py = py < PDy - 1 ? py : PDy - 1;
+    return (uint32_t)(((b * PDx + px) * PDy + py) * PDz);
+  };
+  uint32_t src_off[K::PASSES];
+#pragma unroll
+  for (int i = 0; i < K::PASSES; i++) {
+    int pid = i * 256 + tid;
+    if (pid >= K::NPC) pid = K::NPC - 1;
+    const int col = pid / K::RP, pcs = pid % K::RP;
+    src_off[i] = col_cell0(col / HY, col % HY) * (uint32_t)RB + (uint32_t)pcs * 16u;
+  }
+  uint32_t cnt_cell0;
+  {
+    int e = wave * 64 + lane;
+    if (e >= K::NCOL) e = K::NCOL - 1;
+    cnt_cell0 = col_cell0(e / HY, e % HY);
+  }
+  // inline slot records of the 16 interior cells of an output plane: wave w, lane l < 16 -> piece w*16 + l
+  uint32_t rec_cell0;
+  int rec_k;
+  {
+    const int piece = wave * 16 + (lane & 15);
+    const int col = piece >> 2;
+    rec_k = piece & 3;
+    rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
+  }
+  const char *Sb = reinterpret_cast<const char *>(S_);
+  auto issue = [&](int plane) {
+    int pz = pz0 + plane;
+    pz = pz < PDz - 1 ? pz : PDz - 1;
+    char *buf = lds + (plane % 3) * K2::SPLIT_BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < K::PASSES; i++) {
+      // a wave whose 64 pieces of the last pass all lie beyond the plane repeats its pass-0 load (same data to the
+      // same place): the instruction count per wave stays NI and the ring slots need no padding
+      const bool surplus = (i * 256 + wave * 64) >= K::NPC;            // wave-uniform
+      const int ii = surplus ? 0 : i;
+      const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+    const int32_t *csrc = cell_n + cnt_cell0 + pz;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
+                                     (__attribute__((address_space(3))) void *)(buf + K2::SPLIT_PLANE + wave * 256), 4, 0, 0);
+    int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
+    po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
+    const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
+    if (lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rsrc,
+                                       (__attribute__((address_space(3))) void *)(lds + K2::SPLIT_REC_OFF + (plane & 3) * K2::REC_BYTES + wave * 256), 16, 0, 0);
+  };
+  // ---- this group's column ----
+  const int grp = tid >> 4, li = tid & 15;
+  const int ix = grp / TY, iy = grp % TY;
+  const bool col_ok = (x0 + ix < Dx) && (y0 + iy < Dy);
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const uint32_t row_lane = (uint32_t)((ix * HY + iy) * RB + li * 16);
+  const uint32_t cnt_lane = (uint32_t)((ix * HY + iy) * 4);
+  const uint32_t abuf0 = lds_base + K2::SPLIT_ABUF_OFF, ncnt0 = lds_base + K2::SPLIT_NCNT_OFF;
+  const int rowbase = lane & ~15;                      // first lane of this group's DPP row
+  const int ch0 = 4 * li;
+  const bool hi = PAIR && li >= 8;
+  const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * C * IO_BYTES));
+  float w0[4], w1[4], w2[4], al[4], gw[4], gb[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int ch = ch0 + e, tc = ch % cg;
+    w0[e] = w_pos[3 * tc + 0]; w1[e] = w_pos[3 * tc + 1]; w2[e] = w_pos[3 * tc + 2];
+    al[e] = alpha ? alpha[tc] : 1.0f;
+    gw[e] = ln_w[ch]; gb[e] = ln_b[ch];
+  }
+  float4 r0[P], r1[P];
+  float c0 = 0.f, c1 = 0.f;
+  int n_prev = 0;                                      // voxels in this group's cell of the previous plane
+#pragma unroll
+  for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (producer) {
+    issue(0);
+    if (nplanes > 1) issue(1);
+  }
+  for (int i = 0; i <= nplanes; i++) {
+    if (producer) {
+      if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the A rows of the previous step are in LDS
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (producer && i >= nplanes) continue;
+    if (producer && i + 2 < nplanes) issue(i + 2);
+    const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
+    const int j = producer ? i : i - 1;                      // the output-plane step this half works on
+    const uint32_t abuf = abuf0 + (uint32_t)((j & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((j & 1) * K2::NG * 4);
+    if (!producer && (j < R - 1 || j >= nplanes)) continue;
+    float4 cur[P];
+    float cc = 0.f;
+    int n_here = 0;
+    if (producer) {
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
+      dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
+      dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
+      if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
+    }
+    n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+    }
+    if (j >= R - 1) {
+      const int po = pz0 + j - (R - 1) + HLO;
+      if (producer) {
+      float4 a[P];
+      float den;
+      if (R == 3) {
+        den = (c0 + c1) + cc;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          a[pp].x = (r0[pp].x + r1[pp].x) + cur[pp].x; a[pp].y = (r0[pp].y + r1[pp].y) + cur[pp].y;
+          a[pp].z = (r0[pp].z + r1[pp].z) + cur[pp].z; a[pp].w = (r0[pp].w + r1[pp].w) + cur[pp].w;
+        }
+      } else {
+        den = c1 + cc;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          a[pp].x = r1[pp].x + cur[pp].x; a[pp].y = r1[pp].y + cur[pp].y;
+          a[pp].z = r1[pp].z + cur[pp].z; a[pp].w = r1[pp].w + cur[pp].w;
+        }
+      }
+      const float inv = den > 0.f ? 1.0f / den : 0.f;
+      // ---- A rows + counts of the plane's 16 cells -> LDS ----
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+        lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
+                    make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
+      const int n_cell = (R == 3) ? n_prev : n_prev;   // the plane that closed is the previous one for both R
+      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_cell : 0);
+      } else {
+      // ---- deal the plane's voxels out as pairs ----
+      const int nli = lds_rd_b32(ncnt + (uint32_t)(li * 4));          // lane li of every row: cell li
+      int incl = nli;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+      const int Tv = __shfl(incl, rowbase + 15, 64);
+      const int npair = single ? Tv : (Tv + 1) >> 1;
+      const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (j & 3) * K2::REC_BYTES);
+      for (int p = grp; p < npair; p += 16) {
+        const int vA = single ? p : 2 * p, vB = (!single && 2 * p + 1 < Tv) ? 2 * p + 1 : vA;
+        const bool hasB = !single && 2 * p + 1 < Tv;
+        const unsigned long long mA = __ballot(incl <= vA), mB = __ballot(incl <= vB);
+        const int cA = __popc((unsigned)(mA >> rowbase) & 0xFFFFu), cB = __popc((unsigned)(mB >> rowbase) & 0xFFFFu);
+        const int eA = cA ? __shfl(incl, rowbase + cA - 1, 64) : 0, eB = cB ? __shfl(incl, rowbase + cB - 1, 64) : 0;
+        const int kA = vA - eA, kB = vB - eB;
+        v4f_t qa, qb;
+        lds_rd2_b128(recb + (uint32_t)((cA * DC_INL + (kA < DC_INL ? kA : 0)) * 16),
+                     recb + (uint32_t)((cB * DC_INL + (kB < DC_INL ? kB : 0)) * 16), qa, qb);
+        int4 recA = make_int4(__float_as_int(qa.x), __float_as_int(qa.y), __float_as_int(qa.z), __float_as_int(qa.w));
+        int4 recB = make_int4(__float_as_int(qb.x), __float_as_int(qb.y), __float_as_int(qb.z), __float_as_int(qb.w));
+        if (kA >= DC_INL || kB >= DC_INL) {             // overflow records: rare, ordinary loads
+          const int pcA = ((b * PDx + x0 + cA / TY + 1) * PDy + y0 + cA % TY + 1) * PDz + po;
+          const int pcB = ((b * PDx + x0 + cB / TY + 1) * PDy + y0 + cB % TY + 1) * PDz + po;
+          if (kA >= DC_INL) recA = slots[dc_slot(g, pcA, kA)];
+          if (kB >= DC_INL) recB = slots[dc_slot(g, pcB, kB)];
+        }
+        v4f_t A0v, A1v, B0v, B1v, A2v = {0.f, 0.f, 0.f, 0.f}, B2v = {0.f, 0.f, 0.f, 0.f};
+        lds_rd2_b128(abuf + (uint32_t)(cA * RB + li * 16), abuf + (uint32_t)(cA * RB + C * 4 + li * 16), A0v, A1v);
+        lds_rd2_b128(abuf + (uint32_t)(cB * RB + li * 16), abuf + (uint32_t)(cB * RB + C * 4 + li * 16), B0v, B1v);
+        float4 fx = make_float4(0.f, 0.f, 0.f, 0.f), fy = fx;
+        if (OP == LINK_OP_COSX) {
+          lds_rd2_b128(abuf + (uint32_t)(cA * RB + 2 * C * 4 + li * 16), abuf + (uint32_t)(cB * RB + 2 * C * 4 + li * 16), A2v, B2v);
+          fx = *reinterpret_cast<const float4 *>(&fin[(int64_t)recA.w * C + ch0]);
+          fy = *reinterpret_cast<const float4 *>(&fin[(int64_t)recB.w * C + ch0]);
+        }
+        // ---- theta / sincos / de-modulate / LayerNorm / store (k_dc_demod's body) ----
+        float thA[4], thB[4];
+        bool big = false;
+        {
+          const bool swapped = PAIR && hi && hasB;
+          float xa = (float)(swapped ? recB.x : recA.x), ya = (float)(swapped ? recB.y : recA.y), za = (float)(swapped ? recB.z : recA.z);
+          float xb = (float)recB.x, yb = (float)recB.y, zb = (float)recB.z;
+          if (DIV) { xa = xa / coord_div; ya = ya / coord_div; za = za / coord_div; xb = xb / coord_div; yb = yb / coord_div; zb = zb / coord_div; }
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            thA[e] = theta_of(xa, ya, za, w0[e], w1[e], w2[e], al[e]);
+            thB[e] = PAIR ? thA[e] : theta_of(xb, yb, zb, w0[e], w1[e], w2[e], al[e]);
+            big |= !(fabsf(thA[e]) < 32768.0f) || !(fabsf(thB[e]) < 32768.0f);
+          }
+        }
+        float snA[4], csA[4], snB[4], csB[4];
+        if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sincos_nocall(thA[e], snA[e], csA[e]);
+            if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_nocall(thB[e], snB[e], csB[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sincos_small(thA[e], snA[e], csA[e]);
+            if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_small(thB[e], snB[e], csB[e]);
+          }
+        }
+        if (PAIR) {
+          const bool swapped = hi && hasB;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float sn = snA[e], cs = csA[e];
+            const float so = partner<LPR>(sn), co = partner<LPR>(cs);
+            snA[e] = swapped ? so : sn; csA[e] = swapped ? co : cs;
+            snB[e] = hi ? sn : so;      csB[e] = hi ? cs : co;
+          }
+        }
+        const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
+        float nvA[4], nvB[4], sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float A0 = A0v[e], A1 = A1v[e], B0 = B0v[e], B1 = B1v[e];
+          if (OP == LINK_OP_SIN) {                                                   // linkunet.py:148
+            nvA[e] = __fsub_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
+            nvB[e] = __fsub_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
+          } else {                                                                   // :162
+            nvA[e] = __fadd_rn(__fmul_rn(A0, csA[e]), __fmul_rn(A1, snA[e]));
+            nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
+          }
+          if (OP == LINK_OP_COSX) {                                                  // :176
+            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], __fmul_rn(fxa[e], thA[e])));
+            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], __fmul_rn(fya[e], thB[e])));
+          }
+          sA += nvA[e]; sB += nvB[e];
+        }
+        sA = grp_sum<LPR>(sA);
+        sB = grp_sum<LPR>(sB);
+        const float meanA = sA * (1.0f / C), meanB = sB * (1.0f / C);
+        float qA = 0.f, qB = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float dA = nvA[e] - meanA, dB = nvB[e] - meanB;
+          qA += dA * dA; qB += dB * dB;
+        }
+        qA = grp_sum<LPR>(qA);
+        qB = grp_sum<LPR>(qB);
+        const float rsA = __builtin_amdgcn_rsqf(qA * (1.0f / C) + eps), rsB = __builtin_amdgcn_rsqf(qB * (1.0f / C) + eps);
+        float4 oa, ob;
+        oa.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0]; oa.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
+        oa.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2]; oa.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
+        ob.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0]; ob.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
+        ob.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2]; ob.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
+        io_st4(r_out, (uint32_t)recA.w * (uint32_t)C + (uint32_t)ch0, true, oa);
+        io_st4(r_out, (uint32_t)recB.w * (uint32_t)C + (uint32_t)ch0, hasB, ob);
+      }
+      }
+    }
+    if (producer) {
+#pragma unroll
+      for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
+      c0 = c1; c1 = cc;
+      n_prev = n_here;
+    }
+  }
+}
+
+
 template <int OP, int R>
 static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                      hipStream_t st) {
@@ -1036,6 +1343,20 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   const bool two_part = d.op == LINK_OP_COS || d.op == LINK_OP_SIN;
   const bool pair = d.c == 2 * d.cg && two_part;
   const bool div = d.coord_div != 1.0f;
+#define LINK_K2S(PP, DD)                                                                                              \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_split<OP, R, PP, DD>),                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES);                       \
+    hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES, st, \
+                       b->S, b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w, \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, g_k2_single);     \
+  } while (0)
+  if (g_k2_split && K2::SPLIT_FITS) {
+    if (pair) { if (div) LINK_K2S(true, true); else LINK_K2S(true, false); }
+    else { if (div) LINK_K2S(false, true); else LINK_K2S(false, false); }
+    return check_launch("link_dc_gather_demod");
+  }
+#undef LINK_K2S
 #define LINK_K2(PP, DD)                                                                                               \
   do {                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod<OP, R, PP, DD>),                      \
