@@ -744,6 +744,15 @@ struct dc_k2_cfg {
 __device__ __forceinline__ void lds_rd2_b128(uint32_t a0, uint32_t a1, v4f_t &x0, v4f_t &x1) {
   asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1) : "memory");
 }
+// six b128 reads in flight, ONE wait (the pair's two records and four A-row pieces: three round trips -> one)
+__device__ __forceinline__ void lds_rd6_b128(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
+                                             v4f_t &x0, v4f_t &x1, v4f_t &x2, v4f_t &x3, v4f_t &x4, v4f_t &x5) {
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+               "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5)
+               : "memory");
+}
 __device__ __forceinline__ int lds_rd_b32(uint32_t a) {
   int v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
@@ -1217,8 +1226,11 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
         const int eA = cA ? __shfl(incl, rowbase + cA - 1, 64) : 0, eB = cB ? __shfl(incl, rowbase + cB - 1, 64) : 0;
         const int kA = vA - eA, kB = vB - eB;
         v4f_t qa, qb;
-        lds_rd2_b128(recb + (uint32_t)((cA * DC_INL + (kA < DC_INL ? kA : 0)) * 16),
-                     recb + (uint32_t)((cB * DC_INL + (kB < DC_INL ? kB : 0)) * 16), qa, qb);
+        v4f_t A0v, A1v, B0v, B1v, A2v = {0.f, 0.f, 0.f, 0.f}, B2v = {0.f, 0.f, 0.f, 0.f};
+        lds_rd6_b128(recb + (uint32_t)((cA * DC_INL + (kA < DC_INL ? kA : 0)) * 16),
+                     recb + (uint32_t)((cB * DC_INL + (kB < DC_INL ? kB : 0)) * 16),
+                     abuf + (uint32_t)(cA * RB + li * 16), abuf + (uint32_t)(cA * RB + C * 4 + li * 16),
+                     abuf + (uint32_t)(cB * RB + li * 16), abuf + (uint32_t)(cB * RB + C * 4 + li * 16), qa, qb, A0v, A1v, B0v, B1v);
         int4 recA = make_int4(__float_as_int(qa.x), __float_as_int(qa.y), __float_as_int(qa.z), __float_as_int(qa.w));
         int4 recB = make_int4(__float_as_int(qb.x), __float_as_int(qb.y), __float_as_int(qb.z), __float_as_int(qb.w));
         if (kA >= DC_INL || kB >= DC_INL) {             // overflow records: rare, ordinary loads
@@ -1227,9 +1239,6 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
           if (kA >= DC_INL) recA = slots[dc_slot(g, pcA, kA)];
           if (kB >= DC_INL) recB = slots[dc_slot(g, pcB, kB)];
         }
-        v4f_t A0v, A1v, B0v, B1v, A2v = {0.f, 0.f, 0.f, 0.f}, B2v = {0.f, 0.f, 0.f, 0.f};
-        lds_rd2_b128(abuf + (uint32_t)(cA * RB + li * 16), abuf + (uint32_t)(cA * RB + C * 4 + li * 16), A0v, A1v);
-        lds_rd2_b128(abuf + (uint32_t)(cB * RB + li * 16), abuf + (uint32_t)(cB * RB + C * 4 + li * 16), B0v, B1v);
         float4 fx = make_float4(0.f, 0.f, 0.f, 0.f), fy = fx;
         if (OP == LINK_OP_COSX) {
           lds_rd2_b128(abuf + (uint32_t)(cA * RB + 2 * C * 4 + li * 16), abuf + (uint32_t)(cB * RB + 2 * C * 4 + li * 16), A2v, B2v);
