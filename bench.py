@@ -254,6 +254,66 @@ def cfg3_mode(args, la, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def cfg4_mode(args, la, dev, rank, world, dist):
+    """BASELINE.json configs[3] (labelled, NOT the headline): a batch of 8 S-kitti frames (seeds 0..7) sharded over
+    the ranks by independent frames (link_amd/parallel.py::shard_frames: 8 / 4 / 2 / 1 rounds at 1 / 2 / 4 / 8 GPUs)
+    -- STRONG scaling, no data-path collective; afterwards the per-frame summaries are all-gathered (the "trivial
+    result gather").  A step = the whole batch once: every rank runs the encoder half of ELKEncoder (eval forward,
+    Conv-BN-ReLU fused) on its frames, kernel maps built per frame as the reference does."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import link_encoder as LE
+    from link_amd.parallel import gather_frame_rows, shard_frames
+    from link_amd.synth import s_kitti
+    mine = shard_frames(8, world, rank)
+    frames = []
+    for fid in mine:
+        co, fe = s_kitti(seed=fid)
+        frames.append((fid, torch.from_numpy(co).to(dev), torch.from_numpy(fe).to(dev)))
+    torch.manual_seed(0)
+    net = la.fuse_for_inference(LE.build_reference_shaped_encoder(la, 64, "cos_x", 1)).to(dev).eval()
+
+    def batch():
+        rows = []
+        with torch.no_grad():
+            for fid, coords, feats in frames:
+                _, outs = net(la.SparseTensor(feats, coords, 1), 3, 2)
+                rows.append((fid, coords.shape[0], outs[-1].C.shape[0], outs[-1].F.double().sum()))
+        return rows
+
+    k, w = min(args.steps, 10), min(args.warmup, 2)
+    for _ in range(w):
+        batch()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        rows = batch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    summ = torch.tensor([[float(a), float(b), float(c), float(d)] for a, b, c, d in rows], dtype=torch.float64, device=dev).view(-1, 4)
+    allrows = gather_frame_rows(summ)                  # frame id, voxels, stage-4 voxels, checksum: every rank gets all 8
+    if rank == 0:
+        nvox = float(allrows[:, 1].sum().item())
+        print(json.dumps({
+            "metric": "voxels_per_second", "value": nvox * k / float(dt.item()), "unit": "voxels/s", "n_gpus": world,
+            "steps": k, "warmup": w, "ms_per_step": 1e3 * float(dt.item()) / k, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (8 S-kitti ray-cast frames, SURVEY.md 8d; random-init weights)",
+            "headline": False,
+            "config": {"workload": "cfg4 (labelled secondary mode): 8 S-kitti frames sharded by frame over the ranks, encoder half "
+                                   "of ELKEncoder, eval forward, kernel maps per frame",
+                       "frames": int(allrows.shape[0]), "voxels": nvox, "frames_per_rank": len(mine), "parallelism": f"dp{world}"},
+            "frame_checksums": [float(v) for v in allrows[allrows[:, 0].argsort(), 3].tolist()],
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def cfg5_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[4] shape (labelled, NOT the headline): the sparse half of the detection backbone
     SpMiddleResNetFHDELKv3 (scn.py:452-626: conv_input, 4 x [2 SparseBasicBlocks + tail || TSELKBlock (3x7)^3 + tail],
@@ -323,9 +383,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
                     help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2",
                     help="cfg2 = the headline (R_core, S-uniform); cfg3 = labelled secondary mode: forward and "
-                         "forward+backward of the LinK encoder stages on one S-kitti frame per rank; cfg5 = labelled: "
+                         "forward+backward of the LinK encoder stages on one S-kitti frame per rank; cfg4 = labelled: 8 S-kitti "
+                         "frames sharded over the ranks (strong scaling), encoder eval forward, maps built per frame; cfg5 = labelled: "
                          "sparse half of the detection backbone (SpMiddleResNetFHDELKv3) on one S-nusc frame per rank")
     args = ap.parse_args()
 
@@ -369,6 +430,8 @@ def main():
         return cfg3_mode(args, la, dev, rank, world, dist)
     if args.workload == "cfg5":
         return cfg5_mode(args, la, dev, rank, world, dist)
+    if args.workload == "cfg4":
+        return cfg4_mode(args, la, dev, rank, world, dist)
 
     N, C, G, R, S_ = args.voxels, args.channels, 2, 3, 7
     torch.manual_seed(2)

@@ -492,7 +492,19 @@ class _StridedMap:
     down direction [N_coarse, 8] and of the transposed direction [N_fine, 8] (one parent per fine voxel)."""
 
     def __init__(self, out_coords, nbr_down, nbr_up):
-        self.out_coords, self.nbr_down, self.nbr_up = out_coords, nbr_down, nbr_up
+        self.out_coords, self.nbr_down, self._nbr_up, self._n_in = out_coords, nbr_down, nbr_up, None
+
+    @property
+    def nbr_up(self):
+        """[N_fine, K] with the one coarse row that reads fine row i through offset k (-1 elsewhere): the table of the
+        transposed convolution and of the input gradient.  Built on first use (inference encoders never need it)."""
+        if self._nbr_up is None:
+            down = self.nbr_down
+            jj, kk = torch.nonzero(down >= 0, as_tuple=True)
+            up = torch.full((self._n_in, down.shape[1]), -1, dtype=torch.int32, device=down.device)
+            up[down[jj, kk].long(), kk] = jj.int()
+            self._nbr_up = up
+        return self._nbr_up
 
 
 def neighbor_table_of(x: SparseTensor, kernel_size):
@@ -596,18 +608,30 @@ class Conv3d(nn.Module):
         if km is None:
             ts = int(x.s[0])
             ss = ts * self.stride[0]
-            c = x.C.clone()
-            c[:, :3] = torch.div(c[:, :3], ss, rounding_mode="floor") * ss
-            out_c = torch.unique(c[:, [3, 0, 1, 2]], dim=0)[:, [1, 2, 3, 0]].contiguous()
+            # unique rows in (batch, x, y, z) order through ONE linear key (a 1-D sort instead of a 4-column one)
+            bkey = ("link_bounds", x.C.data_ptr(), x.C.shape[0])
+            bounds = x.cmaps.get(bkey)
+            if bounds is None or x.cmaps.get(("link_bounds_unchecked", x.C.data_ptr(), x.C.shape[0])):
+                from .index import coords_bounds
+                bounds = coords_bounds(x.C.contiguous())
+                if x.C.is_contiguous() and bkey not in x.cmaps:
+                    x.cmaps[bkey] = bounds
+            lo = [bounds[0][k] // ss for k in range(3)]
+            ext = [bounds[1][k] // ss - lo[k] + 1 for k in range(3)]
+            q = torch.div(x.C[:, :3], ss, rounding_mode="floor").long()
+            lin = (((x.C[:, 3].long() - bounds[0][3]) * ext[0] + (q[:, 0] - lo[0])) * ext[1] + (q[:, 1] - lo[1])) * ext[2] + (q[:, 2] - lo[2])
+            u = torch.unique(lin)
+            oz = u % ext[2]; r1 = torch.div(u, ext[2], rounding_mode="floor")
+            oy = r1 % ext[1]; r2 = torch.div(r1, ext[1], rounding_mode="floor")
+            ox = r2 % ext[0]; ob = torch.div(r2, ext[0], rounding_mode="floor")
+            out_c = torch.stack([(ox + lo[0]) * ss, (oy + lo[1]) * ss, (oz + lo[2]) * ss, ob + bounds[0][3]], 1).int().contiguous()
             try:
-                down = foreign_neighbor_map(out_c, 2, step=ts, table_rows=x.C)
+                down = foreign_neighbor_map(out_c, 2, step=ts, table_rows=x.C, bounds=bounds)
             except GridTooLarge:
                 offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
                 down = sphashquery(sphash(out_c, offs), sphash(x.C)).t().contiguous().int()
-            jj, kk = torch.nonzero(down >= 0, as_tuple=True)
-            up = torch.full((x.C.shape[0], down.shape[1]), -1, dtype=torch.int32, device=x.C.device)
-            up[down[jj, kk].long(), kk] = jj.int()
-            km = _StridedMap(out_c, down, up)
+            km = _StridedMap(out_c, down, None)             # the transposed direction's table: built on first use
+            km._n_in = x.C.shape[0]
             x.kmaps[key] = km
         return km
 
