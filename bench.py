@@ -456,11 +456,15 @@ def main():
             dist.barrier()
 
     def geometry(ns):
-        """Launch geometry for the number of frames kept in flight (dense-cell layout): one frame alone wants
-        every kernel spread over 2 workgroups per CU; with several frames in flight half that per kernel lets
-        the kernels of different frames share the CUs (tools/mstream_dc.py)."""
+        """Launch geometry for the number of frames kept in flight (dense-cell layout): one frame alone wants every
+        kernel spread over 2 workgroups per CU (512 workgroups of the fused pre_mix kernel, 5 z-segments of the gather
+        kernel); with several frames in flight the kernels of different frames share the CUs, so each runs at one
+        workgroup per CU and the gather kernel takes 2 z-segments -- fewer halo planes summed twice (measured:
+        2.03 -> 2.10e9 voxels/s; LINK_BENCH_K1_WGS / LINK_BENCH_K2_ZSPLIT override for sweeps)."""
         if plan.dense:
             L.lib().link_dc_set_tuning2(0, int(os.environ.get("LINK_BENCH_K1_WGS", "0")) or (512 if ns == 1 else 256))
+            zs = os.environ.get("LINK_BENCH_K2_ZSPLIT")
+            L.lib().link_dc_set_tuning2(3, int(zs) if zs is not None else (0 if ns == 1 else 2))
             if os.environ.get("LINK_BENCH_K2_SPLIT") is not None:
                 L.lib().link_dc_set_tuning2(6, int(os.environ["LINK_BENCH_K2_SPLIT"]))
 
