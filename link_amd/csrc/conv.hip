@@ -30,7 +30,7 @@ struct conv_epilogue {
   int relu;
 };
 
-template <int CI, int CO, int NT>
+template <int CI, int CO, int NT, bool DEEP>
 __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict__ feats,
                                                         const int32_t *__restrict__ nbr,
                                                         const float *__restrict__ w,
@@ -79,6 +79,84 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
     uint32_t m = wg_mask;                           // offsets the workgroup computes; all others skipped outright
     if (m == 0u) {                                  // (uniform) nothing to do: rows of zeros
       __syncthreads();
+    } else if constexpr (DEEP) {
+      // Small frames (a handful of tiles per wave): a step's MFMAs are over in a few hundred cycles, so the offset loop
+      // is a chain of load latencies.  Everything is requested two steps ahead: W of offsets k+1 / k+2 travel in two
+      // register sets (one is written to the idle LDS buffer per step), and the neighbour rows of offset k+1 are
+      // gathered while offset k is multiplied.  NT == 1.
+      static_assert(!DEEP || NT == 1, "deep pipeline: one tile per wave");
+      auto next_off = [&]() { const int kk = m ? (__ffs(m) - 1) : -1; m &= m - 1; return kk; };
+      auto ld_w = [&](int kk, float4 (&wr)[WREG]) {
+        const float *wk = w + (int64_t)(kk < 0 ? 0 : kk) * CI * CO;
+#pragma unroll
+        for (int q = 0; q < WREG; q++)
+          if ((q * 256 + tid) * 4 < CI * CO) wr[q] = *reinterpret_cast<const float4 *>(&wk[(q * 256 + tid) * 4]);
+      };
+      auto st_w = [&](int b, const float4 (&wr)[WREG]) {
+        float *dst = wt_lds + b * (CO * LDW);
+#pragma unroll
+        for (int q = 0; q < WREG; q++) {
+          const int e = (q * 256 + tid) * 4, ci = e / CO, co = e - ci * CO;
+          if (e < CI * CO) {
+            dst[(co + 0) * LDW + ci] = wr[q].x; dst[(co + 1) * LDW + ci] = wr[q].y;
+            dst[(co + 2) * LDW + ci] = wr[q].z; dst[(co + 3) * LDW + ci] = wr[q].w;
+          }
+        }
+      };
+      auto ld_f = [&](int kk, int &id, float4 (&ff)[TI]) {
+        id = kk >= 0 ? my_nb[(kk * NT) * 16 + li] : -1;
+        const int64_t row = id >= 0 ? id : 0;
+#pragma unroll
+        for (int tt = 0; tt < TI; tt++) ff[tt] = *reinterpret_cast<const float4 *>(&feats[row * CI + 16 * tt + 4 * g]);
+      };
+      auto mma = [&](int b, int id, const float4 (&ff)[TI]) {
+        const bool has = id >= 0;
+        if (!__any(has)) return;                      // wave-uniform
+        const float *wt = wt_lds + b * (CO * LDW);
+#pragma unroll
+        for (int tt = 0; tt < TI; tt++) {
+          const float fx = has ? ff[tt].x : 0.f, fy = has ? ff[tt].y : 0.f, fz = has ? ff[tt].z : 0.f, fw = has ? ff[tt].w : 0.f;
+#pragma unroll
+          for (int tp = 0; tp < TO; tp++) {
+            const float4 a = *reinterpret_cast<const float4 *>(&wt[(16 * tp + li) * LDW + 16 * tt + 4 * g]);
+            acc[0][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, fx, acc[0][tp], 0, 0, 0);
+            acc[0][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, fy, acc[0][tp], 0, 0, 0);
+            acc[0][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, fz, acc[0][tp], 0, 0, 0);
+            acc[0][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, fw, acc[0][tp], 0, 0, 0);
+          }
+        }
+      };
+      float4 wA[WREG], wB[WREG], fA[TI], fB[TI];
+      int idA = -1, idB = -1;
+      int k0 = next_off(), k1 = next_off(), k2 = next_off();
+      ld_w(k0, wA);
+      ld_f(k0, idA, fA);
+      if (k1 >= 0) ld_w(k1, wB);
+      st_w(0, wA);                                    // W_k0 -> buffer 0
+      if (k2 >= 0) ld_w(k2, wA);                      // set A is free again: W_k2
+      __syncthreads();
+      // invariant at the top of a step on (k0, buffer b): W_k0 in LDS buffer b; W_k1 in flight / in set X; W_k2 in
+      // flight in set Y; rows of k0 in the current row set
+      int b = 0;
+      while (true) {
+        // -- even step: rows in fA, W_k1 in wB, W_k2 in wA
+        if (k1 >= 0) ld_f(k1, idB, fB);
+        mma(b, idA, fA);
+        if (k1 < 0) break;
+        st_w(b ^ 1, wB);
+        { const int k3 = next_off(); if (k3 >= 0) ld_w(k3, wB); k0 = k1; k1 = k2; k2 = k3; }
+        __syncthreads();
+        b ^= 1;
+        // -- odd step: rows in fB, W_k1 in wA, W_k2 in wB
+        if (k1 >= 0) ld_f(k1, idA, fA);
+        mma(b, idB, fB);
+        if (k1 < 0) break;
+        st_w(b ^ 1, wA);
+        { const int k3 = next_off(); if (k3 >= 0) ld_w(k3, wA); k0 = k1; k1 = k2; k2 = k3; }
+        __syncthreads();
+        b ^= 1;
+      }
+      __syncthreads();                               // LDS free for the next pass
     } else {
       // software pipeline over the needed offsets: W_next travels global -> registers while W_k is used
       float4 wreg[WREG];
@@ -393,9 +471,11 @@ extern "C" int link_subm_conv_wgrad(const float *feats, const float *gout, const
 
 static int g_conv_wgs = 1024;  // cap (sweep: tools/convsweep.py)
 static int g_conv_nt = 0;      // 0 = by size; 1/2/4 forced (tuning)
+static int g_conv_deep = 1;    // two-steps-ahead pipeline of the table kernel on small frames (key 2)
 extern "C" int link_conv_set_tuning(int key, int value) {
   if (key == 0 && value > 0) { g_conv_wgs = value; return LINK_OK; }
   if (key == 1 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_conv_nt = value; return LINK_OK; }
+  if (key == 2 && (value == 0 || value == 1)) { g_conv_deep = value; return LINK_OK; }
   return LINK_ERR_ARG;
 }
 
@@ -406,13 +486,20 @@ static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const flo
   if (lds > 64 * 1024) {
     // per device and cheap (a host-side table write): no process-wide once-flag, which a second GPU or a
     // device reset would never pass again
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, NT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const int64_t tiles = (n + 15) / 16;
   int64_t wgs = (tiles + 4 * NT - 1) / (4 * NT);
   if (wgs > g_conv_wgs) wgs = g_conv_wgs;
-  hipLaunchKernelGGL((k_subm_conv_mfma<CI, CO, NT>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
+  if (NT == 1 && g_conv_deep && tiles <= 1024) {      // <= 16k voxels: a wave or two per SIMD, the latency-bound regime (larger frames lose occupancy to the extra register sets)
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_mfma<CI, CO, 1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_subm_conv_mfma<CI, CO, 1, true>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
+    return check_launch("link_subm_conv_forward");
+  }
+  hipLaunchKernelGGL((k_subm_conv_mfma<CI, CO, NT, false>), dim3((unsigned)wgs), dim3(256), lds, st, feats, nbr, w, order, n, kvol, out, ep);
   return check_launch("link_subm_conv_forward");
 }
 
