@@ -40,6 +40,25 @@ def test_argument_validation_without_gpu():
     assert lib.link_premix_ln(None, None, None, None, 10, 512, 1e-6, None, None) == L.LINK_ERR_ARG
     assert lib.link_hash_query_workspace_bytes(1000) >= 2 * 1000 * 12
     assert lib.link_index_scratch_bytes(1000, 50000) >= 4 * 4000 + 4 * 50000
+    # round-2 entries: the pair-list convolution, its map builders, the dense-cell step
+    assert lib.link_conv_pairs_supported(64, 64) == 1 and lib.link_conv_pairs_supported(64, 128) == 1
+    assert lib.link_conv_pairs_supported(48, 48) == 0 and lib.link_conv_pairs_supported(64, 256) == 0
+    assert lib.link_conv_pairs_gemm(None, None, None, 0, None, 64, 64, None, None) == L.LINK_OK          # no pairs
+    assert lib.link_conv_pairs_gemm(None, None, None, 100, None, 64, 64, None, None) == L.LINK_ERR_ARG   # not 128-row granules
+    assert lib.link_conv_pairs_gemm(None, None, None, 128, None, 48, 48, None, None) == L.LINK_ERR_ARG   # width
+    assert lib.link_conv_pairs_gemm(None, None, None, 128, None, 64, 64, None, None) == L.LINK_ERR_ARG   # null buffers
+    assert lib.link_conv_pairs_sum(None, None, None, 0, 0, 64, None, None, None, 0.0, None, 0, None, None) == L.LINK_OK
+    assert lib.link_conv_pairs_sum(None, None, None, 10, 11, 64, None, None, None, 0.0, None, 0, None, None) == L.LINK_ERR_ARG
+    assert lib.link_conv_centre_sum(None, None, -1, None, 0, None, None, 10, 64, 64, None, None, None, 0.0, None, 0, None,
+                                    None) == L.LINK_ERR_ARG
+    assert lib.link_pair_plan_count(None, 10, 65, None, None, None) == L.LINK_ERR_ARG                     # kvol > 64
+    assert lib.link_pair_plan_count(None, 0, 27, None, None, None) == L.LINK_OK
+    i3 = ctypes.c_int32 * 3
+    assert lib.link_conv_out_candidate_count(i3(3, 3, 3), i3(2, 2, 2)) == 8
+    assert lib.link_conv_out_candidate_count(i3(3, 1, 1), i3(2, 1, 1)) == 2
+    assert lib.link_conv_out_candidate_count(i3(3, 3, 3), i3(1, 1, 1)) == 27
+    assert lib.link_conv_out_candidates(None, 5, i3(2, 3, 3), i3(2, 2, 2), i3(1, 1, 1), i3(4, 4, 4), None, None) == L.LINK_ERR_ARG
+    assert lib.link_dc_set_tuning2(99, 0) == L.LINK_ERR_ARG
 
 
 def test_grid_from_bounds_host_logic():
