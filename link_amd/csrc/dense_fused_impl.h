@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
-      const int Tv = __shfl(incl, rowbase + 15, 64);
+      const int Tv = __builtin_amdgcn_readlane(incl, 15);          // every DPP row holds the same 16 counts: lane 15 has the total
       const int npair = single ? Tv : (Tv + 1) >> 1;
       const uint32_t recb = lds_base + (uint32_t)(((i % 3) * K2::BUF_BYTES) + K2::REC_OFF);
       for (int p = grp; p < npair; p += 16) {
@@ -1215,7 +1215,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
-      const int Tv = __shfl(incl, rowbase + 15, 64);
+      const int Tv = __builtin_amdgcn_readlane(incl, 15);          // every DPP row holds the same 16 counts: lane 15 has the total
       const int npair = single ? Tv : (Tv + 1) >> 1;
       const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (j & 3) * K2::REC_BYTES);
       for (int p = grp; p < npair; p += 16) {
