@@ -1149,65 +1149,13 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
   int n_prev = 0;                                      // voxels in this group's cell of the previous plane
 #pragma unroll
   for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (producer) {
-    issue(0);
-    if (nplanes > 1) issue(1);
-  }
-  for (int i = 0; i <= nplanes; i++) {
-    if (producer) {
-      if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the A rows of the previous step are in LDS
-    }
-    asm volatile("s_barrier" ::: "memory");
-    if (producer && i >= nplanes) continue;
-    if (producer && i + 2 < nplanes) issue(i + 2);
-    const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
-    const int j = producer ? i : i - 1;                      // the output-plane step this half works on
-    const uint32_t abuf = abuf0 + (uint32_t)((j & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((j & 1) * K2::NG * 4);
-    if (!producer && (j < R - 1 || j >= nplanes)) continue;
-    float4 cur[P];
-    float cc = 0.f;
-    int n_here = 0;
-    if (producer) {
-#pragma unroll
-    for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
-      dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
-      dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
-      if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
-    }
-    n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
-    }
-    if (j >= R - 1) {
-      const int po = pz0 + j - (R - 1) + HLO;
-      if (producer) {
-      float4 a[P];
-      float den;
-      if (R == 3) {
-        den = (c0 + c1) + cc;
-#pragma unroll
-        for (int pp = 0; pp < P; pp++) {
-          a[pp].x = (r0[pp].x + r1[pp].x) + cur[pp].x; a[pp].y = (r0[pp].y + r1[pp].y) + cur[pp].y;
-          a[pp].z = (r0[pp].z + r1[pp].z) + cur[pp].z; a[pp].w = (r0[pp].w + r1[pp].w) + cur[pp].w;
-        }
-      } else {
-        den = c1 + cc;
-#pragma unroll
-        for (int pp = 0; pp < P; pp++) {
-          a[pp].x = r1[pp].x + cur[pp].x; a[pp].y = r1[pp].y + cur[pp].y;
-          a[pp].z = r1[pp].z + cur[pp].z; a[pp].w = r1[pp].w + cur[pp].w;
-        }
-      }
-      const float inv = den > 0.f ? 1.0f / den : 0.f;
-      // ---- A rows + counts of the plane's 16 cells -> LDS ----
-#pragma unroll
-      for (int pp = 0; pp < P; pp++)
-        lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
-                    make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
-      const int n_cell = (R == 3) ? n_prev : n_prev;   // the plane that closed is the previous one for both R
-      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_cell : 0);
-      } else {
+  // pairs pstart, pstart + 32, ... of output plane jp (A rows / counts in LDS image jp & 1, records in ring slot jp & 3).
+  // The consumer waves take pairs 0..15 (+32k), the producer waves -- once their box sums of the next plane are in LDS --
+  // pairs 16..31 (+32k): about half of the planes hold more than 32 voxels, and their second round of pairs used to
+  // double the step.
+  auto pairs_of = [&](int jp, int pstart) {
+      const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
+      const int po = pz0 + jp - (R - 1) + HLO;
       // ---- deal the plane's voxels out as pairs ----
       const int nli = lds_rd_b32(ncnt + (uint32_t)(li * 4));          // lane li of every row: cell li
       int incl = nli;
@@ -1217,8 +1165,8 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
       const int Tv = __builtin_amdgcn_readlane(incl, 15);          // every DPP row holds the same 16 counts: lane 15 has the total
       const int npair = single ? Tv : (Tv + 1) >> 1;
-      const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (j & 3) * K2::REC_BYTES);
-      for (int p = grp; p < npair; p += 16) {
+      const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (jp & 3) * K2::REC_BYTES);
+      for (int p = pstart; p < npair; p += 32) {
         const int vA = single ? p : 2 * p, vB = (!single && 2 * p + 1 < Tv) ? 2 * p + 1 : vA;
         const bool hasB = !single && 2 * p + 1 < Tv;
         const unsigned long long mA = __ballot(incl <= vA), mB = __ballot(incl <= vB);
@@ -1322,13 +1270,79 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
         io_st4(r_out, (uint32_t)recA.w * (uint32_t)C + (uint32_t)ch0, true, oa);
         io_st4(r_out, (uint32_t)recB.w * (uint32_t)C + (uint32_t)ch0, hasB, ob);
       }
+  };
+  if (producer) {
+    issue(0);
+    if (nplanes > 1) issue(1);
+  }
+  for (int i = 0; i <= nplanes; i++) {
+    if (producer) {
+      if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the A rows of the previous step are in LDS
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (producer && i >= nplanes) {
+      if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
+      continue;
+    }
+    if (producer && i + 2 < nplanes) issue(i + 2);
+    const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
+    const int j = producer ? i : i - 1;                      // the output-plane step this half works on
+    const uint32_t abuf = abuf0 + (uint32_t)((j & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((j & 1) * K2::NG * 4);
+    if (!producer) {
+      if (j >= R - 1 && j < nplanes) pairs_of(j, grp);
+      continue;
+    }
+    float4 cur[P];
+    float cc = 0.f;
+    int n_here = 0;
+    if (producer) {
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
+      dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
+      dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
+      if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
+    }
+    n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+    }
+    if (j >= R - 1) {
+      if (producer) {
+      float4 a[P];
+      float den;
+      if (R == 3) {
+        den = (c0 + c1) + cc;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          a[pp].x = (r0[pp].x + r1[pp].x) + cur[pp].x; a[pp].y = (r0[pp].y + r1[pp].y) + cur[pp].y;
+          a[pp].z = (r0[pp].z + r1[pp].z) + cur[pp].z; a[pp].w = (r0[pp].w + r1[pp].w) + cur[pp].w;
+        }
+      } else {
+        den = c1 + cc;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          a[pp].x = r1[pp].x + cur[pp].x; a[pp].y = r1[pp].y + cur[pp].y;
+          a[pp].z = r1[pp].z + cur[pp].z; a[pp].w = r1[pp].w + cur[pp].w;
+        }
+      }
+      const float inv = den > 0.f ? 1.0f / den : 0.f;
+      // ---- A rows + counts of the plane's 16 cells -> LDS ----
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+        lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
+                    make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
+      const int n_cell = (R == 3) ? n_prev : n_prev;   // the plane that closed is the previous one for both R
+      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_cell : 0);
       }
     }
-    if (producer) {
+    {
 #pragma unroll
       for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
       c0 = c1; c1 = cc;
       n_prev = n_here;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
     }
   }
 }
