@@ -457,6 +457,18 @@ int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *w
 int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
                         const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,
                         int32_t *ext_list, void *stream);
+/* The same three entries with fp16 / bf16 feature rows at the boundary (io_dtype = LINK_IO_F32 / F16 / BF16: feats, addend
+ * and out rows in that type; weights, contribution rows, statistics and accumulation fp32) -- the reference's AMP
+ * contract for its convolution (custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18). */
+int link_conv_pairs_gemm_io(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
+                            const float *w, int32_t cin, int32_t cout, float *contrib, void *stream);
+int link_conv_pairs_sum_io(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                           int64_t n_direct, int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                           const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream);
+int link_conv_centre_sum_io(const void *feats, const float *w, int32_t centre, const float *contrib, int64_t contrib_rows,
+                            const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
+                            const float *bias, const float *ln_w, const float *ln_b, float eps, const void *addend,
+                            int32_t relu, void *out, int32_t io_dtype, void *stream);
 /* Weight gradient over the pair list (the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278):
  * gw[k] = sum over the pairs p of offset k of feats[pair_in[p]]^T . gout[pair_out[p]]   (fp32 [kvol, cin, cout]).
  * One MFMA workgroup per 128-pair granule writes partial fp32[rows_pad/128, cin, cout]; the per-offset sums run in

@@ -138,6 +138,11 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "link_conv_out_candidate_count": (c_int32, [c_void_p, c_void_p]),
     "link_conv_out_candidates": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_conv_pairs_gemm_io": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "link_conv_pairs_sum_io": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    "link_conv_centre_sum_io": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                        c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "link_pair_plan_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -26,8 +26,39 @@ using namespace link;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Feature rows at the kernel boundary may be fp32, fp16 or bf16 (io = LINK_IO_*; the reference's AMP contract for its
+// convolution: custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18, with fp32 accumulation).  Everything in
+// between -- weights, contribution rows, statistics -- is fp32.  The switch is wave-uniform.
+typedef _Float16 cp_h4 __attribute__((ext_vector_type(4)));
+typedef unsigned short cp_us4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 cp_ld4(const void *base, int64_t e, int io) {
+  if (io == LINK_IO_F32) return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + e);
+  if (io == LINK_IO_F16) {
+    const cp_h4 h = *reinterpret_cast<const cp_h4 *>(reinterpret_cast<const _Float16 *>(base) + e);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  const cp_us4 u = *reinterpret_cast<const cp_us4 *>(reinterpret_cast<const unsigned short *>(base) + e);
+  return make_float4(__uint_as_float((unsigned)u.x << 16), __uint_as_float((unsigned)u.y << 16),
+                     __uint_as_float((unsigned)u.z << 16), __uint_as_float((unsigned)u.w << 16));
+}
+__device__ __forceinline__ unsigned short cp_bf16(float f) {
+  const unsigned u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void cp_st4(void *base, int64_t e, float4 v, int io) {
+  if (io == LINK_IO_F32) { *reinterpret_cast<float4 *>(reinterpret_cast<float *>(base) + e) = v; return; }
+  if (io == LINK_IO_F16) {
+    const cp_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<cp_h4 *>(reinterpret_cast<_Float16 *>(base) + e) = h;
+    return;
+  }
+  const cp_us4 u = {cp_bf16(v.x), cp_bf16(v.y), cp_bf16(v.z), cp_bf16(v.w)};
+  *reinterpret_cast<cp_us4 *>(reinterpret_cast<unsigned short *>(base) + e) = u;
+}
+
 template <int CI, int CO>
-__global__ void __launch_bounds__(512) k_conv_pairs_gemm(const float *__restrict__ feats,
+__global__ void __launch_bounds__(512) k_conv_pairs_gemm(const void *__restrict__ feats, int io,
                                                          const int32_t *__restrict__ pair_in,
                                                          const int32_t *__restrict__ wg_k,
                                                          const float *__restrict__ w, float *__restrict__ contrib) {
@@ -45,9 +76,9 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm(const float *__restrict
   const int j0 = pair_in[row0 + li];
   float4 f0[TI];
   {
-    const float *r0 = feats + (int64_t)(j0 < 0 ? 0 : j0) * CI + 4 * g;
+    const int64_t r0 = (int64_t)(j0 < 0 ? 0 : j0) * CI + 4 * g;
 #pragma unroll
-    for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const float4 *>(r0 + 16 * t);
+    for (int t = 0; t < TI; t++) f0[t] = cp_ld4(feats, r0 + 16 * t, io);
   }
   const float *wk = w + (int64_t)k * CI * CO;
   for (int e = tid * 4; e < CI * CO; e += 512 * 4) {
@@ -87,14 +118,14 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm(const float *__restrict
 // + addend, ReLU, one store.  On cfg2 (0.15 other neighbours per voxel) the whole convolution is this kernel
 // plus a 17k-row GEMM.
 template <int CI, int CO, bool TAIL>
-__global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict__ feats, const float *__restrict__ w,
+__global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict__ feats, int io, const float *__restrict__ w,
                                                          int centre, const float *__restrict__ contrib,
                                                          uint32_t contrib_bytes, const int32_t *__restrict__ ext_start,
                                                          const int32_t *__restrict__ ext_list, int64_t n,
                                                          const float *__restrict__ bias, const float *__restrict__ ln_w,
                                                          const float *__restrict__ ln_b, float eps,
-                                                         const float *__restrict__ addend, int relu,
-                                                         float *__restrict__ out) {
+                                                         const void *__restrict__ addend, int relu,
+                                                         void *__restrict__ out) {
   constexpr int TI = CI / 16, TO = CO / 16;
   constexpr int LD = CO + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -107,7 +138,7 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict
   const int64_t c0 = ok0 ? v0 : n - 1;
   float4 f0[TI];
 #pragma unroll
-  for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const float4 *>(feats + c0 * CI + 16 * t + 4 * g);
+  for (int t = 0; t < TI; t++) f0[t] = cp_ld4(feats, c0 * CI + 16 * t + 4 * g, io);
   const int s0 = ext_start[c0], e0 = ok0 ? ext_start[c0 + 1] : s0;
   const float *wk = w + (int64_t)centre * CI * CO;
   for (int e = tid * 4; e < CI * CO; e += 512 * 4) {
@@ -192,12 +223,12 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const float *__restrict
       o.x = (o.x - mean) * rstd * lw.x + lb.x; o.y = (o.y - mean) * rstd * lw.y + lb.y;
       o.z = (o.z - mean) * rstd * lw.z + lb.z; o.w = (o.w - mean) * rstd * lw.w + lb.w;
       if (addend) {
-        const float4 ad = *reinterpret_cast<const float4 *>(addend + v0 * CO + 16 * tp + 4 * g);
+        const float4 ad = cp_ld4(addend, v0 * CO + 16 * tp + 4 * g, io);
         o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
       }
       if (relu & 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     }
-    *reinterpret_cast<float4 *>(out + v0 * CO + 16 * tp + 4 * g) = o;
+    cp_st4(out, v0 * CO + 16 * tp + 4 * g, o, io);
   }
 }
 
@@ -218,8 +249,8 @@ __global__ void __launch_bounds__(256) k_conv_pairs_sum(const float *__restrict_
                                                         const int32_t *__restrict__ ext_list, int64_t n,
                                                         int64_t n_direct, const float *__restrict__ bias,
                                                         const float *__restrict__ ln_w, const float *__restrict__ ln_b,
-                                                        float eps, const float *__restrict__ addend, int relu,
-                                                        float *__restrict__ out) {
+                                                        float eps, const void *__restrict__ addend, int relu,
+                                                        void *__restrict__ out, int io) {
   constexpr int C = 4 * LPR, G = 64 / LPR;
   const int lane = threadIdx.x & 63, li = lane & (LPR - 1);
   const int64_t ngroups = (int64_t)gridDim.x * 4 * G;
@@ -231,7 +262,7 @@ __global__ void __launch_bounds__(256) k_conv_pairs_sum(const float *__restrict_
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v < n_direct) acc = *reinterpret_cast<const float4 *>(contrib + v * C + 4 * li);
     float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (TAIL && addend) ad = *reinterpret_cast<const float4 *>(addend + v * C + 4 * li);
+    if (TAIL && addend) ad = cp_ld4(addend, v * C + 4 * li, io);
     int q = s;
     for (; q + 1 < e; q += 2) {                       // two rows in flight per trip
       const int p0 = ext_list[q], p1 = ext_list[q + 1];
@@ -257,18 +288,18 @@ __global__ void __launch_bounds__(256) k_conv_pairs_sum(const float *__restrict_
       acc.z = dz * rstd * gw.z + gb.z + ad.z; acc.w = dw * rstd * gw.w + gb.w + ad.w;
       if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
     }
-    *reinterpret_cast<float4 *>(out + v * C + 4 * li) = acc;
+    cp_st4(out, v * C + 4 * li, acc, io);
   }
 }
 
 template <int CI, int CO>
-static int launch_pairs_gemm(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
+static int launch_pairs_gemm(const void *feats, int io, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
                              const float *w, float *contrib, hipStream_t st) {
   const size_t lds = (size_t)CI * (CO + 4) * sizeof(float);
   if (lds > 64 * 1024)      // per device and cheap: no process-wide "done" flag
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_pairs_gemm<CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_conv_pairs_gemm<CI, CO>), dim3((unsigned)granules), dim3(512), lds, st, feats, pair_in, wg_k, w, contrib);
+  hipLaunchKernelGGL((k_conv_pairs_gemm<CI, CO>), dim3((unsigned)granules), dim3(512), lds, st, feats, io, pair_in, wg_k, w, contrib);
   return check_launch("link_conv_pairs_gemm");
 }
 
@@ -280,14 +311,21 @@ extern "C" int link_conv_pairs_supported(int32_t cin, int32_t cout) {
   return (sq || rect) ? 1 : 0;
 }
 
+extern "C" int link_conv_pairs_gemm_io(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k,
+                                       int64_t rows_pad, const float *w, int32_t cin, int32_t cout, float *contrib, void *stream);
 extern "C" int link_conv_pairs_gemm(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
                                     const float *w, int32_t cin, int32_t cout, float *contrib, void *stream) {
+  return link_conv_pairs_gemm_io(feats, LINK_IO_F32, pair_in, wg_k, rows_pad, w, cin, cout, contrib, stream);
+}
+extern "C" int link_conv_pairs_gemm_io(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k,
+                                       int64_t rows_pad, const float *w, int32_t cin, int32_t cout, float *contrib, void *stream) {
+  if (io_dtype < 0 || io_dtype > 2) return LINK_ERR_ARG;
   if (rows_pad < 0 || (rows_pad & 127) || rows_pad >= (1LL << 31) || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
   if (rows_pad == 0) return LINK_OK;
   if (!feats || !pair_in || !wg_k || !w || !contrib) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
   const int64_t gr = rows_pad / 128;
-#define LINK_CP(I, O) if (cin == I && cout == O) return launch_pairs_gemm<I, O>(feats, pair_in, wg_k, gr, w, contrib, st)
+#define LINK_CP(I, O) if (cin == I && cout == O) return launch_pairs_gemm<I, O>(feats, (int)io_dtype, pair_in, wg_k, gr, w, contrib, st)
   LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
   LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
   LINK_CP(16, 64); LINK_CP(64, 16);
@@ -295,10 +333,20 @@ extern "C" int link_conv_pairs_gemm(const float *feats, const int32_t *pair_in, 
   return LINK_ERR_ARG;
 }
 
+extern "C" int link_conv_pairs_sum_io(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                      int64_t n_direct, int32_t cout, const float *bias, const float *ln_w, const float *ln_b,
+                                      float eps, const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream);
 extern "C" int link_conv_pairs_sum(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
                                    int64_t n_direct, int32_t cout, const float *bias, const float *ln_w,
                                    const float *ln_b, float eps, const float *addend, int32_t relu, float *out,
                                    void *stream) {
+  return link_conv_pairs_sum_io(contrib, ext_start, ext_list, n, n_direct, cout, bias, ln_w, ln_b, eps, addend, relu, out,
+                                LINK_IO_F32, stream);
+}
+extern "C" int link_conv_pairs_sum_io(const float *contrib, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                      int64_t n_direct, int32_t cout, const float *bias, const float *ln_w, const float *ln_b,
+                                      float eps, const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream) {
+  if (io_dtype < 0 || io_dtype > 2) return LINK_ERR_ARG;
   if (n < 0 || n_direct < 0 || n_direct > n) return LINK_ERR_ARG;
   if (cout != 16 && cout != 32 && cout != 64 && cout != 128) return LINK_ERR_ARG;   // power-of-two lane groups
   if ((ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
@@ -312,9 +360,9 @@ extern "C" int link_conv_pairs_sum(const float *contrib, const int32_t *ext_star
 #define LINK_CS(LPRV)                                                                                                  \
   if (lpr == LPRV) {                                                                                                   \
     if (tail) hipLaunchKernelGGL((k_conv_pairs_sum<LPRV, true>), dim3((unsigned)wgs), dim3(256), 0, st, contrib, ext_start,  \
-                                 ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out);                \
+                                 ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out, (int)io_dtype); \
     else hipLaunchKernelGGL((k_conv_pairs_sum<LPRV, false>), dim3((unsigned)wgs), dim3(256), 0, st, contrib, ext_start,      \
-                            ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out);                     \
+                            ext_list, n, n_direct, bias, ln_w, ln_b, eps, addend, (int)relu, out, (int)io_dtype);      \
     return check_launch("link_conv_pairs_sum");                                                                        \
   }
   LINK_CS(4) LINK_CS(8) LINK_CS(16) LINK_CS(32)
@@ -323,38 +371,50 @@ extern "C" int link_conv_pairs_sum(const float *contrib, const int32_t *ext_star
 }
 
 template <int CI, int CO>
-static int launch_centre_sum(const float *feats, const float *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
+static int launch_centre_sum(const void *feats, int io, const float *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
                              const int32_t *ext_list, int64_t n, const float *bias, const float *ln_w, const float *ln_b,
-                             float eps, const float *addend, int relu, float *out, hipStream_t st) {
+                             float eps, const void *addend, int relu, void *out, hipStream_t st) {
   const size_t lds = (size_t)CI * (CO + 4) * sizeof(float);
   const unsigned wgs = (unsigned)((n + 127) / 128);
   if (ln_w) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, true>), dim3(wgs), dim3(512), lds, st, feats, w, centre, contrib, cbytes, ext_start,
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, true>), dim3(wgs), dim3(512), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
                        ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, false>), dim3(wgs), dim3(512), lds, st, feats, w, centre, contrib, cbytes, ext_start,
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, false>), dim3(wgs), dim3(512), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
                        ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
   }
   return check_launch("link_conv_centre_sum");
 }
 
+extern "C" int link_conv_centre_sum_io(const void *feats, const float *w, int32_t centre, const float *contrib,
+                                       int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                       int32_t cin, int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                                       const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream);
 extern "C" int link_conv_centre_sum(const float *feats, const float *w, int32_t centre, const float *contrib,
                                     int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin,
                                     int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
                                     const float *addend, int32_t relu, float *out, void *stream) {
+  return link_conv_centre_sum_io(feats, w, centre, contrib, contrib_rows, ext_start, ext_list, n, cin, cout, bias, ln_w, ln_b, eps,
+                                 addend, relu, out, LINK_IO_F32, stream);
+}
+extern "C" int link_conv_centre_sum_io(const void *feats, const float *w, int32_t centre, const float *contrib,
+                                       int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                       int32_t cin, int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                                       const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream) {
+  if (io_dtype < 0 || io_dtype > 2) return LINK_ERR_ARG;
   if (n < 0 || centre < 0 || !link_conv_pairs_supported(cin, cout) || (ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
   if (contrib_rows < 0 || contrib_rows * (int64_t)cout * 4 >= 0xFFFFFFF0LL) return LINK_ERR_ARG;   // 32-bit row offsets
   const uint32_t cbytes = (uint32_t)(contrib_rows * cout * 4);
   if (n == 0) return LINK_OK;
   if (!feats || !w || !ext_start || !out || (contrib_rows > 0 && (!contrib || !ext_list))) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-#define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O>(feats, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
+#define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O>(feats, (int)io_dtype, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
   LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
   LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
   LINK_CC(16, 64); LINK_CC(64, 16);

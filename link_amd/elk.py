@@ -832,27 +832,29 @@ def _pad_in_channels(f: torch.Tensor, w: torch.Tensor, kernel: torch.Tensor, cin
 
 
 def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False):
+    """f / addend / out rows share one dtype (fp32, fp16 or bf16: link_conv_*_io); everything else fp32."""
     lib, st = L.lib(), _st()
+    io = _IO_DTYPES[f.dtype]
     contrib = plan.contrib(cout)
-    L.check(lib.link_conv_pairs_gemm(f.data_ptr(), plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
-                                     w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
+    L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+                                        w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
     ln_w, ln_b, eps = ln if ln is not None else (None, None, 0.0)
     if plan.direct:
-        L.check(lib.link_conv_centre_sum(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
-                                         plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
-                                         bias.data_ptr() if bias is not None else None,
-                                         ln_w.data_ptr() if ln_w is not None else None,
-                                         ln_b.data_ptr() if ln_b is not None else None, float(eps),
-                                         addend.data_ptr() if addend is not None else None, int(relu),
-                                         out.data_ptr(), st), "link_conv_centre_sum")
+        L.check(lib.link_conv_centre_sum_io(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
+                                            plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
+                                            bias.data_ptr() if bias is not None else None,
+                                            ln_w.data_ptr() if ln_w is not None else None,
+                                            ln_b.data_ptr() if ln_b is not None else None, float(eps),
+                                            addend.data_ptr() if addend is not None else None, int(relu),
+                                            out.data_ptr(), io, st), "link_conv_centre_sum")
         return out
-    L.check(lib.link_conv_pairs_sum(contrib.data_ptr(), plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n,
-                                    0, cout,
-                                    bias.data_ptr() if bias is not None else None,
-                                    ln_w.data_ptr() if ln_w is not None else None,
-                                    ln_b.data_ptr() if ln_b is not None else None, float(eps),
-                                    addend.data_ptr() if addend is not None else None, int(relu),
-                                    out.data_ptr(), st), "link_conv_pairs_sum")
+    L.check(lib.link_conv_pairs_sum_io(contrib.data_ptr(), plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n,
+                                       0, cout,
+                                       bias.data_ptr() if bias is not None else None,
+                                       ln_w.data_ptr() if ln_w is not None else None,
+                                       ln_b.data_ptr() if ln_b is not None else None, float(eps),
+                                       addend.data_ptr() if addend is not None else None, int(relu),
+                                       out.data_ptr(), io, st), "link_conv_pairs_sum")
     return out
 
 
@@ -885,14 +887,15 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
     kvol, cin2, cout = kernel.shape
     n = nbr.shape[0]                                   # output rows (== input rows for the submanifold form)
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
-    f = feats.detach().contiguous().float()
+    half = feats.dtype in (torch.float16, torch.bfloat16)      # AMP rows: the pair-list kernels take them as they are
+    f = feats.detach().contiguous()
+    f = f if half else f.float()
     w = kernel.detach().contiguous().float()
     if form != "table" and w.ndim == 3 and cout < 16 and n > 0 and L.lib().link_conv_pairs_supported((cin + 15) // 16 * 16, 16):
         # few OUTPUT channels (the input gradient of a network's first layer): zero columns up to 16, slice afterwards
         wp = torch.zeros((kvol, cin, 16), dtype=torch.float32, device=w.device)
         wp[:, :, :cout] = w
         return subm_conv(f, wp, nbr, order, form)[:, :cout].contiguous()
-    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     if form != "table" and w.ndim == 3:
         f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
     plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
@@ -901,11 +904,13 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
         if plan is None:
             raise L.LinkAmdError(f"subm_conv(form='pairs'): widths {cin}->{cout} not supported by the pair-list kernels")
     if plan is not None:
-        return _conv_pairs(plan, f, w, cin, cout, out)
+        return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device))
+    f = f.float()                                      # the table kernel is fp32: half rows are widened here
+    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(),
                                            order.data_ptr() if order is not None else None, n, cin, cout,
                                            kvol, out.data_ptr(), _st()), "link_subm_conv_forward")
-    return out
+    return out.to(feats.dtype) if half else out        # half rows in -> half rows out on either form
 
 
 def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
@@ -922,10 +927,10 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     n = nbr.shape[0]                                   # output rows (the table is per output row)
     assert cin2 == cin and nbr.shape == (n, kvol) and nbr.dtype == torch.int32
     assert addend is None or addend.shape == (n, cout)
-    f = feats.detach().contiguous().float()
+    half = feats.dtype in (torch.float16, torch.bfloat16)      # AMP rows stay as they are on the pair-list kernels
+    f = feats.detach().contiguous()
+    f = f if half else f.float()
     w = kernel.detach().contiguous().float()
-    add = addend.detach().contiguous().float() if addend is not None else None
-    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     lw, lb = ln_w.detach().contiguous().float(), ln_b.detach().contiguous().float()
     if form != "table":
         f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
@@ -934,12 +939,17 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
         plan = getattr(nbr, "_link_pairs", None)
     flags = (1 if relu else 0) | (2 if affine else 0)
     if plan is not None:
-        return _conv_pairs(plan, f, w, cin, cout, out, ln=(lw, lb, eps), addend=add, relu=flags)
+        add = addend.detach().contiguous().to(f.dtype) if addend is not None else None
+        return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device),
+                           ln=(lw, lb, eps), addend=add, relu=flags)
+    f = f.float()                                      # the table kernel is fp32: half rows are widened here
+    add = addend.detach().contiguous().float() if addend is not None else None
+    out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     L.check(L.lib().link_subm_conv_ln_add_relu(
         f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(), order.data_ptr() if order is not None else None,
         n, cin, cout, kvol, lw.data_ptr(), lb.data_ptr(), float(eps), add.data_ptr() if add is not None else None,
         flags, out.data_ptr(), _st()), "link_subm_conv_ln_add_relu")
-    return out
+    return out.to(feats.dtype) if half else out
 
 
 class _Tail(torch.autograd.Function):

@@ -51,6 +51,14 @@ def test_argument_validation_without_gpu():
     assert lib.link_conv_pairs_sum(None, None, None, 10, 11, 64, None, None, None, 0.0, None, 0, None, None) == L.LINK_ERR_ARG
     assert lib.link_conv_centre_sum(None, None, -1, None, 0, None, None, 10, 64, 64, None, None, None, 0.0, None, 0, None,
                                     None) == L.LINK_ERR_ARG
+    assert lib.link_conv_pairs_gemm_io(None, 3, None, None, 0, None, 64, 64, None, None) == L.LINK_ERR_ARG    # row type
+    assert lib.link_conv_pairs_gemm_io(None, L.IO_BF16, None, None, 0, None, 64, 64, None, None) == L.LINK_OK
+    assert lib.link_conv_pairs_sum_io(None, None, None, 0, 0, 64, None, None, None, 0.0, None, 0, None, -1, None) == L.LINK_ERR_ARG
+    assert lib.link_conv_pairs_sum_io(None, None, None, 0, 0, 64, None, None, None, 0.0, None, 0, None, L.IO_F16, None) == L.LINK_OK
+    assert lib.link_conv_centre_sum_io(None, None, 13, None, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
+                                       7, None) == L.LINK_ERR_ARG
+    assert lib.link_conv_centre_sum_io(None, None, 13, None, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
+                                       L.IO_F16, None) == L.LINK_OK
     assert lib.link_pair_plan_count(None, 10, 65, None, None, None) == L.LINK_ERR_ARG                     # kvol > 64
     assert lib.link_pair_plan_count(None, 0, 27, None, None, None) == L.LINK_OK
     i3 = ctypes.c_int32 * 3

@@ -276,6 +276,40 @@ def test_pair_form_vs_oracle_and_table_form(cin, cout, kind, n):
     assert plan.pairs + n == int((nbr >= 0).sum().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,kind,n", [(64, 64, "lidar", 20000), (32, 64, "uniform", 9000), (128, 128, "dense", 1500),
+                                             (4, 16, "lidar", 6000)])
+def test_pair_form_half_rows(cin, cout, kind, n, dtype):
+    """fp16 / bf16 feature rows at the boundary (link_conv_*_io; the reference's AMP contract,
+    nn/functional/conv.py:18): the kernels widen on load and round once on store, so on inputs that are exactly
+    representable the result equals the fp32 path's output rounded to the row type (one ulp for ties of the
+    fp32 rounding), with and without the fused epilogue; the table form returns the same dtype."""
+    import link_amd as la
+    from link_amd.elk import subm_conv, subm_conv_ln_add_relu
+    coords = s_uniform(n, grid=96, seed=5) if kind == "uniform" else _frame(kind, n, 1)
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(8)
+    feats = torch.randn(n, cin, generator=g).to(dtype).cuda()
+    conv = la.Conv3d(cin, cout, kernel_size=3).cuda()
+    st = la.SparseTensor(feats.float(), coords.cuda(), 1)
+    nbr, order = conv._neighbor_table(st)
+    w = conv.kernel.detach()
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    a = subm_conv(feats, w, nbr, order, form="pairs")
+    ref = subm_conv(feats.float(), w, nbr, order, form="pairs")
+    assert a.dtype == dtype and ref.dtype == torch.float32
+    assert torch.equal(a, ref.to(dtype))
+    b = subm_conv(feats, w, nbr, order, form="table")
+    assert b.dtype == dtype and rel_err(b.float().cpu().numpy(), ref.cpu().numpy()) < ulp
+    lw, lb = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda()
+    add = torch.randn(n, cout, generator=g).to(dtype).cuda()
+    for affine in (False, True):
+        a = subm_conv_ln_add_relu(feats, w, nbr, order, lw, lb, 1e-6, add, relu=True, form="pairs", affine=affine)
+        ref = subm_conv_ln_add_relu(feats.float(), w, nbr, order, lw, lb, 1e-6, add.float(), relu=True, form="pairs",
+                                    affine=affine)
+        assert a.dtype == dtype and torch.equal(a, ref.to(dtype))
+
+
 def test_pair_form_strided_tables_and_tail():
     """Tables that are not submanifold (k2-s2 down-sampling and its transpose: no identity rows) and the
     LayerNorm + add + ReLU epilogue, pair form vs table form."""
