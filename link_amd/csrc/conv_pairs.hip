@@ -111,14 +111,80 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm(const void *__restrict_
   }
 }
 
+// ---- AMP form: 16-bit rows x 16-bit weights on the f16 / bf16 matrix cores (fp32 accumulation) ----------------
+// custom_fwd(cast_inputs=torch.half) (nn/functional/conv.py:18) rounds the kernel as well as the rows, so with half
+// rows the products are exact in fp32 and v_mfma_f32_16x16x16_{f16,bf16} replaces four v_mfma_f32_16x16x4_f32 at
+// 1/8 of their matrix-pipe time.  The weights arrive already rounded and transposed, wt[k][co][ci] (16-bit): a
+// lane's A operand -- W_k^T[co = 16tp + li][ci = 16t + 4g .. +3] -- is then one 8-byte LDS read, and the B operand
+// is the 8 bytes of the row it loaded (no conversion anywhere).  LDS row stride CI + 8 elements = 4 * odd dwords:
+// the 32 lanes of a ds_read_b64 half hit 32 distinct bank pairs.
+typedef _Float16 cp_f16x4 __attribute__((ext_vector_type(4)));
+typedef short cp_s16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ floatx4 cp_mfma16(uint2 a, uint2 b, floatx4 c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(cp_s16x4, a), __builtin_bit_cast(cp_s16x4, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(cp_f16x4, a), __builtin_bit_cast(cp_f16x4, b), c, 0, 0, 0);
+}
+template <int CI, int CO>
+__device__ __forceinline__ void cp_stage_wt(unsigned short *w_lds, const unsigned short *wk, int tid, int nt = 512) {
+  constexpr int LDH = CI + 8;
+  for (int e = tid * 8; e < CI * CO; e += nt * 8) {
+    const int r = e / CI, col = e - r * CI;
+    *reinterpret_cast<uint4 *>(&w_lds[r * LDH + col]) = *reinterpret_cast<const uint4 *>(&wk[e]);
+  }
+}
+
+template <int CI, int CO, bool BF>
+__global__ void __launch_bounds__(512) k_conv_pairs_gemm_h(const unsigned short *__restrict__ feats,
+                                                           const int32_t *__restrict__ pair_in,
+                                                           const int32_t *__restrict__ wg_k,
+                                                           const unsigned short *__restrict__ wt,
+                                                           float *__restrict__ contrib) {
+  constexpr int TI = CI / 16, TO = CO / 16, LDH = CI + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short *w_lds = reinterpret_cast<unsigned short *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = wg_k[blockIdx.x];
+  if (k < 0) return;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int j0 = pair_in[row0 + li];
+  uint2 f0[TI];
+  {
+    const unsigned short *fr = feats + (int64_t)(j0 < 0 ? 0 : j0) * CI + 4 * g;
+#pragma unroll
+    for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const uint2 *>(fr + 16 * t);
+  }
+  cp_stage_wt<CI, CO>(w_lds, wt + (int64_t)k * CI * CO, tid);
+  __syncthreads();
+  if (__all(j0 < 0)) return;                           // granule padding
+  floatx4 a0[TO];
+#pragma unroll
+  for (int tp = 0; tp < TO; tp++) a0[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < TI; t++) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) {
+      const uint2 a = *reinterpret_cast<const uint2 *>(&w_lds[(16 * tp + li) * LDH + 16 * t + 4 * g]);
+      a0[tp] = cp_mfma16<BF>(a, f0[t], a0[tp]);
+    }
+  }
+  float *o0 = contrib + (row0 + li) * CO + 4 * g;
+  if (j0 >= 0) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++)
+      *reinterpret_cast<float4 *>(o0 + 16 * tp) = make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]);
+  }
+}
+
 // Submanifold tables: the centre offset's pairs are the identity, so its GEMM needs no gather and no
 // contribution rows -- this kernel runs it per tile of 16 output voxels and finishes the voxel in the MFMA
 // accumulator layout (a lane holds 4 channels x CO/16 tiles of ONE voxel): + the voxel's CSR rows of the other
 // offsets (computed before by k_conv_pairs_gemm), + bias, LayerNorm as in-lane adds + 2 cross-lane steps,
 // + addend, ReLU, one store.  On cfg2 (0.15 other neighbours per voxel) the whole convolution is this kernel
 // plus a 17k-row GEMM.
-template <int CI, int CO, bool TAIL>
-__global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict__ feats, int io, const float *__restrict__ w,
+template <int CI, int CO, bool TAIL, int MM>      // MM: 0 = fp32 weights w[k][ci][co]; 1 / 2 = the AMP form, f16 / bf16 weights wt[k][co][ci]
+__global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict__ feats, int io, const void *__restrict__ w,
                                                          int centre, const float *__restrict__ contrib,
                                                          uint32_t contrib_bytes, const int32_t *__restrict__ ext_start,
                                                          const int32_t *__restrict__ ext_list, int64_t n,
@@ -132,18 +198,31 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
   float *w_lds = reinterpret_cast<float *>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int nt = blockDim.x;                           // 512, or fewer waves per workgroup on small frames (more CUs pulling rows)
+  const int64_t row0 = (int64_t)blockIdx.x * (nt / 4) + wave * 16;
   const int64_t v0 = row0 + li;
   const bool ok0 = v0 < n;
   const int64_t c0 = ok0 ? v0 : n - 1;
-  float4 f0[TI];
+  float4 f0[MM ? 1 : TI];
+  uint2 h0[MM ? TI : 1];
+  if constexpr (MM != 0) {
+    const unsigned short *fr = reinterpret_cast<const unsigned short *>(feats) + c0 * CI + 4 * g;
 #pragma unroll
-  for (int t = 0; t < TI; t++) f0[t] = cp_ld4(feats, c0 * CI + 16 * t + 4 * g, io);
+    for (int t = 0; t < TI; t++) h0[t] = *reinterpret_cast<const uint2 *>(fr + 16 * t);
+  } else {
+#pragma unroll
+    for (int t = 0; t < TI; t++) f0[t] = cp_ld4(feats, c0 * CI + 16 * t + 4 * g, io);
+  }
   const int s0 = ext_start[c0], e0 = ok0 ? ext_start[c0 + 1] : s0;
-  const float *wk = w + (int64_t)centre * CI * CO;
-  for (int e = tid * 4; e < CI * CO; e += 512 * 4) {
-    const int r = e / CO, col = e - r * CO;
-    *reinterpret_cast<float4 *>(&w_lds[r * LD + col]) = *reinterpret_cast<const float4 *>(&wk[e]);
+  if constexpr (MM != 0) {
+    cp_stage_wt<CI, CO>(reinterpret_cast<unsigned short *>(smem_raw),
+                        reinterpret_cast<const unsigned short *>(w) + (int64_t)centre * CI * CO, tid, nt);
+  } else {
+    const float *wk = reinterpret_cast<const float *>(w) + (int64_t)centre * CI * CO;
+    for (int e = tid * 4; e < CI * CO; e += nt * 4) {
+      const int r = e / CO, col = e - r * CO;
+      *reinterpret_cast<float4 *>(&w_lds[r * LD + col]) = *reinterpret_cast<const float4 *>(&wk[e]);
+    }
   }
   const int pf0 = s0 < e0 ? ext_list[s0] : -1, pf1 = s0 + 1 < e0 ? ext_list[s0 + 1] : -1;
   __syncthreads();
@@ -151,22 +230,39 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
   floatx4 a0[TO];
 #pragma unroll
   for (int tp = 0; tp < TO; tp++) a0[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (MM != 0) {
+    constexpr int LDH = CI + 8;
+    const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
 #pragma unroll
-  for (int t = 0; t < TI; t++) {
-    const float *wr = &w_lds[(16 * t + 4 * g) * LD + li];
+    for (int t = 0; t < TI; t++) {
 #pragma unroll
-    for (int tp = 0; tp < TO; tp++) {
-      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * tp], f0[t].x, a0[tp], 0, 0, 0);
-      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[LD + 16 * tp], f0[t].y, a0[tp], 0, 0, 0);
-      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2 * LD + 16 * tp], f0[t].z, a0[tp], 0, 0, 0);
-      a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * LD + 16 * tp], f0[t].w, a0[tp], 0, 0, 0);
+      for (int tp = 0; tp < TO; tp++) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * LDH + 16 * t + 4 * g]);
+        a0[tp] = cp_mfma16<MM == 2>(a, h0[t], a0[tp]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TI; t++) {
+      const float *wr = &w_lds[(16 * t + 4 * g) * LD + li];
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * tp], f0[t].x, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[LD + 16 * tp], f0[t].y, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2 * LD + 16 * tp], f0[t].z, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * LD + 16 * tp], f0[t].w, a0[tp], 0, 0, 0);
+      }
     }
   }
   // the other offsets' rows, ascending kernel offset (fixed summation order), NQ per trip: the lists are
   // short but the trip count of a wave is the maximum over its 16 voxels, and a trip is two dependent round
   // trips.  Absent rows read through an out-of-range buffer offset (returns 0): no branch around the loads.
   if (__any(s0 < e0)) {
-    constexpr int NQ = (TO <= 4) ? 4 : 2;              // rows in flight per trip (register budget: NQ * TO dwordx4)
+    #ifndef CP_NQ_SMALL
+#define CP_NQ_SMALL 8
+#define CP_NQ_LARGE 4
+#endif
+    constexpr int NQ = (TO <= 4) ? CP_NQ_SMALL : CP_NQ_LARGE;   // rows in flight per trip (register budget: NQ * TO dwordx4)
     const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(contrib), 0, contrib_bytes, 0x00020000);
     int p[NQ];
     p[0] = pf0; p[1] = pf1;                            // the first trip's row ids were fetched before the MFMAs
@@ -370,23 +466,26 @@ extern "C" int link_conv_pairs_sum_io(const float *contrib, const int32_t *ext_s
   return LINK_ERR_ARG;
 }
 
-template <int CI, int CO>
-static int launch_centre_sum(const void *feats, int io, const float *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
+template <int CI, int CO, int MM>
+static int launch_centre_sum(const void *feats, int io, const void *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
                              const int32_t *ext_list, int64_t n, const float *bias, const float *ln_w, const float *ln_b,
                              float eps, const void *addend, int relu, void *out, hipStream_t st) {
-  const size_t lds = (size_t)CI * (CO + 4) * sizeof(float);
-  const unsigned wgs = (unsigned)((n + 127) / 128);
+  const size_t lds = MM ? (size_t)CO * (CI + 8) * 2 : (size_t)CI * (CO + 4) * sizeof(float);
+  // a workgroup of 8 waves finishes 128 voxels; frames too small to give every CU one of those run 4 or 2 waves per
+  // workgroup instead (the kernel is a row gather: what counts is how many CUs pull rows, W_k staging is per workgroup)
+  const unsigned nt = n > 262144 ? 512u : (n > 24576 ? 256u : 128u);
+  const unsigned wgs = (unsigned)((n + nt / 4 - 1) / (nt / 4));
   if (ln_w) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, true, MM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, true>), dim3(wgs), dim3(512), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, true, MM>), dim3(wgs), dim3(nt), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
                        ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
   } else {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, false>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_centre_sum<CI, CO, false, MM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, false>), dim3(wgs), dim3(512), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
+    hipLaunchKernelGGL((k_conv_centre_sum<CI, CO, false, MM>), dim3(wgs), dim3(nt), lds, st, feats, io, w, centre, contrib, cbytes, ext_start,
                        ext_list, n, bias, ln_w, ln_b, eps, addend, relu, out);
   }
   return check_launch("link_conv_centre_sum");
@@ -414,7 +513,59 @@ extern "C" int link_conv_centre_sum_io(const void *feats, const float *w, int32_
   if (n == 0) return LINK_OK;
   if (!feats || !w || !ext_start || !out || (contrib_rows > 0 && (!contrib || !ext_list))) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-#define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O>(feats, (int)io_dtype, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
+#define LINK_CC(I, O) if (cin == I && cout == O) return launch_centre_sum<I, O, 0>(feats, (int)io_dtype, w, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
+  LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
+  LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
+  LINK_CC(16, 64); LINK_CC(64, 16);
+#undef LINK_CC
+  return LINK_ERR_ARG;
+}
+
+// AMP form (see cp_mfma16): 16-bit rows AND 16-bit weights wt[k][cout][cin] of the same type, fp32 accumulation.
+template <int CI, int CO, bool BF>
+static int launch_pairs_gemm_h(const void *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
+                               const void *wt, float *contrib, hipStream_t st) {
+  const size_t lds = (size_t)CO * (CI + 8) * 2;
+  hipLaunchKernelGGL((k_conv_pairs_gemm_h<CI, CO, BF>), dim3((unsigned)granules), dim3(512), lds, st,
+                     reinterpret_cast<const unsigned short *>(feats), pair_in, wg_k, reinterpret_cast<const unsigned short *>(wt), contrib);
+  return check_launch("link_conv_pairs_gemm_amp");
+}
+
+extern "C" int link_conv_pairs_gemm_amp(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k,
+                                        int64_t rows_pad, const void *wt, int32_t cin, int32_t cout, float *contrib, void *stream) {
+  if (io_dtype != LINK_IO_F16 && io_dtype != LINK_IO_BF16) return LINK_ERR_ARG;
+  if (rows_pad < 0 || (rows_pad & 127) || rows_pad >= (1LL << 31) || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
+  if (rows_pad == 0) return LINK_OK;
+  if (!feats || !pair_in || !wg_k || !wt || !contrib) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const int64_t gr = rows_pad / 128;
+#define LINK_CP(I, O)                                                                                                   \
+  if (cin == I && cout == O)                                                                                            \
+    return io_dtype == LINK_IO_BF16 ? launch_pairs_gemm_h<I, O, true>(feats, pair_in, wg_k, gr, wt, contrib, st)        \
+                                    : launch_pairs_gemm_h<I, O, false>(feats, pair_in, wg_k, gr, wt, contrib, st)
+  LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
+  LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
+  LINK_CP(16, 64); LINK_CP(64, 16);
+#undef LINK_CP
+  return LINK_ERR_ARG;
+}
+
+extern "C" int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, const float *contrib,
+                                        int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
+                                        int32_t cin, int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                                        const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream) {
+  if (io_dtype != LINK_IO_F16 && io_dtype != LINK_IO_BF16) return LINK_ERR_ARG;
+  if (n < 0 || centre < 0 || !link_conv_pairs_supported(cin, cout) || (ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
+  if (contrib_rows < 0 || contrib_rows * (int64_t)cout * 4 >= 0xFFFFFFF0LL) return LINK_ERR_ARG;   // 32-bit row offsets
+  const uint32_t cbytes = (uint32_t)(contrib_rows * cout * 4);
+  if (n == 0) return LINK_OK;
+  if (!feats || !wt || !ext_start || !out || (contrib_rows > 0 && (!contrib || !ext_list))) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+#define LINK_CC(I, O)                                                                                                   \
+  if (cin == I && cout == O)                                                                                            \
+    return io_dtype == LINK_IO_BF16                                                                                     \
+               ? launch_centre_sum<I, O, 2>(feats, (int)io_dtype, wt, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st) \
+               : launch_centre_sum<I, O, 1>(feats, (int)io_dtype, wt, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
   LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
   LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
   LINK_CC(16, 64); LINK_CC(64, 16);

@@ -158,13 +158,14 @@ def _stage_fused(conv, conv_tail, elk, elk_tail, sct, block_sz):
     feats = sct.features
     io_dtype = feats.dtype
     nbr, order = _site_table(sct)
-    x = feats.float().contiguous()
+    x = feats.contiguous()                             # fp16 / bf16 rows stay 16-bit through every convolution (AMP form)
     for blk in conv:
         x = blk.fused(x, nbr, order)
     x_conv = _conv_bn(conv_tail[0], conv_tail[1], x, nbr, order)
-    x_lk = elk(_replace_feature(sct, feats.float()), block_sz).features
-    out = _conv_bn(elk_tail[0], elk_tail[1], x_lk, nbr, order, addend=x_conv, relu=True)
-    return _replace_feature(sct, out if io_dtype == torch.float32 else out.to(io_dtype))
+    x_lk = elk(_replace_feature(sct, feats.float()), block_sz).features      # the block's general layout is fp32
+    out = _conv_bn(elk_tail[0], elk_tail[1], x_lk if io_dtype == torch.float32 else x_lk.to(io_dtype), nbr, order,
+                   addend=x_conv, relu=True)
+    return _replace_feature(sct, out)
 
 
 class ELKv3Stage(nn.Module):

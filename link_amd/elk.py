@@ -831,22 +831,47 @@ def _pad_in_channels(f: torch.Tensor, w: torch.Tensor, kernel: torch.Tensor, cin
     return TF.pad(f, (0, cin_p - cin)), hit[1], cin_p
 
 
-def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False):
-    """f / addend / out rows share one dtype (fp32, fp16 or bf16: link_conv_*_io); everything else fp32."""
+AMP_MFMA = True      # half rows: round the weights to the row type too (the reference's custom_fwd cast) and use the 16-bit matrix cores
+
+
+def _amp_weights(w: torch.Tensor, dtype) -> torch.Tensor:
+    """w [K, cin, cout] fp32 -> [K, cout, cin] in the row type, cached on the fp32 tensor (itself cached per
+    parameter version by the callers: Conv3d.kernel, kernel_kio(), _pad_in_channels)."""
+    hit = getattr(w, "_link_amp", None)
+    ver = (w._version, w.data_ptr(), dtype)
+    if hit is None or hit[0] != ver:
+        hit = (ver, w.detach().float().transpose(1, 2).contiguous().to(dtype))
+        try:
+            w._link_amp = hit
+        except AttributeError:
+            pass
+    return hit[1]
+
+
+def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False, w_key=None):
+    """f / addend / out rows share one dtype (fp32, fp16 or bf16: link_conv_*_io); everything else fp32.  Half rows
+    with AMP_MFMA: weights rounded to the row type (cached on `w_key`, the caller's long-lived weight tensor)."""
     lib, st = L.lib(), _st()
     io = _IO_DTYPES[f.dtype]
     contrib = plan.contrib(cout)
-    L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
-                                        w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
+    amp = AMP_MFMA and io != L.IO_F32
+    if amp:
+        w = _amp_weights(w_key if w_key is not None and w_key.shape == w.shape else w, f.dtype)
+        L.check(lib.link_conv_pairs_gemm_amp(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+                                             w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm_amp")
+    else:
+        L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+                                            w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
     ln_w, ln_b, eps = ln if ln is not None else (None, None, 0.0)
     if plan.direct:
-        L.check(lib.link_conv_centre_sum_io(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
-                                            plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
-                                            bias.data_ptr() if bias is not None else None,
-                                            ln_w.data_ptr() if ln_w is not None else None,
-                                            ln_b.data_ptr() if ln_b is not None else None, float(eps),
-                                            addend.data_ptr() if addend is not None else None, int(relu),
-                                            out.data_ptr(), io, st), "link_conv_centre_sum")
+        centre_sum = lib.link_conv_centre_sum_amp if amp else lib.link_conv_centre_sum_io
+        L.check(centre_sum(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
+                           plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
+                           bias.data_ptr() if bias is not None else None,
+                           ln_w.data_ptr() if ln_w is not None else None,
+                           ln_b.data_ptr() if ln_b is not None else None, float(eps),
+                           addend.data_ptr() if addend is not None else None, int(relu),
+                           out.data_ptr(), io, st), "link_conv_centre_sum")
         return out
     L.check(lib.link_conv_pairs_sum_io(contrib.data_ptr(), plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n,
                                        0, cout,
@@ -904,7 +929,7 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
         if plan is None:
             raise L.LinkAmdError(f"subm_conv(form='pairs'): widths {cin}->{cout} not supported by the pair-list kernels")
     if plan is not None:
-        return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device))
+        return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device), w_key=kernel)
     f = f.float()                                      # the table kernel is fp32: half rows are widened here
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)
     L.check(L.lib().link_subm_conv_forward(f.data_ptr(), nbr.contiguous().data_ptr(), w.data_ptr(),
@@ -941,7 +966,7 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     if plan is not None:
         add = addend.detach().contiguous().to(f.dtype) if addend is not None else None
         return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device),
-                           ln=(lw, lb, eps), addend=add, relu=flags)
+                           ln=(lw, lb, eps), addend=add, relu=flags, w_key=kernel)
     f = f.float()                                      # the table kernel is fp32: half rows are widened here
     add = addend.detach().contiguous().float() if addend is not None else None
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)

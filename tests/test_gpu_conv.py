@@ -279,12 +279,15 @@ def test_pair_form_vs_oracle_and_table_form(cin, cout, kind, n):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,kind,n", [(64, 64, "lidar", 20000), (32, 64, "uniform", 9000), (128, 128, "dense", 1500),
                                              (4, 16, "lidar", 6000)])
-def test_pair_form_half_rows(cin, cout, kind, n, dtype):
-    """fp16 / bf16 feature rows at the boundary (link_conv_*_io; the reference's AMP contract,
-    nn/functional/conv.py:18): the kernels widen on load and round once on store, so on inputs that are exactly
-    representable the result equals the fp32 path's output rounded to the row type (one ulp for ties of the
-    fp32 rounding), with and without the fused epilogue; the table form returns the same dtype."""
+def test_pair_form_half_rows(cin, cout, kind, n, dtype, monkeypatch):
+    """fp16 / bf16 feature rows at the boundary (the reference's AMP contract, nn/functional/conv.py:18).
+    (a) link_conv_*_io (fp32 weights): the kernels widen on load and round once on store, so the result equals the
+    fp32 path's output rounded to the row type, bit for bit, with and without the fused epilogue.
+    (b) link_conv_*_amp (the default for half rows): the weights are rounded to the row type as custom_fwd does and
+    the products run on the 16-bit matrix cores -- exact products, fp32 accumulation in another order: equal to
+    the fp32 path on the rounded weights up to one rounding of the row type.  The table form returns the same dtype."""
     import link_amd as la
+    import link_amd.elk as E
     from link_amd.elk import subm_conv, subm_conv_ln_add_relu
     coords = s_uniform(n, grid=96, seed=5) if kind == "uniform" else _frame(kind, n, 1)
     n = coords.shape[0]
@@ -294,20 +297,32 @@ def test_pair_form_half_rows(cin, cout, kind, n, dtype):
     st = la.SparseTensor(feats.float(), coords.cuda(), 1)
     nbr, order = conv._neighbor_table(st)
     w = conv.kernel.detach()
+    wr = w.to(dtype).float()
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    a = subm_conv(feats, w, nbr, order, form="pairs")
-    ref = subm_conv(feats.float(), w, nbr, order, form="pairs")
-    assert a.dtype == dtype and ref.dtype == torch.float32
-    assert torch.equal(a, ref.to(dtype))
-    b = subm_conv(feats, w, nbr, order, form="table")
-    assert b.dtype == dtype and rel_err(b.float().cpu().numpy(), ref.cpu().numpy()) < ulp
     lw, lb = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda()
     add = torch.randn(n, cout, generator=g).to(dtype).cuda()
-    for affine in (False, True):
-        a = subm_conv_ln_add_relu(feats, w, nbr, order, lw, lb, 1e-6, add, relu=True, form="pairs", affine=affine)
-        ref = subm_conv_ln_add_relu(feats.float(), w, nbr, order, lw, lb, 1e-6, add.float(), relu=True, form="pairs",
-                                    affine=affine)
-        assert a.dtype == dtype and torch.equal(a, ref.to(dtype))
+    for amp in (False, True):
+        monkeypatch.setattr(E, "AMP_MFMA", amp)
+        a = subm_conv(feats, w, nbr, order, form="pairs")
+        ref = subm_conv(feats.float(), wr if amp else w, nbr, order, form="pairs")
+        assert a.dtype == dtype and ref.dtype == torch.float32
+        if amp:
+            assert float((a.float() - ref).abs().max()) <= ulp * float(ref.abs().max())
+            assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < ulp
+        else:
+            assert torch.equal(a, ref.to(dtype))
+        for affine in (False, True):
+            a = subm_conv_ln_add_relu(feats, w, nbr, order, lw, lb, 1e-6, add, relu=True, form="pairs", affine=affine)
+            ref = subm_conv_ln_add_relu(feats.float(), wr if amp else w, nbr, order, lw, lb, 1e-6, add.float(), relu=True,
+                                        form="pairs", affine=affine)
+            assert a.dtype == dtype
+            if amp:
+                assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < ulp
+            else:
+                assert torch.equal(a, ref.to(dtype))
+    b = subm_conv(feats, w, nbr, order, form="table")
+    ref = subm_conv(feats.float(), w, nbr, order, form="pairs")
+    assert b.dtype == dtype and rel_err(b.float().cpu().numpy(), ref.cpu().numpy()) < ulp
 
 
 def test_pair_form_strided_tables_and_tail():

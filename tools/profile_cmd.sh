@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG:-cmd}
 rm -rf $OUT; mkdir -p $OUT
-timeout ${TMO:-150} rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python $GRAFT_REPO_ROOT/$SCRIPT > $OUT/run.log 2>&1
+timeout ${TMO:-150} rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python $GRAFT_REPO_ROOT/$SCRIPT ${ARGS:-} > $OUT/run.log 2>&1
 echo "rocprof rc=$?"
 grep -v amdgpu.ids $OUT/run.log | tail -3
 db=$(find $OUT -name "*.db" | head -1)
