@@ -318,14 +318,15 @@ def cfg5_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[4] shape (labelled, NOT the headline): the sparse half of the detection backbone
     SpMiddleResNetFHDELKv3 (scn.py:452-626: conv_input, 4 x [2 SparseBasicBlocks + tail || TSELKBlock (3x7)^3 + tail],
     3 k3-s2 SparseConv3d, extra_conv, dense -> BEV [1, 256, 180, 180]) on one S-nusc frame per rank
-    (link_amd/synth.py, seed = rank; ~150k voxels, 5 features, grid 1440 x 1440 x 40), eval forward, fp32, random-init
-    weights.  A step builds every kernel map of the frame (as the reference does per frame); the line also carries
+    (link_amd/synth.py, seed = rank; ~150k voxels, 5 features, grid 1440 x 1440 x 40), eval forward, random-init
+    weights; fp32, or with `--io f16|bf16` the AMP form BASELINE.json quotes this configuration in (16-bit rows and
+    weights on the 16-bit matrix cores, fp32 accumulation / BatchNorm folds; the TSELKBlock core in fp32).  A step builds every kernel map of the frame (as the reference does per frame); the line also carries
     the warm-map time.  The dense BEV half (RPN, CenterHead) is plain torch in the reference and not timed."""
     import torch
     from link_amd.synth import s_nusc
     co, fe = s_nusc(seed=rank)
     indices = torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int().to(dev)
-    feats = torch.from_numpy(fe).to(dev)
+    feats = torch.from_numpy(fe).to(dev).to({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io])
     n = indices.shape[0]
     torch.manual_seed(0)
     net = la.SpMiddleResNetFHDELKv3(num_input_features=5).to(dev).eval()
@@ -361,7 +362,9 @@ def cfg5_mode(args, la, dev, rank, world, dist):
         print(json.dumps({
             "metric": "voxels_per_second", "value": float(nv.item()) * k / t_cold, "unit": "voxels/s", "n_gpus": world,
             "steps": k, "warmup": w, "ms_per_step": 1e3 * t_cold / k, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (S-nusc ray-cast frame, SURVEY.md 8d; random-init weights)",
+            "vs_baseline": None,
+            "dtype": "f32" if args.io == "f32" else f"{args.io} rows and convolution weights (16-bit MFMA, f32 accumulation); block core f32",
+            "data": "synthetic (S-nusc ray-cast frame, SURVEY.md 8d; random-init weights)",
             "headline": False,
             "config": {"workload": "cfg5 (labelled secondary mode): sparse half of SpMiddleResNetFHDELKv3, eval forward, kernel "
                                    "maps built per frame, one S-nusc frame per GPU",

@@ -472,13 +472,15 @@ int link_conv_centre_sum_io(const void *feats, const float *w, int32_t centre, c
 /* AMP form of the two MFMA entries: the rows AND the weights are 16-bit (io_dtype = LINK_IO_F16 / LINK_IO_BF16 for both;
  * custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18, rounds the kernel together with the features), the
  * products run on the f16 / bf16 matrix cores with fp32 accumulation; contribution rows, statistics and epilogue
- * stay fp32.  wt = the weights rounded to the row type and transposed per offset: [kvol][cout][cin]. */
+ * stay fp32.  wt = the weights rounded to the row type and transposed per offset: [kvol][cout][cin].
+ * contrib_dtype = LINK_IO_F32, or io_dtype: the contribution rows are stored in the row type too (the reference's half
+ * torch.mm output, convolution_cuda.cu:127-140) and summed in fp32 -- half the bytes of the dominant stream. */
 int link_conv_pairs_gemm_amp(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
-                             const void *wt, int32_t cin, int32_t cout, float *contrib, void *stream);
-int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, const float *contrib, int64_t contrib_rows,
-                             const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
-                             const float *bias, const float *ln_w, const float *ln_b, float eps, const void *addend,
-                             int32_t relu, void *out, int32_t io_dtype, void *stream);
+                             const void *wt, int32_t cin, int32_t cout, void *contrib, int32_t contrib_dtype, void *stream);
+int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, const void *contrib, int32_t contrib_dtype,
+                             int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin,
+                             int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
+                             const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream);
 /* Weight gradient over the pair list (the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278):
  * gw[k] = sum over the pairs p of offset k of feats[pair_in[p]]^T . gout[pair_out[p]]   (fp32 [kvol, cin, cout]).
  * One MFMA workgroup per 128-pair granule writes partial fp32[rows_pad/128, cin, cout]; the per-offset sums run in

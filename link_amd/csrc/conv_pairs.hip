@@ -134,12 +134,14 @@ __device__ __forceinline__ void cp_stage_wt(unsigned short *w_lds, const unsigne
   }
 }
 
-template <int CI, int CO, bool BF>
+// C16: the contribution rows are stored in the row type as well (what the reference's half torch.mm produces,
+// convolution_cuda.cu:127-140); their sum in k_conv_centre_sum stays fp32.
+template <int CI, int CO, bool BF, bool C16>
 __global__ void __launch_bounds__(512) k_conv_pairs_gemm_h(const unsigned short *__restrict__ feats,
                                                            const int32_t *__restrict__ pair_in,
                                                            const int32_t *__restrict__ wg_k,
                                                            const unsigned short *__restrict__ wt,
-                                                           float *__restrict__ contrib) {
+                                                           void *__restrict__ contrib) {
   constexpr int TI = CI / 16, TO = CO / 16, LDH = CI + 8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short *w_lds = reinterpret_cast<unsigned short *>(smem_raw);
@@ -169,11 +171,11 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm_h(const unsigned short 
       a0[tp] = cp_mfma16<BF>(a, f0[t], a0[tp]);
     }
   }
-  float *o0 = contrib + (row0 + li) * CO + 4 * g;
   if (j0 >= 0) {
 #pragma unroll
     for (int tp = 0; tp < TO; tp++)
-      *reinterpret_cast<float4 *>(o0 + 16 * tp) = make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]);
+      cp_st4(contrib, (row0 + li) * CO + 4 * g + 16 * tp, make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]),
+             C16 ? (BF ? LINK_IO_BF16 : LINK_IO_F16) : LINK_IO_F32);
   }
 }
 
@@ -183,9 +185,9 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm_h(const unsigned short 
 // offsets (computed before by k_conv_pairs_gemm), + bias, LayerNorm as in-lane adds + 2 cross-lane steps,
 // + addend, ReLU, one store.  On cfg2 (0.15 other neighbours per voxel) the whole convolution is this kernel
 // plus a 17k-row GEMM.
-template <int CI, int CO, bool TAIL, int MM>      // MM: 0 = fp32 weights w[k][ci][co]; 1 / 2 = the AMP form, f16 / bf16 weights wt[k][co][ci]
+template <int CI, int CO, bool TAIL, int MM>      // MM: 0 = fp32 weights w[k][ci][co]; 1 / 2 = the AMP form, f16 / bf16 weights wt[k][co][ci]; 3 / 4 = AMP with 16-bit contribution rows
 __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict__ feats, int io, const void *__restrict__ w,
-                                                         int centre, const float *__restrict__ contrib,
+                                                         int centre, const void *__restrict__ contrib,
                                                          uint32_t contrib_bytes, const int32_t *__restrict__ ext_start,
                                                          const int32_t *__restrict__ ext_list, int64_t n,
                                                          const float *__restrict__ bias, const float *__restrict__ ln_w,
@@ -194,6 +196,7 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
                                                          void *__restrict__ out) {
   constexpr int TI = CI / 16, TO = CO / 16;
   constexpr int LD = CO + 4;
+  constexpr bool BFW = MM == 2 || MM == 4, C16 = MM >= 3;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *w_lds = reinterpret_cast<float *>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
 #pragma unroll
       for (int tp = 0; tp < TO; tp++) {
         const uint2 a = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * LDH + 16 * t + 4 * g]);
-        a0[tp] = cp_mfma16<MM == 2>(a, h0[t], a0[tp]);
+        a0[tp] = cp_mfma16<BFW>(a, h0[t], a0[tp]);
       }
     }
   } else {
@@ -263,26 +266,46 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
 #define CP_NQ_LARGE 4
 #endif
     constexpr int NQ = (TO <= 4) ? CP_NQ_SMALL : CP_NQ_LARGE;   // rows in flight per trip (register budget: NQ * TO dwordx4)
-    const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(contrib), 0, contrib_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(contrib), 0, contrib_bytes, 0x00020000);
     int p[NQ];
     p[0] = pf0; p[1] = pf1;                            // the first trip's row ids were fetched before the MFMAs
 #pragma unroll
     for (int j = 2; j < NQ; j++) p[j] = s0 + j < e0 ? ext_list[s0 + j] : -1;
     for (int q0 = s0; __any(q0 < e0); q0 += NQ) {
-      floatx4 c[NQ][TO];
+      floatx4 c[C16 ? 1 : NQ][C16 ? 1 : TO];
+      uint2 h[C16 ? NQ : 1][C16 ? TO : 1];
 #pragma unroll
       for (int j = 0; j < NQ; j++)
 #pragma unroll
         for (int tp = 0; tp < TO; tp++) {
-          const uint32_t off = p[j] >= 0 ? (uint32_t)p[j] * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
-          c[j][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, off, 0, 0));
+          if constexpr (C16) {
+            const uint32_t off = p[j] >= 0 ? (uint32_t)p[j] * (uint32_t)(CO * 2) + (uint32_t)((16 * tp + 4 * g) * 2) : 0xFFFFFFF0u;
+            h[j][tp] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r_c, off, 0, 0));
+          } else {
+            const uint32_t off = p[j] >= 0 ? (uint32_t)p[j] * (uint32_t)(CO * 4) + (uint32_t)((16 * tp + 4 * g) * 4) : 0xFFFFFFF0u;
+            c[j][tp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_c, off, 0, 0));
+          }
         }
 #pragma unroll
       for (int j = 0; j < NQ; j++) p[j] = q0 + NQ + j < e0 ? ext_list[q0 + NQ + j] : -1;
 #pragma unroll
       for (int tp = 0; tp < TO; tp++)
 #pragma unroll
-        for (int j = 0; j < NQ; j++) a0[tp] += c[j][tp];
+        for (int j = 0; j < NQ; j++) {
+          if constexpr (C16) {
+            float4 v;
+            if constexpr (BFW) {
+              v = make_float4(__uint_as_float(h[j][tp].x << 16), __uint_as_float(h[j][tp].x & 0xFFFF0000u),
+                              __uint_as_float(h[j][tp].y << 16), __uint_as_float(h[j][tp].y & 0xFFFF0000u));
+            } else {
+              const cp_h4 q = __builtin_bit_cast(cp_h4, h[j][tp]);
+              v = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+            }
+            a0[tp][0] += v.x; a0[tp][1] += v.y; a0[tp][2] += v.z; a0[tp][3] += v.w;
+          } else {
+            a0[tp] += c[j][tp];
+          }
+        }
     }
   }
   if (bias) {
@@ -467,7 +490,7 @@ extern "C" int link_conv_pairs_sum_io(const float *contrib, const int32_t *ext_s
 }
 
 template <int CI, int CO, int MM>
-static int launch_centre_sum(const void *feats, int io, const void *w, int centre, const float *contrib, uint32_t cbytes, const int32_t *ext_start,
+static int launch_centre_sum(const void *feats, int io, const void *w, int centre, const void *contrib, uint32_t cbytes, const int32_t *ext_start,
                              const int32_t *ext_list, int64_t n, const float *bias, const float *ln_w, const float *ln_b,
                              float eps, const void *addend, int relu, void *out, hipStream_t st) {
   const size_t lds = MM ? (size_t)CO * (CI + 8) * 2 : (size_t)CI * (CO + 4) * sizeof(float);
@@ -522,18 +545,21 @@ extern "C" int link_conv_centre_sum_io(const void *feats, const float *w, int32_
 }
 
 // AMP form (see cp_mfma16): 16-bit rows AND 16-bit weights wt[k][cout][cin] of the same type, fp32 accumulation.
-template <int CI, int CO, bool BF>
+template <int CI, int CO, bool BF, bool C16>
 static int launch_pairs_gemm_h(const void *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
-                               const void *wt, float *contrib, hipStream_t st) {
+                               const void *wt, void *contrib, hipStream_t st) {
   const size_t lds = (size_t)CO * (CI + 8) * 2;
-  hipLaunchKernelGGL((k_conv_pairs_gemm_h<CI, CO, BF>), dim3((unsigned)granules), dim3(512), lds, st,
+  hipLaunchKernelGGL((k_conv_pairs_gemm_h<CI, CO, BF, C16>), dim3((unsigned)granules), dim3(512), lds, st,
                      reinterpret_cast<const unsigned short *>(feats), pair_in, wg_k, reinterpret_cast<const unsigned short *>(wt), contrib);
   return check_launch("link_conv_pairs_gemm_amp");
 }
 
 extern "C" int link_conv_pairs_gemm_amp(const void *feats, int32_t io_dtype, const int32_t *pair_in, const int32_t *wg_k,
-                                        int64_t rows_pad, const void *wt, int32_t cin, int32_t cout, float *contrib, void *stream) {
+                                        int64_t rows_pad, const void *wt, int32_t cin, int32_t cout, void *contrib,
+                                        int32_t contrib_dtype, void *stream) {
   if (io_dtype != LINK_IO_F16 && io_dtype != LINK_IO_BF16) return LINK_ERR_ARG;
+  if (contrib_dtype != LINK_IO_F32 && contrib_dtype != io_dtype) return LINK_ERR_ARG;
+  const bool c16 = contrib_dtype != LINK_IO_F32;
   if (rows_pad < 0 || (rows_pad & 127) || rows_pad >= (1LL << 31) || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
   if (rows_pad == 0) return LINK_OK;
   if (!feats || !pair_in || !wg_k || !wt || !contrib) return LINK_ERR_ARG;
@@ -541,8 +567,11 @@ extern "C" int link_conv_pairs_gemm_amp(const void *feats, int32_t io_dtype, con
   const int64_t gr = rows_pad / 128;
 #define LINK_CP(I, O)                                                                                                   \
   if (cin == I && cout == O)                                                                                            \
-    return io_dtype == LINK_IO_BF16 ? launch_pairs_gemm_h<I, O, true>(feats, pair_in, wg_k, gr, wt, contrib, st)        \
-                                    : launch_pairs_gemm_h<I, O, false>(feats, pair_in, wg_k, gr, wt, contrib, st)
+    return io_dtype == LINK_IO_BF16                                                                                     \
+               ? (c16 ? launch_pairs_gemm_h<I, O, true, true>(feats, pair_in, wg_k, gr, wt, contrib, st)                \
+                      : launch_pairs_gemm_h<I, O, true, false>(feats, pair_in, wg_k, gr, wt, contrib, st))              \
+               : (c16 ? launch_pairs_gemm_h<I, O, false, true>(feats, pair_in, wg_k, gr, wt, contrib, st)               \
+                      : launch_pairs_gemm_h<I, O, false, false>(feats, pair_in, wg_k, gr, wt, contrib, st))
   LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
   LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
   LINK_CP(16, 64); LINK_CP(64, 16);
@@ -550,22 +579,24 @@ extern "C" int link_conv_pairs_gemm_amp(const void *feats, int32_t io_dtype, con
   return LINK_ERR_ARG;
 }
 
-extern "C" int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, const float *contrib,
-                                        int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n,
-                                        int32_t cin, int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
-                                        const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream) {
+extern "C" int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, const void *contrib,
+                                        int32_t contrib_dtype, int64_t contrib_rows, const int32_t *ext_start,
+                                        const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout, const float *bias,
+                                        const float *ln_w, const float *ln_b, float eps, const void *addend, int32_t relu,
+                                        void *out, int32_t io_dtype, void *stream) {
   if (io_dtype != LINK_IO_F16 && io_dtype != LINK_IO_BF16) return LINK_ERR_ARG;
+  if (contrib_dtype != LINK_IO_F32 && contrib_dtype != io_dtype) return LINK_ERR_ARG;
+  const bool c16 = contrib_dtype != LINK_IO_F32;
   if (n < 0 || centre < 0 || !link_conv_pairs_supported(cin, cout) || (ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
   if (contrib_rows < 0 || contrib_rows * (int64_t)cout * 4 >= 0xFFFFFFF0LL) return LINK_ERR_ARG;   // 32-bit row offsets
-  const uint32_t cbytes = (uint32_t)(contrib_rows * cout * 4);
+  const uint32_t cbytes = (uint32_t)(contrib_rows * cout * (c16 ? 2 : 4));
   if (n == 0) return LINK_OK;
   if (!feats || !wt || !ext_start || !out || (contrib_rows > 0 && (!contrib || !ext_list))) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
+#define LINK_CA(I, O, M) launch_centre_sum<I, O, M>(feats, (int)io_dtype, wt, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
 #define LINK_CC(I, O)                                                                                                   \
   if (cin == I && cout == O)                                                                                            \
-    return io_dtype == LINK_IO_BF16                                                                                     \
-               ? launch_centre_sum<I, O, 2>(feats, (int)io_dtype, wt, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st) \
-               : launch_centre_sum<I, O, 1>(feats, (int)io_dtype, wt, centre, contrib, cbytes, ext_start, ext_list, n, bias, ln_w, ln_b, eps, addend, (int)relu, out, st)
+    return io_dtype == LINK_IO_BF16 ? (c16 ? LINK_CA(I, O, 4) : LINK_CA(I, O, 2)) : (c16 ? LINK_CA(I, O, 3) : LINK_CA(I, O, 1))
   LINK_CC(16, 16); LINK_CC(32, 32); LINK_CC(64, 64); LINK_CC(128, 128);
   LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
   LINK_CC(16, 64); LINK_CC(64, 16);

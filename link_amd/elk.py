@@ -790,7 +790,12 @@ class _PairPlan:
         self.gran_start, self.wg_k = meta[kvol + nwk: kvol + nwk + kvol + 1], meta[kvol + nwk + kvol + 1:]
         self._contrib: Dict[int, torch.Tensor] = {}
 
-    def contrib(self, cout: int) -> torch.Tensor:
+    def contrib(self, cout: int, dtype=torch.float32) -> torch.Tensor:
+        if dtype != torch.float32:
+            buf = self._contrib.get((cout, dtype))
+            if buf is None:
+                buf = self._contrib[(cout, dtype)] = torch.empty((max(self.rows_pad, 1), cout), dtype=dtype, device=self.pair_in.device)
+            return buf
         buf = self._contrib.get(cout)
         if buf is None:
             if len(self._contrib) >= 2:
@@ -831,6 +836,7 @@ def _pad_in_channels(f: torch.Tensor, w: torch.Tensor, kernel: torch.Tensor, cin
     return TF.pad(f, (0, cin_p - cin)), hit[1], cin_p
 
 
+AMP_CONTRIB16 = (torch.float16,)     # row types whose per-offset contribution rows are stored 16-bit too (as the reference's half mm does)
 AMP_MFMA = True      # half rows: round the weights to the row type too (the reference's custom_fwd cast) and use the 16-bit matrix cores
 
 
@@ -853,19 +859,21 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
     with AMP_MFMA: weights rounded to the row type (cached on `w_key`, the caller's long-lived weight tensor)."""
     lib, st = L.lib(), _st()
     io = _IO_DTYPES[f.dtype]
-    contrib = plan.contrib(cout)
     amp = AMP_MFMA and io != L.IO_F32
+    c16 = amp and plan.direct and f.dtype in AMP_CONTRIB16      # 16-bit contribution rows (submanifold maps)
+    contrib = plan.contrib(cout, f.dtype if c16 else torch.float32)
+    cdt = io if c16 else L.IO_F32
     if amp:
         w = _amp_weights(w_key if w_key is not None and w_key.shape == w.shape else w, f.dtype)
         L.check(lib.link_conv_pairs_gemm_amp(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
-                                             w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm_amp")
+                                             w.data_ptr(), cin, cout, contrib.data_ptr(), cdt, st), "link_conv_pairs_gemm_amp")
     else:
         L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
                                             w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
     ln_w, ln_b, eps = ln if ln is not None else (None, None, 0.0)
     if plan.direct:
         centre_sum = lib.link_conv_centre_sum_amp if amp else lib.link_conv_centre_sum_io
-        L.check(centre_sum(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), plan.rows_pad,
+        L.check(centre_sum(f.data_ptr(), w.data_ptr(), plan.kvol // 2, contrib.data_ptr(), *((cdt,) if amp else ()), plan.rows_pad,
                            plan.ext_start.data_ptr(), plan.ext_list.data_ptr(), plan.n, cin, cout,
                            bias.data_ptr() if bias is not None else None,
                            ln_w.data_ptr() if ln_w is not None else None,

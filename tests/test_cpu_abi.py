@@ -59,12 +59,15 @@ def test_argument_validation_without_gpu():
                                        7, None) == L.LINK_ERR_ARG
     assert lib.link_conv_centre_sum_io(None, None, 13, None, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
                                        L.IO_F16, None) == L.LINK_OK
-    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F32, None, None, 0, None, 64, 64, None, None) == L.LINK_ERR_ARG   # 16-bit rows only
-    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F16, None, None, 0, None, 64, 64, None, None) == L.LINK_OK
-    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F16, None, None, 128, None, 64, 64, None, None) == L.LINK_ERR_ARG  # null buffers
-    assert lib.link_conv_centre_sum_amp(None, None, 13, None, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
+    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F32, None, None, 0, None, 64, 64, None, L.IO_F32, None) == L.LINK_ERR_ARG   # 16-bit rows only
+    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F16, None, None, 0, None, 64, 64, None, L.IO_F16, None) == L.LINK_OK
+    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F16, None, None, 0, None, 64, 64, None, L.IO_BF16, None) == L.LINK_ERR_ARG  # contrib: fp32 or the row type
+    assert lib.link_conv_pairs_gemm_amp(None, L.IO_F16, None, None, 128, None, 64, 64, None, L.IO_F32, None) == L.LINK_ERR_ARG  # null buffers
+    assert lib.link_conv_centre_sum_amp(None, None, 13, None, L.IO_F32, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
                                         L.IO_F32, None) == L.LINK_ERR_ARG
-    assert lib.link_conv_centre_sum_amp(None, None, 13, None, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
+    assert lib.link_conv_centre_sum_amp(None, None, 13, None, L.IO_F16, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
+                                        L.IO_BF16, None) == L.LINK_ERR_ARG
+    assert lib.link_conv_centre_sum_amp(None, None, 13, None, L.IO_BF16, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
                                         L.IO_BF16, None) == L.LINK_OK
     assert lib.link_pair_plan_count(None, 10, 65, None, None, None) == L.LINK_ERR_ARG                     # kvol > 64
     assert lib.link_pair_plan_count(None, 0, 27, None, None, None) == L.LINK_OK

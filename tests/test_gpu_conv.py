@@ -285,7 +285,8 @@ def test_pair_form_half_rows(cin, cout, kind, n, dtype, monkeypatch):
     fp32 path's output rounded to the row type, bit for bit, with and without the fused epilogue.
     (b) link_conv_*_amp (the default for half rows): the weights are rounded to the row type as custom_fwd does and
     the products run on the 16-bit matrix cores -- exact products, fp32 accumulation in another order: equal to
-    the fp32 path on the rounded weights up to one rounding of the row type.  The table form returns the same dtype."""
+    the fp32 path on the rounded weights up to one rounding of the row type; with 16-bit contribution rows (the
+    default for fp16, as the reference's half mm) one more rounding per neighbour.  The table form returns the same dtype."""
     import link_amd as la
     import link_amd.elk as E
     from link_amd.elk import subm_conv, subm_conv_ln_add_relu
@@ -301,14 +302,15 @@ def test_pair_form_half_rows(cin, cout, kind, n, dtype, monkeypatch):
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     lw, lb = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda()
     add = torch.randn(n, cout, generator=g).to(dtype).cuda()
-    for amp in (False, True):
+    for amp, c16 in ((False, False), (True, False), (True, True)):     # c16: contribution rows in the row type too
         monkeypatch.setattr(E, "AMP_MFMA", amp)
+        monkeypatch.setattr(E, "AMP_CONTRIB16", (dtype,) if c16 else ())
         a = subm_conv(feats, w, nbr, order, form="pairs")
         ref = subm_conv(feats.float(), wr if amp else w, nbr, order, form="pairs")
         assert a.dtype == dtype and ref.dtype == torch.float32
         if amp:
-            assert float((a.float() - ref).abs().max()) <= ulp * float(ref.abs().max())
-            assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < ulp
+            assert float((a.float() - ref).abs().max()) <= (3 if c16 else 1) * ulp * float(ref.abs().max())
+            assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < (2 if c16 else 1) * ulp
         else:
             assert torch.equal(a, ref.to(dtype))
         for affine in (False, True):
@@ -317,7 +319,7 @@ def test_pair_form_half_rows(cin, cout, kind, n, dtype, monkeypatch):
                                         form="pairs", affine=affine)
             assert a.dtype == dtype
             if amp:
-                assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < ulp
+                assert rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < (2 if c16 else 1) * ulp
             else:
                 assert torch.equal(a, ref.to(dtype))
     b = subm_conv(feats, w, nbr, order, form="table")
