@@ -31,8 +31,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .elk import (SparseConvTensor, TSELKBlock, _SubmConv, fold_batchnorm, neighbor_table_of, spconv2ts, subm_conv,
-                  subm_conv_ln_add_relu)
+from .elk import (SparseConvTensor, TSELKBlock, _SubmConv, _pair_plan, fold_batchnorm, neighbor_table_of, spconv2ts,
+                  subm_conv, subm_conv_ln_add_relu)
 from .utils import get_kernel_offsets
 
 __all__ = ["SubMConv3d", "SparseConv3d", "SparseBasicBlock", "ELKv3Stage", "SpMiddleResNetFHDELKv3", "to_dense"]
@@ -340,6 +340,46 @@ def to_dense(sct) -> torch.Tensor:
     return out.permute(0, 4, 1, 2, 3).contiguous()
 
 
+MAP_STREAM = True     # build the kernel maps of a frame on a side stream (see _MapAhead)
+
+
+class _MapAhead:
+    """Kernel-map construction ahead of the compute, on its own HIP stream.
+
+    The maps of a frame depend on its coordinates only, but every one of them costs a host round trip (the pair
+    counts / the number of output sites size the next allocation -- the same numbers the reference's nbsizes holds
+    on the host, nn/functional/conv.py:114-116).  On the compute stream each of those round trips would wait for
+    all the convolutions queued before it.  Inside `with maps:` the current stream is a side stream that never
+    waits for the compute stream after the frame has begun, so the host builds scale k+1's maps while the GPU is
+    still computing scale k; leaving the block makes the compute stream wait for the side stream.  Rules that
+    keep this race-free: every tensor a map is built FROM is either the caller's `coors` (the side stream waits
+    for the compute stream once, when the frame begins) or was produced inside an earlier `with maps:` block; map
+    tensors are allocated from the side stream's pool and die with the frame's indice_dict, and the next frame
+    begins with the side stream waiting for the compute stream again, so their memory is not reused early."""
+
+    _streams = {}
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        side = _MapAhead._streams.get(key)
+        if side is None:
+            side = _MapAhead._streams[key] = torch.cuda.Stream(device=device)
+        self.side = side
+        side.wait_stream(self.main)
+        self._ctx = None
+
+    def __enter__(self):
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        self.main.wait_stream(self.side)
+        return False
+
+
 class SpMiddleResNetFHDELKv3(nn.Module):
     """The sparse half of the detection backbone (scn.py:452-626), attribute names as the reference's
     (conv_input, conv{k}, conv{k}_tail, elk{k}, elk{k}_tail, act{k}, down{k}, extra_conv), on the SparseConvTensor
@@ -377,7 +417,12 @@ class SpMiddleResNetFHDELKv3(nn.Module):
         sparse_shape[0] += 1                                           # scn.py:573
         x = SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size, indice_dict=indice_dict)
         fused = not _needs_modules(self, voxel_features)
+        maps = _MapAhead(x.features.device) if fused and MAP_STREAM else None
         if fused:
+            if maps is not None:
+                with maps:                                             # scale 1: site table + its pair plan
+                    nbr, order = _site_table(x)
+                    _pair_plan(nbr, 16, 16)
             nbr, order = _site_table(x)
             sc, sh = fold_batchnorm(self.conv_input[1], self.conv_input[0].bias)
             x = _replace_feature(x, subm_conv_ln_add_relu(x.features, self.conv_input[0].kernel_kio(), nbr, order, sc, sh,
@@ -388,6 +433,12 @@ class SpMiddleResNetFHDELKv3(nn.Module):
         for k in (1, 2, 3, 4):
             if k > 1:
                 down = getattr(self, f"down{k}")
+                if maps is not None:
+                    with maps:                                         # scale k: output sites + gather table of the strided
+                        out_ind, table, _ = down[0]._map(x)            # convolution, then the new sites' table and both plans
+                        _pair_plan(table, down[0].in_channels, down[0].out_channels)
+                        nbr, _ = _site_table(down[0]._out_tensor(x, out_ind, None))
+                        _pair_plan(nbr, down[0].out_channels, down[0].out_channels)
                 x = down[0].fused(x, down[1], relu=True) if fused else _seq_conv_bn(down, x, True)
             parts = [getattr(self, f"{n}{k}{s}") for n, s in (("conv", ""), ("conv", "_tail"), ("elk", ""), ("elk", "_tail"))]
             if fused:
@@ -395,6 +446,10 @@ class SpMiddleResNetFHDELKv3(nn.Module):
             else:
                 x = _stage_modules(*parts, getattr(self, f"act{k}"), x, self.block_sz)
             scales[f"conv{k}"] = x
+        if maps is not None:
+            with maps:
+                _, table, _ = self.extra_conv[0]._map(x)
+                _pair_plan(table, self.extra_conv[0].in_channels, self.extra_conv[0].out_channels)
         ret = self.extra_conv[0].fused(x, self.extra_conv[1], relu=True) if fused else _seq_conv_bn(self.extra_conv, x, True)
         ret = to_dense(ret)
         n, c, d, h, w = ret.shape

@@ -227,3 +227,32 @@ def test_backbone_sparse_half_vs_dense_oracle():
     assert rel_err(bev2.detach().cpu().numpy(), ref.numpy()) < 1e-4
     bev2.square().sum().backward()
     assert torch.isfinite(fin.grad).all() and net.down3[0].weight.grad.abs().sum() > 0
+
+
+def test_backbone_maps_ahead_on_side_stream_is_bitwise_the_same(monkeypatch):
+    """The kernel maps of a frame are built on a side stream while the compute stream is still busy with the
+    previous scale (detstage._MapAhead).  Frames issued back to back without a host synchronisation, each with
+    its own coordinates, must reproduce the single-stream result bit for bit: sites, stage outputs and BEV."""
+    import link_amd as la
+    import link_amd.detstage as D
+    from link_amd.synth import s_nusc
+    torch.manual_seed(2)
+    net = la.SpMiddleResNetFHDELKv3(num_input_features=5).cuda().eval()
+    frames = []
+    for seed in (0, 1, 2):
+        co, fe = s_nusc(seed, n_az=700)                  # ~50k voxels
+        frames.append((torch.from_numpy(fe).cuda(), torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int().cuda()))
+    shape = [1440, 1440, 40]
+    with torch.no_grad():
+        monkeypatch.setattr(D, "MAP_STREAM", False)
+        ref = [net(f, c, 1, shape) for f, c in frames]
+        torch.cuda.synchronize()
+        monkeypatch.setattr(D, "MAP_STREAM", True)
+        for _ in range(3):                                         # no synchronisation between the frames
+            got = [net(f, c, 1, shape) for f, c in frames]
+            torch.cuda.synchronize()
+            for (bev, scales), (rbev, rscales) in zip(got, ref):
+                assert torch.equal(bev, rbev)
+                for k in scales:
+                    assert torch.equal(scales[k].indices, rscales[k].indices)
+                    assert torch.equal(scales[k].features, rscales[k].features)
