@@ -78,7 +78,12 @@ __device__ __forceinline__ void sincos_nocall(float x, float &sn, float &cs) {
 
 // The |x| < 2^15 body of sincos_nocall alone, branch-free (bit-identical there): for code that has already
 // established the range for the whole wave and must stay one basic block.
+__device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs);
+#ifndef LINK_HW_TRIG
+#define LINK_HW_TRIG 0
+#endif
 __device__ __forceinline__ void sincos_small(float x, float &sn, float &cs) {
+  if (LINK_HW_TRIG) { sincos_hw(x, sn, cs); return; }
   const float k = rintf(x * 0.63661977236758134f);
   float r = fmaf(-k, 1.5703125f, x);
   r = fmaf(-k, 4.837512969970703125e-4f, r);
@@ -93,6 +98,21 @@ __device__ __forceinline__ void sincos_small(float x, float &sn, float &cs) {
   const float c0 = (q & 1) ? ps : pc;
   sn = (q & 2) ? -s0 : s0;
   cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Hardware trig (v_sin_f32 / v_cos_f32 take the argument in revolutions): reduction by whole turns -- three-term
+// Cody-Waite 2*pi = 6.28125 + 0x1.fb4p-10 + 0x1.4442d2p-22, exact products under fma for |k| < 2^13 -- then one
+// multiply by 1/(2 pi) and the two transcendental ops: 8 instructions instead of ~25.  Not the libm rounding:
+// max abs error ~3e-7 for |theta| < 3e4 (tools/sintest2.hip), three orders below the 1e-4 relative bar of the
+// path; only the dense-cell kernels may use it (-DLINK_HW_TRIG=1), same range contract as sincos_small.
+__device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs) {
+  const float k = rintf(x * 0.15915494309189535f);
+  float r = fmaf(-k, 6.28125f, x);
+  r = fmaf(-k, 0x1.fb4p-10f, r);
+  r = fmaf(-k, 0x1.4442d2p-22f, r);
+  const float t = r * 0.15915494309189535f;
+  sn = __builtin_amdgcn_sinf(t);
+  cs = __builtin_amdgcn_cosf(t);
 }
 
 template <int LPR>
