@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(512) k_conv_centre_sum(const void *__restrict_
   // trips.  Absent rows read through an out-of-range buffer offset (returns 0): no branch around the loads.
   if (__any(s0 < e0)) {
     #ifndef CP_NQ_SMALL
-#define CP_NQ_SMALL 8
-#define CP_NQ_LARGE 4
+#define CP_NQ_SMALL 4
+#define CP_NQ_LARGE 2
 #endif
     constexpr int NQ = (TO <= 4) ? CP_NQ_SMALL : CP_NQ_LARGE;   // rows in flight per trip (register budget: NQ * TO dwordx4)
     const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(contrib), 0, contrib_bytes, 0x00020000);
@@ -496,7 +496,11 @@ static int launch_centre_sum(const void *feats, int io, const void *w, int centr
   const size_t lds = MM ? (size_t)CO * (CI + 8) * 2 : (size_t)CI * (CO + 4) * sizeof(float);
   // a workgroup of 8 waves finishes 128 voxels; frames too small to give every CU one of those run 4 or 2 waves per
   // workgroup instead (the kernel is a row gather: what counts is how many CUs pull rows, W_k staging is per workgroup)
-  const unsigned nt = n > 262144 ? 512u : (n > 24576 ? 256u : 128u);
+#ifndef CP_NT_BIG
+#define CP_NT_BIG 262144
+#define CP_NT_MID 24576
+#endif
+  const unsigned nt = n > CP_NT_BIG ? 512u : (n > CP_NT_MID ? 256u : 128u);
   const unsigned wgs = (unsigned)((n + nt / 4 - 1) / (nt / 4));
   if (ln_w) {
     if (lds > 64 * 1024)
