@@ -238,6 +238,10 @@ class SparseConv3d(nn.Module):
         return [(a, b, c) for a in range(self.kernel_size[0]) for b in range(self.kernel_size[1])
                 for c in range(self.kernel_size[2])]
 
+    # A strided convolution's table is used once per frame: building its pair plan (two passes + a host round trip)
+    # costs more than the pair-list kernels save over the table kernel.  "auto" / "pairs" select as subm_conv does.
+    form = "table"
+
     def kernel_kio(self) -> torch.Tensor:
         """[taps, Cin, Cout], taps in (a, b, c) row-major order (the table's column order)."""
         ver = (self.weight._version, self.weight.device)
@@ -326,7 +330,8 @@ class SparseConv3d(nn.Module):
     def fused(self, sct, bn, relu=True):
         out_ind, table, _ = self._map(sct)
         sc, sh = fold_batchnorm(bn, self.bias)
-        out = subm_conv_ln_add_relu(sct.features, self.kernel_kio(), table, None, sc, sh, 0.0, None, relu=relu, affine=True)
+        out = subm_conv_ln_add_relu(sct.features, self.kernel_kio(), table, None, sc, sh, 0.0, None, relu=relu, affine=True,
+                                    form=self.form)
         return self._out_tensor(sct, out_ind, out)
 
 
@@ -435,8 +440,9 @@ class SpMiddleResNetFHDELKv3(nn.Module):
                 down = getattr(self, f"down{k}")
                 if maps is not None:
                     with maps:                                         # scale k: output sites + gather table of the strided
-                        out_ind, table, _ = down[0]._map(x)            # convolution, then the new sites' table and both plans
-                        _pair_plan(table, down[0].in_channels, down[0].out_channels)
+                        out_ind, table, _ = down[0]._map(x)            # convolution, then the new sites' table and the plans
+                        if down[0].form != "table":
+                            _pair_plan(table, down[0].in_channels, down[0].out_channels)
                         nbr, _ = _site_table(down[0]._out_tensor(x, out_ind, None))
                         _pair_plan(nbr, down[0].out_channels, down[0].out_channels)
                 x = down[0].fused(x, down[1], relu=True) if fused else _seq_conv_bn(down, x, True)
@@ -449,7 +455,8 @@ class SpMiddleResNetFHDELKv3(nn.Module):
         if maps is not None:
             with maps:
                 _, table, _ = self.extra_conv[0]._map(x)
-                _pair_plan(table, self.extra_conv[0].in_channels, self.extra_conv[0].out_channels)
+                if self.extra_conv[0].form != "table":
+                    _pair_plan(table, self.extra_conv[0].in_channels, self.extra_conv[0].out_channels)
         ret = self.extra_conv[0].fused(x, self.extra_conv[1], relu=True) if fused else _seq_conv_bn(self.extra_conv, x, True)
         ret = to_dense(ret)
         n, c, d, h, w = ret.shape
