@@ -62,6 +62,12 @@ __device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_o
 // ---------------------------------------------------------------------------------------------
 // pre_mix + LayerNorm + modulate + per-cell sum
 // ---------------------------------------------------------------------------------------------
+#ifndef DC_K1_LCAP
+#define DC_K1_LCAP 352
+#endif
+#ifndef DC_K1_NW
+#define DC_K1_NW 4
+#endif
 template <int C, int OP>
 struct dc_k1_cfg {
   static constexpr int T = C / 16;
@@ -72,13 +78,14 @@ struct dc_k1_cfg {
   static constexpr int RGL = P * C / 4;                // lanes holding one row (16 B each)
   static constexpr int RGS = RGL <= 8 ? 8 : (RGL <= 16 ? 16 : (RGL <= 32 ? 32 : 64));
   static constexpr int RG = 64 / RGS;                  // rows summed side by side per wave
-  static constexpr int LCAP = 352;                     // records of one cell range kept in LDS (>= 7^3; two workgroups must fit 160 KB)
+  static constexpr int LCAP = DC_K1_LCAP;                   // records of one cell range kept in LDS (>= 7^3; two workgroups must fit 160 KB)
   static constexpr int W_BYTES = (C * LDW + 2 * C) * 4;
   static constexpr int LIST_OFF = 0;
   static constexpr int SCELL_OFF = LCAP * 16;          // padded cell id of every list slot
   static constexpr int X_OFF = SCELL_OFF + LCAP * 4;
   static constexpr int WAVE_BYTES = X_OFF + 16 * XROW;
-  static constexpr int LDS_BYTES = W_BYTES + 4 * WAVE_BYTES;
+  static constexpr int NW = DC_K1_NW;                  // waves per workgroup (they share one W image)
+  static constexpr int LDS_BYTES = W_BYTES + NW * WAVE_BYTES;
 };
 
 // NB = number of distinct 16-channel theta blocks of a voxel: channel ch uses theta[ch % cg]; when cg is a
@@ -92,7 +99,7 @@ struct dc_k1_cfg {
 #define DC_K1_WAVES 2     /* register budget = 512 / this; LDS (80 KB per workgroup) allows 2 workgroups per CU anyway, and at 3 the tile body spills (A/B: LINK_AMD_CXXFLAGS=-DDC_K1_WAVES=3) */
 #endif
 template <int C, int OP, int NB, bool PIPE>
-__global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsum(
+__global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsum(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
     int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsu
   // the first chunk's cell records and counts are requested BEFORE W is staged: the two latencies overlap
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
   const int Vi = Dx * Dy * Dz * g.dim[3];
-  const int wid = blockIdx.x * 4 + wave;
+  const int wid = blockIdx.x * K::NW + wave;
   const int c_begin = wid * cpw;
   const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
@@ -139,19 +146,20 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsu
     // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
     // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
     constexpr int NF4 = C * C / 4;                     // float4 pieces of W
-    constexpr int NV = (NF4 + 255) / 256;
+    constexpr int NT = 64 * K::NW;
+    constexpr int NV = (NF4 + NT - 1) / NT;
     float4 wv[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-      const int e = (i * 256 + tid) * 4;
-      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[(NF4 % 256 == 0 || e < C * C) ? e : 0]);
+      const int e = (i * NT + tid) * 4;
+      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[(NF4 % NT == 0 || e < C * C) ? e : 0]);
     }
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-      int e = (i * 256 + tid) * 4;
-      if (NF4 % 256 != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
+      int e = (i * NT + tid) * 4;
+      if (NF4 % NT != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
       const int r = e / C, col = e - r * C;
-      *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = (NF4 % 256 == 0 || (i * 256 + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
+      *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = (NF4 % NT == 0 || (i * NT + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
     }
     if (tid < C) ln_lds[tid] = ln_w[tid];
     else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
@@ -480,11 +488,11 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
   int64_t waves = (int64_t)g_k1_wgs * 4;
   int cpw = (int)((vi + waves - 1) / waves);
   if (cpw < 1) cpw = 1;
-  const int64_t wgs = (vi + (int64_t)cpw * 4 - 1) / ((int64_t)cpw * 4);
+  const int64_t wgs = (vi + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
   if (K::LDS_BYTES > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(256), K::LDS_BYTES, st, b->feats,
+  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, b->feats,
                      reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
                      b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr, g_k1_dbg);
   return check_launch("link_dc_premix_modsum");
