@@ -68,6 +68,9 @@ __device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_o
 #ifndef DC_K1_NW
 #define DC_K1_NW 4
 #endif
+#ifndef DC_K1_SUMB
+#define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
+#endif
 template <int C, int OP>
 struct dc_k1_cfg {
   static constexpr int T = C / 16;
@@ -79,7 +82,7 @@ struct dc_k1_cfg {
   static constexpr int RGS = RGL <= 8 ? 8 : (RGL <= 16 ? 16 : (RGL <= 32 ? 32 : 64));
   static constexpr int RG = 64 / RGS;                  // rows summed side by side per wave
   static constexpr int LCAP = DC_K1_LCAP;                   // records of one cell range kept in LDS (>= 7^3; two workgroups must fit 160 KB)
-  static constexpr int W_BYTES = (C * LDW + 2 * C) * 4;
+  static constexpr int W_BYTES = (C * LDW + 2 * C + 4 * C) * 4;   // W, LayerNorm weight / bias, theta weights (w0 | w1 | w2 | alpha per channel)
   static constexpr int LIST_OFF = 0;
   static constexpr int SCELL_OFF = LCAP * 16;          // padded cell id of every list slot
   static constexpr int X_OFF = SCELL_OFF + LCAP * 4;
@@ -113,6 +116,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *w_lds = reinterpret_cast<float *>(smem_raw);
   float *ln_lds = w_lds + C * LDW;
+  float *pw_lds = ln_lds + 2 * C;                      // read per tile: 32 fewer live registers than per-lane copies
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, gq = lane >> 4;
   char *wbase = smem_raw + K::W_BYTES + wave * K::WAVE_BYTES;
@@ -163,6 +167,11 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     }
     if (tid < C) ln_lds[tid] = ln_w[tid];
     else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
+    if (tid < C) {                                     // theta weights of channel tid (channel ch uses theta[ch % cg])
+      const int tc = tid % cg;
+      pw_lds[tid] = w_pos[3 * tc + 0]; pw_lds[C + tid] = w_pos[3 * tc + 1]; pw_lds[2 * C + tid] = w_pos[3 * tc + 2];
+      pw_lds[3 * C + tid] = alpha ? alpha[tc] : 1.0f;
+    }
   }
   if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
@@ -176,16 +185,6 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   const __amdgpu_buffer_rsrc_t r_n = dc_rsrc(cell_n, (uint32_t)(g.vp * 4));
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
-  // theta weights of this lane's channels
-  float w0[NB][4], w1[NB][4], w2[NB][4], al[NB][4];
-#pragma unroll
-  for (int tb = 0; tb < NB; tb++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int tc = (16 * tb + 4 * gq + r) % cg;
-      w0[tb][r] = w_pos[3 * tc + 0]; w1[tb][r] = w_pos[3 * tc + 1]; w2[tb][r] = w_pos[3 * tc + 2];
-      al[tb][r] = alpha ? alpha[tc] : 1.0f;
-    }
   const int rl = lane;                                 // lane's 16-byte piece of an X / S row
   const bool ract = rl < K::RGL;
 
@@ -327,12 +326,16 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
         float th[NB][4];
         bool big = false;
 #pragma unroll
-        for (int tb = 0; tb < NB; tb++)
+        for (int tb = 0; tb < NB; tb++) {
+          const float4 q0 = *reinterpret_cast<const float4 *>(&pw_lds[16 * tb + 4 * gq]);
+          const float4 q1 = *reinterpret_cast<const float4 *>(&pw_lds[C + 16 * tb + 4 * gq]);
+          const float4 q2 = *reinterpret_cast<const float4 *>(&pw_lds[2 * C + 16 * tb + 4 * gq]);
+          const float4 qa = *reinterpret_cast<const float4 *>(&pw_lds[3 * C + 16 * tb + 4 * gq]);
+          th[tb][0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th[tb][1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
+          th[tb][2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th[tb][3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            th[tb][r] = theta_of(x, y, z, w0[tb][r], w1[tb][r], w2[tb][r], al[tb][r]);
-            big |= !(fabsf(th[tb][r]) < 32768.0f);
-          }
+          for (int r = 0; r < 4; r++) big |= !(fabsf(th[tb][r]) < 32768.0f);
+        }
         const bool slow = __any(big);
         const bool more = PIPE && t + 1 < ntile;
         (void)recn;
@@ -421,12 +424,12 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
         const unsigned closes = (unsigned)__ballot(gq == 0 && slot < Ttot && myc != nxc);
         const char *xrow = xbuf + (ract ? rl : 0) * 16;
 #pragma unroll
-        for (int h = 0; h < 16; h += 8) {
-          float4 v[8];
+        for (int h = 0; h < 16; h += DC_K1_SUMB) {
+          float4 v[DC_K1_SUMB];
 #pragma unroll
-          for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const float4 *>(xrow + (h + k) * K::XROW);
+          for (int k = 0; k < DC_K1_SUMB; k++) v[k] = *reinterpret_cast<const float4 *>(xrow + (h + k) * K::XROW);
 #pragma unroll
-          for (int k = 0; k < 8; k++) {
+          for (int k = 0; k < DC_K1_SUMB; k++) {
             if (16 * t + h + k < Ttot) {                // wave-uniform
               acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w;
               if ((closes >> (h + k)) & 1u) {           // wave-uniform
