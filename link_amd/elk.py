@@ -1027,6 +1027,11 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
     # square widths <= 64 keep the table kernel below (measured equal on the kernels, and it needs no second launch for
     # the centre); every other width pair the forward kernels take -- wide and rectangular layers -- runs the pair list
     square_small = cin == cout and cin <= 64 and cin % 4 == 0
+    if (n_out > 0 and len(kernel_shape) == 3 and cin < 16 and not square_small
+            and L.lib().link_conv_pairs_supported(16, cout) and _pair_plan(nbr, 16, cout) is not None):
+        # a network's first layer (4 or 5 point features): rows zero-padded to 16 channels as in the forward
+        # (_pad_in_channels), the gradient of the padding rows dropped
+        return _conv_weight_grad(TF.pad(feats.detach().float(), (0, 16 - cin)), g, nbr, (kvol, 16, cout))[:, :cin].contiguous()
     plan = _pair_plan(nbr, cin, cout) if (n_out > 0 and len(kernel_shape) == 3 and not square_small) else None
     if plan is not None:
         # pair-list form: one MFMA pass over the 128-pair granules + per-offset sums in granule order; the centre

@@ -444,7 +444,8 @@ def test_backend_convolution_names_with_reference_kmap_layout():
     assert rel_err(gw.cpu().numpy(), gw_ref.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,kind", [(128, 128, "lidar"), (32, 64, "lidar"), (64, 128, "uniform"), (128, 64, "dense")])
+@pytest.mark.parametrize("cin,cout,kind", [(128, 128, "lidar"), (32, 64, "lidar"), (64, 128, "uniform"), (128, 64, "dense"),
+                                           (4, 64, "lidar"), (5, 16, "uniform")])     # first layers: rows padded to 16 channels
 def test_pair_list_weight_gradient_wide_and_rectangular(cin, cout, kind):
     """link_conv_pairs_wgrad (widths the table weight-gradient kernel does not take) against fp64 per-offset GEMMs:
     submanifold table (centre offset as identity granules) and a strided table; bitwise reproducible."""
