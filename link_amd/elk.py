@@ -1019,6 +1019,9 @@ class _Tail(torch.autograd.Function):
         return g_x, g_add, tot[:c].view_as(w), tot[c:].view_as(w), None
 
 
+WGRAD_TABLE_SQUARE = True      # square widths <= 64: the table weight-gradient kernel (else the pair list, like every other width)
+
+
 def _conv_weight_grad(feats, g, nbr, kernel_shape):
     """g_w[k] = feats[nbr[:,k]]^T @ g: the MFMA kernel for square widths <= 64, else per offset gather +
     batched library GEMM."""
@@ -1026,7 +1029,7 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
     n_out = nbr.shape[0]
     # square widths <= 64 keep the table kernel below (measured equal on the kernels, and it needs no second launch for
     # the centre); every other width pair the forward kernels take -- wide and rectangular layers -- runs the pair list
-    square_small = cin == cout and cin <= 64 and cin % 4 == 0
+    square_small = WGRAD_TABLE_SQUARE and cin == cout and cin <= 64 and cin % 4 == 0
     if (n_out > 0 and len(kernel_shape) == 3 and cin < 16 and not square_small
             and L.lib().link_conv_pairs_supported(16, cout) and _pair_plan(nbr, 16, cout) is not None):
         # a network's first layer (4 or 5 point features): rows zero-padded to 16 channels as in the forward
@@ -1045,7 +1048,7 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
                                           plan.wg_k.data_ptr(), plan.gran_start.data_ptr(), plan.rows_pad, kvol, n_dir, cin, cout,
                                           part.data_ptr(), gw.data_ptr(), _st()), "link_conv_pairs_wgrad")
         return gw
-    if cin == cout and cin <= 64 and cin % 4 == 0:
+    if cin == cout and cin <= 64 and cin % 4 == 0 and (WGRAD_TABLE_SQUARE or len(kernel_shape) != 3):
         lib = L.lib()
         chunks = int(lib.link_subm_conv_wgrad_chunks())
         nbr_t = getattr(nbr, "_link_t", None)          # transposed table cached on the (kmaps-cached) tensor
