@@ -602,6 +602,26 @@ int link_dc_set_tuning2(int key, int value);
  * deltas: W staging, cell section, pipeline fill, tile bodies, per-cell sums, total, tiles, start); NULL = off. */
 int link_dc_set_debug_buffer(void *device_ptr);
 
+/* =============================================================================================
+ * F. Training-mode BatchNorm statistics over feature rows (row N2; torchsparse/nn/modules/norm.py:10-13 applies
+ * nn.BatchNorm1d to the [N, C] feature matrix after every convolution, linkunet.py:18-92).  Two column reductions at
+ * memory speed with deterministic (fixed-order) double accumulation; the normalisation itself and the input gradient
+ * are one fused multiply-add per element and stay with the caller.  C % 4 == 0, 4 <= C <= 1024.
+ *   partial   f64[link_bn_partial_workgroups(n, c) * 2 * c] scratch
+ *   forward   mean[c], invstd[c] = 1/sqrt(biased var + eps); running_mean / running_var (may be NULL) updated as
+ *             nn.BatchNorm1d does: (1 - momentum) * old + momentum * (mean | unbiased var)
+ *             scale = weight * invstd, shift = bias  (y = (x - mean) * scale + shift)
+ *   backward  sum_g[c] = sum_i g[i], sum_gx[c] = sum_i g[i] * (x[i] - mean) * invstd  (= grad bias, grad weight);
+ *             coef = a | bq | cq with grad_x = a * g + bq * (x - mean) + cq per channel
+ * ============================================================================================= */
+int32_t link_bn_partial_workgroups(int64_t n, int32_t c);
+int link_bn_forward_stats(const float *x, int64_t n, int32_t c, float eps, float momentum, double *partial, float *mean,
+                          float *invstd, float *running_mean, float *running_var, const float *weight /* NULL: 1 */,
+                          const float *bias /* NULL: 0 */, float *scale /* [c] or NULL */, float *shift, void *stream);
+int link_bn_backward_reduce(const float *g, const float *x, const float *mean, const float *invstd, int64_t n, int32_t c,
+                            double *partial, float *sum_g, float *sum_gx, const float *weight /* NULL: 1 */,
+                            float *coef /* [3c] or NULL */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

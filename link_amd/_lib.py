@@ -146,6 +146,11 @@ SIGNATURES = {
     "link_conv_pairs_gemm_amp": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "link_conv_centre_sum_amp": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    "link_bn_partial_workgroups": (c_int32, [c_int64, c_int32]),
+    "link_bn_forward_stats": (c_int, [c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_bn_backward_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -19,8 +19,63 @@ def fapply(input: SparseTensor, fn: Callable[..., torch.Tensor], *args, **kwargs
     return out
 
 
+class _BatchNormTrain(torch.autograd.Function):
+    """Training-mode BatchNorm over feature rows with the statistics on the HIP column-reduction kernels
+    (include/link_amd.h section F): y = (x - mean) * scale + shift with batch statistics, running statistics updated in
+    place; backward: grad_x = a * g + bq * (x - mean) + cq per channel, grad_weight = sum g * xhat, grad_bias = sum g."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        from . import _lib as L
+        n, c = x.shape
+        x = x.contiguous()
+        lib, st = L.lib(), L.current_stream_handle()
+        partial = torch.empty(int(lib.link_bn_partial_workgroups(n, c)) * 2 * c, dtype=torch.float64, device=x.device)
+        vec = torch.empty((4, c), dtype=torch.float32, device=x.device)          # mean | invstd | scale | shift
+        w = weight.detach().contiguous() if weight is not None else None
+        b = bias.detach().contiguous() if bias is not None else None
+        L.check(lib.link_bn_forward_stats(x.data_ptr(), n, c, float(eps), float(momentum), partial.data_ptr(), vec[0].data_ptr(),
+                                          vec[1].data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
+                                          running_var.data_ptr() if running_var is not None else None,
+                                          w.data_ptr() if w is not None else None, b.data_ptr() if b is not None else None,
+                                          vec[2].data_ptr(), vec[3].data_ptr(), st), "link_bn_forward_stats")
+        ctx.save_for_backward(x, vec, *((w,) if w is not None else ()))
+        ctx.partial = partial
+        ctx.has_wb = (weight is not None, bias is not None)
+        return torch.addcmul(vec[3], x - vec[0], vec[2])          # centred first, as torch's kernel: no cancellation
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        x, vec = ctx.saved_tensors[:2]
+        w = ctx.saved_tensors[2] if ctx.has_wb[0] else None
+        n, c = x.shape
+        g = g.contiguous()
+        lib, st = L.lib(), L.current_stream_handle()
+        out = torch.empty((5, c), dtype=torch.float32, device=x.device)           # sum_g | sum_gx | a | bq | cq
+        L.check(lib.link_bn_backward_reduce(g.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), n, c,
+                                            ctx.partial.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                            w.data_ptr() if w is not None else None, out[2].data_ptr(), st),
+                "link_bn_backward_reduce")
+        gx = torch.addcmul(out[4], g, out[2]).addcmul_(x - vec[0], out[3]) if ctx.needs_input_grad[0] else None
+        return gx, (out[1] if ctx.has_wb[0] else None), (out[0] if ctx.has_wb[1] else None), None, None, None, None
+
+
 class BatchNorm(nn.BatchNorm1d):
+    """torchsparse/nn/modules/norm.py:10-13.  Training mode on GPU rows runs the batch statistics through the HIP
+    column reductions (_BatchNormTrain); everything else (eval, CPU, half rows, momentum=None) is nn.BatchNorm1d."""
+
+    hip_stats = True
+
     def forward(self, input: SparseTensor) -> SparseTensor:
+        x = input.feats
+        if (self.hip_stats and self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 1
+                and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024 and self.momentum is not None
+                and (self.weight is None or self.weight.dtype == torch.float32)):
+            rm, rv = (self.running_mean, self.running_var) if self.track_running_stats else (None, None)
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return fapply(input, lambda f: _BatchNormTrain.apply(f, self.weight, self.bias, rm, rv, self.momentum, self.eps))
         return fapply(input, super().forward)
 
 

@@ -69,6 +69,10 @@ def test_argument_validation_without_gpu():
                                         L.IO_BF16, None) == L.LINK_ERR_ARG
     assert lib.link_conv_centre_sum_amp(None, None, 13, None, L.IO_BF16, 0, None, None, 0, 64, 64, None, None, None, 0.0, None, 0, None,
                                         L.IO_BF16, None) == L.LINK_OK
+    assert lib.link_bn_partial_workgroups(100000, 64) >= 1 and lib.link_bn_partial_workgroups(100000, 6) == 0
+    assert lib.link_bn_forward_stats(None, 10, 6, 1e-3, 0.1, None, None, None, None, None, None, None, None, None, None) == L.LINK_ERR_ARG   # C % 4
+    assert lib.link_bn_forward_stats(None, 10, 64, 1e-3, 0.1, None, None, None, None, None, None, None, None, None, None) == L.LINK_ERR_ARG  # null buffers
+    assert lib.link_bn_backward_reduce(None, None, None, None, 0, 64, None, None, None, None, None, None) == L.LINK_ERR_ARG                 # n < 1
     assert lib.link_pair_plan_count(None, 10, 65, None, None, None) == L.LINK_ERR_ARG                     # kvol > 64
     assert lib.link_pair_plan_count(None, 0, 27, None, None, None) == L.LINK_OK
     i3 = ctypes.c_int32 * 3

@@ -144,3 +144,40 @@ def test_fused_conv_bn_relu_equals_module_by_module_and_reference_fixture():
     _, outs = net(la.SparseTensor(f, coords, 1), 3, 2)
     outs[-1].F.square().sum().backward()
     assert torch.isfinite(f.grad).all() and net.stem[0].kernel.grad is not None
+
+
+@pytest.mark.parametrize("n,c", [(113424, 64), (3005, 128), (50, 16), (7, 4), (4001, 48), (2, 256)])
+def test_batchnorm_training_statistics_on_the_hip_reductions(n, c):
+    """link_amd.BatchNorm in training mode (include/link_amd.h section F) against nn.BatchNorm1d in fp64 on the same
+    rows -- output, running statistics, num_batches_tracked and the three gradients over two steps (the second
+    starts from updated running statistics) -- and, loosely, against torch's fp32 kernels (whose fp32 column sums
+    are the less accurate of the two on 100k rows); bitwise reproducible."""
+    import link_amd as la
+    torch.manual_seed(5)
+    x = (torch.randn(n, c) * torch.rand(c) * 3 + torch.randn(c) * 5).cuda()
+    gy = torch.randn(n, c).cuda()
+    coords = torch.zeros(n, 4, dtype=torch.int32).cuda()
+    mk = lambda cls, dt: cls(c, eps=1e-3, momentum=0.01).cuda().to(dt).train()
+    ours, ref, r32 = mk(la.BatchNorm, torch.float32), mk(torch.nn.BatchNorm1d, torch.float64), mk(torch.nn.BatchNorm1d, torch.float32)
+    with torch.no_grad():
+        ours.weight.uniform_(0.5, 1.5); ours.bias.uniform_(-0.5, 0.5)
+        for m in (ref, r32):
+            m.weight.copy_(ours.weight); m.bias.copy_(ours.bias)
+    err = lambda a, b: rel_err(a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy())
+    first = None
+    for step in range(2):
+        xa, xb, xc = x.clone().requires_grad_(True), x.double().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb, yc = ours(la.SparseTensor(xa, coords, 1)).F, ref(xb), r32(xc)
+        ya.backward(gy); yb.backward(gy.double()); yc.backward(gy)
+        first = ya.detach().clone() if first is None else first
+        assert err(ya, yb) < 5e-6 and err(xa.grad, xb.grad) < 1e-5
+        assert err(ours.weight.grad, ref.weight.grad) < 1e-5 and err(ours.bias.grad, ref.bias.grad) < 1e-5
+        assert err(ours.running_mean, ref.running_mean) < 1e-6 and err(ours.running_var, ref.running_var) < 1e-5
+        assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        assert err(ya, yc) < 1e-4 and err(xa.grad, xc.grad) < 1e-3 and err(ours.weight.grad, r32.weight.grad) < 1e-3
+        for m in (ours, ref, r32):
+            m.zero_grad()
+    again = mk(la.BatchNorm, torch.float32)
+    with torch.no_grad():
+        again.weight.copy_(ours.weight); again.bias.copy_(ours.bias)
+    assert torch.equal(again(la.SparseTensor(x, coords, 1)).F, first)
