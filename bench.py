@@ -470,6 +470,11 @@ def main():
             L.lib().link_dc_set_tuning2(3, int(zs) if zs is not None else (0 if ns == 1 else 2))
             if os.environ.get("LINK_BENCH_K2_SPLIT") is not None:
                 L.lib().link_dc_set_tuning2(6, int(os.environ["LINK_BENCH_K2_SPLIT"]))
+            # CU sharing with frames in flight: 2 KB of extra dynamic LDS on the fused pre_mix kernel -- two of its workgroups
+            # then no longer fit one CU, one of them plus a gather workgroup of another frame do (82.9 + 79.0 KB), and
+            # that mix is the faster one (44.1 -> 42.8 us/frame; padding the gather kernel instead costs 8 us)
+            L.lib().link_dc_set_tuning2(7, int(os.environ.get("LINK_BENCH_K1_PAD", "2048")) if ns > 1 else 0)
+            L.lib().link_dc_set_tuning2(8, int(os.environ.get("LINK_BENCH_K2_PAD", "0")) if ns > 1 else 0)
 
     def timed(k, build_index=True, ns=NS):
         """EXACTLY k steps (frames), round-robin over `ns` streams; barrier + synchronize on both sides."""

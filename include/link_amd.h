@@ -595,7 +595,9 @@ int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const l
                                 void *stream);
 /* Tuning hooks (bench only).  link_dc_set_tuning: key 0 premix workgroups, 1 modsum workgroups, 2 gather
  * z-splits, 3 kernel selection (bit0 fused pre_mix+modsum, bit1 dense-cell demod kernel, bit2 fused gather+demod; default 7).
- * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups, 3 z-splits of the fused gather+demod. */
+ * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups, 3 z-splits of the fused gather+demod,
+ * 4 single-tile gather, 5 pipelined pre_mix tiles, 6 producer/consumer gather, 7 / 8 extra dynamic LDS bytes of the fused pre_mix /
+ * gather kernel (CU-sharing policy when several frames are in flight). */
 int link_dc_set_tuning(int key, int value);
 int link_dc_set_tuning2(int key, int value);
 /* Bench only: device buffer u64[waves*8] that the fused kernel fills with per-wave phase timings (s_memtime

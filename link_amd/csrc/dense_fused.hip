@@ -25,6 +25,8 @@ int g_demod_wgs = 1024;
 int g_k2_zsplit = 0;
 int g_k2_single = 0;
 int g_k1_pipe = 0;
+int g_k1_lds_pad = 0;       // extra dynamic LDS of the fused pre_mix kernel / the split gather kernel (CU sharing policy, bench.py)
+int g_k2_lds_pad = 0;
 int g_k2_split = 1;         // producer / consumer form of the fused gather + de-modulate kernel (where two workgroups fit a CU)
 unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
 }
@@ -59,6 +61,8 @@ extern "C" int link_dc_set_tuning2(int key, int value) {
     case 4: g_k2_single = value; break;
     case 5: g_k1_pipe = value; break;
     case 6: g_k2_split = value; break;
+    case 7: g_k1_lds_pad = value <= 16384 ? value : 16384; break;
+    case 8: g_k2_lds_pad = value <= 4096 ? value : 4096; break;
     default: return LINK_ERR_ARG;
   }
   return LINK_OK;

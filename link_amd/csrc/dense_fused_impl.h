@@ -10,7 +10,7 @@
 #include "dense_gather.h"
 
 namespace link {
-extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe, g_k2_split;
+extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe, g_k2_split, g_k1_lds_pad, g_k2_lds_pad;
 extern unsigned long long *g_k1_dbg;
 }
 
@@ -62,11 +62,29 @@ __device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_o
 // ---------------------------------------------------------------------------------------------
 // pre_mix + LayerNorm + modulate + per-cell sum
 // ---------------------------------------------------------------------------------------------
+// x = hi + lo, hi = fp16(x) (round to nearest), lo = fp16(x - hi): four values -> two packed operands
+typedef _Float16 dc_h4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dc_split4(const float4 &v, uint2 &hi, uint2 &lo) {
+  const dc_h4v h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  const dc_h4v l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z), (_Float16)(v.w - (float)h.w)};
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+__device__ __forceinline__ floatx4 dc_mfma_f16(uint2 a, uint2 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(dc_h4v, a), __builtin_bit_cast(dc_h4v, b), c, 0, 0, 0);
+}
+
 #ifndef DC_K1_LCAP
 #define DC_K1_LCAP 352
 #endif
 #ifndef DC_K1_NW
 #define DC_K1_NW 4
+#endif
+#ifndef DC_K1_ABL
+#define DC_K1_ABL 0      /* ablation builds for tools/ab_bench.sh (wrong results!): 1 no MFMA, 2 no sincos, 4 no per-cell sums, 8 rows from one address */
+#endif
+#ifndef DC_K1_SPLIT
+#define DC_K1_SPLIT 1    /* pre_mix contraction as an fp16 hi/lo split on the f16 matrix cores (see mfma_tile); 0 = v_mfma_f32_16x16x4_f32 */
 #endif
 #ifndef DC_K1_SUMB
 #define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
@@ -82,7 +100,9 @@ struct dc_k1_cfg {
   static constexpr int RGS = RGL <= 8 ? 8 : (RGL <= 16 ? 16 : (RGL <= 32 ? 32 : 64));
   static constexpr int RG = 64 / RGS;                  // rows summed side by side per wave
   static constexpr int LCAP = DC_K1_LCAP;                   // records of one cell range kept in LDS (>= 7^3; two workgroups must fit 160 KB)
-  static constexpr int W_BYTES = (C * LDW + 2 * C + 4 * C) * 4;   // W, LayerNorm weight / bias, theta weights (w0 | w1 | w2 | alpha per channel)
+  static constexpr int LDH = 2 * C + 8;                // fp16 image of W, row co = [hi(C) | lo(C) | pad]: 4 * odd dwords, conflict-free ds_read_b64
+  static constexpr int WIMG_BYTES = DC_K1_SPLIT ? C * LDH * 2 : C * LDW * 4;   // same size as the fp32 image: two workgroups per CU
+  static constexpr int W_BYTES = WIMG_BYTES + (2 * C + 4 * C) * 4;   // W, LayerNorm weight / bias, theta weights (w0 | w1 | w2 | alpha per channel)
   static constexpr int LIST_OFF = 0;
   static constexpr int SCELL_OFF = LCAP * 16;          // padded cell id of every list slot
   static constexpr int X_OFF = SCELL_OFF + LCAP * 4;
@@ -115,7 +135,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   constexpr int T = K::T, P = K::P, LDW = K::LDW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *w_lds = reinterpret_cast<float *>(smem_raw);
-  float *ln_lds = w_lds + C * LDW;
+  float *ln_lds = reinterpret_cast<float *>(smem_raw + K::WIMG_BYTES);
   float *pw_lds = ln_lds + 2 * C;                      // read per tile: 32 fewer live registers than per-lane copies
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, gq = lane >> 4;
@@ -146,6 +166,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     rf2 = slots[(int64_t)pc_f * DC_INL + 2]; rf3 = slots[(int64_t)pc_f * DC_INL + 3];
     nv_f = (int)csrc[pc_f];
   }
+  bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
   {                                                    // stage W and the LayerNorm parameters
     // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
     // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
@@ -163,7 +184,18 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
       int e = (i * NT + tid) * 4;
       if (NF4 % NT != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
       const int r = e / C, col = e - r * C;
-      *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = (NF4 % NT == 0 || (i * NT + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
+      const float4 wq = (NF4 % NT == 0 || (i * NT + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
+      if constexpr (DC_K1_SPLIT) {
+        // w = hi + lo with hi = fp16(w), lo = fp16(w - hi): 22 mantissa bits, exact products on the f16 matrix cores
+        uint2 hi, lo;
+        dc_split4(wq, hi, lo);
+        unsigned short *wh = reinterpret_cast<unsigned short *>(smem_raw);
+        *reinterpret_cast<uint2 *>(&wh[r * K::LDH + col]) = hi;
+        *reinterpret_cast<uint2 *>(&wh[r * K::LDH + C + col]) = lo;
+        w_big |= !(fmaxf(fmaxf(fabsf(wq.x), fabsf(wq.y)), fmaxf(fabsf(wq.z), fabsf(wq.w))) < 32768.0f);
+      } else {
+        *reinterpret_cast<float4 *>(&w_lds[r * LDW + col]) = wq;
+      }
     }
     if (tid < C) ln_lds[tid] = ln_w[tid];
     else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
@@ -177,7 +209,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
-  __syncthreads();
+  w_big = DC_K1_SPLIT ? __syncthreads_or(w_big) != 0 : (__syncthreads(), false);
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
   if (c_begin >= c_end) return;
   const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * K::RB));
@@ -276,17 +308,60 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
       rr = list[sl];
 #pragma unroll
       for (int tt = 0; tt < T; tt++)
-        ff[tt] = io_ld4(feats, (int64_t)rr.w * C + 16 * tt + 4 * gq);
+        ff[tt] = io_ld4(feats, (int64_t)((DC_K1_ABL & 8) ? li : rr.w) * C + 16 * tt + 4 * gq);
     };
+    // pre_mix contraction D[co][voxel] = sum_ci W[co][ci] x[voxel][ci].  DC_K1_SPLIT: both operands as fp16 hi + lo
+    // (22 mantissa bits each), products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 -- exact products, fp32
+    // accumulation, the dropped lo*lo term is 2^-22 relative -- 48 matrix instructions of 4 passes instead of 64 of 8
+    // (the matrix pipe's time is fully exposed in this kernel: without it the launch is 6.8 us shorter).  fp16 rows
+    // have lo = 0: two products.  Values outside the fp16 range (|x| or |w| >= 2^15: never on LayerNorm-ed networks)
+    // take the fp32 instruction with W read from global memory -- slow, exact, wave-uniform.
     auto mfma_tile = [&](const float4 (&ff)[T], floatx4 (&cc)[T]) {
+      if (DC_K1_ABL & 1) {
+#pragma unroll
+        for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){ff[tp].x, ff[tp].y, ff[tp].z, ff[tp].w};
+        return;
+      }
 #pragma unroll
       for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (DC_K1_SPLIT) {
+        uint2 bh[T], bl[T];
+        float mx = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < T; tt++) {
+          dc_split4(ff[tt], bh[tt], bl[tt]);
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ff[tt].x), fabsf(ff[tt].y)), fmaxf(fabsf(ff[tt].z), fabsf(ff[tt].w))));
+        }
+        if (__builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
+          const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
+#pragma unroll
+          for (int tt = 0; tt < T; tt++) {
+            uint2 ah[T], al[T];
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) {
+              ah[tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + 16 * tt + 4 * gq]);
+              al[tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + C + 16 * tt + 4 * gq]);
+            }
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(al[tp], bh[tt], cc[tp]);
+            if constexpr (IO != 1) {                      // fp16 rows: lo = 0 exactly
+#pragma unroll
+              for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(ah[tp], bl[tt], cc[tp]);
+            }
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(ah[tp], bh[tt], cc[tp]);
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int tt = 0; tt < T; tt++) {
         float4 a[T];
 #pragma unroll
-        for (int tp = 0; tp < T; tp++)
-          a[tp] = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * tt + 4 * gq]);
+        for (int tp = 0; tp < T; tp++) {
+          if constexpr (DC_K1_SPLIT) a[tp] = *reinterpret_cast<const float4 *>(&w_pre[(16 * tp + li) * C + 16 * tt + 4 * gq]);
+          else a[tp] = *reinterpret_cast<const float4 *>(&w_lds[(16 * tp + li) * LDW + 16 * tt + 4 * gq]);
+        }
 #pragma unroll
         for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].x, ff[tt].x, cc[tp], 0, 0, 0);
 #pragma unroll
@@ -348,7 +423,8 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
           for (int tb = 0; tb < NB; tb++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              if constexpr (SLOW) sincos_nocall(th[tb][r], sn[tb][r], cs[tb][r]);
+              if (DC_K1_ABL & 2) { sn[tb][r] = th[tb][r]; cs[tb][r] = 1.0f - th[tb][r]; }
+              else if constexpr (SLOW) sincos_nocall(th[tb][r], sn[tb][r], cs[tb][r]);
               else sincos_small(th[tb][r], sn[tb][r], cs[tb][r]);
             }
           // LayerNorm over the voxel's C channels: 16 in-lane values + the 4 lane groups
@@ -412,7 +488,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if (PHASE != 2 && dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_body += tqb - tqa; tqa = tqb; tq_tiles++; }
-      if (PHASE == 1) return;
+      if (PHASE == 1 || (DC_K1_ABL & 4)) return;
       // ---- per-cell sums of this tile: ONE stream over the 16 rows in slot order (ascending voxel id inside a
       // cell), every lane owning 16 bytes of the row; a row that closes its cell (the next slot belongs to
       // another cell) is followed by the cell's S row store.  All rows are requested up front, the close
@@ -492,10 +568,13 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
   int cpw = (int)((vi + waves - 1) / waves);
   if (cpw < 1) cpw = 1;
   const int64_t wgs = (vi + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
-  if (K::LDS_BYTES > 64 * 1024)
+  // g_k1_lds_pad: extra dynamic LDS requested on purpose (frames in flight): a workgroup that cannot share its CU with a
+  // second one of its own kind shares it with the other frame's gather kernel instead -- the better mix (bench.py)
+  const int lds_k1 = K::LDS_BYTES + g_k1_lds_pad <= 160 * 1024 ? K::LDS_BYTES + g_k1_lds_pad : K::LDS_BYTES;
+  if (lds_k1 > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, PIPE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, b->feats,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_k1);
+  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(64 * K::NW), lds_k1, st, b->feats,
                      reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
                      b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr, g_k1_dbg);
   return check_launch("link_dc_premix_modsum");
@@ -1380,8 +1459,8 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
 #define LINK_K2S(PP, DD)                                                                                              \
   do {                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_split<OP, R, PP, DD>),                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES);                       \
-    hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES, st, \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES + g_k2_lds_pad);        \
+    hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES + g_k2_lds_pad, st, \
                        b->S, b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w, \
                        b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, g_k2_single);     \
   } while (0)
