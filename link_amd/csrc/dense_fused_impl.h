@@ -73,6 +73,14 @@ __device__ __forceinline__ void dc_split4(const float4 &v, uint2 &hi, uint2 &lo)
 __device__ __forceinline__ floatx4 dc_mfma_f16(uint2 a, uint2 b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(dc_h4v, a), __builtin_bit_cast(dc_h4v, b), c, 0, 0, 0);
 }
+// two 16-channel blocks in one instruction (gfx950: v_mfma_f32_16x16x32_f16, K = 32 in the passes of K = 16): the
+// instruction's k = 8g + j is mapped to channel 4g + j of the first block for j < 4 and of the second for j >= 4 --
+// the same for both operands, so any such permutation of k is correct
+typedef _Float16 dc_h8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ floatx4 dc_mfma_f16x2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, floatx4 c) {
+  const uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y), b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dc_h8v, a), __builtin_bit_cast(dc_h8v, b), c, 0, 0, 0);
+}
 
 #ifndef DC_K1_LCAP
 #define DC_K1_LCAP 352
@@ -85,6 +93,9 @@ __device__ __forceinline__ floatx4 dc_mfma_f16(uint2 a, uint2 b, floatx4 c) {
 #endif
 #ifndef DC_K1_SPLIT
 #define DC_K1_SPLIT 1    /* pre_mix contraction as an fp16 hi/lo split on the f16 matrix cores (see mfma_tile); 0 = v_mfma_f32_16x16x4_f32 */
+#endif
+#ifndef DC_K1_MFMA32
+#define DC_K1_MFMA32 1   /* pairs of 16-channel blocks on v_mfma_f32_16x16x32_f16 */
 #endif
 #ifndef DC_K1_SUMB
 #define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
@@ -334,6 +345,28 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
         }
         if (__builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
           const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
+          if constexpr (DC_K1_MFMA32 && T % 2 == 0) {
+#pragma unroll
+            for (int tt = 0; tt < T; tt += 2) {
+              uint2 ah[2][T], al[2][T];
+#pragma unroll
+              for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int tp = 0; tp < T; tp++) {
+                  ah[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + 16 * (tt + h) + 4 * gq]);
+                  al[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + C + 16 * (tt + h) + 4 * gq]);
+                }
+#pragma unroll
+              for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(al[0][tp], al[1][tp], bh[tt], bh[tt + 1], cc[tp]);
+              if constexpr (IO != 1) {
+#pragma unroll
+                for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bl[tt], bl[tt + 1], cc[tp]);
+              }
+#pragma unroll
+              for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bh[tt], bh[tt + 1], cc[tp]);
+            }
+            return;
+          }
 #pragma unroll
           for (int tt = 0; tt < T; tt++) {
             uint2 ah[T], al[T];
