@@ -469,6 +469,12 @@ int link_conv_centre_sum_io(const void *feats, const float *w, int32_t centre, c
                             const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin, int32_t cout,
                             const float *bias, const float *ln_w, const float *ln_b, float eps, const void *addend,
                             int32_t relu, void *out, int32_t io_dtype, void *stream);
+/* fp32 rows on the f16 matrix cores: link_conv_pairs_gemm with both operands as fp16 hi + lo pairs (22 mantissa bits,
+ * exact products, fp32 accumulation; three 4-pass matrix instructions per 16 input channels instead of four 8-pass).
+ * ws = the weights split and transposed per offset, fp16 [kvol][cout][hi(cin) | lo(cin)]; w = the fp32 weights (used when a
+ * value lies outside the fp16 range); w_big = device flag, non-zero when some |w| >= 2^15.  Inference form. */
+int link_conv_pairs_gemm_split(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad, const void *ws,
+                               const float *w, const int32_t *w_big, int32_t cin, int32_t cout, float *contrib, void *stream);
 /* AMP form of the two MFMA entries: the rows AND the weights are 16-bit (io_dtype = LINK_IO_F16 / LINK_IO_BF16 for both;
  * custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18, rounds the kernel together with the features), the
  * products run on the f16 / bf16 matrix cores with fp32 accumulation; contribution rows, statistics and epilogue

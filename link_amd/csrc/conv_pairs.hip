@@ -179,6 +179,90 @@ __global__ void __launch_bounds__(512) k_conv_pairs_gemm_h(const unsigned short 
   }
 }
 
+// fp32 rows on the f16 matrix cores: x = hi + lo and w = hi + lo as fp16 pairs (22 mantissa bits), products
+// hi*hi + hi*lo + lo*hi with fp32 accumulation -- exact products, the dropped lo*lo term is 2^-22 relative -- three
+// 4-pass instructions per 16 input channels instead of four 8-pass ones (the fp32 form is bound by the matrix pipe from
+// C = 64 up).  The weights arrive split and transposed, ws[k][co][hi(CI) | lo(CI)] (fp16, cached per parameter version by
+// the host side), with a device flag that is non-zero when some |w| >= 2^15; that, or a row value outside the range,
+// sends the wave through the fp32 instruction with W from global memory (never on normalised networks).
+template <int CI, int CO>
+__global__ void __launch_bounds__(512) k_conv_pairs_gemm_split(const float *__restrict__ feats,
+                                                               const int32_t *__restrict__ pair_in,
+                                                               const int32_t *__restrict__ wg_k,
+                                                               const unsigned short *__restrict__ ws,
+                                                               const float *__restrict__ w, const int32_t *__restrict__ w_big,
+                                                               float *__restrict__ contrib) {
+  constexpr int TI = CI / 16, TO = CO / 16, LDH = 2 * CI + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short *w_lds = reinterpret_cast<unsigned short *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = wg_k[blockIdx.x];
+  if (k < 0) return;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int j0 = pair_in[row0 + li];
+  const bool wbig = w_big[0] != 0;
+  float4 f0[TI];
+  {
+    const float *fr = feats + (int64_t)(j0 < 0 ? 0 : j0) * CI + 4 * g;
+#pragma unroll
+    for (int t = 0; t < TI; t++) f0[t] = *reinterpret_cast<const float4 *>(fr + 16 * t);
+  }
+  const unsigned short *wk = ws + (int64_t)k * CO * 2 * CI;
+  for (int e = tid * 8; e < CO * 2 * CI; e += 512 * 8) {
+    const int r = e / (2 * CI), col = e - r * (2 * CI);
+    *reinterpret_cast<uint4 *>(&w_lds[r * LDH + col]) = *reinterpret_cast<const uint4 *>(&wk[e]);
+  }
+  __syncthreads();
+  if (__all(j0 < 0)) return;                           // granule padding
+  floatx4 a0[TO];
+#pragma unroll
+  for (int tp = 0; tp < TO; tp++) a0[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  uint2 bh[TI], bl[TI];
+  float mx = 0.f;
+#pragma unroll
+  for (int t = 0; t < TI; t++) {
+    const cp_h4 h = {(_Float16)f0[t].x, (_Float16)f0[t].y, (_Float16)f0[t].z, (_Float16)f0[t].w};
+    const cp_h4 l = {(_Float16)(f0[t].x - (float)h.x), (_Float16)(f0[t].y - (float)h.y), (_Float16)(f0[t].z - (float)h.z),
+                     (_Float16)(f0[t].w - (float)h.w)};
+    bh[t] = __builtin_bit_cast(uint2, h);
+    bl[t] = __builtin_bit_cast(uint2, l);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(f0[t].x), fabsf(f0[t].y)), fmaxf(fabsf(f0[t].z), fabsf(f0[t].w))));
+  }
+  if (__builtin_expect(!(wbig || __any(!(mx < 32768.0f))), 1)) {
+#pragma unroll
+    for (int t = 0; t < TI; t++) {
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        const uint2 ah = *reinterpret_cast<const uint2 *>(&w_lds[(16 * tp + li) * LDH + 16 * t + 4 * g]);
+        const uint2 al = *reinterpret_cast<const uint2 *>(&w_lds[(16 * tp + li) * LDH + CI + 16 * t + 4 * g]);
+        a0[tp] = cp_mfma16<false>(al, bh[t], a0[tp]);
+        a0[tp] = cp_mfma16<false>(ah, bl[t], a0[tp]);
+        a0[tp] = cp_mfma16<false>(ah, bh[t], a0[tp]);
+      }
+    }
+  } else {
+    const float *wf = w + (int64_t)k * CI * CO;
+#pragma unroll
+    for (int t = 0; t < TI; t++) {
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        const float *wr = wf + (16 * t + 4 * g) * CO + 16 * tp + li;
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], f0[t].x, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[CO], f0[t].y, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2 * CO], f0[t].z, a0[tp], 0, 0, 0);
+        a0[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3 * CO], f0[t].w, a0[tp], 0, 0, 0);
+      }
+    }
+  }
+  float *o0 = contrib + (row0 + li) * CO + 4 * g;
+  if (j0 >= 0) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++)
+      *reinterpret_cast<float4 *>(o0 + 16 * tp) = make_float4(a0[tp][0], a0[tp][1], a0[tp][2], a0[tp][3]);
+  }
+}
+
 // Submanifold tables: the centre offset's pairs are the identity, so its GEMM needs no gather and no
 // contribution rows -- this kernel runs it per tile of 16 output voxels and finishes the voxel in the MFMA
 // accumulator layout (a lane holds 4 channels x CO/16 tiles of ONE voxel): + the voxel's CSR rows of the other
@@ -545,6 +629,34 @@ extern "C" int link_conv_centre_sum_io(const void *feats, const float *w, int32_
   LINK_CC(16, 32); LINK_CC(32, 16); LINK_CC(32, 64); LINK_CC(64, 32); LINK_CC(64, 128); LINK_CC(128, 64);
   LINK_CC(16, 64); LINK_CC(64, 16);
 #undef LINK_CC
+  return LINK_ERR_ARG;
+}
+
+template <int CI, int CO>
+static int launch_pairs_gemm_split(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t granules,
+                                   const void *ws, const float *w, const int32_t *w_big, float *contrib, hipStream_t st) {
+  const size_t lds = (size_t)CO * (2 * CI + 8) * 2;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_pairs_gemm_split<CI, CO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_conv_pairs_gemm_split<CI, CO>), dim3((unsigned)granules), dim3(512), lds, st, feats, pair_in, wg_k,
+                     reinterpret_cast<const unsigned short *>(ws), w, w_big, contrib);
+  return check_launch("link_conv_pairs_gemm_split");
+}
+
+extern "C" int link_conv_pairs_gemm_split(const float *feats, const int32_t *pair_in, const int32_t *wg_k, int64_t rows_pad,
+                                          const void *ws, const float *w, const int32_t *w_big, int32_t cin, int32_t cout,
+                                          float *contrib, void *stream) {
+  if (rows_pad < 0 || (rows_pad & 127) || rows_pad >= (1LL << 31) || !link_conv_pairs_supported(cin, cout)) return LINK_ERR_ARG;
+  if (rows_pad == 0) return LINK_OK;
+  if (!feats || !pair_in || !wg_k || !ws || !w || !w_big || !contrib) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const int64_t gr = rows_pad / 128;
+#define LINK_CP(I, O) if (cin == I && cout == O) return launch_pairs_gemm_split<I, O>(feats, pair_in, wg_k, gr, ws, w, w_big, contrib, st)
+  LINK_CP(16, 16); LINK_CP(32, 32); LINK_CP(64, 64); LINK_CP(128, 128);
+  LINK_CP(16, 32); LINK_CP(32, 16); LINK_CP(32, 64); LINK_CP(64, 32); LINK_CP(64, 128); LINK_CP(128, 64);
+  LINK_CP(16, 64); LINK_CP(64, 16);
+#undef LINK_CP
   return LINK_ERR_ARG;
 }
 

@@ -854,7 +854,27 @@ def _amp_weights(w: torch.Tensor, dtype) -> torch.Tensor:
     return hit[1]
 
 
-def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False, w_key=None):
+SPLIT_MFMA = True    # fp32 rows, inference forms: the pair GEMM as an fp16 hi/lo split on the f16 matrix cores
+
+
+def _split_weights(w: torch.Tensor):
+    """w [K, cin, cout] fp32 -> (fp16 [K, cout, 2 cin] = hi | lo per output channel, int32[1] flag: some |w| >= 2^15),
+    cached on the long-lived fp32 tensor; no host synchronisation."""
+    hit = getattr(w, "_link_split", None)
+    ver = (w._version, w.data_ptr())
+    if hit is None or hit[0] != ver:
+        wt = w.detach().float().transpose(1, 2).contiguous()
+        hi = wt.half()
+        lo = (wt - hi.float()).half()
+        hit = (ver, torch.cat([hi, lo], dim=2).contiguous(), (wt.abs().max() >= 32768.0).to(torch.int32).reshape(1))
+        try:
+            w._link_split = hit
+        except AttributeError:
+            pass
+    return hit[1], hit[2]
+
+
+def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, addend=None, relu=False, w_key=None, split=False):
     """f / addend / out rows share one dtype (fp32, fp16 or bf16: link_conv_*_io); everything else fp32.  Half rows
     with AMP_MFMA: weights rounded to the row type (cached on `w_key`, the caller's long-lived weight tensor)."""
     lib, st = L.lib(), _st()
@@ -867,6 +887,11 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
         w = _amp_weights(w_key if w_key is not None and w_key.shape == w.shape else w, f.dtype)
         L.check(lib.link_conv_pairs_gemm_amp(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
                                              w.data_ptr(), cin, cout, contrib.data_ptr(), cdt, st), "link_conv_pairs_gemm_amp")
+    elif split and SPLIT_MFMA and io == L.IO_F32 and cin >= 32:
+        ws, big = _split_weights(w_key if w_key is not None and w_key.shape == w.shape else w)
+        L.check(lib.link_conv_pairs_gemm_split(f.data_ptr(), plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+                                               ws.data_ptr(), w.data_ptr(), big.data_ptr(), cin, cout, contrib.data_ptr(), st),
+                "link_conv_pairs_gemm_split")
     else:
         L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
                                             w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
@@ -974,7 +999,7 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     if plan is not None:
         add = addend.detach().contiguous().to(f.dtype) if addend is not None else None
         return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device),
-                           ln=(lw, lb, eps), addend=add, relu=flags, w_key=kernel)
+                           ln=(lw, lb, eps), addend=add, relu=flags, w_key=kernel, split=True)
     f = f.float()                                      # the table kernel is fp32: half rows are widened here
     add = addend.detach().contiguous().float() if addend is not None else None
     out = torch.empty((n, cout), dtype=torch.float32, device=feats.device)

@@ -302,6 +302,7 @@ def test_pair_form_half_rows(cin, cout, kind, n, dtype, monkeypatch):
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     lw, lb = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda()
     add = torch.randn(n, cout, generator=g).to(dtype).cuda()
+    monkeypatch.setattr(E, "SPLIT_MFMA", False)        # the fp32 comparison runs use the fp32 matrix instruction, like the _io kernels
     for amp, c16 in ((False, False), (True, False), (True, True)):     # c16: contribution rows in the row type too
         monkeypatch.setattr(E, "AMP_MFMA", amp)
         monkeypatch.setattr(E, "AMP_CONTRIB16", (dtype,) if c16 else ())
@@ -471,3 +472,33 @@ def test_pair_list_weight_gradient_wide_and_rectangular(cin, cout, kind):
     idx = torch.where(km.nbr_down < 0, torch.full_like(km.nbr_down, n), km.nbr_down).long()
     ref = torch.stack([pad[idx[:, k]].t() @ gd.double() for k in range(8)])
     assert rel_err(a.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,kind,n", [(64, 64, "lidar", 20000), (128, 128, "dense", 1500), (32, 64, "uniform", 9000), (128, 64, "lidar", 4000)])
+def test_pair_gemm_fp16_split_of_fp32_rows(cin, cout, kind, n, monkeypatch):
+    """link_conv_pairs_gemm_split (fp32 rows and weights as fp16 hi + lo pairs on the f16 matrix cores; inference forms)
+    against the fp32-instruction kernel: same result to fp32 rounding; values outside the fp16 range -- a row entry
+    of 1e5, a weight of 4e4 -- take the fp32 instruction inside the kernel and stay exact."""
+    import link_amd as la
+    import link_amd.elk as E
+    from link_amd.elk import subm_conv_ln_add_relu
+    coords = s_uniform(n, grid=96, seed=5) if kind == "uniform" else _frame(kind, n, 1)
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(n, cin, generator=g).cuda()
+    conv = la.Conv3d(cin, cout, kernel_size=3).cuda()
+    nbr, order = conv._neighbor_table(la.SparseTensor(feats, coords.cuda(), 1))
+    sc, sh = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+
+    def run(f, w, split):
+        monkeypatch.setattr(E, "SPLIT_MFMA", split)
+        return subm_conv_ln_add_relu(f, w, nbr, order, sc, sh, 0.0, None, relu=False, form="pairs", affine=True)
+
+    w = conv.kernel.detach().clone()
+    a, b = run(feats, w, True), run(feats, w, False)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    assert torch.equal(a, run(feats, w, True))
+    big_f = feats.clone(); big_f[n // 2, 3] = 1.0e5                      # one row outside the range: its wave falls back
+    assert rel_err(run(big_f, w, True).cpu().numpy(), run(big_f, w, False).cpu().numpy()) < 1e-6
+    big_w = w.clone(); big_w[5, 1, 2] = 4.0e4                            # a weight outside the range: every wave falls back
+    assert rel_err(run(feats, big_w, True).cpu().numpy(), run(feats, big_w, False).cpu().numpy()) < 1e-6
