@@ -160,3 +160,30 @@ def test_dense_half_rows(dtype, tol_round, tol_oracle, C, groups, baseop, s, r, 
     with torch.no_grad():
         core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None, C // groups, 1.0)
     assert core.dtype == dtype and rel_err(core.float().cpu().numpy(), o32.cpu().numpy()) < tol_round
+
+
+@pytest.mark.parametrize("C,what", [(64, "rows"), (32, "rows"), (64, "weights"), (16, "weights")])
+def test_dense_premix_values_outside_the_fp16_split_range(C, what):
+    """The fused pre_mix kernel multiplies as an fp16 hi + lo split; feature rows or pre_mix weights with
+    |value| >= 2^15 must take its fp32-instruction path and still agree with the general layout (fp32 MFMA) and the
+    oracle.  Rows: a third of the voxels scaled by 1e5 (LayerNorm removes the scale from the result's size); weights: one
+    entry of 5e4."""
+    import link_amd as la
+    torch.manual_seed(11)
+    groups, baseop, s, r, grid, n = 2, "cos", 7, 3, 64, 6000
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    coords = s_uniform(n, grid=grid, seed=2).cuda()
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
+    if what == "rows":
+        feats[::3] *= 1.0e5
+    else:
+        with torch.no_grad():
+            blk.pre_mix[0].weight[3, 5] = 5.0e4
+    bounds = ((0, 0, 0, 0), (grid - 1, grid - 1, grid - 1, 0))
+    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    general = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "general")
+    od, og = dense.run(feats, coords).clone(), general.run(feats, coords).clone()
+    assert torch.isfinite(od).all()
+    assert rel_err(od.cpu().numpy(), og.cpu().numpy()) < 2e-5
+    assert rel_err(od.cpu().numpy(), _oracle(blk, feats, coords, s, r, baseop, groups)) < 1e-4
+    assert torch.equal(od, dense.run(feats, coords))
