@@ -94,6 +94,9 @@ __device__ __forceinline__ floatx4 dc_mfma_f16x2(uint2 a0, uint2 a1, uint2 b0, u
 #ifndef DC_K1_SPLIT
 #define DC_K1_SPLIT 1    /* pre_mix contraction as an fp16 hi/lo split on the f16 matrix cores (see mfma_tile); 0 = v_mfma_f32_16x16x4_f32 */
 #endif
+#ifndef DC_K2_ABL
+#define DC_K2_ABL 0      /* ablation builds of the split gather kernel (wrong results!): 1 no sincos, 2 no LayerNorm reductions, 4 no pair processing, 8 no output stores */
+#endif
 #ifndef DC_K1_MFMA32
 #define DC_K1_MFMA32 1   /* pairs of 16-channel blocks on v_mfma_f32_16x16x32_f16 */
 #endif
@@ -1277,6 +1280,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
   // pairs 16..31 (+32k): about half of the planes hold more than 32 voxels, and their second round of pairs used to
   // double the step.
   auto pairs_of = [&](int jp, int pstart) {
+      if (DC_K2_ABL & 4) return;
       const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
       const int po = pz0 + jp - (R - 1) + HLO;
       // ---- deal the plane's voxels out as pairs ----
@@ -1341,6 +1345,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
         } else {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
+            if (DC_K2_ABL & 1) { snA[e] = thA[e]; csA[e] = 1.0f - thA[e]; snB[e] = thB[e]; csB[e] = 1.0f - thB[e]; continue; }
             sincos_small(thA[e], snA[e], csA[e]);
             if (PAIR) { snB[e] = snA[e]; csB[e] = csA[e]; } else sincos_small(thB[e], snB[e], csB[e]);
           }
@@ -1373,8 +1378,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
           }
           sA += nvA[e]; sB += nvB[e];
         }
-        sA = grp_sum<LPR>(sA);
-        sB = grp_sum<LPR>(sB);
+        if (!(DC_K2_ABL & 2)) { sA = grp_sum<LPR>(sA); sB = grp_sum<LPR>(sB); }
         const float meanA = sA * (1.0f / C), meanB = sB * (1.0f / C);
         float qA = 0.f, qB = 0.f;
 #pragma unroll
@@ -1382,16 +1386,15 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
           const float dA = nvA[e] - meanA, dB = nvB[e] - meanB;
           qA += dA * dA; qB += dB * dB;
         }
-        qA = grp_sum<LPR>(qA);
-        qB = grp_sum<LPR>(qB);
+        if (!(DC_K2_ABL & 2)) { qA = grp_sum<LPR>(qA); qB = grp_sum<LPR>(qB); }
         const float rsA = __builtin_amdgcn_rsqf(qA * (1.0f / C) + eps), rsB = __builtin_amdgcn_rsqf(qB * (1.0f / C) + eps);
         float4 oa, ob;
         oa.x = (nvA[0] - meanA) * rsA * gw[0] + gb[0]; oa.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
         oa.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2]; oa.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
         ob.x = (nvB[0] - meanB) * rsB * gw[0] + gb[0]; ob.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
         ob.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2]; ob.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
-        io_st4(r_out, (uint32_t)recA.w * (uint32_t)C + (uint32_t)ch0, true, oa);
-        io_st4(r_out, (uint32_t)recB.w * (uint32_t)C + (uint32_t)ch0, hasB, ob);
+        io_st4(r_out, (uint32_t)recA.w * (uint32_t)C + (uint32_t)ch0, !(DC_K2_ABL & 8) || oa.x == 123.456f, oa);
+        io_st4(r_out, (uint32_t)recB.w * (uint32_t)C + (uint32_t)ch0, (!(DC_K2_ABL & 8) || ob.x == 123.456f) && hasB, ob);
       }
   };
   if (producer) {
