@@ -543,12 +543,33 @@ int64_t link_dc_grid_from(const link_grid_t *grid, int32_t k, link_dc_grid_t *ou
 #define LINK_IO_F32 0
 #define LINK_IO_F16 1
 #define LINK_IO_BF16 2
+/* Launch geometry and kernel selection of ONE plan (all zero = defaults).  Part of link_dc_buffers_t, read at every
+ * call: nothing about the dense-cell path is process-global, two plans with different settings can run concurrently
+ * from different threads / streams (re-entrant, no global state). */
+typedef struct {
+  int32_t k1_wgs;      /* workgroups (4 waves each) of the fused pre_mix kernel; 0 = 512.  One frame alone wants 2 per CU
+                          (512); with several frames in flight 256 co-schedules better */
+  int32_t k2_zsplit;   /* z-segments of the fused gather + de-modulate kernel; 0 = auto (enough for ~512 workgroups) */
+  int32_t k1_lds_pad;  /* extra dynamic LDS bytes of the fused pre_mix kernel (<= 16384) / the gather kernel (<= 4096): */
+  int32_t k2_lds_pad;  /* which workgroups share a CU when several frames are in flight */
+  int32_t k1_form;     /* 0 = tile form (id slots, in-wave id sort, per-cell sums by segmented DPP scan in the matrix-core
+                          accumulator layout); 1 = cell-range form of round 2 (LDS voxel list + X tile) */
+  int32_t k2_form;     /* bit 0: single-role gather kernel instead of producer / consumer; bit 1: one voxel per lane group */
+  int32_t mode;        /* 0 = default (7); else bit 0 fused pre_mix+modsum, bit 1 dense-cell demod kernel, bit 2 fused
+                          gather + de-modulate (C = 64) -- the unfused stages are what the fused ones are tested against */
+  int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */
+  int32_t reserved;
+  uint64_t *k1_dbg;    /* bench only: device buffer u64[waves*8] for per-wave phase timings of the cell-range form; NULL = off */
+} link_dc_tuning_t;
+
 typedef struct {
   const void *feats;         /* [N,C] in io_dtype */
   const int32_t *coords;     /* i32[N,4] */
   const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;   /* as link_elk_buffers_t */
   uint32_t *cnt;             /* u32[vp]     voxels per cell; all-zero on entry and on exit (self-cleaning) */
   int32_t *slots;            /* i32[vp*k,4] (x,y,z,id) records; no initialisation needed */
+  uint32_t *sid;             /* u32[vp*max(k,8)] voxel ids per cell in arrival order (tile form of the fused pre_mix kernel:
+                                8 inline ids per cell = one 32-byte piece, then the overflow region); no initialisation */
   int32_t *vrec;             /* i32[N,4]    (x,y,z,id) per voxel, original order */
   int32_t *vcell;            /* i32[N]      padded cell id per voxel (0 for dropped voxels) */
   int32_t *cell_n;           /* i32[vp]     voxels per cell of the last indexed frame (zero-filled once) */
@@ -563,6 +584,7 @@ typedef struct {
                                 LayerNorm statistics stay fp32 -- the reference's AMP contract (custom_fwd(cast_inputs
                                 = torch.half) on voxelize / devoxelize, nn/functional/voxelize.py:13, devoxelize.py:54,
                                 fp32 accumulation) */
+  link_dc_tuning_t tune;
 } link_dc_buffers_t;
 
 int link_dc_premix_insert(const float *feats, const int32_t *coords, const float *w_pre, const float *ln_w,
@@ -599,16 +621,10 @@ int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
-/* Tuning hooks (bench only).  link_dc_set_tuning: key 0 premix workgroups, 1 modsum workgroups, 2 gather
- * z-splits, 3 kernel selection (bit0 fused pre_mix+modsum, bit1 dense-cell demod kernel, bit2 fused gather+demod; default 7).
- * link_dc_set_tuning2: key 0 fused-kernel workgroups, 1 demod workgroups, 2 index workgroups, 3 z-splits of the fused gather+demod,
- * 4 single-tile gather, 5 pipelined pre_mix tiles, 6 producer/consumer gather, 7 / 8 extra dynamic LDS bytes of the fused pre_mix /
- * gather kernel (CU-sharing policy when several frames are in flight). */
-int link_dc_set_tuning(int key, int value);
-int link_dc_set_tuning2(int key, int value);
-/* Bench only: device buffer u64[waves*8] that the fused kernel fills with per-wave phase timings (s_memtime
- * deltas: W staging, cell section, pipeline fill, tile bodies, per-cell sums, total, tiles, start); NULL = off. */
-int link_dc_set_debug_buffer(void *device_ptr);
+/* The slot insert of the tile form: coords -> cnt / sid / vcell (ids only; the fused pre_mix kernel of the tile form
+ * writes the id-ordered (x,y,z,id) records the gather kernel reads into `slots`).  Status bits as link_dc_index. */
+int link_dc_index_ids(const int32_t *coords, int64_t n, const link_dc_grid_t *g /* host */, uint32_t *cnt,
+                      uint32_t *sid, int32_t *vcell, int32_t *hdr, void *stream);
 
 /* =============================================================================================
  * F. Training-mode BatchNorm statistics over feature rows (row N2; torchsparse/nn/modules/norm.py:10-13 applies

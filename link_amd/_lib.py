@@ -17,7 +17,7 @@ LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -66,11 +66,17 @@ class LinkDcGrid(Structure):
         return v
 
 
+class LinkDcTuning(Structure):
+    """link_dc_tuning_t: launch geometry / kernel selection of ONE plan (all zero = defaults)"""
+    _fields_ = [(k, c_int32) for k in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode",
+                                       "k1_pipe", "reserved")] + [("k1_dbg", c_void_p)]
+
+
 class LinkDcBuffers(Structure):
     """link_dc_buffers_t"""
     _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha",
-                                        "ln_w", "ln_b", "cnt", "slots", "vrec", "vcell", "cell_n", "hdr", "fin",
-                                        "S", "A", "out")] + [("io_dtype", c_int32)]
+                                        "ln_w", "ln_b", "cnt", "slots", "sid", "vrec", "vcell", "cell_n", "hdr", "fin",
+                                        "S", "A", "out")] + [("io_dtype", c_int32), ("tune", LinkDcTuning)]
 
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
@@ -177,9 +183,7 @@ SIGNATURES = {
     "link_dc_gather": (c_int, [c_void_p, c_void_p, POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_void_p, c_void_p]),
     "link_elk_core_dense_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                             c_int64, c_int32, c_void_p]),
-    "link_dc_set_tuning": (c_int, [c_int, c_int]),
-    "link_dc_set_tuning2": (c_int, [c_int, c_int]),
-    "link_dc_set_debug_buffer": (c_int, [c_void_p]),
+    "link_dc_index_ids": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_index": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_premix_modsum": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64,
                                       c_int32, c_void_p]),

@@ -20,22 +20,8 @@
 
 using namespace link;
 
-static int g_dc_premix_wgs = 512;
-static int g_dc_modsum_wgs = 768;
-static int g_dc_zsplit = 0;          // 0 = auto
-static int g_dc_mode = 7;          // bit0: fused pre_mix+modsum kernel, bit1: dense-cell demod kernel, bit2: fused gather+demod (C = 64)
-
-extern "C" int link_dc_set_tuning(int key, int value) {
-  if (value < 0) return LINK_ERR_ARG;
-  switch (key) {
-    case 0: g_dc_premix_wgs = value > 0 ? value : 512; break;
-    case 1: g_dc_modsum_wgs = value > 0 ? value : 768; break;
-    case 2: g_dc_zsplit = value; break;
-    case 3: g_dc_mode = value; break;
-    default: return LINK_ERR_ARG;
-  }
-  return LINK_OK;
-}
+// launch geometry of the unfused stages (fixed: they are the reference points the fused kernels are tested against)
+static constexpr int DC_PREMIX_WGS = 512, DC_MODSUM_WGS = 768;
 
 extern "C" int64_t link_dc_grid_from(const link_grid_t *grid, int32_t k, link_dc_grid_t *out) {
   if (!grid || !out || grid->s <= 0) return -1;
@@ -231,7 +217,7 @@ static int launch_dc_premix(const float *feats, const int32_t *coords, const flo
   const size_t lds = ((size_t)C * (C + 4) + 2 * C) * sizeof(float);
   const int64_t tiles = (n + 15) / 16;
   // equal tiles per wave: waves = ceil(tiles / tiles_per_wave) with tiles_per_wave from the workgroup cap
-  int64_t cap = (int64_t)g_dc_premix_wgs * 4;
+  int64_t cap = (int64_t)DC_PREMIX_WGS * 4;
   int64_t tpw = (tiles + cap - 1) / cap;
   int64_t waves = (tiles + tpw - 1) / tpw;
   int64_t wgs = (waves + 3) / 4;
@@ -520,7 +506,7 @@ static void launch_dc_modsum(const link_elk_desc_t &d, const link_dc_grid_t &g, 
                              const float *alpha, bool warm, float *S_, int32_t *hdr) {
   constexpr int G = 64 / LPR;
   const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
-  int64_t wgs = g_dc_modsum_wgs;
+  int64_t wgs = DC_MODSUM_WGS;
   int64_t groups = wgs * 4 * G;
   int run = (int)((vi + groups - 1) / groups);
   if (run < 1) run = 1;
@@ -710,7 +696,7 @@ template <int C, int P, int R>
 static int launch_dc_gather(const link_dc_grid_t &g, hipStream_t st, const float *S_, const int32_t *cell_n, float *A) {
   using K = dc_gather_cfg<C, P, R>;
   const int txn = (g.dim[0] + K::TX - 1) / K::TX, tyn = (g.dim[1] + K::TY - 1) / K::TY;
-  int zsplit = g_dc_zsplit;
+  int zsplit = 0;                                      // auto
   if (zsplit <= 0) {                                  // aim at ~2 workgroups per CU
     const int64_t tiles = (int64_t)txn * tyn * g.dim[3];
     zsplit = (int)(512 / tiles);                      // <= 2 workgroups per CU: one resident round
@@ -767,12 +753,14 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
   if (!b || dc_desc_ok(desc, g) != LINK_OK || n < 0) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   int rc;
-  const bool fused = (g_dc_mode & 1) && desc->c <= 64 && g->k <= 352;
-  if (b->io_dtype != LINK_IO_F32 && (!fused || !(g_dc_mode & 2))) return LINK_ERR_ARG;   // half rows: fused kernels only
+  const int mode = b->tune.mode ? b->tune.mode : 7;   // bit0: fused pre_mix+modsum kernel, bit1: dense-cell demod kernel, bit2: fused gather+demod (C = 64)
+  const bool fused = (mode & 1) && desc->c <= 64 && g->k <= 352;
+  if (b->io_dtype != LINK_IO_F32 && (!fused || !(mode & 2))) return LINK_ERR_ARG;   // half rows: fused kernels only
   if (fused) {
     // index -> fused pre_mix + modulate + per-cell sum -> box gather -> per-voxel de-modulate
     if (build_index) {
-      rc = link_dc_index(b->coords, n, g, b->cnt, b->slots, b->vcell, b->hdr, stream);
+      rc = b->tune.k1_form == 0 ? link_dc_index_ids(b->coords, n, g, b->cnt, b->sid, b->vcell, b->hdr, stream)
+                                : link_dc_index(b->coords, n, g, b->cnt, b->slots, b->vcell, b->hdr, stream);
       if (rc != LINK_OK) return rc;
     }
     rc = link_dc_premix_modsum(b, g, desc, n, build_index ? 0 : 1, stream);
@@ -785,11 +773,11 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
                         b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
-  if ((g_dc_mode & 4) && desc->c == 64)                // box sum + de-modulate fused: the A table never exists
+  if ((mode & 4) && desc->c == 64)                // box sum + de-modulate fused: the A table never exists
     return link_dc_gather_demod(b, g, desc, n, stream);
   rc = link_dc_gather(b->S, b->cell_n, desc, g, b->A, stream);
   if (rc != LINK_OK) return rc;
-  if (g_dc_mode & 2)
+  if (mode & 2)
     return link_dc_demod(b->A, b->fin, b->coords, b->vcell, b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, g, n, b->out,
                          b->io_dtype, stream);
   if (fused && build_index) return LINK_ERR_ARG;       // section C's kernel needs vrec, which only pre_mix+insert writes

@@ -46,6 +46,14 @@ __device__ __forceinline__ uint32_t dc_slot(const link_dc_grid_t &g, int pcell, 
                        : (uint32_t)g.vp * DC_INL + (uint32_t)pcell * (uint32_t)(g.k - DC_INL) + (uint32_t)(rank - DC_INL);
 }
 
+// Id lists of the tile form (link_dc_buffers_t::sid): DC_SID_INL voxel ids inline per cell (32 contiguous bytes: what a
+// lane of the fused pre_mix kernel reads for its cell), then the overflow region with k - DC_SID_INL ids per cell.
+#define DC_SID_INL 8
+__device__ __forceinline__ uint32_t dc_sid_off(const link_dc_grid_t &g, int pcell, int rank) {      // u32 index
+  const int kk = g.k > DC_SID_INL ? g.k - DC_SID_INL : 0;
+  return rank < DC_SID_INL ? (uint32_t)pcell * DC_SID_INL + (uint32_t)rank
+                           : (uint32_t)g.vp * DC_SID_INL + (uint32_t)pcell * (uint32_t)kk + (uint32_t)(rank - DC_SID_INL);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

@@ -20,17 +20,9 @@
 using namespace link;
 
 namespace link {
-int g_k1_wgs = 512;
-int g_demod_wgs = 1024;
-int g_k2_zsplit = 0;
-int g_k2_single = 0;
-int g_k1_pipe = 0;
-int g_k1_lds_pad = 0;       // extra dynamic LDS of the fused pre_mix kernel / the split gather kernel (CU sharing policy, bench.py)
-int g_k2_lds_pad = 0;
-int g_k2_split = 1;         // producer / consumer form of the fused gather + de-modulate kernel (where two workgroups fit a CU)
-unsigned long long *g_k1_dbg = nullptr;      // device buffer for phase timing (bench only)
+// tile form of the fused pre_mix kernel (dense_tiles.hip)
+int dc_tiles_modsum(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d, int64_t n, bool warm, hipStream_t st);
 }
-static int g_index_wgs = 0;
 
 // the fp16 / bf16 instantiations live in their own translation units (dense_fused_f16.hip, dense_fused_bf16.hip)
 #define DC_DECL_IO(NS)                                                                                                    \
@@ -45,28 +37,6 @@ static int g_index_wgs = 0;
 DC_DECL_IO(dcio_f16)
 DC_DECL_IO(dcio_bf16)
 #undef DC_DECL_IO
-
-extern "C" int link_dc_set_debug_buffer(void *p) {
-  g_k1_dbg = reinterpret_cast<unsigned long long *>(p);
-  return LINK_OK;
-}
-
-extern "C" int link_dc_set_tuning2(int key, int value) {
-  if (value < 0) return LINK_ERR_ARG;
-  switch (key) {
-    case 0: g_k1_wgs = value > 0 ? value : 512; break;
-    case 1: g_demod_wgs = value > 0 ? value : 1024; break;
-    case 2: g_index_wgs = value; break;
-    case 3: g_k2_zsplit = value; break;
-    case 4: g_k2_single = value; break;
-    case 5: g_k1_pipe = value; break;
-    case 6: g_k2_split = value; break;
-    case 7: g_k1_lds_pad = value <= 16384 ? value : 16384; break;
-    case 8: g_k2_lds_pad = value <= 4096 ? value : 4096; break;
-    default: return LINK_ERR_ARG;
-  }
-  return LINK_OK;
-}
 
 // ---------------------------------------------------------------------------------------------
 // index: slot insert
@@ -100,7 +70,7 @@ extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_gri
   if (n == 0) return LINK_OK;
   if (!coords || !cnt || !slots || !vcell || !hdr) return LINK_ERR_ARG;
   if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29)) return LINK_ERR_ARG;
-  int64_t wgs = g_index_wgs > 0 ? g_index_wgs : (n + 255) / 256;
+  int64_t wgs = (n + 255) / 256;
   if (wgs > 4096) wgs = 4096;
   hipLaunchKernelGGL(k_dc_index, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
                      *g, cnt, reinterpret_cast<int4 *>(slots), vcell, hdr);
@@ -128,6 +98,7 @@ extern "C" int link_dc_premix_modsum(const link_dc_buffers_t *b, const link_dc_g
       !b->S || !b->hdr)
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
+  if (b->tune.k1_form == 0) return dc_tiles_modsum(b, g, d, n, warm != 0, st);
   switch (b->io_dtype) {
     case 1: return dcio_f16::run_premix_modsum(b, *g, *d, n, warm != 0, st);
     case 2: return dcio_bf16::run_premix_modsum(b, *g, *d, n, warm != 0, st);

@@ -8,79 +8,10 @@
 #include <type_traits>
 
 #include "dense_gather.h"
-
-namespace link {
-extern int g_k1_wgs, g_demod_wgs, g_k2_zsplit, g_k2_single, g_k1_pipe, g_k2_split, g_k1_lds_pad, g_k2_lds_pad;
-extern unsigned long long *g_k1_dbg;
-}
+#include "dense_io.h"
 
 namespace DC_IO_NS {
 using namespace link;
-
-constexpr int IO = DC_IO;
-constexpr int IO_BYTES = IO == 0 ? 4 : 2;             // bytes per feature element at the kernel boundary
-
-typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-
-// four consecutive channels starting at element index e (a multiple of 4)
-__device__ __forceinline__ float4 io_ld4(const void *base, int64_t e) {
-  if constexpr (IO == 0) {
-    return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + e);
-  } else if constexpr (IO == 1) {
-    const h4_t h = *reinterpret_cast<const h4_t *>(reinterpret_cast<const _Float16 *>(base) + e);
-    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
-  } else {
-    const us4_t u = *reinterpret_cast<const us4_t *>(reinterpret_cast<const unsigned short *>(base) + e);
-    return make_float4(__uint_as_float((unsigned)u.x << 16), __uint_as_float((unsigned)u.y << 16),
-                       __uint_as_float((unsigned)u.z << 16), __uint_as_float((unsigned)u.w << 16));
-  }
-}
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-  const unsigned u = __float_as_uint(f);
-  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-// store four channels at BYTE offset of the fp32 layout / 4 * IO_BYTES, i.e. callers pass the element offset
-__device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_off, bool valid, float4 v) {
-  if constexpr (IO == 0) {
-    st16(r, valid ? elem_off * 4u : DC_OOB, v);
-  } else {
-    v2i_t x;
-    if constexpr (IO == 1) {
-      const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-      x = __builtin_bit_cast(v2i_t, h);
-    } else {
-      x.x = (int)(bf16_rne(v.x) | (bf16_rne(v.y) << 16));
-      x.y = (int)(bf16_rne(v.z) | (bf16_rne(v.w) << 16));
-    }
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, valid ? elem_off * 2u : DC_OOB, 0, DC_ST_AUX);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pre_mix + LayerNorm + modulate + per-cell sum
-// ---------------------------------------------------------------------------------------------
-// x = hi + lo, hi = fp16(x) (round to nearest), lo = fp16(x - hi): four values -> two packed operands
-typedef _Float16 dc_h4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dc_split4(const float4 &v, uint2 &hi, uint2 &lo) {
-  const dc_h4v h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-  const dc_h4v l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z), (_Float16)(v.w - (float)h.w)};
-  hi = __builtin_bit_cast(uint2, h);
-  lo = __builtin_bit_cast(uint2, l);
-}
-__device__ __forceinline__ floatx4 dc_mfma_f16(uint2 a, uint2 b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(dc_h4v, a), __builtin_bit_cast(dc_h4v, b), c, 0, 0, 0);
-}
-// two 16-channel blocks in one instruction (gfx950: v_mfma_f32_16x16x32_f16, K = 32 in the passes of K = 16): the
-// instruction's k = 8g + j is mapped to channel 4g + j of the first block for j < 4 and of the second for j >= 4 --
-// the same for both operands, so any such permutation of k is correct
-typedef _Float16 dc_h8v __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ floatx4 dc_mfma_f16x2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, floatx4 c) {
-  const uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y), b = make_uint4(b0.x, b0.y, b1.x, b1.y);
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dc_h8v, a), __builtin_bit_cast(dc_h8v, b), c, 0, 0, 0);
-}
 
 #ifndef DC_K1_LCAP
 #define DC_K1_LCAP 352
@@ -600,26 +531,29 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
                      bool warm, hipStream_t st) {
   using K = dc_k1_cfg<C, OP>;
   const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
-  int64_t waves = (int64_t)g_k1_wgs * 4;
+  int64_t waves = (int64_t)(b->tune.k1_wgs > 0 ? b->tune.k1_wgs : 512) * 4;
   int cpw = (int)((vi + waves - 1) / waves);
   if (cpw < 1) cpw = 1;
   const int64_t wgs = (vi + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
-  // g_k1_lds_pad: extra dynamic LDS requested on purpose (frames in flight): a workgroup that cannot share its CU with a
+  int k1_pad = b->tune.k1_lds_pad;
+  k1_pad = k1_pad < 0 ? 0 : (k1_pad > 16384 ? 16384 : k1_pad);
+  // tune.k1_lds_pad: extra dynamic LDS requested on purpose (frames in flight): a workgroup that cannot share its CU with a
   // second one of its own kind shares it with the other frame's gather kernel instead -- the better mix (bench.py)
-  const int lds_k1 = K::LDS_BYTES + g_k1_lds_pad <= 160 * 1024 ? K::LDS_BYTES + g_k1_lds_pad : K::LDS_BYTES;
+  const int lds_k1 = K::LDS_BYTES + k1_pad <= 160 * 1024 ? K::LDS_BYTES + k1_pad : K::LDS_BYTES;
   if (lds_k1 > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_k1);
   hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, PIPE>), dim3((unsigned)wgs), dim3(64 * K::NW), lds_k1, st, b->feats,
                      reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
-                     b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr, g_k1_dbg);
+                     b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
+                     reinterpret_cast<unsigned long long *>(b->tune.k1_dbg));
   return check_launch("link_dc_premix_modsum");
 }
 
 template <int C, int OP, int NB>
 static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                      bool warm, hipStream_t st) {
-  return g_k1_pipe ? launch_k1p<C, OP, NB, true>(b, g, d, n, warm, st) : launch_k1p<C, OP, NB, false>(b, g, d, n, warm, st);
+  return b->tune.k1_pipe ? launch_k1p<C, OP, NB, true>(b, g, d, n, warm, st) : launch_k1p<C, OP, NB, false>(b, g, d, n, warm, st);
 }
 
 template <int C, int OP>
@@ -808,7 +742,7 @@ static void launch_dc_demod(const link_elk_desc_t &d, int64_t n, int64_t a_rows,
   constexpr int G = 64 / LPR;
   const int64_t npair = (n + 1) / 2;
   int64_t wgs = (npair + 4 * G - 1) / (4 * G);
-  if (wgs > g_demod_wgs) wgs = g_demod_wgs;
+  if (wgs > 1024) wgs = 1024;
   const bool two_part = d.op == LINK_OP_COS || d.op == LINK_OP_SIN;
   const bool pair = LPR >= 2 && d.c == 2 * d.cg && two_part;
   const int4 *co = reinterpret_cast<const int4 *>(coords);
@@ -1480,7 +1414,10 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   using K2 = dc_k2_cfg<OP, R>;
   using K = typename K2::G;
   const int txn = (g.dim[0] + K::TX - 1) / K::TX, tyn = (g.dim[1] + K::TY - 1) / K::TY;
-  int zsplit = g_k2_zsplit;
+  int zsplit = b->tune.k2_zsplit;
+  int k2_pad = b->tune.k2_lds_pad;
+  k2_pad = k2_pad < 0 ? 0 : (k2_pad > 4096 ? 4096 : k2_pad);
+  const int k2_single = (b->tune.k2_form & 2) ? 1 : 0;
   if (zsplit <= 0) {
     const int64_t tiles = (int64_t)txn * tyn * g.dim[3];
     zsplit = (int)(512 / tiles);
@@ -1495,12 +1432,12 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
 #define LINK_K2S(PP, DD)                                                                                              \
   do {                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_split<OP, R, PP, DD>),                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES + g_k2_lds_pad);        \
-    hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES + g_k2_lds_pad, st, \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES + k2_pad);        \
+    hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES + k2_pad, st, \
                        b->S, b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w, \
-                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, g_k2_single);     \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, k2_single);     \
   } while (0)
-  if (g_k2_split && K2::SPLIT_FITS) {
+  if (!(b->tune.k2_form & 1) && K2::SPLIT_FITS) {
     if (pair) { if (div) LINK_K2S(true, true); else LINK_K2S(true, false); }
     else { if (div) LINK_K2S(false, true); else LINK_K2S(false, false); }
     return check_launch("link_dc_gather_demod");
@@ -1512,7 +1449,7 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, K2::LDS_BYTES);                             \
     hipLaunchKernelGGL((k_dc_gather_demod<OP, R, PP, DD>), dim3((unsigned)grid), dim3(256), K2::LDS_BYTES, st, b->S,  \
                        b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w,      \
-                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, g_k2_single);     \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, k2_single);     \
   } while (0)
   if (pair) { if (div) LINK_K2(true, true); else LINK_K2(true, false); }
   else { if (div) LINK_K2(false, true); else LINK_K2(false, false); }

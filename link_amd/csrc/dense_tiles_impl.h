@@ -1,0 +1,552 @@
+// link_amd/csrc/dense_tiles_impl.h -- tile form of the fused pre_mix + LayerNorm + modulate + per-cell-sum kernel
+// (round 3; include/link_amd.h section E, link_dc_tuning_t::k1_form = 0).  Compiled once per feature I/O type like
+// dense_fused_impl.h (DC_IO / DC_IO_NS).
+//
+// What changed against the cell-range form of round 2 (dense_fused_impl.h, kept as k1_form = 1), and why -- the
+// round-2 ablations left 16.7 of 25.6 us in the kernel's frame, not in its arithmetic:
+//   * the slot lists hold voxel IDS (4 bytes, 8 inline per cell = one 32-byte piece per cell) instead of 16-byte
+//     records: a lane owns a cell, sorts its <= 8 ids in registers (19-exchange network) and scatters them to a
+//     flat LDS list by the wave prefix of the counts -- one round trip, no per-record sort loop; cells with more than
+//     8 voxels (2e-4 of the cells on cfg2, every cell of a LiDAR frame) are ranked by counting in their own pass;
+//   * a tile's per-cell sums are formed IN the matrix-core accumulator layout: a DPP row holds the tile's 16 voxels
+//     (same 16 channels each), so the sum over the voxels of a cell is a segmented scan along the row -- four
+//     v_fmac_f32_dpp per value with 0/1 segment masks -- and the closing lane of each segment stores its piece of
+//     the S row.  No X tile in LDS (8.4 KB per wave, a quarter of the old kernel's LDS cycles were bank conflicts),
+//     no second pass over the tile.  A cell that straddles two tiles hands its partial sum over through 512 bytes
+//     of LDS;
+//   * a wave keeps no voxel records: (x, y, z) come from coords[id] with the row gather; the id-ordered records the
+//     gather kernel deals from are written back to `slots` from the tile (one 16-byte store per voxel);
+//   * 36 KB of LDS and <= 128 registers instead of 80 KB / 198: four workgroups per CU instead of two, and room
+//     beside the gather kernel of another frame.
+// Sums are formed in a fixed tree over the id-ordered voxels of a cell: bitwise reproducible, but not the
+// left-to-right order of the cell-range form (the two forms agree to rounding; the reference's own GPU kernel
+// sums with atomics in arrival order, voxelize_cuda.cu:12-25).
+// Non-finite feature rows: 0 * inf inside the segmented scan can spread a NaN to the other cells of the same
+// 16-voxel tile (the reference confines it to the cell's r^3 neighbourhood).
+#pragma once
+#include "dense_io.h"
+
+#ifndef DC_T2_WAVES
+#define DC_T2_WAVES 4     /* register budget = 512 / this */
+#endif
+#ifndef DC_T2_ABL
+#define DC_T2_ABL 0       /* ablation builds (wrong results!): 1 no MFMA, 2 no sincos, 4 no segmented scan, 8 no S stores */
+#endif
+
+namespace DC_IO_NS {
+using namespace link;
+
+template <int C, int OP>
+struct dc_t2_cfg {
+  static constexpr int T = C / 16;
+  static constexpr int P = op_parts<OP>::value;
+  static constexpr int RB = P * C * 4;                 // bytes of one S row
+  static constexpr int RGL = P * C / 4;                // lanes holding one row (16 B each)
+  static constexpr int LDH = 2 * C + 8;                // fp16 image of W, row co = [hi(C) | lo(C) | pad]: conflict-free ds_read_b64
+  static constexpr int WIMG_BYTES = C * LDH * 2;
+  static constexpr int W_BYTES = WIMG_BYTES + (2 * C + 4 * C) * 4;   // W, LayerNorm weight / bias, theta weights (w0 | w1 | w2 | alpha)
+  static constexpr int LIST_N = 512;                   // 64 cells x 8 inline ids
+  static constexpr int DUMP_N = 16;                    // where the writes of empty id slots go
+  static constexpr int RAW_N = 352;                    // ids of one heavy cell (k <= 352, as the cell-range form)
+  static constexpr int LIST_BYTES = (LIST_N + DUMP_N + RAW_N) * 4;
+  static constexpr int CARRY_BYTES = P * C * 4;        // open cell at a tile boundary: 4 lane groups x P parts x C/4 values
+  static constexpr int WAVE_BYTES = LIST_BYTES + CARRY_BYTES;
+  static constexpr int NW = 4;
+  static constexpr int LDS_BYTES = W_BYTES + NW * WAVE_BYTES;
+};
+
+#define DC_ID_BITS 26
+#define DC_ID_MASK ((1u << DC_ID_BITS) - 1u)
+
+// one step of the segmented scan over a DPP row for four values: v += mask * v[lane - 2^k] (mask = 1 where that lane
+// belongs to the same cell).  The s_nop covers the VALU-write -> DPP-read hazard, which hipcc cannot see inside asm.
+#define DC_SCAN4(CTRL, m, a, b, c, d)                                                        \
+  asm volatile("s_nop 1\n\t"                                                                  \
+               "v_fmac_f32_dpp %0, %0, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+               "v_fmac_f32_dpp %1, %1, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+               "v_fmac_f32_dpp %2, %2, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+               "v_fmac_f32_dpp %3, %3, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"     \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d)                                           \
+               : "v"(m))
+
+template <int CTRL>
+__device__ __forceinline__ int dc_dpp_i(int v, int oob) {      // lanes without a source keep `oob`
+  return __builtin_amdgcn_update_dpp(oob, v, CTRL, 0xF, 0xF, false);
+}
+
+template <int C, int OP, int NB>
+__global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
+    const void *__restrict__ feats, const int4 *__restrict__ coords, const uint32_t *__restrict__ sid,
+    int4 *__restrict__ slots, uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
+    const float *__restrict__ w_pre, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg, float coord_div, float eps, int64_t n,
+    link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
+    unsigned long long *__restrict__ dbg) {
+  using K = dc_t2_cfg<C, OP>;
+  // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime values
+  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_chunk = 0, tq_mfma = 0, tq_valu = 0, tq_scan = 0;
+  int tq_tiles = 0;
+  constexpr int T = K::T, P = K::P, NV = 4 * T;        // NV values per part and lane (16 at C = 64)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *ln_lds = reinterpret_cast<float *>(smem_raw + K::WIMG_BYTES);
+  float *pw_lds = ln_lds + 2 * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, gq = lane >> 4;
+  char *wbase = smem_raw + K::W_BYTES + wave * K::WAVE_BYTES;
+  uint32_t *list = reinterpret_cast<uint32_t *>(wbase);
+  uint32_t *raw = list + K::LIST_N + K::DUMP_N;
+  float *carry = reinterpret_cast<float *>(wbase + K::LIST_BYTES);
+  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
+  const int Vi = Dx * Dy * Dz * g.dim[3];
+  const int wid = blockIdx.x * K::NW + wave;
+  const int c_begin = wid * cpw;
+  const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
+  const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
+  const uint4 *__restrict__ sid4 = reinterpret_cast<const uint4 *>(sid);
+  // a chunk = 64 consecutive interior cells, one per lane: padded cell id, count, the 8 inline ids
+  auto cell_of = [&](int chunk, int nrem) {
+    const int q = chunk + (lane < nrem ? lane : 0);
+    const int z = q % Dz;
+    int t = q / Dz;
+    const int y = t % Dy;
+    t /= Dy;
+    return dc_cell(g, t % Dx, y, z, t / Dx);
+  };
+  int pc_n = 0, cn_n = 0;
+  uint4 ia_n = make_uint4(0, 0, 0, 0), ib_n = ia_n;
+  auto load_chunk = [&](int chunk) {                   // the first chunk's request is issued before W is staged
+    const int nrem = (c_end - chunk < 64) ? c_end - chunk : 64;
+    pc_n = cell_of(chunk, nrem);
+    cn_n = (int)csrc[pc_n];
+    ia_n = sid4[(int64_t)pc_n * 2];
+    ib_n = sid4[(int64_t)pc_n * 2 + 1];
+  };
+  if (c_begin < c_end) load_chunk(c_begin);
+  bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction
+  {                                                    // stage W (fp16 hi | lo image) and the parameters: all loads, ONE wait, then the writes
+    constexpr int NF4 = C * C / 4;
+    constexpr int NT = 64 * K::NW;
+    constexpr int NVW = (NF4 + NT - 1) / NT;
+    float4 wv[NVW];
+#pragma unroll
+    for (int i = 0; i < NVW; i++) {
+      const int e = (i * NT + tid) * 4;
+      wv[i] = *reinterpret_cast<const float4 *>(&w_pre[(NF4 % NT == 0 || e < C * C) ? e : 0]);
+    }
+#pragma unroll
+    for (int i = 0; i < NVW; i++) {
+      int e = (i * NT + tid) * 4;
+      if (NF4 % NT != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
+      const int r = e / C, col = e - r * C;
+      const float4 wq = (NF4 % NT == 0 || (i * NT + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
+      uint2 hi, lo;
+      dc_split4(wq, hi, lo);
+      unsigned short *wh = reinterpret_cast<unsigned short *>(smem_raw);
+      *reinterpret_cast<uint2 *>(&wh[r * K::LDH + col]) = hi;
+      *reinterpret_cast<uint2 *>(&wh[r * K::LDH + C + col]) = lo;
+      w_big |= !(fmaxf(fmaxf(fabsf(wq.x), fabsf(wq.y)), fmaxf(fabsf(wq.z), fabsf(wq.w))) < 32768.0f);
+    }
+    if (tid < C) ln_lds[tid] = ln_w[tid];
+    else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
+    if (tid < C) {                                     // theta weights of channel tid (channel ch uses theta[ch % cg])
+      const int tc = tid % cg;
+      pw_lds[tid] = w_pos[3 * tc + 0]; pw_lds[C + tid] = w_pos[3 * tc + 1]; pw_lds[2 * C + tid] = w_pos[3 * tc + 2];
+      pw_lds[3 * C + tid] = alpha ? alpha[tc] : 1.0f;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
+    hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
+    hdr[LINK_HDR_STATUS_ACC] = 0;
+  }
+  w_big = __syncthreads_or(w_big) != 0;
+  if (dbg) tq1 = __builtin_amdgcn_s_memtime();
+  if (c_begin >= c_end) return;
+  const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * K::RB));
+  const __amdgpu_buffer_rsrc_t r_fin = dc_rsrc(fin, (uint32_t)(n * C * 4));     // written for cos_x only
+  const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
+  const __amdgpu_buffer_rsrc_t r_n = dc_rsrc(cell_n, (uint32_t)(g.vp * 4));
+  const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(feats, (uint32_t)(n * C * IO_BYTES));
+  const __amdgpu_buffer_rsrc_t r_coords = dc_rsrc(coords, (uint32_t)(n * 16));
+  const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
+
+  // ---- pre_mix contraction of one tile: D[co][voxel] = sum_ci W[co][ci] x[voxel][ci] as an fp16 hi/lo split of both
+  // operands on v_mfma_f32_16x16x32_f16 (exact products, fp32 accumulation, the dropped lo*lo term is 2^-22 relative;
+  // fp16 rows have lo = 0); |x| or |w| >= 2^15 takes the fp32 instruction with W from global memory, wave-uniform ----
+  auto mfma_tile = [&](const float4 (&ff)[T], floatx4 (&cc)[T]) {
+    if (DC_T2_ABL & 1) {
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){ff[tp].x, ff[tp].y, ff[tp].z, ff[tp].w};
+      return;
+    }
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    uint2 bh[T], bl[T];
+    float mx = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < T; tt++) {
+      dc_split4(ff[tt], bh[tt], bl[tt]);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ff[tt].x), fabsf(ff[tt].y)), fmaxf(fabsf(ff[tt].z), fabsf(ff[tt].w))));
+    }
+    if (__builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
+      if constexpr (T % 2 == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; tt += 2) {
+          uint2 ah[2][T], al[2][T];
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) {
+              ah[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + 16 * (tt + h) + 4 * gq]);
+              al[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + C + 16 * (tt + h) + 4 * gq]);
+            }
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(al[0][tp], al[1][tp], bh[tt], bh[tt + 1], cc[tp]);
+          if constexpr (IO != 1) {
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bl[tt], bl[tt + 1], cc[tp]);
+          }
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bh[tt], bh[tt + 1], cc[tp]);
+        }
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < T; tt++) {
+          uint2 ah[T], al[T];
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) {
+            ah[tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + 16 * tt + 4 * gq]);
+            al[tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + C + 16 * tt + 4 * gq]);
+          }
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(al[tp], bh[tt], cc[tp]);
+          if constexpr (IO != 1) {
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(ah[tp], bl[tt], cc[tp]);
+          }
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16(ah[tp], bh[tt], cc[tp]);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int tt = 0; tt < T; tt++) {
+      float4 a[T];
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) a[tp] = *reinterpret_cast<const float4 *>(&w_pre[(16 * tp + li) * C + 16 * tt + 4 * gq]);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].x, ff[tt].x, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].y, ff[tt].y, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].z, ff[tt].z, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].w, ff[tt].w, cc[tp], 0, 0, 0);
+    }
+  };
+
+  for (int chunk = c_begin; chunk < c_end; chunk += 64) {
+    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    if (chunk != c_begin) load_chunk(chunk);            // launches normally give a wave one chunk (cpw <= 64)
+    const int nrem = (c_end - chunk < 64) ? c_end - chunk : 64;
+    const bool act = lane < nrem;
+    const int pc = pc_n;
+    int cn = act ? cn_n : 0;
+    cn = cn < g.k ? cn : g.k;
+    uint32_t ks[8] = {ia_n.x, ia_n.y, ia_n.z, ia_n.w, ib_n.x, ib_n.y, ib_n.z, ib_n.w};
+    const bool heavy = cn > 8;                          // ranked by counting in its own pass below
+    const int nreg = heavy ? 0 : cn;
+    // ---- ids of the cell in ascending order (the sums and the gather kernel's pairing must not depend on the arrival
+    // order the atomics produced): 19-exchange network, empty slots sort to the end ----
+#pragma unroll
+    for (int j = 0; j < 8; j++) ks[j] = j < nreg ? (ks[j] & DC_ID_MASK) : 0xFFFFFFFFu;
+#define DC_CE(i, j) { const uint32_t lo_ = min(ks[i], ks[j]), hi_ = max(ks[i], ks[j]); ks[i] = lo_; ks[j] = hi_; }
+    DC_CE(0, 1) DC_CE(2, 3) DC_CE(4, 5) DC_CE(6, 7)
+    DC_CE(0, 2) DC_CE(1, 3) DC_CE(4, 6) DC_CE(5, 7)
+    DC_CE(1, 2) DC_CE(5, 6)
+    DC_CE(0, 4) DC_CE(1, 5) DC_CE(2, 6) DC_CE(3, 7)
+    DC_CE(2, 4) DC_CE(3, 5)
+    DC_CE(1, 2) DC_CE(3, 4) DC_CE(5, 6)
+#undef DC_CE
+    int incl = nreg;                                    // inclusive prefix over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int excl = incl - nreg;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      list[j < nreg ? excl + j : K::LIST_N + (lane & (K::DUMP_N - 1))] = ((uint32_t)lane << DC_ID_BITS) | ks[j];
+    {                                                   // publish the counts, reset the counters
+      const uint32_t coff = (act && !warm) ? (uint32_t)pc * 4u : DC_OOB;
+      st4i(r_n, coff, cn);
+      st4i(r_cnt, coff, 0);
+    }
+    for (unsigned long long em = __ballot(act && cn == 0); em; em &= em - 1) {   // empty cells: zero rows
+      const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
+      st16(r_S, lane < K::RGL ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)lane * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_chunk += tqb - tqa; tqa = tqb; }
+    // ---- passes over the LDS list: the chunk's regular cells first, then one pass per heavy cell ----
+    unsigned long long hm = __ballot(act && heavy);
+    int ptotal = total, hcell = -1;                     // hcell: chunk lane of the heavy cell this pass belongs to (-1: regular pass)
+    for (;;) {
+      if (ptotal > 0) {
+        const int ntile = (ptotal + 15) >> 4;
+        bool cont_prev = false;                         // the tile's first voxels continue the cell the previous tile ended in
+        auto ld_rows = [&](int t, uint32_t &key, float4 (&ff)[T], int4 &crd) {
+          int sl = 16 * t + li;
+          sl = sl < ptotal ? sl : ptotal - 1;
+          key = list[sl];
+          const int id = (int)(key & DC_ID_MASK);
+          const v4i_t cr = __builtin_amdgcn_raw_buffer_load_b128(r_coords, (uint32_t)id * 16u, 0, 0);
+          crd = make_int4(cr.x, cr.y, cr.z, cr.w);
+          const uint32_t ro = ((uint32_t)id * (uint32_t)C + (uint32_t)(4 * gq)) * (uint32_t)IO_BYTES;
+          ff[0] = io_ldb4<0>(r_feats, ro);
+          if constexpr (T > 1) ff[1] = io_ldb4<16>(r_feats, ro);
+          if constexpr (T > 2) { ff[2] = io_ldb4<32>(r_feats, ro); ff[3] = io_ldb4<48>(r_feats, ro); }
+        };
+        // one tile: the rows are dead once the matrix cores have them, so the NEXT tile's rows are requested into the same
+        // registers right after the contraction and land while this tile's LayerNorm / sincos / scan run
+        auto tile = [&](int t, uint32_t &key, float4 (&ff)[T], int4 &crd) {
+          const int pos = 16 * t + li;
+          const bool valid = pos < ptotal;
+          const int id = (int)(key & DC_ID_MASK), cl = (int)(key >> DC_ID_BITS);
+          // does the cell of the tile's last voxel go on in the next tile?
+          bool cont_next = false;
+          if (16 * t + 16 < ptotal) {                   // wave-uniform
+            const uint32_t kn = list[16 * t + 16];
+            cont_next = __builtin_amdgcn_readfirstlane((int)(kn >> DC_ID_BITS)) == __builtin_amdgcn_readlane(cl, 15);
+          }
+          // padded cell id and rank inside the cell of this lane's voxel
+          const int pcell = hcell >= 0 ? __builtin_amdgcn_readlane(pc, hcell) : __shfl(pc, cl, 64);
+          const int rank = hcell >= 0 ? pos : pos - __shfl(excl, cl, 64);
+          unsigned long long tqt = dbg ? __builtin_amdgcn_s_memtime() : 0;
+          floatx4 ac[T];
+          mfma_tile(ff, ac);
+          if (dbg) { asm volatile("s_nop 0" :: "v"(ac[0][0])); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_mfma += tqb - tqt; tqt = tqb; }
+          // theta of this voxel's blocks
+          float x = (float)crd.x, y = (float)crd.y, z = (float)crd.z;
+          if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+          float th[NB][4], sn[NB][4], cs[NB][4];
+          bool big = false;
+#pragma unroll
+          for (int tb = 0; tb < NB; tb++) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(&pw_lds[16 * tb + 4 * gq]);
+            const float4 q1 = *reinterpret_cast<const float4 *>(&pw_lds[C + 16 * tb + 4 * gq]);
+            const float4 q2 = *reinterpret_cast<const float4 *>(&pw_lds[2 * C + 16 * tb + 4 * gq]);
+            const float4 qa = *reinterpret_cast<const float4 *>(&pw_lds[3 * C + 16 * tb + 4 * gq]);
+            th[tb][0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th[tb][1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
+            th[tb][2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th[tb][3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
+#pragma unroll
+            for (int r = 0; r < 4; r++) big |= !(fabsf(th[tb][r]) < 32768.0f);
+          }
+          if (__builtin_expect(__any(big), 0)) {        // never on sane inputs
+#pragma unroll
+            for (int tb = 0; tb < NB; tb++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) sincos_nocall(th[tb][r], sn[tb][r], cs[tb][r]);
+          } else {
+#pragma unroll
+            for (int tb = 0; tb < NB; tb++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                if (DC_T2_ABL & 2) { sn[tb][r] = th[tb][r]; cs[tb][r] = 1.0f - th[tb][r]; }
+                else sincos_small(th[tb][r], sn[tb][r], cs[tb][r]);
+              }
+          }
+          // LayerNorm over the voxel's C channels: 4T in-lane values + the 4 lane groups
+          float s = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
+          s += __shfl_xor(s, 16, 64);
+          s += __shfl_xor(s, 32, 64);
+          const float mean = s * (1.0f / C);
+          float qq = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < T; tp++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const float d = ac[tp][r] - mean;
+              qq += d * d;
+            }
+          qq += __shfl_xor(qq, 16, 64);
+          qq += __shfl_xor(qq, 32, 64);
+          const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
+          float fv[NV];
+#pragma unroll
+          for (int tp = 0; tp < T; tp++) {
+            const float4 lw = *reinterpret_cast<const float4 *>(&ln_lds[16 * tp + 4 * gq]);
+            const float4 lb = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * tp + 4 * gq]);
+            fv[4 * tp + 0] = (ac[tp][0] - mean) * rstd * lw.x + lb.x; fv[4 * tp + 1] = (ac[tp][1] - mean) * rstd * lw.y + lb.y;
+            fv[4 * tp + 2] = (ac[tp][2] - mean) * rstd * lw.z + lb.z; fv[4 * tp + 3] = (ac[tp][3] - mean) * rstd * lw.w + lb.w;
+            if (OP == LINK_OP_COSX)                     // the de-modulation of cos_x needs fin (linkunet.py:176)
+              st16(r_fin, valid ? (uint32_t)id * (uint32_t)(C * 4) + (uint32_t)((16 * tp + 4 * gq) * 4) : DC_OOB,
+                   make_float4(fv[4 * tp + 0], fv[4 * tp + 1], fv[4 * tp + 2], fv[4 * tp + 3]));
+          }
+          if (dbg) { asm volatile("s_nop 0" :: "v"(fv[0])); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_valu += tqb - tqt; tqt = tqb; }
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t key_n;
+          int4 crd_n;
+          ld_rows(t + 1, key_n, ff, crd_n);             // clamped to the list's last entry beyond its end
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- segments of the DPP row: lanes li of one cell are adjacent (the list is cell-major); slots beyond the
+          // list's end form segments of their own that are never stored ----
+          const int ckey = valid ? cl : 64 + li;
+          const int prevk = dc_dpp_i<0x111>(ckey, -1);               // row_shr:1 (lane 0: -1 -> head)
+          const int nextk = dc_dpp_i<0x101>(ckey, -2);               // row_shl:1 (lane 15: no source)
+          int seg = (prevk != ckey) ? li : 0;                         // segment start, spread by a max-scan
+          seg = max(seg, dc_dpp_i<0x111>(seg, 0));
+          seg = max(seg, dc_dpp_i<0x112>(seg, 0));
+          seg = max(seg, dc_dpp_i<0x114>(seg, 0));
+          seg = max(seg, dc_dpp_i<0x118>(seg, 0));
+          const float m1 = (li - 1 >= seg) ? 1.0f : 0.0f, m2 = (li - 2 >= seg) ? 1.0f : 0.0f;
+          const float m4 = (li - 4 >= seg) ? 1.0f : 0.0f, m8 = (li - 8 >= seg) ? 1.0f : 0.0f;
+          const bool closes = valid && (li == 15 ? !cont_next : nextk != ckey);
+          const uint32_t srow = closes && !(DC_T2_ABL & 8) ? (uint32_t)pcell * (uint32_t)K::RB + (uint32_t)(16 * gq) : DC_OOB;
+          // one part at a time (cos | sin | theta): modulate, carry in, segmented scan, store, carry out
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            float pv[NV];
+#pragma unroll
+            for (int tp = 0; tp < T; tp++) {
+              const int tb = tp % NB;
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const float f = fv[4 * tp + r];
+                if (pp == 2) pv[4 * tp + r] = f * th[tb][r];
+                else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[4 * tp + r] = f * sn[tb][r];
+                else pv[4 * tp + r] = f * cs[tb][r];
+              }
+            }
+            float *cbuf = carry + (pp * 4 + gq) * NV;
+            if (cont_prev) {                            // wave-uniform: only lane 0 of the row takes the carry (the scan spreads it)
+              const float c0 = li == 0 ? 1.0f : 0.0f;
+#pragma unroll
+              for (int i = 0; i < NV; i += 4) {
+                const float4 cv = *reinterpret_cast<const float4 *>(&cbuf[i]);
+                pv[i + 0] = fmaf(cv.x, c0, pv[i + 0]); pv[i + 1] = fmaf(cv.y, c0, pv[i + 1]);
+                pv[i + 2] = fmaf(cv.z, c0, pv[i + 2]); pv[i + 3] = fmaf(cv.w, c0, pv[i + 3]);
+              }
+            }
+            if (!(DC_T2_ABL & 4)) {
+#pragma unroll
+              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:1", m1, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+#pragma unroll
+              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:2", m2, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+#pragma unroll
+              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:4", m4, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+#pragma unroll
+              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:8", m8, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+            }
+#pragma unroll
+            for (int tp = 0; tp < T; tp++)
+              st16(r_S, srow == DC_OOB ? DC_OOB : srow + (uint32_t)(pp * C * 4 + 64 * tp),
+                   make_float4(pv[4 * tp + 0], pv[4 * tp + 1], pv[4 * tp + 2], pv[4 * tp + 3]));
+            if (cont_next && li == 15) {                // the open cell's partial sums wait in LDS for the next tile
+#pragma unroll
+              for (int i = 0; i < NV; i += 4)
+                *reinterpret_cast<float4 *>(&cbuf[i]) = make_float4(pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+            }
+          }
+          // the id-ordered record of this voxel, where the gather kernel deals from
+          st16i(r_slots, (valid && gq == 0 && !warm) ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(crd.x, crd.y, crd.z, id));
+          if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_scan += tqb - tqt; tq_tiles++; }
+          cont_prev = cont_next;
+          key = key_n;
+          crd = crd_n;
+          __builtin_amdgcn_wave_barrier();
+        };
+        uint32_t key0 = 0;
+        float4 f0[T];
+        int4 crd0 = make_int4(0, 0, 0, 0);
+        ld_rows(0, key0, f0, crd0);
+        for (int t = 0; t < ntile; t++) tile(t, key0, f0, crd0);
+      }
+      if (!hm) break;
+      // ---- a heavy cell (more than 8 voxels): its ids -> LDS, rank = number of smaller ids, list = the cell alone ----
+      hcell = __builtin_ctzll(hm);
+      hm &= hm - 1;
+      const int hc = __builtin_amdgcn_readlane(cn, hcell), hpc = __builtin_amdgcn_readlane(pc, hcell);
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < hc; e += 64) raw[e] = sid[dc_sid_off(g, hpc, e)] & DC_ID_MASK;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int e = lane; e < hc; e += 64) {
+        const uint32_t mine = raw[e];
+        int rk = 0;
+        for (int j = 0; j < hc; j++) rk += raw[j] < mine ? 1 : 0;
+        list[rk] = ((uint32_t)hcell << DC_ID_BITS) | mine;
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ptotal = hc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (dbg && lane == 0) {
+    unsigned long long *d = dbg + (size_t)wid * 8;
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    d[0] = tq1 - tq0; d[1] = tq_chunk; d[2] = tq_mfma; d[3] = tq_valu; d[4] = tq_scan; d[5] = te - tq0; d[6] = tq_tiles; d[7] = tq0;
+  }
+}
+
+template <int C, int OP, int NB>
+static int launch_t2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                     bool warm, hipStream_t st) {
+  using K = dc_t2_cfg<C, OP>;
+  const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
+  const int64_t waves = (int64_t)(b->tune.k1_wgs > 0 ? b->tune.k1_wgs : 512) * K::NW;
+  int cpw = (int)((vi + waves - 1) / waves);
+  if (cpw < 1) cpw = 1;
+  const int64_t wgs = (vi + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
+  int pad = b->tune.k1_lds_pad;
+  pad = pad < 0 ? 0 : (pad > 16384 ? 16384 : pad);
+  const int lds = K::LDS_BYTES + pad <= 160 * 1024 ? K::LDS_BYTES + pad : K::LDS_BYTES;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_tiles<C, OP, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((k_dc_tiles<C, OP, NB>), dim3((unsigned)wgs), dim3(64 * K::NW), lds, st, b->feats,
+                     reinterpret_cast<const int4 *>(b->coords), b->sid, reinterpret_cast<int4 *>(b->slots), b->cnt,
+                     b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b, b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw,
+                     warm, b->S, b->fin, b->hdr, reinterpret_cast<unsigned long long *>(b->tune.k1_dbg));
+  return check_launch("link_dc_premix_modsum");
+}
+
+template <int C, int OP>
+static int dispatch_t2_nb(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                          bool warm, hipStream_t st) {
+  constexpr int T = C / 16;
+  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
+  if (nb > T) nb = T;
+  if (T >= 2 && nb == T / 2) return launch_t2<C, OP, (T >= 2 ? T / 2 : 1)>(b, g, d, n, warm, st);
+  if (T >= 4 && nb == T / 4) return launch_t2<C, OP, (T >= 4 ? T / 4 : 1)>(b, g, d, n, warm, st);
+  return launch_t2<C, OP, T>(b, g, d, n, warm, st);    // any other grouping: every block evaluates its own theta
+}
+
+template <int C>
+static int dispatch_t2_op(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                          bool warm, hipStream_t st) {
+  switch (d.op) {
+    case LINK_OP_COS: return dispatch_t2_nb<C, LINK_OP_COS>(b, g, d, n, warm, st);
+    case LINK_OP_SIN: return dispatch_t2_nb<C, LINK_OP_SIN>(b, g, d, n, warm, st);
+    default: return dispatch_t2_nb<C, LINK_OP_COSX>(b, g, d, n, warm, st);
+  }
+}
+
+int run_tiles_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n, bool warm,
+                     hipStream_t st) {
+  switch (d.c) {
+    case 16: return dispatch_t2_op<16>(b, g, d, n, warm, st);
+    case 32: return dispatch_t2_op<32>(b, g, d, n, warm, st);
+    default: return dispatch_t2_op<64>(b, g, d, n, warm, st);
+  }
+}
+
+}  // namespace DC_IO_NS

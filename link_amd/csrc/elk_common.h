@@ -80,7 +80,8 @@ __device__ __forceinline__ void sincos_nocall(float x, float &sn, float &cs) {
 // established the range for the whole wave and must stay one basic block.
 __device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs);
 #ifndef LINK_HW_TRIG
-#define LINK_HW_TRIG 0
+#define LINK_HW_TRIG 1      /* fused dense-cell kernels: hardware trig (sincos_hw below; 4e-7 absolute, inside the path's 1e-4 bar).
+                               -DLINK_HW_TRIG=0 restores the libm-rounded polynomial (bit-identical to the general layout) */
 #endif
 __device__ __forceinline__ void sincos_small(float x, float &sn, float &cs) {
   if (LINK_HW_TRIG) { sincos_hw(x, sn, cs); return; }

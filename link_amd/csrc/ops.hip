@@ -18,7 +18,7 @@ void set_error(const char *what, hipError_t e) {
 
 using namespace link;
 
-extern "C" int link_abi_version(void) { return 3; }
+extern "C" int link_abi_version(void) { return 4; }
 extern "C" const char *link_last_error(void) { return link::g_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------

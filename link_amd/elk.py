@@ -130,8 +130,11 @@ class ElkCorePlan:
     number of SURVEY.md section 8d."""
 
     def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
-                 coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0):
+                 coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0,
+                 frames_in_flight: int = 1, **tuning):
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
+        self.frames_in_flight = max(1, int(frames_in_flight))
+        self._tuning = dict(tuning)
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
@@ -184,8 +187,33 @@ class ElkCorePlan:
         b.cnt, b.slots, b.vrec, b.vcell = self.cnt.data_ptr(), self.slots.data_ptr(), self.vrec.data_ptr(), self.vcell.data_ptr()
         b.cell_n, b.hdr, b.fin = self.cell_n.data_ptr(), self.hdr.data_ptr(), self.fin.data_ptr()
         b.S, b.A, b.out = self.S.data_ptr(), self.A.data_ptr(), self.out.data_ptr()
+        self.sid = torch.empty(vp * max(int(g.k), 8), **i32)          # voxel ids per cell (tile form of the fused pre_mix kernel)
+        b.sid = self.sid.data_ptr()
         self._fn = L.lib().link_elk_core_dense_forward
         self.m_cap = vp
+        self.set_tuning(**self._tuning)
+
+    def set_tuning(self, **kw):
+        """Launch geometry / kernel selection of THIS plan (link_dc_tuning_t; nothing is process-global).  Defaults follow
+        `frames_in_flight`: one frame alone spreads every kernel over two workgroups per CU (k1_wgs 512, z-segments by
+        the tile count); with several frames in flight the kernels of different frames share the CUs, so each takes one
+        workgroup per CU and the gather kernel 2 z-segments (fewer halo planes summed twice).  Keyword overrides:
+        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 tile form, 1 cell-range form), k2_form, mode, k1_pipe."""
+        if not self.dense:
+            if kw:
+                raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan tuning")
+            return self
+        t = self.buf.tune
+        multi = self.frames_in_flight > 1
+        t.k1_wgs, t.k2_zsplit = (256, 2) if multi else (512, 0)
+        t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = t.k1_pipe = 0
+        for k, v in kw.items():
+            if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg"):
+                raise L.LinkAmdError(f"ElkCorePlan.set_tuning: unknown key {k!r}")
+            setattr(t, k, v)
+        if t.k1_form == 1 and multi and "k1_lds_pad" not in kw:
+            t.k1_lds_pad = 2048      # cell-range form: one of its 80 KB workgroups + a gather workgroup of another frame per CU
+        return self
 
     def _init_general(self):
         device, n_cap, c = self.device, self.n_cap, self.c
@@ -1196,12 +1224,12 @@ class _ELKBase(nn.Module):
             # first visit of this coordinate set: the slot-insert kernel alone fills the per-cell counters; their
             # maximum and the number of occupied cells decide (two tiny reductions, one host round trip)
             cc = coords.contiguous()
-            L.check(L.lib().link_dc_index(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.slots.data_ptr(),
-                                          plan.vcell.data_ptr(), plan.hdr.data_ptr(), _st()), "link_dc_index")
+            L.check(L.lib().link_dc_index_ids(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.sid.data_ptr(),
+                                              plan.vcell.data_ptr(), plan.hdr.data_ptr(), _st()), "link_dc_index_ids")
             mx, m, n_in = torch.stack([plan.cnt.max(), (plan.cnt > 0).sum(), plan.cnt.sum()]).tolist()
             plan.cnt.zero_()                                   # the step below inserts again
             plan._indexed = None
-            ok = st.cmaps[okey] = bool(m > 0 and n_in <= DENSE_MAX_MEAN * m and mx <= DENSE_MAX_CELL)
+            ok = st.cmaps[okey] = bool(m > 0 and n_in <= DENSE_MAX_MEAN * m and mx <= min(DENSE_MAX_CELL, int(plan.dcg.k)))
             if not ok:
                 plan.hdr.zero_()                               # nothing of this frame stays behind in the shared plan
                 return None

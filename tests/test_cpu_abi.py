@@ -80,7 +80,8 @@ def test_argument_validation_without_gpu():
     assert lib.link_conv_out_candidate_count(i3(3, 1, 1), i3(2, 1, 1)) == 2
     assert lib.link_conv_out_candidate_count(i3(3, 3, 3), i3(1, 1, 1)) == 27
     assert lib.link_conv_out_candidates(None, 5, i3(2, 3, 3), i3(2, 2, 2), i3(1, 1, 1), i3(4, 4, 4), None, None) == L.LINK_ERR_ARG
-    assert lib.link_dc_set_tuning2(99, 0) == L.LINK_ERR_ARG
+    assert lib.link_dc_index_ids(None, 5, None, None, None, None, None, None) == L.LINK_ERR_ARG
+    assert lib.link_dc_index_ids(None, 0, ctypes.byref(L.LinkDcGrid()), None, None, None, None, None) == L.LINK_OK
 
 
 def test_grid_from_bounds_host_logic():

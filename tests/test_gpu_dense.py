@@ -9,9 +9,9 @@ from helpers import rel_err, s_uniform
 pytestmark = pytest.mark.gpu
 
 
-def _plan(la, blk, n, C, groups, baseop, r, s, bounds, layout, coord_div=1.0):
+def _plan(la, blk, n, C, groups, baseop, r, s, bounds, layout, coord_div=1.0, **tuning):
     plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, torch.device("cuda"), coord_div=coord_div,
-                          layout=layout)
+                          layout=layout, **(tuning if layout != "general" else {}))
     plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
               blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
     return plan
@@ -27,14 +27,16 @@ def _oracle(blk, feats, coords, s, r, baseop, groups):
     (64, 2, "cos", 7, 3, 80, 9000), (32, 2, "sin", 3, 2, 40, 6000), (16, 2, "cos", 7, 3, 256, 10000),
     (128, 2, "cos", 5, 3, 60, 7000), (64, 1, "cos_x", 3, 2, 36, 5000), (64, 1, "cos_x", 3, 3, 30, 4000),
     (32, 1, "cos", 4, 3, 50, 8000), (16, 1, "cos_x", 2, 2, 24, 3000), (128, 1, "cos_x", 4, 2, 40, 3000)])
-def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n):
+@pytest.mark.parametrize("k1_form", [0, 1])
+def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n, k1_form):
+    """k1_form: 0 = tile form of the fused pre_mix kernel (round 3, the default), 1 = cell-range form of round 2."""
     import link_amd as la
     torch.manual_seed(5)
     blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
     coords = s_uniform(n, grid=grid, seed=C + r).cuda()
     feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
     bounds = ((0, 0, 0, 0), (grid - 1, grid - 1, grid - 1, 0))
-    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense", k1_form=k1_form)
     general = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "general")
     assert dense.dense and not general.dense
     od = dense.run(feats, coords).clone()
@@ -52,8 +54,10 @@ def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n):
     assert int(dense.cnt.abs().sum().item()) == 0           # the counters cleaned themselves
 
 
-def test_dense_large_cells_negative_coords_batches():
-    """Cells with many voxels (selection path, > 4 per cell), negative coordinates, two batch items."""
+@pytest.mark.parametrize("k1_form", [0, 1])
+def test_dense_large_cells_negative_coords_batches(k1_form):
+    """Cells with many voxels (~80 per cell: the counting-rank pass of the tile form, the insertion path of the cell-range
+    form), negative coordinates, two batch items."""
     import link_amd as la
     torch.manual_seed(9)
     C, groups, baseop, s, r = 64, 2, "cos", 7, 3
@@ -67,10 +71,10 @@ def test_dense_large_cells_negative_coords_batches():
     n = coords.shape[0]
     feats = torch.randn(n, C, generator=torch.Generator().manual_seed(4)).cuda()
     bounds = ((-11, -11, -11, 0), (12, 12, 12, 1))
-    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
+    dense = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense", k1_form=k1_form)
     od = dense.run(feats, coords).clone()
     assert dense.blocks() > 0
-    assert int(dense.cell_n.max().item()) > 4
+    assert int(dense.cell_n.max().item()) > 8
     ref = _oracle(blk, feats, coords, s, r, baseop, groups)
     assert rel_err(od.cpu().numpy(), ref) < 1e-4
     for _ in range(3):
@@ -110,8 +114,12 @@ def test_dense_status_word_and_capacity_reuse():
     assert torch.equal(out, plan.run(feats, coords))
 
 
-def test_dense_cfg2_full_size():
-    """BASELINE.json configs[1] at full size: dense-cell vs general layout vs oracle; M = 43 334."""
+@pytest.mark.parametrize("tuning", [{}, {"k1_form": 1}, {"k1_wgs": 256, "k2_zsplit": 2}, {"k1_wgs": 256, "k2_zsplit": 2, "k1_form": 1, "k1_lds_pad": 2048},
+                                    {"k1_wgs": 1024}, {"k2_zsplit": 1}, {"k2_form": 1}])
+def test_dense_cfg2_full_size(tuning):
+    """BASELINE.json configs[1] at full size: dense-cell vs general layout vs oracle; M = 43 334 -- under every launch
+    geometry bench.py times (one frame: defaults; frames in flight: 256 workgroups + 2 z-segments (+ LDS pad on the
+    cell-range form)) and both forms of the fused pre_mix kernel."""
     import link_amd as la
     torch.manual_seed(2)
     N, C = 100_000, 64
@@ -119,7 +127,7 @@ def test_dense_cfg2_full_size():
     coords = s_uniform(N, seed=0).cuda()
     feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1)).cuda()
     bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
-    dense = _plan(la, blk, N, C, 2, "cos", 3, 7, bounds, "auto")
+    dense = _plan(la, blk, N, C, 2, "cos", 3, 7, bounds, "auto", **tuning)
     general = _plan(la, blk, N, C, 2, "cos", 3, 7, bounds, "general")
     assert dense.dense
     od, og = dense.run(feats, coords).clone(), general.run(feats, coords).clone()
@@ -187,3 +195,40 @@ def test_dense_premix_values_outside_the_fp16_split_range(C, what):
     assert rel_err(od.cpu().numpy(), og.cpu().numpy()) < 2e-5
     assert rel_err(od.cpu().numpy(), _oracle(blk, feats, coords, s, r, baseop, groups)) < 1e-4
     assert torch.equal(od, dense.run(feats, coords))
+
+
+def test_three_plans_in_flight_on_three_streams():
+    """What bench.py times: three frames in flight on separate HIP streams, each with its own plan (arena + per-plan launch
+    geometry, frames_in_flight = 3); every output equals the same plan run alone with the single-frame geometry within
+    rounding of the summation tree (bitwise where the geometry does not change the order of any sum) and sits on the
+    oracle."""
+    import link_amd as la
+    torch.manual_seed(2)
+    N, C = 100_000, 64
+    blk = la.ELKBlock(C, C, groups=2, baseop="cos").cuda().eval()
+    bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
+    frames, plans, streams = [], [], []
+    for k in range(3):
+        frames.append((torch.randn(N, C, generator=torch.Generator().manual_seed(1 + k)).cuda(), s_uniform(N, seed=k).cuda()))
+        pl = la.ElkCorePlan(N, C, "cos", 32, 3, 7, bounds, torch.device("cuda"), frames_in_flight=3)
+        pl.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+                blk.norm.weight, blk.norm.bias)
+        plans.append(pl)
+        streams.append(torch.cuda.Stream())
+    torch.cuda.synchronize()
+    for i in range(12):
+        j = i % 3
+        with torch.cuda.stream(streams[j]):
+            plans[j].run(*frames[j])
+    torch.cuda.synchronize()
+    outs = [pl.out[:N].clone() for pl in plans]
+    for pl in plans:
+        pl.check()
+    ref0 = _oracle(blk, frames[0][0], frames[0][1], 7, 3, "cos", 2)
+    assert rel_err(outs[0].cpu().numpy(), ref0) < 1e-4
+    for j in range(3):
+        alone = la.ElkCorePlan(N, C, "cos", 32, 3, 7, bounds, torch.device("cuda"))
+        alone.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+                   blk.norm.weight, blk.norm.bias)
+        o1 = alone.run(*frames[j])
+        assert rel_err(outs[j].cpu().numpy(), o1.cpu().numpy()) < 2e-6
