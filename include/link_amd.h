@@ -559,7 +559,8 @@ typedef struct {
                           gather + de-modulate (C = 64) -- the unfused stages are what the fused ones are tested against */
   int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */
   int32_t reserved;
-  uint64_t *k1_dbg;    /* bench only: device buffer u64[waves*8] for per-wave phase timings of the cell-range form; NULL = off */
+  uint64_t *k1_dbg;    /* bench only: device buffer u64[waves*8] for per-wave phase timings of the fused pre_mix kernel; NULL = off */
+  uint64_t *k2_dbg;    /* bench only: device buffer u64[workgroups*8*8] for per-wave timings of the producer / consumer gather kernel */
 } link_dc_tuning_t;
 
 typedef struct {

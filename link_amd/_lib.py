@@ -69,7 +69,7 @@ class LinkDcGrid(Structure):
 class LinkDcTuning(Structure):
     """link_dc_tuning_t: launch geometry / kernel selection of ONE plan (all zero = defaults)"""
     _fields_ = [(k, c_int32) for k in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode",
-                                       "k1_pipe", "reserved")] + [("k1_dbg", c_void_p)]
+                                       "k1_pipe", "reserved")] + [("k1_dbg", c_void_p), ("k2_dbg", c_void_p)]
 
 
 class LinkDcBuffers(Structure):

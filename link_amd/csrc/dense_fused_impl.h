@@ -1101,12 +1101,17 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ fin, const float *__restrict__ w_pos, const float *__restrict__ alpha,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n,
-    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, void *__restrict__ out, int single) {
+    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, void *__restrict__ out, int single,
+    unsigned long long *__restrict__ dbg) {
   using K2 = dc_k2_cfg<OP, R>;
   using K = typename K2::G;
   constexpr int C = 64, P = K2::P, LPR = 16, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
   constexpr int RB = P * C * 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // optional per-wave timing (tools/k2prof.py): s_memtime ticks spent waiting for the plane DMA, in the barrier, in the box
+  // sums and in the pair loop
+  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_dma = 0, tq_bar = 0, tq_box = 0, tq_pairs = 0;
+  int tq_iters = 0;
   // Producer / consumer form: waves 0-3 run the plane ring and the box sums exactly as k_dc_gather_demod does and
   // leave the A rows + counts of output plane j in LDS buffer j & 1; waves 4-7 deal plane j's voxels out as pairs
   // and finish them ONE STEP LATER, while the producers already sum plane j+1.  One barrier per step instead of
@@ -1228,6 +1233,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       const int npair = single ? Tv : (Tv + 1) >> 1;
       const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (jp & 3) * K2::REC_BYTES);
       for (int p = pstart; p < npair; p += 32) {
+        if (dbg) tq_iters++;
         const int vA = single ? p : 2 * p, vB = (!single && 2 * p + 1 < Tv) ? 2 * p + 1 : vA;
         const bool hasB = !single && 2 * p + 1 < Tv;
         const unsigned long long mA = __ballot(incl <= vA), mB = __ballot(incl <= vB);
@@ -1336,13 +1342,17 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     if (nplanes > 1) issue(1);
   }
   for (int i = 0; i <= nplanes; i++) {
+    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
     if (producer) {
       if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the A rows of the previous step are in LDS
     }
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_dma += tqb - tqa; tqa = tqb; }
     asm volatile("s_barrier" ::: "memory");
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
     if (producer && i >= nplanes) {
       if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; }
       continue;
     }
     if (producer && i + 2 < nplanes) issue(i + 2);
@@ -1351,12 +1361,12 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     const uint32_t abuf = abuf0 + (uint32_t)((j & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((j & 1) * K2::NG * 4);
     if (!producer) {
       if (j >= R - 1 && j < nplanes) pairs_of(j, grp);
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; }
       continue;
     }
     float4 cur[P];
     float cc = 0.f;
     int n_here = 0;
-    if (producer) {
 #pragma unroll
     for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
@@ -1366,9 +1376,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
     }
     n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
-    }
     if (j >= R - 1) {
-      if (producer) {
       float4 a[P];
       float den;
       if (R == 3) {
@@ -1392,18 +1400,21 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       for (int pp = 0; pp < P; pp++)
         lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
                     make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
-      const int n_cell = (R == 3) ? n_prev : n_prev;   // the plane that closed is the previous one for both R
-      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_cell : 0);
-      }
+      if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_prev : 0);   // the plane that closed is the previous one for both R
     }
-    {
 #pragma unroll
-      for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
-      c0 = c1; c1 = cc;
-      n_prev = n_here;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
-    }
+    for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
+    c0 = c1; c1 = cc;
+    n_prev = n_here;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_box += tqb - tqa; tqa = tqb; }
+    if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; }
+  }
+  if (dbg && lane == 0) {
+    unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    d[0] = te - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_box; d[4] = tq_pairs; d[5] = tq_iters; d[6] = nplanes; d[7] = producer ? 1 : 2;
   }
 }
 
@@ -1435,7 +1446,8 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, K2::SPLIT_LDS_BYTES + k2_pad);        \
     hipLaunchKernelGGL((k_dc_gather_demod_split<OP, R, PP, DD>), dim3((unsigned)grid), dim3(512), K2::SPLIT_LDS_BYTES + k2_pad, st, \
                        b->S, b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w, \
-                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, k2_single);     \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, k2_single,       \
+                       reinterpret_cast<unsigned long long *>(b->tune.k2_dbg));                                       \
   } while (0)
   if (!(b->tune.k2_form & 1) && K2::SPLIT_FITS) {
     if (pair) { if (div) LINK_K2S(true, true); else LINK_K2S(true, false); }

@@ -27,7 +27,12 @@
 #include "dense_io.h"
 
 #ifndef DC_T2_WAVES
-#define DC_T2_WAVES 4     /* register budget = 512 / this */
+#define DC_T2_WAVES 3     /* register budget = 512 / this; at 4 (128 registers) the tile body spills 40 of them */
+#endif
+#ifndef DC_T2_X1
+#define DC_T2_X1 0
+#define DC_T2_X2 0
+#define DC_T2_X3 0
 #endif
 #ifndef DC_T2_ABL
 #define DC_T2_ABL 0       /* ablation builds (wrong results!): 1 no MFMA, 2 no sincos, 4 no segmented scan, 8 no S stores */
@@ -68,6 +73,21 @@ struct dc_t2_cfg {
                "v_fmac_f32_dpp %3, %3, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"     \
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d)                                           \
                : "v"(m))
+
+// v + v[lane ^ 16] + v[lane ^ 32] + v[lane ^ 48]: the four lane groups of a voxel, through the gfx950 row swaps (VALU; a
+// __shfl_xor is an LDS round trip each).  v_permlane32_swap exchanges the upper half of one operand with the lower half
+// of the other, v_permlane16_swap the odd rows of one with the even rows of the other: with both operands = v, the two
+// results hold {own, partner} in some order, so their sum is the butterfly step.
+__device__ __forceinline__ float dc_sum_groups(float v) {
+  // inline asm: hipcc (ROCm 7.2) returns the first result of __builtin_amdgcn_permlane{16,32}_swap for both elements;
+  // the instruction itself rewrites BOTH of its operands.  s_nop: VALU write -> permlane read hazard
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a += b;
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 
 template <int CTRL>
 __device__ __forceinline__ int dc_dpp_i(int v, int oob) {      // lanes without a source keep `oob`
@@ -154,6 +174,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
       pw_lds[3 * C + tid] = alpha ? alpha[tc] : 1.0f;
     }
   }
+  for (int i = lane; i < K::CARRY_BYTES / 4; i += 64) carry[i] = 0.f;     // read unconditionally by every tile (times 0 unless a cell straddles)
   if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
@@ -188,27 +209,30 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
       dc_split4(ff[tt], bh[tt], bl[tt]);
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ff[tt].x), fabsf(ff[tt].y)), fmaxf(fabsf(ff[tt].z), fabsf(ff[tt].w))));
     }
-    if (__builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
+    if (DC_T2_X1 || __builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
       if constexpr (T % 2 == 0) {
+        // two output blocks x two input-block pairs at a time: 8 operand pieces (16 registers) in flight instead of 4T
 #pragma unroll
-        for (int tt = 0; tt < T; tt += 2) {
-          uint2 ah[2][T], al[2][T];
+        for (int tq = 0; tq < T; tq += 2)
 #pragma unroll
-          for (int h = 0; h < 2; h++)
+          for (int tt = 0; tt < T; tt += 2) {
+            uint2 ah[2][2], al[2][2];
 #pragma unroll
-            for (int tp = 0; tp < T; tp++) {
-              ah[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + 16 * (tt + h) + 4 * gq]);
-              al[h][tp] = *reinterpret_cast<const uint2 *>(&wh[(16 * tp + li) * K::LDH + C + 16 * (tt + h) + 4 * gq]);
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+              for (int u = 0; u < 2; u++) {
+                ah[h][u] = *reinterpret_cast<const uint2 *>(&wh[(16 * (tq + u) + li) * K::LDH + 16 * (tt + h) + 4 * gq]);
+                al[h][u] = *reinterpret_cast<const uint2 *>(&wh[(16 * (tq + u) + li) * K::LDH + C + 16 * (tt + h) + 4 * gq]);
+              }
+#pragma unroll
+            for (int u = 0; u < 2; u++) cc[tq + u] = dc_mfma_f16x2(al[0][u], al[1][u], bh[tt], bh[tt + 1], cc[tq + u]);
+            if constexpr (IO != 1) {
+#pragma unroll
+              for (int u = 0; u < 2; u++) cc[tq + u] = dc_mfma_f16x2(ah[0][u], ah[1][u], bl[tt], bl[tt + 1], cc[tq + u]);
             }
 #pragma unroll
-          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(al[0][tp], al[1][tp], bh[tt], bh[tt + 1], cc[tp]);
-          if constexpr (IO != 1) {
-#pragma unroll
-            for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bl[tt], bl[tt + 1], cc[tp]);
+            for (int u = 0; u < 2; u++) cc[tq + u] = dc_mfma_f16x2(ah[0][u], ah[1][u], bh[tt], bh[tt + 1], cc[tq + u]);
           }
-#pragma unroll
-          for (int tp = 0; tp < T; tp++) cc[tp] = dc_mfma_f16x2(ah[0][tp], ah[1][tp], bh[tt], bh[tt + 1], cc[tp]);
-        }
       } else {
 #pragma unroll
         for (int tt = 0; tt < T; tt++) {
@@ -331,6 +355,8 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
           floatx4 ac[T];
           mfma_tile(ff, ac);
           if (dbg) { asm volatile("s_nop 0" :: "v"(ac[0][0])); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_mfma += tqb - tqt; tqt = tqb; }
+          // the id-ordered record of this voxel, where the gather kernel deals from
+          st16i(r_slots, (valid && gq == 0 && !warm) ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(crd.x, crd.y, crd.z, id));
           // theta of this voxel's blocks
           float x = (float)crd.x, y = (float)crd.y, z = (float)crd.z;
           if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
@@ -347,7 +373,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
 #pragma unroll
             for (int r = 0; r < 4; r++) big |= !(fabsf(th[tb][r]) < 32768.0f);
           }
-          if (__builtin_expect(__any(big), 0)) {        // never on sane inputs
+          if (!DC_T2_X2 && __builtin_expect(__any(big), 0)) {        // never on sane inputs
 #pragma unroll
             for (int tb = 0; tb < NB; tb++)
 #pragma unroll
@@ -365,8 +391,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
           float s = 0.f;
 #pragma unroll
           for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
+          s = dc_sum_groups(s);
           const float mean = s * (1.0f / C);
           float qq = 0.f;
 #pragma unroll
@@ -376,26 +401,9 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
               const float d = ac[tp][r] - mean;
               qq += d * d;
             }
-          qq += __shfl_xor(qq, 16, 64);
-          qq += __shfl_xor(qq, 32, 64);
+          qq = dc_sum_groups(qq);
           const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
-          float fv[NV];
-#pragma unroll
-          for (int tp = 0; tp < T; tp++) {
-            const float4 lw = *reinterpret_cast<const float4 *>(&ln_lds[16 * tp + 4 * gq]);
-            const float4 lb = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * tp + 4 * gq]);
-            fv[4 * tp + 0] = (ac[tp][0] - mean) * rstd * lw.x + lb.x; fv[4 * tp + 1] = (ac[tp][1] - mean) * rstd * lw.y + lb.y;
-            fv[4 * tp + 2] = (ac[tp][2] - mean) * rstd * lw.z + lb.z; fv[4 * tp + 3] = (ac[tp][3] - mean) * rstd * lw.w + lb.w;
-            if (OP == LINK_OP_COSX)                     // the de-modulation of cos_x needs fin (linkunet.py:176)
-              st16(r_fin, valid ? (uint32_t)id * (uint32_t)(C * 4) + (uint32_t)((16 * tp + 4 * gq) * 4) : DC_OOB,
-                   make_float4(fv[4 * tp + 0], fv[4 * tp + 1], fv[4 * tp + 2], fv[4 * tp + 3]));
-          }
-          if (dbg) { asm volatile("s_nop 0" :: "v"(fv[0])); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_valu += tqb - tqt; tqt = tqb; }
-          __builtin_amdgcn_sched_barrier(0);
-          uint32_t key_n;
-          int4 crd_n;
-          ld_rows(t + 1, key_n, ff, crd_n);             // clamped to the list's last entry beyond its end
-          __builtin_amdgcn_sched_barrier(0);
+          if (dbg) { asm volatile("s_nop 0" :: "v"(rstd)); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_valu += tqb - tqt; tqt = tqb; }
           // ---- segments of the DPP row: lanes li of one cell are adjacent (the list is cell-major); slots beyond the
           // list's end form segments of their own that are never stored ----
           const int ckey = valid ? cl : 64 + li;
@@ -406,57 +414,71 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
           seg = max(seg, dc_dpp_i<0x112>(seg, 0));
           seg = max(seg, dc_dpp_i<0x114>(seg, 0));
           seg = max(seg, dc_dpp_i<0x118>(seg, 0));
-          const float m1 = (li - 1 >= seg) ? 1.0f : 0.0f, m2 = (li - 2 >= seg) ? 1.0f : 0.0f;
-          const float m4 = (li - 4 >= seg) ? 1.0f : 0.0f, m8 = (li - 8 >= seg) ? 1.0f : 0.0f;
+          const int soff = li - seg;                                  // position of this lane's voxel inside its segment
+          const float m1 = soff >= 1 ? 1.0f : 0.0f, m2 = soff >= 2 ? 1.0f : 0.0f;
+          const float m4 = soff >= 4 ? 1.0f : 0.0f, m8 = soff >= 8 ? 1.0f : 0.0f;
+          // most cells hold one to four voxels: the stride-4 / stride-8 steps run only for tiles that have such a segment
+          const bool step4 = __any(soff >= 4), step8 = __any(soff >= 8);
           const bool closes = valid && (li == 15 ? !cont_next : nextk != ckey);
           const uint32_t srow = closes && !(DC_T2_ABL & 8) ? (uint32_t)pcell * (uint32_t)K::RB + (uint32_t)(16 * gq) : DC_OOB;
-          // one part at a time (cos | sin | theta): modulate, carry in, segmented scan, store, carry out
+          const float cin = (cont_prev && li == 0) ? 1.0f : 0.0f;
+          // the next tile's rows are requested here: they land while the blocks below are normalised, modulated and summed
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t key_n;
+          int4 crd_n;
+          ld_rows(t + 1, key_n, ff, crd_n);             // clamped to the list's last entry beyond its end
+          __builtin_amdgcn_sched_barrier(0);
+          // one 16-channel block (4 values per lane) and one part (cos | sin | theta) at a time: normalise, modulate,
+          // carry in, segmented scan, store, carry out -- 8 live values instead of 2 x 4T
+          // LayerNorm weights and the carried partial sums of block tp+1 are requested before block tp is worked on: the
+          // LDS round trips hide behind the scans instead of heading every block
+          float4 lw_n = *reinterpret_cast<const float4 *>(&ln_lds[4 * gq]);
+          float4 lb_n = *reinterpret_cast<const float4 *>(&ln_lds[C + 4 * gq]);
+          float4 cv_n[P];
 #pragma unroll
-          for (int pp = 0; pp < P; pp++) {
-            float pv[NV];
+          for (int pp = 0; pp < P; pp++) cv_n[pp] = *reinterpret_cast<const float4 *>(carry + (pp * 4 + gq) * NV);
 #pragma unroll
-            for (int tp = 0; tp < T; tp++) {
-              const int tb = tp % NB;
+          for (int tp = 0; tp < T; tp++) {
+            const int tb = tp % NB;
+            const float4 lw = lw_n, lb = lb_n;
+            float4 cv[P];
+#pragma unroll
+            for (int pp = 0; pp < P; pp++) cv[pp] = cv_n[pp];
+            if (tp + 1 < T) {
+              lw_n = *reinterpret_cast<const float4 *>(&ln_lds[16 * (tp + 1) + 4 * gq]);
+              lb_n = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * (tp + 1) + 4 * gq]);
+#pragma unroll
+              for (int pp = 0; pp < P; pp++) cv_n[pp] = *reinterpret_cast<const float4 *>(carry + (pp * 4 + gq) * NV + 4 * (tp + 1));
+            }
+            const float fv[4] = {(ac[tp][0] - mean) * rstd * lw.x + lb.x, (ac[tp][1] - mean) * rstd * lw.y + lb.y,
+                                 (ac[tp][2] - mean) * rstd * lw.z + lb.z, (ac[tp][3] - mean) * rstd * lw.w + lb.w};
+            if (OP == LINK_OP_COSX)                     // the de-modulation of cos_x needs fin (linkunet.py:176)
+              st16(r_fin, valid ? (uint32_t)id * (uint32_t)(C * 4) + (uint32_t)((16 * tp + 4 * gq) * 4) : DC_OOB,
+                   make_float4(fv[0], fv[1], fv[2], fv[3]));
+#pragma unroll
+            for (int pp = 0; pp < P; pp++) {
+              float pv[4];
 #pragma unroll
               for (int r = 0; r < 4; r++) {
-                const float f = fv[4 * tp + r];
-                if (pp == 2) pv[4 * tp + r] = f * th[tb][r];
-                else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[4 * tp + r] = f * sn[tb][r];
-                else pv[4 * tp + r] = f * cs[tb][r];
+                if (pp == 2) pv[r] = fv[r] * th[tb][r];
+                else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[r] = fv[r] * sn[tb][r];
+                else pv[r] = fv[r] * cs[tb][r];
               }
-            }
-            float *cbuf = carry + (pp * 4 + gq) * NV;
-            if (cont_prev) {                            // wave-uniform: only lane 0 of the row takes the carry (the scan spreads it)
-              const float c0 = li == 0 ? 1.0f : 0.0f;
-#pragma unroll
-              for (int i = 0; i < NV; i += 4) {
-                const float4 cv = *reinterpret_cast<const float4 *>(&cbuf[i]);
-                pv[i + 0] = fmaf(cv.x, c0, pv[i + 0]); pv[i + 1] = fmaf(cv.y, c0, pv[i + 1]);
-                pv[i + 2] = fmaf(cv.z, c0, pv[i + 2]); pv[i + 3] = fmaf(cv.w, c0, pv[i + 3]);
+              // lane 0 of the row takes the partial sum the previous tile left open (cin = 0 otherwise; stale LDS content
+              // is finite: the buffer is zeroed at kernel start), the scan spreads it over the cell's lanes
+              pv[0] = fmaf(cv[pp].x, cin, pv[0]); pv[1] = fmaf(cv[pp].y, cin, pv[1]);
+              pv[2] = fmaf(cv[pp].z, cin, pv[2]); pv[3] = fmaf(cv[pp].w, cin, pv[3]);
+              if (!(DC_T2_ABL & 4)) {
+                DC_SCAN4("row_shr:1", m1, pv[0], pv[1], pv[2], pv[3]);
+                DC_SCAN4("row_shr:2", m2, pv[0], pv[1], pv[2], pv[3]);
+                if (step4) DC_SCAN4("row_shr:4", m4, pv[0], pv[1], pv[2], pv[3]);
+                if (step8) DC_SCAN4("row_shr:8", m8, pv[0], pv[1], pv[2], pv[3]);
               }
-            }
-            if (!(DC_T2_ABL & 4)) {
-#pragma unroll
-              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:1", m1, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
-#pragma unroll
-              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:2", m2, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
-#pragma unroll
-              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:4", m4, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
-#pragma unroll
-              for (int i = 0; i < NV; i += 4) DC_SCAN4("row_shr:8", m8, pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
-            }
-#pragma unroll
-            for (int tp = 0; tp < T; tp++)
-              st16(r_S, srow == DC_OOB ? DC_OOB : srow + (uint32_t)(pp * C * 4 + 64 * tp),
-                   make_float4(pv[4 * tp + 0], pv[4 * tp + 1], pv[4 * tp + 2], pv[4 * tp + 3]));
-            if (cont_next && li == 15) {                // the open cell's partial sums wait in LDS for the next tile
-#pragma unroll
-              for (int i = 0; i < NV; i += 4)
-                *reinterpret_cast<float4 *>(&cbuf[i]) = make_float4(pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+              st16(r_S, srow == DC_OOB ? DC_OOB : srow + (uint32_t)(pp * C * 4 + 64 * tp), make_float4(pv[0], pv[1], pv[2], pv[3]));
+              if (cont_next && li == 15)                // the open cell's partial sums wait in LDS for the next tile
+                *reinterpret_cast<float4 *>(carry + (pp * 4 + gq) * NV + 4 * tp) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             }
           }
-          // the id-ordered record of this voxel, where the gather kernel deals from
-          st16i(r_slots, (valid && gq == 0 && !warm) ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(crd.x, crd.y, crd.z, id));
           if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_scan += tqb - tqt; tq_tiles++; }
           cont_prev = cont_next;
           key = key_n;
@@ -469,7 +491,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
         ld_rows(0, key0, f0, crd0);
         for (int t = 0; t < ntile; t++) tile(t, key0, f0, crd0);
       }
-      if (!hm) break;
+      if (DC_T2_X3 || !hm) break;
       // ---- a heavy cell (more than 8 voxels): its ids -> LDS, rank = number of smaller ids, list = the cell alone ----
       hcell = __builtin_ctzll(hm);
       hm &= hm - 1;
@@ -507,7 +529,7 @@ static int launch_t2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   if (cpw < 1) cpw = 1;
   const int64_t wgs = (vi + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
   int pad = b->tune.k1_lds_pad;
-  pad = pad < 0 ? 0 : (pad > 16384 ? 16384 : pad);
+  pad = pad < 0 ? 0 : (pad > 65536 ? 65536 : pad);
   const int lds = K::LDS_BYTES + pad <= 160 * 1024 ? K::LDS_BYTES + pad : K::LDS_BYTES;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_tiles<C, OP, NB>),

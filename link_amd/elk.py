@@ -208,7 +208,7 @@ class ElkCorePlan:
         t.k1_wgs, t.k2_zsplit = (256, 2) if multi else (512, 0)
         t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = t.k1_pipe = 0
         for k, v in kw.items():
-            if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg"):
+            if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg", "k2_dbg"):
                 raise L.LinkAmdError(f"ElkCorePlan.set_tuning: unknown key {k!r}")
             setattr(t, k, v)
         if t.k1_form == 1 and multi and "k1_lds_pad" not in kw:

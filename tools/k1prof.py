@@ -51,14 +51,15 @@ def k1_time(p, iters=60):
     return v[len(v) // 2], w[len(w) // 2]
 
 
-for form in (0, 1):
-    for wgs in (256, 384, 512, 768, 1024, 2048):
-        p = plan(k1_form=form, k1_wgs=wgs)
-        k1, k2 = k1_time(p)
-        print(f"k1_form {form} k1_wgs {wgs:5d}: K1 {k1:6.2f} us   K2 {k2:6.2f} us")
+for wgs, pad in ((512, 0), (512, 20000), (512, 45056), (768, 0), (768, 18000), (1024, 0), (1024, 5000)):
+    p = plan(k1_form=0, k1_wgs=wgs, k1_lds_pad=pad)
+    k1, k2 = k1_time(p)
+    print(f"tile form k1_wgs {wgs:5d} lds pad {pad:6d}: K1 {k1:6.2f} us   K2 {k2:6.2f} us")
+p = plan(k1_form=1, k1_wgs=512)
+print("cell-range form 512: K1 %.2f K2 %.2f" % k1_time(p))
 
-for wgs in (256, 512, 1024):
-    p = plan(k1_form=0, k1_wgs=wgs)
+for wgs, pad in ((512, 0), (512, 45056), (768, 18000)):
+    p = plan(k1_form=0, k1_wgs=wgs, k1_lds_pad=pad)
     dbg = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
     p.buf.tune.k1_dbg = dbg.data_ptr()
     for _ in range(3):
@@ -67,7 +68,7 @@ for wgs in (256, 512, 1024):
     d = dbg.view(-1, 8).cpu().numpy()
     d = d[d[:, 5] > 0]
     names = ["W staging", "chunk section", "mfma (+row wait)", "theta/sincos/LN", "scan+stores", "total"]
-    print(f"tile form, k1_wgs {wgs}: {len(d)} waves; s_memtime ticks per wave (mean / p50 / max), tiles per wave {d[:, 6].mean():.2f}")
+    print(f"tile form, k1_wgs {wgs} pad {pad}: {len(d)} waves; s_memtime ticks per wave (mean / p50 / max), tiles per wave {d[:, 6].mean():.2f}")
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {d[:, i].mean():9.0f} {np.median(d[:, i]):9.0f} {d[:, i].max():9.0f}")
     tl = d[:, 6].sum()
