@@ -184,19 +184,18 @@ def timed_regions(la, blk, feats, coords, C, s, r, iters=30):
 def cfg3_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[2] shape (labelled, NOT the headline): the encoder common to both segmentation models
     (stem -> 4 x [k2-s2 down, 2 residual blocks + tail || ELKBlock cos_x (2x3)^3 + tail, add/ReLU],
-    linkencoder.py:186-368; assembled in tests/link_encoder.py from link_amd modules) on one S-kitti frame per
+    linkencoder.py:186-368; assembled in link_amd/networks.py from link_amd modules) on one S-kitti frame per
     rank (link_amd/synth.py, seed = rank; full size, ~113k voxels), warm kernel maps.  A step = one eval
     forward; the line also carries forward+backward (sum-of-squares loss on stage 4) and the time inside the
     four ELK blocks."""
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import link_encoder as LE
+    from link_amd import networks as LE
     from link_amd.synth import s_kitti, block_stats
     co, fe = s_kitti(seed=rank)
     coords, feats = torch.from_numpy(co).to(dev), torch.from_numpy(fe).to(dev)
     n = coords.shape[0]
     torch.manual_seed(0)
-    # the reference's ELKEncoder encoder half, class by class (tests/link_encoder.py mirrors linkencoder.py:186-290
+    # the reference's ELKEncoder encoder half, class by class (link_amd/networks.py mirrors linkencoder.py:186-290
     # with the reference's attribute names), its Conv3d -> BatchNorm -> ReLU runs fused for inference
     net = la.fuse_for_inference(LE.build_reference_shaped_encoder(la, 64, "cos_x", 1)).to(dev)
     net.elk = [getattr(net, f"elk{i}") for i in (1, 2, 3, 4)]
@@ -280,8 +279,7 @@ def cfg4_mode(args, la, dev, rank, world, dist):
     result gather").  A step = the whole batch once: every rank runs the encoder half of ELKEncoder (eval forward,
     Conv-BN-ReLU fused) on its frames, kernel maps built per frame as the reference does."""
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import link_encoder as LE
+    from link_amd import networks as LE
     from link_amd.parallel import gather_frame_rows, shard_frames
     from link_amd.synth import s_kitti
     mine = shard_frames(8, world, rank)
@@ -537,8 +535,11 @@ def main():
         elapsed_warm = float(rows[:, 5].max())
         elapsed_single = float(rows[:, 6].max())
         total_vox = float(rows[:, 1].sum())
+        rank_rows = [{"rank": int(r[0]), "voxels": int(r[1]), "blocks": int(r[2]), "checksum": float(r[3])}
+                     for r in rows[rows[:, 0].argsort()].tolist()]
     else:
         total_vox = float(N)
+        rank_rows = [{"rank": 0, "voxels": N, "blocks": int(M), "checksum": checksum}]
 
     if rank != 0:
         if world > 1:
@@ -657,6 +658,7 @@ def main():
         "single_stream_value": round(total_vox * args.steps / elapsed_single, 1),
         "warm_index_value": round(total_vox * args.steps / elapsed_warm, 1),
         "timed_configuration_check": timed_check,
+        "ranks": rank_rows,          # the trivial result gather: one summary row per rank (frame 0 of each rank)
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
     }
     print(json.dumps(line))

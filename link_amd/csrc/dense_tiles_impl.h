@@ -53,7 +53,7 @@ struct dc_t2_cfg {
   static constexpr int LIST_N = 512;                   // 64 cells x 8 inline ids
   static constexpr int DUMP_N = 16;                    // where the writes of empty id slots go
   static constexpr int RAW_N = 352;                    // ids of one heavy cell (k <= 352, as the cell-range form)
-  static constexpr int LIST_BYTES = (LIST_N + DUMP_N + RAW_N) * 4;
+  static constexpr int LIST_BYTES = (LIST_N + DUMP_N) * 8 + RAW_N * 4;   // list entries: (chunk lane << 26 | voxel id, padded cell id)
   static constexpr int CARRY_BYTES = P * C * 4;        // open cell at a tile boundary: 4 lane groups x P parts x C/4 values
   static constexpr int WAVE_BYTES = LIST_BYTES + CARRY_BYTES;
   static constexpr int NW = 4;
@@ -113,8 +113,8 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, gq = lane >> 4;
   char *wbase = smem_raw + K::W_BYTES + wave * K::WAVE_BYTES;
-  uint32_t *list = reinterpret_cast<uint32_t *>(wbase);
-  uint32_t *raw = list + K::LIST_N + K::DUMP_N;
+  uint2 *list = reinterpret_cast<uint2 *>(wbase);
+  uint32_t *raw = reinterpret_cast<uint32_t *>(list + K::LIST_N + K::DUMP_N);
   float *carry = reinterpret_cast<float *>(wbase + K::LIST_BYTES);
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
   const int Vi = Dx * Dy * Dz * g.dim[3];
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
     const int total = __builtin_amdgcn_readlane(incl, 63);
 #pragma unroll
     for (int j = 0; j < 8; j++)
-      list[j < nreg ? excl + j : K::LIST_N + (lane & (K::DUMP_N - 1))] = ((uint32_t)lane << DC_ID_BITS) | ks[j];
+      list[j < nreg ? excl + j : K::LIST_N + (lane & (K::DUMP_N - 1))] = make_uint2(((uint32_t)lane << DC_ID_BITS) | ks[j], (uint32_t)pc);
     {                                                   // publish the counts, reset the counters
       const uint32_t coff = (act && !warm) ? (uint32_t)pc * 4u : DC_OOB;
       st4i(r_n, coff, cn);
@@ -324,10 +324,13 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
       if (ptotal > 0) {
         const int ntile = (ptotal + 15) >> 4;
         bool cont_prev = false;                         // the tile's first voxels continue the cell the previous tile ended in
-        auto ld_rows = [&](int t, uint32_t &key, float4 (&ff)[T], int4 &crd) {
+        int rank_carry = 0;                             // ... and this many of that cell's voxels came before this tile
+        auto ld_rows = [&](int t, uint32_t &key, int &pcell, float4 (&ff)[T], int4 &crd) {
           int sl = 16 * t + li;
           sl = sl < ptotal ? sl : ptotal - 1;
-          key = list[sl];
+          const uint2 e = list[sl];
+          key = e.x;
+          pcell = (int)e.y;
           const int id = (int)(key & DC_ID_MASK);
           const v4i_t cr = __builtin_amdgcn_raw_buffer_load_b128(r_coords, (uint32_t)id * 16u, 0, 0);
           crd = make_int4(cr.x, cr.y, cr.z, cr.w);
@@ -338,25 +341,20 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
         };
         // one tile: the rows are dead once the matrix cores have them, so the NEXT tile's rows are requested into the same
         // registers right after the contraction and land while this tile's LayerNorm / sincos / scan run
-        auto tile = [&](int t, uint32_t &key, float4 (&ff)[T], int4 &crd) {
+        auto tile = [&](int t, uint32_t &key, int &pcell, float4 (&ff)[T], int4 &crd) {
           const int pos = 16 * t + li;
           const bool valid = pos < ptotal;
           const int id = (int)(key & DC_ID_MASK), cl = (int)(key >> DC_ID_BITS);
-          // does the cell of the tile's last voxel go on in the next tile?
-          bool cont_next = false;
-          if (16 * t + 16 < ptotal) {                   // wave-uniform
-            const uint32_t kn = list[16 * t + 16];
-            cont_next = __builtin_amdgcn_readfirstlane((int)(kn >> DC_ID_BITS)) == __builtin_amdgcn_readlane(cl, 15);
-          }
-          // padded cell id and rank inside the cell of this lane's voxel
-          const int pcell = hcell >= 0 ? __builtin_amdgcn_readlane(pc, hcell) : __shfl(pc, cl, 64);
-          const int rank = hcell >= 0 ? pos : pos - __shfl(excl, cl, 64);
           unsigned long long tqt = dbg ? __builtin_amdgcn_s_memtime() : 0;
           floatx4 ac[T];
           mfma_tile(ff, ac);
+          // the rows are dead once the matrix cores have them: the next tile's rows are requested into the same registers
+          // and land while this tile's theta / sincos / LayerNorm / scans run
+          uint32_t key_n;
+          int pcell_n;
+          int4 crd_n;
+          ld_rows(t + 1, key_n, pcell_n, ff, crd_n);    // clamped to the list's last entry beyond its end
           if (dbg) { asm volatile("s_nop 0" :: "v"(ac[0][0])); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_mfma += tqb - tqt; tqt = tqb; }
-          // the id-ordered record of this voxel, where the gather kernel deals from
-          st16i(r_slots, (valid && gq == 0 && !warm) ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(crd.x, crd.y, crd.z, id));
           // theta of this voxel's blocks
           float x = (float)crd.x, y = (float)crd.y, z = (float)crd.z;
           if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
@@ -419,15 +417,16 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
           const float m4 = soff >= 4 ? 1.0f : 0.0f, m8 = soff >= 8 ? 1.0f : 0.0f;
           // most cells hold one to four voxels: the stride-4 / stride-8 steps run only for tiles that have such a segment
           const bool step4 = __any(soff >= 4), step8 = __any(soff >= 8);
+          const float cin = (cont_prev && li == 0) ? 1.0f : 0.0f;
+          // the id-ordered record of this voxel, where the gather kernel deals from: rank inside the cell = position in the
+          // segment (+ what previous tiles held of a cell that straddles)
+          const int rank = soff + ((cont_prev && seg == 0) ? rank_carry : 0);
+          st16i(r_slots, (valid && gq == 0 && !warm) ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(crd.x, crd.y, crd.z, id));
+          // does the cell of the tile's last voxel go on in the next tile?  (its first entry is lane 0 of the prefetched keys)
+          const bool cont_next = 16 * t + 16 < ptotal &&
+                                 (int)((uint32_t)__builtin_amdgcn_readlane((int)key_n, 0) >> DC_ID_BITS) == __builtin_amdgcn_readlane(cl, 15);
           const bool closes = valid && (li == 15 ? !cont_next : nextk != ckey);
           const uint32_t srow = closes && !(DC_T2_ABL & 8) ? (uint32_t)pcell * (uint32_t)K::RB + (uint32_t)(16 * gq) : DC_OOB;
-          const float cin = (cont_prev && li == 0) ? 1.0f : 0.0f;
-          // the next tile's rows are requested here: they land while the blocks below are normalised, modulated and summed
-          __builtin_amdgcn_sched_barrier(0);
-          uint32_t key_n;
-          int4 crd_n;
-          ld_rows(t + 1, key_n, ff, crd_n);             // clamped to the list's last entry beyond its end
-          __builtin_amdgcn_sched_barrier(0);
           // one 16-channel block (4 values per lane) and one part (cos | sin | theta) at a time: normalise, modulate,
           // carry in, segmented scan, store, carry out -- 8 live values instead of 2 x 4T
           // LayerNorm weights and the carried partial sums of block tp+1 are requested before block tp is worked on: the
@@ -480,16 +479,22 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
             }
           }
           if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_scan += tqb - tqt; tq_tiles++; }
+          if (cont_next) {                              // wave-uniform
+            const int seg15 = __builtin_amdgcn_readlane(seg, 15);
+            rank_carry = 16 - seg15 + ((cont_prev && seg15 == 0) ? rank_carry : 0);
+          }
           cont_prev = cont_next;
           key = key_n;
+          pcell = pcell_n;
           crd = crd_n;
           __builtin_amdgcn_wave_barrier();
         };
         uint32_t key0 = 0;
+        int pcell0 = 0;
         float4 f0[T];
         int4 crd0 = make_int4(0, 0, 0, 0);
-        ld_rows(0, key0, f0, crd0);
-        for (int t = 0; t < ntile; t++) tile(t, key0, f0, crd0);
+        ld_rows(0, key0, pcell0, f0, crd0);
+        for (int t = 0; t < ntile; t++) tile(t, key0, pcell0, f0, crd0);
       }
       if (DC_T2_X3 || !hm) break;
       // ---- a heavy cell (more than 8 voxels): its ids -> LDS, rank = number of smaller ids, list = the cell alone ----
@@ -504,7 +509,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
         const uint32_t mine = raw[e];
         int rk = 0;
         for (int j = 0; j < hc; j++) rk += raw[j] < mine ? 1 : 0;
-        list[rk] = ((uint32_t)hcell << DC_ID_BITS) | mine;
+        list[rk] = make_uint2(((uint32_t)hcell << DC_ID_BITS) | mine, (uint32_t)hpc);
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

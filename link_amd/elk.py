@@ -836,8 +836,8 @@ class _PairPlan:
 def _pair_plan(nbr: torch.Tensor, cin: int, cout: int) -> Optional[_PairPlan]:
     """The table's pair plan when the pair-list kernels should run it (sparse neighbourhoods, supported
     widths), else None; built once per table and cached on the (kmaps-cached) table tensor."""
-    if not L.lib().link_conv_pairs_supported(cin, cout):
-        return None
+    if not L.lib().link_conv_pairs_supported(cin, cout) or nbr.shape[1] > 64:
+        return None                 # the pair plan holds one 64-bit offset mask per voxel: 5^3 / 7^3 kernels run the table kernel
     plan = getattr(nbr, "_link_pairs", False)
     if plan is False:
         plan = _PairPlan(nbr)

@@ -109,60 +109,4 @@ def oracle_stages(lo, sd, feats, coords, s, r, baseop="cos_x", groups=1, n_stage
     return outs
 
 
-def build_reference_shaped_encoder(la, c=16, baseop="cos_x", groups=1):
-    """The encoder half of the reference's ELKEncoder (linkencoder.py:186-290) from link_amd modules with the
-    reference's attribute names, so that the reference's own state_dict loads with strict=True
-    (tests/golden/g_encoder_*.npz).  Forward = linkencoder.py:339-368 up to x4."""
-    spnn = la
-
-    class BasicConvolutionBlock(nn.Module):                      # linkencoder.py:23-39
-        def __init__(self, inc, outc, ks=3, stride=1):
-            super().__init__()
-            self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=ks, stride=stride), spnn.BatchNorm(outc),
-                                     spnn.ReLU(True))
-
-        def forward(self, x):
-            return self.net(x)
-
-    class ResidualBlock(nn.Module):                              # linkencoder.py:61-92
-        def __init__(self, inc, outc, ks=3):
-            super().__init__()
-            self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=ks, stride=1), spnn.BatchNorm(outc),
-                                     spnn.ReLU(True), spnn.Conv3d(outc, outc, kernel_size=ks, stride=1),
-                                     spnn.BatchNorm(outc))
-            self.downsample = nn.Sequential() if inc == outc else nn.Sequential(
-                spnn.Conv3d(inc, outc, kernel_size=1, stride=1), spnn.BatchNorm(outc))
-            self.relu = spnn.ReLU(True)
-
-        def forward(self, x):
-            y = self.net(x)
-            sc = self.downsample(x)
-            out = la.SparseTensor(y.F + sc.F, y.C, y.s)
-            out.cmaps, out.kmaps = x.cmaps, x.kmaps
-            return self.relu(out)
-
-    class Encoder(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.stem = nn.Sequential(spnn.Conv3d(4, c, kernel_size=3, stride=1), spnn.BatchNorm(c), spnn.ReLU(True),
-                                      spnn.Conv3d(c, c, kernel_size=3, stride=1), spnn.BatchNorm(c), spnn.ReLU(True))
-            for i in (1, 2, 3, 4):
-                setattr(self, f"down{i}", nn.Sequential(BasicConvolutionBlock(c, c, ks=2, stride=2)))
-                setattr(self, f"stage{i}", nn.Sequential(ResidualBlock(c, c), ResidualBlock(c, c)))
-                setattr(self, f"stage{i}_tail", nn.Sequential(spnn.Conv3d(c, c, kernel_size=3, stride=1), spnn.BatchNorm(c)))
-                setattr(self, f"elk{i}", la.ELKBlock(c, c, groups, baseop=baseop, variant="encoder"))
-                setattr(self, f"elk{i}_tail", nn.Sequential(spnn.Conv3d(c, c, kernel_size=3, stride=1), spnn.BatchNorm(c)))
-
-        def forward(self, x, s, r):
-            x0 = self.stem(x)
-            prev, outs = x0, []
-            for i in (1, 2, 3, 4):
-                d = getattr(self, f"down{i}")(prev)
-                xi = getattr(self, f"stage{i}_tail")(getattr(self, f"stage{i}")(d))
-                lk = getattr(self, f"elk{i}_tail")(getattr(self, f"elk{i}")(d, d.s[0] * s, r))
-                xi.F = torch.relu(xi.F + lk.F)
-                outs.append(xi)
-                prev = xi
-            return x0, outs
-
-    return Encoder()
+from link_amd.networks import build_reference_shaped_encoder  # noqa: E402,F401  (moved into the package: bench.py uses it)

@@ -1,0 +1,41 @@
+"""bench.py end to end on the GPU box: the default line's contract, and the N > 1 path with two ranks sharing the one
+device over gloo (LINK_BENCH_BACKEND=gloo: the branch exists for exactly this; the real multi-GPU run uses RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=400):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_gloo_on_one_device():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (127.0.0.1 rendezvous),
+    every rank times its own frames, rank 0 prints ONE line with n_gpus = 2 and one gathered summary row per rank; the
+    rows equal what each rank's frame gives on its own (rank r runs frames with seed r * 64 + k)."""
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+             {"LINK_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"})
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert all(r["voxels"] == 100000 and 43000 < r["blocks"] < 43700 for r in d["ranks"])
+    assert d["ranks"][0]["checksum"] != d["ranks"][1]["checksum"]           # different frames per rank
+    assert d["value"] > 0 and d["config"]["frames_in_flight_per_gpu"] == 3
+    single = _run(["--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+    assert single["n_gpus"] == 1 and single["ranks"][0]["blocks"] == d["ranks"][0]["blocks"]
+    assert abs(single["ranks"][0]["checksum"] - d["ranks"][0]["checksum"]) <= 1e-6 * abs(single["ranks"][0]["checksum"]) + 1e-3
+    chk = single["timed_configuration_check"]
+    assert chk["frames"] == 3 and chk["max_rel_err_vs_single_frame_geometry"] < 2e-6
+    assert single["roofline"]["bound"] == "hbm" and 0 < single["roofline"]["frac"] < 1

@@ -502,3 +502,32 @@ def test_pair_gemm_fp16_split_of_fp32_rows(cin, cout, kind, n, monkeypatch):
     assert rel_err(run(big_f, w, True).cpu().numpy(), run(big_f, w, False).cpu().numpy()) < 1e-6
     big_w = w.clone(); big_w[5, 1, 2] = 4.0e4                            # a weight outside the range: every wave falls back
     assert rel_err(run(feats, big_w, True).cpu().numpy(), run(feats, big_w, False).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("C,ks", [(16, 5), (32, 5), (64, 5), (16, 7)])
+def test_odd_kernels_larger_than_3_run_the_table_kernel(C, ks):
+    """Conv3d advertises odd cubic kernels at stride 1; at the widths the pair-list kernels take (16/32/64/128) a 5^3 or
+    7^3 neighbourhood has more offsets than the pair plan's 64-bit per-voxel mask holds, so these must fall through to
+    the table kernel (forward, input gradient, weight gradient) instead of raising."""
+    import link_amd as la
+    from oracle import link_oracle as lo
+    coords = s_uniform(1500, grid=16, seed=8)
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(n, C, generator=g)
+    conv = la.Conv3d(C, C, kernel_size=ks).cuda()
+    assert conv.kernel.shape[0] == ks ** 3
+    f = feats.cuda().requires_grad_(True)
+    out = conv(la.SparseTensor(f, coords.cuda(), 1)).F
+    fr = feats.double().requires_grad_(True)
+    kr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    ref = lo.subm_conv_torch(fr, coords, kr, 1)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    go = torch.randn(n, C, generator=g)
+    out.backward(go.cuda())
+    ref.backward(go.double())
+    assert rel_err(f.grad.cpu().numpy(), fr.grad.numpy()) < 1e-5
+    assert rel_err(conv.kernel.grad.cpu().numpy(), kr.grad.numpy()) < 1e-5
+    with torch.no_grad():                                # the fused inference tail takes the same route
+        blk_out = conv(la.SparseTensor(feats.cuda(), coords.cuda(), 1)).F
+    assert rel_err(blk_out.cpu().numpy(), ref.detach().numpy()) < 1e-5

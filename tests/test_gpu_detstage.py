@@ -256,3 +256,50 @@ def test_backbone_maps_ahead_on_side_stream_is_bitwise_the_same(monkeypatch):
                 for k in scales:
                     assert torch.equal(scales[k].indices, rscales[k].indices)
                     assert torch.equal(scales[k].features, rscales[k].features)
+
+
+def test_cfg5_full_size_fp16_backbone_and_block_cores():
+    """BASELINE.json configs[4] at full size: one S-nusc frame (~150k voxels, grid 1440 x 1440 x 40).
+    (a) the sparse half of the backbone in the AMP form (fp16 rows + fp16 convolution weights on the f16 matrix cores, fp32
+        accumulation / BatchNorm folds / block cores) against the fp32 path fed the SAME fp16-rounded inputs: every site set
+        bit-exact, stage outputs and BEV within 2e-2 of the stage maximum (thirty layers of half-precision rows; the fp32
+        path itself is pinned on the dense definitions by test_backbone_sparse_half_vs_dense_oracle);
+    (b) the four TSELKBlock cores (C = 16 / 32 / 64 / 128, r = 3, s = 7, first-half theta tiling) on the frame's real
+        stage site sets (150k / 89k / 32k / 10k voxels, 20-30 voxels per occupied block) against the oracle: 1e-4."""
+    import link_amd as la
+    from link_amd.synth import s_nusc
+    from oracle import link_oracle as O
+    co, fe = s_nusc(seed=0)
+    n = co.shape[0]
+    assert 120_000 < n < 200_000
+    indices = torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int().cuda()
+    feats = torch.from_numpy(fe).cuda()
+    torch.manual_seed(0)
+    net = la.SpMiddleResNetFHDELKv3(num_input_features=5).cuda().eval()
+    shape = [1440, 1440, 40]
+    fh = feats.half()
+    with torch.no_grad():
+        bev16, sc16 = net(fh, indices, 1, shape)
+        bev32, sc32 = net(fh.float(), indices, 1, shape)
+    assert bev16.dtype == torch.float16 and tuple(bev16.shape) == tuple(bev32.shape) == (1, 256, 180, 180)
+    sizes = []
+    for k in (1, 2, 3, 4):
+        a, b = sc16[f"conv{k}"], sc32[f"conv{k}"]
+        assert torch.equal(a.indices, b.indices) and list(a.spatial_shape) == list(b.spatial_shape)
+        assert rel_err(a.features.float().cpu().numpy(), b.features.cpu().numpy()) < 2e-2, f"stage {k}"
+        sizes.append(b.features.shape[0])
+    assert rel_err(bev16.float().cpu().numpy(), bev32.cpu().numpy()) < 2e-2
+    assert sizes[0] == n and sizes[0] > sizes[1] > sizes[2] > sizes[3] > 5000
+    # (b) block cores on the real stage site sets
+    g = torch.Generator().manual_seed(7)
+    for k, c in zip((1, 2, 3, 4), (16, 32, 64, 128)):
+        sites = sc32[f"conv{k}"]
+        blk = getattr(net, f"elk{k}")
+        f = torch.randn(sites.indices.shape[0], c, generator=g)
+        coords = sites.indices.cpu()[:, [3, 2, 1, 0]].contiguous()
+        st = la.SparseTensor(f.cuda(), coords.cuda(), 1)
+        with torch.no_grad():
+            core = blk._core(st, 7, 3, blk.pos_weight[0].weight[: c // 2], None, c // 2, 1.0)
+        params = {kk: v.detach().cpu() for kk, v in blk.state_dict().items()}
+        ref = O.elk_core_torch(f, coords, params, 7, 3, "cos", 1, variant="det", agg=O.aggregate_c)
+        assert rel_err(core.cpu().numpy(), ref.numpy()) < 1e-4, f"elk{k} core (C = {c}, {f.shape[0]} voxels)"

@@ -112,6 +112,36 @@ def test_encoder_vs_reference_network_fixture():
         assert rel_err(o.F.cpu().numpy(), g[f"x{i}_F"]) < 1e-4, f"stage {i} features"
 
 
+def test_whole_unet_vs_reference_network_fixture():
+    """SURVEY.md section 8 row b7, decoder half included: the REFERENCE's ELKUNet (linkunet.py:186-385), run unmodified by
+    the imported reference on its CPU path (tests/golden/make_golden_unet.py; r = 2: every number reference output), against
+    link_amd.networks.build_reference_shaped_unet with the reference's state_dict loaded strict=True.  Beyond the encoder
+    this pins the transposed convolutions (which require the kernel map cached by the matching down-convolution,
+    conv.py:122-138), torchsparse.cat with the skips, the rectangular residual blocks (2C -> C with a 1x1 shortcut) and the
+    classifier -- plain and with every Conv-BN(-ReLU) run fused for inference."""
+    import link_amd as la
+    from helpers import load_golden
+    from link_amd.networks import build_reference_shaped_unet
+    g = load_golden("g_unet_cosx_s3_r2.npz")
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    for fuse in (False, True):
+        net = build_reference_shaped_unet(la, cr=0.25, baseop="cos_x", groups=1, s=3, r=2, num_classes=19)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().eval()
+        if fuse:
+            net = la.fuse_for_inference(net)
+        x = la.SparseTensor(torch.from_numpy(g["feats"]).cuda(), torch.from_numpy(g["coords"]).cuda(), 1)
+        with torch.no_grad():
+            logits = net(x)
+        for i in (1, 2, 3, 4):
+            y = net.trace[f"y{i}"]
+            assert np.array_equal(y.C.cpu().numpy(), g[f"y{i}_C"]), f"decoder stage {i} coordinates (fused={fuse})"
+            assert rel_err(y.F.cpu().numpy(), g[f"y{i}_F"]) < 2e-4, f"decoder stage {i} features (fused={fuse})"
+        assert tuple(logits.shape) == tuple(g["logits"].shape) == (g["coords"].shape[0], 19)
+        assert rel_err(logits.cpu().numpy(), g["logits"]) < 2e-4, f"logits (fused={fuse})"
+        assert float((logits.argmax(1).cpu() == torch.from_numpy(g["logits"]).argmax(1)).float().mean()) > 0.999
+
+
 def test_fused_conv_bn_relu_equals_module_by_module_and_reference_fixture():
     """link_amd.fuse_for_inference: the [Conv3d, BatchNorm, ReLU] runs of the reference-shaped encoder collapse to
     one launch each (BatchNorm folded into the convolution's finish phase).  Same state_dict keys, same outputs as
