@@ -181,6 +181,62 @@ def timed_regions(la, blk, feats, coords, C, s, r, iters=30):
                     "R_core cold/warm are `value`/`warm_index_value` (arena path, one FFI call per step)"}
 
 
+def core_roofline(torch, blocks, step, iters=20):
+    """R_core of every LinK block of a network against the HBM roofline: wraps each block's `_core`
+    with HIP events on the launch stream (`step()` runs the network once, warm kernel maps), and prices the measured time
+    against B_alg = N*16 + 2*N*esz*C + 2*M*4*(W+1) with the stage's own N, M (occupied blocks at its s_eff), C, W.
+    Returns the `roofline` object of the JSON line: the sum over the blocks + one entry per block."""
+    rec = [{"ev": [], "meta": None} for _ in blocks]
+    saved = [b._core for b in blocks]
+
+    def wrap(i, f0):
+        def core(st, s_eff, r, w_pos, alpha, cg, coord_div):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = f0(st, s_eff, r, w_pos, alpha, cg, coord_div)
+            e1.record()
+            rec[i]["ev"].append((e0, e1))
+            if rec[i]["meta"] is None:
+                c = st.C
+                blk = torch.cat([torch.div(c[:, :3], int(s_eff), rounding_mode="floor"), c[:, 3:]], 1)
+                m = int(torch.unique(blk, dim=0).shape[0])
+                parts = 3 if blocks[i].baseop == "cos_x" else 2
+                rec[i]["meta"] = {"voxels": int(c.shape[0]), "blocks": m, "channels": int(st.F.shape[1]),
+                                  "w": parts * int(st.F.shape[1]), "s_eff": int(s_eff), "r": int(r),
+                                  "esz": st.F.element_size()}
+            return out
+        return core
+    for i, b in enumerate(blocks):
+        b._core = wrap(i, saved[i])
+    try:
+        for _ in range(3):
+            step()
+        for r_ in rec:
+            r_["ev"].clear()
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        for b, f0 in zip(blocks, saved):
+            b._core = f0
+    stages, tot_b, tot_t = [], 0.0, 0.0
+    for r_ in rec:
+        m = r_["meta"]
+        v = sorted(1e3 * a.elapsed_time(b) for a, b in r_["ev"])
+        us = v[len(v) // 2]
+        alg = m["voxels"] * 16 + 2 * m["voxels"] * m["esz"] * m["channels"] + 2 * m["blocks"] * 4 * (m["w"] + 1)
+        gbs = alg / (us * 1e-6) / 1e9
+        stages.append({**{k: m[k] for k in ("voxels", "blocks", "channels", "w", "s_eff", "r")}, "us": round(us, 2),
+                       "alg_bytes": alg, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        tot_b += alg
+        tot_t += us
+    ach = tot_b / (tot_t * 1e-6) / 1e9
+    return {"bound": "hbm", "region": "R_core of the network's LinK blocks (HIP events on the launch stream around each core, "
+                                      "host-inclusive: the module path allocates and launches per call; warm kernel maps)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "alg_bytes": tot_b, "us": round(tot_t, 2), "stages": stages}
+
+
 def cfg3_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[2] shape (labelled, NOT the headline): the encoder common to both segmentation models
     (stem -> 4 x [k2-s2 down, 2 residual blocks + tail || ELKBlock cos_x (2x3)^3 + tail, add/ReLU],
@@ -253,6 +309,7 @@ def cfg3_mode(args, la, dev, rank, world, dist):
         step(False)
     for m, f0 in zip(net.elk, saved):
         m.forward = f0
+    roof = core_roofline(torch, net.elk, lambda: step(False)) if rank == 0 else None
     nv = torch.tensor([float(n)], device=dev)
     if world > 1:
         dist.all_reduce(nv)
@@ -267,7 +324,7 @@ def cfg3_mode(args, la, dev, rank, world, dist):
                        "voxels": n, "stage_voxels": sizes, "blocks_s6_on_input_voxels": int(block_stats(co, 6)[1]),
                        "parallelism": f"dp{world}"},
             "fwd_bwd_ms": 1e3 * t_tr / max(1, k // 4), "elk_blocks_fwd_ms": 1e3 * elk_t[0] / 5,
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": roof, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -372,6 +429,14 @@ def cfg5_mode(args, la, dev, rank, world, dist):
     t_warm = timed(k, w, {})
     with torch.no_grad():
         bev, scales = net(feats, indices, 1, shape)
+    roof = None
+    if rank == 0:
+        warm_maps = {}
+
+        def one():
+            with torch.no_grad():
+                net(feats, indices, 1, shape, indice_dict=warm_maps)
+        roof = core_roofline(torch, [net.elk1, net.elk2, net.elk3, net.elk4], one)
     nv = torch.tensor([float(n)], device=dev)
     if world > 1:
         dist.all_reduce(nv)
@@ -387,7 +452,7 @@ def cfg5_mode(args, la, dev, rank, world, dist):
                                    "maps built per frame, one S-nusc frame per GPU",
                        "voxels": n, "stage_voxels": [scales[f"conv{i}"].features.shape[0] for i in (1, 2, 3, 4)],
                        "bev": list(bev.shape), "parallelism": f"dp{world}"},
-            "warm_maps_ms": 1e3 * t_warm / k, "roofline": None, "cpu_baseline": None}))
+            "warm_maps_ms": 1e3 * t_warm / k, "roofline": roof, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -554,7 +554,9 @@ typedef struct {
   int32_t k2_lds_pad;  /* which workgroups share a CU when several frames are in flight */
   int32_t k1_form;     /* 0 = tile form (id slots, in-wave id sort, per-cell sums by segmented DPP scan in the matrix-core
                           accumulator layout); 1 = cell-range form of round 2 (LDS voxel list + X tile) */
-  int32_t k2_form;     /* bit 0: single-role gather kernel instead of producer / consumer; bit 1: one voxel per lane group */
+  int32_t k2_form;     /* 0 = producer / consumer form; bit 0: single-role form (workgroup-wide dealing); bit 1: one voxel per lane
+                          group instead of a pair (forms 0 / 1); bit 2: own-cell form (a lane group de-modulates its own cell from the
+                          A row in registers; 2-slot plane ring fed by a dedicated DMA wave; 39 KB of LDS) */
   int32_t mode;        /* 0 = default (7); else bit 0 fused pre_mix+modsum, bit 1 dense-cell demod kernel, bit 2 fused
                           gather + de-modulate (C = 64) -- the unfused stages are what the fused ones are tested against */
   int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */

@@ -1096,6 +1096,8 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
   }
 }
 
+#include "dense_gather_own_impl.h"
+
 template <int OP, int R, bool PAIR, bool DIV>
 __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
@@ -1449,6 +1451,25 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
                        b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out, k2_single,       \
                        reinterpret_cast<unsigned long long *>(b->tune.k2_dbg));                                       \
   } while (0)
+  // k2_form 0 = by measurement (tools/k2ab.py, cfg2-sized frames): the producer / consumer form where two of its workgroups fit
+  // a CU (two-part rows: 29.9 us, own-cell 29.9, single-role 30.4); three-part rows (cos_x) r = 3: own-cell 38.2 us against
+  // 53.5 for the single-role kernel (81 KB plane ring: one workgroup per CU); r = 2: single-role 32.9, own-cell 34.4
+  const bool own = (b->tune.k2_form & 4) || (!(b->tune.k2_form & 1) && !K2::SPLIT_FITS && R == 3);
+  if (own) {                                           // own-cell form: 5 waves, 2-slot ring fed by a dedicated DMA wave
+    using KO = dc_k2o_cfg<OP, R>;
+#define LINK_K2O(PP, DD)                                                                                              \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_own<OP, R, PP, DD>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, KO::LDS_BYTES + k2_pad);                   \
+    hipLaunchKernelGGL((k_dc_gather_demod_own<OP, R, PP, DD>), dim3((unsigned)grid), dim3(320), KO::LDS_BYTES + k2_pad, st, b->S, \
+                       b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w,      \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out);                  \
+  } while (0)
+    if (pair) { if (div) LINK_K2O(true, true); else LINK_K2O(true, false); }
+    else { if (div) LINK_K2O(false, true); else LINK_K2O(false, false); }
+#undef LINK_K2O
+    return check_launch("link_dc_gather_demod");
+  }
   if (!(b->tune.k2_form & 1) && K2::SPLIT_FITS) {
     if (pair) { if (div) LINK_K2S(true, true); else LINK_K2S(true, false); }
     else { if (div) LINK_K2S(false, true); else LINK_K2S(false, false); }

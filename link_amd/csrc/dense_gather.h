@@ -102,5 +102,69 @@ __device__ __forceinline__ void dc_read_dx(uint32_t ra, uint32_t ca, float4 (&cu
 #undef Q_
 }
 
+// Pipelined form of the three dc_read_dx calls of one plane (P = 2, R = 3: the cfg2 / detection case): the rows of x-offset
+// 0 and 1 are requested together, offset 2 (into offset 0's registers) while offset 0 is being added, so the plane costs
+// ONE LDS latency plus the transfers instead of three dependent round trips.  Guide section 5.7 form (ii): every statement
+// that waits names the registers that become valid there as "+v", so nothing consumes them earlier; the sums are formed in
+// the order dc_read_dx forms them (bitwise identical results).  Needs 27 more registers than the one-offset-at-a-time form.
+template <int C>
+__device__ __forceinline__ void dc_read_plane_p2r3(uint32_t ra, uint32_t ca, float4 (&cur)[2], float &cc) {
+  using K = dc_gather_cfg<C, 2, 3>;
+  constexpr int RB = 2 * C * 4;
+#define O_(dx, dy, pp) "i"((((dx) * K::HY + (dy)) * RB) + (pp) * C * 4)
+#define Q_(dx, dy) "i"(((dx) * K::HY + (dy)) * 4)
+  v4f_t a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
+  int m0, m1, m2, n0, n1, n2;
+  asm volatile(
+      "ds_read_b128 %0, %18 offset:%c20\n\tds_read_b128 %1, %18 offset:%c21\n\t"
+      "ds_read_b128 %2, %18 offset:%c22\n\tds_read_b128 %3, %18 offset:%c23\n\t"
+      "ds_read_b128 %4, %18 offset:%c24\n\tds_read_b128 %5, %18 offset:%c25\n\t"
+      "ds_read_b32 %6, %19 offset:%c26\n\tds_read_b32 %7, %19 offset:%c27\n\tds_read_b32 %8, %19 offset:%c28\n\t"
+      "ds_read_b128 %9, %18 offset:%c29\n\tds_read_b128 %10, %18 offset:%c30\n\t"
+      "ds_read_b128 %11, %18 offset:%c31\n\tds_read_b128 %12, %18 offset:%c32\n\t"
+      "ds_read_b128 %13, %18 offset:%c33\n\tds_read_b128 %14, %18 offset:%c34\n\t"
+      "ds_read_b32 %15, %19 offset:%c35\n\tds_read_b32 %16, %19 offset:%c36\n\tds_read_b32 %17, %19 offset:%c37\n\t"
+      "s_waitcnt lgkmcnt(9)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(m0), "=&v"(m1), "=&v"(m2),
+        "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(n0), "=&v"(n1), "=&v"(n2)
+      : "v"(ra), "v"(ca), O_(0, 0, 0), O_(0, 0, 1), O_(0, 1, 0), O_(0, 1, 1), O_(0, 2, 0), O_(0, 2, 1), Q_(0, 0), Q_(0, 1), Q_(0, 2),
+        O_(1, 0, 0), O_(1, 0, 1), O_(1, 1, 0), O_(1, 1, 1), O_(1, 2, 0), O_(1, 2, 1), Q_(1, 0), Q_(1, 1), Q_(1, 2)
+      : "memory");
+  {
+    const v4f_t a = (a0 + a2) + a4, b = (a1 + a3) + a5;
+    cur[0].x += a.x; cur[0].y += a.y; cur[0].z += a.z; cur[0].w += a.w;
+    cur[1].x += b.x; cur[1].y += b.y; cur[1].z += b.z; cur[1].w += b.w;
+    cc += (float)m0 + (float)m1 + (float)m2;
+  }
+  asm volatile(
+      "ds_read_b128 %0, %18 offset:%c20\n\tds_read_b128 %1, %18 offset:%c21\n\t"
+      "ds_read_b128 %2, %18 offset:%c22\n\tds_read_b128 %3, %18 offset:%c23\n\t"
+      "ds_read_b128 %4, %18 offset:%c24\n\tds_read_b128 %5, %18 offset:%c25\n\t"
+      "ds_read_b32 %6, %19 offset:%c26\n\tds_read_b32 %7, %19 offset:%c27\n\tds_read_b32 %8, %19 offset:%c28\n\t"
+      "s_waitcnt lgkmcnt(9)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(m0), "=&v"(m1), "=&v"(m2),
+        "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(n0), "+v"(n1), "+v"(n2)
+      : "v"(ra), "v"(ca), O_(2, 0, 0), O_(2, 0, 1), O_(2, 1, 0), O_(2, 1, 1), O_(2, 2, 0), O_(2, 2, 1), Q_(2, 0), Q_(2, 1), Q_(2, 2)
+      : "memory");
+  {
+    const v4f_t a = (b0 + b2) + b4, b = (b1 + b3) + b5;
+    cur[0].x += a.x; cur[0].y += a.y; cur[0].z += a.z; cur[0].w += a.w;
+    cur[1].x += b.x; cur[1].y += b.y; cur[1].z += b.z; cur[1].w += b.w;
+    cc += (float)n0 + (float)n1 + (float)n2;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(m0), "+v"(m1), "+v"(m2)
+               :
+               : "memory");
+  {
+    const v4f_t a = (a0 + a2) + a4, b = (a1 + a3) + a5;
+    cur[0].x += a.x; cur[0].y += a.y; cur[0].z += a.z; cur[0].w += a.w;
+    cur[1].x += b.x; cur[1].y += b.y; cur[1].z += b.z; cur[1].w += b.w;
+    cc += (float)m0 + (float)m1 + (float)m2;
+  }
+#undef O_
+#undef Q_
+}
+
 
 }  // namespace link
