@@ -624,7 +624,7 @@ def main():
         # the three launches of one step (index -> pre_mix+modulate+cell sums -> box sum+de-modulate); C = 64
         stages = {
             "index": (lambda: lib.link_dc_index_ids(coords.data_ptr(), N, ctypes.byref(g), b.cnt, b.sid, b.vcell, b.hdr, st))
-            if b.tune.k1_form == 0 else
+            if b.tune.k1_form == 1 else
             (lambda: lib.link_dc_index(coords.data_ptr(), N, ctypes.byref(g), b.cnt, b.slots, b.vcell, b.hdr, st)),
             "premix_modsum": lambda: lib.link_dc_premix_modsum(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, 0, st),
             "gather_demod": lambda: lib.link_dc_gather_demod(ctypes.byref(b), ctypes.byref(g), ctypes.byref(desc), N, st),

@@ -36,6 +36,9 @@ extern "C" {
 
 /* Version of this ABI (bumped on any signature change). */
 int link_abi_version(void);
+/* sizeof of the structs crossing this boundary (0 link_grid_t, 1 link_elk_desc_t, 2 link_elk_buffers_t, 3 link_dc_grid_t,
+ * 4 link_dc_tuning_t, 5 link_dc_buffers_t; -1 otherwise): what a binding checks its own layout against. */
+int32_t link_abi_struct_size(int32_t which);
 /* Human-readable last HIP error string of the calling thread ("" if none). Host pointer. */
 const char *link_last_error(void);
 
@@ -226,7 +229,13 @@ typedef struct {
                             does it): 1.0 everywhere except the encoder cos_x variant, which feeds
                             coords / tensor_stride (linkencoder.py:165) */
   float eps;             /* LayerNorm eps (1e-6, linkunet.py:111,121) */
+  int32_t flags;         /* general layout: kernel-path selection of THIS call (0 = defaults; nothing is process-global).  The
+                            alternative paths are what the default ones are tested against (tests/test_gpu_split_paths.py) */
 } link_elk_desc_t;
+#define LINK_ELK_LANE_CHANNEL 1    /* lane = channel kernels instead of the lane-group kernels */
+#define LINK_ELK_NO_PAIR 2         /* no voxel-pair sharing of sincos between channels j and j + C/2 */
+#define LINK_ELK_FUSED_GATHER 4    /* one fused gather + de-modulate kernel instead of block gather + per-voxel kernel */
+#define LINK_ELK_NO_DENSE_GRID 8   /* block gather: column-walking form even on mostly occupied grids */
 
 /* pre_mix: fin = LayerNorm(F @ Wpre^T) * g + b  (linkunet.py:109-112,132).  F fp[N,C], Wpre fp[C,C]
  * (nn.Linear layout [out,in]).  C <= 256. */
@@ -291,11 +300,6 @@ typedef struct {
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
 } link_elk_buffers_t;
 
-/* Tuning hook for bench/profiling (value > 0).  Keys: 0/1/2/5 = workgroups of the modulate / fused-gather /
- * pre_mix / block-gather launches; 3 = 1 group kernels | 2 lane=channel kernels; 4 = 1 voxel-pair sincos
- * sharing | 2 off; 6 = 1 split gather | 2 fused gather; 7 = mean voxels/block above which the modulate
- * kernel's groups cooperate per block.  Not needed for correct operation. */
-int link_set_tuning(int key, int value);
 
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
@@ -405,8 +409,6 @@ int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const flo
 int32_t link_subm_conv_wgrad_chunks(void);
 int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c,
                          int32_t kvol, float *partial, void *stream);
-/* Tuning hook (bench only): key 0 = workgroup cap of the MFMA kernel, key 1 = tiles per wave (0 auto, 1/2/4). */
-int link_conv_set_tuning(int key, int value);
 
 /* Pair-list form of the same convolution, for sparse frames (few of the K neighbours present per voxel).
  * The kernel map is the reference's own: per kernel offset the list of (input row, output row) pairs
@@ -552,8 +554,9 @@ typedef struct {
   int32_t k2_zsplit;   /* z-segments of the fused gather + de-modulate kernel; 0 = auto (enough for ~512 workgroups) */
   int32_t k1_lds_pad;  /* extra dynamic LDS bytes of the fused pre_mix kernel (<= 16384) / the gather kernel (<= 4096): */
   int32_t k2_lds_pad;  /* which workgroups share a CU when several frames are in flight */
-  int32_t k1_form;     /* 0 = tile form (id slots, in-wave id sort, per-cell sums by segmented DPP scan in the matrix-core
-                          accumulator layout); 1 = cell-range form of round 2 (LDS voxel list + X tile) */
+  int32_t k1_form;     /* 0 = cell-range form (a wave owns a range of cells: LDS voxel list + X tile; the faster one with frames in
+                          flight); 1 = tile form (id slots, in-wave id sort, per-cell sums by segmented DPP scan in the matrix-core
+                          accumulator layout; 36 KB of LDS, any cell size up to the slot capacity in one pass structure) */
   int32_t k2_form;     /* 0 = producer / consumer form; bit 0: single-role form (workgroup-wide dealing); bit 1: one voxel per lane
                           group instead of a pair (forms 0 / 1); bit 2: own-cell form (a lane group de-modulates its own cell from the
                           A row in registers; 2-slot plane ring fed by a dedicated DMA wave; 39 KB of LDS) */

@@ -16,6 +16,7 @@ SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
 LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
+ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID = 1, 2, 4, 8     # link_elk_desc_t::flags
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
 ABI_VERSION = 4
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
@@ -41,7 +42,7 @@ class LinkGrid(Structure):
 class LinkElkDesc(Structure):
     """link_elk_desc_t"""
     _fields_ = [("op", c_int32), ("c", c_int32), ("cg", c_int32), ("r", c_int32),
-                ("coord_div", c_float), ("eps", c_float)]
+                ("coord_div", c_float), ("eps", c_float), ("flags", c_int32)]
 
 
 class LinkElkBuffers(Structure):
@@ -82,6 +83,7 @@ class LinkDcBuffers(Structure):
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
 SIGNATURES = {
     "link_abi_version": (c_int, []),
+    "link_abi_struct_size": (c_int32, [c_int32]),
     "link_last_error": (c_char_p, []),
     "link_hash": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "link_kernel_hash": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -124,7 +126,6 @@ SIGNATURES = {
     "link_gather_demod_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, POINTER(LinkGrid), c_void_p,
                                      POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
-    "link_set_tuning": (c_int, [c_int, c_int]),
     "link_elk_core_forward": (c_int, [POINTER(LinkElkBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc),
                                       c_int64, c_int64, c_int32, c_void_p]),
     "link_elk_mid_forward": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
@@ -135,7 +136,6 @@ SIGNATURES = {
                                        c_void_p, c_void_p]),
     "link_aux_to_voxel_forward_grid": (c_int, [c_void_p] * 4 + [POINTER(LinkGrid), c_void_p, c_void_p, c_int64,
                                                c_int64, c_int32, c_int32] + [c_void_p] * 5),
-    "link_conv_set_tuning": (c_int, [c_int, c_int]),
     "link_conv_pairs_supported": (c_int, [c_int32, c_int32]),
     "link_conv_pairs_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "link_conv_pairs_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
@@ -216,6 +216,10 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         if handle.link_abi_version() != ABI_VERSION:
             raise LinkAmdError("liblink_amd.so ABI version mismatch; rebuild with link_amd/build.py")
+        for which, cls in enumerate((LinkGrid, LinkElkDesc, LinkElkBuffers, LinkDcGrid, LinkDcTuning, LinkDcBuffers)):
+            if handle.link_abi_struct_size(which) != ctypes.sizeof(cls):
+                raise LinkAmdError(f"liblink_amd.so: layout of {cls.__name__} differs from include/link_amd.h "
+                                   f"({ctypes.sizeof(cls)} bytes here, {handle.link_abi_struct_size(which)} in the library)")
         _lib = handle
     return _lib
 

@@ -469,15 +469,9 @@ extern "C" int link_subm_conv_wgrad(const float *feats, const float *gout, const
   return check_launch("link_subm_conv_wgrad");
 }
 
-static int g_conv_wgs = 1024;  // cap (sweep: tools/convsweep.py)
-static int g_conv_nt = 0;      // 0 = by size; 1/2/4 forced (tuning)
-static int g_conv_deep = 1;    // two-steps-ahead pipeline of the table kernel on small frames (key 2)
-extern "C" int link_conv_set_tuning(int key, int value) {
-  if (key == 0 && value > 0) { g_conv_wgs = value; return LINK_OK; }
-  if (key == 1 && (value == 0 || value == 1 || value == 2 || value == 4)) { g_conv_nt = value; return LINK_OK; }
-  if (key == 2 && (value == 0 || value == 1)) { g_conv_deep = value; return LINK_OK; }
-  return LINK_ERR_ARG;
-}
+static constexpr int g_conv_wgs = 1024;  // cap (sweep recorded in DESIGN.md 4b)
+static constexpr int g_conv_nt = 0;      // tiles per wave: by size
+static constexpr int g_conv_deep = 1;    // two-steps-ahead pipeline of the table kernel on small frames
 
 template <int CI, int CO, int NT>
 static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,

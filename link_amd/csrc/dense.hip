@@ -759,7 +759,7 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
   if (fused) {
     // index -> fused pre_mix + modulate + per-cell sum -> box gather -> per-voxel de-modulate
     if (build_index) {
-      rc = b->tune.k1_form == 0 ? link_dc_index_ids(b->coords, n, g, b->cnt, b->sid, b->vcell, b->hdr, stream)
+      rc = b->tune.k1_form == 1 ? link_dc_index_ids(b->coords, n, g, b->cnt, b->sid, b->vcell, b->hdr, stream)
                                 : link_dc_index(b->coords, n, g, b->cnt, b->slots, b->vcell, b->hdr, stream);
       if (rc != LINK_OK) return rc;
     }

@@ -98,7 +98,7 @@ extern "C" int link_dc_premix_modsum(const link_dc_buffers_t *b, const link_dc_g
       !b->S || !b->hdr)
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  if (b->tune.k1_form == 0) return dc_tiles_modsum(b, g, d, n, warm != 0, st);
+  if (b->tune.k1_form == 1) return dc_tiles_modsum(b, g, d, n, warm != 0, st);
   switch (b->io_dtype) {
     case 1: return dcio_f16::run_premix_modsum(b, *g, *d, n, warm != 0, st);
     case 2: return dcio_bf16::run_premix_modsum(b, *g, *d, n, warm != 0, st);

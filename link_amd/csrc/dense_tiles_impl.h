@@ -1,8 +1,8 @@
 // link_amd/csrc/dense_tiles_impl.h -- tile form of the fused pre_mix + LayerNorm + modulate + per-cell-sum kernel
-// (round 3; include/link_amd.h section E, link_dc_tuning_t::k1_form = 0).  Compiled once per feature I/O type like
+// (round 3; include/link_amd.h section E, link_dc_tuning_t::k1_form = 1).  Compiled once per feature I/O type like
 // dense_fused_impl.h (DC_IO / DC_IO_NS).
 //
-// What changed against the cell-range form of round 2 (dense_fused_impl.h, kept as k1_form = 1), and why -- the
+// What changed against the cell-range form of round 2 (dense_fused_impl.h, the default, k1_form = 0), and why -- the
 // round-2 ablations left 16.7 of 25.6 us in the kernel's frame, not in its arithmetic:
 //   * the slot lists hold voxel IDS (4 bytes, 8 inline per cell = one 32-byte piece per cell) instead of 16-byte
 //     records: a lane owns a cell, sorts its <= 8 ids in registers (19-exchange network) and scatters them to a

@@ -313,34 +313,14 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
   }
 }
 
-// launch geometry knobs (defaults chosen from measurements in profiles/; link_set_tuning is a
-// bench/tuning hook, not part of the functional ABI)
-static int g_modsum_wgs = 1024;   // chosen by sweep (tools/mstream.py): flat 512..2048, smaller grids co-run better
-static int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one resident round
-static int g_premix_wgs = 1024;
-static int g_use_group_path = 1;
-static int g_use_pair = 1;
-static int g_wt = 15;               // write-through (sc1) output stores: bit0 pre_mix, 1 modulate, 2 block gather, 3 voxel
-static int g_coop_threshold = 4;   // mean voxels/block above which a wave's groups cooperate per block
-static int g_bgather_wgs = 512;
-static int g_use_split = 1;
-static int g_use_dense = 1;        // dense-grid block gather for occupied grids (device-side regime switch)
-extern "C" int link_set_tuning(int key, int value) {
-  if (value <= 0) return LINK_ERR_ARG;
-  switch (key) {
-    case 0: g_modsum_wgs = (value + 7) & ~7; return LINK_OK;
-    case 1: g_gather_wgs = (value + 7) & ~7; return LINK_OK;
-    case 2: g_premix_wgs = value; return LINK_OK;
-    case 3: g_use_group_path = (value == 1); return LINK_OK;   // 1 = group kernels, 2 = lane=channel kernels
-    case 4: g_use_pair = (value == 1); return LINK_OK;         // 1 = voxel-pair sincos sharing, 2 = off
-    case 5: g_bgather_wgs = (value + 7) & ~7; return LINK_OK;
-    case 7: g_coop_threshold = value; return LINK_OK;
-    case 8: g_wt = value - 1; return LINK_OK;                  // value-1 = bitmask of kernels using sc1 stores
-    case 6: g_use_split = (value == 1); return LINK_OK;        // 1 = split gather (block + voxel kernels)
-    case 9: g_use_dense = (value == 1); return LINK_OK;        // 1 = dense-grid block gather allowed, 2 = never
-    default: return LINK_ERR_ARG;
-  }
-}
+// launch geometry (fixed: chosen from the sweeps recorded in DESIGN.md 5a; nothing here is mutable process state -- the
+// alternative kernel paths are selected per call through link_elk_desc_t::flags)
+static constexpr int g_modsum_wgs = 1024;   // flat 512..2048 in the sweep, smaller grids co-run better
+static constexpr int g_gather_wgs = 1024;   // 4 waves/SIMD resident at ~100 VGPRs -> one resident round
+static constexpr int g_premix_wgs = 1024;
+static constexpr int g_coop_threshold = 4;  // mean voxels/block above which a wave's groups cooperate per block
+static constexpr int g_bgather_wgs = 512;
+static constexpr int g_wt = 15;             // write-through (sc1) output stores in all four streaming kernels
 
 template <int CPL>
 static void launch_modsum(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
@@ -1598,10 +1578,10 @@ static inline int lanes_per_row(int c) {
 template <int LPR>
 static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4 *vox, const float *w_pos,
                             const float *alpha, const int32_t *blk_start, const int32_t *hdr, int c, int cg,
-                            float div, float *S, int64_t m_cap, const float *row_den = nullptr) {
+                            float div, float *S, int64_t m_cap, const float *row_den = nullptr, int flags = 0) {
   dim3 grid(g_modsum_wgs), block(256);
   const bool two_part = op == LINK_OP_COS || op == LINK_OP_SIN || op == LINK_OPI_SIN_BWD;
-  const bool pair = g_use_pair && LPR >= 2 && c == 2 * cg && c == 4 * LPR && two_part;
+  const bool pair = !(flags & LINK_ELK_NO_PAIR) && LPR >= 2 && c == 2 * cg && c == 4 * LPR && two_part;
 #define LINK_MS(OPP, PP)                                                                                         \
   hipLaunchKernelGGL((k_modulate_sum_g<LPR, OPP, PP>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, \
                      c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0, row_den)
@@ -1621,7 +1601,7 @@ static void launch_gdl_g_r(int r, hipStream_t st, int64_t m_cap, const float *S_
                            const int32_t *blk_start, const int4 *blk_coords, const int32_t *cell_blk,
                            const link_grid_t &g, const int32_t *hdr, const link_elk_desc_t &d, float *out) {
   dim3 grid(g_gather_wgs), block(256);
-  const bool pair = g_use_pair && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && OP != LINK_OP_COSX;
+  const bool pair = !(d.flags & LINK_ELK_NO_PAIR) && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && OP != LINK_OP_COSX;
 #define LINK_GDLG(RR, PP)                                                                                     \
   hipLaunchKernelGGL((k_gather_demod_ln_g<LPR, OP, RR, PP>), grid, block, 0, st, S_, fin, vox, w_pos, alpha,  \
                      ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, d.c, d.cg, d.coord_div, d.eps, out, m_cap)
@@ -1657,11 +1637,11 @@ static void launch_gdl_g(int op, int r, hipStream_t st, int64_t m_cap, const flo
 template <int LPR, int P>
 static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
                                 const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
-                                int64_t m_cap, float *A, int flags, float *den_out) {
+                                int64_t m_cap, float *A, int flags, float *den_out, bool allow_dense) {
   const bool wt = (g_wt & 4) != 0;
   unsigned wgs = (unsigned)g_bgather_wgs;
   int tiles_y = 0, tiles_z = 0;
-  if (LPR <= 32 && r == 3 && g_use_dense) {         // widen the launch for the dense-grid form (same kernel)
+  if (LPR <= 32 && r == 3 && allow_dense) {         // widen the launch for the dense-grid form (same kernel)
     constexpr int G = 64 / LPR, TZ = 4;
     tiles_y = (g.dim[1] + G - 1) / G;
     tiles_z = (g.dim[2] + TZ - 1) / TZ;
@@ -1698,9 +1678,10 @@ static int block_gather_impl(const float *S_, const int32_t *blk_coords, const i
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   const bool p3 = desc->op == LINK_OP_COSX;
+  const bool dense_ok = !(desc->flags & LINK_ELK_NO_DENSE_GRID);
 #define LINK_BG(L)                                                                                                   \
-  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out);    \
-  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out)
+  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok); \
+  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok)
   switch (lanes_per_row(desc->c)) {
     case 1: case 2: case 4: LINK_BG(4); break;
     case 8: LINK_BG(8); break;
@@ -1724,7 +1705,7 @@ static void launch_voxel_demod(const link_elk_desc_t &d, int64_t n, hipStream_t 
                                const float *alpha, const float *ln_w, const float *ln_b, const int32_t *hdr,
                                float *out) {
   constexpr int G = 64 / LPR;
-  const bool pair = g_use_pair && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && d.op != LINK_OP_COSX;
+  const bool pair = !(d.flags & LINK_ELK_NO_PAIR) && LPR >= 2 && d.c == 2 * d.cg && d.c == 4 * LPR && d.op != LINK_OP_COSX;
   const int64_t groups = pair ? (n + 1) / 2 : n;
   const int64_t wgs = (groups + 4 * G - 1) / (4 * G);
   dim3 grid((unsigned)wgs), block(256);
@@ -1774,9 +1755,9 @@ static int voxel_demod_impl(const float *A, const float *fin, const int32_t *vox
 static bool modsum_group_path(const link_elk_desc_t *d, hipStream_t st, const float *fin, const int4 *vox,
                               const float *w_pos, const float *alpha, const int32_t *blk_start,
                               const int32_t *hdr, float *S_, int64_t m_cap, int op, const float *row_den) {
-  if (!g_use_group_path || (d->c & 3) != 0) return false;
+  if ((d->flags & LINK_ELK_LANE_CHANNEL) || (d->c & 3) != 0) return false;
   if (op < 0) op = d->op;
-#define LINK_MSG(L) launch_modsum_g<L>(op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap, row_den)
+#define LINK_MSG(L) launch_modsum_g<L>(op, st, fin, vox, w_pos, alpha, blk_start, hdr, d->c, d->cg, d->coord_div, S_, m_cap, row_den, d->flags)
   switch (lanes_per_row(d->c)) {
     case 1: case 2: case 4: LINK_MSG(4); break;
     case 8: LINK_MSG(8); break;
@@ -1793,7 +1774,7 @@ static bool gather_group_path(const link_elk_desc_t *d, hipStream_t st, const fl
                               const float *ln_b, const int32_t *blk_start, const int4 *blk_coords,
                               const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, float *out,
                               int64_t m_cap) {
-  if (!g_use_group_path || (d->c & 3) != 0 || d->r > 3) return false;
+  if ((d->flags & LINK_ELK_LANE_CHANNEL) || (d->c & 3) != 0 || d->r > 3) return false;
   switch (lanes_per_row(d->c)) {
     case 1: case 2: case 4: launch_gdl_g<4>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
     case 8: launch_gdl_g<8>(d->op, d->r, st, m_cap, S_, fin, vox, w_pos, alpha, ln_w, ln_b, blk_start, blk_coords, cell_blk, g, hdr, *d, out); break;
@@ -2592,7 +2573,7 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
   if (rc != LINK_OK) return rc;
-  if (g_use_split && b->A && b->pos_blk && (desc->c & 3) == 0 && desc->r <= 3) {
+  if (!(desc->flags & LINK_ELK_FUSED_GATHER) && b->A && b->pos_blk && (desc->c & 3) == 0 && desc->r <= 3) {
     rc = link_block_gather(b->S, b->blk_coords, b->cell_blk, grid, b->hdr, desc, m_cap, b->A, stream);
     if (rc != LINK_OK) return rc;
     return link_voxel_demod_ln(b->A, b->fin, b->vox_sorted, b->pos_blk, b->w_pos, b->alpha, b->ln_w, b->ln_b,

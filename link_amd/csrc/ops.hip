@@ -19,6 +19,17 @@ void set_error(const char *what, hipError_t e) {
 using namespace link;
 
 extern "C" int link_abi_version(void) { return 4; }
+extern "C" int32_t link_abi_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(link_grid_t);
+    case 1: return (int32_t)sizeof(link_elk_desc_t);
+    case 2: return (int32_t)sizeof(link_elk_buffers_t);
+    case 3: return (int32_t)sizeof(link_dc_grid_t);
+    case 4: return (int32_t)sizeof(link_dc_tuning_t);
+    case 5: return (int32_t)sizeof(link_dc_buffers_t);
+    default: return -1;
+  }
+}
 extern "C" const char *link_last_error(void) { return link::g_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------

@@ -198,7 +198,7 @@ class ElkCorePlan:
         `frames_in_flight`: one frame alone spreads every kernel over two workgroups per CU (k1_wgs 512, z-segments by
         the tile count); with several frames in flight the kernels of different frames share the CUs, so each takes one
         workgroup per CU and the gather kernel 2 z-segments (fewer halo planes summed twice).  Keyword overrides:
-        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 tile form, 1 cell-range form), k2_form, mode, k1_pipe."""
+        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form), k2_form, mode, k1_pipe."""
         if not self.dense:
             if kw:
                 raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan tuning")
@@ -211,7 +211,7 @@ class ElkCorePlan:
             if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg", "k2_dbg"):
                 raise L.LinkAmdError(f"ElkCorePlan.set_tuning: unknown key {k!r}")
             setattr(t, k, v)
-        if t.k1_form == 1 and multi and "k1_lds_pad" not in kw:
+        if t.k1_form == 0 and multi and "k1_lds_pad" not in kw:
             t.k1_lds_pad = 2048      # cell-range form: one of its 80 KB workgroups + a gather workgroup of another frame per CU
         return self
 

@@ -24,8 +24,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     assert L.lib().link_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header (sizes in bytes)
-    assert ctypes.sizeof(L.LinkGrid) == 36 and ctypes.sizeof(L.LinkElkDesc) == 24
+    assert ctypes.sizeof(L.LinkGrid) == 36 and ctypes.sizeof(L.LinkElkDesc) == 28
     assert ctypes.sizeof(L.LinkElkBuffers) == 26 * 8
+    for which, cls in enumerate((L.LinkGrid, L.LinkElkDesc, L.LinkElkBuffers, L.LinkDcGrid, L.LinkDcTuning, L.LinkDcBuffers)):
+        assert handle.link_abi_struct_size(which) == ctypes.sizeof(cls), cls.__name__
+    assert handle.link_abi_struct_size(99) == -1
+    # no process-global tuning state in the library: the setters of rounds 1-2 are gone from the ABI
+    for gone in ("link_set_tuning", "link_conv_set_tuning", "link_dc_set_tuning", "link_dc_set_tuning2", "link_dc_set_debug_buffer"):
+        assert not hasattr(handle, gone), gone
 
 
 def test_argument_validation_without_gpu():

@@ -29,7 +29,7 @@ def _oracle(blk, feats, coords, s, r, baseop, groups):
     (32, 1, "cos", 4, 3, 50, 8000), (16, 1, "cos_x", 2, 2, 24, 3000), (128, 1, "cos_x", 4, 2, 40, 3000)])
 @pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (0, 4), (1, 4)])
 def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n, k1_form, k2_form):
-    """k1_form: 0 = tile form of the fused pre_mix kernel (round 3), 1 = cell-range form of round 2; k2_form (C = 64): 0 =
+    """k1_form: 0 = cell-range form of the fused pre_mix kernel (the default), 1 = tile form (round 3); k2_form (C = 64): 0 =
     producer / consumer gather kernel, 4 = own-cell form (round 3)."""
     import link_amd as la
     torch.manual_seed(5)

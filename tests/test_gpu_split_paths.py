@@ -1,6 +1,6 @@
 """The alternative kernel paths of the C ABI must agree: split gather (link_block_gather +
 link_voxel_demod_ln) vs fused group gather vs lane=channel generic gather, and group vs generic
-modulate kernels -- selected through link_set_tuning -- on the same inputs."""
+modulate kernels -- selected per call through link_elk_desc_t::flags (no process-global switches) -- on the same inputs."""
 import ctypes
 
 import numpy as np
@@ -24,20 +24,17 @@ def test_kernel_paths_agree(C, groups, baseop, s, r):
     coords = s_uniform(n, grid=80, seed=C + r).cuda()
     feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
     lo, hi = (0, 0, 0, 0), (79, 79, 79, 0)
-    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device)
+    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device, layout="general")   # the flags select general-layout kernels
     plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
               blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
     outs = {}
-    try:
-        for name, settings in {"split+group+pair": {3: 1, 4: 1, 6: 1}, "fused-group": {3: 1, 4: 1, 6: 2},
-                               "no-pair": {3: 1, 4: 2, 6: 1}, "generic": {3: 2, 4: 2, 6: 2}}.items():
-            for k, v in settings.items():
-                assert lib.link_set_tuning(k, v) == 0
-            outs[name] = plan.run(feats, coords).clone()
-            assert plan.blocks() > 0
-    finally:
-        for k in (3, 4, 6):
-            lib.link_set_tuning(k, 1)
+    for name, flags in {"split+group+pair": 0, "fused-group": L.ELK_FUSED_GATHER, "no-pair": L.ELK_NO_PAIR,
+                        "column-walking gather": L.ELK_NO_DENSE_GRID,
+                        "generic": L.ELK_LANE_CHANNEL | L.ELK_NO_PAIR | L.ELK_FUSED_GATHER}.items():
+        plan.desc.flags = flags
+        outs[name] = plan.run(feats, coords).clone()
+        assert plan.blocks() > 0
+    plan.desc.flags = 0
     # every path within the parity gate of the ORACLE (1e-4 rel), and within 5e-5 of each other
     from oracle import link_oracle as O
     params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/k1ab.sh -- bench.py with the tile form (k1_form 0) and the cell-range form (k1_form 1) of the fused pre_mix kernel, 3 and 1 frames in flight
+# tools/k1ab.sh -- bench.py with the cell-range form (k1_form 0) and the tile form (k1_form 1) of the fused pre_mix kernel, 3 and 1 frames in flight
 R=${GRAFT_REPO_ROOT:-.}
 for form in ${FORMS:-0 1}; do
   for st in ${STREAMS:-3 1}; do

@@ -32,7 +32,7 @@ def plan(**kw):
 def k1_time(p, iters=60):
     b, g, d = p.buf, p.dcg, p.desc
     st = torch.cuda.current_stream().cuda_stream
-    idx = (lambda: lib.link_dc_index_ids(b.coords, N, ctypes.byref(g), b.cnt, b.sid, b.vcell, b.hdr, st)) if b.tune.k1_form == 0 else \
+    idx = (lambda: lib.link_dc_index_ids(b.coords, N, ctypes.byref(g), b.cnt, b.sid, b.vcell, b.hdr, st)) if b.tune.k1_form == 1 else \
           (lambda: lib.link_dc_index(b.coords, N, ctypes.byref(g), b.cnt, b.slots, b.vcell, b.hdr, st))
     p.run(feats, coords)
     ts, ts2 = [], []
@@ -52,14 +52,14 @@ def k1_time(p, iters=60):
 
 
 for wgs, pad in ((512, 0), (512, 20000), (512, 45056), (768, 0), (768, 18000), (1024, 0), (1024, 5000)):
-    p = plan(k1_form=0, k1_wgs=wgs, k1_lds_pad=pad)
+    p = plan(k1_form=1, k1_wgs=wgs, k1_lds_pad=pad)
     k1, k2 = k1_time(p)
     print(f"tile form k1_wgs {wgs:5d} lds pad {pad:6d}: K1 {k1:6.2f} us   K2 {k2:6.2f} us")
-p = plan(k1_form=1, k1_wgs=512)
+p = plan(k1_form=0, k1_wgs=512)
 print("cell-range form 512: K1 %.2f K2 %.2f" % k1_time(p))
 
 for wgs, pad in ((512, 0), (512, 45056), (768, 18000)):
-    p = plan(k1_form=0, k1_wgs=wgs, k1_lds_pad=pad)
+    p = plan(k1_form=1, k1_wgs=wgs, k1_lds_pad=pad)
     dbg = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
     p.buf.tune.k1_dbg = dbg.data_ptr()
     for _ in range(3):

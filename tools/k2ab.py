@@ -21,7 +21,7 @@ lib = L.lib()
 ref = None
 for form in (0, 4, 1):
     for zs in (0, 2, 3, 8):
-        p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k2_form=form, k2_zsplit=zs, k1_form=1)
+        p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k2_form=form, k2_zsplit=zs)
         p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
                blk.norm.weight, blk.norm.bias)
         out = p.run(feats, coords).clone()
@@ -48,7 +48,7 @@ for r, s in ((2, 6), (3, 7)):
     blkx = la.ELKBlock(C, C, groups=1, baseop="cos_x").to(dev).eval()
     ref = None
     for form in (0, 4):
-        p = la.ElkCorePlan(N, C, "cos_x", C, r, s, bounds, dev, layout="dense", k2_form=form, k1_form=1)
+        p = la.ElkCorePlan(N, C, "cos_x", C, r, s, bounds, dev, layout="dense", k2_form=form)
         p.bind(blkx.pre_mix[0].weight, blkx.pre_mix[1].weight, blkx.pre_mix[1].bias, blkx.pos_weight[0].weight, blkx.alpha,
                blkx.norm.weight, blkx.norm.bias)
         out = p.run(feats, coords).clone()
