@@ -40,7 +40,8 @@ from .tensor import SparseTensor
 from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
-           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv", "subm_conv_ln_add_relu"]
+           "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv", "subm_conv_ln_add_relu",
+           "invalidate_derived_weights"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
 _IO_DTYPES = {torch.float32: L.IO_F32, torch.float16: L.IO_F16, torch.bfloat16: L.IO_BF16}
@@ -944,17 +945,43 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
     return out
 
 
+def can_fold_batchnorm(bn: nn.Module) -> bool:
+    """A BatchNorm can be folded into a convolution's finish phase when it normalises with running statistics."""
+    return isinstance(bn, nn.BatchNorm1d) and bn.track_running_stats and bn.running_mean is not None and bn.running_var is not None
+
+
+def invalidate_derived_weights(model: nn.Module) -> None:
+    """Drop every cache derived from parameter VALUES (folded BatchNorm scale / shift, transposed / rounded / split
+    convolution weights).  The caches are keyed on tensor versions and storage pointers, which writes through `.data`
+    (EMA swaps, `param.data.copy_`) do not change: call this after such writes.  `load_state_dict` bumps versions and
+    needs no call."""
+    for m in model.modules():
+        m.__dict__.pop("_link_fold", None)
+        if "_kio" in m.__dict__:
+            m._kio = None
+        for p in m.parameters(recurse=False):
+            for k in ("_link_amp", "_link_split", "_link_padded"):
+                p.__dict__.pop(k, None)
+
+
 def fold_batchnorm(bn: nn.BatchNorm1d, conv_bias: Optional[torch.Tensor] = None):
     """(scale, shift) with bn(y + conv_bias) == y * scale + shift for a BatchNorm in inference mode (running
-    statistics); cached on the module and refreshed when any of its tensors changes (eight tiny launches
-    otherwise, per call)."""
-    ver = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
-        ((conv_bias._version, conv_bias.data_ptr()) if conv_bias is not None else ()) + (bn.weight.device,)
+    statistics; affine optional); cached on the module and refreshed when any of its tensors changes (eight tiny
+    launches otherwise, per call).  Writes through `.data` do not bump versions: see invalidate_derived_weights."""
+    if not can_fold_batchnorm(bn):
+        raise L.LinkAmdError("fold_batchnorm: the BatchNorm keeps no running statistics (track_running_stats=False)")
+    ts = tuple(t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
+    ver = tuple((t._version, t.data_ptr()) for t in ts) + \
+        ((conv_bias._version, conv_bias.data_ptr()) if conv_bias is not None else ()) + (bn.running_mean.device,)
     hit = bn.__dict__.get("_link_fold")
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
-    sc = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-    sh = bn.bias.detach().float() - bn.running_mean.float() * sc
+    sc = torch.rsqrt(bn.running_var.float() + bn.eps)
+    if bn.weight is not None:
+        sc = bn.weight.detach().float() * sc
+    sh = -bn.running_mean.float() * sc
+    if bn.bias is not None:
+        sh = sh + bn.bias.detach().float()
     if conv_bias is not None:
         sh = sh + conv_bias.detach().float() * sc
     sc, sh = sc.contiguous(), sh.contiguous()

@@ -124,14 +124,14 @@ def fuse_for_inference(model: nn.Module) -> nn.Module:
     (linkunet.py:18-92,217-224), so it applies to the reference's own network classes built on the aliased
     surface.  Children, parameter names and state_dict keys are untouched (only the container's class changes);
     training mode and autograd run the modules one by one as before.  Returns `model`."""
-    from .elk import Conv3d
+    from .elk import Conv3d, can_fold_batchnorm
     for mod in list(model.modules()):
         if not isinstance(mod, nn.Sequential) or isinstance(mod, _FusedSequential):
             continue
         kids = list(mod)
         groups, i = {}, 0
         while i < len(kids):
-            if isinstance(kids[i], Conv3d) and i + 1 < len(kids) and isinstance(kids[i + 1], nn.BatchNorm1d):
+            if isinstance(kids[i], Conv3d) and i + 1 < len(kids) and can_fold_batchnorm(kids[i + 1]):
                 relu = i + 2 < len(kids) and isinstance(kids[i + 2], nn.ReLU)
                 groups[i] = (i + 1, relu, i + (3 if relu else 2))
                 i += 3 if relu else 2

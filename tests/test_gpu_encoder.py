@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import lidar_like, rel_err
+from helpers import lidar_like, rel_err, s_uniform
 import link_encoder as LE
 
 pytestmark = pytest.mark.gpu
@@ -211,3 +211,36 @@ def test_batchnorm_training_statistics_on_the_hip_reductions(n, c):
     with torch.no_grad():
         again.weight.copy_(ours.weight); again.bias.copy_(ours.bias)
     assert torch.equal(again(la.SparseTensor(x, coords, 1)).F, first)
+
+
+def test_fuse_for_inference_skips_batchnorm_without_running_statistics_and_invalidation_hook():
+    """fuse_for_inference folds a BatchNorm only when it normalises with running statistics (affine optional); a Conv-BN
+    group with track_running_stats=False keeps running module by module; writes through `.data` (which bump no tensor
+    version) are picked up after la.invalidate_derived_weights(model)."""
+    import link_amd as la
+    torch.manual_seed(4)
+    coords = s_uniform(3000, grid=24, seed=5).cuda()
+    feats = torch.randn(3000, 16).cuda()
+
+    def net(affine, track):
+        m = torch.nn.Sequential(la.Conv3d(16, 16, 3), la.BatchNorm(16, affine=affine, track_running_stats=track), la.ReLU(True)).cuda().eval()
+        if track:
+            m[1].running_mean.uniform_(-0.3, 0.3); m[1].running_var.uniform_(0.5, 1.5)
+        return m
+    for affine, track in ((True, True), (False, True), (True, False)):
+        plain = net(affine, track)
+        with torch.no_grad():
+            ref = plain(la.SparseTensor(feats, coords, 1)).F.clone()
+            fused = la.fuse_for_inference(plain)
+            got = fused(la.SparseTensor(feats, coords, 1)).F
+        assert (type(fused).__name__ == "_FusedSequential") == track
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (affine, track)
+    m = la.fuse_for_inference(net(True, True))
+    with torch.no_grad():
+        a = m(la.SparseTensor(feats, coords, 1)).F.clone()
+        m[1].running_mean.data.add_(0.5)                   # no version bump
+        m[1].weight.data.mul_(2.0)
+        la.invalidate_derived_weights(m)
+        b = m(la.SparseTensor(feats, coords, 1)).F
+        ref = torch.relu(m[1](m[0](la.SparseTensor(feats, coords, 1))).F)
+    assert not torch.equal(a, b) and rel_err(b.cpu().numpy(), ref.cpu().numpy()) < 1e-5
