@@ -557,9 +557,12 @@ typedef struct {
   int32_t k1_form;     /* 0 = cell-range form (a wave owns a range of cells: LDS voxel list + X tile; the faster one with frames in
                           flight); 1 = tile form (id slots, in-wave id sort, per-cell sums by segmented DPP scan in the matrix-core
                           accumulator layout; 36 KB of LDS, any cell size up to the slot capacity in one pass structure) */
-  int32_t k2_form;     /* 0 = producer / consumer form; bit 0: single-role form (workgroup-wide dealing); bit 1: one voxel per lane
-                          group instead of a pair (forms 0 / 1); bit 2: own-cell form (a lane group de-modulates its own cell from the
-                          A row in registers; 2-slot plane ring fed by a dedicated DMA wave; 39 KB of LDS) */
+  int32_t k2_form;     /* 0 = by measurement: producer / consumer form with quad consumers (two-part rows whose channels j and j + C/2
+                          share theta), producer / consumer form with pair consumers (other two-part rows), own-cell form (cos_x, r = 3),
+                          single-role form (cos_x, r = 2).  bit 3: pair consumers (the round-2 kernel) instead of quad consumers;
+                          bit 0: single-role form (workgroup-wide dealing); bit 1: one voxel per lane group instead of a pair (pair
+                          forms); bit 2: own-cell form (a lane group de-modulates its own cell from the A row in registers; 2-slot
+                          plane ring fed by a dedicated DMA wave; 39 KB of LDS) */
   int32_t mode;        /* 0 = default (7); else bit 0 fused pre_mix+modsum, bit 1 dense-cell demod kernel, bit 2 fused
                           gather + de-modulate (C = 64) -- the unfused stages are what the fused ones are tested against */
   int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */

@@ -28,6 +28,12 @@ using namespace link;
 #ifndef DC_K2_ABL
 #define DC_K2_ABL 0      /* ablation builds of the split gather kernel (wrong results!): 1 no sincos, 2 no LayerNorm reductions, 4 no pair processing, 8 no output stores */
 #endif
+#ifndef DC_K2_SECOND_ROUND
+#define DC_K2_SECOND_ROUND 1 /* split gather kernel: the producer waves take pairs 16..31 of the previous plane (0: the consumer waves take every pair) */
+#endif
+#ifndef DC_K2_PIPE_READS
+#define DC_K2_PIPE_READS 0   /* split gather kernel, producer half: the plane's three x-offsets as one pipelined LDS request (dense_gather.h) */
+#endif
 #ifndef DC_K1_MFMA32
 #define DC_K1_MFMA32 1   /* pairs of 16-channel blocks on v_mfma_f32_16x16x32_f16 */
 #endif
@@ -1098,6 +1104,8 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
 
 #include "dense_gather_own_impl.h"
 
+#include "dense_gather_quad_impl.h"
+
 template <int OP, int R, bool PAIR, bool DIV>
 __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
@@ -1234,7 +1242,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
       const int Tv = __builtin_amdgcn_readlane(incl, 15);          // every DPP row holds the same 16 counts: lane 15 has the total
       const int npair = single ? Tv : (Tv + 1) >> 1;
       const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (jp & 3) * K2::REC_BYTES);
-      for (int p = pstart; p < npair; p += 32) {
+      for (int p = pstart; p < npair; p += DC_K2_SECOND_ROUND ? 32 : 16) {
         if (dbg) tq_iters++;
         const int vA = single ? p : 2 * p, vB = (!single && 2 * p + 1 < Tv) ? 2 * p + 1 : vA;
         const bool hasB = !single && 2 * p + 1 < Tv;
@@ -1353,7 +1361,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     asm volatile("s_barrier" ::: "memory");
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
     if (producer && i >= nplanes) {
-      if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
+      if (DC_K2_SECOND_ROUND && i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
       if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; }
       continue;
     }
@@ -1373,9 +1381,13 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
       const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
-      dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
-      dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
-      if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
+      if constexpr (P == 2 && R == 3 && DC_K2_PIPE_READS) {
+        dc_read_plane_p2r3<C>(ra, ca, cur, cc);       // one pipelined LDS request instead of three dependent round trips
+      } else {
+        dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
+        dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
+        if (R == 3) dc_read_dx<C, P, R, R == 3 ? 2 : 1>(ra, ca, cur, cc);
+      }
     }
     n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
     if (j >= R - 1) {
@@ -1410,7 +1422,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
     n_prev = n_here;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_box += tqb - tqa; tqa = tqb; }
-    if (i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
+    if (DC_K2_SECOND_ROUND && i - 1 >= R - 1) pairs_of(i - 1, grp + 16);
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; }
   }
   if (dbg && lane == 0) {
@@ -1463,12 +1475,29 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, KO::LDS_BYTES + k2_pad);                   \
     hipLaunchKernelGGL((k_dc_gather_demod_own<OP, R, PP, DD>), dim3((unsigned)grid), dim3(320), KO::LDS_BYTES + k2_pad, st, b->S, \
                        b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->fin, b->w_pos, b->alpha, b->ln_w,      \
-                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out);                  \
+                       b->ln_b, d.cg, d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out,                   \
+                       reinterpret_cast<unsigned long long *>(b->tune.k2_dbg));                                       \
   } while (0)
     if (pair) { if (div) LINK_K2O(true, true); else LINK_K2O(true, false); }
     else { if (div) LINK_K2O(false, true); else LINK_K2O(false, false); }
 #undef LINK_K2O
     return check_launch("link_dc_gather_demod");
+  }
+  if constexpr (dc_k2q_cfg<OP, R>::FITS) {             // two-part rows, theta shared by channels j / j + 32: quad consumers (bit 3: round-2 pair form)
+    if (pair && !(b->tune.k2_form & 9) && !k2_single) {
+      using KQ = dc_k2q_cfg<OP, R>;
+#define LINK_K2Q(DD)                                                                                                  \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_quad<OP, R, DD>),                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, KQ::LDS_BYTES + k2_pad);                   \
+    hipLaunchKernelGGL((k_dc_gather_demod_quad<OP, R, DD>), dim3((unsigned)grid), dim3(512), KQ::LDS_BYTES + k2_pad, st, b->S, \
+                       b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->w_pos, b->alpha, b->ln_w, b->ln_b, d.cg, \
+                       d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out);                                  \
+  } while (0)
+      if (div) LINK_K2Q(true); else LINK_K2Q(false);
+#undef LINK_K2Q
+      return check_launch("link_dc_gather_demod");
+    }
   }
   if (!(b->tune.k2_form & 1) && K2::SPLIT_FITS) {
     if (pair) { if (div) LINK_K2S(true, true); else LINK_K2S(true, false); }

@@ -24,7 +24,12 @@ struct dc_k2o_cfg {
   static constexpr int PLANE = NPW * 1024;
   static constexpr int CNT_OFF = PLANE, REC_OFF = PLANE + 256;
   static constexpr int BUF_BYTES = REC_OFF + 16 * DC_INL * 16;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+#ifndef DC_K2O_RING
+#define DC_K2O_RING 2      /* plane ring slots: 2 = prefetch distance 1 (39 KB), 3 = distance 2 (59 KB) */
+#endif
+  static constexpr int RING = DC_K2O_RING;
+  static constexpr int NI = NPW + 2;                   // DMA instructions per plane
+  static constexpr int LDS_BYTES = RING * BUF_BYTES;
   static_assert(G::NCOL <= 64, "count image: one wave-instruction");
   static_assert(G::NG == 16, "16 columns per workgroup");
 };
@@ -34,8 +39,10 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ fin, const float *__restrict__ w_pos, const float *__restrict__ alpha,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n,
-    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, void *__restrict__ out) {
+    link_dc_grid_t g, int txn, int tyn, int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg) {
   using KO = dc_k2o_cfg<OP, R>;
+  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_bar = 0, tq_box = 0, tq_pairs = 0, tq_dma = 0;
+  int tq_rounds = 0;
   using K = typename KO::G;
   constexpr int C = 64, P = KO::P, LPR = 16, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
   constexpr int RB = P * C * 4;
@@ -80,7 +87,7 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
     auto issue = [&](int plane) {
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
-      char *buf = lds + (plane & 1) * KO::BUF_BYTES;
+      char *buf = lds + (plane % KO::RING) * KO::BUF_BYTES;
 #pragma unroll
       for (int i = 0; i < KO::NPW; i++) {
         const char *src = Sb + (size_t)src_off[i] + (size_t)pz * RB;
@@ -96,15 +103,36 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rsrc,
                                        (__attribute__((address_space(3))) void *)(buf + KO::REC_OFF), 16, 0, 0);
     };
-    issue(0);
-    wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");
-    for (int i = 0; i < nplanes; i++) {
-      if (i + 1 < nplanes) {                            // ring slot (i+1) & 1 was read during step i-1: free since the last barrier
-        issue(i + 1);
-        wait_vmcnt<0>();
-      }
+    if constexpr (KO::RING == 2) {
+      issue(0);
+      wait_vmcnt<0>();
       asm volatile("s_barrier" ::: "memory");
+      for (int i = 0; i < nplanes; i++) {
+        unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
+        if (i + 1 < nplanes) {                          // ring slot (i+1) & 1 was read during step i-1: free since the last barrier
+          issue(i + 1);
+          wait_vmcnt<0>();
+        }
+        if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_dma += tqb - tqa; tqa = tqb; }
+        asm volatile("s_barrier" ::: "memory");
+        if (dbg) tq_bar += __builtin_amdgcn_s_memtime() - tqa;
+      }
+    } else {
+      issue(0);
+      if (nplanes > 1) issue(1);
+      if (nplanes > 1) wait_vmcnt<KO::NI>(); else wait_vmcnt<0>();      // plane 0 landed (this wave issues nothing but DMAs: exact counts)
+      asm volatile("s_barrier" ::: "memory");
+      for (int i = 0; i < nplanes; i++) {
+        if (i + 2 < nplanes) issue(i + 2);              // ring slot (i+2) % 3 was read during step i-1
+        if (i + 1 < nplanes) {                          // plane i+1 must be in before the next barrier
+          if (i + 2 < nplanes) wait_vmcnt<KO::NI>(); else wait_vmcnt<0>();
+        }
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+    if (dbg && lane == 0) {
+      unsigned long long *d = dbg + ((size_t)L * 8 + 4) * 8;
+      d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[6] = nplanes; d[7] = 3;
     }
     return;
   }
@@ -133,7 +161,8 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
   for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
   asm volatile("s_barrier" ::: "memory");              // plane 0 is in ring slot 0
   for (int i = 0; i < nplanes; i++) {
-    const uint32_t bufa = lds_base + (uint32_t)((i & 1) * KO::BUF_BYTES);
+    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const uint32_t bufa = lds_base + (uint32_t)((i % KO::RING) * KO::BUF_BYTES);
     float4 cur[P];
     float cc = 0.f;
 #pragma unroll
@@ -149,6 +178,7 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
       }
     }
     const int n_here = lds_rd_b32(bufa + (uint32_t)KO::CNT_OFF + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+    if (dbg) { asm volatile("" :: "v"(cur[0].x)); const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_box += tqb - tqa; tqa = tqb; }
     if (i >= R - 1) {
       const int po = pz0 + i - (R - 1) + HLO;
       float4 a[P];
@@ -175,6 +205,7 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
       const int n_own = col_ok ? n_prev : 0;            // the plane that closed is the previous one for both R
       const uint32_t recb = bufa + (uint32_t)KO::REC_OFF + (uint32_t)(grp * DC_INL * 16);
       for (int k = 0; k < n_own; k += 2) {              // the cell's voxels two at a time (ascending id: the fused pre_mix kernel ordered them)
+        if (dbg) tq_rounds++;
         const bool hasB = k + 1 < n_own;
         const int kA = k, kB = hasB ? k + 1 : k;
         v4f_t qa, qb;
@@ -273,6 +304,12 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
     for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
     c0 = c1; c1 = cc;
     n_prev = n_here;
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_pairs += tqb - tqa; tqa = tqb; }
     asm volatile("s_barrier" ::: "memory");            // every wave is done with ring slot i & 1; plane i+1 is in the other one
+    if (dbg) tq_bar += __builtin_amdgcn_s_memtime() - tqa;
+  }
+  if (dbg && lane == 0) {
+    unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
+    d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = 0; d[2] = tq_bar; d[3] = tq_box; d[4] = tq_pairs; d[5] = tq_rounds; d[6] = nplanes; d[7] = 1;
   }
 }

@@ -1,0 +1,320 @@
+// link_amd/csrc/dense_gather_quad_impl.h -- producer / consumer form of the fused box sum + de-modulate kernel with
+// QUAD consumers (C = 64, two-part rows, theta shared by channels j and j + 32; round 3).  Included inside DC_IO_NS by
+// dense_fused_impl.h after the K2 configuration structs and LDS helpers.
+//
+// tools/k2prof.py on the round-2 producer / consumer form (k_dc_gather_demod_split): a plane step lasts ~4600 ticks; the
+// producer waves spend 1930 of them in three dependent LDS round trips of the box sum, 625 in a second round of pairs and
+// 844 in the barrier, the consumer waves 2277 in the pair loop and 1447 in the barrier.  Both halves are chains of
+// dependent latencies (LDS round trips, DPP reductions), not pipe time: VALU 40 % busy, LDS array 20 %.  This form
+// shortens both chains:
+//   * producers and consumers run SEPARATE loops (own live registers: the producers' box sum takes the plane's three
+//     x-offsets as one pipelined LDS request, dense_gather.h -- in the common loop of the round-2 kernel that spilled);
+//     the producers issue no stores and never take pairs, so their counted DMA waits are exact;
+//   * a consumer voxel is handled by a QUAD of lanes (16 channels each) instead of a pair of voxels by 16 lanes (4
+//     channels each): the four consumer waves take 64 voxels per round -- a plane holds ~32, so there is ONE round per
+//     plane where the pair form needed 1.5 of 16 pairs plus the producers' help; LayerNorm sums are 15 in-lane adds + two
+//     quad steps instead of four 16-lane reductions; the voxel -> (cell, slot) map is 15 scalar compares against the
+//     plane's count prefix (v_readlane) instead of scan / two ballots / three ds_bpermute per pair.
+// Lane q of a quad holds the 16-byte pieces q, q+4, q+8, q+12 of a row (channels 16 j + 4 q + e): pieces p and p + 8
+// share theta, so a lane evaluates 8 sincos per voxel.
+#pragma once
+
+template <int OP, int R>
+struct dc_k2q_cfg {
+  using K2 = dc_k2_cfg<OP, R>;
+  static constexpr int PAR_OFF = K2::SPLIT_LDS_BYTES;            // LayerNorm weight | bias image (2 x 64 floats)
+  static constexpr int LDS_BYTES = PAR_OFF + 2 * 64 * 4;
+  static constexpr bool FITS = K2::P == 2 && 2 * LDS_BYTES <= 160 * 1024;
+};
+
+// record + the eight A-row pieces of a quad lane: nine b128 reads in flight, ONE wait
+__device__ __forceinline__ void lds_rd9_b128(uint32_t ar, uint32_t a0, uint32_t a1, v4f_t &r, v4f_t (&x)[2][4]) {
+  asm volatile("ds_read_b128 %0, %9\n\t"
+               "ds_read_b128 %1, %10\n\tds_read_b128 %2, %10 offset:64\n\tds_read_b128 %3, %10 offset:128\n\tds_read_b128 %4, %10 offset:192\n\t"
+               "ds_read_b128 %5, %11\n\tds_read_b128 %6, %11 offset:64\n\tds_read_b128 %7, %11 offset:128\n\tds_read_b128 %8, %11 offset:192\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(r), "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[0][3]), "=&v"(x[1][0]), "=&v"(x[1][1]),
+                 "=&v"(x[1][2]), "=&v"(x[1][3])
+               : "v"(ar), "v"(a0), "v"(a1)
+               : "memory");
+}
+__device__ __forceinline__ void lds_rd8_b128(uint32_t a0, uint32_t a1, v4f_t (&x)[2][4]) {
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:192\n\t"
+               "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:64\n\tds_read_b128 %6, %9 offset:128\n\tds_read_b128 %7, %9 offset:192\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[0][3]), "=&v"(x[1][0]), "=&v"(x[1][1]), "=&v"(x[1][2]),
+                 "=&v"(x[1][3])
+               : "v"(a0), "v"(a1)
+               : "memory");
+}
+// sum over the four lanes of a quad (quad_perm [1,0,3,2] then [2,3,0,1])
+__device__ __forceinline__ float dc_quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
+template <int OP, int R, bool DIV>
+__global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
+    const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
+    const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
+    int zsplit, int nwg, void *__restrict__ out) {
+  using K2 = dc_k2_cfg<OP, R>;
+  using KQ = dc_k2q_cfg<OP, R>;
+  using K = typename K2::G;
+  constexpr int C = 64, P = 2, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
+  constexpr int RB = P * C * 4;
+  static_assert(K2::P == 2, "two-part rows");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const bool producer = threadIdx.x < 256;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x & 255) >> 6);
+  const int per = (nwg + 7) >> 3;
+  const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (L >= nwg) return;
+  int t = L;
+  const int zseg = t % zsplit; t /= zsplit;
+  const int ty = t % tyn; t /= tyn;
+  const int tx = t % txn;
+  const int b = t / txn;
+  const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
+  const int PDx = g.pdim[0], PDy = g.pdim[1], PDz = g.pdim[2];
+  const int x0 = tx * TX, y0 = ty * TY;
+  const int zs = (int)(((long long)Dz * zseg) / zsplit), ze = (int)(((long long)Dz * (zseg + 1)) / zsplit);
+  if (zs >= ze) return;
+  const int nplanes = (ze - zs) + R - 1;
+  const int pz0 = zs + 1 - HLO;
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const uint32_t abuf0 = lds_base + K2::SPLIT_ABUF_OFF, ncnt0 = lds_base + K2::SPLIT_NCNT_OFF;
+  if (threadIdx.x < 128) {                             // LayerNorm weight | bias image for the consumers
+    float *par = reinterpret_cast<float *>(lds + KQ::PAR_OFF);
+    par[threadIdx.x] = threadIdx.x < 64 ? ln_w[threadIdx.x] : ln_b[threadIdx.x - 64];
+  }
+  if (producer) {
+    // ================= producers: plane ring (LDS-DMA, 3 slots, prefetch distance 2) + box sums -> A rows =================
+    auto col_cell0 = [&](int hx, int hy) {           // padded cell id of (haloed column, z = 0), clamped into the grid
+      int px = x0 + 1 - HLO + hx, py = y0 + 1 - HLO + hy;
+      px = px < PDx - 1 ? px : PDx - 1;
+      py = py < PDy - 1 ? py : PDy - 1;
+      return (uint32_t)(((b * PDx + px) * PDy + py) * PDz);
+    };
+    uint32_t src_off[K::PASSES];
+#pragma unroll
+    for (int i = 0; i < K::PASSES; i++) {
+      int pid = i * 256 + tid;
+      if (pid >= K::NPC) pid = K::NPC - 1;
+      const int col = pid / K::RP, pcs = pid % K::RP;
+      src_off[i] = col_cell0(col / HY, col % HY) * (uint32_t)RB + (uint32_t)pcs * 16u;
+    }
+    uint32_t cnt_cell0;
+    {
+      int e = wave * 64 + lane;
+      if (e >= K::NCOL) e = K::NCOL - 1;
+      cnt_cell0 = col_cell0(e / HY, e % HY);
+    }
+    uint32_t rec_cell0;                                // inline slot records of the 16 interior cells of an output plane
+    int rec_k;
+    {
+      const int piece = wave * 16 + (lane & 15);
+      const int col = piece >> 2;
+      rec_k = piece & 3;
+      rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
+    }
+    const char *Sb = reinterpret_cast<const char *>(S_);
+    auto issue = [&](int plane) {
+      int pz = pz0 + plane;
+      pz = pz < PDz - 1 ? pz : PDz - 1;
+      char *buf = lds + (plane % 3) * K2::SPLIT_BUF_BYTES;
+#pragma unroll
+      for (int i = 0; i < K::PASSES; i++) {
+        const bool surplus = (i * 256 + wave * 64) >= K::NPC;            // wave-uniform: repeat pass 0 (same data, same place)
+        const int ii = surplus ? 0 : i;
+        const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+      const int32_t *csrc = cell_n + cnt_cell0 + pz;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
+                                       (__attribute__((address_space(3))) void *)(buf + K2::SPLIT_PLANE + wave * 256), 4, 0, 0);
+      int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
+      po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
+      const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
+      if (lane < 16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rsrc,
+                                         (__attribute__((address_space(3))) void *)(lds + K2::SPLIT_REC_OFF + (plane & 3) * K2::REC_BYTES + wave * 256), 16, 0, 0);
+    };
+    const int grp = tid >> 4, li = tid & 15;
+    const int ix = grp / TY, iy = grp % TY;
+    const bool col_ok = (x0 + ix < Dx) && (y0 + iy < Dy);
+    const uint32_t row_lane = (uint32_t)((ix * HY + iy) * RB + li * 16);
+    const uint32_t cnt_lane = (uint32_t)((ix * HY + iy) * 4);
+    float4 r0[P], r1[P];
+    float c0 = 0.f, c1 = 0.f;
+    int n_prev = 0;                                    // voxels in this group's cell of the previous plane
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    issue(0);
+    if (nplanes > 1) issue(1);
+    for (int i = 0; i <= nplanes; i++) {
+      if (i < nplanes) {
+        if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the A rows of the previous step are in LDS
+      asm volatile("s_barrier" ::: "memory");
+      if (i >= nplanes) break;
+      if (i + 2 < nplanes) issue(i + 2);
+      const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
+      float4 cur[P];
+      float cc = 0.f;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+      {
+        const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
+        if constexpr (R == 3) {
+          dc_read_plane_p2r3<C>(ra, ca, cur, cc);
+        } else {
+          dc_read_dx<C, P, R, 0>(ra, ca, cur, cc);
+          dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
+        }
+      }
+      const int n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+      if (i >= R - 1) {
+        const uint32_t abuf = abuf0 + (uint32_t)((i & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((i & 1) * K2::NG * 4);
+        float4 a[P];
+        float den;
+        if (R == 3) {
+          den = (c0 + c1) + cc;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            a[pp].x = (r0[pp].x + r1[pp].x) + cur[pp].x; a[pp].y = (r0[pp].y + r1[pp].y) + cur[pp].y;
+            a[pp].z = (r0[pp].z + r1[pp].z) + cur[pp].z; a[pp].w = (r0[pp].w + r1[pp].w) + cur[pp].w;
+          }
+        } else {
+          den = c1 + cc;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            a[pp].x = r1[pp].x + cur[pp].x; a[pp].y = r1[pp].y + cur[pp].y;
+            a[pp].z = r1[pp].z + cur[pp].z; a[pp].w = r1[pp].w + cur[pp].w;
+          }
+        }
+        const float inv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++)
+          lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
+                      make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
+        if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_prev : 0);   // the plane that closed is the previous one for both R
+      }
+#pragma unroll
+      for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
+      c0 = c1; c1 = cc;
+      n_prev = n_here;
+    }
+    return;
+  }
+  // ================= consumers: one voxel per quad of lanes =================
+  const int q = lane & 3, li16 = lane & 15;
+  const int qd = wave * 16 + (lane >> 2);              // 0..63: this quad's slot among the plane's voxels
+  const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * C * IO_BYTES));
+  // theta weights of the lane's channels 16 j + 4 q + e: blocks j and j + 2 share theta (channels ch and ch + 32)
+  float w0[2][4], w1[2][4], w2[2][4], al[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int tc = (16 * j + 4 * q + e) % cg;
+      w0[j][e] = w_pos[3 * tc + 0]; w1[j][e] = w_pos[3 * tc + 1]; w2[j][e] = w_pos[3 * tc + 2];
+      al[j][e] = alpha ? alpha[tc] : 1.0f;
+    }
+  const uint32_t par = lds_base + (uint32_t)KQ::PAR_OFF + (uint32_t)(q * 16);
+  for (int i = 0; i <= nplanes; i++) {
+    asm volatile("s_barrier" ::: "memory");
+    const int jp = i - 1;                               // the output-plane step whose A rows the producers finished last step
+    if (jp < R - 1 || jp >= nplanes) continue;
+    const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
+    const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (jp & 3) * K2::REC_BYTES);
+    const int po = pz0 + jp - (R - 1) + HLO;
+    // inclusive prefix of the 16 cell counts: every DPP row holds all of them, so they become wave-uniform scalars
+    int incl = lds_rd_b32(ncnt + (uint32_t)(li16 * 4));
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+    int e_[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) e_[k] = __builtin_amdgcn_readlane(incl, k);
+    const int Tv = e_[15];
+    for (int base = 0; base < Tv; base += 64) {         // wave-uniform: one pass unless the plane holds more than 64 voxels
+      const bool valid = base + qd < Tv;                // quads without a voxel repeat the last one and store nothing
+      const int v = valid ? base + qd : Tv - 1;
+      int c = 0, start = 0;                             // cell of voxel v = number of prefix entries <= v; start = the last such entry
+#pragma unroll
+      for (int k = 0; k < 15; k++) {
+        const bool le = e_[k] <= v;                     // e_ is non-decreasing and wave-uniform (scalar operands)
+        c += le ? 1 : 0;
+        start = le ? e_[k] : start;
+      }
+      const int k = v - start;
+      v4f_t rq, Av[2][4];
+      lds_rd9_b128(recb + (uint32_t)((c * DC_INL + (k < DC_INL ? k : 0)) * 16), abuf + (uint32_t)(c * RB + q * 16),
+                   abuf + (uint32_t)(c * RB + C * 4 + q * 16), rq, Av);
+      int4 rec = make_int4(__float_as_int(rq.x), __float_as_int(rq.y), __float_as_int(rq.z), __float_as_int(rq.w));
+      if (k >= DC_INL) {                                // overflow records (cells with more than DC_INL voxels): ordinary loads
+        const int pcell = ((b * PDx + x0 + c / TY + 1) * PDy + y0 + c % TY + 1) * PDz + po;
+        rec = slots[dc_slot(g, pcell, k)];
+      }
+      float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
+      if (DIV) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+      float th[2][4], sn[2][4], cs[2][4];
+      bool big = false;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          th[j][e] = theta_of(x, y, z, w0[j][e], w1[j][e], w2[j][e], al[j][e]);
+          big |= !(fabsf(th[j][e]) < 32768.0f);
+        }
+      if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) sincos_nocall(th[j][e], sn[j][e], cs[j][e]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) sincos_small(th[j][e], sn[j][e], cs[j][e]);
+      }
+      float nv[4][4], s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float A0 = Av[0][j][e], A1 = Av[1][j][e], cc_ = cs[j & 1][e], ss_ = sn[j & 1][e];
+          if (OP == LINK_OP_SIN) nv[j][e] = __fsub_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));      // linkunet.py:148
+          else nv[j][e] = __fadd_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));                         // :162
+          s += nv[j][e];
+        }
+      s = dc_quad_sum(s);
+      const float mean = s * (1.0f / C);
+      float qq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float d = nv[j][e] - mean;
+          qq += d * d;
+        }
+      qq = dc_quad_sum(qq);
+      const float rs = __builtin_amdgcn_rsqf(qq * (1.0f / C) + eps);
+      v4f_t gwb[2][4];                                  // LayerNorm weight | bias pieces q, q+4, q+8, q+12
+      lds_rd8_b128(par, par + 256u, gwb);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float4 o;
+        o.x = (nv[j][0] - mean) * rs * gwb[0][j][0] + gwb[1][j][0]; o.y = (nv[j][1] - mean) * rs * gwb[0][j][1] + gwb[1][j][1];
+        o.z = (nv[j][2] - mean) * rs * gwb[0][j][2] + gwb[1][j][2]; o.w = (nv[j][3] - mean) * rs * gwb[0][j][3] + gwb[1][j][3];
+        io_st4(r_out, (uint32_t)rec.w * (uint32_t)C + (uint32_t)(16 * j + 4 * q), valid, o);
+      }
+    }
+  }
+}

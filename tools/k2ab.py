@@ -1,4 +1,4 @@
-"""tools/k2ab.py -- forms of the fused gather + de-modulate kernel on cfg2 (k2_form 0 producer / consumer, 4 own-cell, 1 single-role) x z-segments: HIP-event time of the kernel inside the full step + bitwise comparison of the outputs."""
+"""tools/k2ab.py -- forms of the fused gather + de-modulate kernel on cfg2 (k2_form 0 default = quad consumers, 8 pair consumers, 4 own-cell, 1 single-role) x z-segments: HIP-event time of the kernel inside the full step + bitwise comparison of the outputs."""
 import ctypes
 import os
 import sys
@@ -19,7 +19,7 @@ coords = s_uniform(N, seed=0).to(dev)
 bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
 lib = L.lib()
 ref = None
-for form in (0, 4, 1):
+for form in (8, 0, 4, 1):
     for zs in (0, 2, 3, 8):
         p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k2_form=form, k2_zsplit=zs)
         p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,

@@ -17,8 +17,9 @@ blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev).eval()
 feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1)).to(dev)
 coords = s_uniform(N, seed=0).to(dev)
 bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
-for zs in (0, 2, 1):
-    p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k2_zsplit=zs)
+FORM = int(os.environ.get("K2_FORM", 0))
+for zs in (0, 2):
+    p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k2_zsplit=zs, k2_form=FORM)
     p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
            blk.norm.weight, blk.norm.bias)
     dbg = torch.zeros(1024 * 64, dtype=torch.int64, device=dev)
@@ -27,8 +28,10 @@ for zs in (0, 2, 1):
         p.run(feats, coords)
     torch.cuda.synchronize()
     d = dbg.view(-1, 8).cpu().numpy()
-    for role, nm in ((1, "producer"), (2, "consumer")):
+    for role, nm in ((1, "producer / compute"), (2, "consumer"), (3, "DMA wave")):
         e = d[d[:, 7] == role]
+        if len(e) == 0:
+            continue
         print(f"zsplit {zs} {nm}: {len(e)} waves, planes {e[:, 6].mean():.1f}; ticks per wave mean (per plane-step)")
         for i, k in enumerate(["total", "dma wait", "barrier", "box sums", "pairs"]):
             print(f"   {k:10s} {e[:, i].mean():9.0f}  ({e[:, i].sum() / e[:, 6].sum():7.0f})   max {e[:, i].max():9.0f}")
