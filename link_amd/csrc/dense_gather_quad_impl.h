@@ -59,9 +59,13 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
-    int zsplit, int nwg, void *__restrict__ out) {
+    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg) {
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
+  // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
+  // the quad round
+  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
+  int tq_rounds = 0;
   using K = typename K2::G;
   constexpr int C = 64, P = 2, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
   constexpr int RB = P * C * 4;
@@ -156,11 +160,14 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     issue(0);
     if (nplanes > 1) issue(1);
     for (int i = 0; i <= nplanes; i++) {
+      unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
       if (i < nplanes) {
         if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the A rows of the previous step are in LDS
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_dma += tqb - tqa; tqa = tqb; }
       asm volatile("s_barrier" ::: "memory");
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
       if (i >= nplanes) break;
       if (i + 2 < nplanes) issue(i + 2);
       const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
@@ -208,6 +215,11 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
       for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
       c0 = c1; c1 = cc;
       n_prev = n_here;
+      if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_work += __builtin_amdgcn_s_memtime() - tqa; }
+    }
+    if (dbg && lane == 0) {
+      unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
+      d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_work; d[4] = 0; d[5] = 0; d[6] = nplanes; d[7] = 1;
     }
     return;
   }
@@ -227,7 +239,9 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     }
   const uint32_t par = lds_base + (uint32_t)KQ::PAR_OFF + (uint32_t)(q * 16);
   for (int i = 0; i <= nplanes; i++) {
+    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_barrier" ::: "memory");
+    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
     const int jp = i - 1;                               // the output-plane step whose A rows the producers finished last step
     if (jp < R - 1 || jp >= nplanes) continue;
     const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
@@ -244,6 +258,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     for (int k = 0; k < 16; k++) e_[k] = __builtin_amdgcn_readlane(incl, k);
     const int Tv = e_[15];
     for (int base = 0; base < Tv; base += 64) {         // wave-uniform: one pass unless the plane holds more than 64 voxels
+      if (dbg) tq_rounds++;
       const bool valid = base + qd < Tv;                // quads without a voxel repeat the last one and store nothing
       const int v = valid ? base + qd : Tv - 1;
       int c = 0, start = 0;                             // cell of voxel v = number of prefix entries <= v; start = the last such entry
@@ -316,5 +331,10 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
         io_st4(r_out, (uint32_t)rec.w * (uint32_t)C + (uint32_t)(16 * j + 4 * q), valid, o);
       }
     }
+    if (dbg) tq_work += __builtin_amdgcn_s_memtime() - tqa;
+  }
+  if (dbg && lane == 0) {
+    unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
+    d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = 0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
   }
 }
