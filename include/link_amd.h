@@ -236,6 +236,8 @@ typedef struct {
 #define LINK_ELK_NO_PAIR 2         /* no voxel-pair sharing of sincos between channels j and j + C/2 */
 #define LINK_ELK_FUSED_GATHER 4    /* one fused gather + de-modulate kernel instead of block gather + per-voxel kernel */
 #define LINK_ELK_NO_DENSE_GRID 8   /* block gather: column-walking form even on mostly occupied grids */
+#define LINK_ELK_TILES 16          /* link_elk_core_forward: the tile form (two launches: link_elk_premix_modsum_tiles +
+                                      link_elk_gather_demod_tiles); needs link_elk_buffers_t::s_bytes */
 
 /* pre_mix: fin = LayerNorm(F @ Wpre^T) * g + b  (linkunet.py:109-112,132).  F fp[N,C], Wpre fp[C,C]
  * (nn.Linear layout [out,in]).  C <= 256. */
@@ -298,7 +300,31 @@ typedef struct {
   float *S;                  /* fp[(m_cap+1)*(P*C+1)] scratch: block table rows + zero row + counts */
   float *A;                  /* fp[m_cap, P*C]     scratch: normalised neighbour sums (NULL: fused gather) */
   float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
+  int64_t s_bytes;           /* bytes available at S (0: the size above); LINK_ELK_TILES needs link_elk_tiles_table_bytes() */
 } link_elk_buffers_t;
+
+/* Tile form of the section-C kernels on a built index (elk_tiles_impl.h): TWO launches for R_core instead of four, made for
+ * the frames the dense-cell layout (section E) does not take: sparse block grids with many voxels per occupied block
+ * (LiDAR: linkunet.py:345-363 on SemanticKITTI, scn.py:586-607 on nuScenes), C in {16, 32, 64, 128}, r in {2, 3}.
+ *   link_elk_premix_modsum_tiles  = link_premix_ln + link_modulate_block_sum in one pass over the voxels in block order
+ *       (pre_mix on the matrix cores; per-block sums by segmented scans in the accumulator layout; blocks of any size are
+ *       split over waves and combined in a fixed order: bitwise reproducible, no atomics).  Writes the table S (rows,
+ *       zero row, counts -- the layout of link_modulate_block_sum -- followed by scratch rows: S must hold
+ *       link_elk_tiles_table_bytes(desc, n, m_cap) bytes) and, for LINK_OP_COSX only, fin.
+ *   link_elk_gather_demod_tiles   = link_block_gather + link_voxel_demod_ln in one kernel: a wave per 16-64 sorted positions,
+ *       the neighbour sums of the blocks among them formed once in LDS.
+ * Same results as the four-kernel form to rounding (sums are formed in a different, fixed order). */
+int64_t link_elk_tiles_table_bytes(const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap);
+int link_elk_premix_modsum_tiles(const float *feats, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                 const int32_t *blk_start, const int32_t *hdr, const float *w_pre,
+                                 const float *pre_ln_w, const float *pre_ln_b, const float *w_pos, const float *alpha,
+                                 const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap, float *S,
+                                 int64_t s_bytes, float *fin, void *stream);
+int link_elk_gather_demod_tiles(const float *S, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid /* host */,
+                                const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
+                                const float *ln_b, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
+                                float *out, void *stream);
 
 
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,

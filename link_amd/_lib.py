@@ -16,9 +16,9 @@ SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
 LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
-ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID = 1, 2, 4, 8     # link_elk_desc_t::flags
+ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -51,7 +51,8 @@ class LinkElkBuffers(Structure):
                                         "ln_w", "ln_b", "cell_counts", "scratch")] + \
                [("scratch_bytes", c_size_t)] + \
                [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "pos_blk", "blk_start",
-                                        "blk_coords", "counts", "hdr", "fin", "S", "A", "out")]
+                                        "blk_coords", "counts", "hdr", "fin", "S", "A", "out")] + \
+               [("s_bytes", c_int64)]
 
 
 class LinkDcGrid(Structure):
@@ -128,6 +129,11 @@ SIGNATURES = {
                                      POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
     "link_elk_core_forward": (c_int, [POINTER(LinkElkBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc),
                                       c_int64, c_int64, c_int32, c_void_p]),
+    "link_elk_tiles_table_bytes": (c_int64, [POINTER(LinkElkDesc), c_int64, c_int64]),
+    "link_elk_premix_modsum_tiles": (c_int, [c_void_p] * 10 + [POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_int64,
+                                             c_void_p, c_void_p]),
+    "link_elk_gather_demod_tiles": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid)] + [c_void_p] * 5 +
+                                    [POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
     "link_elk_mid_forward": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                      POINTER(LinkElkDesc), c_void_p, c_void_p, c_int64, c_int64] + [c_void_p] * 5),
     "link_elk_out_ln_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p,

@@ -2568,6 +2568,13 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
                           b->blk_coords, b->counts, b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
+  if (desc->flags & LINK_ELK_TILES) {
+    rc = link_elk_premix_modsum_tiles(b->feats, b->vox_sorted, b->pos_blk, b->blk_start, b->hdr, b->w_pre, b->pre_ln_w,
+                                      b->pre_ln_b, b->w_pos, b->alpha, desc, n, m_cap, b->S, b->s_bytes, b->fin, stream);
+    if (rc != LINK_OK) return rc;
+    return link_elk_gather_demod_tiles(b->S, b->fin, b->vox_sorted, b->pos_blk, b->blk_coords, b->cell_blk, grid, b->hdr,
+                                       b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, n, m_cap, b->out, stream);
+  }
   rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
   if (rc != LINK_OK) return rc;
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,

@@ -1,0 +1,149 @@
+// link_amd/csrc/elk_tiles.hip -- tile form of R_core on the general layout (elk_tiles_impl.h): C ABI and dispatch.
+#define DC_IO 0
+#define DC_IO_NS elkt_f32
+#include "elk_tiles_impl.h"
+
+using namespace link;
+using namespace elkt_f32;
+
+// Sorted positions per workgroup of k_elk_tiles: one 16-voxel tile per wave on small frames (a tile is ~4 us of one wave's
+// dependent work, so a frame's waves should all be resident together), two from 32k voxels (fewer prologues: 20.4 against
+// 24.1 us at 59k voxels, C = 64; 11.7 against 15.1 at 3k), more only beyond 4096 workgroups.
+#ifdef ELK_T_SPAN
+static int tiles_span(int64_t) { return ELK_T_SPAN; }
+#else
+static int tiles_span(int64_t n) {
+  if (n <= 32768) return 64;
+  const int64_t k = (n + 128 * 4096 - 1) / (128 * 4096);
+  return 128 * (int)(k > 1 ? k : 1);
+}
+#endif
+
+#ifdef ELK_T_DBG
+extern "C" int link_elk_tiles_debug_read(void *host_dst, int64_t bytes) {      // profiling builds only
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_t_dbg), (size_t)bytes) == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
+}
+#endif
+
+static bool tiles_desc_ok(const link_elk_desc_t *d) {
+  return d && dc_width_ok(d->c) && (d->r == 2 || d->r == 3) && d->cg >= 1 && d->c % d->cg == 0 &&
+         (d->op == LINK_OP_COS || d->op == LINK_OP_SIN || d->op == LINK_OP_COSX);
+}
+
+static int64_t tiles_wgs(int64_t n) { return (n + tiles_span(n) - 1) / tiles_span(n); }
+
+extern "C" int64_t link_elk_tiles_table_bytes(const link_elk_desc_t *desc, int64_t n, int64_t m_cap) {
+  if (!tiles_desc_ok(desc) || n < 0 || m_cap < 0) return -1;
+  const int rs = (desc->op == LINK_OP_COSX ? 3 : 2) * desc->c;
+  // two partial rows per wave, at one 16-voxel tile per wave (the smallest span): monotone in n, so a table sized for a
+  // plan's capacity serves every smaller frame
+  return elk_t_part_off(m_cap, rs) + ((n > 0 ? n : 1) + 63) / 64 * 4 * 2 * (int64_t)rs * 4;
+}
+
+template <int C, int OP, int NB>
+static int launch_tiles(const void *feats, const int32_t *vox_sorted, const int32_t *pos_blk, const int32_t *blk_start,
+                        const int32_t *hdr, const float *w_pre, const float *ln_w, const float *ln_b, const float *w_pos,
+                        const float *alpha, const link_elk_desc_t &d, int64_t n, int64_t m_cap, float *S_, int64_t s_bytes,
+                        float *fin, hipStream_t st) {
+  using K = elk_t_cfg<C, OP>;
+  const int lds = K::LDS_BYTES;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_elk_tiles<C, OP, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((k_elk_tiles<C, OP, NB>), dim3((unsigned)tiles_wgs(n)), dim3(64 * K::NW), lds, st, feats,
+                     reinterpret_cast<const int4 *>(vox_sorted), pos_blk, blk_start, hdr, w_pre, ln_w, ln_b, w_pos, alpha, d.cg,
+                     d.coord_div, d.eps, n, m_cap, tiles_span(n), S_, (uint32_t)s_bytes, (uint32_t)elk_t_part_off(m_cap, K::P * C), fin);
+  return check_launch("link_elk_premix_modsum_tiles");
+}
+
+template <int C, int OP, typename... A>
+static int tiles_nb(const link_elk_desc_t &d, A... a) {
+  constexpr int T = C / 16;
+  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
+  if (nb > T) nb = T;
+  if (T >= 2 && nb == T / 2) return launch_tiles<C, OP, (T >= 2 ? T / 2 : 1)>(a...);
+  if (T >= 4 && nb == T / 4) return launch_tiles<C, OP, (T >= 4 ? T / 4 : 1)>(a...);
+  return launch_tiles<C, OP, T>(a...);                  // any other grouping: every 16-channel block evaluates its own theta
+}
+
+template <int C, typename... A>
+static int tiles_op(const link_elk_desc_t &d, A... a) {
+  switch (d.op) {
+    case LINK_OP_COS: return tiles_nb<C, LINK_OP_COS>(d, a...);
+    case LINK_OP_SIN: return tiles_nb<C, LINK_OP_SIN>(d, a...);
+    default: return tiles_nb<C, LINK_OP_COSX>(d, a...);
+  }
+}
+
+extern "C" int link_elk_premix_modsum_tiles(const float *feats, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                            const int32_t *blk_start, const int32_t *hdr, const float *w_pre,
+                                            const float *pre_ln_w, const float *pre_ln_b, const float *w_pos,
+                                            const float *alpha, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
+                                            float *S_, int64_t s_bytes, float *fin, void *stream) {
+  if (n < 0 || !tiles_desc_ok(desc)) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!feats || !vox_sorted || !pos_blk || !blk_start || !hdr || !w_pre || !pre_ln_w || !pre_ln_b || !w_pos || !S_) return LINK_ERR_ARG;
+  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
+  const int64_t need = link_elk_tiles_table_bytes(desc, n, m_cap);
+  // 32-bit byte offsets into the table, the rows and the records
+  if (m_cap < 1 || s_bytes < need || need >= (1LL << 32) || n * desc->c * 4 >= (1LL << 32)) return LINK_ERR_ARG;
+  const link_elk_desc_t &d = *desc;
+  hipStream_t st = S(stream);
+#define LINK_T_ARGS d, static_cast<const void *>(feats), vox_sorted, pos_blk, blk_start, hdr, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, d, n, m_cap, S_, need, fin, st
+  switch (d.c) {
+    case 16: return tiles_op<16>(LINK_T_ARGS);
+    case 32: return tiles_op<32>(LINK_T_ARGS);
+    case 64: return tiles_op<64>(LINK_T_ARGS);
+    default: return tiles_op<128>(LINK_T_ARGS);
+  }
+#undef LINK_T_ARGS
+}
+
+template <int C, int OP, int R>
+static int launch_gather(const float *S_, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                         const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr,
+                         const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
+                         const link_elk_desc_t &d, int64_t n, int64_t m_cap, float *out, hipStream_t st) {
+  using K = elk_g_cfg<C, OP, R>;
+  // a multiple of 8: the kernel deals contiguous eighths of the tiles to the XCDs (workgroup w runs on XCD w % 8)
+  const int64_t wgs = ((n + (int64_t)K::WP * K::NW - 1) / ((int64_t)K::WP * K::NW) + 7) & ~(int64_t)7;
+  if (K::LDS_BYTES > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_elk_gather_tiles<C, OP, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              K::LDS_BYTES);
+  hipLaunchKernelGGL((k_elk_gather_tiles<C, OP, R>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, S_, fin,
+                     reinterpret_cast<const int4 *>(vox_sorted), pos_blk, reinterpret_cast<const int4 *>(blk_coords), cell_blk, g, hdr,
+                     w_pos, alpha, ln_w, ln_b, d.cg, d.coord_div, d.eps, m_cap, static_cast<void *>(out));
+  return check_launch("link_elk_gather_demod_tiles");
+}
+
+template <int C, typename... A>
+static int gather_op_r(const link_elk_desc_t &d, A... a) {
+#define LINK_G_CASE(OPV)                                                        \
+  return d.r == 2 ? launch_gather<C, OPV, 2>(a...) : launch_gather<C, OPV, 3>(a...)
+  switch (d.op) {
+    case LINK_OP_COS: LINK_G_CASE(LINK_OP_COS);
+    case LINK_OP_SIN: LINK_G_CASE(LINK_OP_SIN);
+    default: LINK_G_CASE(LINK_OP_COSX);
+  }
+#undef LINK_G_CASE
+}
+
+extern "C" int link_elk_gather_demod_tiles(const float *S_, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                           const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid,
+                                           const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
+                                           const float *ln_b, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
+                                           float *out, void *stream) {
+  if (n < 0 || !tiles_desc_ok(desc) || !grid) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!S_ || !vox_sorted || !pos_blk || !blk_coords || !cell_blk || !hdr || !w_pos || !ln_w || !ln_b || !out || m_cap < 1) return LINK_ERR_ARG;
+  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
+  const link_elk_desc_t &d = *desc;
+  hipStream_t st = S(stream);
+#define LINK_G_ARGS d, S_, fin, vox_sorted, pos_blk, blk_coords, cell_blk, *grid, hdr, w_pos, alpha, ln_w, ln_b, d, n, m_cap, out, st
+  switch (d.c) {
+    case 16: return gather_op_r<16>(LINK_G_ARGS);
+    case 32: return gather_op_r<32>(LINK_G_ARGS);
+    case 64: return gather_op_r<64>(LINK_G_ARGS);
+    default: return gather_op_r<128>(LINK_G_ARGS);
+  }
+#undef LINK_G_ARGS
+}

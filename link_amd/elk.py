@@ -54,14 +54,17 @@ def _st():
 # ------------------------------------------------------------------------------------------------
 # fused R_core (inference)
 # ------------------------------------------------------------------------------------------------
+TILE_FORM = True      # inference R_core on the general layout: the two-launch tile form where its widths / r apply (tests flip it)
+
+
 def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex, w_pre: torch.Tensor,
                    pre_ln_w: torch.Tensor, pre_ln_b: torch.Tensor, w_pos: torch.Tensor,
                    alpha: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor, baseop: str,
                    cg: int, r: int, coord_div: float = 1.0, eps: float = 1e-6,
                    m_cap: Optional[int] = None) -> torch.Tensor:
     """R_core of ELKBlock.forward: pre_mix -> theta -> modulate -> block
-    pre-aggregation -> r^3 neighbour sum -> de-modulate -> norm.  3 kernel launches, no host sync.
-    w_pos fp32[cg,3]; channel j uses theta[j % cg]."""
+    pre-aggregation -> r^3 neighbour sum -> de-modulate -> norm.  2 kernel launches (tile form; 4 for other widths), no
+    host sync.  w_pos fp32[cg,3]; channel j uses theta[j % cg]."""
     n, c = feats.shape
     dev = feats.device
     feats = feats.contiguous().float()
@@ -69,14 +72,34 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     parts = 3 if op == L.OP_COSX else 2
     if m_cap is None:
         m_cap = index._m if index._m is not None else n
-    fin = torch.empty((n, c), dtype=torch.float32, device=dev)
     m_cap = max(m_cap, 1)
-    S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
     out = _alloc_out(index, (n, c), dev)
     desc = L.LinkElkDesc(op, c, cg, r, float(coord_div), float(eps))
     lib, st = L.lib(), _st()
     w_pos = w_pos.contiguous().float()
     al = alpha.contiguous().float().view(-1) if alpha is not None else None
+    if TILE_FORM and c in (16, 32, 64, 128) and r in (2, 3) and n > 0:
+        # tile form: two launches (pre_mix + modulate + block sums on the matrix cores; neighbour sum + de-modulate + norm)
+        s_bytes = int(lib.link_elk_tiles_table_bytes(ctypes.byref(desc), n, m_cap))
+        if 0 < s_bytes < 2 ** 32 and n * c * 4 < 2 ** 32:
+            S = torch.empty((s_bytes + 3) // 4, dtype=torch.float32, device=dev)
+            fin = torch.empty((n, c), dtype=torch.float32, device=dev) if op == L.OP_COSX else None
+            fin_p = fin.data_ptr() if fin is not None else None
+            L.check(lib.link_elk_premix_modsum_tiles(feats.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
+                                                     index.blk_start.data_ptr(), index.hdr.data_ptr(),
+                                                     w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(), pre_ln_b.data_ptr(),
+                                                     w_pos.data_ptr(), al.data_ptr() if al is not None else None,
+                                                     ctypes.byref(desc), n, m_cap, S.data_ptr(), s_bytes, fin_p, st),
+                    "link_elk_premix_modsum_tiles")
+            L.check(lib.link_elk_gather_demod_tiles(S.data_ptr(), fin_p, index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
+                                                    index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
+                                                    ctypes.byref(index.grid), index.hdr.data_ptr(), w_pos.data_ptr(),
+                                                    al.data_ptr() if al is not None else None, ln_w.data_ptr(), ln_b.data_ptr(),
+                                                    ctypes.byref(desc), n, m_cap, out.data_ptr(), st),
+                    "link_elk_gather_demod_tiles")
+            return out
+    fin = torch.empty((n, c), dtype=torch.float32, device=dev)
+    S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
     L.check(lib.link_premix_ln(feats.data_ptr(), w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(),
                                pre_ln_b.data_ptr(), n, c, float(eps), fin.data_ptr(), st), "link_premix_ln")
     L.check(lib.link_modulate_block_sum(fin.data_ptr(), index.vox_sorted.data_ptr(), w_pos.data_ptr(),
@@ -136,6 +159,7 @@ class ElkCorePlan:
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
         self.frames_in_flight = max(1, int(frames_in_flight))
         self._tuning = dict(tuning)
+        self._tiles_opt = bool(self._tuning.pop("tiles", True))     # general layout: the two-launch tile form where it applies
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
@@ -202,7 +226,8 @@ class ElkCorePlan:
         k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form), k2_form, mode, k1_pipe."""
         if not self.dense:
             if kw:
-                raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan tuning")
+                raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan launch geometry "
+                                     "(general layout: ElkCorePlan(..., tiles=False) selects the four-kernel form)")
             return self
         t = self.buf.tune
         multi = self.frames_in_flight > 1
@@ -233,13 +258,25 @@ class ElkCorePlan:
         self.blk_start = torch.empty(n_cap + 1, **i32)
         self.blk_coords = torch.empty((n_cap, 4), **i32)
         self.counts = torch.empty(n_cap, **i32)
-        self.S = torch.empty((n_cap + 1) * (self.parts * c + 1), **f32)
-        self.A = torch.empty((n_cap, self.parts * c), **f32)
+        # tile form (two launches, link_elk_premix_modsum_tiles + link_elk_gather_demod_tiles): the widths / r the fused
+        # kernels are built for; its table carries scratch rows behind the counts
+        self.tiles = self._tiles_opt and c in (16, 32, 64, 128) and self.r in (2, 3)
+        s_bytes = (n_cap + 1) * (self.parts * c + 1) * 4
+        if self.tiles:
+            s_bytes = int(L.lib().link_elk_tiles_table_bytes(ctypes.byref(self.desc), n_cap, n_cap))
+            self.tiles = 0 < s_bytes < 2 ** 32 and n_cap * c * 4 < 2 ** 32
+        if self.tiles:
+            self.desc.flags |= L.ELK_TILES
+        else:
+            s_bytes = (n_cap + 1) * (self.parts * c + 1) * 4
+        self.S = torch.empty((s_bytes + 3) // 4, **f32)
+        self.A = torch.empty((n_cap, self.parts * c), **f32) if not self.tiles else None
         b = self.buf = L.LinkElkBuffers()
         b.cell_counts, b.scratch, b.scratch_bytes = self.cell_counts.data_ptr(), self.scratch.data_ptr(), nbytes
         b.cell_blk, b.vox_blk, b.idx_query = self.cell_blk.data_ptr(), self.vox_blk.data_ptr(), self.idx_query.data_ptr()
         b.perm, b.blk_start, b.blk_coords = self.perm.data_ptr(), self.blk_start.data_ptr(), self.blk_coords.data_ptr()
-        b.vox_sorted, b.pos_blk, b.A = self.vox_sorted.data_ptr(), self.pos_blk.data_ptr(), self.A.data_ptr()
+        b.vox_sorted, b.pos_blk = self.vox_sorted.data_ptr(), self.pos_blk.data_ptr()
+        b.A, b.s_bytes = (self.A.data_ptr() if self.A is not None else None), s_bytes
         b.counts, b.hdr = self.counts.data_ptr(), self.hdr.data_ptr()
         b.fin, b.S, b.out = self.fin.data_ptr(), self.S.data_ptr(), self.out.data_ptr()
         self._fn = L.lib().link_elk_core_forward

@@ -24,7 +24,8 @@ def test_kernel_paths_agree(C, groups, baseop, s, r):
     coords = s_uniform(n, grid=80, seed=C + r).cuda()
     feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
     lo, hi = (0, 0, 0, 0), (79, 79, 79, 0)
-    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device, layout="general")   # the flags select general-layout kernels
+    # the flags select general-layout kernels; tiles=False: the four-kernel plan (with the A matrix of the split gather)
+    plan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device, layout="general", tiles=False)
     plan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
               blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
     outs = {}
@@ -35,6 +36,12 @@ def test_kernel_paths_agree(C, groups, baseop, s, r):
         outs[name] = plan.run(feats, coords).clone()
         assert plan.blocks() > 0
     plan.desc.flags = 0
+    if C in (16, 32, 64, 128):          # the two-launch tile form of the same layout
+        tplan = la.ElkCorePlan(n, C, baseop, C // groups, r, s, (lo, hi), feats.device, layout="general")
+        assert tplan.tiles and tplan.desc.flags & L.ELK_TILES
+        tplan.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+                   blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
+        outs["tiles"] = tplan.run(feats, coords).clone()
     # every path within the parity gate of the ORACLE (1e-4 rel), and within 5e-5 of each other
     from oracle import link_oracle as O
     params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
