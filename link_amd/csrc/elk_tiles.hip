@@ -20,8 +20,10 @@ static int tiles_span(int64_t n) {
 #endif
 
 #ifdef ELK_T_DBG
-extern "C" int link_elk_tiles_debug_read(void *host_dst, int64_t bytes) {      // profiling builds only
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_t_dbg), (size_t)bytes) == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
+extern "C" int link_elk_tiles_debug_read(void *host_dst, int64_t bytes, int which) {      // profiling builds only
+  const hipError_t e = which ? hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_g_dbg), (size_t)bytes)
+                             : hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_t_dbg), (size_t)bytes);
+  return e == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
 }
 #endif
 

@@ -22,6 +22,7 @@
 
 #ifdef ELK_T_DBG          /* profiling builds only (tools/lidar_prof.py): per-wave s_memtime phases in a device array */
 __device__ unsigned long long elk_t_dbg[8 * 32768];
+__device__ unsigned long long elk_g_dbg[8 * 32768];
 #define ELK_T_TICK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
 #define ELK_T_TICK(v)
@@ -74,26 +75,32 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
     if (tid < K::RGL) st16(r_S, (uint32_t)m_cap * (uint32_t)K::RB + (uint32_t)tid * 16u, make_float4(0.f, 0.f, 0.f, 0.f));
     else st4i(r_S, (uint32_t)(m_cap + 1) * (uint32_t)K::RB + (uint32_t)m_cap * 4u, 0);
   }
-  // ---- this workgroup's range of sorted positions: the nominal span, both ends moved up to the next block boundary ----
+  // ---- this workgroup's range of sorted positions: the nominal span, both ends moved up to the next block boundary.
+  // Branch-free (clamped buffer loads + selects): the three dependent round trips (header -> block of the position -> that
+  // block's end) run while the weights are on their way, there is no branch for the compiler to wait in front of ----
+  const __amdgpu_buffer_rsrc_t r_pb = dc_rsrc(pos_blk, (uint32_t)(n * 4));
+  const __amdgpu_buffer_rsrc_t r_bs = dc_rsrc(blk_start, (uint32_t)((n + 1) * 4));
   auto boundary = [&](int64_t q) -> int {
-    if (q <= 0) return 0;
-    if (q >= nv) return nv;
-    const int bp = pos_blk[q - 1], bq = pos_blk[q];
-    return bp != bq ? (int)q : blk_start[bq + 1];
+    const int qc = q < 1 ? 1 : (q >= nv ? (nv > 1 ? nv - 1 : 1) : (int)q);
+    const int bp = __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)(qc - 1) * 4u, 0, 0);
+    const int bq = __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)qc * 4u, 0, 0);      // beyond the array: 0
+    const int nx = __builtin_amdgcn_raw_buffer_load_b32(r_bs, (uint32_t)(bq + 1) * 4u, 0, 0);
+    return q <= 0 ? 0 : (q >= nv ? nv : (bp != bq ? (int)q : nx));
   };
   const int a = boundary((int64_t)blockIdx.x * span), e = boundary((int64_t)(blockIdx.x + 1) * span);
-  if (a >= e) return;
   ELK_T_TICK(tq1);
   const int tpw = (((e - a + 15) >> 4) + K::NW - 1) / K::NW;        // tiles per wave
   const int wa = a + wave * tpw * 16;
   const int wb = (wa + tpw * 16 < e) ? wa + tpw * 16 : e;
-  const bool has = wa < wb;
-  const bool head_open = has && wa > a && pos_blk[wa - 1] == pos_blk[wa];
-  const bool tail_open = has && wb < e && pos_blk[wb - 1] == pos_blk[wb];
+  const bool has = wa < wb;                            // false for every wave of a workgroup whose range is empty (a >= e)
+  const int wac = has ? wa : 1, wbc = has ? wb : 1;
+  const bool head_open = has && wa > a && __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)(wac - 1) * 4u, 0, 0) ==
+                                              __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)wac * 4u, 0, 0);
+  const bool tail_open = has && wb < e && __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)(wbc - 1) * 4u, 0, 0) ==
+                                              __builtin_amdgcn_raw_buffer_load_b32(r_pb, (uint32_t)wbc * 4u, 0, 0);
   const __amdgpu_buffer_rsrc_t r_fin = dc_rsrc(fin, (uint32_t)(n * C * 4));     // written for cos_x only
   const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(feats, (uint32_t)(n * C * IO_BYTES));
   const __amdgpu_buffer_rsrc_t r_vox = dc_rsrc(vox_sorted, (uint32_t)(n * 16));
-  const __amdgpu_buffer_rsrc_t r_pb = dc_rsrc(pos_blk, (uint32_t)(n * 4));
   // records of the first two tiles are on their way while W is staged
   auto ld_rec = [&](int t, int4 &rec, int &blk) {
     int pos = wa + 16 * t + li;
@@ -110,6 +117,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
   bool w_big = dc_stage_weights<C, 64 * K::NW>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
   for (int i = lane; i < K::CARRY_BYTES / 4; i += 64) carry[i] = 0.f;     // read unconditionally by every tile (times 0 unless a block straddles)
   w_big = __syncthreads_or(w_big) != 0;
+  if (a >= e) return;                                  // nominal span inside one block that an earlier workgroup owns
   ELK_T_TICK(tq2);
 #ifdef ELK_T_DBG
   unsigned long long tq_mfma = 0, tq_ln = 0, tq_scan = 0, tq_rows = 0;
@@ -350,7 +358,10 @@ struct elk_g_cfg {
   static constexpr int P = op_parts<OP>::value;
   static constexpr int RS = P * C;                     // floats of one table row
   static constexpr int R3 = R * R * R;
-  static constexpr int WP = 8 * G < 64 ? 8 * G : 64;   // sorted positions per wave: 8 voxel steps per group (4 at C = 16)
+#ifndef ELK_G_STEPS
+#define ELK_G_STEPS 4     /* 8: 25.7 against 19.5 us on 59k voxels (C = 64, r = 2), 12.0 against 8.2 us on 3k: the slowest tile sets the time */
+#endif
+  static constexpr int WP = ELK_G_STEPS * G < 64 ? ELK_G_STEPS * G : 64;   // sorted positions per wave: 4 voxel steps per group
   static constexpr int STEPS = WP / G;
   static constexpr int RMAX = WP / 2 < 16 ? WP / 2 : 16;   // blocks whose neighbour sums sit in LDS at a time
   static constexpr int NW = 4;
@@ -380,6 +391,10 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & (LPR - 1), grp = lane / LPR;
+  ELK_T_TICK(tg0);
+#ifdef ELK_T_DBG
+  unsigned long long tg_nb = 0, tg_a = 0, tg_v = 0;
+#endif
   char *wbase = smem_raw + wave * K::WAVE_BYTES;
   float *A_lds = reinterpret_cast<float *>(wbase);
   int32_t *nb_lds = reinterpret_cast<int32_t *>(wbase + K::A_BYTES);
@@ -428,8 +443,13 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
     }
   }
 
+#ifdef ELK_T_DBG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ELK_T_TICK(tg1);
   for (int rb = 0; rb < nruns; rb += K::RMAX) {
     const int nr = nruns - rb < K::RMAX ? nruns - rb : K::RMAX;
+    ELK_T_TICK(tpa);
     if (head && my_run >= rb && my_run < rb + nr) run_blk[my_run - rb] = blk;
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -444,6 +464,7 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ELK_T_TICK(tpb);
     // ---- A rows: a group per block, a plane of r^2 rows in flight ----
     for (int j = grp; j < nr; j += G) {
       float acc[P][4], den = 0.f;
@@ -451,26 +472,31 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
       for (int pp = 0; pp < P; pp++)
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[pp][q] = 0.f;
-      // rows in flight per batch: a plane of r^2 (r = 3), the whole neighbourhood (r = 2)
-      constexpr int BR = R == 2 ? R3 : R2;
+      // rows in flight per batch: as many of the r^3 as ~28 16-byte registers hold (r = 2: all 8; r = 3: 14 + 13 with two
+      // parts, 3 x 9 with three)
+      constexpr int NBAT = (R3 * P + 27) / 28, BR = (R3 + NBAT - 1) / NBAT;
 #pragma unroll
-      for (int bt = 0; bt < R3 / BR; bt++) {
+      for (int bt = 0; bt < NBAT; bt++) {
         float4 v[BR][P];
         float vd[BR];
 #pragma unroll
         for (int t = 0; t < BR; t++) {
-          const int nb = nb_lds[j * R3 + bt * BR + t];
-          const float *row = S + (int64_t)nb * RS + ch0;
-          vd[t] = Scnt[nb];
+          if (bt * BR + t < R3) {
+            const int nb = nb_lds[j * R3 + bt * BR + t];
+            const float *row = S + (int64_t)nb * RS + ch0;
+            vd[t] = Scnt[nb];
 #pragma unroll
-          for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * C]);
+            for (int pp = 0; pp < P; pp++) v[t][pp] = *reinterpret_cast<const float4 *>(&row[pp * C]);
+          }
         }
 #pragma unroll
         for (int t = 0; t < BR; t++) {
-          den += vd[t];
+          if (bt * BR + t < R3) {
+            den += vd[t];
 #pragma unroll
-          for (int pp = 0; pp < P; pp++) {
-            acc[pp][0] += v[t][pp].x; acc[pp][1] += v[t][pp].y; acc[pp][2] += v[t][pp].z; acc[pp][3] += v[t][pp].w;
+            for (int pp = 0; pp < P; pp++) {
+              acc[pp][0] += v[t][pp].x; acc[pp][1] += v[t][pp].y; acc[pp][2] += v[t][pp].z; acc[pp][3] += v[t][pp].w;
+            }
           }
         }
       }
@@ -481,6 +507,7 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ELK_T_TICK(tpc);
     // ---- voxels of the pass: position grp, grp + G, ... ----
     auto step_ok = [&](int l, int &rl) {
       rl = __popcll(hm & ((2ull << l) - 1ull)) - 1;
@@ -545,7 +572,18 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
       }
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef ELK_T_DBG
+    ELK_T_TICK(tpd);
+    tg_nb += tpb - tpa; tg_a += tpc - tpb; tg_v += tpd - tpc;
+#endif
   }
+#ifdef ELK_T_DBG
+  if (lane == 0 && wg * K::NW + wave < 32768) {
+    unsigned long long *d = elk_g_dbg + (size_t)(wg * K::NW + wave) * 8;
+    const unsigned long long tg2 = __builtin_amdgcn_s_memtime();
+    d[0] = tg1 - tg0; d[1] = tg_nb; d[2] = tg_a; d[3] = tg_v; d[4] = nruns; d[5] = 0; d[6] = 0; d[7] = tg2 - tg0;
+  }
+#endif
 }
 
 }  // namespace DC_IO_NS

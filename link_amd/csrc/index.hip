@@ -138,11 +138,30 @@ __global__ void __launch_bounds__(256) k_cell_count(const int4 *__restrict__ coo
   // kernel boundary)
   for (int64_t t = gid; t < tiles; t += (int64_t)gridDim.x * blockDim.x) desc[t] = 0ULL;
   if (gid == 0) *ticket = 0u;
-  if (gid >= n) return;
-  int4 c = coords[gid];
-  int32_t cell = cell_of(g, floordiv(c.x, g.s), floordiv(c.y, g.s), floordiv(c.z, g.s), c.w);
-  vox_cell[gid] = cell;
-  if (cell >= 0) vox_rank[gid] = (int32_t)atomicAdd(&cell_counts[cell], 1u);
+  const bool live = gid < n;
+  int32_t cell = -1;
+  if (live) {
+    const int4 c = coords[gid];
+    cell = cell_of(g, floordiv(c.x, g.s), floordiv(c.y, g.s), floordiv(c.z, g.s), c.w);
+    vox_cell[gid] = cell;
+  }
+  // The lanes of a wave that fall into the same cell make ONE atomic between them.  LiDAR frames keep spatially close
+  // voxels close in memory (sensor scan order, or the lexicographic order of torch.unique), so the ~30 atomics per counter
+  // of a big block -- which serialise in the L2 -- become a handful; a frame in random order pays one pass of the loop per
+  // lane (64 x ~8 scalar / vector ops) and issues the same atomics as before.
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(cell >= 0), mine = 0;
+  while (todo) {
+    const int cj = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
+    const unsigned long long m = __ballot(cell == cj);
+    if (cell == cj) mine = m;
+    todo &= ~m;
+  }
+  const int leader = mine ? __builtin_ctzll(mine) : lane;
+  unsigned int base = 0;
+  if (cell >= 0 && lane == leader) base = atomicAdd(&cell_counts[cell], (unsigned int)__popcll(mine));
+  base = __shfl(base, leader, 64);
+  if (cell >= 0) vox_rank[gid] = (int32_t)(base + (unsigned int)__popcll(mine & ((1ull << lane) - 1ull)));
 }
 
 // descriptor: [63:62] flag (0 invalid, 1 aggregate, 2 inclusive prefix) [61:31] occupied [30:0] voxels
@@ -327,8 +346,14 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
   int32_t len = en - st;
   int64_t dst = p;
   if (len > 1 && len <= SORT_MAX_SEG) {
-    int32_t r = 0;
-    for (int32_t q = st; q < en; q++) r += (perm_tmp[q] < i);
+    int32_t r = 0, q = st;
+    // big blocks (LiDAR: tens to hundreds of voxels): 16-byte pieces between the unaligned ends
+    for (; q < en && (reinterpret_cast<uintptr_t>(perm_tmp + q) & 15); q++) r += (perm_tmp[q] < i);
+    for (; q + 4 <= en; q += 4) {
+      const int4 v = *reinterpret_cast<const int4 *>(perm_tmp + q);
+      r += (v.x < i) + (v.y < i) + (v.z < i) + (v.w < i);
+    }
+    for (; q < en; q++) r += (perm_tmp[q] < i);
     dst = st + r;
   }
   perm[dst] = i;

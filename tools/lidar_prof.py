@@ -30,15 +30,19 @@ def main():
         plan.run(feats, coords, build_index=True)
     torch.cuda.synchronize()
     lib = ctypes.CDLL(L.lib()._name)
-    buf = np.zeros(8 * 32768, dtype=np.uint64)
-    assert lib.link_elk_tiles_debug_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(buf.nbytes)) == 0
-    d = buf.reshape(-1, 8)
-    d = d[d[:, 7] > 0]
-    names = ["boundary", "stage W + barrier", "wait rows", "mfma", "theta prep + LayerNorm", "sincos + scans + stores", "combine", "total"]
-    print(f"stage {k} ({cfg}): n={n} C={c} op={b.baseop}; {len(d)} waves with work; s_memtime ticks (100 MHz)")
-    for i, nm in enumerate(names):
-        v = d[:, i].astype(np.float64)
-        print(f"  {nm:28s} mean {v.mean():8.1f}  p50 {np.median(v):8.1f}  max {v.max():8.1f}")
+    for which, title, names in (
+            (0, "k_elk_tiles", ["boundary", "stage W + barrier", "wait rows", "mfma", "theta prep + LayerNorm", "sincos + scans + stores", "combine", "total"]),
+            (1, "k_elk_gather_tiles", ["positions, records, run heads", "neighbour ids", "A rows", "voxel steps", "(runs in the tile)", "-", "-", "total"])):
+        buf = np.zeros(8 * 32768, dtype=np.uint64)
+        assert lib.link_elk_tiles_debug_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(buf.nbytes), ctypes.c_int(which)) == 0
+        d = buf.reshape(-1, 8)
+        d = d[d[:, 7] > 0]
+        print(f"stage {k} ({cfg}): n={n} C={c} op={b.baseop}; {title}: {len(d)} waves with work; s_memtime ticks")
+        for i, nm in enumerate(names):
+            if nm == "-":
+                continue
+            v = d[:, i].astype(np.float64)
+            print(f"  {nm:30s} mean {v.mean():8.1f}  p50 {np.median(v):8.1f}  max {v.max():8.1f}")
 
 
 if __name__ == "__main__":
