@@ -331,6 +331,10 @@ class ElkCorePlan:
             self.check()
         return out if out is not None else own[:n]
 
+    def arena_bytes(self) -> int:
+        """Device bytes this plan holds (its preallocated buffers)."""
+        return sum(t.numel() * t.element_size() for t in self.__dict__.values() if isinstance(t, torch.Tensor))
+
     def check(self) -> None:
         """Read the device status word of the last step (one 32-byte D2H sync) and raise if a voxel was
         dropped: outside the plan's bounds (its `out` row was not written), or in a cell whose slot list was
@@ -1231,6 +1235,7 @@ class _SubmConv(torch.autograd.Function):
 # modules
 # ------------------------------------------------------------------------------------------------
 DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take
+DENSE_PLAN_CACHE_BYTES = 4 << 30             # arenas a module keeps for its dense-cell plans (ElkCorePlan.arena_bytes)
 
 
 class _ELKBase(nn.Module):
@@ -1268,17 +1273,26 @@ class _ELKBase(nn.Module):
             bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
         cache = self.__dict__.setdefault("_dc_plans", {})
         n_cap = 1 << max(10, (n - 1).bit_length())
-        key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, bounds, float(coord_div))
+        # plans are keyed by the bounds padded out to whole blocks (the grid they imply is the same): the exact extents of
+        # real frames move from frame to frame, and every new key is a new arena (zero-filled tables, a slot arena of up
+        # to 1 GiB) plus an occupancy probe.  Coarser padding would merge more frames but the gather kernel streams every
+        # cell of the grid (cfg2: + 26 % cells at 4-block padding)
+        q = int(s_eff)
+        qbounds = (tuple((int(v) // q) * q for v in bounds[0][:3]) + (int(bounds[0][3]),),
+                   tuple((int(v) // q) * q + q - 1 for v in bounds[1][:3]) + (int(bounds[1][3]),))
+        key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, qbounds, float(coord_div))
         plan = cache.get(key, False)
         if plan is False:
             plan = None
-            if ElkCorePlan.would_be_dense(n_cap, c, self.baseop, r, s_eff, bounds):
+            if ElkCorePlan.would_be_dense(n_cap, c, self.baseop, r, s_eff, qbounds):
                 try:
-                    plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, bounds, feats.device, coord_div=coord_div,
+                    plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, qbounds, feats.device, coord_div=coord_div,
                                        layout="dense")
                 except L.LinkAmdError:
                     plan = None
-            if len(cache) >= 8:                              # arenas are large: keep the cache small
+            # arenas are large: the cache is capped by bytes (and by entries, for the None markers)
+            budget = DENSE_PLAN_CACHE_BYTES - (plan.arena_bytes() if plan is not None else 0)
+            while cache and (len(cache) >= 8 or sum(p.arena_bytes() for p in cache.values() if p is not None) > max(budget, 0)):
                 cache.pop(next(iter(cache)))
             cache[key] = plan
         if plan is None:
