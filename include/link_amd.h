@@ -485,6 +485,16 @@ int link_pair_plan_count(const int32_t *nbr, int64_t n, int32_t kvol, int32_t *w
 int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, const int32_t *base_k,
                         const int32_t *wg_base, const int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,
                         int32_t *ext_list, void *stream);
+/* The step between the two, on the device (no host round trip; one workgroup): from link_pair_plan_count's per-workgroup
+ * counts to base_k i32[kvol] (first contribution row of every offset, 128-row granules), wg_base i32[ceil(n/256), kvol]
+ * (pairs of earlier workgroups per offset), gran_start i32[kvol + 1], wg_k i32[gran_cap] (offset of every granule, -1 behind
+ * the last: the GEMM kernels return there, so they can be launched over the capacity) and hdr i32[8] = {pairs, rows_pad,
+ * granules, rows whose centre neighbour is not the row itself, capacity exceeded, 0, 0, 0} for a later, asynchronous read.
+ * skip_centre as in link_pair_plan_fill (the caller knows a submanifold table structurally).  A capacity of
+ * ceil((n * kvol + 127 * kvol) / 128) granules is never exceeded.  The reference reads its counts back per layer
+ * (nn/functional/conv.py:103-122, `nbsizes.cpu()`). */
+int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
+                          int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_k, int32_t *hdr, void *stream);
 /* The same three entries with fp16 / bf16 feature rows at the boundary (io_dtype = LINK_IO_F32 / F16 / BF16: feats, addend
  * and out rows in that type; weights, contribution rows, statistics and accumulation fp32) -- the reference's AMP
  * contract for its convolution (custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18). */

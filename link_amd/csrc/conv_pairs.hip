@@ -825,6 +825,76 @@ extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, 
   return check_launch("link_pair_plan_fill");
 }
 
+// Layout of a pair plan ON THE DEVICE (what the host otherwise computes between link_pair_plan_count and
+// link_pair_plan_fill after reading the counts back): one workgroup.  Phase 1: a wave per offset column, exclusive scan of
+// the per-workgroup counts (-> wg_base) and the column totals.  Phase 2 (one lane): granule-aligned row ranges per offset.
+// Phase 3: the offset of every granule up to the caller's capacity, -1 behind the last one (the GEMM kernels return there).
+__global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
+                                                          int skip_centre, int64_t gran_cap, int32_t *__restrict__ base_k,
+                                                          int32_t *__restrict__ wg_base, int32_t *__restrict__ gran_start,
+                                                          int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr) {
+  __shared__ int s_tot[65], s_gs[66];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k <= kvol; k += 4) {
+    int running = 0;
+    for (int c = 0; c < nwg; c += 64) {
+      const int w = c + lane;
+      const int v = w < nwg ? wg_counts[(int64_t)w * (kvol + 1) + k] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+      }
+      if (w < nwg && k < kvol) wg_base[(int64_t)w * kvol + k] = running + incl - v;
+      running += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) s_tot[k] = running;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t rows = 0, gran = 0, pairs = 0;
+    for (int k = 0; k < kvol; k++) {
+      const int cnt = (skip_centre && k == centre) ? 0 : s_tot[k];
+      base_k[k] = (int32_t)rows;
+      gran_start[k] = s_gs[k] = (int32_t)gran;
+      const int64_t gk = (cnt + 127) / 128;
+      rows += gk * 128;
+      gran += gk;
+      pairs += cnt;
+    }
+    gran_start[kvol] = s_gs[kvol] = (int32_t)gran;
+    hdr[0] = (int32_t)pairs;
+    hdr[1] = (int32_t)rows;
+    hdr[2] = (int32_t)gran;
+    hdr[3] = s_tot[kvol];                              // rows whose centre neighbour is not the row itself
+    hdr[4] = gran > gran_cap ? 1 : 0;                  // capacity exceeded: cannot happen with the bound of the C ABI comment
+    hdr[5] = hdr[6] = hdr[7] = 0;
+  }
+  __syncthreads();
+  const int total = s_gs[kvol];
+  for (int64_t g = threadIdx.x; g < gran_cap; g += 256) {
+    int k = -1;
+    if (g < total) {
+      k = 0;
+      while (k + 1 < kvol && s_gs[k + 1] <= g) k++;
+    }
+    wg_k[g] = k;
+  }
+}
+
+extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
+                                     int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_k, int32_t *hdr,
+                                     void *stream) {
+  if (n < 0 || kvol <= 0 || kvol > 64 || gran_cap < 0) return LINK_ERR_ARG;
+  if (!wg_counts || !base_k || !wg_base || !gran_start || !hdr || (gran_cap > 0 && !wg_k)) return LINK_ERR_ARG;
+  const int64_t nwg = (n + 255) / 256;
+  if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(256), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                     (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr);
+  return check_launch("link_pair_plan_layout");
+}
+
 // ---------------------------------------------------------------------------------------------
 // output sites of a site-creating (regular) sparse convolution: candidate rows
 // ---------------------------------------------------------------------------------------------

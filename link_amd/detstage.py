@@ -300,6 +300,7 @@ class SparseConv3d(nn.Module):
         full = foreign_neighbor_map(rows.contiguous(), 3, table_rows=in_xyzb,
                                     bounds=((0, 0, 0, 0), (shp[2] - 1, shp[1] - 1, shp[0] - 1, int(sct.batch_size) - 1)))
         table = full[:, sel_t].contiguous()
+        table._link_subm = False                         # structural mark for the pair plan: a gather table between two site sets
         back = None                                      # transposed direction: built on the first backward
         hit = sct.indice_dict[key] = [out_ind.contiguous(), table, back, sct.indices]
         return hit[0], hit[1], hit[2]

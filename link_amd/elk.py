@@ -600,6 +600,11 @@ def neighbor_table_of(x: SparseTensor, kernel_size):
         except GridTooLarge:
             offs = get_kernel_offsets(kernel_size, stride=x.s, device=x.F.device)
             nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
+        try:
+            # structural mark for the pair plan: odd kernel over one coordinate set -> the centre column is the identity
+            nbr._link_subm = all(int(k) % 2 == 1 for k in kernel_size)
+        except AttributeError:
+            pass
         nbr = (nbr, _TileOrder(x.C, 4 * ts))
         x.kmaps[key] = nbr
     return nbr
@@ -799,6 +804,19 @@ def spdownsample(coords: torch.Tensor, stride=2, kernel_size=2, tensor_stride=1)
 # a voxel with more neighbours than this runs on the output-stationary table kernel (conv.hip): measured
 # cross-over of the two forms on MI355X (tools/convbench.py)
 PAIR_DENSITY_MAX = 17.0
+ASYNC_PAIR_PLANS = True      # lay pair plans out on the device when the table's structure is known (no host round trip)
+_DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
+_PINNED: list = []
+
+
+def _pinned_slot() -> torch.Tensor:
+    """8 ints of pinned host memory from a small ring (allocating pinned memory per plan would cost more than the round
+    trip it replaces); a slot is reused after 512 later plans."""
+    if not _PINNED:
+        _PINNED.extend([torch.empty((512, 8), dtype=torch.int32).pin_memory(), 0])
+    buf, i = _PINNED
+    _PINNED[1] = (i + 1) % buf.shape[0]
+    return buf[i]
 
 
 class _PairPlan:
@@ -808,7 +826,15 @@ class _PairPlan:
     rows in ascending offset order (`ext_start`, `ext_list`).  For a submanifold table (odd kernel, same
     coordinates in and out) the centre pairs are the identity and occupy rows [0, n)."""
 
-    def __init__(self, nbr: torch.Tensor):
+    def __init__(self, nbr: torch.Tensor, subm: Optional[bool] = None):
+        """`subm`: what the caller knows about the table structurally -- True: a submanifold table (odd kernel, the same
+        unique coordinates in and out, so the centre column is the identity), False: not one, None: unknown.  With a
+        structural answer and ASYNC_PAIR_PLANS the plan is laid out on the device (link_pair_plan_layout) over capacity-
+        sized buffers and nothing waits for the host; the counts arrive later in pinned memory (`density`, `finalize`)."""
+        if subm is not None and ASYNC_PAIR_PLANS and nbr.is_cuda and nbr.shape[0] > 0:
+            self._init_async(nbr, bool(subm))
+            return
+        self.exact = True
         n, kvol = nbr.shape
         dev = nbr.device
         centre = kvol // 2
@@ -831,7 +857,8 @@ class _PairPlan:
             cnt_k[centre] = 0
         self.pairs = int(sum(cnt_k))
         self.n, self.kvol, self.direct = n, kvol, direct
-        self.density = (self.pairs + (n if direct else 0)) / max(n, 1)
+        self._density = (self.pairs + (n if direct else 0)) / max(n, 1)
+        _DENSITY_SEEN[kvol] = self._density
         base_k, gran, acc = [], [], 0
         for c in cnt_k:
             base_k.append(acc)
@@ -860,6 +887,92 @@ class _PairPlan:
         self.gran_start, self.wg_k = meta[kvol + nwk: kvol + nwk + kvol + 1], meta[kvol + nwk + kvol + 1:]
         self._contrib: Dict[int, torch.Tensor] = {}
 
+    def _init_async(self, nbr: torch.Tensor, direct: bool):
+        n, kvol = nbr.shape
+        dev = nbr.device
+        lib, st = L.lib(), _st()
+        nbr = nbr.contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        nwg = (n + 255) // 256
+        wg_counts = torch.empty((nwg, kvol + 1), **i32)
+        row_info = torch.empty(n, **i32)
+        L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, wg_counts.data_ptr(), row_info.data_ptr(), st),
+                "link_pair_plan_count")
+        # capacity: every (voxel, offset) a pair, every offset's last granule partly filled
+        cap_pairs = n * (kvol - (1 if direct else 0))
+        gran_cap = (cap_pairs + 127 * kvol + 127) // 128
+        self.n, self.kvol, self.direct, self.exact = n, kvol, direct, False
+        self.pairs, self.rows_pad, self._density = None, gran_cap * 128, None
+        meta = torch.empty(kvol + nwg * kvol + kvol + 1, **i32)            # base_k | wg_base | gran_start
+        wg_k = torch.empty(gran_cap, **i32)
+        hdr = torch.empty(8, **i32)
+        gs = meta[kvol + nwg * kvol:]
+        L.check(lib.link_pair_plan_layout(wg_counts.data_ptr(), n, kvol, 1 if direct else 0, gran_cap, meta.data_ptr(),
+                                          meta[kvol:].data_ptr(), gs.data_ptr(), wg_k.data_ptr(), hdr.data_ptr(), st),
+                "link_pair_plan_layout")
+        ext_cnt = (row_info & 0xFFFF) - (row_info >> 16) if direct else row_info & 0xFFFF
+        ext_start = torch.zeros(n + 1, **i32)
+        torch.cumsum(ext_cnt, 0, out=ext_start[1:])
+        pair_io = torch.full((2, self.rows_pad), -1, **i32)
+        ext_list = torch.empty(max(cap_pairs, 1), **i32)
+        L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), meta[kvol:].data_ptr(),
+                                        ext_start.data_ptr(), pair_io[0].data_ptr(), pair_io[1].data_ptr(), ext_list.data_ptr(), st),
+                "link_pair_plan_fill")
+        self._meta, self._hdr = meta, hdr
+        self.pair_in, self.pair_out, self.ext_start, self.ext_list = pair_io[0], pair_io[1], ext_start, ext_list
+        self.gran_start, self.wg_k = gs, wg_k
+        self._contrib = {}
+        # the counts travel to pinned memory behind the kernels; whoever asks first after they arrived checks them
+        self._host = _pinned_slot()
+        self._host.copy_(hdr, non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+
+    def _arrived(self, wait: bool) -> bool:
+        if self.exact or self._density is not None:
+            return True
+        if wait:
+            self._ev.synchronize()
+        elif not self._ev.query():
+            return False
+        pairs, rows, gran, misses, over = [int(v) for v in self._host[:5].tolist()]
+        if over or (self.direct and misses):
+            raise L.LinkAmdError("pair plan: the table handed over as submanifold is not one (duplicate coordinates? "
+                                 f"{misses} rows whose centre neighbour is not the row itself)" if misses else
+                                 "pair plan: granule capacity exceeded")
+        self.pairs = pairs
+        self._density = (pairs + (self.n if self.direct else 0)) / max(self.n, 1)
+        self._exact_rows = rows
+        _DENSITY_SEEN[self.kvol] = self._density
+        return True
+
+    @property
+    def density(self) -> float:
+        """Pairs per output row.  A device-laid-out plan whose counts have not arrived yet answers with the last density seen
+        for this kernel volume (frames of a stream resemble each other; the pair-list kernels are correct at any density)."""
+        if self._arrived(False):
+            return self._density
+        return _DENSITY_SEEN.get(self.kvol, 0.0)
+
+    @property
+    def rows_launch(self) -> int:
+        """Contribution rows a GEMM launch has to cover: the exact count once it is known, the capacity before (the
+        granules behind the last one return at once)."""
+        if self.exact or not self._arrived(False):
+            return self.rows_pad
+        return self._exact_rows
+
+    def finalize(self) -> "_PairPlan":
+        """Wait for the counts of a device-laid-out plan and trim it to its exact size (what the weight-gradient kernel,
+        whose launch covers every granule, needs)."""
+        if not self.exact:
+            self._arrived(True)
+            self.rows_pad = self._exact_rows
+            self.wg_k = self.wg_k[: max(self._exact_rows // 128, 1)]
+            self._contrib.clear()
+            self.exact = True
+        return self
+
     def contrib(self, cout: int, dtype=torch.float32) -> torch.Tensor:
         if dtype != torch.float32:
             buf = self._contrib.get((cout, dtype))
@@ -877,13 +990,17 @@ class _PairPlan:
 
 def _pair_plan(nbr: torch.Tensor, cin: int, cout: int) -> Optional[_PairPlan]:
     """The table's pair plan when the pair-list kernels should run it (sparse neighbourhoods, supported
-    widths), else None; built once per table and cached on the (kmaps-cached) table tensor."""
+    widths), else None; built once per table and cached on the (kmaps-cached) table tensor.  Tables that carry their
+    builder's structural mark (`_link_subm`: neighbor_table_of / the strided convolutions' gather tables) get their plan
+    laid out on the device without a host round trip when no gradient is being recorded."""
     if not L.lib().link_conv_pairs_supported(cin, cout) or nbr.shape[1] > 64:
         return None                 # the pair plan holds one 64-bit offset mask per voxel: 5^3 / 7^3 kernels run the table kernel
     plan = getattr(nbr, "_link_pairs", False)
     if plan is False:
-        plan = _PairPlan(nbr)
+        plan = _PairPlan(nbr, None if torch.is_grad_enabled() else getattr(nbr, "_link_subm", None))
         nbr._link_pairs = plan
+    if torch.is_grad_enabled() and not plan.exact:
+        plan.finalize()
     return plan if plan.density <= PAIR_DENSITY_MAX else None
 
 
@@ -955,15 +1072,15 @@ def _conv_pairs(plan: _PairPlan, f, w, cin, cout, out, bias=None, ln=None, adden
     cdt = io if c16 else L.IO_F32
     if amp:
         w = _amp_weights(w_key if w_key is not None and w_key.shape == w.shape else w, f.dtype)
-        L.check(lib.link_conv_pairs_gemm_amp(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+        L.check(lib.link_conv_pairs_gemm_amp(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_launch,
                                              w.data_ptr(), cin, cout, contrib.data_ptr(), cdt, st), "link_conv_pairs_gemm_amp")
     elif split and SPLIT_MFMA and io == L.IO_F32 and cin >= 32:
         ws, big = _split_weights(w_key if w_key is not None and w_key.shape == w.shape else w)
-        L.check(lib.link_conv_pairs_gemm_split(f.data_ptr(), plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+        L.check(lib.link_conv_pairs_gemm_split(f.data_ptr(), plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_launch,
                                                ws.data_ptr(), w.data_ptr(), big.data_ptr(), cin, cout, contrib.data_ptr(), st),
                 "link_conv_pairs_gemm_split")
     else:
-        L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_pad,
+        L.check(lib.link_conv_pairs_gemm_io(f.data_ptr(), io, plan.pair_in.data_ptr(), plan.wg_k.data_ptr(), plan.rows_launch,
                                             w.data_ptr(), cin, cout, contrib.data_ptr(), st), "link_conv_pairs_gemm")
     ln_w, ln_b, eps = ln if ln is not None else (None, None, 0.0)
     if plan.direct:
@@ -1161,6 +1278,7 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
         # pair-list form: one MFMA pass over the 128-pair granules + per-offset sums in granule order; the centre
         # offset of a submanifold table (identity pairs, not in the plan) is the plain feats^T . g
         lib = L.lib()
+        plan.finalize()                                  # this launch covers every granule: a device-laid-out plan is trimmed first
         f = feats.detach().contiguous().float()
         gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=g.device)
         n_dir = plan.n if plan.direct else 0

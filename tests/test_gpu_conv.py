@@ -531,3 +531,48 @@ def test_odd_kernels_larger_than_3_run_the_table_kernel(C, ks):
     with torch.no_grad():                                # the fused inference tail takes the same route
         blk_out = conv(la.SparseTensor(feats.cuda(), coords.cuda(), 1)).F
     assert rel_err(blk_out.cpu().numpy(), ref.detach().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_pair_plan_laid_out_on_the_device_matches_the_host_layout(subm):
+    """link_pair_plan_layout (no host round trip) against the host-side layout of the same table: same pairs, same rows per
+    output, same convolution result; the counts that arrive later agree; finalize() trims to the exact plan."""
+    import link_amd as la
+    from link_amd import elk
+    torch.manual_seed(11)
+    n, c = 30000, 32
+    coords = s_uniform(n, grid=64, seed=5).cuda()
+    st = la.SparseTensor(torch.randn(n, c).cuda(), coords, 1)
+    nbr, order = elk.neighbor_table_of(st, (3, 3, 3))
+    if not subm:                                       # a gather table between two site sets: drop the identity column's meaning
+        nbr = nbr[torch.randperm(n, device=nbr.device)].contiguous()
+    host = elk._PairPlan(nbr, None)
+    dev = elk._PairPlan(nbr, subm)
+    assert host.exact and not dev.exact and host.direct == dev.direct == subm
+    w = torch.randn(27, c, c).cuda() * 0.1
+    outs = []
+    for plan in (host, dev):
+        out = torch.empty((n, c), device="cuda")
+        outs.append(elk._conv_pairs(plan, st.F, w, c, c, out).clone())
+    assert torch.equal(outs[0], outs[1])
+    torch.cuda.synchronize()
+    assert abs(dev.density - host.density) < 1e-12 and dev.pairs == host.pairs
+    assert dev.rows_launch == host.rows_pad
+    dev.finalize()
+    assert dev.exact and dev.rows_pad == host.rows_pad
+    assert torch.equal(dev.wg_k[: host.wg_k.numel()], host.wg_k)
+    assert torch.equal(dev.pair_in[: host.rows_pad], host.pair_in) and torch.equal(dev.pair_out[: host.rows_pad], host.pair_out)
+    assert torch.equal(dev.ext_start, host.ext_start) and torch.equal(dev.ext_list[: host.pairs], host.ext_list[: host.pairs])
+
+
+def test_pair_plan_on_device_rejects_a_wrong_structural_claim():
+    import link_amd as la
+    from link_amd import _lib as L, elk
+    n = 5000
+    coords = s_uniform(n, grid=40, seed=6).cuda()
+    st = la.SparseTensor(torch.randn(n, 16).cuda(), coords, 1)
+    nbr, _ = elk.neighbor_table_of(st, (3, 3, 3))
+    shuffled = nbr[torch.randperm(n, device=nbr.device)].contiguous()        # centre column no longer the identity
+    plan = elk._PairPlan(shuffled, True)
+    with pytest.raises(L.LinkAmdError):
+        plan.finalize()
