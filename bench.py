@@ -429,6 +429,33 @@ def cfg5_mode(args, la, dev, rank, world, dist):
     t_warm = timed(k, w, {})
     with torch.no_grad():
         bev, scales = net(feats, indices, 1, shape)
+    bev_ms = with_bev_ms = None
+    if args.bev:
+        # what BASELINE.json's configs[4] names in full: backbone + CenterPoint head.  The BEV half is plain torch in the
+        # reference as well (vendor dense-convolution library), outside the LinK hot path: timed separately and together
+        from link_amd.bevhead import BevHalf
+        half = BevHalf(num_input_features=bev.shape[1]).to(dev).eval()
+        half = half.to(feats.dtype) if feats.dtype != torch.float32 else half
+
+        def both(maps):
+            b, _ = net(feats, indices, 1, shape, indice_dict=maps)
+            return half(b.to(feats.dtype))
+        with torch.no_grad():
+            for _ in range(3):
+                preds = both(None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                both(None)
+            torch.cuda.synchronize()
+            with_bev_ms = 1e3 * (time.perf_counter() - t0) / k
+            x = bev.to(feats.dtype)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                half(x)
+            torch.cuda.synchronize()
+            bev_ms = 1e3 * (time.perf_counter() - t0) / k
+        assert len(preds) == 6 and preds[0]["hm"].shape[-2:] == bev.shape[-2:]
     roof = None
     if rank == 0:
         warm_maps = {}
@@ -452,7 +479,8 @@ def cfg5_mode(args, la, dev, rank, world, dist):
                                    "maps built per frame, one S-nusc frame per GPU",
                        "voxels": n, "stage_voxels": [scales[f"conv{i}"].features.shape[0] for i in (1, 2, 3, 4)],
                        "bev": list(bev.shape), "parallelism": f"dp{world}"},
-            "warm_maps_ms": 1e3 * t_warm / k, "roofline": roof, "cpu_baseline": None}))
+            "warm_maps_ms": 1e3 * t_warm / k, "bev_half_ms": bev_ms, "backbone_plus_bev_half_ms": with_bev_ms,
+            "roofline": roof, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -466,6 +494,8 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--streams", type=int, default=3, help="independent frames in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bev", action="store_true",
+                    help="cfg5: also run the dense BEV half (RPN + CenterHead in plain torch, link_amd/bevhead.py) behind the backbone")
     ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
                     help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2",

@@ -222,3 +222,18 @@ def test_reference_network_classes_build_on_the_aliased_surface():
         for k in [k for k in sys.modules if k == "torchsparse" or k.startswith("torchsparse.") or k == "core"
                   or k.startswith("core.")]:
             del sys.modules[k]
+
+
+def test_bev_half_harness_shapes():
+    """The plain-torch stand-in of the detection model's dense half (RPN + CenterHead; outside the hot path, used by
+    `bench.py --workload cfg5 --bev`): six tasks, the config's head widths, predictions at the BEV map's resolution."""
+    import torch
+    from link_amd.bevhead import BevCenterHead, BevHalf
+    m = BevHalf().eval()
+    with torch.no_grad():
+        out = m(torch.randn(1, 256, 20, 20))
+    assert len(out) == 6
+    for task, ncls in zip(out, BevCenterHead.NUSC_TASKS):
+        assert {k: v.shape[1] for k, v in task.items()} == {"reg": 2, "height": 1, "dim": 3, "rot": 2, "vel": 2, "hm": ncls}
+        assert all(v.shape[-2:] == (20, 20) for v in task.values())
+    assert m.neck.out_channels == 512
