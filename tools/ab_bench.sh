@@ -12,7 +12,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('   streams $st: %.2f us/frame  value %.3e  kernels %s  whole-step frac %.3f' % (d['ms_per_step'] * 1e3, d['value'], r.get('kernel_us'), r['whole_step']['frac']))
+        print('   streams $st: %.2f us/frame  value %.3e  kernels %s  whole-step frac %.3f' % (d['us_per_frame'], d['value'], r.get('kernel_us'), r['whole_step']['frac']))
 "
   done
 done

@@ -8,7 +8,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('   k1_form $form streams $st: %.2f us/frame  value %.3e  kernels %s  single-frame median %.2f  whole-step frac %.3f  check %s' % (d['ms_per_step'] * 1e3, d['value'], r.get('kernel_us'), r['single_frame_step']['median_us'], r['whole_step']['frac'], d.get('timed_configuration_check')))
+        print('   k1_form $form streams $st: %.2f us/frame  value %.3e  kernels %s  single-frame median %.2f  whole-step frac %.3f  check %s' % (d['us_per_frame'], d['value'], r.get('kernel_us'), r['single_frame_step']['median_us'], r['whole_step']['frac'], d.get('timed_configuration_check')))
 "
   done
 done

@@ -7,6 +7,6 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('   k2_form $k2 k1_form $form streams $st k1_wgs $wgs zsplit $zs: %.2f us/frame  frac %.3f' % (d['ms_per_step'] * 1e3, r['whole_step']['frac']))
+        print('   k2_form $k2 k1_form $form streams $st k1_wgs $wgs zsplit $zs: %.2f us/frame  frac %.3f' % (d['us_per_frame'], r['whole_step']['frac']))
 "
 done; done; done; done; done
