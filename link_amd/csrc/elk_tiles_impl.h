@@ -27,10 +27,6 @@ __device__ unsigned long long elk_g_dbg[8 * 32768];
 #else
 #define ELK_T_TICK(v)
 #endif
-#ifndef ELK_T_X
-#define ELK_T_X 0         /* experiment builds (wrong results!): 1 no range check of the fp16 split, 2 no cross-wave combine, 4 no sincos,
-                             8 no matrix-core contraction, 16 prologue only */
-#endif
 
 namespace DC_IO_NS {
 using namespace link;
@@ -127,7 +123,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
   const uint32_t my_part = part_off + (uint32_t)((blockIdx.x * K::NW + wave) * 2) * (uint32_t)K::RB;
   bool through = false;
 
-  if (has && !(ELK_T_X & 16)) {
+  if (has) {
     const int ntile = (wb - wa + 15) >> 4;
     bool cont_prev = false;                             // the tile's first voxels continue the block the previous tile ended in
     int rank_carry = 0;                                 // ... and this many of that block's voxels came before this tile (in this wave)
@@ -153,17 +149,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
       ELK_T_TICK(tb);
       tq_rows += tb - ta;
 #endif
-      if (ELK_T_X & 8) {
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) ac[tp] = (floatx4){ff[tp].x, ff[tp].y, ff[tp].z, ff[tp].w};
-      } else if (ELK_T_X & 1) {
-        float4 fs[T];
-#pragma unroll
-        for (int tp = 0; tp < T; tp++) fs[tp] = make_float4(fminf(ff[tp].x, 1.f), fminf(ff[tp].y, 1.f), fminf(ff[tp].z, 1.f), fminf(ff[tp].w, 1.f));
-        dc_premix_tile<C>(wh, w_pre, false, li, gq, fs, ac);
-      } else {
-        dc_premix_tile<C>(wh, w_pre, w_big, li, gq, ff, ac);
-      }
+      dc_premix_tile<C>(wh, w_pre, w_big, li, gq, ff, ac);
 #ifdef ELK_T_DBG
       asm volatile("s_nop 0" ::"v"(ac[0][0]));
       ELK_T_TICK(tc);
@@ -192,10 +178,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
         bool big = false;
 #pragma unroll
         for (int r = 0; r < 4; r++) big |= !(fabsf(th_[r]) < 32768.0f);
-        if (ELK_T_X & 4) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) { sn_[r] = th_[r]; cs_[r] = 1.f - th_[r]; }
-        } else if (__builtin_expect(__any(big), 0)) {           // never on sane inputs
+        if (__builtin_expect(__any(big), 0)) {           // never on sane inputs
 #pragma unroll
           for (int r = 0; r < 4; r++) sincos_nocall(th_[r], sn_[r], cs_[r]);
         } else {
@@ -323,7 +306,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partial rows have left this wave
   __syncthreads();
-  if (!(ELK_T_X & 2) && tail_open && !through) {
+  if (tail_open && !through) {
     const int b = flags[K::NW + wave];
     int last = wave + 1;                                  // the wave the block ends in
     while (flags[last] & 2) last++;

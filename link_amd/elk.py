@@ -805,18 +805,26 @@ def spdownsample(coords: torch.Tensor, stride=2, kernel_size=2, tensor_stride=1)
 # cross-over of the two forms on MI355X (tools/convbench.py)
 PAIR_DENSITY_MAX = 17.0
 ASYNC_PAIR_PLANS = True      # lay pair plans out on the device when the table's structure is known (no host round trip)
+ASYNC_PAIR_PLAN_MAX = 8_000_000   # ... up to this many table entries: the buffers are sized for every entry being a pair
+                                  # (contribution rows at 64 channels: 256 B per entry), beyond it the exact host layout
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
 _PINNED: list = []
 
 
-def _pinned_slot() -> torch.Tensor:
-    """8 ints of pinned host memory from a small ring (allocating pinned memory per plan would cost more than the round
-    trip it replaces); a slot is reused after 512 later plans."""
+def _pinned_slot():
+    """(8 ints of pinned host memory, slot, generation) from a small ring (allocating pinned memory per plan would cost
+    more than the round trip it replaces).  A slot is handed out again after 512 later plans; a plan that looks at its
+    counts only then sees the generation moved on and reads its device header instead (_pinned_current)."""
     if not _PINNED:
-        _PINNED.extend([torch.empty((512, 8), dtype=torch.int32).pin_memory(), 0])
-    buf, i = _PINNED
+        _PINNED.extend([torch.empty((512, 8), dtype=torch.int32).pin_memory(), 0, [0] * 512])
+    buf, i, gen = _PINNED
     _PINNED[1] = (i + 1) % buf.shape[0]
-    return buf[i]
+    gen[i] += 1
+    return buf[i], i, gen[i]
+
+
+def _pinned_current(slot: int, generation: int) -> bool:
+    return _PINNED[2][slot] == generation
 
 
 class _PairPlan:
@@ -831,7 +839,7 @@ class _PairPlan:
         unique coordinates in and out, so the centre column is the identity), False: not one, None: unknown.  With a
         structural answer and ASYNC_PAIR_PLANS the plan is laid out on the device (link_pair_plan_layout) over capacity-
         sized buffers and nothing waits for the host; the counts arrive later in pinned memory (`density`, `finalize`)."""
-        if subm is not None and ASYNC_PAIR_PLANS and nbr.is_cuda and nbr.shape[0] > 0:
+        if subm is not None and ASYNC_PAIR_PLANS and nbr.is_cuda and 0 < nbr.shape[0] * nbr.shape[1] <= ASYNC_PAIR_PLAN_MAX:
             self._init_async(nbr, bool(subm))
             return
         self.exact = True
@@ -923,7 +931,7 @@ class _PairPlan:
         self.gran_start, self.wg_k = gs, wg_k
         self._contrib = {}
         # the counts travel to pinned memory behind the kernels; whoever asks first after they arrived checks them
-        self._host = _pinned_slot()
+        self._host, self._slot, self._gen = _pinned_slot()
         self._host.copy_(hdr, non_blocking=True)
         self._ev = torch.cuda.Event()
         self._ev.record()
@@ -935,7 +943,8 @@ class _PairPlan:
             self._ev.synchronize()
         elif not self._ev.query():
             return False
-        pairs, rows, gran, misses, over = [int(v) for v in self._host[:5].tolist()]
+        src = self._host if _pinned_current(self._slot, self._gen) else self._hdr      # slot reused since: read the device copy
+        pairs, rows, gran, misses, over = [int(v) for v in src[:5].tolist()]
         if over or (self.direct and misses):
             raise L.LinkAmdError("pair plan: the table handed over as submanifold is not one (duplicate coordinates? "
                                  f"{misses} rows whose centre neighbour is not the row itself)" if misses else
