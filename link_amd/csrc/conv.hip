@@ -30,6 +30,61 @@ struct conv_epilogue {
   int relu;
 };
 
+// Store phase shared by the matrix-core kernels: the accumulator layout holds 16 channels of ONE voxel per lane group
+// pass (lane (li, g): voxel li, channels 16 tp + 4 g .. + 3), so LayerNorm statistics are in-lane adds + 2 cross-lane steps.
+// row N2: out = relu(addend + LayerNorm(conv) * ln_w + ln_b); bit 1 of ep.relu: ln_w / ln_b are a plain per-channel affine
+// (folded BatchNorm, scn.py:486-489), no statistics; ln_w == NULL: the plain convolution output.
+template <int CO>
+__device__ __forceinline__ void conv_finish(const floatx4 (&acc)[CO / 16], int64_t v, int g, const conv_epilogue &ep,
+                                            float *__restrict__ out) {
+  constexpr int TO = CO / 16;
+  if (ep.ln_w) {
+    float mean = 0.f, rstd = 1.f;
+    if (!(ep.relu & 2)) {
+      float sm = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) sm += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      mean = sm * (1.0f / CO);
+      float q = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float d = acc[tp][r] - mean;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      rstd = 1.0f / sqrtf(q * (1.0f / CO) + ep.eps);
+    }
+    if (v >= 0) {
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        const int ch = 16 * tp + 4 * g;
+        const float4 lw = *reinterpret_cast<const float4 *>(&ep.ln_w[ch]);
+        const float4 lb = *reinterpret_cast<const float4 *>(&ep.ln_b[ch]);
+        float4 o;
+        o.x = (acc[tp][0] - mean) * rstd * lw.x + lb.x;
+        o.y = (acc[tp][1] - mean) * rstd * lw.y + lb.y;
+        o.z = (acc[tp][2] - mean) * rstd * lw.z + lb.z;
+        o.w = (acc[tp][3] - mean) * rstd * lw.w + lb.w;
+        if (ep.addend) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * CO + ch]);
+          o.x = a4.x + o.x; o.y = a4.y + o.y; o.z = a4.z + o.z; o.w = a4.w + o.w;
+        }
+        if (ep.relu & 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4 *>(&out[v * CO + ch]) = o;
+      }
+    }
+  } else if (v >= 0) {
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++)
+      *reinterpret_cast<float4 *>(&out[v * CO + 16 * tp + 4 * g]) = make_float4(acc[tp][0], acc[tp][1], acc[tp][2], acc[tp][3]);
+  }
+}
+
 template <int CI, int CO, int NT, bool DEEP>
 __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict__ feats,
                                                         const int32_t *__restrict__ nbr,
@@ -240,59 +295,284 @@ __global__ void __launch_bounds__(256) k_subm_conv_mfma(const float *__restrict_
       __syncthreads();                               // LDS free for the next pass
     }
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      const int64_t v = vox[j];
-      if (ep.ln_w) {
-        // row N2: out = relu(addend + LayerNorm(conv)) -- the accumulator layout holds 16 channels of ONE
-        // voxel per lane (the quarter-waves hold the other 48), so the statistics are 16 in-lane adds + 2
-        // cross-lane steps, exactly as in the pre_mix kernel
-        float mean = 0.f, rstd = 1.f;               // bit 1 of ep.relu: ln_w / ln_b are a plain per-channel affine
-        if (!(ep.relu & 2)) {                       // (folded BatchNorm, scn.py:486-489), no statistics
-          float sm = 0.f;
+    for (int j = 0; j < NT; j++) conv_finish<CO>(acc[j], vox[j], g, ep, out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Narrow layers (C = 16 / 32: the first two stages of the detection backbone, scn.py:467-470, the stem of the
+// segmentation encoders): ALL 27 W_k fit in LDS at once (27 x 16 x 16 floats = 27 KB, 27 x 32 x 32 = 108 KB), so the
+// workgroup stages them ONCE and its waves walk tiles of 16 output voxels with no barrier and no weight traffic in the
+// offset loop -- the kernel above re-stages W_k and synchronises per offset, which at these widths is all it does
+// (4 MFMAs between two barriers), and the pair-list form moves every (voxel, offset) contribution through HBM twice
+// (105 MB out + 105 MB back for 150 k voxels at C = 16: at the HBM roofline for bytes this form never moves).  Per tile:
+// the 27 x 16 neighbour ids -> LDS in one round trip, the offsets some voxel of the tile has (7 ballots), then per such
+// offset one gathered row piece per lane and TI x TO x 4 v_mfma_f32_16x16x4_f32 (exact f32, A operand from the resident
+// image), the rows of 8 offsets requested back to back, two accumulator sets.  Same store phase (conv_finish).
+// ---------------------------------------------------------------------------------------------
+#ifdef CONV_RES_DBG        /* profiling builds only: per-wave s_memtime phases of the resident-weights kernel */
+__device__ unsigned long long conv_res_dbg[8 * 16384];
+extern "C" int link_conv_resident_debug_read(void *host_dst, int64_t bytes) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(conv_res_dbg), (size_t)bytes) == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
+}
+#define CONV_TICK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define CONV_TICK(v)
+#endif
+
+template <int CI, int CO>
+struct conv_res_cfg {
+  static constexpr int TI = CI / 16, TO = CO / 16, KV = 27;
+  static constexpr int LDW = CI + 4;                   // row stride of W_k^T [co][ci]: 16 (mod 32) banks between the half-wave's two rows
+  static constexpr int W_FLOATS = KV * CO * LDW;
+  // waves sharing one image: the tile loop is a chain of round trips (ids, batches of rows, addend), so the CU wants 4-6
+  // waves per SIMD; an image beyond 48 KB admits one workgroup per CU: 16 waves there, 8 (x 3 workgroups) below
+  static constexpr int NW = (W_FLOATS * 4 > 48 * 1024) ? 16 : 8;
+  static constexpr int LDS_BYTES = W_FLOATS * 4 + NW * (KV + 1) * 16 * 4;     // + per wave the tile's 27 x 16 neighbour ids (+ a spare row)
+};
+
+typedef _Float16 conv_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 conv_h8 __attribute__((ext_vector_type(8)));
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): four values -> two packed operands
+__device__ __forceinline__ void conv_split4(const float4 &v, uint2 &hi, uint2 &lo) {
+  const conv_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  const conv_h4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z), (_Float16)(v.w - (float)h.w)};
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+
+// SPLIT: the products run on the f16 matrix cores with both operands split into fp16 hi + lo (hi*hi + hi*lo + lo*hi, fp32
+// accumulation; the dropped lo*lo term is 2^-22 relative) -- what the pair-list form's inference kernel does
+// (k_conv_pairs_gemm_split): a 16-channel k-step is ONE v_mfma_f32_16x16x16_f16 of 16 cycles instead of four
+// v_mfma_f32_16x16x4_f32 of 32, two k-steps one v_mfma_f32_16x16x32_f16.  The resident image holds [hi(CI) | lo(CI)] halves
+// per output channel (the same 4 CI + 16 bytes per row as the fp32 image).  A row or a weight beyond the fp16 range
+// (|x| >= 2^15) sends the tile to the exact instruction with W from global memory (wave-uniform, never on sane data).
+template <int CI, int CO, bool SPLIT>
+__global__ void __launch_bounds__(64 * (conv_res_cfg<CI, CO>::NW)) k_subm_conv_resident(
+    const float *__restrict__ feats, const int32_t *__restrict__ nbr, const float *__restrict__ w,
+    const int32_t *__restrict__ order, int64_t n, int kvol, float *__restrict__ out, conv_epilogue ep) {
+  using K = conv_res_cfg<CI, CO>;
+  constexpr int TI = K::TI, TO = K::TO, LDW = K::LDW, NT = 64 * K::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *wt_lds = reinterpret_cast<float *>(smem_raw);                  // [k][co][ci], row stride LDW
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  int32_t *my_nb = reinterpret_cast<int32_t *>(wt_lds + K::W_FLOATS) + wave * ((K::KV + 1) * 16);
+  CONV_TICK(tc0);
+#ifdef CONV_RES_DBG
+  unsigned long long tc_ids = 0, tc_ld = 0, tc_mma = 0, tc_fin = 0, tc_tiles = 0;
+#endif
+  // W [k][ci][co] -> LDS [k][co][ci]: 16-byte loads along co, four scattered writes each (fp32, or fp16 hi and lo)
+  constexpr int LDH = 2 * CI + 8;                      // halves per row of the split image: [hi(CI) | lo(CI) | pad]
+  bool w_big = false;
+  for (int e = tid * 4; e < kvol * CI * CO; e += NT * 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(&w[e]);
+    const int k = e / (CI * CO), r = e - k * (CI * CO), ci = r / CO, co = r - ci * CO;
+    if constexpr (SPLIT) {
+      _Float16 *dst = reinterpret_cast<_Float16 *>(smem_raw) + (k * CO + co) * LDH + ci;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int tp = 0; tp < TO; tp++) sm += (acc[j][tp][0] + acc[j][tp][1]) + (acc[j][tp][2] + acc[j][tp][3]);
-          sm += __shfl_xor(sm, 16, 64);
-          sm += __shfl_xor(sm, 32, 64);
-          mean = sm * (1.0f / CO);
-          float q = 0.f;
-#pragma unroll
-          for (int tp = 0; tp < TO; tp++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const float d = acc[j][tp][r] - mean;
-              q += d * d;
-            }
-          q += __shfl_xor(q, 16, 64);
-          q += __shfl_xor(q, 32, 64);
-          rstd = 1.0f / sqrtf(q * (1.0f / CO) + ep.eps);
-        }
-        if (v >= 0) {
-#pragma unroll
-          for (int tp = 0; tp < TO; tp++) {
-            const int ch = 16 * tp + 4 * g;
-            const float4 lw = *reinterpret_cast<const float4 *>(&ep.ln_w[ch]);
-            const float4 lb = *reinterpret_cast<const float4 *>(&ep.ln_b[ch]);
-            float4 o;
-            o.x = (acc[j][tp][0] - mean) * rstd * lw.x + lb.x;
-            o.y = (acc[j][tp][1] - mean) * rstd * lw.y + lb.y;
-            o.z = (acc[j][tp][2] - mean) * rstd * lw.z + lb.z;
-            o.w = (acc[j][tp][3] - mean) * rstd * lw.w + lb.w;
-            if (ep.addend) {
-              const float4 a4 = *reinterpret_cast<const float4 *>(&ep.addend[v * CO + ch]);
-              o.x = a4.x + o.x; o.y = a4.y + o.y; o.z = a4.z + o.z; o.w = a4.w + o.w;
-            }
-            if (ep.relu & 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            *reinterpret_cast<float4 *>(&out[v * CO + ch]) = o;
-          }
-        }
-      } else if (v >= 0) {
-#pragma unroll
-        for (int tp = 0; tp < TO; tp++)
-          *reinterpret_cast<float4 *>(&out[v * CO + 16 * tp + 4 * g]) =
-              make_float4(acc[j][tp][0], acc[j][tp][1], acc[j][tp][2], acc[j][tp][3]);
+      for (int q4 = 0; q4 < 4; q4++) {
+        const _Float16 h = (_Float16)vv[q4];
+        dst[q4 * LDH] = h;
+        dst[q4 * LDH + CI] = (_Float16)(vv[q4] - (float)h);
+        w_big |= !(fabsf(vv[q4]) < 32768.0f);
       }
+    } else {
+      float *dst = wt_lds + (k * CO + co) * LDW + ci;
+      dst[0] = v.x; dst[LDW] = v.y; dst[2 * LDW] = v.z; dst[3 * LDW] = v.w;
     }
   }
+  if constexpr (SPLIT) w_big = __syncthreads_or(w_big) != 0;
+  else __syncthreads();
+  CONV_TICK(tc1);
+  const int64_t tiles = (n + 15) / 16;
+  // (contiguous eighths of the tiles per XCD were tried: 37.2 against 36.3 us at C = 16 -- the gathers are not what bounds it)
+  const int64_t waves_total = (int64_t)gridDim.x * K::NW;
+  for (int64_t tile = (int64_t)blockIdx.x * K::NW + wave; tile < tiles; tile += waves_total) {
+    const int64_t q = tile * 16 + li;
+    const int64_t v = (q < n) ? (order ? (int64_t)order[q] : q) : -1;
+    CONV_TICK(ta);
+    // neighbour ids of the tile: lane group g loads the offsets k = g (mod 4) -- unconditional loads on clamped indices, so
+    // the seven requests are in flight together (a conditional load is a branch and a full wait each); which offsets
+    // does the tile have at all?
+    const int64_t vc = v >= 0 ? v : 0;
+    int idr[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int k = 4 * j + g;
+      idr[j] = nbr[vc * kvol + (k < kvol ? k : 0)];
+    }
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int k = 4 * j + g;
+      const int id = (k < kvol && v >= 0) ? idr[j] : -1;
+      my_nb[k * 16 + li] = id;                         // k = 27 (j = 6, g = 3) lands in a spare slot
+      const unsigned long long bal = __ballot(id >= 0);
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++)
+        if ((bal >> (16 * gg)) & 0xFFFFull) mask |= 1u << (4 * j + gg);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CONV_TICK(tb);
+#ifdef CONV_RES_DBG
+    tc_ids += tb - ta;
+#endif
+    // two accumulator sets, alternating by offset: consecutive MFMAs do not wait for each other's result
+    floatx4 acc[TO], acc2[TO];
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) acc[tp] = acc2[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    auto next_off = [&]() { const int kk = mask ? (__ffs(mask) - 1) : -1; mask &= mask - 1; return kk; };
+    auto mma = [&](int kk, bool has, const float4 (&ff)[TI], floatx4 (&ac)[TO], bool exact) {
+      if constexpr (SPLIT) {
+        if (!exact) {
+          const _Float16 *wh = reinterpret_cast<const _Float16 *>(smem_raw) + (size_t)kk * (CO * LDH);
+          uint2 bh[TI], bl[TI];
+#pragma unroll
+          for (int tt = 0; tt < TI; tt++) {
+            conv_split4(ff[tt], bh[tt], bl[tt]);
+            bh[tt].x = has ? bh[tt].x : 0u; bh[tt].y = has ? bh[tt].y : 0u;
+            bl[tt].x = has ? bl[tt].x : 0u; bl[tt].y = has ? bl[tt].y : 0u;
+          }
+#pragma unroll
+          for (int tp = 0; tp < TO; tp++) {
+            const _Float16 *row = wh + (16 * tp + li) * LDH + 4 * g;
+            if constexpr (TI == 2) {
+              // two 16-channel k-steps in one instruction: its k = 8 g + j is channel 4 g + j of the first block (j < 4) and
+              // of the second (j >= 4), for both operands alike
+              const uint2 ah0 = *reinterpret_cast<const uint2 *>(row), ah1 = *reinterpret_cast<const uint2 *>(row + 16);
+              const uint2 al0 = *reinterpret_cast<const uint2 *>(row + CI), al1 = *reinterpret_cast<const uint2 *>(row + CI + 16);
+              const uint4 Ah = make_uint4(ah0.x, ah0.y, ah1.x, ah1.y), Al = make_uint4(al0.x, al0.y, al1.x, al1.y);
+              const uint4 Bh = make_uint4(bh[0].x, bh[0].y, bh[1].x, bh[1].y), Bl = make_uint4(bl[0].x, bl[0].y, bl[1].x, bl[1].y);
+              ac[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(conv_h8, Al), __builtin_bit_cast(conv_h8, Bh), ac[tp], 0, 0, 0);
+              ac[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(conv_h8, Ah), __builtin_bit_cast(conv_h8, Bl), ac[tp], 0, 0, 0);
+              ac[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(conv_h8, Ah), __builtin_bit_cast(conv_h8, Bh), ac[tp], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int tt = 0; tt < TI; tt++) {
+                const uint2 ah = *reinterpret_cast<const uint2 *>(row + 16 * tt), al = *reinterpret_cast<const uint2 *>(row + CI + 16 * tt);
+                ac[tp] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(conv_h4, al), __builtin_bit_cast(conv_h4, bh[tt]), ac[tp], 0, 0, 0);
+                ac[tp] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(conv_h4, ah), __builtin_bit_cast(conv_h4, bl[tt]), ac[tp], 0, 0, 0);
+                ac[tp] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(conv_h4, ah), __builtin_bit_cast(conv_h4, bh[tt]), ac[tp], 0, 0, 0);
+              }
+            }
+          }
+          return;
+        }
+      }
+      // exact f32: A operand from the resident fp32 image, or (SPLIT kernels' out-of-range tiles) from global memory
+#pragma unroll
+      for (int tt = 0; tt < TI; tt++) {
+        const float fx = has ? ff[tt].x : 0.f, fy = has ? ff[tt].y : 0.f, fz = has ? ff[tt].z : 0.f, fw = has ? ff[tt].w : 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TO; tp++) {
+          float4 a;
+          if constexpr (SPLIT) {
+            const float *wk = w + (size_t)kk * (CI * CO) + (size_t)(16 * tt + 4 * g) * CO + 16 * tp + li;
+            a = make_float4(wk[0], wk[CO], wk[2 * CO], wk[3 * CO]);
+          } else {
+            a = *reinterpret_cast<const float4 *>(&wt_lds[(size_t)kk * (CO * LDW) + (16 * tp + li) * LDW + 16 * tt + 4 * g]);
+          }
+          ac[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, fx, ac[tp], 0, 0, 0);
+          ac[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, fy, ac[tp], 0, 0, 0);
+          ac[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, fz, ac[tp], 0, 0, 0);
+          ac[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, fw, ac[tp], 0, 0, 0);
+        }
+      }
+    };
+    // batches of BATCH offsets, straight-line: all ids from LDS, all rows requested, then the products (an offset slot
+    // beyond the tile's last one multiplies zeros: at most BATCH - 1 per tile)
+    constexpr int BATCH = 8 / TI;
+    auto load_batch = [&](int (&ks)[BATCH], int (&ids)[BATCH], float4 (&fs)[BATCH][TI]) {
+      const bool any = mask != 0u;
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int kk = next_off();
+        ks[i] = kk < 0 ? 0 : kk;
+        const int id = my_nb[ks[i] * 16 + li];
+        ids[i] = kk < 0 ? -1 : id;
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int64_t row = ids[i] >= 0 ? ids[i] : 0;
+#pragma unroll
+        for (int tt = 0; tt < TI; tt++) fs[i][tt] = *reinterpret_cast<const float4 *>(&feats[row * CI + 16 * tt + 4 * g]);
+      }
+      __builtin_amdgcn_sched_barrier(0);               // the batch's requests go out before anything that follows
+      return any;
+    };
+    auto products = [&](const int (&ks)[BATCH], const int (&ids)[BATCH], const float4 (&fs)[BATCH][TI]) {
+      bool exact = !SPLIT;
+      if constexpr (SPLIT) {
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < BATCH; i++)
+#pragma unroll
+          for (int tt = 0; tt < TI; tt++)
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(fs[i][tt].x), fabsf(fs[i][tt].y)), fmaxf(fabsf(fs[i][tt].z), fabsf(fs[i][tt].w))));
+        exact = w_big || __any(!(mx < 32768.0f));
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) mma(ks[i], ids[i] >= 0, fs[i], (i & 1) ? acc2 : acc, exact);
+    };
+    // (two row sets with the next batch in flight during the products were tried: 161 registers halve the waves per SIMD
+    // and the kernel got slower, 36 -> 49 us at C = 16)
+    int ksA[BATCH], idsA[BATCH];
+    float4 fA[BATCH][TI];
+    CONV_TICK(tl0);
+    while (load_batch(ksA, idsA, fA)) products(ksA, idsA, fA);
+#ifdef CONV_RES_DBG
+    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc2[0][0]));
+    CONV_TICK(tl2);
+    tc_mma += tl2 - tl0;
+#endif
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) acc[tp] += acc2[tp];
+    CONV_TICK(tf0);
+    conv_finish<CO>(acc, v, g, ep, out);
+    __builtin_amdgcn_wave_barrier();                   // the id list is rewritten by the next tile
+#ifdef CONV_RES_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CONV_TICK(tf1);
+    tc_fin += tf1 - tf0;
+    tc_tiles++;
+#endif
+  }
+#ifdef CONV_RES_DBG
+  if (lane == 0 && blockIdx.x * K::NW + wave < 16384) {
+    unsigned long long *d = conv_res_dbg + (size_t)(blockIdx.x * K::NW + wave) * 8;
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    d[0] = tc1 - tc0; d[1] = tc_ids; d[2] = tc_ld; d[3] = tc_mma; d[4] = tc_fin; d[5] = tc_tiles; d[6] = tc0; d[7] = te - tc0;
+  }
+#endif
+}
+
+template <int CI, int CO>
+static int launch_conv_resident(const float *feats, const int32_t *nbr, const float *w, const int32_t *order, int64_t n,
+                                int kvol, float *out, const conv_epilogue &ep, bool split, hipStream_t st) {
+  using K = conv_res_cfg<CI, CO>;
+  const int64_t tiles = (n + 15) / 16;
+  // persistent workgroups: as many as stay resident (LDS-bound), each wave strides over the tiles -- the image is staged
+  // once per workgroup, not once per tile
+  const int per_cu = (160 * 1024) / K::LDS_BYTES;
+  int64_t wgs = (tiles + K::NW - 1) / K::NW;
+  if (wgs > 256 * per_cu) wgs = 256 * per_cu;
+  if (split) {
+    if (K::LDS_BYTES > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_resident<CI, CO, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    hipLaunchKernelGGL((k_subm_conv_resident<CI, CO, true>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, feats, nbr, w,
+                       order, n, kvol, out, ep);
+  } else {
+    if (K::LDS_BYTES > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_resident<CI, CO, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    hipLaunchKernelGGL((k_subm_conv_resident<CI, CO, false>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, feats, nbr, w,
+                       order, n, kvol, out, ep);
+  }
+  return check_launch("link_subm_conv_forward");
 }
 
 // any Cin / Cout <= 256: one wave per output voxel, lanes = output channels (no MFMA; small widths)
@@ -472,6 +752,9 @@ extern "C" int link_subm_conv_wgrad(const float *feats, const float *gout, const
 static constexpr int g_conv_wgs = 1024;  // cap (sweep recorded in DESIGN.md 4b)
 static constexpr int g_conv_nt = 0;      // tiles per wave: by size
 static constexpr int g_conv_deep = 1;    // two-steps-ahead pipeline of the table kernel on small frames
+#ifndef CONV_RESIDENT_MIN
+#define CONV_RESIDENT_MIN 1              /* voxels from which the resident-weights kernel takes the narrow layers */
+#endif
 
 template <int CI, int CO, int NT>
 static int launch_conv_mfma_nt(const float *feats, const int32_t *nbr, const float *w, const int32_t *order,
@@ -540,6 +823,15 @@ static int subm_conv_impl(const float *feats, const int32_t *nbr, const float *w
   if (n == 0) return LINK_OK;
   if (!feats || !nbr || !w || !out) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
+  if (mfma_ok && kvol <= 27 && n >= CONV_RESIDENT_MIN) {          // narrow layers: every W_k resident in LDS
+    // the fused inference forms (epilogue set: link_subm_conv_ln_add_relu) take the fp16-split products, like the pair-list
+    // form's inference kernel; the plain forward (what autograd records) stays on the exact f32 instruction
+    const bool split = ep.ln_w != nullptr;
+    if (cin == 16 && cout == 16) return launch_conv_resident<16, 16>(feats, nbr, w, order, n, kvol, out, ep, split, st);
+    if (cin == 32 && cout == 32) return launch_conv_resident<32, 32>(feats, nbr, w, order, n, kvol, out, ep, split, st);
+    if (cin == 16 && cout == 32) return launch_conv_resident<16, 32>(feats, nbr, w, order, n, kvol, out, ep, split, st);
+    if (cin == 32 && cout == 16) return launch_conv_resident<32, 16>(feats, nbr, w, order, n, kvol, out, ep, split, st);
+  }
   if (mfma_ok) {
 #define LINK_CONV(I, O) if (cin == I && cout == O) return launch_conv_mfma<I, O>(feats, nbr, w, order, n, kvol, out, ep, st)
     LINK_CONV(16, 16); LINK_CONV(32, 32); LINK_CONV(48, 48); LINK_CONV(64, 64); LINK_CONV(80, 80); LINK_CONV(96, 96);

@@ -1156,6 +1156,15 @@ def fold_batchnorm(bn: nn.BatchNorm1d, conv_bias: Optional[torch.Tensor] = None)
     return sc, sh
 
 
+RESIDENT_FORM = True         # narrow fp32 layers (16 / 32 channels): the table kernel with every W_k resident in LDS (conv.hip)
+RESIDENT_TILE_ORDER = False  # ... over the voxels in memory order (LiDAR frames arrive spatially coherent; no tile index to build)
+_RESIDENT_SHAPES = ((16, 16), (32, 32), (16, 32), (32, 16))
+
+
+def _resident_form(cin: int, cout: int, kvol: int, half: bool, form: str) -> bool:
+    return RESIDENT_FORM and form == "auto" and not half and kvol <= 27 and (cin, cout) in _RESIDENT_SHAPES
+
+
 def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
               order: Optional[torch.Tensor] = None, form: str = "auto") -> torch.Tensor:
     """out = sum_k feats[nbr[:,k]] @ kernel[k] (include/link_amd.h section D), no autograd.  `form`:
@@ -1178,11 +1187,14 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
         return subm_conv(f, wp, nbr, order, form)[:, :cout].contiguous()
     if form != "table" and w.ndim == 3:
         f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
-    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
+    resident = _resident_form(cin, cout, kvol, half, form)
+    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 and not resident else None
     if form == "pairs" and plan is None:
         plan = getattr(nbr, "_link_pairs", None)
         if plan is None:
             raise L.LinkAmdError(f"subm_conv(form='pairs'): widths {cin}->{cout} not supported by the pair-list kernels")
+    if resident and not RESIDENT_TILE_ORDER:
+        order = None
     if plan is not None:
         return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device), w_key=kernel)
     f = f.float()                                      # the table kernel is fp32: half rows are widened here
@@ -1214,9 +1226,12 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     lw, lb = ln_w.detach().contiguous().float(), ln_b.detach().contiguous().float()
     if form != "table":
         f, w, cin = _pad_in_channels(f, w, kernel, cin, cout)
-    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 else None
+    resident = _resident_form(cin, cout, kvol, half, form)
+    plan = _pair_plan(nbr, cin, cout) if form != "table" and n > 0 and not resident else None
     if form == "pairs" and plan is None:
         plan = getattr(nbr, "_link_pairs", None)
+    if resident and not RESIDENT_TILE_ORDER:
+        order = None
     flags = (1 if relu else 0) | (2 if affine else 0)
     if plan is not None:
         add = addend.detach().contiguous().to(f.dtype) if addend is not None else None

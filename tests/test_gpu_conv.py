@@ -576,3 +576,50 @@ def test_pair_plan_on_device_rejects_a_wrong_structural_claim():
     plan = elk._PairPlan(shuffled, True)
     with pytest.raises(L.LinkAmdError):
         plan.finalize()
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (16, 32), (32, 16)])
+def test_resident_weights_kernel_exact_and_split(cin, cout):
+    """Narrow layers (conv.hip: k_subm_conv_resident, every W_k in LDS): the plain forward on the exact f32 instruction and the
+    fused inference entry on the fp16-split products, against a float64 restatement -- LayerNorm and folded-affine
+    epilogues with addend + ReLU, a table with fewer taps than 27, rows beyond the fp16 range (exact fallback), and the
+    pair-list form on the same inputs."""
+    import link_amd as la
+    from link_amd import elk
+    torch.manual_seed(cin + cout)
+    coords = torch.from_numpy(lidar_like(30000, seed=9, stride=1))
+    n = coords.shape[0]
+    feats = torch.randn(n, cin, generator=torch.Generator().manual_seed(1))
+    feats[::113] *= 3e5                                 # beyond 2^15: those tiles take the exact instruction
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), 1)
+    nbr, _ = elk.neighbor_table_of(st, (3, 3, 3))
+    w = (torch.randn(27, cin, cout, generator=torch.Generator().manual_seed(2)) * 0.2).cuda()
+    assert elk._resident_form(cin, cout, 27, False, "auto")
+
+    def ref64(table, wk):
+        f64 = torch.cat([feats.double(), torch.zeros(1, cin, dtype=torch.float64)], 0)
+        idx = table.cpu().long()
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, n))
+        return torch.einsum("nkc,kcd->nd", f64[idx], wk.cpu().double())
+
+    ref = ref64(nbr, w)
+    plain = elk.subm_conv(st.F, w, nbr, None)           # exact f32 products
+    assert rel_err(plain.cpu().numpy(), ref.numpy()) < 2e-6
+    pairs = elk.subm_conv(st.F, w, nbr, None, form="pairs")
+    assert rel_err(pairs.cpu().numpy(), ref.numpy()) < 2e-6
+    # fused inference entry (fp16-split products): folded affine + addend + ReLU ...
+    sc, sh = (torch.rand(cout) + 0.5).cuda(), torch.randn(cout).cuda()
+    add = torch.randn(n, cout).cuda()
+    got = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 0.0, add, relu=True, affine=True)
+    want = torch.relu(add.cpu().double() + ref * sc.cpu().double() + sh.cpu().double())
+    assert rel_err(got.cpu().numpy(), want.numpy()) < 5e-6
+    # ... and LayerNorm (the LinK block's tail)
+    got = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 1e-6, add, relu=False)
+    want = add.cpu().double() + torch.nn.functional.layer_norm(ref, (cout,), sc.cpu().double(), sh.cpu().double(), 1e-6)
+    assert rel_err(got.cpu().numpy(), want.numpy()) < 2e-5
+    # a table with 3 taps (the backbone's extra_conv shape)
+    t3 = nbr[:, [4, 13, 22]].contiguous()
+    got3 = elk.subm_conv(st.F, w[:3].contiguous(), t3, None)
+    assert rel_err(got3.cpu().numpy(), ref64(t3, w[:3]).numpy()) < 2e-6
+    again = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 1e-6, add, relu=False)
+    assert torch.equal(again, got)
