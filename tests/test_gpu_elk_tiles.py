@@ -127,3 +127,38 @@ def test_tiles_plan_capacity_larger_than_frame_and_large_rows():
               blk.norm.weight, blk.norm.bias)
     got = plan.run(feats.cuda(), coords.cuda())
     assert rel_err(got.cpu().numpy(), ref) < TOL
+
+
+def test_tiles_randomized_against_the_four_kernel_form():
+    """60 random (frame shape, size, block edge, r, width, op) draws: the tile form against the four-kernel form of the same
+    layout (both inside the oracle's gate on every case the oracle tests above cover; here the point is the rare paths --
+    blocks ending exactly at tile / wave / workgroup boundaries, runs through several waves, tiles of one-voxel blocks)."""
+    import link_amd as la
+    g = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(60):
+        C = int(g.choice([16, 32, 64, 128]))
+        baseop = str(g.choice(["cos", "sin", "cos_x"]))
+        groups = int(g.choice([1, 2])) if baseop != "cos_x" else 1
+        r = int(g.choice([2, 3]))
+        s = int(g.choice([2, 3, 4, 7, 12]))
+        kind = int(g.integers(0, 3))
+        if kind == 0:                                   # solid box (+ noise): blocks of s^3 voxels
+            coords = _solid_and_sparse(int(g.integers(8, 20)) ** 3, int(g.integers(1, 2000)), seed=case)
+        elif kind == 1:                                 # LiDAR-like surface
+            coords = torch.from_numpy(lidar_like(int(g.integers(500, 30000)), seed=case, stride=1))
+        else:                                           # scattered
+            coords = s_uniform(int(g.integers(1, 20000)), grid=int(g.integers(30, 120)), seed=case)
+        n = coords.shape[0]
+        torch.manual_seed(case)
+        blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+        feats = torch.randn(n, C, generator=torch.Generator().manual_seed(case)).cuda()
+        tp, fp = _plan_pair(la, blk, n, C, baseop, groups, r, s, coords.cuda())
+        a = tp.run(feats, coords.cuda()).clone()
+        b = fp.run(feats, coords.cuda()).clone()
+        assert tp.blocks() == fp.blocks()
+        err = rel_err(a.cpu().numpy(), b.cpu().numpy())
+        worst = max(worst, err)
+        assert err < 1e-4, (case, C, baseop, groups, r, s, kind, n, err)
+        assert torch.equal(tp.run(feats, coords.cuda(), build_index=False), a), case
+    assert worst > 0.0                                  # the two forms do differ in the last bits (sanity of the comparison)
