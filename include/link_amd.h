@@ -525,6 +525,15 @@ int link_conv_centre_sum_amp(const void *feats, const void *wt, int32_t centre, 
                              int64_t contrib_rows, const int32_t *ext_start, const int32_t *ext_list, int64_t n, int32_t cin,
                              int32_t cout, const float *bias, const float *ln_w, const float *ln_b, float eps,
                              const void *addend, int32_t relu, void *out, int32_t io_dtype, void *stream);
+/* Narrow layers in the AMP form without a pair list (conv.hip: every W_k resident in LDS; cin, cout in {16, 32}, kvol <= 27):
+ * out = epilogue(sum_k feats[nbr[:, k]] . wt[k]^T) over the per-output neighbour table nbr i32[n, kvol] (as
+ * link_subm_conv_forward), rows / addend / out in io_dtype (LINK_IO_F16 or LINK_IO_BF16), wt = [kvol][cout][cin] in the
+ * row type (as link_conv_pairs_gemm_amp), fp32 accumulation over all offsets, statistics / affine in fp32.  ln_w NULL: the
+ * plain convolution; relu bit 0 ReLU, bit 1 "ln_w / ln_b are a per-channel affine" (folded BatchNorm), as
+ * link_subm_conv_ln_add_relu.  Replaces convolution_forward_cuda (pybind_cuda.cpp:19) under autocast for those widths. */
+int link_subm_conv_resident_amp(const void *feats, int32_t io_dtype, const int32_t *nbr, const void *wt, const int32_t *order,
+                                int64_t n, int32_t cin, int32_t cout, int32_t kvol, const float *ln_w, const float *ln_b,
+                                float eps, const void *addend, int32_t relu, void *out, void *stream);
 /* Weight gradient over the pair list (the weight half of convolution_backward_cuda, convolution_cuda.cu:167-278):
  * gw[k] = sum over the pairs p of offset k of feats[pair_in[p]]^T . gout[pair_out[p]]   (fp32 [kvol, cin, cout]).
  * One MFMA workgroup per 128-pair granule writes partial fp32[rows_pad/128, cin, cout]; the per-offset sums run in

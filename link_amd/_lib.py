@@ -167,6 +167,8 @@ SIGNATURES = {
     "link_pair_plan_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "link_subm_conv_resident_amp": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                            c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p]),
     "link_pair_plan_layout": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "link_conv_pairs_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,

@@ -575,6 +575,214 @@ static int launch_conv_resident(const float *feats, const int32_t *nbr, const fl
   return check_launch("link_subm_conv_forward");
 }
 
+// ---------------------------------------------------------------------------------------------
+// AMP form of the resident-weights kernel: rows AND weights are 16-bit (fp16 or bf16: the reference's
+// custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18), products on the 16-bit matrix cores with fp32 accumulation
+// over ALL offsets (the pair-list AMP form rounds each offset's product to the row type first, as the reference's half mm
+// does: this one is closer to the fp32 result), statistics / affine in fp32, 16-bit out.  wt = [kvol][cout][cin] in the row
+// type (what link_conv_pairs_gemm_amp takes): the LDS image is a padded copy, a gathered row piece is 8 bytes and goes to
+// the matrix core as it is -- no conversion in the offset loop.
+// ---------------------------------------------------------------------------------------------
+struct conv_epilogue_amp {
+  const float *ln_w, *ln_b;
+  const unsigned short *addend;
+  float eps;
+  int relu;
+};
+typedef short conv_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float conv_h2f(unsigned short v, bool bf) {
+  if (bf) return __uint_as_float((unsigned)v << 16);
+  return (float)__builtin_bit_cast(_Float16, v);
+}
+__device__ __forceinline__ unsigned short conv_f2h(float f, bool bf) {
+  if (bf) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  }
+  return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+
+template <int CI, int CO>
+struct conv_amp_cfg {
+  static constexpr int TI = CI / 16, TO = CO / 16, KV = 27, NW = 8;
+  static constexpr int LDH = CI + 8;                   // halves per row of the image
+  static constexpr int W_BYTES = KV * CO * LDH * 2;
+  static constexpr int LDS_BYTES = W_BYTES + NW * (KV + 1) * 16 * 4;
+};
+
+template <int CI, int CO, bool BF>
+__global__ void __launch_bounds__(512) k_subm_conv_resident_amp(
+    const unsigned short *__restrict__ feats, const int32_t *__restrict__ nbr, const unsigned short *__restrict__ wt,
+    const int32_t *__restrict__ order, int64_t n, int kvol, unsigned short *__restrict__ out, conv_epilogue_amp ep) {
+  using K = conv_amp_cfg<CI, CO>;
+  constexpr int TI = K::TI, TO = K::TO, LDH = K::LDH;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short *wh = reinterpret_cast<unsigned short *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  int32_t *my_nb = reinterpret_cast<int32_t *>(smem_raw + K::W_BYTES) + wave * ((K::KV + 1) * 16);
+  for (int e = tid * 4; e < kvol * CO * CI; e += 512 * 4) {              // [k][co][ci] -> rows padded to LDH
+    const uint2 v = *reinterpret_cast<const uint2 *>(&wt[e]);
+    const int rowi = e / CI, ci = e - rowi * CI;
+    *reinterpret_cast<uint2 *>(&wh[rowi * LDH + ci]) = v;
+  }
+  __syncthreads();
+  const int64_t tiles = (n + 15) / 16;
+  const int64_t waves_total = (int64_t)gridDim.x * K::NW;
+  for (int64_t tile = (int64_t)blockIdx.x * K::NW + wave; tile < tiles; tile += waves_total) {
+    const int64_t q = tile * 16 + li;
+    const int64_t v = (q < n) ? (order ? (int64_t)order[q] : q) : -1;
+    const int64_t vc = v >= 0 ? v : 0;
+    int idr[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int k = 4 * j + g;
+      idr[j] = nbr[vc * kvol + (k < kvol ? k : 0)];
+    }
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int k = 4 * j + g;
+      const int id = (k < kvol && v >= 0) ? idr[j] : -1;
+      my_nb[k * 16 + li] = id;
+      const unsigned long long bal = __ballot(id >= 0);
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++)
+        if ((bal >> (16 * gg)) & 0xFFFFull) mask |= 1u << (4 * j + gg);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    floatx4 acc[TO], acc2[TO];
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) acc[tp] = acc2[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    auto next_off = [&]() { const int kk = mask ? (__ffs(mask) - 1) : -1; mask &= mask - 1; return kk; };
+    constexpr int BATCH = 16 / TI;
+    while (mask) {
+      int ks[BATCH], ids[BATCH];
+      uint2 fs[BATCH][TI];
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int kk = next_off();
+        ks[i] = kk < 0 ? 0 : kk;
+        const int id = my_nb[ks[i] * 16 + li];
+        ids[i] = kk < 0 ? -1 : id;
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int64_t row = ids[i] >= 0 ? ids[i] : 0;
+#pragma unroll
+        for (int tt = 0; tt < TI; tt++) fs[i][tt] = *reinterpret_cast<const uint2 *>(&feats[row * CI + 16 * tt + 4 * g]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const bool has = ids[i] >= 0;
+        const unsigned short *wk = wh + (size_t)ks[i] * (CO * LDH);
+#pragma unroll
+        for (int tt = 0; tt < TI; tt++) {
+          uint2 b = fs[i][tt];
+          b.x = has ? b.x : 0u; b.y = has ? b.y : 0u;
+#pragma unroll
+          for (int tp = 0; tp < TO; tp++) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(&wk[(16 * tp + li) * LDH + 16 * tt + 4 * g]);
+            floatx4 &ac = (i & 1) ? acc2[tp] : acc[tp];
+            if constexpr (BF) ac = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(conv_s4, a), __builtin_bit_cast(conv_s4, b), ac, 0, 0, 0);
+            else ac = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(conv_h4, a), __builtin_bit_cast(conv_h4, b), ac, 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int tp = 0; tp < TO; tp++) acc[tp] += acc2[tp];
+    // store phase: as conv_finish, 16-bit addend / out
+    float mean = 0.f, rstd = 1.f;
+    if (ep.ln_w && !(ep.relu & 2)) {
+      float sm = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) sm += (acc[tp][0] + acc[tp][1]) + (acc[tp][2] + acc[tp][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      mean = sm * (1.0f / CO);
+      float qv = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float d = acc[tp][r] - mean;
+          qv += d * d;
+        }
+      qv += __shfl_xor(qv, 16, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      rstd = 1.0f / sqrtf(qv * (1.0f / CO) + ep.eps);
+    }
+    if (v >= 0) {
+#pragma unroll
+      for (int tp = 0; tp < TO; tp++) {
+        const int ch = 16 * tp + 4 * g;
+        float o[4] = {acc[tp][0], acc[tp][1], acc[tp][2], acc[tp][3]};
+        if (ep.ln_w) {
+          const float4 lw = *reinterpret_cast<const float4 *>(&ep.ln_w[ch]);
+          const float4 lb = *reinterpret_cast<const float4 *>(&ep.ln_b[ch]);
+          o[0] = (o[0] - mean) * rstd * lw.x + lb.x; o[1] = (o[1] - mean) * rstd * lw.y + lb.y;
+          o[2] = (o[2] - mean) * rstd * lw.z + lb.z; o[3] = (o[3] - mean) * rstd * lw.w + lb.w;
+        }
+        if (ep.addend) {
+          const uint2 a4 = *reinterpret_cast<const uint2 *>(&ep.addend[v * CO + ch]);
+          o[0] += conv_h2f((unsigned short)(a4.x & 0xFFFFu), BF); o[1] += conv_h2f((unsigned short)(a4.x >> 16), BF);
+          o[2] += conv_h2f((unsigned short)(a4.y & 0xFFFFu), BF); o[3] += conv_h2f((unsigned short)(a4.y >> 16), BF);
+        }
+        if (ep.relu & 1) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        uint2 pk;
+        pk.x = (unsigned)conv_f2h(o[0], BF) | ((unsigned)conv_f2h(o[1], BF) << 16);
+        pk.y = (unsigned)conv_f2h(o[2], BF) | ((unsigned)conv_f2h(o[3], BF) << 16);
+        *reinterpret_cast<uint2 *>(&out[v * CO + ch]) = pk;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int CI, int CO>
+static int launch_conv_resident_amp(const void *feats, int io, const int32_t *nbr, const void *wt, const int32_t *order, int64_t n,
+                                    int kvol, void *out, const conv_epilogue_amp &ep, hipStream_t st) {
+  using K = conv_amp_cfg<CI, CO>;
+  const int64_t tiles = (n + 15) / 16;
+  const int per_cu = (160 * 1024) / K::LDS_BYTES > 4 ? 4 : (160 * 1024) / K::LDS_BYTES;
+  int64_t wgs = (tiles + K::NW - 1) / K::NW;
+  if (wgs > 256 * per_cu) wgs = 256 * per_cu;
+  const unsigned short *f = static_cast<const unsigned short *>(feats), *w16 = static_cast<const unsigned short *>(wt);
+  unsigned short *o = static_cast<unsigned short *>(out);
+  if (io == LINK_IO_BF16) {
+    if (K::LDS_BYTES > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_resident_amp<CI, CO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    hipLaunchKernelGGL((k_subm_conv_resident_amp<CI, CO, true>), dim3((unsigned)wgs), dim3(512), K::LDS_BYTES, st, f, nbr, w16, order, n, kvol, o, ep);
+  } else {
+    if (K::LDS_BYTES > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_subm_conv_resident_amp<CI, CO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    hipLaunchKernelGGL((k_subm_conv_resident_amp<CI, CO, false>), dim3((unsigned)wgs), dim3(512), K::LDS_BYTES, st, f, nbr, w16, order, n, kvol, o, ep);
+  }
+  return check_launch("link_subm_conv_resident_amp");
+}
+
+extern "C" int link_subm_conv_resident_amp(const void *feats, int32_t io_dtype, const int32_t *nbr, const void *wt,
+                                           const int32_t *order, int64_t n, int32_t cin, int32_t cout, int32_t kvol,
+                                           const float *ln_w, const float *ln_b, float eps, const void *addend, int32_t relu,
+                                           void *out, void *stream) {
+  if (io_dtype != LINK_IO_F16 && io_dtype != LINK_IO_BF16) return LINK_ERR_ARG;
+  if (n < 0 || kvol <= 0 || kvol > 27 || (ln_w == nullptr) != (ln_b == nullptr)) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!feats || !nbr || !wt || !out) return LINK_ERR_ARG;
+  const conv_epilogue_amp ep = {ln_w, ln_b, static_cast<const unsigned short *>(addend), eps, relu & 3};
+  hipStream_t st = S(stream);
+  if (cin == 16 && cout == 16) return launch_conv_resident_amp<16, 16>(feats, io_dtype, nbr, wt, order, n, kvol, out, ep, st);
+  if (cin == 32 && cout == 32) return launch_conv_resident_amp<32, 32>(feats, io_dtype, nbr, wt, order, n, kvol, out, ep, st);
+  if (cin == 16 && cout == 32) return launch_conv_resident_amp<16, 32>(feats, io_dtype, nbr, wt, order, n, kvol, out, ep, st);
+  if (cin == 32 && cout == 16) return launch_conv_resident_amp<32, 16>(feats, io_dtype, nbr, wt, order, n, kvol, out, ep, st);
+  return LINK_ERR_ARG;
+}
+
 // any Cin / Cout <= 256: one wave per output voxel, lanes = output channels (no MFMA; small widths)
 template <int CPL>
 __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restrict__ feats,

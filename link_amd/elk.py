@@ -1162,7 +1162,23 @@ _RESIDENT_SHAPES = ((16, 16), (32, 32), (16, 32), (32, 16))
 
 
 def _resident_form(cin: int, cout: int, kvol: int, half: bool, form: str) -> bool:
-    return RESIDENT_FORM and form == "auto" and not half and kvol <= 27 and (cin, cout) in _RESIDENT_SHAPES
+    """fp32 rows: link_subm_conv_forward / _ln_add_relu take these shapes to the resident-weights kernel on their own;
+    16-bit rows: link_subm_conv_resident_amp (weights rounded to the row type: the AMP contract, AMP_MFMA)."""
+    return (RESIDENT_FORM and form == "auto" and kvol <= 27 and (cin, cout) in _RESIDENT_SHAPES and (not half or AMP_MFMA))
+
+
+def _conv_resident_amp(f, w, w_key, nbr, order, cin, cout, ln=None, addend=None, flags=0):
+    """16-bit rows through the AMP resident-weights kernel: out in the row type."""
+    n, kvol = nbr.shape
+    wt = _amp_weights(w_key if w_key is not None and w_key.shape == w.shape else w, f.dtype)
+    out = torch.empty((n, cout), dtype=f.dtype, device=f.device)
+    lw, lb, eps = ln if ln is not None else (None, None, 0.0)
+    L.check(L.lib().link_subm_conv_resident_amp(
+        f.data_ptr(), _IO_DTYPES[f.dtype], nbr.contiguous().data_ptr(), wt.data_ptr(),
+        order.data_ptr() if order is not None else None, n, cin, cout, kvol,
+        lw.data_ptr() if lw is not None else None, lb.data_ptr() if lb is not None else None, float(eps),
+        addend.data_ptr() if addend is not None else None, int(flags), out.data_ptr(), _st()), "link_subm_conv_resident_amp")
+    return out
 
 
 def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
@@ -1195,6 +1211,8 @@ def subm_conv(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.Tensor,
             raise L.LinkAmdError(f"subm_conv(form='pairs'): widths {cin}->{cout} not supported by the pair-list kernels")
     if resident and not RESIDENT_TILE_ORDER:
         order = None
+    if resident and half and n > 0:
+        return _conv_resident_amp(f, w, kernel, nbr, order, cin, cout)
     if plan is not None:
         return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device), w_key=kernel)
     f = f.float()                                      # the table kernel is fp32: half rows are widened here
@@ -1233,6 +1251,9 @@ def subm_conv_ln_add_relu(feats: torch.Tensor, kernel: torch.Tensor, nbr: torch.
     if resident and not RESIDENT_TILE_ORDER:
         order = None
     flags = (1 if relu else 0) | (2 if affine else 0)
+    if resident and half and n > 0:
+        add = addend.detach().contiguous().to(f.dtype) if addend is not None else None
+        return _conv_resident_amp(f, w, kernel, nbr, order, cin, cout, ln=(lw, lb, eps), addend=add, flags=flags)
     if plan is not None:
         add = addend.detach().contiguous().to(f.dtype) if addend is not None else None
         return _conv_pairs(plan, f, w, cin, cout, torch.empty((n, cout), dtype=f.dtype, device=feats.device),

@@ -623,3 +623,37 @@ def test_resident_weights_kernel_exact_and_split(cin, cout):
     assert rel_err(got3.cpu().numpy(), ref64(t3, w[:3]).numpy()) < 2e-6
     again = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 1e-6, add, relu=False)
     assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (16, 32)])
+def test_resident_weights_kernel_half_rows(cin, cout, dtype):
+    """AMP form (16-bit rows and weights, fp32 accumulation): against the float64 result on the SAME rounded rows and
+    weights (accumulation error only), and against the pair-list AMP form (which rounds every offset's product first)."""
+    import link_amd as la
+    from link_amd import elk
+    torch.manual_seed(cin * 3 + cout)
+    coords = torch.from_numpy(lidar_like(20000, seed=10, stride=1))
+    n = coords.shape[0]
+    feats = torch.randn(n, cin, generator=torch.Generator().manual_seed(1)).to(dtype)
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), 1)
+    nbr, _ = elk.neighbor_table_of(st, (3, 3, 3))
+    w = (torch.randn(27, cin, cout, generator=torch.Generator().manual_seed(2)) * 0.2).cuda()
+    wr = w.to(dtype).double().cpu()                    # the AMP contract rounds the kernel with the features
+    f64 = torch.cat([feats.double(), torch.zeros(1, cin, dtype=torch.float64)], 0)
+    idx = nbr.cpu().long()
+    idx = torch.where(idx >= 0, idx, torch.full_like(idx, n))
+    ref = torch.einsum("nkc,kcd->nd", f64[idx], wr)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    got = elk.subm_conv(st.F, w, nbr, None)
+    assert got.dtype == dtype and rel_err(got.float().cpu().numpy(), ref.numpy()) < ulp
+    sc, sh = (torch.rand(cout) + 0.5).cuda(), torch.randn(cout).cuda()
+    add = torch.randn(n, cout).to(dtype).cuda()
+    got = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 0.0, add, relu=True, affine=True)
+    want = torch.relu(add.double().cpu() + ref * sc.cpu().double() + sh.cpu().double())
+    assert got.dtype == dtype and rel_err(got.float().cpu().numpy(), want.numpy()) < ulp
+    pair = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 0.0, add, relu=True, affine=True, form="pairs")
+    assert rel_err(got.float().cpu().numpy(), pair.float().cpu().numpy()) < 4 * ulp
+    got_ln = elk.subm_conv_ln_add_relu(st.F, w, nbr, None, sc, sh, 1e-6, add, relu=False)
+    want = add.double().cpu() + torch.nn.functional.layer_norm(ref, (cout,), sc.cpu().double(), sh.cpu().double(), 1e-6)
+    assert rel_err(got_ln.float().cpu().numpy(), want.numpy()) < 2 * ulp
