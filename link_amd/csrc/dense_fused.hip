@@ -33,6 +33,8 @@ int dc_tiles_modsum(const link_dc_buffers_t *b, const link_dc_grid_t *g, const l
                 const float *, const float *, const link_elk_desc_t &, const link_dc_grid_t &, int64_t, void *,            \
                 hipStream_t);                                                                                              \
   int run_gather_demod(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, hipStream_t); \
+  int run_gather_demod_cells(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t,          \
+                             hipStream_t);                                                                                 \
   }
 DC_DECL_IO(dcio_f16)
 DC_DECL_IO(dcio_bf16)
@@ -126,11 +128,18 @@ extern "C" int link_dc_demod(const float *A, const float *fin, const int32_t *co
 
 extern "C" int link_dc_gather_demod(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d,
                                     int64_t n, void *stream) {
-  if (dc_common_ok(b, g, d, n) != LINK_OK || d->c != 64 || (d->r != 2 && d->r != 3)) return LINK_ERR_ARG;
+  if (dc_common_ok(b, g, d, n) != LINK_OK || !dc_width_ok(d->c) || (d->r != 2 && d->r != 3)) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   if (!b->S || !b->cell_n || !b->slots || !b->w_pos || !b->ln_w || !b->ln_b || !b->out || (d->op == LINK_OP_COSX && !b->fin))
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
+  if (d->c != 64) {                                    // cells form (dense_gather_cells_impl.h): C = 16 / 32 / 128
+    switch (b->io_dtype) {
+      case 1: return dcio_f16::run_gather_demod_cells(b, *g, *d, n, st);
+      case 2: return dcio_bf16::run_gather_demod_cells(b, *g, *d, n, st);
+      default: return dcio_f32::run_gather_demod_cells(b, *g, *d, n, st);
+    }
+  }
   switch (b->io_dtype) {
     case 1: return dcio_f16::run_gather_demod(b, *g, *d, n, st);
     case 2: return dcio_bf16::run_gather_demod(b, *g, *d, n, st);
