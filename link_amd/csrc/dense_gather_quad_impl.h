@@ -18,6 +18,10 @@
 // Lane q of a quad holds the 16-byte pieces q, q+4, q+8, q+12 of a row (channels 16 j + 4 q + e): pieces p and p + 8
 // share theta, so a lane evaluates 8 sincos per voxel.
 #pragma once
+#ifndef DC_K2_MAP
+#define DC_K2_MAP 1      /* tile enumeration by y-halves (0: ty fastest over the whole grid): FETCH_SIZE of the kernel 27.2 -> 23.9 MB
+                          (x 2: 54.4 -> 47.9 MB from the memory side) on cfg2, same time */
+#endif
 
 template <int OP, int R>
 struct dc_k2q_cfg {
@@ -78,9 +82,21 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
   if (L >= nwg) return;
   int t = L;
   const int zseg = t % zsplit; t /= zsplit;
+#if DC_K2_MAP
+  // tiles of one batch item enumerated y-half by y-half: a contiguous range of L (what one XCD runs) is then ~2.5 x 5 tiles
+  // instead of ~1.25 x 10 -- fewer halo rows fetched into two L2s
+  const int per_b = txn * tyn;
+  const int b = t / per_b;
+  int tt2 = t - b * per_b;
+  const int H = (tyn + 1) >> 1;
+  int tx, ty;
+  if (tt2 < txn * H) { tx = tt2 / H; ty = tt2 - tx * H; }
+  else { tt2 -= txn * H; const int H2 = tyn - H; tx = tt2 / H2; ty = H + tt2 - tx * H2; }
+#else
   const int ty = t % tyn; t /= tyn;
   const int tx = t % txn;
   const int b = t / txn;
+#endif
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
   const int PDx = g.pdim[0], PDy = g.pdim[1], PDz = g.pdim[2];
   const int x0 = tx * TX, y0 = ty * TY;
