@@ -175,6 +175,9 @@ int link_neighbor_map(const int32_t *blk_coords, const int32_t *cell_blk, const 
  * zero-initialised (first row wins for duplicates), then look up.  Rows outside the grid -> status. */
 int link_cell_table_build(const int32_t *rows, int64_t m, const link_grid_t *grid, int32_t *cell_blk,
                           int32_t *hdr, void *stream);
+/* ... and back: zero the cells link_cell_table_build wrote for the same rows (m scattered stores), so that a table kept
+ * between calls is all zero again without a memset over every cell of a sparse grid. */
+int link_cell_table_clear(const int32_t *rows, int64_t m, const link_grid_t *grid, int32_t *cell_blk, void *stream);
 
 /* Indexed block mean (spvoxelize forward, utils.py:52): out[b] = sum_{i in block b, ascending i}
  * in[i]/counts[b].  Deterministic, no atomics; rows [0,M) of out[.,c] written.  `m_cap` = rows

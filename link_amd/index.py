@@ -33,6 +33,13 @@ class _Workspace:
         self.cell_counts = None
         self.scratch = None
 
+    def cell_table(self, v: int) -> torch.Tensor:
+        """int32[>= v], all zero on entry of every user (each clears what it wrote: link_cell_table_clear)."""
+        t = self.__dict__.get("_cell_table")
+        if t is None or t.numel() < v:
+            t = self._cell_table = torch.zeros(max(v, 1 << 16), dtype=torch.int32, device=self.device)
+        return t
+
     def ensure(self, n: int, v: int):
         if self.cell_counts is None or self.cell_counts.numel() < v:
             self.cell_counts = torch.zeros(max(v, 1 << 16), dtype=torch.int32, device=self.device)
@@ -212,10 +219,14 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, st
         raise GridTooLarge(str(e))
     if grid.cells > MAX_CELLS:
         raise GridTooLarge(f"dense block grid would need {grid.cells} cells")
-    table = torch.zeros(grid.cells, dtype=torch.int32, device=dev)
+    # the cell table lives in the (device, stream) workspace and is kept all zero between calls: built by m scattered
+    # writes, undone by m scattered zeros -- not a memset over every cell of a sparse grid per call
+    table = _workspace(dev).cell_table(grid.cells)
     st = L.current_stream_handle()
     L.check(L.lib().link_cell_table_build(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), None,
                                           st), "link_cell_table_build")
     L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
                                       int(step), 1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
+    L.check(L.lib().link_cell_table_clear(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), st),
+            "link_cell_table_clear")
     return nbr
