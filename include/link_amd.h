@@ -473,6 +473,16 @@ int link_conv_pairs_sum(const float *contrib, const int32_t *ext_start, const in
 int32_t link_conv_out_candidate_count(const int32_t *kernel, const int32_t *stride);
 int link_conv_out_candidates(const int32_t *indices, int64_t n, const int32_t *kernel, const int32_t *stride,
                              const int32_t *padding, const int32_t *out_shape, int32_t *cand, void *stream);
+/* Gather table of such a convolution straight from the (b, z, y, x) rows: link_conv_site_table scatters input row + 1 into a
+ * table over (batch, in_shape) that the caller keeps all zero between uses (clear != 0 undoes the scatter of the same rows:
+ * no memset over a sparse grid); link_conv_gather_table then writes table i32[m, taps] = the input row at
+ * out * stride - padding + tap for the taps (a, b, c) in row-major order over `kernel` (each 1..3), -1 where no site.
+ * batch * prod(in_shape) < 2^31. */
+int link_conv_site_table(const int32_t *indices, int64_t n, const int32_t *in_shape, int32_t batch, int32_t *table,
+                         int32_t clear, void *stream);
+int link_conv_gather_table(const int32_t *out_indices, int64_t m, const int32_t *kernel, const int32_t *stride,
+                           const int32_t *padding, const int32_t *in_shape, int32_t batch, const int32_t *site_table,
+                           int32_t *table, void *stream);
 /* Building the pair plan from a per-output neighbour table nbr i32[n, kvol] (-1 absent), kvol <= 64 -- the device
  * half of what nn/functional/conv.py:109-122 does with nonzero / sum on the host side.  G = ceil(n / 256) workgroups:
  *   link_pair_plan_count   wg_counts i32[G, kvol + 1]: per workgroup, pairs of every offset, and (last column) rows

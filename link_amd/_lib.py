@@ -112,6 +112,9 @@ SIGNATURES = {
     "link_neighbor_map": (c_int, [c_void_p, c_void_p, POINTER(LinkGrid), c_void_p, c_int64, c_int32,
                                   c_int32, c_int32, c_void_p, c_void_p]),
     "link_cell_table_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_void_p]),
+    "link_conv_site_table": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    "link_conv_gather_table": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                       c_void_p]),
     "link_cell_table_clear": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p]),
     "link_block_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p]),

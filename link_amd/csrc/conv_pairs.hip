@@ -953,6 +953,84 @@ extern "C" int link_conv_out_candidates(const int32_t *indices, int64_t n, const
   return check_launch("link_conv_out_candidates");
 }
 
+// ---------------------------------------------------------------------------------------------
+// gather table of a site-creating convolution, straight from the (b, z, y, x) rows
+// ---------------------------------------------------------------------------------------------
+// site table: cell (b, z, y, x) of the input shape -> input row + 1 (0 = no site); the smallest row wins a duplicate.
+// CLEAR: undo it (the table lives in the caller's workspace and stays all zero between uses).
+template <bool CLEAR>
+__global__ void __launch_bounds__(256) k_conv_site_table(const int4 *__restrict__ ind, int64_t n, int Z, int Y, int X, int B,
+                                                         unsigned int *__restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 r = ind[i];                               // (b, z, y, x)
+  if ((unsigned)r.x >= (unsigned)B || (unsigned)r.y >= (unsigned)Z || (unsigned)r.z >= (unsigned)Y || (unsigned)r.w >= (unsigned)X) return;
+  const int64_t cell = (((int64_t)r.x * Z + r.y) * Y + r.z) * X + r.w;
+  if (CLEAR) { table[cell] = 0u; return; }
+  const unsigned v = (unsigned)i + 1u;
+  unsigned old = atomicCAS(&table[cell], 0u, v);
+  while (old != 0u && old > v) {
+    const unsigned prev = atomicCAS(&table[cell], old, v);
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+// table[j, t] = input row at out[j] * stride - padding + tap_t (per axis; taps (a, b, c) row-major over the kernel), -1 absent
+__global__ void __launch_bounds__(256) k_conv_gather_table(const int4 *__restrict__ out_ind, int64_t m, conv_geom g, int Z, int Y,
+                                                           int X, int B, const unsigned int *__restrict__ site,
+                                                           int32_t *__restrict__ table) {
+  const int ntap = g.k[0] * g.k[1] * g.k[2];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m * ntap) return;
+  const int64_t j = t / ntap;
+  int tap = (int)(t - j * ntap);
+  const int c = tap % g.k[2]; tap /= g.k[2];
+  const int b = tap % g.k[1];
+  const int a = tap / g.k[1];
+  const int4 o = out_ind[j];                           // (b, z, y, x)
+  const int z = o.y * g.s[0] - g.p[0] + a, y = o.z * g.s[1] - g.p[1] + b, x = o.w * g.s[2] - g.p[2] + c;
+  int32_t v = -1;
+  if ((unsigned)o.x < (unsigned)B && (unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)x < (unsigned)X)
+    v = (int32_t)site[(((int64_t)o.x * Z + z) * Y + y) * X + x] - 1;
+  table[t] = v;
+}
+
+extern "C" int link_conv_site_table(const int32_t *indices, int64_t n, const int32_t *in_shape, int32_t batch, int32_t *table,
+                                    int32_t clear, void *stream) {
+  if (n < 0 || !in_shape || batch <= 0) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!indices || !table || in_shape[0] <= 0 || in_shape[1] <= 0 || in_shape[2] <= 0) return LINK_ERR_ARG;
+  if ((int64_t)batch * in_shape[0] * in_shape[1] * in_shape[2] >= (1LL << 31)) return LINK_ERR_ARG;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (clear)
+    hipLaunchKernelGGL(k_conv_site_table<true>, grid, dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(indices), n,
+                       in_shape[0], in_shape[1], in_shape[2], batch, reinterpret_cast<unsigned int *>(table));
+  else
+    hipLaunchKernelGGL(k_conv_site_table<false>, grid, dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(indices), n,
+                       in_shape[0], in_shape[1], in_shape[2], batch, reinterpret_cast<unsigned int *>(table));
+  return check_launch("link_conv_site_table");
+}
+
+extern "C" int link_conv_gather_table(const int32_t *out_indices, int64_t m, const int32_t *kernel, const int32_t *stride,
+                                      const int32_t *padding, const int32_t *in_shape, int32_t batch, const int32_t *site_table,
+                                      int32_t *table, void *stream) {
+  if (m < 0 || !kernel || !stride || !padding || !in_shape || batch <= 0) return LINK_ERR_ARG;
+  if (m == 0) return LINK_OK;
+  if (!out_indices || !site_table || !table) return LINK_ERR_ARG;
+  conv_geom g = {};
+  for (int a = 0; a < 3; a++) {
+    if (kernel[a] < 1 || kernel[a] > 3 || stride[a] < 1) return LINK_ERR_ARG;
+    g.k[a] = kernel[a]; g.s[a] = stride[a]; g.p[a] = padding[a];
+  }
+  if ((int64_t)batch * in_shape[0] * in_shape[1] * in_shape[2] >= (1LL << 31)) return LINK_ERR_ARG;
+  const int ntap = g.k[0] * g.k[1] * g.k[2];
+  hipLaunchKernelGGL(k_conv_gather_table, dim3((unsigned)((m * ntap + 255) / 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const int4 *>(out_indices), m, g, in_shape[0], in_shape[1], in_shape[2], batch,
+                     reinterpret_cast<const unsigned int *>(site_table), table);
+  return check_launch("link_conv_gather_table");
+}
+
 extern "C" int32_t link_conv_out_candidate_count(const int32_t *kernel, const int32_t *stride) {
   int ncomb = 1;
   for (int d = 0; d < 3; d++) ncomb *= (kernel[d] == 3 && stride[d] == 2) ? 2 : kernel[d];

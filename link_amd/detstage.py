@@ -45,6 +45,14 @@ def _replace_feature(sct, feats):
     return out
 
 
+def _plan_ahead(nbr, c: int, dtype) -> None:
+    """Build the stage's pair plan ahead of its convolutions -- unless they run the resident-weights kernel, which reads the
+    table itself (16 / 32 channels)."""
+    from .elk import _resident_form
+    if not _resident_form(c, c, nbr.shape[1], dtype != torch.float32, "auto"):
+        _pair_plan(nbr, c, c)
+
+
 def _site_table(sct):
     """(neighbour table int32[N,27] in link_amd's offset order, spatial tile order) of the tensor's active sites:
     the same cached table the TSELKBlock's local_mix convolution uses (all submanifold convolutions of a stage
@@ -292,14 +300,27 @@ class SparseConv3d(nn.Module):
         sites, hdr = unique_cells(cand[: n * ncomb], ((0, 0, 0, 0), hi))
         m = int(hdr[L.HDR_M].item())                     # the one host round trip of this map
         out_ind = sites[:m]
-        # table[j, t] = input row at out_ind[j] * s - p + tap_t (dense cell table of the input sites).  A 3-wide window
-        # per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its tap is the centre
-        rows = out_ind[:, [3, 2, 1, 0]] * mul_t + add_t                                    # (x, y, z, b) window centres
-        in_xyzb = ind[:, [3, 2, 1, 0]].contiguous()
+        # table[j, t] = input row at out_ind[j] * s - p + tap_t, straight from the (b, z, y, x) rows: the input sites go into the
+        # workspace's cell table (kept all zero between uses), one kernel writes the table, the sites are taken out again
         shp = [int(v) for v in sct.spatial_shape]
-        full = foreign_neighbor_map(rows.contiguous(), 3, table_rows=in_xyzb,
-                                    bounds=((0, 0, 0, 0), (shp[2] - 1, shp[1] - 1, shp[0] - 1, int(sct.batch_size) - 1)))
-        table = full[:, sel_t].contiguous()
+        from .index import _workspace
+        cells = int(sct.batch_size) * shp[0] * shp[1] * shp[2]
+        out_ind = out_ind.contiguous()
+        if cells < 2 ** 31:
+            site = _workspace(dev).cell_table(cells)
+            shp_a = i3(*shp)
+            table = torch.empty((m, len(self._taps())), dtype=torch.int32, device=dev)
+            L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 0, stream), "link_conv_site_table")
+            L.check(lib.link_conv_gather_table(out_ind.data_ptr(), m, ka, sa, pa, shp_a, int(sct.batch_size), site.data_ptr(),
+                                               table.data_ptr(), stream), "link_conv_gather_table")
+            L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 1, stream), "link_conv_site_table")
+        else:
+            # A 3-wide window per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its tap is the centre
+            rows = out_ind[:, [3, 2, 1, 0]] * mul_t + add_t                                    # (x, y, z, b) window centres
+            in_xyzb = ind[:, [3, 2, 1, 0]].contiguous()
+            full = foreign_neighbor_map(rows.contiguous(), 3, table_rows=in_xyzb,
+                                        bounds=((0, 0, 0, 0), (shp[2] - 1, shp[1] - 1, shp[0] - 1, int(sct.batch_size) - 1)))
+            table = full[:, sel_t].contiguous()
         table._link_subm = False                         # structural mark for the pair plan: a gather table between two site sets
         back = None                                      # transposed direction: built on the first backward
         hit = sct.indice_dict[key] = [out_ind.contiguous(), table, back, sct.indices]
@@ -428,7 +449,7 @@ class SpMiddleResNetFHDELKv3(nn.Module):
             if maps is not None:
                 with maps:                                             # scale 1: site table + its pair plan
                     nbr, order = _site_table(x)
-                    _pair_plan(nbr, 16, 16)
+                    _plan_ahead(nbr, 16, x.features.dtype)
             nbr, order = _site_table(x)
             sc, sh = fold_batchnorm(self.conv_input[1], self.conv_input[0].bias)
             x = _replace_feature(x, subm_conv_ln_add_relu(x.features, self.conv_input[0].kernel_kio(), nbr, order, sc, sh,
@@ -445,7 +466,7 @@ class SpMiddleResNetFHDELKv3(nn.Module):
                         if down[0].form != "table":
                             _pair_plan(table, down[0].in_channels, down[0].out_channels)
                         nbr, _ = _site_table(down[0]._out_tensor(x, out_ind, None))
-                        _pair_plan(nbr, down[0].out_channels, down[0].out_channels)
+                        _plan_ahead(nbr, down[0].out_channels, x.features.dtype)
                 x = down[0].fused(x, down[1], relu=True) if fused else _seq_conv_bn(down, x, True)
             parts = [getattr(self, f"{n}{k}{s}") for n, s in (("conv", ""), ("conv", "_tail"), ("elk", ""), ("elk", "_tail"))]
             if fused:
