@@ -508,6 +508,14 @@ int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, int32_t ski
  * (nn/functional/conv.py:103-122, `nbsizes.cpu()`). */
 int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
                           int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_k, int32_t *hdr, void *stream);
+/* All three steps in one call, for capacity-sized lists (what link_amd's device-laid-out plans use): the fill pass computes
+ * ext_start i32[n + 1] itself (wg_ext i32[ceil(n/256)] scratch: rows of earlier workgroups) and the layout pass writes -1
+ * into the unused tail of every offset's last granule, so neither a prefix-sum pass nor a fill of pair_in / pair_out
+ * (i32[gran_cap * 128] each, otherwise uninitialised) is needed.  ext_list i32[>= n * kvol]. */
+int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap, int32_t *wg_counts,
+                         int32_t *row_info, int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_ext,
+                         int32_t *wg_k, int32_t *hdr, int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,
+                         int32_t *ext_list, void *stream);
 /* The same three entries with fp16 / bf16 feature rows at the boundary (io_dtype = LINK_IO_F32 / F16 / BF16: feats, addend
  * and out rows in that type; weights, contribution rows, statistics and accumulation fp32) -- the reference's AMP
  * contract for its convolution (custom_fwd(cast_inputs=torch.half), nn/functional/conv.py:18). */

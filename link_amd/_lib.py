@@ -173,6 +173,7 @@ SIGNATURES = {
                                     c_void_p]),
     "link_subm_conv_resident_amp": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                             c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p]),
+    "link_pair_plan_build": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int64] + [c_void_p] * 13),
     "link_pair_plan_layout": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "link_conv_pairs_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,

@@ -740,7 +740,8 @@ __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ n
                                                    const int32_t *__restrict__ wg_base, const int32_t *__restrict__ ext_start,
                                                    int32_t *__restrict__ wg_counts, int32_t *__restrict__ row_info,
                                                    int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out,
-                                                   int32_t *__restrict__ ext_list) {
+                                                   int32_t *__restrict__ ext_list, const int32_t *__restrict__ wg_ext = nullptr,
+                                                   int32_t *__restrict__ ext_start_out = nullptr) {
   extern __shared__ int32_t smem[];
   int32_t *tile = smem;                                // [256][kvol]
   int32_t *wcnt = smem + 256 * kvol;                   // [4][kvol + 1]: pairs per wave and offset (+ identity misses)
@@ -783,7 +784,26 @@ __global__ void __launch_bounds__(256) k_pair_plan(const int32_t *__restrict__ n
   }
   // pass B: contribution row = first row of the offset's granules + pairs of earlier workgroups + earlier waves of
   // this workgroup + earlier lanes of this wave: deterministic placement, voxel ascending inside an offset
-  int q = live ? ext_start[row0 + r] : 0;
+  int q;
+  if (wg_ext) {
+    // the CSR start of every row without a separate prefix-sum pass: rows of earlier workgroups (wg_ext, from the layout
+    // kernel) + the rows before this one in the workgroup (wave prefix + the earlier waves' totals through LDS)
+    int incl = live ? nvalid : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    __shared__ int s_wave_tot[4];
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    int before_w = 0;
+    for (int w = 0; w < wave; w++) before_w += s_wave_tot[w];
+    q = wg_ext[blockIdx.x] + before_w + incl - (live ? nvalid : 0);
+    if (live) ext_start_out[row0 + r] = q;
+  } else {
+    q = live ? ext_start[row0 + r] : 0;
+  }
   for (int k = 0; k < kvol; k++) {
     if (skip_centre && k == centre) continue;
     const int v = live ? mine[k] : -1;
@@ -832,8 +852,11 @@ extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, 
 __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
                                                           int skip_centre, int64_t gran_cap, int32_t *__restrict__ base_k,
                                                           int32_t *__restrict__ wg_base, int32_t *__restrict__ gran_start,
-                                                          int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr) {
-  __shared__ int s_tot[65], s_gs[66];
+                                                          int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr,
+                                                          int32_t *__restrict__ wg_ext = nullptr, int32_t *__restrict__ pair_in = nullptr,
+                                                          int32_t *__restrict__ pair_out = nullptr,
+                                                          int32_t *__restrict__ ext_total = nullptr) {
+  __shared__ int s_tot[65], s_gs[66], s_base[65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = wave; k <= kvol; k += 4) {
     int running = 0;
@@ -856,7 +879,7 @@ __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restr
     int64_t rows = 0, gran = 0, pairs = 0;
     for (int k = 0; k < kvol; k++) {
       const int cnt = (skip_centre && k == centre) ? 0 : s_tot[k];
-      base_k[k] = (int32_t)rows;
+      base_k[k] = s_base[k] = (int32_t)rows;
       gran_start[k] = s_gs[k] = (int32_t)gran;
       const int64_t gk = (cnt + 127) / 128;
       rows += gk * 128;
@@ -870,8 +893,26 @@ __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restr
     hdr[3] = s_tot[kvol];                              // rows whose centre neighbour is not the row itself
     hdr[4] = gran > gran_cap ? 1 : 0;                  // capacity exceeded: cannot happen with the bound of the C ABI comment
     hdr[5] = hdr[6] = hdr[7] = 0;
+    if (ext_total) *ext_total = (int32_t)pairs;       // ext_start[n]
   }
   __syncthreads();
+  if (wg_ext) {
+    // rows of earlier workgroups over all offsets (the fill kernel's CSR starts), and -1 in the unused tail of every
+    // offset's last granule (the only padding a GEMM workgroup ever reads: granules behind the last one return on wg_k)
+    for (int w = threadIdx.x; w < nwg; w += 256) {
+      int acc = 0;
+      for (int k = 0; k < kvol; k++) acc += (skip_centre && k == centre) ? 0 : wg_base[(int64_t)w * kvol + k];
+      wg_ext[w] = acc;
+    }
+    for (int k = 0; k < kvol; k++) {
+      const int cnt = (skip_centre && k == centre) ? 0 : s_tot[k];
+      const int end = ((cnt + 127) / 128) * 128;
+      for (int r = cnt + threadIdx.x; r < end; r += 256) {
+        pair_in[s_base[k] + r] = -1;
+        pair_out[s_base[k] + r] = -1;
+      }
+    }
+  }
   const int total = s_gs[kvol];
   for (int64_t g = threadIdx.x; g < gran_cap; g += 256) {
     int k = -1;
@@ -951,6 +992,30 @@ extern "C" int link_conv_out_candidates(const int32_t *indices, int64_t n, const
   hipLaunchKernelGGL(k_conv_out_candidates, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream),
                      reinterpret_cast<const int4 *>(indices), n, g, ncomb, reinterpret_cast<int4 *>(cand));
   return check_launch("link_conv_out_candidates");
+}
+
+// count -> layout -> fill in one call (what link_amd's device-laid-out plans run): the fill pass computes the CSR starts
+// itself and the layout pass writes the padding tails, so no prefix-sum pass and no -1 fill of the capacity-sized lists.
+extern "C" int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
+                                    int32_t *wg_counts, int32_t *row_info, int32_t *base_k, int32_t *wg_base, int32_t *gran_start,
+                                    int32_t *wg_ext, int32_t *wg_k, int32_t *hdr, int32_t *ext_start, int32_t *pair_in,
+                                    int32_t *pair_out, int32_t *ext_list, void *stream) {
+  if (n <= 0 || kvol <= 0 || kvol > 64 || gran_cap <= 0) return LINK_ERR_ARG;
+  if (!nbr || !wg_counts || !row_info || !base_k || !wg_base || !gran_start || !wg_ext || !wg_k || !hdr || !ext_start || !pair_in ||
+      !pair_out || !ext_list)
+    return LINK_ERR_ARG;
+  const int64_t nwg = (n + 255) / 256;
+  if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
+  int rc = link_pair_plan_count(nbr, n, kvol, wg_counts, row_info, stream);
+  if (rc != LINK_OK) return rc;
+  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(256), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                     (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
+  rc = check_launch("link_pair_plan_build");
+  if (rc != LINK_OK) return rc;
+  hipLaunchKernelGGL(k_pair_plan<true>, dim3((unsigned)nwg), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
+                     (int)kvol, (int)(kvol / 2), (int)skip_centre, base_k, wg_base, (const int32_t *)nullptr, (int32_t *)nullptr,
+                     (int32_t *)nullptr, pair_in, pair_out, ext_list, wg_ext, ext_start);
+  return check_launch("link_pair_plan_build");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -691,20 +691,42 @@ class Conv3d(nn.Module):
                 bounds = coords_bounds(x.C.contiguous())
                 if x.C.is_contiguous() and bkey not in x.cmaps:
                     x.cmaps[bkey] = bounds
+            # sorted unique (batch, x', y', z') rows of the block coordinates through the dense cell grid (link_index_cells:
+            # four launches and the one host round trip that sizes the output, instead of a 1-D key, torch.unique's device
+            # sort with its own round trip, and the decode)
+            from .index import unique_cells
             lo = [bounds[0][k] // ss for k in range(3)]
-            ext = [bounds[1][k] // ss - lo[k] + 1 for k in range(3)]
-            q = torch.div(x.C[:, :3], ss, rounding_mode="floor").long()
-            lin = (((x.C[:, 3].long() - bounds[0][3]) * ext[0] + (q[:, 0] - lo[0])) * ext[1] + (q[:, 1] - lo[1])) * ext[2] + (q[:, 2] - lo[2])
-            u = torch.unique(lin)
-            oz = u % ext[2]; r1 = torch.div(u, ext[2], rounding_mode="floor")
-            oy = r1 % ext[1]; r2 = torch.div(r1, ext[1], rounding_mode="floor")
-            ox = r2 % ext[0]; ob = torch.div(r2, ext[0], rounding_mode="floor")
-            out_c = torch.stack([(ox + lo[0]) * ss, (oy + lo[1]) * ss, (oz + lo[2]) * ss, ob + bounds[0][3]], 1).int().contiguous()
+            hi = [bounds[1][k] // ss for k in range(3)]
+            q = torch.div(x.C[:, :3], ss, rounding_mode="floor")
+            rows = torch.cat([x.C[:, 3:4], q], 1).int().contiguous()
+            out_c = None
+            try:
+                sites, hdr = unique_cells(rows, ((bounds[0][3], lo[0], lo[1], lo[2]), (bounds[1][3], hi[0], hi[1], hi[2])))
+                m = int(hdr[L.HDR_M].item())
+                out_c = torch.cat([sites[:m, 1:4] * ss, sites[:m, 0:1]], 1).contiguous()
+            except GridTooLarge:
+                pass
+            if out_c is None:                           # grid beyond the dense-table limit: sort-based unique
+                ext = [hi[k] - lo[k] + 1 for k in range(3)]
+                ql = q.long()
+                lin = (((x.C[:, 3].long() - bounds[0][3]) * ext[0] + (ql[:, 0] - lo[0])) * ext[1] + (ql[:, 1] - lo[1])) * ext[2] + (ql[:, 2] - lo[2])
+                u = torch.unique(lin)
+                oz = u % ext[2]; r1 = torch.div(u, ext[2], rounding_mode="floor")
+                oy = r1 % ext[1]; r2 = torch.div(r1, ext[1], rounding_mode="floor")
+                ox = r2 % ext[0]; ob = torch.div(r2, ext[0], rounding_mode="floor")
+                out_c = torch.stack([(ox + lo[0]) * ss, (oy + lo[1]) * ss, (oz + lo[2]) * ss, ob + bounds[0][3]], 1).int().contiguous()
+            # the coarse set's bounding box follows from the fine one: no second pass over the coordinates, no round trip
+            x.cmaps.setdefault(("link_bounds", out_c.data_ptr(), out_c.shape[0]),
+                               ((lo[0] * ss, lo[1] * ss, lo[2] * ss, bounds[0][3]), (hi[0] * ss, hi[1] * ss, hi[2] * ss, bounds[1][3])))
             try:
                 down = foreign_neighbor_map(out_c, 2, step=ts, table_rows=x.C, bounds=bounds)
             except GridTooLarge:
                 offs = get_kernel_offsets(self.kernel_size, stride=x.s, device=x.F.device)
                 down = sphashquery(sphash(out_c, offs), sphash(x.C)).t().contiguous().int()
+            try:
+                down._link_subm = False                     # structural mark for the pair plan: a gather table between two site sets
+            except AttributeError:
+                pass
             km = _StridedMap(out_c, down, None)             # the transposed direction's table: built on first use
             km._n_in = x.C.shape[0]
             x.kmaps[key] = km
@@ -902,32 +924,28 @@ class _PairPlan:
         nbr = nbr.contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
         nwg = (n + 255) // 256
-        wg_counts = torch.empty((nwg, kvol + 1), **i32)
-        row_info = torch.empty(n, **i32)
-        L.check(lib.link_pair_plan_count(nbr.data_ptr(), n, kvol, wg_counts.data_ptr(), row_info.data_ptr(), st),
-                "link_pair_plan_count")
         # capacity: every (voxel, offset) a pair, every offset's last granule partly filled
         cap_pairs = n * (kvol - (1 if direct else 0))
         gran_cap = (cap_pairs + 127 * kvol + 127) // 128
         self.n, self.kvol, self.direct, self.exact = n, kvol, direct, False
         self.pairs, self.rows_pad, self._density = None, gran_cap * 128, None
-        meta = torch.empty(kvol + nwg * kvol + kvol + 1, **i32)            # base_k | wg_base | gran_start
-        wg_k = torch.empty(gran_cap, **i32)
-        hdr = torch.empty(8, **i32)
+        # one arena for everything the three kernels touch (count -> layout -> fill, one FFI call: link_pair_plan_build);
+        # nothing in it needs initialising
+        sizes = [nwg * (kvol + 1), n, kvol + nwg * kvol + kvol + 1, nwg, gran_cap, 8, n + 1, self.rows_pad, self.rows_pad,
+                 max(cap_pairs, 1)]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + ((sz + 3) & ~3))          # 16-byte aligned pieces
+        arena = torch.empty(offs[-1], **i32)
+        wg_counts, row_info, meta, wg_ext, wg_k, hdr, ext_start, pair_in, pair_out, ext_list = [
+            arena[offs[i]: offs[i] + sizes[i]] for i in range(len(sizes))]
         gs = meta[kvol + nwg * kvol:]
-        L.check(lib.link_pair_plan_layout(wg_counts.data_ptr(), n, kvol, 1 if direct else 0, gran_cap, meta.data_ptr(),
-                                          meta[kvol:].data_ptr(), gs.data_ptr(), wg_k.data_ptr(), hdr.data_ptr(), st),
-                "link_pair_plan_layout")
-        ext_cnt = (row_info & 0xFFFF) - (row_info >> 16) if direct else row_info & 0xFFFF
-        ext_start = torch.zeros(n + 1, **i32)
-        torch.cumsum(ext_cnt, 0, out=ext_start[1:])
-        pair_io = torch.full((2, self.rows_pad), -1, **i32)
-        ext_list = torch.empty(max(cap_pairs, 1), **i32)
-        L.check(lib.link_pair_plan_fill(nbr.data_ptr(), n, kvol, 1 if direct else 0, meta.data_ptr(), meta[kvol:].data_ptr(),
-                                        ext_start.data_ptr(), pair_io[0].data_ptr(), pair_io[1].data_ptr(), ext_list.data_ptr(), st),
-                "link_pair_plan_fill")
-        self._meta, self._hdr = meta, hdr
-        self.pair_in, self.pair_out, self.ext_start, self.ext_list = pair_io[0], pair_io[1], ext_start, ext_list
+        L.check(lib.link_pair_plan_build(nbr.data_ptr(), n, kvol, 1 if direct else 0, gran_cap, wg_counts.data_ptr(),
+                                         row_info.data_ptr(), meta.data_ptr(), meta[kvol:].data_ptr(), gs.data_ptr(),
+                                         wg_ext.data_ptr(), wg_k.data_ptr(), hdr.data_ptr(), ext_start.data_ptr(),
+                                         pair_in.data_ptr(), pair_out.data_ptr(), ext_list.data_ptr(), st), "link_pair_plan_build")
+        self._meta, self._hdr, self._arena = meta, hdr, arena
+        self.pair_in, self.pair_out, self.ext_start, self.ext_list = pair_in, pair_out, ext_start, ext_list
         self.gran_start, self.wg_k = gs, wg_k
         self._contrib = {}
         # the counts travel to pinned memory behind the kernels; whoever asks first after they arrived checks them
