@@ -694,10 +694,16 @@ int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const
 int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                          const link_elk_desc_t *desc /* host */, int64_t n, void *stream);
 /* One call = one R_core step on the dense-cell path (build_index = 0 reuses slots/cell_n of the previous
- * call on the same coordinates: the "warm" figure). */
+ * call on the same coordinates: the "warm" figure; 1 inserts the frame first; 2 = link_dc_index_probe inserted it). */
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
+/* The slot insert of a step (the form buf->tune picks) that also reports the frame's occupancy on this grid: stats
+ * i32[3] (device, zeroed by the caller) += voxels inside the grid, += occupied cells, max= fullest cell's count.  For the
+ * first visit of a coordinate set: a caller that accepts the layout continues with build_index = 2, one that does not
+ * zero-fills cnt and hdr (nothing else of the frame stays behind). */
+int link_dc_index_probe(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */, int64_t n, int32_t *stats,
+                        void *stream);
 /* The slot insert of the tile form: coords -> cnt / sid / vcell (ids only; the fused pre_mix kernel of the tile form
  * writes the id-ordered (x,y,z,id) records the gather kernel reads into `slots`).  Status bits as link_dc_index. */
 int link_dc_index_ids(const int32_t *coords, int64_t n, const link_dc_grid_t *g /* host */, uint32_t *cnt,

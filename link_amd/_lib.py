@@ -198,6 +198,7 @@ SIGNATURES = {
     "link_dc_gather": (c_int, [c_void_p, c_void_p, POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_void_p, c_void_p]),
     "link_elk_core_dense_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                             c_int64, c_int32, c_void_p]),
+    "link_dc_index_probe": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), c_int64, c_void_p, c_void_p]),
     "link_dc_index_ids": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_index": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_premix_modsum": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64,

@@ -747,6 +747,20 @@ extern "C" int link_dc_demod(const float *A, const float *fin, const int32_t *co
                              const link_elk_desc_t *d, const link_dc_grid_t *g, int64_t n, void *out, int32_t io_dtype,
                              void *stream);
 
+namespace link {
+int dc_index_ids_stats(const link_dc_buffers_t *, const link_dc_grid_t *, int64_t, int32_t *, hipStream_t);
+int dc_index_stats_run(const link_dc_buffers_t *, const link_dc_grid_t *, int64_t, int32_t *, hipStream_t);
+}  // namespace link
+
+// The slot insert of a step (the form b->tune picks) + the frame's occupancy on this grid: stats i32[3], zeroed by the
+// caller, receive (voxels inside the grid, occupied cells, fullest cell's count).  A caller that likes what it reads runs
+// link_elk_core_dense_forward with build_index = 2 (the insert is already there); one that does not zero-fills cnt and hdr.
+extern "C" int link_dc_index_probe(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, void *stream) {
+  if (!b || !g || !stats || n < 0) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  return b->tune.k1_form == 1 ? dc_index_ids_stats(b, g, n, stats, S(stream)) : dc_index_stats_run(b, g, n, stats, S(stream));
+}
+
 extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const link_dc_grid_t *g,
                                            const link_elk_desc_t *desc, int64_t n, int32_t build_index,
                                            void *stream) {
@@ -756,9 +770,10 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
   const int mode = b->tune.mode ? b->tune.mode : 7;   // bit0: fused pre_mix+modsum kernel, bit1: dense-cell demod kernel, bit2: fused gather+demod (C = 64), bit3: ... at the other widths too
   const bool fused = (mode & 1) && desc->c <= 64 && g->k <= 352;
   if (b->io_dtype != LINK_IO_F32 && (!fused || !(mode & 2))) return LINK_ERR_ARG;   // half rows: fused kernels only
+  if (build_index == 2 && !fused) return LINK_ERR_ARG;                              // the probe feeds the fused kernels only
   if (fused) {
     // index -> fused pre_mix + modulate + per-cell sum -> box gather -> per-voxel de-modulate
-    if (build_index) {
+    if (build_index == 1) {                            // 2: link_dc_index_probe inserted this frame already
       rc = b->tune.k1_form == 1 ? link_dc_index_ids(b->coords, n, g, b->cnt, b->sid, b->vcell, b->hdr, stream)
                                 : link_dc_index(b->coords, n, g, b->cnt, b->slots, b->vcell, b->hdr, stream);
       if (rc != LINK_OK) return rc;

@@ -33,6 +33,26 @@ __device__ __forceinline__ void st4i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off
   __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, 0);
 }
 
+// Occupancy statistics of an insert pass (the STATS variants of the index kernels): stats[0] += voxels inside the grid,
+// stats[1] += cells that got their first voxel, stats[2] = max(count of a cell).  One atomic each per wave and pass; the
+// wave maximum comes from ballots over the bits of rank + 1 (lanes past the end of the loop are simply absent from them).
+__device__ __forceinline__ void dc_index_stats(int32_t *stats, bool inside, int rank) {
+  const unsigned long long in_m = __ballot(inside), first_m = __ballot(inside && rank == 0);
+  const int m = inside ? rank + 1 : 0;
+  unsigned long long cand = __ballot(true);
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int b = 30; b >= 0; b--) {
+    const unsigned long long t = __ballot((m >> b) & 1) & cand;
+    if (t) cand = t;
+  }
+  if (lane == __builtin_ctzll(cand)) {
+    if (in_m) atomicAdd(&stats[0], (int32_t)__popcll(in_m));
+    if (first_m) atomicAdd(&stats[1], (int32_t)__popcll(first_m));
+    if (m) atomicMax(&stats[2], m);
+  }
+}
+
 __device__ __forceinline__ int dc_cell(const link_dc_grid_t &g, int ux, int uy, int uz, int ub) {
   return ((ub * g.pdim[0] + ux + 1) * g.pdim[1] + uy + 1) * g.pdim[2] + uz + 1;
 }

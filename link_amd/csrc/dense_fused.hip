@@ -43,9 +43,11 @@ DC_DECL_IO(dcio_bf16)
 // ---------------------------------------------------------------------------------------------
 // index: slot insert
 // ---------------------------------------------------------------------------------------------
+template <bool STATS>
 __global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
                                                   uint32_t *__restrict__ cnt, int4 *__restrict__ slots,
-                                                  int32_t *__restrict__ vcell, int32_t *__restrict__ hdr) {
+                                                  int32_t *__restrict__ vcell, int32_t *__restrict__ hdr,
+                                                  int32_t *__restrict__ stats) {
   const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
@@ -63,6 +65,7 @@ __global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coord
     const bool keep = pcell != 0 && !full;
     st16i(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
     vcell[v] = keep ? pcell : 0;
+    if (STATS) dc_index_stats(stats, pcell != 0, rank);
   }
 }
 
@@ -74,10 +77,23 @@ extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_gri
   if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29)) return LINK_ERR_ARG;
   int64_t wgs = (n + 255) / 256;
   if (wgs > 4096) wgs = 4096;
-  hipLaunchKernelGGL(k_dc_index, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
-                     *g, cnt, reinterpret_cast<int4 *>(slots), vcell, hdr);
+  hipLaunchKernelGGL(k_dc_index<false>, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
+                     *g, cnt, reinterpret_cast<int4 *>(slots), vcell, hdr, (int32_t *)nullptr);
   return check_launch("link_dc_index");
 }
+
+namespace link {
+// the insert of link_dc_index + occupancy statistics (behind link_dc_index_probe, dense.hip)
+int dc_index_stats_run(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, hipStream_t st) {
+  if (!b->coords || !b->cnt || !b->slots || !b->vcell || !b->hdr) return LINK_ERR_ARG;
+  if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29)) return LINK_ERR_ARG;
+  int64_t wgs = (n + 255) / 256;
+  if (wgs > 4096) wgs = 4096;
+  hipLaunchKernelGGL(k_dc_index<true>, dim3((unsigned)wgs), dim3(256), 0, st, reinterpret_cast<const int4 *>(b->coords), n, *g, b->cnt,
+                     reinterpret_cast<int4 *>(b->slots), b->vcell, b->hdr, stats);
+  return check_launch("link_dc_index_probe");
+}
+}  // namespace link
 
 static int dc_common_ok(const link_dc_buffers_t *b, const link_dc_grid_t *g, const link_elk_desc_t *d, int64_t n) {
   if (!b || !g || !d || n < 0) return LINK_ERR_ARG;

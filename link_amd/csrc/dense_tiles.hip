@@ -9,9 +9,14 @@ using namespace link;
 // coords -> cell, rank = cnt[cell]++, sid[cell][rank] = voxel id, vcell[id] = cell.  Every store is an unconditional
 // buffer store whose offset is out of range when the lane has nothing to write (hardware drops it): no branch around
 // a VMEM op, hence counted vmcnt waits (load -> atomic -> store is the whole kernel: latency only).
+//
+// STATS (first visit of a coordinate set, link_dc_index_probe): voxels inside the grid, occupied cells and the fullest
+// cell's count also go to stats[0..2], one atomic per wave and pass -- the frame's occupancy without a second insert.
+template <bool STATS>
 __global__ void __launch_bounds__(256) k_dc_index_ids(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
                                                       uint32_t *__restrict__ cnt, uint32_t *__restrict__ sid,
-                                                      int32_t *__restrict__ vcell, int32_t *__restrict__ hdr, uint32_t sid_bytes) {
+                                                      int32_t *__restrict__ vcell, int32_t *__restrict__ hdr, uint32_t sid_bytes,
+                                                      int32_t *__restrict__ stats) {
   const __amdgpu_buffer_rsrc_t r_sid = dc_rsrc(sid, sid_bytes);
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
@@ -29,6 +34,7 @@ __global__ void __launch_bounds__(256) k_dc_index_ids(const int4 *__restrict__ c
     const bool keep = pcell != 0 && !full;
     st4i(r_sid, keep ? dc_sid_off(g, pcell, rank) * 4u : DC_OOB, (int)v);
     vcell[v] = keep ? pcell : 0;
+    if (STATS) dc_index_stats(stats, pcell != 0, rank);
   }
 }
 
@@ -42,10 +48,23 @@ extern "C" int link_dc_index_ids(const int32_t *coords, int64_t n, const link_dc
   if (g->k < 1 || dc_sid_words(g) * 4 >= (1LL << 32) || n > (1LL << DC_ID_BITS)) return LINK_ERR_ARG;
   int64_t wgs = (n + 255) / 256;
   if (wgs > 4096) wgs = 4096;
-  hipLaunchKernelGGL(k_dc_index_ids, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
-                     *g, cnt, sid, vcell, hdr, (uint32_t)(dc_sid_words(g) * 4));
+  hipLaunchKernelGGL(k_dc_index_ids<false>, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
+                     *g, cnt, sid, vcell, hdr, (uint32_t)(dc_sid_words(g) * 4), (int32_t *)nullptr);
   return check_launch("link_dc_index_ids");
 }
+
+namespace link {
+// the insert of link_dc_index_ids + occupancy statistics (behind link_dc_index_probe, dense.hip)
+int dc_index_ids_stats(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, hipStream_t st) {
+  if (!b->coords || !b->cnt || !b->sid || !b->vcell || !b->hdr) return LINK_ERR_ARG;
+  if (g->k < 1 || dc_sid_words(g) * 4 >= (1LL << 32) || n > (1LL << DC_ID_BITS)) return LINK_ERR_ARG;
+  int64_t wgs = (n + 255) / 256;
+  if (wgs > 4096) wgs = 4096;
+  hipLaunchKernelGGL(k_dc_index_ids<true>, dim3((unsigned)wgs), dim3(256), 0, st, reinterpret_cast<const int4 *>(b->coords), n, *g,
+                     b->cnt, b->sid, b->vcell, b->hdr, (uint32_t)(dc_sid_words(g) * 4), stats);
+  return check_launch("link_dc_index_probe");
+}
+}  // namespace link
 
 namespace dcio_f16 { int run_tiles_modsum(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, bool, hipStream_t); }
 namespace dcio_bf16 { int run_tiles_modsum(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, bool, hipStream_t); }

@@ -320,8 +320,7 @@ class ElkCorePlan:
         self.buf.out = (out if out is not None else own).data_ptr()
         st = L.current_stream_handle()
         if self.dense:
-            rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
-                          1 if build_index else 0, st)
+            rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n, int(build_index), st)
         else:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
                           min(self.m_cap, n), 1 if build_index else 0, st)
@@ -330,6 +329,23 @@ class ElkCorePlan:
         if L.DEBUG:
             self.check()
         return out if out is not None else own[:n]
+
+    def _probe_fused(self) -> bool:
+        """Whether the step's own insert can serve as the occupancy probe (the fused dense-cell kernels run this plan)."""
+        return bool(self.dense and self.c <= 64 and int(self.dcg.k) <= 352 and (int(self.buf.tune.mode) or 7) & 1)
+
+    def _probe(self, coords: torch.Tensor, n: int, stats: torch.Tensor) -> None:
+        """Insert `coords` into this plan's cells and add (voxels inside, occupied cells, fullest cell) to stats i32[3]."""
+        self.buf.coords = coords.data_ptr()
+        self._indexed = None
+        L.check(L.lib().link_dc_index_probe(ctypes.byref(self.buf), ctypes.byref(self.dcg), n, stats.data_ptr(),
+                                            L.current_stream_handle()), "link_dc_index_probe")
+
+    def _unprobe(self) -> None:
+        """Forget a probed frame: counters and status word back to zero (the slot lists need no cleaning)."""
+        self.cnt.zero_()
+        self.hdr.zero_()
+        self._indexed = None
 
     def arena_bytes(self) -> int:
         """Device bytes this plan holds (its preallocated buffers)."""
@@ -830,6 +846,7 @@ ASYNC_PAIR_PLANS = True      # lay pair plans out on the device when the table's
 ASYNC_PAIR_PLAN_MAX = 8_000_000   # ... up to this many table entries: the buffers are sized for every entry being a pair
                                   # (contribution rows at 64 channels: 256 B per entry), beyond it the exact host layout
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
+_BBOX_STATS_INIT: Dict[torch.device, torch.Tensor] = {}   # (bbox init, zeroed occupancy counters) per device
 _PINNED: list = []
 
 
@@ -1449,11 +1466,30 @@ class _ELKBase(nn.Module):
             return None
         bkey = ("link_bounds", coords.data_ptr(), n)
         bounds = st.cmaps.get(bkey)
-        if bounds is None:
-            from .index import coords_bounds
-            bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
-        cache = self.__dict__.setdefault("_dc_plans", {})
         n_cap = 1 << max(10, (n - 1).bit_length())
+        sig = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, float(coord_div))
+        spec = None
+        if bounds is None:
+            last = self.__dict__.get("_dc_last")
+            if ok is None and last is not None and last[0] == sig and last[1]._probe_fused():
+                # a new coordinate set on a module that has just run the dense layout: bounding box and occupancy in ONE
+                # round trip -- the frame is inserted into the last plan's grid on the guess that its (block-aligned)
+                # bounds are that plan's again, which is what frames of a stream do; a wrong guess costs a zero-fill
+                init = _BBOX_STATS_INIT.get(feats.device)
+                if init is None:
+                    init = _BBOX_STATS_INIT[feats.device] = torch.tensor([2 ** 31 - 1] * 4 + [-2 ** 31] * 4 + [0] * 4, dtype=torch.int32,
+                                                                          device=feats.device)
+                both = init.clone()
+                cc = coords.contiguous()
+                L.check(L.lib().link_coords_bbox(cc.data_ptr(), n, both.data_ptr(), _st()), "link_coords_bbox")
+                last[1]._probe(cc, n, both[8:])
+                vals = both.tolist()
+                bounds = st.cmaps[bkey] = (tuple(vals[:4]), tuple(vals[4:8]))
+                spec = (last[1], vals[8:11])
+            else:
+                from .index import coords_bounds
+                bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
+        cache = self.__dict__.setdefault("_dc_plans", {})
         # plans are keyed by the bounds padded out to whole blocks (the grid they imply is the same): the exact extents of
         # real frames move from frame to frame, and every new key is a new arena (zero-filled tables, a slot arena of up
         # to 1 GiB) plus an occupancy probe.  Coarser padding would merge more frames but the gather kernel streams every
@@ -1476,22 +1512,36 @@ class _ELKBase(nn.Module):
             while cache and (len(cache) >= 8 or sum(p.arena_bytes() for p in cache.values() if p is not None) > max(budget, 0)):
                 cache.pop(next(iter(cache)))
             cache[key] = plan
+        if spec is not None and spec[0] is not plan:
+            spec[0]._unprobe()                                 # guessed the wrong grid: that plan forgets the frame
+            spec = None
         if plan is None:
             st.cmaps[okey] = False
             return None
+        inserted = False
         if ok is None:
-            # first visit of this coordinate set: the slot-insert kernel alone fills the per-cell counters; their
-            # maximum and the number of occupied cells decide (two tiny reductions, one host round trip)
+            # first visit of this coordinate set: the step's own slot insert, in a variant that also counts the voxels
+            # inside the grid, the occupied cells and the fullest cell (link_dc_index_probe); one host round trip, and the
+            # step below starts behind the insert (build_index = 2)
             cc = coords.contiguous()
-            L.check(L.lib().link_dc_index_ids(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.sid.data_ptr(),
-                                              plan.vcell.data_ptr(), plan.hdr.data_ptr(), _st()), "link_dc_index_ids")
-            mx, m, n_in = torch.stack([plan.cnt.max(), (plan.cnt > 0).sum(), plan.cnt.sum()]).tolist()
-            plan.cnt.zero_()                                   # the step below inserts again
-            plan._indexed = None
+            if spec is not None:
+                n_in, m, mx = spec[1]
+                inserted = True
+            elif plan._probe_fused():
+                stats = torch.zeros(3, dtype=torch.int32, device=feats.device)
+                plan._probe(cc, n, stats)
+                n_in, m, mx = stats.tolist()
+                inserted = True
+            else:                                              # C = 128 / long slot lists: the insert alone, then the counters
+                L.check(L.lib().link_dc_index_ids(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.sid.data_ptr(),
+                                                  plan.vcell.data_ptr(), plan.hdr.data_ptr(), _st()), "link_dc_index_ids")
+                mx, m, n_in = torch.stack([plan.cnt.max(), (plan.cnt > 0).sum(), plan.cnt.sum()]).tolist()
+                plan._unprobe()                                # the step below inserts again
             ok = st.cmaps[okey] = bool(m > 0 and n_in <= DENSE_MAX_MEAN * m and mx <= min(DENSE_MAX_CELL, int(plan.dcg.k)))
             if not ok:
-                plan.hdr.zero_()                               # nothing of this frame stays behind in the shared plan
+                plan._unprobe()                                # nothing of this frame stays behind in the shared plan
                 return None
+            self.__dict__["_dc_last"] = (sig, plan)
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
         ikey = (coords.data_ptr(), n, coords._version)
@@ -1499,7 +1549,7 @@ class _ELKBase(nn.Module):
         # rows of voxels outside them are never written, so they start as zeros (status word)
         alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
         out = alloc((n, c), dtype=feats.dtype, device=feats.device)
-        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=2 if inserted else plan.__dict__.get("_indexed") != ikey, out=out)
         plan._indexed = ikey
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
         return out

@@ -256,3 +256,41 @@ def test_three_plans_in_flight_on_three_streams():
                    blk.norm.weight, blk.norm.bias)
         o1 = alone.run(*frames[j])
         assert rel_err(outs[j].cpu().numpy(), o1.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("C,groups,baseop,s,r", [(64, 2, "cos", 7, 3), (32, 1, "cos_x", 3, 2), (128, 2, "cos", 5, 3)])
+def test_module_first_visits_probe_once_and_guess_the_grid(C, groups, baseop, s, r):
+    """A stream of new coordinate sets through one module (elk.py:_core_dense): the first visit's occupancy probe is the
+    step's own slot insert (link_dc_index_probe, then build_index = 2), and from the second frame on bounding box and probe
+    share one round trip on the guess that the frame lands on the last plan's grid -- right for frames 1-2 (same extents),
+    wrong for frame 3 (shifted and smaller: that plan forgets the frame) and frame 4 (clumped: the general layout runs).
+    Every frame against a fresh module on the same weights, and the kept plan's counters are clean afterwards."""
+    import link_amd as la
+    torch.manual_seed(9)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    grid, n = 72, 7000
+    frames = []
+    for k in range(3):
+        c = s_uniform(n, grid=grid, seed=20 + k)
+        c[0, :3], c[1, :3] = 0, grid - 1                      # same extents, hence the same block-aligned grid
+        frames.append(c)
+    shifted = s_uniform(6000, grid=grid // 2, seed=31)        # same row capacity as the frames before: the guess is made, and wrong
+    shifted[:, :3] += 11
+    clumped = s_uniform(n, grid=8, seed=32)                   # ~ 14 voxels per cell position: far above DENSE_MAX_MEAN
+    clumped = torch.unique(clumped, dim=0)
+    frames += [shifted, clumped, frames[0].clone()]
+    for k, c in enumerate(frames):
+        c = c.cuda()
+        feats = torch.randn(c.shape[0], C, generator=torch.Generator().manual_seed(40 + k)).cuda()
+        with torch.no_grad():
+            got = blk._core(la.SparseTensor(feats, c, 1), s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None,
+                            C // groups, 1.0).float()
+            fresh = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+            fresh.load_state_dict(blk.state_dict())
+            fresh.dense_layout = False                       # the general layout: no probe, no shared plan
+            ref = fresh._core(la.SparseTensor(feats, c.clone(), 1), s, r, fresh.pos_weight[0].weight,
+                              fresh.alpha if baseop == "cos_x" else None, C // groups, 1.0).float()
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 2e-5, k
+    for plan in blk._dc_plans.values():
+        if plan is not None and plan.__dict__.get("_indexed") is None:
+            assert int(plan.cnt.sum()) == 0 and int(plan.hdr.abs().sum()) == 0
