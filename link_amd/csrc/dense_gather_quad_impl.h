@@ -23,11 +23,25 @@
                           (x 2: 54.4 -> 47.9 MB from the memory side) on cfg2, same time */
 #endif
 
+#ifndef DC_K2_SKIP
+#define DC_K2_SKIP 0     /* 1: rows of empty cells (a quarter of cfg2's padded grid) are not fetched -- the plane DMA of such a row
+                          becomes an out-of-range buffer load, which writes zeros to LDS without touching memory; the counts
+                          run two planes ahead of the rows for that.  Correct (tests pass either way) and ~12 MB less traffic
+                          per frame, but the kernel is not bandwidth-bound: the producers' count look-up before every plane
+                          request costs more than the bytes save (same box, cfg2: 27.6 against 26.3 us; 38.2 against 37.1 us
+                          per frame with three frames in flight).  Off. */
+#endif
+
 template <int OP, int R>
 struct dc_k2q_cfg {
   using K2 = dc_k2_cfg<OP, R>;
   static constexpr int PAR_OFF = K2::SPLIT_LDS_BYTES;            // LayerNorm weight | bias image (2 x 64 floats)
+  // count images run two planes ahead of the row images (the producers look a plane's counts up before they request its
+  // rows): a ring of five 256-byte images (the tile's <= 64 haloed columns, requested by every producer wave alike) laid
+  // into the three plane slots' 1 KB count areas -- no LDS beyond the round-2 layout, whose size the frames in flight
+  // are tuned to
   static constexpr int LDS_BYTES = PAR_OFF + 2 * 64 * 4;
+  static_assert(!DC_K2_SKIP || K2::G::NCOL <= 64, "one count image = one wave's 64 entries");
   static constexpr bool FITS = K2::P == 2 && 2 * LDS_BYTES <= 160 * 1024;
 };
 
@@ -50,6 +64,25 @@ __device__ __forceinline__ void lds_rd8_b128(uint32_t a0, uint32_t a1, v4f_t (&x
                  "=&v"(x[1][3])
                : "v"(a0), "v"(a1)
                : "memory");
+}
+// the counts of a lane's N row pieces: N reads in flight, one wait
+template <int N>
+__device__ __forceinline__ void lds_rd_counts(uint32_t base, const uint32_t (&off)[N], int (&cn)[N]) {
+  if constexpr (N == 5) {
+    asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %6\n\tds_read_b32 %2, %7\n\tds_read_b32 %3, %8\n\tds_read_b32 %4, %9\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(cn[0]), "=&v"(cn[1]), "=&v"(cn[2]), "=&v"(cn[3]), "=&v"(cn[4])
+                 : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3]), "v"(base + off[4])
+                 : "memory");
+  } else if constexpr (N == 4) {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(cn[0]), "=&v"(cn[1]), "=&v"(cn[2]), "=&v"(cn[3])
+                 : "v"(base + off[0]), "v"(base + off[1]), "v"(base + off[2]), "v"(base + off[3])
+                 : "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) cn[i] = lds_rd_b32(base + off[i]);
+  }
 }
 // sum over the four lanes of a quad (quad_perm [1,0,3,2] then [2,3,0,1])
 __device__ __forceinline__ float dc_quad_sum(float v) {
@@ -118,20 +151,34 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
       py = py < PDy - 1 ? py : PDy - 1;
       return (uint32_t)(((b * PDx + px) * PDy + py) * PDz);
     };
-    uint32_t src_off[K::PASSES];
+    uint32_t src_off[K::PASSES], cnt_off[K::PASSES];
 #pragma unroll
     for (int i = 0; i < K::PASSES; i++) {
       int pid = i * 256 + tid;
       if (pid >= K::NPC) pid = K::NPC - 1;
       const int col = pid / K::RP, pcs = pid % K::RP;
       src_off[i] = col_cell0(col / HY, col % HY) * (uint32_t)RB + (uint32_t)pcs * 16u;
+      cnt_off[i] = (uint32_t)col * 4u;
     }
     uint32_t cnt_cell0;
     {
-      int e = wave * 64 + lane;
+      int e = DC_K2_SKIP ? lane : wave * 64 + lane;      // skip form: every wave requests the same image (same data, same place)
       if (e >= K::NCOL) e = K::NCOL - 1;
       cnt_cell0 = col_cell0(e / HY, e % HY);
     }
+    const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * RB));
+    auto cnt_slot = [&](int plane) -> uint32_t {     // LDS byte offset of the count image of `plane`
+      if (!DC_K2_SKIP) return (uint32_t)((plane % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
+      const int sl = plane % 5;
+      return (uint32_t)((sl % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE + (sl / 3) * 256);
+    };
+    auto issue_cnt = [&](int plane) {
+      int pz = pz0 + plane;
+      pz = pz < PDz - 1 ? pz : PDz - 1;
+      const int32_t *csrc = cell_n + cnt_cell0 + pz;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
+                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, 0);
+    };
     uint32_t rec_cell0;                                // inline slot records of the 16 interior cells of an output plane
     int rec_k;
     {
@@ -141,21 +188,34 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
       rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
     }
     const char *Sb = reinterpret_cast<const char *>(S_);
-    auto issue = [&](int plane) {
+    auto issue = [&](int plane, bool known) {          // known: the plane's count image is in LDS (every plane but the first two)
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
       char *buf = lds + (plane % 3) * K2::SPLIT_BUF_BYTES;
+      if (DC_K2_SKIP && known) {
+        const uint32_t cb = lds_base + cnt_slot(plane);
+        int cn[K::PASSES];
+        lds_rd_counts<K::PASSES>(cb, cnt_off, cn);
 #pragma unroll
-      for (int i = 0; i < K::PASSES; i++) {
-        const bool surplus = (i * 256 + wave * 64) >= K::NPC;            // wave-uniform: repeat pass 0 (same data, same place)
-        const int ii = surplus ? 0 : i;
-        const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < K::PASSES; i++) {
+          const bool surplus = (i * 256 + wave * 64) >= K::NPC;          // wave-uniform: repeat pass 0 (same data, same place)
+          const int ii = surplus ? 0 : i;
+          const uint32_t off = (surplus ? src_off[0] : src_off[i]) + (uint32_t)pz * (uint32_t)RB;
+          const int c_ = surplus ? cn[0] : cn[i];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_S, (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16,
+                                                   c_ != 0 ? off : DC_OOB, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < K::PASSES; i++) {
+          const bool surplus = (i * 256 + wave * 64) >= K::NPC;          // wave-uniform: repeat pass 0 (same data, same place)
+          const int ii = surplus ? 0 : i;
+          const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
+        }
       }
-      const int32_t *csrc = cell_n + cnt_cell0 + pz;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
-                                       (__attribute__((address_space(3))) void *)(buf + K2::SPLIT_PLANE + wave * 256), 4, 0, 0);
+      issue_cnt(DC_K2_SKIP ? plane + 2 : plane);       // NI instructions per call either way
       int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
       po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
       const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
@@ -173,8 +233,9 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     int n_prev = 0;                                    // voxels in this group's cell of the previous plane
 #pragma unroll
     for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-    issue(0);
-    if (nplanes > 1) issue(1);
+    if (DC_K2_SKIP) { issue_cnt(0); issue_cnt(1); }    // older than everything a counted wait leaves in flight
+    issue(0, false);
+    if (nplanes > 1) issue(1, false);
     for (int i = 0; i <= nplanes; i++) {
       unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
       if (i < nplanes) {
@@ -185,14 +246,14 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
       asm volatile("s_barrier" ::: "memory");
       if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
       if (i >= nplanes) break;
-      if (i + 2 < nplanes) issue(i + 2);
+      if (i + 2 < nplanes) issue(i + 2, true);
       const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
       float4 cur[P];
       float cc = 0.f;
 #pragma unroll
       for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
       {
-        const uint32_t ra = bufa + row_lane, ca = bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane;
+        const uint32_t ra = bufa + row_lane, ca = lds_base + cnt_slot(i) + cnt_lane;
         if constexpr (R == 3) {
           dc_read_plane_p2r3<C>(ra, ca, cur, cc);
         } else {
@@ -200,7 +261,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
           dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
         }
       }
-      const int n_here = lds_rd_b32(bufa + (uint32_t)K2::SPLIT_PLANE + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+      const int n_here = lds_rd_b32(lds_base + cnt_slot(i) + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
       if (i >= R - 1) {
         const uint32_t abuf = abuf0 + (uint32_t)((i & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((i & 1) * K2::NG * 4);
         float4 a[P];
