@@ -80,27 +80,20 @@ __device__ __forceinline__ float group_sum(float v) {
 // kernel is still running instead of waiting, dirty, for the write-back at the kernel boundary
 // (MI355X_MICROARCH.md: boundary "+ B / 6 TB/s when the predecessor leaves B bytes dirty"; "publish-large":
 // plain stores + flush 8.2 us vs sc1 write-through 3.0 us).  The next kernel runs on other XCDs anyway.
-// Inline asm stores are invisible to the compiler's vmcnt bookkeeping; that only makes its later
-// waits conservative (vmcnt retires in order), never too weak.  g_wt_stores toggles it for A/B tests.
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-// The asm form below was validated (repeat-bitwise tests + stale-cache tests) with the toolchain of ROCm 7.2
-// (clang 22).  It carries a hand-placed hazard pad the compiler cannot see, so any OTHER compiler major falls
-// back to an ordinary store until it has been re-validated -- the dense-cell kernels (dense_common.h) already
-// use the compiler-visible form, __builtin_amdgcn_raw_buffer_store_b128 with aux = sc1.
-#define LINK_STORE_WT_VALIDATED_CLANG 22
-__device__ __forceinline__ void store_wt(float4 *p, float4 v) {
-#if defined(__clang_major__) && __clang_major__ == LINK_STORE_WT_VALIDATED_CLANG
-  const v4f_t x = {v.x, v.y, v.z, v.w};
-  // s_nop 1: a VMEM store of more than 8 bytes needs wait states before its data VGPRs are overwritten;
-  // hipcc pads that hazard for its own instructions but cannot see inside an asm statement.
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-#else
-  *p = v;
-#endif
+// The store is the buffer-store builtin with aux = sc1 (as in the dense-cell kernels, dense_common.h): visible to the
+// compiler's hazard and vmcnt bookkeeping.  It addresses base + 32-bit byte offset, so the launchers ask for it only for
+// tables below 4 GiB (link::wt_ok); larger ones take ordinary stores.
+typedef int v4i_wt_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_out(float *base, int64_t elem, float4 v, bool wt) {
+  if (wt) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000);
+    const v4i_wt_t x = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z),
+                        __builtin_bit_cast(int, v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (uint32_t)(elem * 4), 0, 16);
+  } else {
+    *reinterpret_cast<float4 *>(base + elem) = v;
+  }
 }
-__device__ __forceinline__ void store_out(float4 *p, float4 v, bool wt) {
-  if (wt) store_wt(p, v);
-  else *p = v;
-}
+static inline bool wt_ok(int64_t rows, int64_t row_floats) { return rows * row_floats * 4 < (1LL << 32); }
 
 }  // namespace link

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_premix_ln_tlp(const float *__restrict__
         o.y = (acc[tp][1] - mean) * rstd * lw.y + lb.y;
         o.z = (acc[tp][2] - mean) * rstd * lw.z + lb.z;
         o.w = (acc[tp][3] - mean) * rstd * lw.w + lb.w;
-        store_out(reinterpret_cast<float4 *>(&fin[v * C + 16 * tp + 4 * g]), o, wt);
+        store_out(fin, v * C + 16 * tp + 4 * g, o, wt);
       }
     }
   }
@@ -122,7 +122,7 @@ static int launch_premix_tlp(const float *feats, const float *w_pre, const float
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_premix_ln_tlp<C>, dim3((unsigned)wgs), dim3(256), lds, st, feats, w_pre, ln_w, ln_b, n,
-                     eps, fin, g_wt_fwd());
+                     eps, fin, g_wt_fwd() && wt_ok(n, C));
   return check_launch("link_premix_ln");
 }
 
@@ -725,9 +725,9 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
     float *row = S + (int64_t)b * rs;
     const float k = row_den ? 1.0f / row_den[b] : 1.0f;    // backward: rows pre-divided by the forward's denominator
     if (act) {
-      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
-      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
-      if (P == 3) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
+      store_out(S, (int64_t)b * rs + ch0, make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
+      store_out(S, (int64_t)b * rs + c + ch0, make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
+      if (P == 3) store_out(S, (int64_t)b * rs + 2 * c + ch0, make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
 #pragma unroll
@@ -780,9 +780,9 @@ __device__ __forceinline__ void modulate_sum_per_group(const float *__restrict__
     float *row = S + (int64_t)b * rs;
     const float k = row_den ? 1.0f / row_den[b] : 1.0f;
     if (act) {
-      store_out(reinterpret_cast<float4 *>(&row[ch0]), make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
-      store_out(reinterpret_cast<float4 *>(&row[c + ch0]), make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
-      if (P == 3) store_out(reinterpret_cast<float4 *>(&row[2 * c + ch0]), make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
+      store_out(S, (int64_t)b * rs + ch0, make_float4(a0[0] * k, a0[1] * k, a0[2] * k, a0[3] * k), wt);
+      store_out(S, (int64_t)b * rs + c + ch0, make_float4(a1[0] * k, a1[1] * k, a1[2] * k, a1[3] * k), wt);
+      if (P == 3) store_out(S, (int64_t)b * rs + 2 * c + ch0, make_float4(a2[0] * k, a2[1] * k, a2[2] * k, a2[3] * k), wt);
     }
     if (li == 0) Scnt[b] = (float)(seg_end - seg_beg);
   }
@@ -1274,10 +1274,9 @@ __device__ __forceinline__ bool block_gather_dense_body(const float *__restrict_
         const float k = (flags & 2) ? 1.0f : 1.0f / den;
         if (den_out && li == 0) den_out[oid] = den;
         if (act) {
-          float *arow = A_tab + (int64_t)oid * rs;
 #pragma unroll
           for (int pp = 0; pp < P; pp++)
-            store_out(reinterpret_cast<float4 *>(&arow[pp * c + ch0]),
+            store_out(A_tab, (int64_t)oid * rs + pp * c + ch0,
                       make_float4(((ring[0][pp][0] + ring[1][pp][0]) + ring[2][pp][0]) * k,
                                   ((ring[0][pp][1] + ring[1][pp][1]) + ring[2][pp][1]) * k,
                                   ((ring[0][pp][2] + ring[1][pp][2]) + ring[2][pp][2]) * k,
@@ -1448,10 +1447,9 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
       const float rden = (flags & 2) ? 1.0f : 1.0f / den;   // den is an exact small integer; x*(1/d) vs x/d: <= 1 ulp
       if (den_out && on && li == 0) den_out[bb + jj] = den;
       if (on && act) {
-        float *arow = A_tab + (int64_t)(bb + jj) * rs;
 #pragma unroll
         for (int pp = 0; pp < P; pp++)
-          store_out(reinterpret_cast<float4 *>(&arow[pp * c + ch0]),
+          store_out(A_tab, (int64_t)(bb + jj) * rs + pp * c + ch0,
                     make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden), wt);   // utils.py:80
       }
     }
@@ -1535,8 +1533,8 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     sA += nvA[e]; sB += nvB[e];
   }
   if (!ln_w) {                                   // training forward: the raw de-modulated rows (no LayerNorm)
-    if (act && vok) store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]), make_float4(nvA[0], nvA[1], nvA[2], nvA[3]), wt);
-    if (PAIR && act && hasB) store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]), make_float4(nvB[0], nvB[1], nvB[2], nvB[3]), wt);
+    if (act && vok) store_out(out, (int64_t)rcA.w * c + ch0, make_float4(nvA[0], nvA[1], nvA[2], nvA[3]), wt);
+    if (PAIR && act && hasB) store_out(out, (int64_t)rcB.w * c + ch0, make_float4(nvB[0], nvB[1], nvB[2], nvB[3]), wt);
     return;
   }
   sA = grp_sum<LPR>(sA);
@@ -1557,7 +1555,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     o.y = (nvA[1] - meanA) * rsA * gw[1] + gb[1];
     o.z = (nvA[2] - meanA) * rsA * gw[2] + gb[2];
     o.w = (nvA[3] - meanA) * rsA * gw[3] + gb[3];
-    store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcA.w * c + ch0]), o, wt);
+    store_out(out, (int64_t)rcA.w * c + ch0, o, wt);
   }
   if (PAIR && act && hasB) {
     float4 o;
@@ -1565,7 +1563,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
     o.y = (nvB[1] - meanB) * rsB * gw[1] + gb[1];
     o.z = (nvB[2] - meanB) * rsB * gw[2] + gb[2];
     o.w = (nvB[3] - meanB) * rsB * gw[3] + gb[3];
-    store_out(reinterpret_cast<float4 *>(&out[(int64_t)rcB.w * c + ch0]), o, wt);
+    store_out(out, (int64_t)rcB.w * c + ch0, o, wt);
   }
 }
 
@@ -1584,7 +1582,7 @@ static void launch_modsum_g(int op, hipStream_t st, const float *fin, const int4
   const bool pair = !(flags & LINK_ELK_NO_PAIR) && LPR >= 2 && c == 2 * cg && c == 4 * LPR && two_part;
 #define LINK_MS(OPP, PP)                                                                                         \
   hipLaunchKernelGGL((k_modulate_sum_g<LPR, OPP, PP>), grid, block, 0, st, fin, vox, w_pos, alpha, blk_start, hdr, \
-                     c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0, row_den)
+                     c, cg, div, S, m_cap, g_coop_threshold, (g_wt & 2) != 0 && wt_ok(m_cap + 1, 3 * (int64_t)c), row_den)
   switch (op) {
     case LINK_OP_COS: if (pair) LINK_MS(LINK_OP_COS, true); else LINK_MS(LINK_OP_COS, false); break;
     case LINK_OP_SIN: if (pair) LINK_MS(LINK_OP_SIN, true); else LINK_MS(LINK_OP_SIN, false); break;
@@ -1638,7 +1636,7 @@ template <int LPR, int P>
 static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
                                 const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
                                 int64_t m_cap, float *A, int flags, float *den_out, bool allow_dense) {
-  const bool wt = (g_wt & 4) != 0;
+  const bool wt = (g_wt & 4) != 0 && wt_ok(m_cap + 1, 3 * (int64_t)c);
   unsigned wgs = (unsigned)g_bgather_wgs;
   int tiles_y = 0, tiles_z = 0;
   if (LPR <= 32 && r == 3 && allow_dense) {         // widen the launch for the dense-grid form (same kernel)
@@ -1711,7 +1709,7 @@ static void launch_voxel_demod(const link_elk_desc_t &d, int64_t n, hipStream_t 
   dim3 grid((unsigned)wgs), block(256);
 #define LINK_VD(OPP, PP)                                                                                  \
   hipLaunchKernelGGL((k_voxel_demod_ln_g<LPR, OPP, PP>), grid, block, 0, st, A, fin, vox, pos_blk, w_pos,  \
-                     alpha, ln_w, ln_b, hdr, d.c, d.cg, d.coord_div, d.eps, out, (g_wt & 8) != 0)
+                     alpha, ln_w, ln_b, hdr, d.c, d.cg, d.coord_div, d.eps, out, (g_wt & 8) != 0 && wt_ok(n, d.c))
   if (d.op == LINK_OP_COS) { if (pair) LINK_VD(LINK_OP_COS, true); else LINK_VD(LINK_OP_COS, false); }
   else if (d.op == LINK_OP_SIN) { if (pair) LINK_VD(LINK_OP_SIN, true); else LINK_VD(LINK_OP_SIN, false); }
   else LINK_VD(LINK_OP_COSX, false);
