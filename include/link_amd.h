@@ -328,6 +328,19 @@ int link_elk_gather_demod_tiles(const float *S, const float *fin, const int32_t 
                                 const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
                                 const float *ln_b, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                                 float *out, void *stream);
+/* The two tile-form entries with fp16 / bf16 feature rows at the kernel boundary (io_dtype = LINK_IO_F32 / LINK_IO_F16 /
+ * LINK_IO_BF16, section D: feats of the first, out of the second; tables, fin, sums and LayerNorm stay fp32) -- what
+ * TSELKBlock runs under autocast on LiDAR-shaped frames, with no cast pass on either side. */
+int link_elk_premix_modsum_tiles_io(const void *feats, int32_t io_dtype, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                    const int32_t *blk_start, const int32_t *hdr, const float *w_pre, const float *pre_ln_w,
+                                    const float *pre_ln_b, const float *w_pos, const float *alpha,
+                                    const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap, float *S,
+                                    int64_t s_bytes, float *fin, void *stream);
+int link_elk_gather_demod_tiles_io(const float *S, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                   const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid /* host */,
+                                   const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
+                                   const float *ln_b, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
+                                   void *out, int32_t io_dtype, void *stream);
 
 
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,

@@ -138,6 +138,10 @@ SIGNATURES = {
                                              c_void_p, c_void_p]),
     "link_elk_gather_demod_tiles": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid)] + [c_void_p] * 5 +
                                     [POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_void_p]),
+    "link_elk_premix_modsum_tiles_io": (c_int, [c_void_p, c_int32] + [c_void_p] * 9 + [POINTER(LinkElkDesc), c_int64, c_int64, c_void_p,
+                                                c_int64, c_void_p, c_void_p]),
+    "link_elk_gather_demod_tiles_io": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid)] + [c_void_p] * 5 +
+                                       [POINTER(LinkElkDesc), c_int64, c_int64, c_void_p, c_int32, c_void_p]),
     "link_elk_mid_forward": (c_int, [c_void_p] * 6 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                      POINTER(LinkElkDesc), c_void_p, c_void_p, c_int64, c_int64] + [c_void_p] * 5),
     "link_elk_out_ln_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p,

@@ -54,21 +54,30 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {
   if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+// four channels as 16-bit elements of the boundary type (IO = 1, 2)
+__device__ __forceinline__ v2i_t io_pack4(float4 v) {
+  v2i_t x;
+  if constexpr (IO == 1) {
+    const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    x = __builtin_bit_cast(v2i_t, h);
+  } else {
+    x.x = (int)(bf16_rne(v.x) | (bf16_rne(v.y) << 16));
+    x.y = (int)(bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+  }
+  return x;
+}
 // store four channels at BYTE offset of the fp32 layout / 4 * IO_BYTES, i.e. callers pass the element offset
 __device__ __forceinline__ void io_st4(__amdgpu_buffer_rsrc_t r, uint32_t elem_off, bool valid, float4 v) {
   if constexpr (IO == 0) {
     st16(r, valid ? elem_off * 4u : DC_OOB, v);
   } else {
-    v2i_t x;
-    if constexpr (IO == 1) {
-      const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-      x = __builtin_bit_cast(v2i_t, h);
-    } else {
-      x.x = (int)(bf16_rne(v.x) | (bf16_rne(v.y) << 16));
-      x.y = (int)(bf16_rne(v.z) | (bf16_rne(v.w) << 16));
-    }
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, valid ? elem_off * 2u : DC_OOB, 0, DC_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(io_pack4(v), r, valid ? elem_off * 2u : DC_OOB, 0, DC_ST_AUX);
   }
+}
+// the same through a 64-bit element index into `base` (rows beyond the 4 GiB a descriptor spans)
+__device__ __forceinline__ void io_st4_ptr(void *base, int64_t elem, float4 v) {
+  if constexpr (IO == 0) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(base) + elem) = v;
+  else *reinterpret_cast<v2i_t *>(reinterpret_cast<char *>(base) + elem * 2) = io_pack4(v);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,28 +1,30 @@
-// link_amd/csrc/elk_tiles.hip -- tile form of R_core on the general layout (elk_tiles_impl.h): C ABI and dispatch.
+// link_amd/csrc/elk_tiles.hip -- tile form of R_core on the general layout (elk_tiles_impl.h): C ABI; the kernels for fp32
+// feature rows (fp16 / bf16 rows at the kernel boundary: elk_tiles_f16.hip, elk_tiles_bf16.hip).
 #define DC_IO 0
 #define DC_IO_NS elkt_f32
 #include "elk_tiles_impl.h"
+#include "elk_tiles_dispatch.h"
 
 using namespace link;
 using namespace elkt_f32;
 
-// Sorted positions per workgroup of k_elk_tiles: one 16-voxel tile per wave on small frames (a tile is ~4 us of one wave's
-// dependent work, so a frame's waves should all be resident together), two from 32k voxels (fewer prologues: 20.4 against
-// 24.1 us at 59k voxels, C = 64; 11.7 against 15.1 at 3k), more only beyond 4096 workgroups.
-#ifdef ELK_T_SPAN
-static int tiles_span(int64_t) { return ELK_T_SPAN; }
-#else
-static int tiles_span(int64_t n) {
-  if (n <= 32768) return 64;
-  const int64_t k = (n + 128 * 4096 - 1) / (128 * 4096);
-  return 128 * (int)(k > 1 ? k : 1);
-}
-#endif
+#define ELKT_DECL(NS)                                                                                                              \
+  namespace NS {                                                                                                                   \
+  int run_premix(const void *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, const float *, const float *,   \
+                 const float *, const float *, const float *, const link_elk_desc_t &, int64_t, int64_t, float *, int64_t, float *, \
+                 hipStream_t);                                                                                                     \
+  int run_gather(const float *, const float *, const int32_t *, const int32_t *, const int32_t *, const int32_t *,                 \
+                 const link_grid_t &, const int32_t *, const float *, const float *, const float *, const float *,                 \
+                 const link_elk_desc_t &, int64_t, int64_t, void *, hipStream_t);                                                  \
+  }
+ELKT_DECL(elkt_f16)
+ELKT_DECL(elkt_bf16)
+#undef ELKT_DECL
 
 #ifdef ELK_T_DBG
 extern "C" int link_elk_tiles_debug_read(void *host_dst, int64_t bytes, int which) {      // profiling builds only
-  const hipError_t e = which ? hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_g_dbg), (size_t)bytes)
-                             : hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elk_t_dbg), (size_t)bytes);
+  const hipError_t e = which ? hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elkt_f32::elk_g_dbg), (size_t)bytes)
+                             : hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(elkt_f32::elk_t_dbg), (size_t)bytes);
   return e == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
 }
 #endif
@@ -32,8 +34,6 @@ static bool tiles_desc_ok(const link_elk_desc_t *d) {
          (d->op == LINK_OP_COS || d->op == LINK_OP_SIN || d->op == LINK_OP_COSX);
 }
 
-static int64_t tiles_wgs(int64_t n) { return (n + tiles_span(n) - 1) / tiles_span(n); }
-
 extern "C" int64_t link_elk_tiles_table_bytes(const link_elk_desc_t *desc, int64_t n, int64_t m_cap) {
   if (!tiles_desc_ok(desc) || n < 0 || m_cap < 0) return -1;
   const int rs = (desc->op == LINK_OP_COSX ? 3 : 2) * desc->c;
@@ -42,38 +42,26 @@ extern "C" int64_t link_elk_tiles_table_bytes(const link_elk_desc_t *desc, int64
   return elk_t_part_off(m_cap, rs) + ((n > 0 ? n : 1) + 63) / 64 * 4 * 2 * (int64_t)rs * 4;
 }
 
-template <int C, int OP, int NB>
-static int launch_tiles(const void *feats, const int32_t *vox_sorted, const int32_t *pos_blk, const int32_t *blk_start,
-                        const int32_t *hdr, const float *w_pre, const float *ln_w, const float *ln_b, const float *w_pos,
-                        const float *alpha, const link_elk_desc_t &d, int64_t n, int64_t m_cap, float *S_, int64_t s_bytes,
-                        float *fin, hipStream_t st) {
-  using K = elk_t_cfg<C, OP>;
-  const int lds = K::LDS_BYTES;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_elk_tiles<C, OP, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((k_elk_tiles<C, OP, NB>), dim3((unsigned)tiles_wgs(n)), dim3(64 * K::NW), lds, st, feats,
-                     reinterpret_cast<const int4 *>(vox_sorted), pos_blk, blk_start, hdr, w_pre, ln_w, ln_b, w_pos, alpha, d.cg,
-                     d.coord_div, d.eps, n, m_cap, tiles_span(n), S_, (uint32_t)s_bytes, (uint32_t)elk_t_part_off(m_cap, K::P * C), fin);
-  return check_launch("link_elk_premix_modsum_tiles");
-}
-
-template <int C, int OP, typename... A>
-static int tiles_nb(const link_elk_desc_t &d, A... a) {
-  constexpr int T = C / 16;
-  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
-  if (nb > T) nb = T;
-  if (T >= 2 && nb == T / 2) return launch_tiles<C, OP, (T >= 2 ? T / 2 : 1)>(a...);
-  if (T >= 4 && nb == T / 4) return launch_tiles<C, OP, (T >= 4 ? T / 4 : 1)>(a...);
-  return launch_tiles<C, OP, T>(a...);                  // any other grouping: every 16-channel block evaluates its own theta
-}
-
-template <int C, typename... A>
-static int tiles_op(const link_elk_desc_t &d, A... a) {
-  switch (d.op) {
-    case LINK_OP_COS: return tiles_nb<C, LINK_OP_COS>(d, a...);
-    case LINK_OP_SIN: return tiles_nb<C, LINK_OP_SIN>(d, a...);
-    default: return tiles_nb<C, LINK_OP_COSX>(d, a...);
+extern "C" int link_elk_premix_modsum_tiles_io(const void *feats, int32_t io_dtype, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                               const int32_t *blk_start, const int32_t *hdr, const float *w_pre,
+                                               const float *pre_ln_w, const float *pre_ln_b, const float *w_pos,
+                                               const float *alpha, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
+                                               float *S_, int64_t s_bytes, float *fin, void *stream) {
+  if (n < 0 || !tiles_desc_ok(desc) || io_dtype < LINK_IO_F32 || io_dtype > LINK_IO_BF16) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!feats || !vox_sorted || !pos_blk || !blk_start || !hdr || !w_pre || !pre_ln_w || !pre_ln_b || !w_pos || !S_) return LINK_ERR_ARG;
+  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
+  const int64_t need = link_elk_tiles_table_bytes(desc, n, m_cap);
+  // 32-bit byte offsets into the table, the rows and the records
+  if (m_cap < 1 || s_bytes < need || need >= (1LL << 32) || n * desc->c * 4 >= (1LL << 32)) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+#define LINK_T_CALL(NS) NS::run_premix(feats, vox_sorted, pos_blk, blk_start, hdr, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, *desc, n, m_cap, S_, need, fin, st)
+  switch (io_dtype) {
+    case LINK_IO_F16: return LINK_T_CALL(elkt_f16);
+    case LINK_IO_BF16: return LINK_T_CALL(elkt_bf16);
+    default: return LINK_T_CALL(elkt_f32);
   }
+#undef LINK_T_CALL
 }
 
 extern "C" int link_elk_premix_modsum_tiles(const float *feats, const int32_t *vox_sorted, const int32_t *pos_blk,
@@ -81,52 +69,27 @@ extern "C" int link_elk_premix_modsum_tiles(const float *feats, const int32_t *v
                                             const float *pre_ln_w, const float *pre_ln_b, const float *w_pos,
                                             const float *alpha, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
                                             float *S_, int64_t s_bytes, float *fin, void *stream) {
-  if (n < 0 || !tiles_desc_ok(desc)) return LINK_ERR_ARG;
+  return link_elk_premix_modsum_tiles_io(feats, LINK_IO_F32, vox_sorted, pos_blk, blk_start, hdr, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha,
+                                         desc, n, m_cap, S_, s_bytes, fin, stream);
+}
+
+extern "C" int link_elk_gather_demod_tiles_io(const float *S_, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
+                                              const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t *grid,
+                                              const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
+                                              const float *ln_b, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
+                                              void *out, int32_t io_dtype, void *stream) {
+  if (n < 0 || !tiles_desc_ok(desc) || !grid || io_dtype < LINK_IO_F32 || io_dtype > LINK_IO_BF16) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
-  if (!feats || !vox_sorted || !pos_blk || !blk_start || !hdr || !w_pre || !pre_ln_w || !pre_ln_b || !w_pos || !S_) return LINK_ERR_ARG;
+  if (!S_ || !vox_sorted || !pos_blk || !blk_coords || !cell_blk || !hdr || !w_pos || !ln_w || !ln_b || !out || m_cap < 1) return LINK_ERR_ARG;
   if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
-  const int64_t need = link_elk_tiles_table_bytes(desc, n, m_cap);
-  // 32-bit byte offsets into the table, the rows and the records
-  if (m_cap < 1 || s_bytes < need || need >= (1LL << 32) || n * desc->c * 4 >= (1LL << 32)) return LINK_ERR_ARG;
-  const link_elk_desc_t &d = *desc;
   hipStream_t st = S(stream);
-#define LINK_T_ARGS d, static_cast<const void *>(feats), vox_sorted, pos_blk, blk_start, hdr, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, d, n, m_cap, S_, need, fin, st
-  switch (d.c) {
-    case 16: return tiles_op<16>(LINK_T_ARGS);
-    case 32: return tiles_op<32>(LINK_T_ARGS);
-    case 64: return tiles_op<64>(LINK_T_ARGS);
-    default: return tiles_op<128>(LINK_T_ARGS);
+#define LINK_G_CALL(NS) NS::run_gather(S_, fin, vox_sorted, pos_blk, blk_coords, cell_blk, *grid, hdr, w_pos, alpha, ln_w, ln_b, *desc, n, m_cap, out, st)
+  switch (io_dtype) {
+    case LINK_IO_F16: return LINK_G_CALL(elkt_f16);
+    case LINK_IO_BF16: return LINK_G_CALL(elkt_bf16);
+    default: return LINK_G_CALL(elkt_f32);
   }
-#undef LINK_T_ARGS
-}
-
-template <int C, int OP, int R>
-static int launch_gather(const float *S_, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
-                         const int32_t *blk_coords, const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr,
-                         const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
-                         const link_elk_desc_t &d, int64_t n, int64_t m_cap, float *out, hipStream_t st) {
-  using K = elk_g_cfg<C, OP, R>;
-  // a multiple of 8: the kernel deals contiguous eighths of the tiles to the XCDs (workgroup w runs on XCD w % 8)
-  const int64_t wgs = ((n + (int64_t)K::WP * K::NW - 1) / ((int64_t)K::WP * K::NW) + 7) & ~(int64_t)7;
-  if (K::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_elk_gather_tiles<C, OP, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              K::LDS_BYTES);
-  hipLaunchKernelGGL((k_elk_gather_tiles<C, OP, R>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, S_, fin,
-                     reinterpret_cast<const int4 *>(vox_sorted), pos_blk, reinterpret_cast<const int4 *>(blk_coords), cell_blk, g, hdr,
-                     w_pos, alpha, ln_w, ln_b, d.cg, d.coord_div, d.eps, m_cap, static_cast<void *>(out));
-  return check_launch("link_elk_gather_demod_tiles");
-}
-
-template <int C, typename... A>
-static int gather_op_r(const link_elk_desc_t &d, A... a) {
-#define LINK_G_CASE(OPV)                                                        \
-  return d.r == 2 ? launch_gather<C, OPV, 2>(a...) : launch_gather<C, OPV, 3>(a...)
-  switch (d.op) {
-    case LINK_OP_COS: LINK_G_CASE(LINK_OP_COS);
-    case LINK_OP_SIN: LINK_G_CASE(LINK_OP_SIN);
-    default: LINK_G_CASE(LINK_OP_COSX);
-  }
-#undef LINK_G_CASE
+#undef LINK_G_CALL
 }
 
 extern "C" int link_elk_gather_demod_tiles(const float *S_, const float *fin, const int32_t *vox_sorted, const int32_t *pos_blk,
@@ -134,18 +97,6 @@ extern "C" int link_elk_gather_demod_tiles(const float *S_, const float *fin, co
                                            const int32_t *hdr, const float *w_pos, const float *alpha, const float *ln_w,
                                            const float *ln_b, const link_elk_desc_t *desc, int64_t n, int64_t m_cap,
                                            float *out, void *stream) {
-  if (n < 0 || !tiles_desc_ok(desc) || !grid) return LINK_ERR_ARG;
-  if (n == 0) return LINK_OK;
-  if (!S_ || !vox_sorted || !pos_blk || !blk_coords || !cell_blk || !hdr || !w_pos || !ln_w || !ln_b || !out || m_cap < 1) return LINK_ERR_ARG;
-  if (desc->op == LINK_OP_COSX && !fin) return LINK_ERR_ARG;
-  const link_elk_desc_t &d = *desc;
-  hipStream_t st = S(stream);
-#define LINK_G_ARGS d, S_, fin, vox_sorted, pos_blk, blk_coords, cell_blk, *grid, hdr, w_pos, alpha, ln_w, ln_b, d, n, m_cap, out, st
-  switch (d.c) {
-    case 16: return gather_op_r<16>(LINK_G_ARGS);
-    case 32: return gather_op_r<32>(LINK_G_ARGS);
-    case 64: return gather_op_r<64>(LINK_G_ARGS);
-    default: return gather_op_r<128>(LINK_G_ARGS);
-  }
-#undef LINK_G_ARGS
+  return link_elk_gather_demod_tiles_io(S_, fin, vox_sorted, pos_blk, blk_coords, cell_blk, grid, hdr, w_pos, alpha, ln_w, ln_b, desc, n,
+                                        m_cap, out, LINK_IO_F32, stream);
 }

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
       if (ok) {
         const float4 o = make_float4((nvv[0] - mean) * rstd * gw.x + gb.x, (nvv[1] - mean) * rstd * gw.y + gb.y,
                                      (nvv[2] - mean) * rstd * gw.z + gb.z, (nvv[3] - mean) * rstd * gw.w + gb.w);
-        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + (int64_t)rec.w * C + ch0) = o;
+        io_st4_ptr(out, (int64_t)rec.w * C + ch0, o);
       }
     }
     __builtin_amdgcn_wave_barrier();

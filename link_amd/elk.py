@@ -67,7 +67,10 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     host sync.  w_pos fp32[cg,3]; channel j uses theta[j % cg]."""
     n, c = feats.shape
     dev = feats.device
-    feats = feats.contiguous().float()
+    tiles = TILE_FORM and c in (16, 32, 64, 128) and r in (2, 3) and n > 0
+    # fp16 / bf16 rows (autocast) go through the tile form as they are and come back in their type; the four-kernel form is fp32
+    io = _IO_DTYPES[feats.dtype] if (tiles and feats.dtype in _IO_DTYPES) else L.IO_F32
+    feats = feats.contiguous() if io != L.IO_F32 else feats.contiguous().float()
     op = _OPS[baseop]
     parts = 3 if op == L.OP_COSX else 2
     if m_cap is None:
@@ -78,26 +81,32 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     lib, st = L.lib(), _st()
     w_pos = w_pos.contiguous().float()
     al = alpha.contiguous().float().view(-1) if alpha is not None else None
-    if TILE_FORM and c in (16, 32, 64, 128) and r in (2, 3) and n > 0:
+    # parameters are read as fp32 whatever the module was cast to
+    w_pre, pre_ln_w, pre_ln_b, ln_w, ln_b = (t.contiguous().float() for t in (w_pre, pre_ln_w, pre_ln_b, ln_w, ln_b))
+    if tiles:
         # tile form: two launches (pre_mix + modulate + block sums on the matrix cores; neighbour sum + de-modulate + norm)
         s_bytes = int(lib.link_elk_tiles_table_bytes(ctypes.byref(desc), n, m_cap))
         if 0 < s_bytes < 2 ** 32 and n * c * 4 < 2 ** 32:
+            if io != L.IO_F32:
+                out = _alloc_out(index, (n, c), dev, feats.dtype)
             S = torch.empty((s_bytes + 3) // 4, dtype=torch.float32, device=dev)
             fin = torch.empty((n, c), dtype=torch.float32, device=dev) if op == L.OP_COSX else None
             fin_p = fin.data_ptr() if fin is not None else None
-            L.check(lib.link_elk_premix_modsum_tiles(feats.data_ptr(), index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
-                                                     index.blk_start.data_ptr(), index.hdr.data_ptr(),
-                                                     w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(), pre_ln_b.data_ptr(),
-                                                     w_pos.data_ptr(), al.data_ptr() if al is not None else None,
-                                                     ctypes.byref(desc), n, m_cap, S.data_ptr(), s_bytes, fin_p, st),
-                    "link_elk_premix_modsum_tiles")
-            L.check(lib.link_elk_gather_demod_tiles(S.data_ptr(), fin_p, index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
-                                                    index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
-                                                    ctypes.byref(index.grid), index.hdr.data_ptr(), w_pos.data_ptr(),
-                                                    al.data_ptr() if al is not None else None, ln_w.data_ptr(), ln_b.data_ptr(),
-                                                    ctypes.byref(desc), n, m_cap, out.data_ptr(), st),
-                    "link_elk_gather_demod_tiles")
+            L.check(lib.link_elk_premix_modsum_tiles_io(feats.data_ptr(), io, index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
+                                                        index.blk_start.data_ptr(), index.hdr.data_ptr(),
+                                                        w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(), pre_ln_b.data_ptr(),
+                                                        w_pos.data_ptr(), al.data_ptr() if al is not None else None,
+                                                        ctypes.byref(desc), n, m_cap, S.data_ptr(), s_bytes, fin_p, st),
+                    "link_elk_premix_modsum_tiles_io")
+            L.check(lib.link_elk_gather_demod_tiles_io(S.data_ptr(), fin_p, index.vox_sorted.data_ptr(), index.pos_blk.data_ptr(),
+                                                       index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
+                                                       ctypes.byref(index.grid), index.hdr.data_ptr(), w_pos.data_ptr(),
+                                                       al.data_ptr() if al is not None else None, ln_w.data_ptr(), ln_b.data_ptr(),
+                                                       ctypes.byref(desc), n, m_cap, out.data_ptr(), io, st),
+                    "link_elk_gather_demod_tiles_io")
             return out
+        if io != L.IO_F32:                                   # table beyond 32-bit offsets: the fp32 four-kernel form below
+            feats = feats.float()
     fin = torch.empty((n, c), dtype=torch.float32, device=dev)
     S = torch.empty((m_cap + 1) * (parts * c + 1), dtype=torch.float32, device=dev)
     L.check(lib.link_premix_ln(feats.data_ptr(), w_pre.contiguous().data_ptr(), pre_ln_w.data_ptr(),
@@ -128,13 +137,13 @@ def elk_core_fused(feats: torch.Tensor, coords: torch.Tensor, index: BlockIndex,
     return out
 
 
-def _alloc_out(index: BlockIndex, shape, dev) -> torch.Tensor:
+def _alloc_out(index: BlockIndex, shape, dev, dtype=torch.float32) -> torch.Tensor:
     """Output rows of a core call.  The kernels write the rows of every *indexed* voxel; a voxel outside
     caller-supplied bounds is dropped by the index (hdr[STATUS] bit 0), so when the bounds were not derived
     from the coordinates themselves the rows start as zeros instead of uninitialised memory."""
     if getattr(index, "rows_checked", True):
-        return torch.empty(shape, dtype=torch.float32, device=dev)
-    return torch.zeros(shape, dtype=torch.float32, device=dev)
+        return torch.empty(shape, dtype=dtype, device=dev)
+    return torch.zeros(shape, dtype=dtype, device=dev)
 
 
 class ElkCorePlan:

@@ -162,3 +162,42 @@ def test_tiles_randomized_against_the_four_kernel_form():
         assert err < 1e-4, (case, C, baseop, groups, r, s, kind, n, err)
         assert torch.equal(tp.run(feats, coords.cuda(), build_index=False), a), case
     assert worst > 0.0                                  # the two forms do differ in the last bits (sanity of the comparison)
+
+
+@pytest.mark.parametrize("dtype,tol_round,tol_oracle", [(torch.float16, 1.2e-3, 6e-3), (torch.bfloat16, 9e-3, 5e-2)])
+@pytest.mark.parametrize("C,groups,baseop,s,r", [(16, 2, "cos", 7, 3), (32, 2, "cos", 7, 3), (64, 1, "cos_x", 6, 2), (128, 2, "cos", 7, 3)])
+def test_tiles_half_rows_at_the_boundary(dtype, tol_round, tol_oracle, C, groups, baseop, s, r):
+    """fp16 / bf16 feature rows in and out of the two tile-form kernels (link_elk_*_tiles_io; what TSELKBlock runs under
+    autocast, scn.py:586-607 with fp16_enabled): against the fp32 tile form on the SAME (already rounded) rows -- the only
+    difference left is the output rounding -- and against the oracle on the unrounded rows.  Tolerances as for the dense
+    layout's half rows (tests/test_gpu_dense.py)."""
+    import link_amd as la
+    from link_amd.elk import elk_core_fused
+    from link_amd.index import BlockIndex
+    torch.manual_seed(C)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    coords = torch.from_numpy(lidar_like(20000, seed=C + r)).cuda()
+    n = coords.shape[0]
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    ref = O.elk_core_torch(feats, coords.cpu(), params, s, r, baseop, groups, agg=O.aggregate_c).numpy()
+    index = BlockIndex(coords, s)
+    args = (coords, index, blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+            blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias, baseop, C // groups, r)
+    fh = feats.cuda().to(dtype)
+    with torch.no_grad():
+        got = elk_core_fused(fh, *args)
+        full = elk_core_fused(fh.float(), *args)
+    assert got.dtype == dtype and full.dtype == torch.float32
+    assert rel_err(got.float().cpu().numpy(), full.cpu().numpy()) < tol_round
+    assert rel_err(got.float().cpu().numpy(), ref) < tol_oracle
+    # a module cast to half as a whole (parameters too) reads its parameters as fp32 copies: same rows out
+    blk_h = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
+    blk_h.load_state_dict(blk.state_dict())
+    blk_h = blk_h.to(dtype)
+    # (the position weights stay fp32: theta = w . xyz with |xyz| ~ 10^3 does not survive a 16-bit w)
+    args_h = (coords, index, blk_h.pre_mix[0].weight, blk_h.pre_mix[1].weight, blk_h.pre_mix[1].bias, blk.pos_weight[0].weight,
+              blk.alpha if baseop == "cos_x" else None, blk_h.norm.weight, blk_h.norm.bias, baseop, C // groups, r)
+    with torch.no_grad():
+        got_h = elk_core_fused(fh, *args_h)
+    assert got_h.dtype == dtype and rel_err(got_h.float().cpu().numpy(), ref) < 4 * tol_oracle
