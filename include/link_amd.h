@@ -214,6 +214,13 @@ int link_aux_to_voxel_forward_grid(const float *small_f, const int32_t *counts, 
                                    const int32_t *hdr, const int64_t *idx, int64_t n, int64_t m, int32_t w,
                                    int32_t r, float *S, float *new_feat, float *denom, float *out,
                                    void *stream);
+/* The same result with the rows written by the gather kernel itself: out[perm[p]] = the row of block b for p in
+ * [blk_start[b], blk_start[b + 1]) (perm / blk_start of link_index_build).  Two launches; neither the [M, W] table of
+ * neighbour means (`new_feat`) nor the row gather exist.  denom f32[M] as above. */
+int link_aux_to_voxel_forward_scatter(const float *small_f, const int32_t *counts, const int32_t *blk_coords,
+                                      const int32_t *cell_blk, const link_grid_t *grid /* host */, const int32_t *hdr,
+                                      const int32_t *blk_start, const int32_t *perm, int64_t n, int64_t m, int32_t w, int32_t r,
+                                      float *S /* scratch f32[(M+1)*(W+1)] */, float *denom, float *out, void *stream);
 
 /* =============================================================================================
  * C. Fused ELKBlock core (R_core of SURVEY.md section 8d)

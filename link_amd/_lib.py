@@ -150,6 +150,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p]),
     "link_aux_to_voxel_forward_grid": (c_int, [c_void_p] * 4 + [POINTER(LinkGrid), c_void_p, c_void_p, c_int64,
                                                c_int64, c_int32, c_int32] + [c_void_p] * 5),
+    "link_aux_to_voxel_forward_scatter": (c_int, [c_void_p] * 4 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p, c_int64,
+                                                  c_int64, c_int32, c_int32] + [c_void_p] * 4),
     "link_conv_pairs_supported": (c_int, [c_int32, c_int32]),
     "link_conv_pairs_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "link_conv_pairs_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,

@@ -71,17 +71,19 @@ class _AuxToVoxel(Function):
         n = idx.shape[0]
         k = r ** 3
         dev = small_f.device
-        new_feat = torch.empty((m, c), dtype=torch.float32, device=dev)
         denom = torch.empty(m, dtype=torch.float32, device=dev)
-        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        # rows of voxels the index dropped (outside caller-supplied bounds, hdr[STATUS]) are never written: zeros then
+        out = (torch.empty if getattr(index, "rows_checked", True) else torch.zeros)((n, c), dtype=torch.float32, device=dev)
         if (c % 8 == 0 or c % 12 == 0) and r <= 3 and c <= 512 and m > 0 and (m + 1) * (c + 1) * 4 < 2 ** 32:
-            # dense-grid form: the fused path's block-gather kernel (no neighbour table needed)
+            # dense-grid form: the fused path's block-gather kernel (no neighbour table needed), which also hands each
+            # block's row to the block's voxels (`new_feat[idx]`, utils.py:84, without new_feat)
             S = torch.empty((m + 1) * (c + 1), dtype=torch.float32, device=dev)
-            L.check(L.lib().link_aux_to_voxel_forward_grid(
+            L.check(L.lib().link_aux_to_voxel_forward_scatter(
                 small_f.data_ptr(), counts.data_ptr(), index.blk_coords.data_ptr(), index.cell_blk.data_ptr(),
-                ctypes.byref(index.grid), index.hdr.data_ptr(), idx.data_ptr(), n, m, c, r, S.data_ptr(),
-                new_feat.data_ptr(), denom.data_ptr(), out.data_ptr(), _st()), "link_aux_to_voxel_forward_grid")
+                ctypes.byref(index.grid), index.hdr.data_ptr(), index.blk_start.data_ptr(), index.perm.data_ptr(), n, m, c, r,
+                S.data_ptr(), denom.data_ptr(), out.data_ptr(), _st()), "link_aux_to_voxel_forward_scatter")
         else:
+            new_feat = torch.empty((m, c), dtype=torch.float32, device=dev)
             nbr = index.neighbor_map(r)
             k = nbr.shape[1]
             L.check(L.lib().link_aux_to_voxel_forward(small_f.data_ptr(), counts.data_ptr(), nbr.data_ptr(),

@@ -1159,12 +1159,31 @@ __device__ __forceinline__ bool dense_regime(const link_grid_t &g, int m) {
 // against ~17 per block for the column-walking kernel, and the neighbour ids come from ONE round trip
 // (cell arithmetic + cell_blk) instead of two.  Same summation order on every run: deterministic.
 // ---------------------------------------------------------------------------------------------
+// Optional epilogue of the block gather: the finished row of block `b` goes straight to the rows of the block's voxels
+// (perm[blk_start[b] .. blk_start[b + 1]) = their ids) instead of -- or besides -- the [M, P*C] table: what aux_to_voxel
+// needs (utils.py:84, `new_feat[idx]`), without the table's round trip through memory and the row-gather launch.
+struct bg_scatter_t {
+  const int32_t *blk_start;
+  const int32_t *perm;
+  float *out;                                          // nullptr: no scatter
+};
+template <int P>
+__device__ __forceinline__ void bg_scatter_row(const bg_scatter_t &sc, uint32_t b, int rs, int c, int ch0, const float4 (&row)[P]) {
+  const int p0 = sc.blk_start[b], p1 = sc.blk_start[b + 1];
+  for (int p = p0; p < p1; p++) {
+    float *dst = sc.out + (int64_t)sc.perm[p] * rs + ch0;
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) *reinterpret_cast<float4 *>(dst + pp * c) = row[pp];
+  }
+}
+
 template <int LPR, int P, int TZ>
 __device__ __forceinline__ bool block_gather_dense_body(const float *__restrict__ S,
                                                             const int32_t *__restrict__ cell_blk, link_grid_t g,
                                                             const int32_t *__restrict__ hdr, int c, int64_t m_cap,
                                                             float *__restrict__ A_tab, bool wt, int flags,
-                                                            float *__restrict__ den_out, int tiles_y, int tiles_z) {
+                                                            float *__restrict__ den_out, int tiles_y, int tiles_z,
+                                                            const bg_scatter_t &sc) {
   constexpr int G = 64 / LPR;
   constexpr int NY = G + 2, NZ = TZ + 2, NCELL = 3 * NY * NZ;
   static_assert(G >= 2, "needs at least two columns per wave");
@@ -1274,13 +1293,18 @@ __device__ __forceinline__ bool block_gather_dense_body(const float *__restrict_
         const float k = (flags & 2) ? 1.0f : 1.0f / den;
         if (den_out && li == 0) den_out[oid] = den;
         if (act) {
+          float4 row[P];
 #pragma unroll
           for (int pp = 0; pp < P; pp++)
-            store_out(A_tab, (int64_t)oid * rs + pp * c + ch0,
-                      make_float4(((ring[0][pp][0] + ring[1][pp][0]) + ring[2][pp][0]) * k,
+            row[pp] = make_float4(((ring[0][pp][0] + ring[1][pp][0]) + ring[2][pp][0]) * k,
                                   ((ring[0][pp][1] + ring[1][pp][1]) + ring[2][pp][1]) * k,
                                   ((ring[0][pp][2] + ring[1][pp][2]) + ring[2][pp][2]) * k,
-                                  ((ring[0][pp][3] + ring[1][pp][3]) + ring[2][pp][3]) * k), wt);
+                                  ((ring[0][pp][3] + ring[1][pp][3]) + ring[2][pp][3]) * k);
+          if (A_tab) {
+#pragma unroll
+            for (int pp = 0; pp < P; pp++) store_out(A_tab, (int64_t)oid * rs + pp * c + ch0, row[pp], wt);
+          }
+          if (sc.out) bg_scatter_row<P>(sc, oid, rs, c, ch0, row);
         }
       }
     }
@@ -1302,12 +1326,12 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
                                                         const int32_t *__restrict__ hdr, int c,
                                                         int64_t m_cap, float *__restrict__ A_tab, bool wt,
                                                         int flags, float *__restrict__ den_out, int sparse_wgs,
-                                                        int tiles_y, int tiles_z) {
+                                                        int tiles_y, int tiles_z, bg_scatter_t sc) {
   // flags bit2: the launch is wide enough for the dense-grid form, which takes the frame when the block grid
   // is at least 1/DENSE_RATIO occupied (device-side decision: the host never learns M)
   if constexpr (DENSE && R == 3 && LPR <= 32) {
     if ((flags & 4) &&
-        block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z))
+        block_gather_dense_body<LPR, P, 4>(S, cell_blk, g, hdr, c, m_cap, A_tab, wt, flags, den_out, tiles_y, tiles_z, sc))
       return;
   }
   if ((int)blockIdx.x >= sparse_wgs) return;        // column-walking form: the first sparse_wgs workgroups
@@ -1447,10 +1471,14 @@ __global__ void __launch_bounds__(256) k_block_gather_g(const float *__restrict_
       const float rden = (flags & 2) ? 1.0f : 1.0f / den;   // den is an exact small integer; x*(1/d) vs x/d: <= 1 ulp
       if (den_out && on && li == 0) den_out[bb + jj] = den;
       if (on && act) {
+        float4 row[P];
 #pragma unroll
-        for (int pp = 0; pp < P; pp++)
-          store_out(A_tab, (int64_t)(bb + jj) * rs + pp * c + ch0,
-                    make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden), wt);   // utils.py:80
+        for (int pp = 0; pp < P; pp++) row[pp] = make_float4(Av[pp][0] * rden, Av[pp][1] * rden, Av[pp][2] * rden, Av[pp][3] * rden);   // utils.py:80
+        if (A_tab) {
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) store_out(A_tab, (int64_t)(bb + jj) * rs + pp * c + ch0, row[pp], wt);
+        }
+        if (sc.out) bg_scatter_row<P>(sc, (uint32_t)(bb + jj), rs, c, ch0, row);
       }
     }
   }
@@ -1635,7 +1663,8 @@ static void launch_gdl_g(int op, int r, hipStream_t st, int64_t m_cap, const flo
 template <int LPR, int P>
 static void launch_block_gather(int r, hipStream_t st, const float *S_, const int4 *blk_coords,
                                 const int32_t *cell_blk, const link_grid_t &g, const int32_t *hdr, int c,
-                                int64_t m_cap, float *A, int flags, float *den_out, bool allow_dense) {
+                                int64_t m_cap, float *A, int flags, float *den_out, bool allow_dense,
+                                const bg_scatter_t &sc = bg_scatter_t{nullptr, nullptr, nullptr}) {
   const bool wt = (g_wt & 4) != 0 && wt_ok(m_cap + 1, 3 * (int64_t)c);
   unsigned wgs = (unsigned)g_bgather_wgs;
   int tiles_y = 0, tiles_z = 0;
@@ -1657,7 +1686,7 @@ static void launch_block_gather(int r, hipStream_t st, const float *S_, const in
   dim3 grid(wgs), block(256);
 #define LINK_BGK(RR, DD)                                                                                          \
   hipLaunchKernelGGL((k_block_gather_g<LPR, P, RR, DD>), grid, block, 0, st, S_, blk_coords, cell_blk, g, hdr, c, \
-                     m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z)
+                     m_cap, A, wt, flags, den_out, g_bgather_wgs, tiles_y, tiles_z, sc)
   switch (r) {
     case 1: LINK_BGK(1, false); break;
     case 2: LINK_BGK(2, false); break;
@@ -1668,18 +1697,20 @@ static void launch_block_gather(int r, hipStream_t st, const float *S_, const in
 
 static int block_gather_impl(const float *S_, const int32_t *blk_coords, const int32_t *cell_blk,
                              const link_grid_t *grid, const int32_t *hdr, const link_elk_desc_t *desc,
-                             int64_t m_cap, float *A, int flags, float *den_out, void *stream) {
+                             int64_t m_cap, float *A, int flags, float *den_out, void *stream,
+                             const bg_scatter_t &sc = bg_scatter_t{nullptr, nullptr, nullptr}) {
   if (check_desc(desc) != LINK_OK || !grid || m_cap < 0 || desc->r > 3 || (desc->c & 3) != 0) return LINK_ERR_ARG;
   if (m_cap == 0) return LINK_OK;
-  if (!S_ || !blk_coords || !cell_blk || !hdr || !A) return LINK_ERR_ARG;
+  if (!S_ || !blk_coords || !cell_blk || !hdr || (!A && !sc.out)) return LINK_ERR_ARG;
+  if (sc.out && (!sc.blk_start || !sc.perm)) return LINK_ERR_ARG;
   if ((m_cap + 1) * (int64_t)(desc->c * 3 + 1) * 4 >= (1LL << 32)) return LINK_ERR_ARG;   // 32-bit row offsets
   const int4 *b4 = reinterpret_cast<const int4 *>(blk_coords);
   hipStream_t st = S(stream);
   const bool p3 = desc->op == LINK_OP_COSX;
   const bool dense_ok = !(desc->flags & LINK_ELK_NO_DENSE_GRID);
 #define LINK_BG(L)                                                                                                   \
-  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok); \
-  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok)
+  if (p3) launch_block_gather<L, 3>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok, sc); \
+  else launch_block_gather<L, 2>(desc->r, st, S_, b4, cell_blk, *grid, hdr, desc->c, m_cap, A, flags, den_out, dense_ok, sc)
   switch (lanes_per_row(desc->c)) {
     case 1: case 2: case 4: LINK_BG(4); break;
     case 8: LINK_BG(8); break;
@@ -2550,6 +2581,26 @@ extern "C" int link_aux_to_voxel_forward_grid(const float *small_f, const int32_
     hipLaunchKernelGGL(k_row_gather4, dim3(blocks_for(n * (w / 4), 256)), dim3(256), 0, st, new_feat, idx, n, (int)w, out);
   }
   return check_launch("link_aux_to_voxel_forward_grid");
+}
+
+// The same with the rows scattered by the gather kernel itself: out[perm[p]] = row of block b for p in
+// [blk_start[b], blk_start[b + 1]) -- no [M, W] table of neighbour means, no row-gather launch (two launches in all).
+extern "C" int link_aux_to_voxel_forward_scatter(const float *small_f, const int32_t *counts, const int32_t *blk_coords,
+                                                 const int32_t *cell_blk, const link_grid_t *grid, const int32_t *hdr,
+                                                 const int32_t *blk_start, const int32_t *perm, int64_t n, int64_t m, int32_t w,
+                                                 int32_t r, float *S_, float *denom, float *out, void *stream) {
+  if (n < 0 || m < 0 || w <= 0 || r <= 0 || r > 3 || !grid) return LINK_ERR_ARG;
+  int parts = 0;
+  if (w % 8 == 0 && w / 2 <= 256) parts = 2;
+  else if (w % 12 == 0 && w / 3 <= 256) parts = 3;
+  if (!parts) return LINK_ERR_ARG;
+  if (m == 0 || n == 0) return LINK_OK;
+  if (!small_f || !counts || !blk_coords || !cell_blk || !hdr || !blk_start || !perm || !S_ || !denom || !out) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  hipLaunchKernelGGL(k_means_to_table, dim3(blocks_for((m + 1) * (w / 4), 256)), dim3(256), 0, st, small_f, counts, m, (int)w, S_);
+  link_elk_desc_t d = {parts == 3 ? LINK_OP_COSX : LINK_OP_COS, w / parts, w / parts, r, 1.0f, 1e-6f};
+  const bg_scatter_t sc = {blk_start, perm, out};
+  return block_gather_impl(S_, blk_coords, cell_blk, grid, hdr, &d, m, nullptr, 0, denom, stream, sc);
 }
 
 // ---------------------------------------------------------------------------------------------

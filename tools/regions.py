@@ -28,7 +28,7 @@ def r_agg(cached):
     small, idx, counts = la.voxel_to_aux(st, 7)
     return la.aux_to_voxel(small, st, idx, counts, 3).F
 st0 = la.SparseTensor(x, coords, 1); la.voxel_to_aux(st0, 7); kcache, ccache = st0.kmaps, st0.cmaps
-print(f"R_agg surface, cold (index + bbox sync per call): {timeit(lambda: r_agg(False)):.1f} us")
+print(f"R_agg surface, cold (index + bbox sync per call): {timeit(lambda: r_agg(False), warm=40):.1f} us")   # first calls grow the allocator pools
 print(f"R_agg surface, warm (index cached on kmaps):      {timeit(lambda: r_agg(True)):.1f} us")
 blk.eval()
 def core_infer():
