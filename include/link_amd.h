@@ -719,7 +719,8 @@ int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const l
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
 /* The slot insert of a step (the form buf->tune picks) that also reports the frame's occupancy on this grid: stats
- * i32[3] (device, zeroed by the caller) += voxels inside the grid, += occupied cells, max= fullest cell's count.  For the
+ * i32[16][16] (device, zeroed by the caller): 16 partial slots on separate cache lines, [k][0] += voxels inside the grid,
+ * [k][1] += occupied cells, [k][2] max= fullest cell's count -- the reader sums / sums / maxes over k.  For the
  * first visit of a coordinate set: a caller that accepts the layout continues with build_index = 2, one that does not
  * zero-fills cnt and hdr (nothing else of the frame stays behind). */
 int link_dc_index_probe(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */, int64_t n, int32_t *stats,

@@ -27,19 +27,37 @@ __global__ void __launch_bounds__(256) k_block_mean(const float *__restrict__ in
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v++) acc[v] = 0.f;
-    if (j < c) {
-      for (int p = st; p < en; p++) {
-        const float *src = in + (int64_t)perm[p] * c + j;
-        if (VEC == 4) {
-          float4 x = *reinterpret_cast<const float4 *>(src);
-          acc[0] += x.x / fc; acc[1 % VEC] += x.y / fc; acc[2 % VEC] += x.z / fc; acc[3 % VEC] += x.w / fc;
-        } else if (VEC == 2) {
-          float2 x = *reinterpret_cast<const float2 *>(src);
-          acc[0] += x.x / fc; acc[1 % VEC] += x.y / fc;
-        } else {
-          acc[0] += src[0] / fc;
+    // the block's voxel ids 64 at a time (one load per lane, then lane broadcasts), rows four in flight: the chain per
+    // voxel was id -> row -> add, one after the other (same additions in the same order: bitwise the same means)
+    const int jj = j < c ? j : 0;
+    for (int p0 = st; p0 < en; p0 += 64) {
+      const int np = en - p0 < 64 ? en - p0 : 64;
+      const int my = perm[p0 + (lane < np ? lane : 0)];
+      for (int q = 0; q < np; q += 4) {
+        float x[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int id = __shfl(my, q + u < np ? q + u : q, 64);
+          const float *src = in + (int64_t)id * c + jj;
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(src);
+            x[u][0] = t.x; x[u][1 % VEC] = t.y; x[u][2 % VEC] = t.z; x[u][3 % VEC] = t.w;
+          } else if (VEC == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(src);
+            x[u][0] = t.x; x[u][1 % VEC] = t.y;
+          } else {
+            x[u][0] = src[0];
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (q + u < np) {                            // wave-uniform
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] += x[u][v] / fc;
+          }
       }
+    }
+    if (j < c) {
       float *dst = out + b * (int64_t)c + j;
 #pragma unroll
       for (int v = 0; v < VEC; v++) dst[v] = acc[v];

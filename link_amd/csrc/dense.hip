@@ -752,8 +752,8 @@ int dc_index_ids_stats(const link_dc_buffers_t *, const link_dc_grid_t *, int64_
 int dc_index_stats_run(const link_dc_buffers_t *, const link_dc_grid_t *, int64_t, int32_t *, hipStream_t);
 }  // namespace link
 
-// The slot insert of a step (the form b->tune picks) + the frame's occupancy on this grid: stats i32[3], zeroed by the
-// caller, receive (voxels inside the grid, occupied cells, fullest cell's count).  A caller that likes what it reads runs
+// The slot insert of a step (the form b->tune picks) + the frame's occupancy on this grid: stats i32[16][16], zeroed by the
+// caller; slot k holds partial (voxels inside the grid, occupied cells, fullest cell's count) in [k][0..2] -- sum, sum, max.  A caller that likes what it reads runs
 // link_elk_core_dense_forward with build_index = 2 (the insert is already there); one that does not zero-fills cnt and hdr.
 extern "C" int link_dc_index_probe(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, void *stream) {
   if (!b || !g || !stats || n < 0) return LINK_ERR_ARG;

@@ -33,23 +33,30 @@ __device__ __forceinline__ void st4i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off
   __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, 0);
 }
 
-// Occupancy statistics of an insert pass (the STATS variants of the index kernels): stats[0] += voxels inside the grid,
-// stats[1] += cells that got their first voxel, stats[2] = max(count of a cell).  One atomic each per wave and pass; the
-// wave maximum comes from ballots over the bits of rank + 1 (lanes past the end of the loop are simply absent from them).
-__device__ __forceinline__ void dc_index_stats(int32_t *stats, bool inside, int rank) {
-  const unsigned long long in_m = __ballot(inside), first_m = __ballot(inside && rank == 0);
-  const int m = inside ? rank + 1 : 0;
-  unsigned long long cand = __ballot(true);
-  const int lane = (int)(threadIdx.x & 63);
+// Occupancy statistics of an insert pass (the STATS variants of the index kernels).  Every lane keeps its own three numbers
+// over the kernel's loop; at the end the workgroup reduces them (wave butterfly, four waves through LDS) and one thread adds
+// them to one of 16 slots, each on its own 64-byte line: stats i32[16][16], slot [k][0] += voxels inside the grid,
+// [k][1] += cells that got their first voxel, [k][2] = max(count of a cell); the reader sums / maxes the 16 slots.  (One
+// atomic per wave and pass on a single line made the kernel 59 us instead of 8: same-address atomics serialise in the L2.)
+#define DC_STATS_SLOTS 16
+__device__ __forceinline__ void dc_index_stats_flush(int32_t *stats, int n_in, int n_first, int mx) {
+  __shared__ int s_part[4][3];
 #pragma unroll
-  for (int b = 30; b >= 0; b--) {
-    const unsigned long long t = __ballot((m >> b) & 1) & cand;
-    if (t) cand = t;
+  for (int o = 32; o > 0; o >>= 1) {
+    n_in += __shfl_xor(n_in, o, 64);
+    n_first += __shfl_xor(n_first, o, 64);
+    mx = max(mx, __shfl_xor(mx, o, 64));
   }
-  if (lane == __builtin_ctzll(cand)) {
-    if (in_m) atomicAdd(&stats[0], (int32_t)__popcll(in_m));
-    if (first_m) atomicAdd(&stats[1], (int32_t)__popcll(first_m));
-    if (m) atomicMax(&stats[2], m);
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  if (lane == 0) { s_part[wave][0] = n_in; s_part[wave][1] = n_first; s_part[wave][2] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0, f = 0, m = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { a += s_part[w][0]; f += s_part[w][1]; m = max(m, s_part[w][2]); }
+    int32_t *slot = stats + (blockIdx.x % DC_STATS_SLOTS) * 16;
+    if (a) atomicAdd(&slot[0], a);
+    if (f) atomicAdd(&slot[1], f);
+    if (m) atomicMax(&slot[2], m);
   }
 }
 

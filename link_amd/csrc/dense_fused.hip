@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coord
                                                   int32_t *__restrict__ stats) {
   const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  int st_in = 0, st_first = 0, st_max = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
     const int4 rc = coords[v];
@@ -65,8 +66,9 @@ __global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coord
     const bool keep = pcell != 0 && !full;
     st16i(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
     vcell[v] = keep ? pcell : 0;
-    if (STATS) dc_index_stats(stats, pcell != 0, rank);
+    if (STATS) { st_in += pcell != 0; st_first += (pcell != 0 && rank == 0); st_max = max(st_max, pcell != 0 ? rank + 1 : 0); }
   }
+  if (STATS) dc_index_stats_flush(stats, st_in, st_first, st_max);
 }
 
 extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_grid_t *g, uint32_t *cnt,

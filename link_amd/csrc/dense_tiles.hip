@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(256) k_dc_index_ids(const int4 *__restrict__ c
                                                       int32_t *__restrict__ stats) {
   const __amdgpu_buffer_rsrc_t r_sid = dc_rsrc(sid, sid_bytes);
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  int st_in = 0, st_first = 0, st_max = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
     const int4 rc = coords[v];
@@ -34,8 +35,9 @@ __global__ void __launch_bounds__(256) k_dc_index_ids(const int4 *__restrict__ c
     const bool keep = pcell != 0 && !full;
     st4i(r_sid, keep ? dc_sid_off(g, pcell, rank) * 4u : DC_OOB, (int)v);
     vcell[v] = keep ? pcell : 0;
-    if (STATS) dc_index_stats(stats, pcell != 0, rank);
+    if (STATS) { st_in += pcell != 0; st_first += (pcell != 0 && rank == 0); st_max = max(st_max, pcell != 0 ? rank + 1 : 0); }
   }
+  if (STATS) dc_index_stats_flush(stats, st_in, st_first, st_max);
 }
 
 static inline int64_t dc_sid_words(const link_dc_grid_t *g) { return g->vp * (int64_t)(g->k > DC_SID_INL ? g->k : DC_SID_INL); }

@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -344,7 +344,8 @@ class ElkCorePlan:
         return bool(self.dense and self.c <= 64 and int(self.dcg.k) <= 352 and (int(self.buf.tune.mode) or 7) & 1)
 
     def _probe(self, coords: torch.Tensor, n: int, stats: torch.Tensor) -> None:
-        """Insert `coords` into this plan's cells and add (voxels inside, occupied cells, fullest cell) to stats i32[3]."""
+        """Insert `coords` into this plan's cells; (voxels inside, occupied cells, fullest cell) go to stats i32[16][16] as 16
+        partial slots (_probe_stats)."""
         self.buf.coords = coords.data_ptr()
         self._indexed = None
         L.check(L.lib().link_dc_index_probe(ctypes.byref(self.buf), ctypes.byref(self.dcg), n, stats.data_ptr(),
@@ -856,6 +857,11 @@ ASYNC_PAIR_PLAN_MAX = 8_000_000   # ... up to this many table entries: the buffe
                                   # (contribution rows at 64 channels: 256 B per entry), beyond it the exact host layout
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
 _BBOX_STATS_INIT: Dict[torch.device, torch.Tensor] = {}   # (bbox init, zeroed occupancy counters) per device
+
+
+def _probe_stats(slots) -> Tuple[int, int, int]:
+    """(voxels inside the grid, occupied cells, fullest cell) from link_dc_index_probe's 16 partial slots of 16 ints."""
+    return (sum(slots[0:256:16]), sum(slots[1:256:16]), max(slots[2:256:16]))
 _PINNED: list = []
 
 
@@ -1486,15 +1492,15 @@ class _ELKBase(nn.Module):
                 # bounds are that plan's again, which is what frames of a stream do; a wrong guess costs a zero-fill
                 init = _BBOX_STATS_INIT.get(feats.device)
                 if init is None:
-                    init = _BBOX_STATS_INIT[feats.device] = torch.tensor([2 ** 31 - 1] * 4 + [-2 ** 31] * 4 + [0] * 4, dtype=torch.int32,
-                                                                          device=feats.device)
+                    init = _BBOX_STATS_INIT[feats.device] = torch.tensor([2 ** 31 - 1] * 4 + [-2 ** 31] * 4 + [0] * (8 + 256),
+                                                                          dtype=torch.int32, device=feats.device)
                 both = init.clone()
                 cc = coords.contiguous()
                 L.check(L.lib().link_coords_bbox(cc.data_ptr(), n, both.data_ptr(), _st()), "link_coords_bbox")
-                last[1]._probe(cc, n, both[8:])
+                last[1]._probe(cc, n, both[16:])                      # 64-byte aligned: the 16 slots sit on their own lines
                 vals = both.tolist()
                 bounds = st.cmaps[bkey] = (tuple(vals[:4]), tuple(vals[4:8]))
-                spec = (last[1], vals[8:11])
+                spec = (last[1], _probe_stats(vals[16:]))
             else:
                 from .index import coords_bounds
                 bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
@@ -1537,9 +1543,9 @@ class _ELKBase(nn.Module):
                 n_in, m, mx = spec[1]
                 inserted = True
             elif plan._probe_fused():
-                stats = torch.zeros(3, dtype=torch.int32, device=feats.device)
+                stats = torch.zeros(256, dtype=torch.int32, device=feats.device)
                 plan._probe(cc, n, stats)
-                n_in, m, mx = stats.tolist()
+                n_in, m, mx = _probe_stats(stats.tolist())
                 inserted = True
             else:                                              # C = 128 / long slot lists: the insert alone, then the counters
                 L.check(L.lib().link_dc_index_ids(cc.data_ptr(), n, ctypes.byref(plan.dcg), plan.cnt.data_ptr(), plan.sid.data_ptr(),
