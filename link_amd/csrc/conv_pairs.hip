@@ -849,7 +849,7 @@ extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, 
 // link_pair_plan_fill after reading the counts back): one workgroup.  Phase 1: a wave per offset column, exclusive scan of
 // the per-workgroup counts (-> wg_base) and the column totals.  Phase 2 (one lane): granule-aligned row ranges per offset.
 // Phase 3: the offset of every granule up to the caller's capacity, -1 behind the last one (the GEMM kernels return there).
-__global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
+__global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
                                                           int skip_centre, int64_t gran_cap, int32_t *__restrict__ base_k,
                                                           int32_t *__restrict__ wg_base, int32_t *__restrict__ gran_start,
                                                           int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr,
@@ -858,7 +858,8 @@ __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restr
                                                           int32_t *__restrict__ ext_total = nullptr) {
   __shared__ int s_tot[65], s_gs[66], s_base[65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k <= kvol; k += 4) {
+  const int nthr = (int)blockDim.x, nwave = nthr >> 6;    // one workgroup of 16 waves: the offset columns are scanned two per wave
+  for (int k = wave; k <= kvol; k += nwave) {
     int running = 0;
     for (int c = 0; c < nwg; c += 64) {
       const int w = c + lane;
@@ -899,7 +900,7 @@ __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restr
   if (wg_ext) {
     // rows of earlier workgroups over all offsets (the fill kernel's CSR starts), and -1 in the unused tail of every
     // offset's last granule (the only padding a GEMM workgroup ever reads: granules behind the last one return on wg_k)
-    for (int w = threadIdx.x; w < nwg; w += 256) {
+    for (int w = threadIdx.x; w < nwg; w += nthr) {
       int acc = 0;
       for (int k = 0; k < kvol; k++) acc += (skip_centre && k == centre) ? 0 : wg_base[(int64_t)w * kvol + k];
       wg_ext[w] = acc;
@@ -907,14 +908,14 @@ __global__ void __launch_bounds__(256) k_pair_plan_layout(const int32_t *__restr
     for (int k = 0; k < kvol; k++) {
       const int cnt = (skip_centre && k == centre) ? 0 : s_tot[k];
       const int end = ((cnt + 127) / 128) * 128;
-      for (int r = cnt + threadIdx.x; r < end; r += 256) {
+      for (int r = cnt + threadIdx.x; r < end; r += nthr) {
         pair_in[s_base[k] + r] = -1;
         pair_out[s_base[k] + r] = -1;
       }
     }
   }
   const int total = s_gs[kvol];
-  for (int64_t g = threadIdx.x; g < gran_cap; g += 256) {
+  for (int64_t g = threadIdx.x; g < gran_cap; g += nthr) {
     int k = -1;
     if (g < total) {
       k = 0;
@@ -931,7 +932,7 @@ extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_
   if (!wg_counts || !base_k || !wg_base || !gran_start || !hdr || (gran_cap > 0 && !wg_k)) return LINK_ERR_ARG;
   const int64_t nwg = (n + 255) / 256;
   if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
-  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(256), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(1024), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
                      (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr);
   return check_launch("link_pair_plan_layout");
 }
@@ -1008,7 +1009,7 @@ extern "C" int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol,
   if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
   int rc = link_pair_plan_count(nbr, n, kvol, wg_counts, row_info, stream);
   if (rc != LINK_OK) return rc;
-  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(256), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(1024), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
                      (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
   rc = check_launch("link_pair_plan_build");
   if (rc != LINK_OK) return rc;
