@@ -88,6 +88,22 @@ def test_argument_validation_without_gpu():
     assert lib.link_conv_out_candidates(None, 5, i3(2, 3, 3), i3(2, 2, 2), i3(1, 1, 1), i3(4, 4, 4), None, None) == L.LINK_ERR_ARG
     assert lib.link_dc_index_ids(None, 5, None, None, None, None, None, None) == L.LINK_ERR_ARG
     assert lib.link_dc_index_ids(None, 0, ctypes.byref(L.LinkDcGrid()), None, None, None, None, None) == L.LINK_OK
+    # end of round 3: one-call pair plans, the dense-layout probe, half rows through the tile form, aux_to_voxel with the scatter
+    assert lib.link_pair_plan_build(None, 0, 27, 1, 10, *([None] * 13)) == L.LINK_ERR_ARG                  # n < 1
+    assert lib.link_pair_plan_build(None, 10, 65, 1, 10, *([None] * 13)) == L.LINK_ERR_ARG                 # kvol > 64
+    assert lib.link_pair_plan_build(None, 10, 27, 1, 10, *([None] * 13)) == L.LINK_ERR_ARG                 # null buffers
+    assert lib.link_dc_index_probe(None, None, 5, None, None) == L.LINK_ERR_ARG
+    assert lib.link_dc_index_probe(ctypes.byref(L.LinkDcBuffers()), ctypes.byref(L.LinkDcGrid()), 5, None, None) == L.LINK_ERR_ARG  # no stats
+    desc = L.LinkElkDesc(L.OP_COS, 64, 32, 3, 1.0, 1e-6)
+    assert lib.link_elk_premix_modsum_tiles_io(None, 3, *([None] * 9), ctypes.byref(desc), 10, 10, None, 0, None, None) == L.LINK_ERR_ARG   # row type
+    assert lib.link_elk_premix_modsum_tiles_io(None, L.IO_F16, *([None] * 9), ctypes.byref(desc), 0, 10, None, 0, None, None) == L.LINK_OK   # empty frame
+    assert lib.link_elk_premix_modsum_tiles_io(None, L.IO_F16, *([None] * 9), ctypes.byref(desc), 10, 10, None, 0, None, None) == L.LINK_ERR_ARG  # null buffers
+    g = L.LinkGrid()
+    assert lib.link_elk_gather_demod_tiles_io(*([None] * 6), ctypes.byref(g), *([None] * 5), ctypes.byref(desc), 10, 10, None, -1, None) == L.LINK_ERR_ARG
+    assert lib.link_elk_gather_demod_tiles_io(*([None] * 6), ctypes.byref(g), *([None] * 5), ctypes.byref(desc), 0, 10, None, L.IO_BF16, None) == L.LINK_OK
+    assert lib.link_aux_to_voxel_forward_scatter(*([None] * 4), ctypes.byref(g), None, None, None, 10, 10, 10, 3, None, None, None, None) == L.LINK_ERR_ARG   # width 10: neither 2 nor 3 parts
+    assert lib.link_aux_to_voxel_forward_scatter(*([None] * 4), ctypes.byref(g), None, None, None, 10, 0, 128, 3, None, None, None, None) == L.LINK_OK       # no blocks
+    assert lib.link_aux_to_voxel_forward_scatter(*([None] * 4), ctypes.byref(g), None, None, None, 10, 10, 128, 3, None, None, None, None) == L.LINK_ERR_ARG  # null buffers
 
 
 def test_grid_from_bounds_host_logic():
