@@ -91,8 +91,13 @@ extern "C" int link_coords_bbox(const int32_t *coords, int64_t n, int32_t *bbox,
 // index build
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 cells per workgroup
+#ifndef LINK_SCAN_ITEMS
+#define LINK_SCAN_ITEMS 8
+#endif
+constexpr int SCAN_ITEMS = LINK_SCAN_ITEMS;           // cells per thread (a multiple of 4).  16 / 32 (fewer tiles in the look-back chain) measured
+                                                      // slower on every LiDAR stage frame: index rebuilt + 2 … + 8 us (A/B on one box, round 3)
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // cells per workgroup
+static_assert(SCAN_ITEMS % 4 == 0, "uint4 pieces");
 
 struct IndexScratch {
   int32_t *vox_cell;   // [n]
@@ -186,12 +191,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_cell_scan(
   unsigned int cnt[SCAN_ITEMS];
   if (base + SCAN_ITEMS <= v) {
     const uint4 *p = reinterpret_cast<const uint4 *>(cell_counts + base);
-    uint4 a = p[0], b = p[1];
-    cnt[0] = a.x; cnt[1] = a.y; cnt[2] = a.z; cnt[3] = a.w;
-    cnt[4] = b.x; cnt[5] = b.y; cnt[6] = b.z; cnt[7] = b.w;
+    uint4 a[SCAN_ITEMS / 4];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) a[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) { cnt[4 * i] = a[i].x; cnt[4 * i + 1] = a[i].y; cnt[4 * i + 2] = a[i].z; cnt[4 * i + 3] = a[i].w; }
     uint4 z = make_uint4(0, 0, 0, 0);
     uint4 *q = reinterpret_cast<uint4 *>(cell_counts + base);
-    q[0] = z; q[1] = z;  // self-clean
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) q[i] = z;  // self-clean
   } else {
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
