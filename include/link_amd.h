@@ -299,7 +299,7 @@ int link_voxel_demod_ln(const float *A, const float *fin, const int32_t *vox_sor
  * that a host written in an interpreted language pays ONE FFI crossing per LinK block instead of one
  * per kernel.  All pointers are device pointers with the meanings documented above. */
 typedef struct {
-  const float *feats;        /* fp[N,C]  block input (st.F) */
+  const void *feats;         /* [N,C]  block input (st.F): fp32, or io_dtype rows with LINK_ELK_TILES */
   const int32_t *coords;     /* i32[N,4] (st.C) */
   const float *w_pre, *pre_ln_w, *pre_ln_b;   /* pre_mix.0.weight [C,C], pre_mix.1.{weight,bias} [C] */
   const float *w_pos, *alpha;                 /* pos_weight.0.weight [cg,3]; alpha [cg] or NULL */
@@ -309,8 +309,11 @@ typedef struct {
   float *fin;                /* fp[N,C]            scratch: pre_mix output */
   float *S;                  /* fp[(m_cap+1)*(P*C+1)] scratch: block table rows + zero row + counts */
   float *A;                  /* fp[m_cap, P*C]     scratch: normalised neighbour sums (NULL: fused gather) */
-  float *out;                /* fp[N,C]            result (new_st_F after self.norm) */
+  void *out;                 /* [N,C]              result (new_st_F after self.norm), same element type as feats */
   int64_t s_bytes;           /* bytes available at S (0: the size above); LINK_ELK_TILES needs link_elk_tiles_table_bytes() */
+  int32_t io_dtype;          /* LINK_IO_F32 (0) / LINK_IO_F16 / LINK_IO_BF16: element type of feats and out; 16-bit rows need
+                                LINK_ELK_TILES (the four-kernel form is fp32) */
+  int32_t reserved;
 } link_elk_buffers_t;
 
 /* Tile form of the section-C kernels on a built index (elk_tiles_impl.h): TWO launches for R_core instead of four, made for

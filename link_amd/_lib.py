@@ -18,7 +18,7 @@ HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -52,7 +52,7 @@ class LinkElkBuffers(Structure):
                [("scratch_bytes", c_size_t)] + \
                [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "pos_blk", "blk_start",
                                         "blk_coords", "counts", "hdr", "fin", "S", "A", "out")] + \
-               [("s_bytes", c_int64)]
+               [("s_bytes", c_int64), ("io_dtype", c_int32), ("reserved", c_int32)]
 
 
 class LinkDcGrid(Structure):

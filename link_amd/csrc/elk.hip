@@ -2618,13 +2618,16 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
     if (rc != LINK_OK) return rc;
   }
   if (desc->flags & LINK_ELK_TILES) {
-    rc = link_elk_premix_modsum_tiles(b->feats, b->vox_sorted, b->pos_blk, b->blk_start, b->hdr, b->w_pre, b->pre_ln_w,
-                                      b->pre_ln_b, b->w_pos, b->alpha, desc, n, m_cap, b->S, b->s_bytes, b->fin, stream);
+    rc = link_elk_premix_modsum_tiles_io(b->feats, b->io_dtype, b->vox_sorted, b->pos_blk, b->blk_start, b->hdr, b->w_pre, b->pre_ln_w,
+                                         b->pre_ln_b, b->w_pos, b->alpha, desc, n, m_cap, b->S, b->s_bytes, b->fin, stream);
     if (rc != LINK_OK) return rc;
-    return link_elk_gather_demod_tiles(b->S, b->fin, b->vox_sorted, b->pos_blk, b->blk_coords, b->cell_blk, grid, b->hdr,
-                                       b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, n, m_cap, b->out, stream);
+    return link_elk_gather_demod_tiles_io(b->S, b->fin, b->vox_sorted, b->pos_blk, b->blk_coords, b->cell_blk, grid, b->hdr,
+                                          b->w_pos, b->alpha, b->ln_w, b->ln_b, desc, n, m_cap, b->out, b->io_dtype, stream);
   }
-  rc = link_premix_ln(b->feats, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
+  if (b->io_dtype != LINK_IO_F32) return LINK_ERR_ARG;         // the four-kernel form is fp32
+  const float *feats32 = static_cast<const float *>(b->feats);
+  float *out32 = static_cast<float *>(b->out);
+  rc = link_premix_ln(feats32, b->w_pre, b->pre_ln_w, b->pre_ln_b, n, desc->c, desc->eps, b->fin, stream);
   if (rc != LINK_OK) return rc;
   rc = link_modulate_block_sum(b->fin, b->vox_sorted, b->w_pos, b->alpha, b->blk_start, b->hdr, desc, n,
                                m_cap, b->S, stream);
@@ -2633,9 +2636,9 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
     rc = link_block_gather(b->S, b->blk_coords, b->cell_blk, grid, b->hdr, desc, m_cap, b->A, stream);
     if (rc != LINK_OK) return rc;
     return link_voxel_demod_ln(b->A, b->fin, b->vox_sorted, b->pos_blk, b->w_pos, b->alpha, b->ln_w, b->ln_b,
-                               b->hdr, desc, n, b->out, stream);
+                               b->hdr, desc, n, out32, stream);
   }
   return link_gather_demod_ln(b->S, b->fin, b->vox_sorted, b->w_pos, b->alpha, b->ln_w, b->ln_b,
-                              b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, b->out,
+                              b->blk_start, b->blk_coords, b->cell_blk, grid, b->hdr, desc, n, m_cap, out32,
                               stream);
 }

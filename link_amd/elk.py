@@ -315,15 +315,14 @@ class ElkCorePlan:
         self.buf.feats, self.buf.coords = feats.data_ptr(), coords.data_ptr()
         own = self.out
         if feats.dtype != torch.float32:
-            # fp16 / bf16 rows at the kernel boundary (AMP): fused dense-cell kernels only
-            if not (self.dense and self.c <= 64 and int(self.dcg.k) <= 352):
-                raise L.LinkAmdError("ElkCorePlan: fp16/bf16 feature rows need the fused dense-cell kernels "
-                                     "(dense layout, C <= 64, s^3 <= 352)")
+            # fp16 / bf16 rows at the kernel boundary (AMP): the fused dense-cell kernels, or the tile form of the general layout
+            if not ((self.dense and self.c <= 64 and int(self.dcg.k) <= 352) or (not self.dense and getattr(self, "tiles", False))):
+                raise L.LinkAmdError("ElkCorePlan: fp16/bf16 feature rows need the fused dense-cell kernels (dense layout, "
+                                     "C <= 64, s^3 <= 352) or the tile form of the general layout (tiles=True)")
             own = self.__dict__.setdefault("_out_half", {}).get(feats.dtype)
             if own is None and out is None:
                 own = self._out_half[feats.dtype] = torch.empty((self.n_cap, self.c), dtype=feats.dtype, device=self.device)
-        if self.dense:
-            self.buf.io_dtype = _IO_DTYPES[feats.dtype]
+        self.buf.io_dtype = _IO_DTYPES[feats.dtype]
         if out is not None:
             assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
         self.buf.out = (out if out is not None else own).data_ptr()

@@ -190,6 +190,13 @@ def test_tiles_half_rows_at_the_boundary(dtype, tol_round, tol_oracle, C, groups
         full = elk_core_fused(fh.float(), *args)
     assert got.dtype == dtype and full.dtype == torch.float32
     assert rel_err(got.float().cpu().numpy(), full.cpu().numpy()) < tol_round
+    # the plan path (one FFI call per step, link_elk_buffers_t::io_dtype): the same rows, bit for bit; the four-kernel form
+    # refuses 16-bit rows
+    tp, fp = _plan_pair(la, blk, n, C, baseop, groups, r, s, coords)
+    assert torch.equal(tp.run(fh, coords), got)
+    from link_amd._lib import LinkAmdError
+    with pytest.raises(LinkAmdError):
+        fp.run(fh, coords)
     assert rel_err(got.float().cpu().numpy(), ref) < tol_oracle
     # a module cast to half as a whole (parameters too) reads its parameters as fp32 copies: same rows out
     blk_h = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
