@@ -73,6 +73,12 @@ int link_hash_query(const int64_t *query, int64_t n1, const int64_t *target,
  * Histogram; idx<0 (or >= s) ignored.  `out` is zeroed by the call. */
 int link_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stream);
 
+/* calc_ti_weights(coords fp32[P,4] (x,y,z,batch), idx_query i64[8,P], scale) -> fp32[8,P]
+ *                                              torchsparse/nn/functional/devoxelize.py:10-48
+ * Trilinear weights of a point's 8 corner voxels (corner k = 4 dx + 2 dy + dz), zero where idx_query is -1,
+ * renormalised by (their sum + 1e-8).  One kernel, one thread per point. */
+int link_ti_weights(const float *coords, const int64_t *idx_query, int64_t p, float scale, float *w, void *stream);
+
 /* voxelize_forward_cuda(in fp[N,c], idx i32[N], counts i32[N1]) -> fp[N1,c]
  *                                             backend/voxelize/voxelize_cuda.cu:12-25,44-61
  * out[idx[i]] += in[i] / (float)counts[idx[i]].  `out` is zeroed by the call.  Generic form for an

@@ -92,6 +92,7 @@ SIGNATURES = {
     "link_hash_query": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     "link_count": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "link_ti_weights": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "link_voxelize_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                       c_void_p]),
     "link_voxelize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

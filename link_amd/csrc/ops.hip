@@ -189,6 +189,47 @@ extern "C" int link_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s
 }
 
 // ---------------------------------------------------------------------------------------------
+// trilinear weights of the 8 corner voxels of a point (calc_ti_weights, nn/functional/devoxelize.py:10-48): one thread
+// per point; the reference composes ~30 elementwise launches over [8, P] temporaries
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ti_weights(const float *__restrict__ pts, const int64_t *__restrict__ idx, int64_t p,
+                                                    float scale, float inv_div, bool scaled, float *__restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  const float4 q = *reinterpret_cast<const float4 *>(pts + 4 * i);
+  const float c[3] = {q.x, q.y, q.z};
+  float near_[3], far_[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float lo = scaled ? __fmul_rn(floorf(__fdiv_rn(c[a], scale)), scale) : floorf(c[a]);
+    const float hi = __fadd_rn(lo, scale);
+    near_[a] = __fsub_rn(hi, c[a]);                    // weight of the low corner on this axis
+    far_[a] = __fsub_rn(c[a], lo);
+  }
+  float v[8], sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {                        // corner k = 4 dx + 2 dy + dz: the order of get_kernel_offsets(2)
+    float t = __fmul_rn(__fmul_rn((k & 4) ? far_[0] : near_[0], (k & 2) ? far_[1] : near_[1]), (k & 1) ? far_[2] : near_[2]);
+    if (scaled) t = __fdiv_rn(t, inv_div);
+    if (idx[(int64_t)k * p + i] == -1) t = 0.f;
+    v[k] = t;
+    sum = __fadd_rn(sum, t);
+  }
+  const float den = __fadd_rn(sum, 1e-8f);
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[(int64_t)k * p + i] = __fdiv_rn(v[k], den);
+}
+
+extern "C" int link_ti_weights(const float *pts, const int64_t *idx_query, int64_t p, float scale, float *w, void *stream) {
+  if (p < 0 || !(scale > 0.f)) return LINK_ERR_ARG;
+  if (p == 0) return LINK_OK;
+  if (!pts || !idx_query || !w) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_ti_weights, dim3(blocks_for(p, 256)), dim3(256), 0, S(stream), pts, idx_query, p, scale,
+                     (float)((double)scale * scale * scale), scale != 1.0f, w);
+  return check_launch("link_ti_weights");
+}
+
+// ---------------------------------------------------------------------------------------------
 // voxelize forward (generic idx): one wave per input row, lanes stride the channels -> coalesced
 // row reads; fp32 atomics into the output row like the reference kernel.
 // ---------------------------------------------------------------------------------------------

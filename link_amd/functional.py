@@ -92,6 +92,15 @@ def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tenso
 def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float = 1) -> torch.Tensor:
     """Trilinear interpolation weights [8, P] of the corner voxels (corner k = 4*dx + 2*dy + dz, the order of
     get_kernel_offsets(2)), zero for absent corners, renormalised to sum to one (+1e-8)."""
+    if coords.is_cuda and coords.shape[1] == 4 and idx_query.dim() == 2 and idx_query.shape[0] == 8:
+        # one HIP kernel (link_ti_weights) instead of ~30 elementwise launches over [8, P] temporaries
+        from . import _lib as L
+        pts = coords.detach().float().contiguous()
+        idx = idx_query.long().contiguous()
+        w = torch.empty((8, pts.shape[0]), dtype=torch.float32, device=coords.device)
+        L.check(L.lib().link_ti_weights(pts.data_ptr(), idx.data_ptr(), pts.shape[0], float(scale), w.data_ptr(),
+                                        L.current_stream_handle()), "link_ti_weights")
+        return w
     with torch.no_grad():
         p = coords[:, :3]
         lo = (torch.floor(p / scale) * scale if scale != 1 else torch.floor(p)).float()

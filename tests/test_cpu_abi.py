@@ -88,6 +88,8 @@ def test_argument_validation_without_gpu():
     assert lib.link_conv_out_candidates(None, 5, i3(2, 3, 3), i3(2, 2, 2), i3(1, 1, 1), i3(4, 4, 4), None, None) == L.LINK_ERR_ARG
     assert lib.link_dc_index_ids(None, 5, None, None, None, None, None, None) == L.LINK_ERR_ARG
     assert lib.link_dc_index_ids(None, 0, ctypes.byref(L.LinkDcGrid()), None, None, None, None, None) == L.LINK_OK
+    assert lib.link_ti_weights(None, None, 10, 0.0, None, None) == L.LINK_ERR_ARG and lib.link_ti_weights(None, None, 0, 1.0, None, None) == L.LINK_OK
+    assert lib.link_ti_weights(None, None, 10, 1.0, None, None) == L.LINK_ERR_ARG
     # end of round 3: one-call pair plans, the dense-layout probe, half rows through the tile form, aux_to_voxel with the scatter
     assert lib.link_pair_plan_build(None, 0, 27, 1, 10, *([None] * 13)) == L.LINK_ERR_ARG                  # n < 1
     assert lib.link_pair_plan_build(None, 10, 65, 1, 10, *([None] * 13)) == L.LINK_ERR_ARG                 # kvol > 64

@@ -61,3 +61,59 @@ def test_voxel_to_point_gradient():
     ref = torch.zeros_like(f).index_add_(0, idx.clamp(min=0).reshape(-1),
                                          ((w * (idx >= 0))[..., None] * go[:, None, :]).reshape(-1, f.shape[1]))
     assert rel_err(f.grad.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+def test_dense_grid_path_against_the_hash_path(monkeypatch):
+    """The native forms (one dense-grid index over the points; dense cell table look-ups) against the reference algorithm on
+    the op kernels, which point sets beyond the dense-grid limit still take (pointvoxel.py: GridTooLarge): same voxel set in
+    the same (hash) order, same point -> voxel maps and counts bit for bit, same corner tables; features to rounding; the
+    gradient of the voxel means reaches the point features through the indexed kernel.  Negative coordinates, 2 batch items,
+    a full-size frame."""
+    import link_amd as la
+    from link_amd import pointvoxel as PV
+    from link_amd.index import GridTooLarge
+    g = torch.Generator().manual_seed(11)
+    P = 120000
+    pts = torch.cat([(torch.rand(P, 3, generator=g) - 0.4) * torch.tensor([90.0, 70.0, 12.0]), torch.randint(0, 2, (P, 1), generator=g).float()], 1).cuda()
+    feats = torch.randn(P, 9, generator=g).cuda()
+
+    def run(force_hash):
+        with monkeypatch.context() as mp:
+            if force_hash:
+                def boom(*a, **k):
+                    raise GridTooLarge("forced")
+                mp.setattr(PV, "BlockIndex", boom)
+                mp.setattr(PV, "foreign_neighbor_map", boom)
+            f = feats.clone().requires_grad_(True)
+            z = la.PointTensor(f, pts.clone())
+            st = la.initial_voxelize(z, 1.0, 0.5)
+            st.F.square().sum().backward()
+            v = la.point_to_voxel(st, z)
+            x2 = la.SparseTensor(torch.ones(st.C.shape[0], 4, device="cuda"), st.C, 1)
+            p = la.voxel_to_point(x2, z)
+            return st, z, v, p, f.grad
+    a, b = run(False), run(True)
+    assert torch.equal(a[0].C, b[0].C) and a[0].C.shape[0] > 50000
+    for key in ("idx_query", "counts"):
+        assert torch.equal(a[1].additional_features[key][1], b[1].additional_features[key][1]), key
+    assert rel_err(a[0].F.detach().cpu().numpy(), b[0].F.detach().cpu().numpy()) < 1e-5
+    assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) < 1e-5
+    assert torch.equal(a[1].idx_query[(1, 1, 1)], b[1].idx_query[(1, 1, 1)])
+    assert rel_err(a[2].F.detach().cpu().numpy(), b[2].F.detach().cpu().numpy()) < 1e-5
+    assert rel_err(a[3].F.detach().cpu().numpy(), b[3].F.detach().cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("scale", [1, 2, 4])
+def test_trilinear_weights_kernel_against_the_composition(scale):
+    """link_ti_weights (one kernel) against the elementwise composition of devoxelize.py:10-48 (run on the CPU copies):
+    absent corners, negative coordinates, the scale-dependent cell origin."""
+    import link_amd as la
+    g = torch.Generator().manual_seed(scale)
+    P = 20000
+    pts = torch.cat([(torch.rand(P, 3, generator=g) - 0.5) * 60.0, torch.zeros(P, 1)], 1)
+    idx = torch.randint(-1, 500, (8, P), generator=g)
+    idx[:, :5] = -1                                        # points with no corner at all: 0 / 1e-8
+    ref = la.calc_ti_weights(pts, idx, scale=scale)
+    got = la.calc_ti_weights(pts.cuda(), idx.cuda(), scale=scale)
+    assert got.is_cuda and got.shape == (8, P)
+    assert float((got.cpu() - ref).abs().max()) < 2e-6
