@@ -195,12 +195,20 @@ def small_to_large_v2(small_x: SparseTensor, large_x: SparseTensor, idx: torch.T
 def upsample_voxel(x: SparseTensor, ref_x: SparseTensor) -> SparseTensor:
     """/root/reference/segmentation/core/models/utils.py:327-340: give every fine voxel of `ref_x` the
     features of the coarse voxel of `x` that contains it (parent = floor(coord / x.stride)); a fine voxel
-    whose parent is absent gets x.F[-1] exactly as the reference's `x.F[idx_query]` with idx -1 does.
-    Runs on the HIP op kernels (sphash + wait-free sphashquery)."""
+    whose parent is absent gets x.F[-1] exactly as the reference's `x.F[idx_query]` with idx -1 does."""
     stride = x.s[0]
     x_C = torch.cat([torch.div(x.C[:, :3], stride, rounding_mode="floor").int(), x.C[:, 3:]], dim=1)
     ref_x_C = torch.cat([torch.div(ref_x.C[:, :3], stride, rounding_mode="floor").int(), ref_x.C[:, 3:]], dim=1)
-    idx_query = F.sphashquery(F.sphash(ref_x_C), F.sphash(x_C))
+    # the fine voxel's parent among the coarse voxels: one look-up per fine voxel in a dense cell table of the coarse set
+    # (hash table beyond the dense-grid limit)
+    bounds = None
+    cb = x.cmaps.get(("link_bounds", x.C.data_ptr(), x.C.shape[0]))
+    if cb is not None and not x.cmaps.get(("link_bounds_unchecked", x.C.data_ptr(), x.C.shape[0])):
+        bounds = (tuple(v // stride for v in cb[0][:3]) + (cb[0][3],), tuple(v // stride for v in cb[1][:3]) + (cb[1][3],))
+    try:
+        idx_query = foreign_neighbor_map(ref_x_C.contiguous(), 1, table_rows=x_C.contiguous(), bounds=bounds).view(-1).long()
+    except GridTooLarge:
+        idx_query = F.sphashquery(F.sphash(ref_x_C), F.sphash(x_C))
     new_tensor = SparseTensor(x.F[idx_query], ref_x.C, ref_x.s)
     new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     return new_tensor
