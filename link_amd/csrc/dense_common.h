@@ -40,7 +40,7 @@ __device__ __forceinline__ void st4i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off
 // atomic per wave and pass on a single line made the kernel 59 us instead of 8: same-address atomics serialise in the L2.)
 #define DC_STATS_SLOTS 16
 __device__ __forceinline__ void dc_index_stats_flush(int32_t *stats, int n_in, int n_first, int mx) {
-  __shared__ int s_part[4][3];
+  __shared__ int s_part[16][3];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     n_in += __shfl_xor(n_in, o, 64);

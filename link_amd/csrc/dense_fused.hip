@@ -44,7 +44,10 @@ DC_DECL_IO(dcio_bf16)
 // index: slot insert
 // ---------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
+#ifndef DC_INDEX_THREADS
+#define DC_INDEX_THREADS 256     /* 128 / 512 / 1024: no difference (A/B on one box: 37.0-38.2 us/frame, index 10.0-10.5 us with events) */
+#endif
+__global__ void __launch_bounds__(DC_INDEX_THREADS) k_dc_index(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
                                                   uint32_t *__restrict__ cnt, int4 *__restrict__ slots,
                                                   int32_t *__restrict__ vcell, int32_t *__restrict__ hdr,
                                                   int32_t *__restrict__ stats) {
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(256) k_dc_index(const int4 *__restrict__ coord
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
   int st_in = 0, st_first = 0, st_max = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
+  for (int64_t v = (int64_t)blockIdx.x * DC_INDEX_THREADS + threadIdx.x; v < n; v += (int64_t)gridDim.x * DC_INDEX_THREADS) {
     const int4 rc = coords[v];
     const unsigned ux = (unsigned)(floordiv(rc.x, g.s) - g.lo[0]), uy = (unsigned)(floordiv(rc.y, g.s) - g.lo[1]);
     const unsigned uz = (unsigned)(floordiv(rc.z, g.s) - g.lo[2]), ub = (unsigned)(rc.w - g.lo[3]);
@@ -77,9 +80,9 @@ extern "C" int link_dc_index(const int32_t *coords, int64_t n, const link_dc_gri
   if (n == 0) return LINK_OK;
   if (!coords || !cnt || !slots || !vcell || !hdr) return LINK_ERR_ARG;
   if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29)) return LINK_ERR_ARG;
-  int64_t wgs = (n + 255) / 256;
+  int64_t wgs = (n + DC_INDEX_THREADS - 1) / DC_INDEX_THREADS;
   if (wgs > 4096) wgs = 4096;
-  hipLaunchKernelGGL(k_dc_index<false>, dim3((unsigned)wgs), dim3(256), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
+  hipLaunchKernelGGL(k_dc_index<false>, dim3((unsigned)wgs), dim3(DC_INDEX_THREADS), 0, S(stream), reinterpret_cast<const int4 *>(coords), n,
                      *g, cnt, reinterpret_cast<int4 *>(slots), vcell, hdr, (int32_t *)nullptr);
   return check_launch("link_dc_index");
 }
@@ -89,9 +92,9 @@ namespace link {
 int dc_index_stats_run(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, hipStream_t st) {
   if (!b->coords || !b->cnt || !b->slots || !b->vcell || !b->hdr) return LINK_ERR_ARG;
   if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29)) return LINK_ERR_ARG;
-  int64_t wgs = (n + 255) / 256;
+  int64_t wgs = (n + DC_INDEX_THREADS - 1) / DC_INDEX_THREADS;
   if (wgs > 4096) wgs = 4096;
-  hipLaunchKernelGGL(k_dc_index<true>, dim3((unsigned)wgs), dim3(256), 0, st, reinterpret_cast<const int4 *>(b->coords), n, *g, b->cnt,
+  hipLaunchKernelGGL(k_dc_index<true>, dim3((unsigned)wgs), dim3(DC_INDEX_THREADS), 0, st, reinterpret_cast<const int4 *>(b->coords), n, *g, b->cnt,
                      reinterpret_cast<int4 *>(b->slots), b->vcell, b->hdr, stats);
   return check_launch("link_dc_index_probe");
 }
