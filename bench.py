@@ -31,6 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SHADER_CLOCK_HZ = 2.4e9
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -588,6 +589,9 @@ def main():
                 pl.frames_in_flight = ns
                 pl.set_tuning(**kw)
 
+    last_out = [None] * NS                 # what each plan's latest step RETURNED (fp32 rows: the plan's own buffer; half rows:
+                                           # its per-dtype buffer -- never read `plan.out` directly, it is the fp32 one)
+
     def timed(k, build_index=True, ns=NS):
         """EXACTLY k steps; a step = one batch of `ns` independent frames, one per stream (the frames a GPU keeps in
         flight: the unit the path shards by), so k steps are k * ns frames; barrier + synchronize on both sides."""
@@ -598,7 +602,7 @@ def main():
         for _ in range(k):
             for j in range(ns):
                 with torch.cuda.stream(streams[j]):
-                    plans[j].run(frames[j][0], frames[j][1], build_index=build_index)
+                    last_out[j] = plans[j].run(frames[j][0], frames[j][1], build_index=build_index)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
@@ -613,17 +617,37 @@ def main():
     elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt for every frame)
     # what was just timed is what gets checked: every plan's output under the timed configuration (NS frames in flight,
     # their launch geometry), kept for the comparison with the single-frame geometry below and with the oracle
-    outs_timed = [pl.out[:N].clone() for pl in plans]
+    outs_timed = [o.clone() for o in last_out]       # the rows the timed steps wrote, in the row type they were written in
     for pl in plans:
         pl.check()
+    # device-event view of the same configuration (SURVEY.md 8d asks for event medians): one event per stream after every
+    # frame; the interval between consecutive completions on ONE stream is the period of a batch in steady state
+    def batch_period_events(k):
+        geometry(NS)
+        torch.cuda.synchronize()
+        evs = [[] for _ in range(NS)]
+        for _ in range(k + 1):
+            for j in range(NS):
+                with torch.cuda.stream(streams[j]):
+                    plans[j].run(frames[j][0], frames[j][1])
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    evs[j].append(e)
+        torch.cuda.synchronize()
+        per = sorted(1e3 * a.elapsed_time(b) for ev in evs for a, b in zip(ev[:-1], ev[1:]))
+        return {"median_us": round(per[len(per) // 2], 2), "mean_us": round(sum(per) / len(per), 2), "n": len(per),
+                "note": "HIP events, one per stream after every frame: interval between consecutive completions on one stream = "
+                        "time of one batch of the frames in flight, steady state"}
+    batch_ev = batch_period_events(max(50, min(args.steps, 200)))
     elapsed_single = timed(args.steps * NS, ns=1)    # the same number of frames, one in flight
     M = plan.blocks()
     timed_check = {"frames": NS, "bitwise_equal_to_single_frame_geometry": True, "max_rel_err_vs_single_frame_geometry": 0.0}
     for j in range(NS):
-        o1 = plans[j].run(frames[j][0], frames[j][1]).float()
-        d = float((outs_timed[j].float() - o1).abs().max() / o1.abs().max())
+        o1 = plans[j].run(frames[j][0], frames[j][1])          # same frame, single-frame launch geometry
+        torch.cuda.synchronize()
+        d = float((outs_timed[j].float() - o1.float()).abs().max() / o1.float().abs().max())
         timed_check["max_rel_err_vs_single_frame_geometry"] = max(timed_check["max_rel_err_vs_single_frame_geometry"], d)
-        timed_check["bitwise_equal_to_single_frame_geometry"] &= bool(torch.equal(outs_timed[j], plans[j].out[:N]))
+        timed_check["bitwise_equal_to_single_frame_geometry"] &= bool(torch.equal(outs_timed[j], o1))
     out = plan.run(feats, coords)
     torch.cuda.synchronize()
     checksum = float(out.double().sum().item())
@@ -734,17 +758,25 @@ def main():
     achieved = kab[dom] / (core[dom] * 1e-6) / 1e9
     # memory-side bytes per launch: rocprofv3 PMC passes over this workload (tools/pmc_dc.sh -> profiles/traffic.json;
     # they cannot be collected from inside the timed process)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, mfma_cyc = None, None, {}
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj) and (N, C) == (100000, 64) and args.io == "f32":
         tdb = json.load(open(tj))
         traffic = tdb.get("kernels", {}).get(dom)
         traffic_src = tdb.get("source")
+        mfma_cyc = tdb.get("mfma_busy_cycles", {})
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "alg_bytes_per_launch": kab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
                 "layout": "dense-cell" if plan.dense else "general",
+                # north_star: MFMA utilisation of the kernel that holds the dense contraction = SQ_VALU_MFMA_BUSY_CYCLES (cycles,
+                # summed over the chip's 1024 SIMDs; PMC pass of profiles/traffic.json) / (kernel duration x 1024 SIMDs x clock)
+                "mfma_util": ({"kernel": "premix_modsum", "busy_cycles_per_launch": mfma_cyc["premix_modsum"],
+                               "frac": round(mfma_cyc["premix_modsum"] / (kern_us["premix_modsum"] * 1e-6 * 1024 * SHADER_CLOCK_HZ), 4),
+                               "note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel us x 1024 SIMDs x 2.4 GHz); the contraction is 0.82 GFLOP "
+                                       "per frame -- not a grading bound (SURVEY.md 8d)"}
+                              if "premix_modsum" in mfma_cyc and "premix_modsum" in kern_us else None),
                 "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / (args.steps * NS), 2),
                                "frac": round(ab["total"] / (elapsed / (args.steps * NS)) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "per frame: B_alg of one frame over the timed region's time per frame"},
@@ -767,6 +799,7 @@ def main():
         "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
         "value": round(total_vox * frames_timed / elapsed, 1), "unit": "voxels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "settle_steps_before_warmup": SETTLE_STEPS, "ms_per_step": round(ms, 5),
+        "ms_per_step_event_median": round(batch_ev["median_us"] * 1e-3, 5), "batch_period_events": batch_ev,
         "frames_per_step": NS * world,
         "us_per_frame": round(1e6 * elapsed / frames_timed, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
@@ -776,6 +809,9 @@ def main():
                                "cos:(3x7)^3 block forward (R_core, index rebuilt every step)",
                    "voxels_per_frame": N, "blocks_per_frame": M, "channels": C, "baseop": "cos", "groups": G,
                    "r": R, "s": S_, "frames_in_flight_per_gpu": NS,
+                   "contraction": ("fp16 hi/lo split of both operands on the f16 matrix cores, fp32 accumulate (22-bit operands, "
+                                   "exact products; fp32 instruction outside the fp16 range)" if args.io != "f16" else
+                                   "fp16 rows x fp16 hi/lo split weights on the f16 matrix cores, fp32 accumulate"),
                    "step": f"one batch of {NS} independent frames per GPU (one per HIP stream); value = voxels of all timed frames / time",
                    "parallelism": f"{world} GPU(s) x {NS} independent frames in flight (one HIP stream each), "
                                   "no data-path collective"},

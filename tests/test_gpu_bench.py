@@ -44,3 +44,17 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     chk = single["timed_configuration_check"]
     assert chk["frames"] == 3 and chk["max_rel_err_vs_single_frame_geometry"] < 2e-6
     assert single["roofline"]["bound"] == "hbm" and 0 < single["roofline"]["frac"] < 1
+
+
+def test_bench_half_rows_check_reads_what_the_step_wrote():
+    """`--io f16`: the timed steps write fp16 rows into the plan's per-dtype buffer; the line's checks must be computed from
+    THAT buffer (round 3 compared the stale fp32 buffer with itself).  Half tolerances: the single-frame geometry gives the
+    same rows up to the fp16 rounding of the output (2^-10 relative to the row's scale), the oracle on the rounded inputs
+    agrees to 6e-3 (max-norm)."""
+    d = _run(["--io", "f16", "--steps", "3", "--warmup", "2"], timeout=600)
+    chk = d["timed_configuration_check"]
+    assert chk["frames"] == 3 and 0.0 <= chk["max_rel_err_vs_single_frame_geometry"] < 2e-3
+    err = d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"]
+    assert err == err and 0.0 < err < 6e-3, err
+    assert d["dtype"].startswith("f16") and "fp16" in d["config"]["contraction"]
+    assert d["ms_per_step_event_median"] > 0 and d["batch_period_events"]["n"] >= 50
