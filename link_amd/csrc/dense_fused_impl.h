@@ -1491,7 +1491,7 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   do {                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_quad<OP, R, DD>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, KQ::LDS_BYTES + k2_pad);                   \
-    hipLaunchKernelGGL((k_dc_gather_demod_quad<OP, R, DD>), dim3((unsigned)grid), dim3(512), KQ::LDS_BYTES + k2_pad, st, b->S, \
+    hipLaunchKernelGGL((k_dc_gather_demod_quad<OP, R, DD>), dim3((unsigned)grid), dim3(KQ::THREADS), KQ::LDS_BYTES + k2_pad, st, b->S, \
                        b->cell_n, reinterpret_cast<const int4 *>(b->slots), b->w_pos, b->alpha, b->ln_w, b->ln_b, d.cg, \
                        d.coord_div, d.eps, n, g, txn, tyn, zsplit, (int)nwg, b->out,                                   \
                        reinterpret_cast<unsigned long long *>(b->tune.k2_dbg));                                       \

@@ -32,6 +32,24 @@
                           per frame with three frames in flight).  Off. */
 #endif
 
+#ifndef DC_K2Q_CW
+#define DC_K2Q_CW 3      /* consumer waves: 16 voxel slots each.  A cfg2 plane holds ~32 voxels (Poisson: more than 48 in 0.3 % of the
+                            planes), so three waves still finish a plane in ONE round and the fourth only issued instructions for empty
+                            slots (round 4; 4 = the round-3 geometry) */
+#endif
+#ifndef DC_K2Q_PMAP
+#define DC_K2Q_PMAP 1    /* the voxel -> (cell, slot) map of a plane is laid out by ONE extra wave (the mapper), two steps ahead, from the
+                            plane's count image (a lane per voxel slot: 16 broadcast LDS reads, an in-lane prefix, 15 compares), and a
+                            consumer lane reads its entry: the consumers' count prefix (LDS read, 4 DPP steps, 16 v_readlane, 45
+                            scalar-operand VALU per wave and plane) leaves the step's critical path.  Not a producer's job: with the
+                            map in their loop the producers spilled, and scratch traffic would break their counted vmcnt waits.
+                            (0 = round-3 consumers) */
+#endif
+#ifndef DC_K2Q_FMA
+#define DC_K2Q_FMA 1     /* de-modulation A0 cos + A1 sin as mul + fma (0: separate IEEE mul / mul / add like the reference's eager
+                            ops -- the difference is one rounding, 6e-8 relative, next to the hardware trig's 4e-7) */
+#endif
+
 template <int OP, int R>
 struct dc_k2q_cfg {
   using K2 = dc_k2_cfg<OP, R>;
@@ -40,7 +58,10 @@ struct dc_k2q_cfg {
   // rows): a ring of five 256-byte images (the tile's <= 64 haloed columns, requested by every producer wave alike) laid
   // into the three plane slots' 1 KB count areas -- no LDS beyond the round-2 layout, whose size the frames in flight
   // are tuned to
-  static constexpr int LDS_BYTES = PAR_OFF + 2 * 64 * 4;
+  static constexpr int MAP_OFF = PAR_OFF + 2 * 64 * 4;           // 3 voxel maps: 64 entries (cell << 12 | slot) + the plane's voxel count
+  static constexpr int MAP_BYTES = 64 * 4 + 16;
+  static constexpr int LDS_BYTES = MAP_OFF + (DC_K2Q_PMAP ? 3 * MAP_BYTES : 0);
+  static constexpr int THREADS = 256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0));     // producers + consumers (+ the mapper wave)
   static_assert(!DC_K2_SKIP || K2::G::NCOL <= 64, "one count image = one wave's 64 entries");
   static constexpr bool FITS = K2::P == 2 && 2 * LDS_BYTES <= 160 * 1024;
 };
@@ -92,7 +113,7 @@ __device__ __forceinline__ float dc_quad_sum(float v) {
 }
 
 template <int OP, int R, bool DIV>
-__global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
+__global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0)), 4) k_dc_gather_demod_quad(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
@@ -300,9 +321,52 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     }
     return;
   }
+  constexpr int CW = DC_K2Q_CW, SLOTS = 16 * CW;
+  if (DC_K2Q_PMAP && wave == CW) {
+    // ================= mapper: one wave lays out the voxel -> (cell, slot) map of every plane =================
+    // After barrier i the count image of plane i is in LDS (the producers waited for its DMA before the barrier; its ring
+    // slot is requested again only at step i + 1).  Lane v finds the cell of the plane's v-th voxel -- cells in group order,
+    // slots in id order -- from the plane's 16 interior counts (broadcast reads, four per round trip) and writes
+    // cell << 12 | slot; the consumers read the entry two barriers later (plane i is the output plane of step i + 1).
+    for (int i = 0; i <= nplanes; i++) {
+      asm volatile("s_barrier" ::: "memory");
+      if (i >= nplanes) break;
+      const uint32_t ca = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
+      int run = 0, c_ = 0, start = 0;
+#define Q_(k) "i"(((((k) / TY) + HLO) * HY + ((k) % TY) + HLO) * 4)
+#define DC_MAP4(K0)                                                                                                          \
+      {                                                                                                                      \
+        int n0, n1, n2, n3;                                                                                                  \
+        asm volatile("ds_read_b32 %0, %4 offset:%c5\n\tds_read_b32 %1, %4 offset:%c6\n\tds_read_b32 %2, %4 offset:%c7\n\t"     \
+                     "ds_read_b32 %3, %4 offset:%c8\n\ts_waitcnt lgkmcnt(0)"                                                \
+                     : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)                                                            \
+                     : "v"(ca), Q_(K0), Q_(K0 + 1), Q_(K0 + 2), Q_(K0 + 3)                                                   \
+                     : "memory");                                                                                            \
+        const int nn[4] = {n0, n1, n2, n3};                                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                   \
+          const int k = K0 + kk;                                                                                             \
+          const bool okk = (x0 + k / TY < Dx) && (y0 + k % TY < Dy);   /* wave-uniform: columns beyond the grid hold nothing */ \
+          run += okk ? nn[kk] : 0;                                                                                           \
+          if (k < 15) {                                                                                                      \
+            const bool le = run <= lane;                                                                                     \
+            c_ += le ? 1 : 0;                                                                                                \
+            start = le ? run : start;                                                                                        \
+          }                                                                                                                  \
+        }                                                                                                                    \
+      }
+      DC_MAP4(0) DC_MAP4(4) DC_MAP4(8) DC_MAP4(12)
+#undef DC_MAP4
+#undef Q_
+      const uint32_t mb = lds_base + (uint32_t)(KQ::MAP_OFF + (i % 3) * KQ::MAP_BYTES);
+      lds_wr_b32(mb + (uint32_t)(lane * 4), (c_ << 12) | ((lane - start) & 4095));
+      if (lane == 0) lds_wr_b32(mb + 256u, run);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
   // ================= consumers: one voxel per quad of lanes =================
   const int q = lane & 3, li16 = lane & 15;
-  const int qd = wave * 16 + (lane >> 2);              // 0..63: this quad's slot among the plane's voxels
+  const int qd = wave * 16 + (lane >> 2);              // 0..SLOTS-1: this quad's slot among the plane's voxels
   const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * C * IO_BYTES));
   // theta weights of the lane's channels 16 j + 4 q + e: blocks j and j + 2 share theta (channels ch and ch + 32)
   float w0[2][4], w1[2][4], w2[2][4], al[2][4];
@@ -324,28 +388,63 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
     const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
     const uint32_t recb = lds_base + (uint32_t)(K2::SPLIT_REC_OFF + (jp & 3) * K2::REC_BYTES);
     const int po = pz0 + jp - (R - 1) + HLO;
-    // inclusive prefix of the 16 cell counts: every DPP row holds all of them, so they become wave-uniform scalars
-    int incl = lds_rd_b32(ncnt + (uint32_t)(li16 * 4));
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+    int Tv, m0 = 0;
+    uint32_t mb = 0;
+    if (DC_K2Q_PMAP) {
+      // the producers laid the plane's voxel map out two steps ago (plane jp - 1): entry = cell << 12 | slot, then the voxel count
+      mb = lds_base + (uint32_t)(KQ::MAP_OFF + ((jp - 1) % 3) * KQ::MAP_BYTES);
+      int tv_;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(m0), "=&v"(tv_) : "v"(mb + (uint32_t)(qd * 4)), "v"(mb) : "memory");
+      Tv = __builtin_amdgcn_readfirstlane(tv_);
+    } else {
+      Tv = 0;
+    }
     int e_[16];
+    if (!DC_K2Q_PMAP) {
+      // inclusive prefix of the 16 cell counts: every DPP row holds all of them, so they become wave-uniform scalars
+      int incl = lds_rd_b32(ncnt + (uint32_t)(li16 * 4));
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
 #pragma unroll
-    for (int k = 0; k < 16; k++) e_[k] = __builtin_amdgcn_readlane(incl, k);
-    const int Tv = e_[15];
-    for (int base = 0; base < Tv; base += 64) {         // wave-uniform: one pass unless the plane holds more than 64 voxels
+      for (int k = 0; k < 16; k++) e_[k] = __builtin_amdgcn_readlane(incl, k);
+      Tv = e_[15];
+    }
+    for (int base = 0; base < Tv; base += SLOTS) {      // wave-uniform: one pass unless the plane holds more than SLOTS voxels
       if (dbg) tq_rounds++;
-      const bool valid = base + qd < Tv;                // quads without a voxel repeat the last one and store nothing
-      const int v = valid ? base + qd : Tv - 1;
-      int c = 0, start = 0;                             // cell of voxel v = number of prefix entries <= v; start = the last such entry
+      const bool valid = base + qd < Tv;                // quads without a voxel take the plane's first one and store nothing
+      int c, k;
+      if (DC_K2Q_PMAP) {
+        if (Tv <= 64) {                                 // wave-uniform: the map covers the plane (a second round re-reads it)
+          const int mm = base == 0 ? m0 : lds_rd_b32(mb + (uint32_t)((valid ? base + qd : 0) * 4));
+          c = valid ? (mm >> 12) : 0;
+          k = valid ? (mm & 4095) : 0;
+        } else {                                        // a plane with more voxels than the map holds (dense cells): walk the counts
+          const int v = valid ? base + qd : 0;
+          int run = 0, start = 0;
+          c = 0;
+          for (int kk = 0; kk < 15; kk++) {
+            run += lds_rd_b32(ncnt + (uint32_t)(kk * 4));
+            const bool le = run <= v;
+            c += le ? 1 : 0;
+            start = le ? run : start;
+          }
+          k = v - start;
+        }
+      } else {
+        const int v = valid ? base + qd : Tv - 1;
+        c = 0;
+        int start = 0;                                  // cell of voxel v = number of prefix entries <= v; start = the last such entry
 #pragma unroll
-      for (int k = 0; k < 15; k++) {
-        const bool le = e_[k] <= v;                     // e_ is non-decreasing and wave-uniform (scalar operands)
-        c += le ? 1 : 0;
-        start = le ? e_[k] : start;
+        for (int kk = 0; kk < 15; kk++) {
+          const bool le = e_[kk] <= v;                  // e_ is non-decreasing and wave-uniform (scalar operands)
+          c += le ? 1 : 0;
+          start = le ? e_[kk] : start;
+        }
+        k = v - start;
       }
-      const int k = v - start;
       v4f_t rq, Av[2][4];
       lds_rd9_b128(recb + (uint32_t)((c * DC_INL + (k < DC_INL ? k : 0)) * 16), abuf + (uint32_t)(c * RB + q * 16),
                    abuf + (uint32_t)(c * RB + C * 4 + q * 16), rq, Av);
@@ -363,8 +462,14 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           th[j][e] = theta_of(x, y, z, w0[j][e], w1[j][e], w2[j][e], al[j][e]);
-          big |= !(fabsf(th[j][e]) < 32768.0f);
         }
+      {                                                 // range of the fast sincos: ONE compare on the largest magnitude (an
+        float mx = fmaxf(fmaxf(fabsf(th[0][0]), fabsf(th[0][1])), fabsf(th[0][2]));   // infinity survives v_max; a NaN theta gives
+        mx = fmaxf(fmaxf(mx, fabsf(th[0][3])), fabsf(th[1][0]));                       // NaN on either path)
+        mx = fmaxf(fmaxf(mx, fabsf(th[1][1])), fabsf(th[1][2]));
+        mx = fmaxf(mx, fabsf(th[1][3]));
+        big = !(mx < 32768.0f);
+      }
       if (__builtin_expect(__any(big), 0)) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -382,8 +487,12 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_quad(
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const float A0 = Av[0][j][e], A1 = Av[1][j][e], cc_ = cs[j & 1][e], ss_ = sn[j & 1][e];
-          if (OP == LINK_OP_SIN) nv[j][e] = __fsub_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));      // linkunet.py:148
-          else nv[j][e] = __fadd_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));                         // :162
+          if (DC_K2Q_FMA) {
+            nv[j][e] = fmaf(OP == LINK_OP_SIN ? -A1 : A1, ss_, A0 * cc_);
+          } else {
+            if (OP == LINK_OP_SIN) nv[j][e] = __fsub_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));      // linkunet.py:148
+            else nv[j][e] = __fadd_rn(__fmul_rn(A0, cc_), __fmul_rn(A1, ss_));                         // :162
+          }
           s += nv[j][e];
         }
       s = dc_quad_sum(s);
