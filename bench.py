@@ -124,6 +124,33 @@ def cpu_baseline(blk, feats, coords, out, N, C, S_, R, G):
         O.set_omp(False)
         set_threads(1)
     best = max(sweep, key=lambda k: sweep[k]["voxels_per_s"])
+    # the reference's OWN compiled CPU ops (oracle/_ref/ref_backend.so: hash_cpu.cpp, count_cpu.cpp, voxelize_cpu.cpp compiled
+    # where they lie by oracle/build_ref.py in the build container; the .so travels like any built .so) on this frame's index
+    # and modulated rows -- the three reference ops of voxel_to_aux that ARE buildable and correct here (devoxelize_cpu.cpp is
+    # 8-neighbour-only: invalid at r = 3; query_cpu.cpp needs sparsehash).  A labelled sub-field, kind "reference".
+    ref_ops = None
+    try:
+        from oracle import build_ref
+        if os.path.exists(build_ref.SO):
+            rb = build_ref.load_module()
+            _, idx_q, cnts = O.voxel_to_aux_index(cc.numpy(), S_)
+            idx_t, cnt_t = torch.from_numpy(idx_q.astype("int32")), torch.from_numpy(cnts.astype("int32"))
+            xrows = torch.randn(N, 2 * C, generator=torch.Generator().manual_seed(3))
+            cc32 = cc.int().contiguous()
+
+            def tmin(fn, reps=3):
+                best_t = 1e9
+                for _ in range(reps):
+                    t0 = time.perf_counter(); fn(); best_t = min(best_t, time.perf_counter() - t0)
+                return best_t
+            ref_ops = {"kind": "reference", "threads": 1,
+                       "hash_cpu_ms": round(1e3 * tmin(lambda: rb.hash_cpu(cc32)), 3),
+                       "count_cpu_ms": round(1e3 * tmin(lambda: rb.count_cpu(idx_t, int(cnt_t.numel()))), 3),
+                       "voxelize_forward_cpu_ms": round(1e3 * tmin(lambda: rb.voxelize_forward_cpu(xrows, idx_t, cnt_t)), 2),
+                       "note": f"compiled reference ops on the full frame (N={N}, W={2 * C}), OMP_NUM_THREADS = 1 (the best point "
+                               "of the sweep), best of 3"}
+    except Exception as e:  # noqa: BLE001 -- a baseline sub-field must never take the bench line down
+        ref_ops = {"kind": "reference", "error": repr(e)[:200]}
     return {"value": sweep[best]["voxels_per_s"], "unit": "voxels/s", "cores": best, "kind": "port", "cpu_model": model,
             "sample": f"R_core on the first {sweep[best]['sample_voxels']} voxels of the same frame (C={C}) through oracle/'s OpenMP twin "
                       f"(pragmas at the reference's loop placement, voxelize_cpu.cpp:17, devoxelize_cpu.cpp:16) at the best thread "
@@ -134,6 +161,7 @@ def cpu_baseline(blk, feats, coords, out, N, C, S_, R, G):
             "single_core_port": {"value": round(one_core, 1), "cores": 1,
                                  "sample": f"{reps} full passes (N={N}) through the scalar C restatement + single-thread "
                                            f"torch dense ops, {t_cpu:.1f} s"},
+            "reference_ops": ref_ops,
             "host_cpus": os.cpu_count(), "gpu_vs_oracle_max_rel_err": err}
 
 

@@ -584,6 +584,8 @@ static int dispatch_k1_op(const link_dc_buffers_t *b, const link_dc_grid_t &g, c
   }
 }
 
+#include "dense_fused_mm_impl.h"
+
 // ---------------------------------------------------------------------------------------------
 // per-voxel de-modulate + LayerNorm, original voxel order
 // ---------------------------------------------------------------------------------------------
@@ -1523,6 +1525,10 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
 
 int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                       bool warm, hipStream_t st) {
+  if (b->tune.k1_form == 2) {                          // matrix-core sums form (dense_fused_mm_impl.h): C = 32 / 64
+    if (d.c == 64) return dispatch_k1m_op<64>(b, g, d, n, warm, st);
+    if (d.c == 32) return dispatch_k1m_op<32>(b, g, d, n, warm, st);
+  }
   switch (d.c) {
     case 16: return dispatch_k1_op<16>(b, g, d, n, warm, st);
     case 32: return dispatch_k1_op<32>(b, g, d, n, warm, st);

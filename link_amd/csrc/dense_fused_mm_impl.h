@@ -37,9 +37,26 @@
 #ifndef DC_K1M_WAVES
 #define DC_K1M_WAVES 4     /* register budget: 512 / this per lane */
 #endif
+#ifndef DC_K1M_PREFETCH
+#define DC_K1M_PREFETCH 1  /* the next tile's feature rows are requested right after this tile's contraction (0: at the end of the tile) */
+#endif
+#ifndef DC_K1M_SUM32
+#define DC_K1M_SUM32 0     /* second product on v_mfma_f32_16x16x4_f32 (exact fp32 chain; 32 instructions of 32 cycles per tile: the
+                              matrix pipe's time, 4 x what the adds would take on the VALU, ends up on the wave's critical path:
+                              2.8 k ticks per tile measured) instead of the fp16 hi/lo split on v_mfma_f32_16x16x16_f16 */
+#endif
 #ifndef DC_K1M_LCAP
 #define DC_K1M_LCAP 352    /* voxel records of one chunk of cells kept in LDS (>= 7^3: a whole cell) */
 #endif
+
+// the T 16-channel pieces of a lane's feature row: one address register, compile-time element offsets
+template <int TT, int T>
+__device__ __forceinline__ void dc_ld_row_pieces(__amdgpu_buffer_rsrc_t r, uint32_t ro, float4 (&ff)[T]) {
+  if constexpr (TT < T) {
+    ff[TT] = io_ldb4<16 * TT>(r, ro);
+    dc_ld_row_pieces<TT + 1, T>(r, ro, ff);
+  }
+}
 
 template <int C, int OP>
 struct dc_k1m_cfg {
@@ -51,13 +68,17 @@ struct dc_k1m_cfg {
   static constexpr int LCAP = DC_K1M_LCAP;
   static constexpr int PLANE = C * 16;                 // one W plane: C rows (co) x 8 halves
   static constexpr int WIMG_BYTES = KB * 2 * 4 * PLANE;   // [kb][hi | lo][g]
+  // per-channel parameter tables, transposed so that a lane (channel l16 of every block) takes ONE 16-byte read per table:
+  // LayerNorm weight [l16][cb] | bias [l16][cb] (16 x T floats each) and theta weights [l16][tb][w0 w1 w2 alpha]
+  static constexpr int LNW_OFF = WIMG_BYTES, LNB_OFF = LNW_OFF + 16 * T * 4, PW_OFF = LNB_OFF + 16 * T * 4;
+  static constexpr int W_BYTES = PW_OFF + 16 * T * 16;
   static constexpr int LIST_OFF = 0;                   // int4 (x, y, z, id) per list entry
   static constexpr int ORD_OFF = LCAP * 16;            // u8: ordinal (among the chunk's occupied cells) of every entry's cell
   static constexpr int PCS_OFF = ORD_OFF + ((LCAP + 15) / 16) * 16;   // i32[64 + 16]: padded cell id by ordinal
   static constexpr int CARRY_OFF = PCS_OFF + 80 * 4;   // P * C floats: partial sums of a cell that spans tiles
   static constexpr int WAVE_BYTES = CARRY_OFF + P * C * 4;
   static constexpr int NW = DC_K1M_NW;
-  static constexpr int LDS_BYTES = WIMG_BYTES + NW * WAVE_BYTES;
+  static constexpr int LDS_BYTES = W_BYTES + NW * WAVE_BYTES;
 };
 
 template <int C, int OP, int NB>
@@ -69,12 +90,12 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     unsigned long long *__restrict__ dbg) {
   using K = dc_k1m_cfg<C, OP>;
   constexpr int T = K::T, KB = K::KB, P = K::P, RB = K::RB;
-  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_body = 0;
+  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_mm = 0, tq_ln = 0, tq_sum = 0;
   int tq_tiles = 0;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, gq = lane >> 4;
-  char *wbase = smem_raw + K::WIMG_BYTES + wave * K::WAVE_BYTES;
+  char *wbase = smem_raw + K::W_BYTES + wave * K::WAVE_BYTES;
   int4 *list = reinterpret_cast<int4 *>(wbase + K::LIST_OFF);
   unsigned char *ordof = reinterpret_cast<unsigned char *>(wbase + K::ORD_OFF);
   int *pcs = reinterpret_cast<int *>(wbase + K::PCS_OFF);
@@ -93,15 +114,17 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     t /= Dy;
     return dc_cell(g, t % Dx, y, z, t / Dx);
   };
-  // the first chunk's cell records and counts are requested BEFORE W is staged: the two latencies overlap
-  int pc_f = 0, nv_f = 0;
-  int4 rf0 = make_int4(0, 0, 0, 0), rf1 = rf0, rf2 = rf0, rf3 = rf0;
-  if (c_begin < c_end) {
-    pc_f = cell_of(c_begin, (c_end - c_begin < 64) ? c_end - c_begin : 64);
-    rf0 = slots[(int64_t)pc_f * DC_INL + 0]; rf1 = slots[(int64_t)pc_f * DC_INL + 1];
-    rf2 = slots[(int64_t)pc_f * DC_INL + 2]; rf3 = slots[(int64_t)pc_f * DC_INL + 3];
-    nv_f = (int)csrc[pc_f];
-  }
+  // the first chunk's cell records and counts are requested BEFORE W is staged (the two latencies overlap); every later
+  // chunk's at the bottom of the chunk loop -- so these registers are live only from a request to the cell section that uses it
+  int pc = 0, nv = 0;
+  int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+  auto request_chunk = [&](int chunk) {
+    pc = cell_of(chunk, (c_end - chunk < 64) ? c_end - chunk : 64);
+    r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
+    r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
+    nv = (int)csrc[pc];
+  };
+  if (c_begin < c_end) request_chunk(c_begin);
   bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
   {
     // W image: the float4 W[co][4p .. 4p+3] is piece g = p % 4 of 16-channel block tt = p / 4; its hi / lo halves go to
@@ -128,15 +151,14 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
       w_big |= !(fmaxf(fmaxf(fabsf(wq.x), fabsf(wq.y)), fmaxf(fabsf(wq.z), fabsf(wq.w))) < 32768.0f);
     }
   }
-  // per-lane parameters: LayerNorm weight / bias of the lane's channel in every block, theta weights of its NB theta blocks
-  float lnw[T], lnb[T], pw0[NB], pw1[NB], pw2[NB], pal[NB];
-#pragma unroll
-  for (int cb = 0; cb < T; cb++) { lnw[cb] = ln_w[16 * cb + l16]; lnb[cb] = ln_b[16 * cb + l16]; }
-#pragma unroll
-  for (int tb = 0; tb < NB; tb++) {
-    const int tc = (16 * tb + l16) % cg;               // channel ch uses theta[ch % cg]
-    pw0[tb] = w_pos[3 * tc + 0]; pw1[tb] = w_pos[3 * tc + 1]; pw2[tb] = w_pos[3 * tc + 2];
-    pal[tb] = alpha ? alpha[tc] : 1.0f;
+  // parameter tables (read per tile: 16 fewer live registers than per-lane copies held for the whole kernel)
+  if (tid < C) {
+    const int cb = tid >> 4, li = tid & 15;
+    reinterpret_cast<float *>(smem_raw + K::LNW_OFF)[li * T + cb] = ln_w[tid];
+    reinterpret_cast<float *>(smem_raw + K::LNB_OFF)[li * T + cb] = ln_b[tid];
+    const int tc = tid % cg;                           // channel ch uses theta[ch % cg]; block tb < NB holds channels 16 tb + li
+    reinterpret_cast<float4 *>(smem_raw + K::PW_OFF)[li * T + cb] =
+        make_float4(w_pos[3 * tc + 0], w_pos[3 * tc + 1], w_pos[3 * tc + 2], alpha ? alpha[tc] : 1.0f);
   }
   if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
@@ -150,35 +172,33 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
   const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   const __amdgpu_buffer_rsrc_t r_n = dc_rsrc(cell_n, (uint32_t)(g.vp * 4));
   const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(feats, (uint32_t)(n * C * IO_BYTES));
+  const __amdgpu_buffer_rsrc_t r_w = dc_rsrc(w_pre, (uint32_t)(C * C * 4));
   const bool ract = lane < RB / 16;                    // lanes holding a 16-byte piece of an S row (zero rows of empty cells)
   const float inv_c = 1.0f / (float)C;
 
   for (int chunk = c_begin; chunk < c_end;) {
     const int nrem = (c_end - chunk < 64) ? c_end - chunk : 64;
     unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    // ---- cell lanes: count, padded cell id, inline records (all requested before anything is consumed) ----
-    int pc, nv;
-    int4 r0, r1, r2, r3;
-    if (chunk == c_begin) {                             // wave-uniform: the first chunk was requested before the staging
-      pc = pc_f; nv = nv_f; r0 = rf0; r1 = rf1; r2 = rf2; r3 = rf3;
-    } else {
-      pc = cell_of(chunk, nrem);
-      r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
-      r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
-      nv = (int)csrc[pc];
-    }
+    // ---- cell lanes: count, padded cell id, inline records (requested by request_chunk) ----
     nv = nv < g.k ? nv : g.k;
     nv = nv < K::LCAP ? nv : K::LCAP;
     if (lane >= nrem) nv = 0;
-    int incl = nv;                                      // inclusive prefix over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
+    // inclusive prefix over the wave: DPP row scan (zeros shifted in) + the three row totals as scalars -- no per-lane
+    // permute addresses to keep (the __shfl_up form's six address registers were spilled, and a scratch reload waits for
+    // every store in flight)
+    int incl = nv;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+    {
+      const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+      incl += gq == 0 ? 0 : (gq == 1 ? t0 : (gq == 2 ? t0 + t1 : t0 + t1 + t2));
     }
     const unsigned long long fit = __ballot(lane < nrem && incl <= K::LCAP);
     const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
-    const int Ttot = __builtin_amdgcn_readfirstlane(__shfl(incl, nfit - 1, 64));
+    const int Ttot = __builtin_amdgcn_readlane(incl, nfit - 1);
     const bool mine = lane < nfit;
     const int excl = incl - nv;
     // ordinal of this cell among the chunk's occupied cells: the column (mod 16) its sums take in the tiles' second product
@@ -209,14 +229,15 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
         st16i(r_slots, (j < nv && nv <= DC_INL && !warm) ? ((uint32_t)pc * DC_INL + j) * 16u : DC_OOB, r);
       }
       for (int k = DC_INL; k < nv; k++) {               // overflow records: insertion by id (rare)
-        const int4 r = slots[dc_slot(g, pc, k)];
+        const v4i_t rv = __builtin_amdgcn_raw_buffer_load_b128(r_slots, dc_slot(g, pc, k) * 16u, 0, 0);
+        const int rx = rv.x, ry = rv.y, rz = rv.z, rw = rv.w;      // (scalars: an int4 held across the loop went to the stack)
         ordof[excl + k] = (unsigned char)ord;
         int pos = k;
-        while (pos > 0 && list[excl + pos - 1].w > r.w) {
+        while (pos > 0 && list[excl + pos - 1].w > rw) {
           list[excl + pos] = list[excl + pos - 1];
           pos--;
         }
-        list[excl + pos] = r;
+        list[excl + pos] = make_int4(rx, ry, rz, rw);
       }
       if (nv > DC_INL && !warm)
         for (int k = 0; k < nv; k++) slots[dc_slot(g, pc, k)] = list[excl + k];
@@ -257,8 +278,8 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     };
     auto ld_rows = [&](int b, int len, float4 (&ff)[T]) {
       const int id = list[b + (l16 < len ? l16 : len - 1)].w;
-#pragma unroll
-      for (int tt = 0; tt < T; tt++) ff[tt] = io_ld4(feats, (int64_t)id * C + 16 * tt + 4 * gq);
+      const uint32_t ro = (uint32_t)id * (uint32_t)(C * IO_BYTES) + (uint32_t)(4 * gq * IO_BYTES);
+      dc_ld_row_pieces<0, T>(r_feats, ro, ff);
     };
     float4 ff[T];
     tile_t cur = {0, 0, 0, false, false};
@@ -266,21 +287,42 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     for (int base = 0; base < Ttot;) {
       const tile_t t = cur;
       const int nbase = base + t.len;
-      // ---- the tile's records: the 4 voxels this lane holds accumulator rows of (4 gq + j) ----
-      int4 rec[4];
-      int colj[4];
+      unsigned long long tqt = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      // ---- the tile's records: the 4 voxels this lane holds accumulator rows of (4 gq + j); theta and the membership
+      // column at once, so that only they stay live through the contraction ----
+      float th[NB][4], mj[4];
+      int idj[OP == LINK_OP_COSX ? 4 : 1];
+      bool big;
+      {
+        float4 pw[NB];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int vv = 4 * gq + j;
-        const int sl = base + (vv < t.len ? vv : t.len - 1);
-        rec[j] = list[sl];
-        colj[j] = (int)ordof[sl] & 15;
+        for (int tb = 0; tb < NB; tb++) pw[tb] = reinterpret_cast<const float4 *>(smem_raw + K::PW_OFF)[l16 * T + tb];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int vv = 4 * gq + j;
+          const int sl = base + (vv < t.len ? vv : t.len - 1);
+          const int4 rec = list[sl];
+          mj[j] = (vv < t.len && ((int)ordof[sl] & 15) == l16) ? 1.0f : 0.0f;   // B operand of the second product
+          if (OP == LINK_OP_COSX) idj[j] = rec.w;
+          float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
+          if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
+#pragma unroll
+          for (int tb = 0; tb < NB; tb++) {
+            th[tb][j] = theta_of(x, y, z, pw[tb].x, pw[tb].y, pw[tb].z, pw[tb].w);
+            mx = fmaxf(mx, fabsf(th[tb][j]));
+          }
+        }
+        big = !(mx < 32768.0f);                         // (an infinite theta survives v_max; a NaN gives NaN on either path)
       }
+      const uint2 mjh = make_uint2((mj[0] != 0.f ? 0x3C00u : 0u) | (mj[1] != 0.f ? 0x3C000000u : 0u),
+                                   (mj[2] != 0.f ? 0x3C00u : 0u) | (mj[3] != 0.f ? 0x3C000000u : 0u));   // 1.0h / 0
+      (void)mjh;
       // column role: the cell whose sums this lane's column (l16) receives, its S row, whether the row is complete here
       const int ord_c = t.ordF + ((l16 - t.ordF) & 15);
-      const bool col_act = ord_c < t.ordF + t.ncell;
       const int pc_c = pcs[ord_c];
-      const bool col_store = col_act && !(t.cont_out && ord_c == t.ordF + t.ncell - 1);
+      const bool col_store = ord_c < t.ordF + t.ncell && !(t.cont_out && ord_c == t.ordF + t.ncell - 1);
+      const uint32_t s_off = col_store ? (uint32_t)pc_c * (uint32_t)RB + (uint32_t)(gq * 16) : DC_OOB;
       // ---- pre_mix contraction D[voxel][co]: fp16 hi/lo split of both operands, three products, fp32 accumulation ----
       floatx4 acc[T];
 #pragma unroll
@@ -294,18 +336,41 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
           mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ff[tt].x), fabsf(ff[tt].y)), fmaxf(fabsf(ff[tt].z), fabsf(ff[tt].w))));
         }
         if (__builtin_expect(!(w_big || __any(!(mx < 32768.0f))), 1)) {
+          // B operands two blocks at a time, the next pair requested before this pair is multiplied (two register sets)
+          constexpr int NG = KB * T / 2;                // groups of two 16-channel blocks
+          auto ld_b = [&](int gi, uint4 (&bh)[2], uint4 (&bl)[2]) {
+            const int kb = gi / (T / 2), cb0 = 2 * (gi % (T / 2));
 #pragma unroll
-          for (int kb = 0; kb < KB; kb++)
+            for (int u = 0; u < 2; u++) {
+              bh[u] = *reinterpret_cast<const uint4 *>(smem_raw + ((kb * 2 + 0) * 4 + gq) * K::PLANE + (16 * (cb0 + u) + l16) * 16);
+              bl[u] = *reinterpret_cast<const uint4 *>(smem_raw + ((kb * 2 + 1) * 4 + gq) * K::PLANE + (16 * (cb0 + u) + l16) * 16);
+            }
+          };
+          auto mm_b = [&](int gi, const uint4 (&bh)[2], const uint4 (&bl)[2]) {
+            const int kb = gi / (T / 2), cb0 = 2 * (gi % (T / 2));
 #pragma unroll
-            for (int cb = 0; cb < T; cb++) {
-              const uint4 bh = *reinterpret_cast<const uint4 *>(smem_raw + ((kb * 2 + 0) * 4 + gq) * K::PLANE + (16 * cb + l16) * 16);
-              const uint4 bl = *reinterpret_cast<const uint4 *>(smem_raw + ((kb * 2 + 1) * 4 + gq) * K::PLANE + (16 * cb + l16) * 16);
-              const uint2 bh0 = make_uint2(bh.x, bh.y), bh1 = make_uint2(bh.z, bh.w);
-              const uint2 bl0 = make_uint2(bl.x, bl.y), bl1 = make_uint2(bl.z, bl.w);
+            for (int u = 0; u < 2; u++) {
+              const int cb = cb0 + u;
+              const uint2 bh0 = make_uint2(bh[u].x, bh[u].y), bh1 = make_uint2(bh[u].z, bh[u].w);
+              const uint2 bl0 = make_uint2(bl[u].x, bl[u].y), bl1 = make_uint2(bl[u].z, bl[u].w);
               if constexpr (IO != 1) acc[cb] = dc_mfma_f16x2(al[2 * kb], al[2 * kb + 1], bh0, bh1, acc[cb]);   // fp16 rows: lo = 0 exactly
               acc[cb] = dc_mfma_f16x2(ah[2 * kb], ah[2 * kb + 1], bl0, bl1, acc[cb]);
               acc[cb] = dc_mfma_f16x2(ah[2 * kb], ah[2 * kb + 1], bh0, bh1, acc[cb]);
             }
+          };
+          uint4 bhA[2], blA[2], bhB[2], blB[2];
+          ld_b(0, bhA, blA);
+#pragma unroll
+          for (int gi = 0; gi < NG; gi += 2) {
+            if (gi + 1 < NG) ld_b(gi + 1, bhB, blB);
+            mm_b(gi, bhA, blA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 1 < NG) {
+              if (gi + 2 < NG) ld_b(gi + 2, bhA, blA);
+              mm_b(gi + 1, bhB, blB);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         } else {
           // values outside the fp16 range: the fp32 instruction, B from global memory (slow, exact, wave-uniform, rare):
           // A[voxel l16][k = gq] = F[voxel][16 tt + 4 gq + e], B[k = gq][co] = W[co][16 tt + 4 gq + e]
@@ -313,33 +378,22 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
           for (int tt = 0; tt < T; tt++)
 #pragma unroll
             for (int cb = 0; cb < T; cb++) {
-              const float4 wq = *reinterpret_cast<const float4 *>(&w_pre[(16 * cb + l16) * C + 16 * tt + 4 * gq]);
+              const v4i_t wi = __builtin_amdgcn_raw_buffer_load_b128(r_w, (uint32_t)(((16 * cb + l16) * C + 16 * tt + 4 * gq) * 4), 0, 0);
+              const float4 wq = make_float4(__int_as_float(wi.x), __int_as_float(wi.y), __int_as_float(wi.z), __int_as_float(wi.w));
               acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[tt].x, wq.x, acc[cb], 0, 0, 0);
               acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[tt].y, wq.y, acc[cb], 0, 0, 0);
               acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[tt].z, wq.z, acc[cb], 0, 0, 0);
               acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[tt].w, wq.w, acc[cb], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
             }
         }
       }
       // ---- the next tile's rows are requested now: they fly while this tile goes through the VALU and the second product ----
+#if DC_K1M_PREFETCH
       if (nbase < Ttot) { cur = describe(nbase); ld_rows(nbase, cur.len, ff); }
-      // ---- theta of the lane's 4 voxels x NB theta blocks ----
-      float th[NB][4];
-      bool big = false;
-      {
-        float mx = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          float x = (float)rec[j].x, y = (float)rec[j].y, z = (float)rec[j].z;
-          if (coord_div != 1.0f) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
-#pragma unroll
-          for (int tb = 0; tb < NB; tb++) {
-            th[tb][j] = theta_of(x, y, z, pw0[tb], pw1[tb], pw2[tb], pal[tb]);
-            mx = fmaxf(mx, fabsf(th[tb][j]));
-          }
-        }
-        big = !(mx < 32768.0f);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_mm += tqb - tqt; tqt = tqb; }
       const bool slow = __any(big);
       float sn[NB][4], cs[NB][4];
       if (__builtin_expect(slow, 0)) {
@@ -354,32 +408,46 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
           for (int j = 0; j < 4; j++) sincos_small(th[tb][j], sn[tb][j], cs[tb][j]);
       }
       // ---- LayerNorm over each voxel's C channels: T in-lane values + the 16 lanes of the accumulator row ----
-      bool bad = false;                                 // a voxel whose row is not finite (its cell's sums become NaN below)
-      bool badj[4];
+      unsigned badm = 0;                                // bit j: voxel 4 gq + j is not finite (its cell's sums become NaN below)
+      {
+        float lnw[T], lnb[T];
+        if constexpr (T == 4) {
+          const float4 lw4 = reinterpret_cast<const float4 *>(smem_raw + K::LNW_OFF)[l16];
+          const float4 lb4 = reinterpret_cast<const float4 *>(smem_raw + K::LNB_OFF)[l16];
+          lnw[0] = lw4.x; lnw[1] = lw4.y; lnw[2] = lw4.z; lnw[3] = lw4.w;
+          lnb[0] = lb4.x; lnb[1] = lb4.y; lnb[2] = lb4.z; lnb[3] = lb4.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float s = 0.f;
-#pragma unroll
-        for (int cb = 0; cb < T; cb++) s += acc[cb][j];
-        s = grp_sum<16>(s);
-        const float mean = s * inv_c;
-        float qq = 0.f;
-#pragma unroll
-        for (int cb = 0; cb < T; cb++) {
-          const float d = acc[cb][j] - mean;
-          acc[cb][j] = d;
-          qq = fmaf(d, d, qq);
+          for (int cb = 0; cb < T; cb++) {
+            lnw[cb] = reinterpret_cast<const float *>(smem_raw + K::LNW_OFF)[l16 * T + cb];
+            lnb[cb] = reinterpret_cast<const float *>(smem_raw + K::LNB_OFF)[l16 * T + cb];
+          }
         }
-        qq = grp_sum<16>(qq);
-        const float rstd = __builtin_amdgcn_rsqf(fmaf(qq, inv_c, eps));
-        badj[j] = !(qq < __builtin_inff()) || (slow && !(fabsf(th[0][j]) < __builtin_inff()));
-        if (NB > 1 && slow) {
 #pragma unroll
-          for (int tb = 1; tb < NB; tb++) badj[j] |= !(fabsf(th[tb][j]) < __builtin_inff());
+        for (int j = 0; j < 4; j++) {
+          float s = 0.f;
+#pragma unroll
+          for (int cb = 0; cb < T; cb++) s += acc[cb][j];
+          s = grp_sum<16>(s);
+          const float mean = s * inv_c;
+          float qq = 0.f;
+#pragma unroll
+          for (int cb = 0; cb < T; cb++) {
+            const float d = acc[cb][j] - mean;
+            acc[cb][j] = d;
+            qq = fmaf(d, d, qq);
+          }
+          qq = grp_sum<16>(qq);
+          const float rstd = __builtin_amdgcn_rsqf(fmaf(qq, inv_c, eps));
+          bool bj = !(qq < __builtin_inff());
+          if (slow) {
+#pragma unroll
+            for (int tb = 0; tb < NB; tb++) bj |= !(fabsf(th[tb][j]) < __builtin_inff());
+          }
+          badm |= bj ? (1u << j) : 0u;
+#pragma unroll
+          for (int cb = 0; cb < T; cb++) acc[cb][j] = fmaf(acc[cb][j] * rstd, lnw[cb], lnb[cb]);
         }
-        bad |= badj[j];
-#pragma unroll
-        for (int cb = 0; cb < T; cb++) acc[cb][j] = fmaf(acc[cb][j] * rstd, lnw[cb], lnb[cb]);
       }
       if (OP == LINK_OP_COSX) {                         // the de-modulation of cos_x needs fin (linkunet.py:176)
 #pragma unroll
@@ -387,77 +455,106 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
 #pragma unroll
           for (int cb = 0; cb < T; cb++)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[cb][j]), r_fin,
-                                                  (4 * gq + j) < t.len ? (uint32_t)rec[j].w * (uint32_t)(C * 4) + (uint32_t)((16 * cb + l16) * 4) : DC_OOB,
+                                                  (4 * gq + j) < t.len ? (uint32_t)idj[j] * (uint32_t)(C * 4) + (uint32_t)((16 * cb + l16) * 4) : DC_OOB,
                                                   0, DC_ST_AUX);
       }
-      // ---- membership of the lane's 4 voxels in the lane's column: the B operand of the second product ----
-      float mj[4];
+      __builtin_amdgcn_sched_barrier(0);
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_ln += tqb - tqt; tqt = tqb; }
+      // ---- modulate -> second product -> S rows, part by part.  SAN: the tile holds a non-finite voxel (never on finite
+      // inputs): its X is kept out of the product (0 x NaN would reach the other cells' sums) and its cell's rows become NaN ----
+      auto parts = [&](auto san_tag) {
+        constexpr bool SAN = decltype(san_tag)::value;
+        unsigned nanmask = 0;                           // columns (cells) that hold a non-finite voxel
+        if constexpr (SAN) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) mj[j] = ((4 * gq + j) < t.len && colj[j] == l16) ? 1.0f : 0.0f;
-      const bool anybad = __any(bad);                   // wave-uniform, never on finite inputs
-      unsigned nanmask = 0;                             // columns (cells) that hold a non-finite voxel
-      if (__builtin_expect(anybad, 0)) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) nanmask |= (badj[j] && (4 * gq + j) < t.len) ? (1u << colj[j]) : 0u;
-        nanmask |= __shfl_xor((int)nanmask, 16, 64);
-        nanmask |= __shfl_xor((int)nanmask, 32, 64);
-      }
-      // ---- modulate -> second product -> S rows, part by part ----
-#pragma unroll
-      for (int p = 0; p < P; p++) {
-        floatx4 aS[T];
-        if (__builtin_expect(t.cont_in, 0)) {           // the first cell continues: its partial sums come from the carry row
-          const bool keep = l16 == (t.ordF & 15);
-#pragma unroll
-          for (int cb = 0; cb < T; cb++) {
-            const float4 cv = *reinterpret_cast<const float4 *>(&carry[p * C + 16 * cb + 4 * gq]);
-            aS[cb] = keep ? (floatx4){cv.x, cv.y, cv.z, cv.w} : (floatx4){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 4; j++) {
+            const int vv = 4 * gq + j;
+            const int sl = base + (vv < t.len ? vv : t.len - 1);
+            nanmask |= (((badm >> j) & 1u) && vv < t.len) ? (1u << ((int)ordof[sl] & 15)) : 0u;
           }
-        } else {
-#pragma unroll
-          for (int cb = 0; cb < T; cb++) aS[cb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+          // (row-uniform: the LayerNorm statistics are) -> the four lane groups' masks as scalars
+          nanmask = (unsigned)(__builtin_amdgcn_readlane((int)nanmask, 0) | __builtin_amdgcn_readlane((int)nanmask, 16) |
+                               __builtin_amdgcn_readlane((int)nanmask, 32) | __builtin_amdgcn_readlane((int)nanmask, 48));
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int p = 0; p < P; p++) {
+          floatx4 aS[T];
+          if (__builtin_expect(t.cont_in, 0)) {         // the first cell continues: its partial sums come from the carry row
+            const bool keep = l16 == (t.ordF & 15);
+#pragma unroll
+            for (int cb = 0; cb < T; cb++) {
+              const float4 cv = *reinterpret_cast<const float4 *>(&carry[p * C + 16 * cb + 4 * gq]);
+              aS[cb] = keep ? (floatx4){cv.x, cv.y, cv.z, cv.w} : (floatx4){0.f, 0.f, 0.f, 0.f};
+            }
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < T; cb++) aS[cb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+          }
 #pragma unroll
           for (int cb = 0; cb < T; cb++) {
             const int tb = cb % NB;
-            const float m = p == 2 ? th[tb][j] : ((p == 0) == (OP != LINK_OP_SIN) ? cs[tb][j] : sn[tb][j]);   // cos|sin (sin: sin|cos), theta
-            float xv = acc[cb][j] * m;
-            if (__builtin_expect(anybad, 0)) xv = badj[j] ? 0.f : xv;      // keeps 0 x NaN out of the other cells' sums
-            aS[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, mj[j], aS[cb], 0, 0, 0);
-          }
-        if (__builtin_expect(anybad, 0)) {
-          if ((nanmask >> l16) & 1u) {
+            float xv[4];
 #pragma unroll
-            for (int cb = 0; cb < T; cb++) aS[cb] = (floatx4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            for (int j = 0; j < 4; j++) {
+              const float m = p == 2 ? th[tb][j] : ((p == 0) == (OP != LINK_OP_SIN) ? cs[tb][j] : sn[tb][j]);   // cos|sin (sin: sin|cos), theta
+              // The product must exist as an fp32 VALUE before it is split (the empty asm pins it): hipcc otherwise folds this
+              // multiply into the split's subtraction (lo = fp16(fma(a, m, -hi)) with hi = fp16(a m) in ONE rounding) while the hi
+              // it packs for the matrix core is fp16(fp32(a m)): the two hi differ by an fp16 ulp once in ~10^4 values (double
+              // rounding) and the lo no longer matches -- tools/k1mdbg.py found it; __fmul_rn does not stop the fold
+              xv[j] = acc[cb][j] * m;
+              asm volatile("" : "+v"(xv[j]));
+              if constexpr (SAN) xv[j] = ((badm >> j) & 1u) ? 0.f : xv[j];
+            }
+#if DC_K1M_SUM32
+#pragma unroll
+            for (int j = 0; j < 4; j++) aS[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[j], mj[j], aS[cb], 0, 0, 0);
+#else
+            // X = hi + lo (fp16 pairs, 22 bits).  ONE v_mfma_f32_16x16x32_f16 per block: the lane's k = 8 gq .. 8 gq + 7 are
+            // [hi of its four voxels | lo of the same four] against [their membership flags | the same flags] as halves (any
+            // assignment of k is right as long as both operands use it); products with 0 / 1 are exact, fp32 accumulation.
+            // (As two dependent v_mfma_f32_16x16x16_f16 the lo term went missing in ~1 of 10^4 sums: tools/k1mdbg.py.)
+            uint2 xh, xl;
+            dc_split4(make_float4(xv[0], xv[1], xv[2], xv[3]), xh, xl);
+            aS[cb] = dc_mfma_f16x2(xh, xl, mjh, mjh, aS[cb]);
+#endif
+          }
+          if constexpr (SAN) {
+            if ((nanmask >> l16) & 1u) {
+#pragma unroll
+              for (int cb = 0; cb < T; cb++) aS[cb] = (floatx4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            }
+          }
+          // lane (column l16, group gq) holds S[cell][p*C + 16 cb + 4 gq .. +3]
+#pragma unroll
+          for (int cb = 0; cb < T; cb++)
+            st16(r_S, s_off + (col_store ? (uint32_t)((p * C + 16 * cb) * 4) : 0u), make_float4(aS[cb][0], aS[cb][1], aS[cb][2], aS[cb][3]));
+          __builtin_amdgcn_sched_barrier(0);
+          if (__builtin_expect(t.cont_out, 0)) {        // the last cell continues: hand its partial sums to the next tile
+            if (l16 == ((t.ordF + t.ncell - 1) & 15)) {
+#pragma unroll
+              for (int cb = 0; cb < T; cb++)
+                *reinterpret_cast<float4 *>(&carry[p * C + 16 * cb + 4 * gq]) = make_float4(aS[cb][0], aS[cb][1], aS[cb][2], aS[cb][3]);
+            }
           }
         }
-        // lane (column l16, group gq) holds S[cell][p*C + 16 cb + 4 gq .. +3]
-#pragma unroll
-        for (int cb = 0; cb < T; cb++)
-          st16(r_S, col_store ? (uint32_t)pc_c * (uint32_t)RB + (uint32_t)((p * C + 16 * cb + 4 * gq) * 4) : DC_OOB,
-               make_float4(aS[cb][0], aS[cb][1], aS[cb][2], aS[cb][3]));
-        if (__builtin_expect(t.cont_out, 0)) {          // the last cell continues: hand its partial sums to the next tile
-          if (l16 == ((t.ordF + t.ncell - 1) & 15)) {
-#pragma unroll
-            for (int cb = 0; cb < T; cb++)
-              *reinterpret_cast<float4 *>(&carry[p * C + 16 * cb + 4 * gq]) = make_float4(aS[cb][0], aS[cb][1], aS[cb][2], aS[cb][3]);
-          }
-        }
-      }
+      };
+      if (__builtin_expect(__any(badm != 0), 0)) parts(std::true_type{}); else parts(std::false_type{});
+      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_sum += tqb - tqt; }
       if (__builtin_expect(t.cont_out, 0)) __builtin_amdgcn_wave_barrier();
+#if !DC_K1M_PREFETCH
+      if (nbase < Ttot) { cur = describe(nbase); ld_rows(nbase, cur.len, ff); }
+#endif
       base = nbase;
       if (dbg) tq_tiles++;
     }
     __builtin_amdgcn_wave_barrier();
-    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_body += tqb - tqa; }
     chunk += nfit;
+    if (chunk < c_end) request_chunk(chunk);
   }
   if (dbg && lane == 0) {
     unsigned long long *d = dbg + (size_t)wid * 8;
     const unsigned long long te = __builtin_amdgcn_s_memtime();
-    d[0] = tq1 - tq0; d[1] = tq_cell; d[2] = 0; d[3] = tq_body; d[4] = 0; d[5] = te - tq0; d[6] = tq_tiles; d[7] = tq0;
+    d[0] = tq1 - tq0; d[1] = tq_cell; d[2] = tq_mm; d[3] = tq_ln; d[4] = tq_sum; d[5] = te - tq0; d[6] = tq_tiles; d[7] = tq0;
   }
 }
 

@@ -303,17 +303,22 @@ class SparseConv3d(nn.Module):
         # table[j, t] = input row at out_ind[j] * s - p + tap_t, straight from the (b, z, y, x) rows: the input sites go into the
         # workspace's cell table (kept all zero between uses), one kernel writes the table, the sites are taken out again
         shp = [int(v) for v in sct.spatial_shape]
-        from .index import _workspace
+        from .index import MAX_CELLS, _workspace
         cells = int(sct.batch_size) * shp[0] * shp[1] * shp[2]
         out_ind = out_ind.contiguous()
-        if cells < 2 ** 31:
-            site = _workspace(dev).cell_table(cells)
+        if cells <= MAX_CELLS:                           # the persistent workspace table is capped at 1 GiB (index.MAX_CELLS)
+            ws = _workspace(dev)
+            site = ws.cell_table(cells)
             shp_a = i3(*shp)
             table = torch.empty((m, len(self._taps())), dtype=torch.int32, device=dev)
-            L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 0, stream), "link_conv_site_table")
-            L.check(lib.link_conv_gather_table(out_ind.data_ptr(), m, ka, sa, pa, shp_a, int(sct.batch_size), site.data_ptr(),
-                                               table.data_ptr(), stream), "link_conv_gather_table")
-            L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 1, stream), "link_conv_site_table")
+            try:
+                L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 0, stream), "link_conv_site_table")
+                L.check(lib.link_conv_gather_table(out_ind.data_ptr(), m, ka, sa, pa, shp_a, int(sct.batch_size), site.data_ptr(),
+                                                   table.data_ptr(), stream), "link_conv_gather_table")
+                L.check(lib.link_conv_site_table(ind.data_ptr(), n, shp_a, int(sct.batch_size), site.data_ptr(), 1, stream), "link_conv_site_table")
+            except Exception:
+                ws.drop_cell_table()                     # never leave a dirty table behind for the next map
+                raise
         else:
             # A 3-wide window per axis around `base`: kernel 3 -> base = o*s - p + 1 (taps at -1, 0, +1); kernel 1 -> its tap is the centre
             rows = out_ind[:, [3, 2, 1, 0]] * mul_t + add_t                                    # (x, y, z, b) window centres

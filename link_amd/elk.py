@@ -232,7 +232,7 @@ class ElkCorePlan:
         `frames_in_flight`: one frame alone spreads every kernel over two workgroups per CU (k1_wgs 512, z-segments by
         the tile count); with several frames in flight the kernels of different frames share the CUs, so each takes one
         workgroup per CU and the gather kernel 2 z-segments (fewer halo planes summed twice).  Keyword overrides:
-        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form), k2_form, mode, k1_pipe."""
+        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form, 2 matrix-core sums form), k2_form, mode, k1_pipe."""
         if not self.dense:
             if kw:
                 raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan launch geometry "

@@ -34,11 +34,19 @@ class _Workspace:
         self.scratch = None
 
     def cell_table(self, v: int) -> torch.Tensor:
-        """int32[>= v], all zero on entry of every user (each clears what it wrote: link_cell_table_clear)."""
+        """int32[>= v], all zero on entry of every user (each clears what it wrote: link_cell_table_clear).  Persistent: it grows
+        to the largest grid this (device, stream) has seen, at most MAX_CELLS entries (1 GiB); `release_workspaces()` frees it."""
+        if v > MAX_CELLS:
+            raise GridTooLarge(f"cell table of {v} cells (> {MAX_CELLS})")
         t = self.__dict__.get("_cell_table")
         if t is None or t.numel() < v:
             t = self._cell_table = torch.zeros(max(v, 1 << 16), dtype=torch.int32, device=self.device)
         return t
+
+    def drop_cell_table(self) -> None:
+        """Forget the cell table (after a failed build / look-up / clear triple it may hold stale entries: the next user gets a
+        freshly zeroed one)."""
+        self.__dict__.pop("_cell_table", None)
 
     def ensure(self, n: int, v: int):
         if self.cell_counts is None or self.cell_counts.numel() < v:
@@ -50,6 +58,14 @@ class _Workspace:
 
 
 _workspaces: Dict[Tuple[int, int], _Workspace] = {}
+
+
+def release_workspaces(device=None) -> None:
+    """Free the per-(device, stream) scratch this module keeps between calls (cell counters, index scratch and the cell table:
+    up to 1 GiB each on a stream that has mapped a MAX_CELLS grid).  INTEGRATION.md "persistent footprint"."""
+    for key in list(_workspaces):
+        if device is None or key[0] == (device.index if getattr(device, "index", None) is not None else key[0]):
+            del _workspaces[key]
 
 
 def _workspace(device) -> _Workspace:
@@ -221,12 +237,17 @@ def foreign_neighbor_map(rows: torch.Tensor, r: int, transpose: bool = False, st
         raise GridTooLarge(f"dense block grid would need {grid.cells} cells")
     # the cell table lives in the (device, stream) workspace and is kept all zero between calls: built by m scattered
     # writes, undone by m scattered zeros -- not a memset over every cell of a sparse grid per call
-    table = _workspace(dev).cell_table(grid.cells)
+    ws = _workspace(dev)
+    table = ws.cell_table(grid.cells)
     st = L.current_stream_handle()
-    L.check(L.lib().link_cell_table_build(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), None,
-                                          st), "link_cell_table_build")
-    L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
-                                      int(step), 1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
-    L.check(L.lib().link_cell_table_clear(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), st),
-            "link_cell_table_clear")
+    try:
+        L.check(L.lib().link_cell_table_build(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), None,
+                                              st), "link_cell_table_build")
+        L.check(L.lib().link_neighbor_map(rows.data_ptr(), table.data_ptr(), ctypes.byref(grid), None, m, int(r),
+                                          int(step), 1 if transpose else 0, nbr.data_ptr(), st), "link_neighbor_map")
+        L.check(L.lib().link_cell_table_clear(src.data_ptr(), src.shape[0], ctypes.byref(grid), table.data_ptr(), st),
+                "link_cell_table_clear")
+    except Exception:
+        ws.drop_cell_table()          # the 'all zero between calls' invariant no longer holds for this table
+        raise
     return nbr

@@ -27,9 +27,10 @@ def _oracle(blk, feats, coords, s, r, baseop, groups):
     (64, 2, "cos", 7, 3, 80, 9000), (32, 2, "sin", 3, 2, 40, 6000), (16, 2, "cos", 7, 3, 256, 10000),
     (128, 2, "cos", 5, 3, 60, 7000), (64, 1, "cos_x", 3, 2, 36, 5000), (64, 1, "cos_x", 3, 3, 30, 4000),
     (32, 1, "cos", 4, 3, 50, 8000), (16, 1, "cos_x", 2, 2, 24, 3000), (128, 1, "cos_x", 4, 2, 40, 3000)])
-@pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (0, 4), (1, 4), (0, 8)])
+@pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (2, 0), (0, 4), (1, 4), (2, 4), (0, 8)])
 def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n, k1_form, k2_form):
-    """k1_form: 0 = cell-range form of the fused pre_mix kernel (the default), 1 = tile form (round 3); k2_form (C = 64): 0 =
+    """k1_form: 0 = cell-range form of the fused pre_mix kernel, 1 = tile form (round 3), 2 = matrix-core sums form (round 4;
+    C = 32 / 64, the other widths take the cell-range form); k2_form (C = 64): 0 =
     by measurement (quad consumers where the rows allow), 4 = own-cell form, 8 = pair consumers (the round-2 kernel)."""
     import link_amd as la
     torch.manual_seed(5)
@@ -77,7 +78,7 @@ def test_dense_fused_gather_cells_form_other_widths(C, groups, baseop, s, r, gri
     assert torch.equal(cells.run(feats, coords, build_index=False), oc)
 
 
-@pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (0, 4), (0, 8)])
+@pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (2, 0), (0, 4), (0, 8)])
 def test_dense_large_cells_negative_coords_batches(k1_form, k2_form):
     """Cells with many voxels (~80 per cell: the counting-rank pass of the tile form, the insertion path of the cell-range
     form), negative coordinates, two batch items."""
@@ -137,7 +138,8 @@ def test_dense_status_word_and_capacity_reuse():
     assert torch.equal(out, plan.run(feats, coords))
 
 
-@pytest.mark.parametrize("tuning", [{}, {"k1_form": 1}, {"k1_wgs": 256, "k2_zsplit": 2}, {"k1_wgs": 256, "k2_zsplit": 2, "k1_form": 1, "k1_lds_pad": 2048},
+@pytest.mark.parametrize("tuning", [{}, {"k1_form": 1}, {"k1_form": 2}, {"k1_form": 2, "k1_wgs": 256, "k2_zsplit": 2}, {"k1_form": 2, "k1_wgs": 1024},
+                                    {"k1_wgs": 256, "k2_zsplit": 2}, {"k1_wgs": 256, "k2_zsplit": 2, "k1_form": 1, "k1_lds_pad": 2048},
                                     {"k1_wgs": 1024}, {"k2_zsplit": 1}, {"k2_form": 1}, {"k2_form": 2}, {"k2_form": 4}, {"k2_form": 8}, {"k2_form": 8, "k2_zsplit": 2},
                                     {"k2_form": 4, "k2_zsplit": 2, "k1_wgs": 256}])
 def test_dense_cfg2_full_size(tuning):
