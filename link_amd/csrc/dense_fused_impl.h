@@ -1487,7 +1487,7 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
     return check_launch("link_dc_gather_demod");
   }
   if constexpr (dc_k2q_cfg<OP, R>::FITS) {             // two-part rows, theta shared by channels j / j + 32: quad consumers (bit 3: round-2 pair form)
-    if (pair && !(b->tune.k2_form & 9) && !k2_single) {
+    if (pair && !b->alpha && !(b->tune.k2_form & 9) && !k2_single) {
       using KQ = dc_k2q_cfg<OP, R>;
 #define LINK_K2Q(DD)                                                                                                  \
   do {                                                                                                                \

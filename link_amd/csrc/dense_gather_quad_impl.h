@@ -369,14 +369,14 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
   const int qd = wave * 16 + (lane >> 2);              // 0..SLOTS-1: this quad's slot among the plane's voxels
   const __amdgpu_buffer_rsrc_t r_out = dc_rsrc(out, (uint32_t)(n * C * IO_BYTES));
   // theta weights of the lane's channels 16 j + 4 q + e: blocks j and j + 2 share theta (channels ch and ch + 32)
-  float w0[2][4], w1[2][4], w2[2][4], al[2][4];
+  // (no alpha here: the launcher sends blocks with a theta scale -- cos_x only in the reference, linkunet.py:165 -- to the other forms)
+  float w0[2][4], w1[2][4], w2[2][4];
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int tc = (16 * j + 4 * q + e) % cg;
       w0[j][e] = w_pos[3 * tc + 0]; w1[j][e] = w_pos[3 * tc + 1]; w2[j][e] = w_pos[3 * tc + 2];
-      al[j][e] = alpha ? alpha[tc] : 1.0f;
     }
   const uint32_t par = lds_base + (uint32_t)KQ::PAR_OFF + (uint32_t)(q * 16);
   for (int i = 0; i <= nplanes; i++) {
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
       for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          th[j][e] = theta_of(x, y, z, w0[j][e], w1[j][e], w2[j][e], al[j][e]);
+          th[j][e] = fmaf(z, w2[j][e], fmaf(y, w1[j][e], x * w0[j][e]));      // theta_of without the scale
         }
       {                                                 // range of the fast sincos: ONE compare on the largest magnitude (an
         float mx = fmaxf(fmaxf(fabsf(th[0][0]), fabsf(th[0][1])), fabsf(th[0][2]));   // infinity survives v_max; a NaN theta gives

@@ -58,3 +58,25 @@ def test_bench_half_rows_check_reads_what_the_step_wrote():
     assert err == err and 0.0 < err < 6e-3, err
     assert d["dtype"].startswith("f16") and "fp16" in d["config"]["contraction"]
     assert d["ms_per_step_event_median"] > 0 and d["batch_period_events"]["n"] >= 50
+
+
+def test_bench_cfg4_two_ranks_checksums_match_one_rank_and_the_committed_ones():
+    """BASELINE.json configs[3] (`--workload cfg4`: 8 S-kitti frames sharded by frame): two ranks over gloo on the one device
+    give the same eight per-frame checksums as one rank -- the frames are independent, whichever rank runs them -- and both
+    equal tests/golden/g_cfg4_checksums.json (recorded from a 1-GPU run; what an 8-GPU run's line is to be compared with).
+    Seeds 0, 1 and 7 of these frames are checked against the oracle in tests/test_gpu_encoder.py."""
+    one = _run(["--workload", "cfg4", "--gpus", "1", "--steps", "1", "--warmup", "1"], timeout=600)
+    two = _run(["--workload", "cfg4", "--gpus", "2", "--steps", "1", "--warmup", "1"],
+               {"LINK_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"}, timeout=600)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["config"]["frames"] == two["config"]["frames"] == 8
+    assert one["config"]["frames_per_rank"] == 8 and two["config"]["frames_per_rank"] == 4
+    a, b = one["frame_checksums"], two["frame_checksums"]
+    assert len(a) == len(b) == 8
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 1e-6 * abs(x), (a, b)
+    with open(os.path.join(ROOT, "tests", "golden", "g_cfg4_checksums.json")) as f:
+        gold = json.load(f)
+    assert gold["voxels"] == one["config"]["voxels"]
+    for x, y in zip(a, gold["frame_checksums"]):
+        assert abs(x - y) <= 1e-5 * abs(y), (a, gold["frame_checksums"])

@@ -17,7 +17,10 @@ torch.manual_seed(2)
 blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev).eval()
 feats = torch.randn(N, C, generator=torch.Generator().manual_seed(1)).to(dev)
 coords = s_uniform(N, seed=0).to(dev)
-p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, ((0, 0, 0, 0), (255, 255, 255, 0)), dev, layout=layout)
+tune = {k: int(os.environ[e]) for k, e in (("k1_form", "DC_K1_FORM"), ("k1_wgs", "DC_K1_WGS"), ("k2_zsplit", "DC_K2_ZSPLIT"),
+                                           ("k2_form", "DC_K2_FORM")) if os.environ.get(e) not in (None, "")}
+p = la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, ((0, 0, 0, 0), (255, 255, 255, 0)), dev, layout=layout,
+                   **(tune if layout == "dense" else {}))
 p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
        blk.norm.weight, blk.norm.bias)
 for _ in range(steps):
