@@ -220,3 +220,57 @@ def test_oracle_vs_compiled_reference_ops():
     w = rng.random((700, 8)).astype(np.float32)
     c = ref.devoxelize_forward_cpu(torch.from_numpy(top), torch.from_numpy(ind), torch.from_numpy(w)).numpy()
     assert np.array_equal(c, O.spdevoxelize_fwd(top, ind, w))   # K=8: identical op order
+
+
+@pytest.mark.parametrize("name", golden_files("g_agg_*.npz"))
+def test_aggregate_fixture_indices_hold_by_definition(name):
+    """Pins the fixtures' `idx_query` / `nbr` arrays -- which went through the oracle's restatement of hash_query_cpu when they
+    were generated (query_cpu.cpp needs sparsehash: oracle/ref_bind.cpp) -- on the DEFINITIONS of utils.py:44-58 and :61-73,
+    with nothing from oracle/ in the check: (a) small_c is the sorted unique set of floor(coords / s) rows (torch.unique order);
+    (b) small_c[idx_query[i]] is voxel i's block; (c) counts is its histogram; (d) small_c[nbr[m, k]] == small_c[m] + offset_k
+    wherever nbr >= 0, and where nbr == -1 that block is absent (checked against a Python set); offsets in the reference's
+    get_kernel_offsets order (nn/utils/kernel.py:11-32), restated here by its rule: odd volume x fastest, even volume z fastest."""
+    g = load_golden(name)
+    s, r = g["meta"]["s"], g["meta"]["r"]
+    coords = g["coords"].astype(np.int64)
+    blk = np.concatenate([np.floor_divide(coords[:, :3], s), coords[:, 3:]], 1)
+    small_c = g["small_c"].astype(np.int64)
+    assert np.array_equal(small_c, np.unique(blk, axis=0))                                  # (a) sorted unique rows
+    assert np.array_equal(small_c[g["idx_query"]], blk)                                     # (b)
+    assert np.array_equal(g["counts"], np.bincount(g["idx_query"], minlength=small_c.shape[0]))   # (c)
+    if "nbr" not in g:
+        return
+    ax = list(range(-r // 2 + 1, r // 2 + 1))
+    offs = [(x, y, z) for z in ax for y in ax for x in ax] if (r ** 3) % 2 == 1 else [(x, y, z) for x in ax for y in ax for z in ax]
+    present = {tuple(row) for row in small_c.tolist()}
+    nbr = g["nbr"]
+    assert nbr.shape == (small_c.shape[0], r ** 3)
+    for k, (dx, dy, dz) in enumerate(offs):
+        want = small_c + np.array([dx, dy, dz, 0])
+        hit = nbr[:, k] >= 0
+        assert np.array_equal(small_c[nbr[hit, k]], want[hit]), f"offset {k}"
+        assert not any(tuple(row) in present for row in want[~hit].tolist()), f"offset {k}: a present block reported absent"
+    assert (nbr >= 0).any(axis=1).all()                                                     # the own block is always there
+
+
+@pytest.mark.parametrize("name", golden_files("g_pointvoxel_*.npz"))
+def test_pointvoxel_fixture_indices_hold_by_definition(name):
+    """The same for the point <-> voxel fixtures (core/models/utils.py:234-324): idx_query maps every point to the voxel that
+    holds floor(point / voxel size) -- vox_C[idx_query[i]] equals the point's cell row -- and counts is its histogram; the
+    v2p index arrays name, for every point and corner, a voxel whose coordinate IS that corner (or -1 with the corner absent)."""
+    g = load_golden(name)
+    vox_c = g["vox_C"].astype(np.int64)
+    cell = np.concatenate([np.floor(g["z_C"][:, :3]).astype(np.int64), g["z_C"][:, 3:].astype(np.int64)], 1)
+    assert np.array_equal(vox_c[g["idx_query"]], cell)
+    assert np.array_equal(g["counts"], np.bincount(g["idx_query"], minlength=vox_c.shape[0]))
+    assert len({tuple(r) for r in vox_c.tolist()}) == vox_c.shape[0]                        # voxels are unique
+    present = {tuple(r): j for j, r in enumerate(vox_c.tolist())}
+    if "v2p1_idx" not in g:
+        return
+    idx = g["v2p1_idx"]
+    offs = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]                      # get_kernel_offsets(2): z fastest
+    for k, (dx, dy, dz) in enumerate(offs):
+        want = cell + np.array([dx, dy, dz, 0])
+        got = idx[:, k]
+        exp = np.array([present.get(tuple(r), -1) for r in want.tolist()])
+        assert np.array_equal(got, exp), f"corner {k}"
