@@ -272,18 +272,18 @@ def core_roofline(torch, blocks, step, iters=20):
 def cfg3_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[2] shape (labelled, NOT the headline): the encoder common to both segmentation models
     (stem -> 4 x [k2-s2 down, 2 residual blocks + tail || ELKBlock cos_x (2x3)^3 + tail, add/ReLU],
-    linkencoder.py:186-368; assembled in link_amd/networks.py from link_amd modules) on one S-kitti frame per
+    linkencoder.py:186-368; assembled in harness/networks.py from link_amd modules) on one S-kitti frame per
     rank (link_amd/synth.py, seed = rank; full size, ~113k voxels), warm kernel maps.  A step = one eval
     forward; the line also carries forward+backward (sum-of-squares loss on stage 4) and the time inside the
     four ELK blocks."""
     import torch
-    from link_amd import networks as LE
+    from harness import networks as LE
     from link_amd.synth import s_kitti, block_stats
     co, fe = s_kitti(seed=rank)
     coords, feats = torch.from_numpy(co).to(dev), torch.from_numpy(fe).to(dev)
     n = coords.shape[0]
     torch.manual_seed(0)
-    # the reference's ELKEncoder encoder half, class by class (link_amd/networks.py mirrors linkencoder.py:186-290
+    # the reference's ELKEncoder encoder half, class by class (harness/networks.py mirrors linkencoder.py:186-290
     # with the reference's attribute names), its Conv3d -> BatchNorm -> ReLU runs fused for inference
     net = la.fuse_for_inference(LE.build_reference_shaped_encoder(la, 64, "cos_x", 1)).to(dev)
     net.elk = [getattr(net, f"elk{i}") for i in (1, 2, 3, 4)]
@@ -368,7 +368,7 @@ def cfg4_mode(args, la, dev, rank, world, dist):
     result gather").  A step = the whole batch once: every rank runs the encoder half of ELKEncoder (eval forward,
     Conv-BN-ReLU fused) on its frames, kernel maps built per frame as the reference does."""
     import torch
-    from link_amd import networks as LE
+    from harness import networks as LE
     from link_amd.parallel import gather_frame_rows, shard_frames
     from link_amd.synth import s_kitti
     mine = shard_frames(8, world, rank)
@@ -465,7 +465,7 @@ def cfg5_mode(args, la, dev, rank, world, dist):
     if args.bev:
         # what BASELINE.json's configs[4] names in full: backbone + CenterPoint head.  The BEV half is plain torch in the
         # reference as well (vendor dense-convolution library), outside the LinK hot path: timed separately and together
-        from link_amd.bevhead import BevHalf
+        from harness.bevhead import BevHalf
         half = BevHalf(num_input_features=bev.shape[1]).to(dev).eval()
         half = half.to(feats.dtype) if feats.dtype != torch.float32 else half
 
@@ -527,7 +527,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="independent frames in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bev", action="store_true",
-                    help="cfg5: also run the dense BEV half (RPN + CenterHead in plain torch, link_amd/bevhead.py) behind the backbone")
+                    help="cfg5: also run the dense BEV half (RPN + CenterHead in plain torch, harness/bevhead.py) behind the backbone")
     ap.add_argument("--io", choices=("f32", "f16", "bf16"), default="f32",
                     help="feature-row type at the kernel boundary (f32 = the headline; f16/bf16: AMP rows, fp32 inside)")
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2",

@@ -109,4 +109,4 @@ def oracle_stages(lo, sd, feats, coords, s, r, baseop="cos_x", groups=1, n_stage
     return outs
 
 
-from link_amd.networks import build_reference_shaped_encoder  # noqa: E402,F401  (moved into the package: bench.py uses it)
+from harness.networks import build_reference_shaped_encoder  # noqa: E402,F401  (moved into the package: bench.py uses it)

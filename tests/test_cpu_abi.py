@@ -246,7 +246,7 @@ def test_bev_half_harness_shapes():
     """The plain-torch stand-in of the detection model's dense half (RPN + CenterHead; outside the hot path, used by
     `bench.py --workload cfg5 --bev`): six tasks, the config's head widths, predictions at the BEV map's resolution."""
     import torch
-    from link_amd.bevhead import BevCenterHead, BevHalf
+    from harness.bevhead import BevCenterHead, BevHalf
     m = BevHalf().eval()
     with torch.no_grad():
         out = m(torch.randn(1, 256, 20, 20))

@@ -115,13 +115,13 @@ def test_encoder_vs_reference_network_fixture():
 def test_whole_unet_vs_reference_network_fixture():
     """SURVEY.md section 8 row b7, decoder half included: the REFERENCE's ELKUNet (linkunet.py:186-385), run unmodified by
     the imported reference on its CPU path (tests/golden/make_golden_unet.py; r = 2: every number reference output), against
-    link_amd.networks.build_reference_shaped_unet with the reference's state_dict loaded strict=True.  Beyond the encoder
+    harness.networks.build_reference_shaped_unet with the reference's state_dict loaded strict=True.  Beyond the encoder
     this pins the transposed convolutions (which require the kernel map cached by the matching down-convolution,
     conv.py:122-138), torchsparse.cat with the skips, the rectangular residual blocks (2C -> C with a 1x1 shortcut) and the
     classifier -- plain and with every Conv-BN(-ReLU) run fused for inference."""
     import link_amd as la
     from helpers import load_golden
-    from link_amd.networks import build_reference_shaped_unet
+    from harness.networks import build_reference_shaped_unet
     g = load_golden("g_unet_cosx_s3_r2.npz")
     sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
     for fuse in (False, True):

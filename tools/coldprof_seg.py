@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 
 import link_amd as la
-from link_amd import aggregate, elk, index, networks as LE
+from link_amd import aggregate, elk, index
+from harness import networks as LE
 from link_amd.synth import s_kitti
 
 acc = {}

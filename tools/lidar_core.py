@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 
 import link_amd as la
-from link_amd import networks as LE
+from harness import networks as LE
 from link_amd.elk import ElkCorePlan
 from link_amd.index import coords_bounds
 from link_amd.synth import s_kitti, s_nusc
