@@ -727,6 +727,20 @@ int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
+/* One call = one R_core step on the SPARSE-CELL layout (round 4): the dense-cell addressing (table row, counter and slot list of a
+ * block at its padded grid cell) with a sparse iteration, for frames that occupy a few percent of their block grid (LiDAR:
+ * linkunet.py:345-363 call sites) -- three launches with the index rebuilt, no scan / sort / block numbering:
+ *   slot insert + `occ[i]` = the cell voxel i was the first of (0 otherwise) + cell_n of the previous frame's cells (its marks
+ *   occ_prev[0 .. n_prev)) back to zero  ->  fused pre_mix + LayerNorm + modulate + per-cell sums over the cells marked in each
+ *   wave's range of voxel ids  ->  fused r^3 neighbour sum (a neighbour is present iff cell_n > 0) + de-modulate + LayerNorm.
+ * Buffers as link_elk_core_dense_forward (cnt, cell_n zero-filled once; S, slots need no initialisation beyond row 0 of S being
+ * zero; A, sid, vrec unused) plus two i32[n_cap] mark arrays the caller alternates between steps: `occ` is written (read when
+ * build_index = 0), `occ_prev` / `n_prev` are the marks and voxel count of the previous indexed step on these buffers (n_prev = 0
+ * on the first).  C in {16, 32, 64}, r in {2, 3}, slot capacity g->k <= 64 (a cell is one wave's serial work; frames with
+ * bigger blocks belong on section C's tile form).  Replaces utils.py:44-84 + query_cuda.cu:9-58 on such frames. */
+int link_elk_core_sparse_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
+                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index, int32_t *occ,
+                                 const int32_t *occ_prev, int64_t n_prev, void *stream);
 /* The slot insert of a step (the form buf->tune picks) that also reports the frame's occupancy on this grid: stats
  * i32[16][16] (device, zeroed by the caller): 16 partial slots on separate cache lines, [k][0] += voxels inside the grid,
  * [k][1] += occupied cells, [k][2] max= fullest cell's count -- the reader sums / sums / maxes over k.  For the

@@ -72,13 +72,20 @@ struct dc_k1_cfg {
 #ifndef DC_K1_WAVES
 #define DC_K1_WAVES 2     /* register budget = 512 / this; LDS (80 KB per workgroup) allows 2 workgroups per CU anyway, and at 3 the tile body spills (A/B: LINK_AMD_CXXFLAGS=-DDC_K1_WAVES=3) */
 #endif
-template <int C, int OP, int NB, bool PIPE>
+// SPARSE (round 4, the sparse-cell layout of LiDAR-shaped frames: dense_gather_sparse_impl.h): the cells a wave owns are
+// not a range of the grid but the cells whose FIRST voxel (insert rank 0) has an id in the wave's range of voxel ids --
+// `occ[i]` = that cell for voxel i, 0 otherwise (written by k_dc_index_sparse).  Every occupied cell is owned exactly once,
+// no cell of the (mostly empty) grid is visited for nothing, no zero rows are written: absent neighbours are recognised by
+// cell_n == 0 in the gather kernel.  Which wave owns a cell varies from run to run (the atomic ranks do); what it computes
+// for the cell does not (records in id order, sums in that order).
+template <int C, int OP, int NB, bool PIPE, bool SPARSE = false>
 __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsum(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
     int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
     float coord_div, float eps, int64_t n, link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_,
-    float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg) {
+    float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg,
+    const int32_t *__restrict__ occ = nullptr) {
   using K = dc_k1_cfg<C, OP>;
   // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime deltas
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_fill = 0, tq_body = 0, tq_sum = 0;
@@ -96,13 +103,14 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   char *xbuf = wbase + K::X_OFF;
   // the first chunk's cell records and counts are requested BEFORE W is staged: the two latencies overlap
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
-  const int Vi = Dx * Dy * Dz * g.dim[3];
+  const int Vi = SPARSE ? (int)n : Dx * Dy * Dz * g.dim[3];
   const int wid = blockIdx.x * K::NW + wave;
   const int c_begin = wid * cpw;
   const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
   auto cell_of = [&](int chunk, int nrem) {
     const int q = chunk + (lane < nrem ? lane : 0);
+    if constexpr (SPARSE) return (int)occ[q];          // 0 = this voxel is not the first of its cell: an idle lane (count 0)
     const int z = q % Dz;
     int t = q / Dz;
     const int y = t % Dy;
@@ -236,13 +244,15 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
         for (int k = 0; k < nv; k++) slots[dc_slot(g, pc, k)] = list[excl + k];
     }
     {                                                   // publish the counts, reset the counters
-      const uint32_t coff = (lane < nfit && !warm) ? (uint32_t)pc * 4u : DC_OOB;
+      const uint32_t coff = (lane < nfit && !warm && (!SPARSE || pc != 0)) ? (uint32_t)pc * 4u : DC_OOB;
       st4i(r_n, coff, nv);
       st4i(r_cnt, coff, 0);
     }
-    for (unsigned long long em = __ballot(lane < nfit && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
-      const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
-      st16(r_S, ract ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
+    if constexpr (!SPARSE) {
+      for (unsigned long long em = __ballot(lane < nfit && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
+        const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
+        st16(r_S, ract ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -554,6 +564,42 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
                      b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
                      reinterpret_cast<unsigned long long *>(b->tune.k1_dbg));
   return check_launch("link_dc_premix_modsum");
+}
+
+// sparse-cell layout: one chunk of 64 voxel ids per wave (the cells those voxels were first in)
+template <int C, int OP, int NB>
+static int launch_k1_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                            bool warm, const int32_t *occ, hipStream_t st) {
+  using K = dc_k1_cfg<C, OP>;
+  const int cpw = 64;
+  const int64_t wgs = (n + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
+  if (K::LDS_BYTES > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, false, true>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st,
+                     b->feats, reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
+                     b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
+                     reinterpret_cast<unsigned long long *>(b->tune.k1_dbg), occ);
+  return check_launch("link_dc_premix_modsum(sparse)");
+}
+template <int C, int OP>
+static int dispatch_k1s_nb(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                           bool warm, const int32_t *occ, hipStream_t st) {
+  constexpr int T = C / 16;
+  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
+  if (nb > T) nb = T;
+  if (T >= 2 && nb == T / 2) return launch_k1_sparse<C, OP, (T >= 2 ? T / 2 : 1)>(b, g, d, n, warm, occ, st);
+  if (T >= 4 && nb == T / 4) return launch_k1_sparse<C, OP, (T >= 4 ? T / 4 : 1)>(b, g, d, n, warm, occ, st);
+  return launch_k1_sparse<C, OP, T>(b, g, d, n, warm, occ, st);
+}
+template <int C>
+static int dispatch_k1s_op(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                           bool warm, const int32_t *occ, hipStream_t st) {
+  switch (d.op) {
+    case LINK_OP_COS: return dispatch_k1s_nb<C, LINK_OP_COS>(b, g, d, n, warm, occ, st);
+    case LINK_OP_SIN: return dispatch_k1s_nb<C, LINK_OP_SIN>(b, g, d, n, warm, occ, st);
+    default: return dispatch_k1s_nb<C, LINK_OP_COSX>(b, g, d, n, warm, occ, st);
+  }
 }
 
 template <int C, int OP, int NB>
@@ -1523,6 +1569,8 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   return check_launch("link_dc_gather_demod");
 }
 
+#include "dense_gather_sparse_impl.h"
+
 int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                       bool warm, hipStream_t st) {
   if (b->tune.k1_form == 2) {                          // matrix-core sums form (dense_fused_mm_impl.h): C = 32 / 64
@@ -1533,6 +1581,15 @@ int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
     case 16: return dispatch_k1_op<16>(b, g, d, n, warm, st);
     case 32: return dispatch_k1_op<32>(b, g, d, n, warm, st);
     default: return dispatch_k1_op<64>(b, g, d, n, warm, st);
+  }
+}
+
+int run_premix_modsum_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
+                             bool warm, const int32_t *occ, hipStream_t st) {
+  switch (d.c) {
+    case 16: return dispatch_k1s_op<16>(b, g, d, n, warm, occ, st);
+    case 32: return dispatch_k1s_op<32>(b, g, d, n, warm, occ, st);
+    default: return dispatch_k1s_op<64>(b, g, d, n, warm, occ, st);
   }
 }
 

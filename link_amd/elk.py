@@ -164,7 +164,7 @@ class ElkCorePlan:
 
     def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
                  coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0,
-                 frames_in_flight: int = 1, **tuning):
+                 frames_in_flight: int = 1, slot_cap: int = 0, sparse_auto: bool = False, **tuning):
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
         self.frames_in_flight = max(1, int(frames_in_flight))
         self._tuning = dict(tuning)
@@ -173,14 +173,29 @@ class ElkCorePlan:
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
         self.device = device
-        if layout not in ("auto", "dense", "general"):
-            raise ValueError(f"layout must be auto|dense|general, got {layout!r}")
-        dcg = L.dc_grid_from(self.grid) if layout != "general" else None
+        if layout not in ("auto", "dense", "general", "sparse"):
+            raise ValueError(f"layout must be auto|dense|general|sparse, got {layout!r}")
+        try:
+            dcg = L.dc_grid_from(self.grid, int(slot_cap) if slot_cap else 0) if layout != "general" else None
+        except L.LinkAmdError:
+            if layout in ("dense", "sparse"):
+                raise
+            dcg = None
         ok = dcg is not None and self._dense_supported(dcg, n_cap, c, r, self.parts)
         if layout == "dense" and not ok:
             raise L.LinkAmdError("ElkCorePlan(layout='dense'): width / r / grid size not supported by the "
                                  "dense-cell path (include/link_amd.h section E)")
-        self.dense = ok and (layout == "dense" or dcg.vp <= dense_ratio * max(n_cap, 1))
+        self.dense = ok and (layout == "dense" or (layout == "auto" and dcg.vp <= dense_ratio * max(n_cap, 1)))
+        # sparse-cell layout (round 4): dense-cell addressing, sparse iteration -- frames that occupy a few percent of their
+        # block grid with small blocks (slot capacity <= 64: S-kitti stages; link_elk_core_sparse_forward).  Explicit, or what
+        # "auto" picks when the grid is too empty for the dense-cell kernels but its tables are still addressable.
+        sp_ok = dcg is not None and self._sparse_supported(dcg, n_cap, c, r, self.parts)
+        if layout == "sparse" and not sp_ok:
+            raise L.LinkAmdError("ElkCorePlan(layout='sparse'): needs C in {16,32,64}, r in {2,3}, slot capacity <= 64 and tables "
+                                 "below 4 GiB (include/link_amd.h, link_elk_core_sparse_forward)")
+        self.sparse = (not self.dense) and sp_ok and (layout == "sparse" or (layout == "auto" and sparse_auto))
+        if self.sparse:
+            self.dense = True                            # same buffers and one-call structure; run() picks the entry point
         self.dcg = dcg if self.dense else None
         self.out = torch.empty((n_cap, c), dtype=torch.float32, device=device)
         self.fin = torch.empty((n_cap, c), dtype=torch.float32, device=device)
@@ -195,6 +210,12 @@ class ElkCorePlan:
         # 32-bit byte offsets in every table, and a slot arena (vp * k records of 16 B) of at most 1 GiB
         return (c in (16, 32, 64, 128) and r in (2, 3) and (dcg.vp + 1) * parts * c * 4 < 2 ** 32
                 and n_cap * c * 4 < 2 ** 32 and dcg.vp * dcg.k * 16 <= 2 ** 30)
+
+    @staticmethod
+    def _sparse_supported(dcg, n_cap: int, c: int, r: int, parts: int) -> bool:
+        # 32-bit byte offsets in every table (S: (vp + 1) rows, slots: vp * k records); memory is touched only where voxels land
+        return (c in (16, 32, 64) and r in (2, 3) and int(dcg.k) <= 64 and (dcg.vp + 1) * parts * c * 4 < 2 ** 32
+                and n_cap * c * 4 < 2 ** 32 and dcg.vp * dcg.k * 16 < 2 ** 32)
 
     @classmethod
     def would_be_dense(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, dense_ratio: float = 4.0) -> bool:
@@ -215,14 +236,28 @@ class ElkCorePlan:
         self.vrec = torch.empty((n_cap, 4), **i32)
         self.vcell = torch.empty(n_cap, **i32)
         self.cell_n = torch.zeros(vp, **i32)
-        self.S = torch.zeros((vp + 1, w), **f32)                       # border rows stay zero
-        self.A = torch.zeros((vp + 1, w), **f32)
+        if self.sparse:
+            # rows are touched only where voxels land; row 0 (what absent neighbours point at) must be zero, the rest needs no
+            # initialisation (a row is read only if its cell's count says it was written this frame)
+            self.S = torch.empty((vp + 1, w), **f32)
+            self.S[0].zero_()
+            self.A = self.S[:1]                          # not used by the sparse path
+        else:
+            self.S = torch.zeros((vp + 1, w), **f32)                   # border rows stay zero
+            self.A = torch.zeros((vp + 1, w), **f32)
         b = self.buf = L.LinkDcBuffers()
         b.cnt, b.slots, b.vrec, b.vcell = self.cnt.data_ptr(), self.slots.data_ptr(), self.vrec.data_ptr(), self.vcell.data_ptr()
         b.cell_n, b.hdr, b.fin = self.cell_n.data_ptr(), self.hdr.data_ptr(), self.fin.data_ptr()
         b.S, b.A, b.out = self.S.data_ptr(), self.A.data_ptr(), self.out.data_ptr()
-        self.sid = torch.empty(vp * max(int(g.k), 8), **i32)          # voxel ids per cell (tile form of the fused pre_mix kernel)
-        b.sid = self.sid.data_ptr()
+        if self.sparse:
+            # first-voxel marks of the current / previous indexed frame (alternating), and that frame's voxel count
+            self.occ = [torch.zeros(n_cap, **i32), torch.zeros(n_cap, **i32)]
+            self._occ_cur, self._n_prev = 0, 0
+            self.sid = None
+            b.sid = None
+        else:
+            self.sid = torch.empty(vp * max(int(g.k), 8), **i32)          # voxel ids per cell (tile form of the fused pre_mix kernel)
+            b.sid = self.sid.data_ptr()
         self._fn = L.lib().link_elk_core_dense_forward
         self.m_cap = vp
         self.set_tuning(**self._tuning)
@@ -327,7 +362,16 @@ class ElkCorePlan:
             assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
         self.buf.out = (out if out is not None else own).data_ptr()
         st = L.current_stream_handle()
-        if self.dense:
+        if self.dense and self.sparse:
+            if build_index:
+                self._occ_cur ^= 1
+            cur, prev = self.occ[self._occ_cur], self.occ[self._occ_cur ^ 1]
+            rc = L.lib().link_elk_core_sparse_forward(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
+                                                      int(bool(build_index)), cur.data_ptr(), prev.data_ptr(),
+                                                      int(self._n_prev) if build_index else 0, st)
+            if build_index:
+                self._n_prev = n
+        elif self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n, int(build_index), st)
         else:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
