@@ -62,6 +62,60 @@ struct dc_k1_cfg {
   static constexpr int LDS_BYTES = W_BYTES + NW * WAVE_BYTES;
 };
 
+
+// Cell section of the sparse-cell kernels: the records of a chunk's cells into a block-major LDS list, cooperatively.
+// LiDAR blocks hold 5-27 voxels: the dense form's per-cell-lane fetch (4 inline records + a serial loop of dependent loads for
+// the rest, an insertion sort in LDS) took 40-90 us per wave there.  Here the cell lanes only lay out WHERE each list position
+// comes from (scell[p] = its cell, sseg[p] = the cell's first position | count << 16); then every lane takes positions
+// p = lane, lane + 64 and loads slot (cell, p - first) -- all records in one round trip -- and, when the slot order is still the
+// insert's (SORT: rank order of the atomics), finds its place in the cell's id order by counting smaller ids in LDS and writes
+// the record there (and back to the slot list, so that later readers find id order).  At most DC_SP_LCAP records per chunk.
+#define DC_SP_LCAP 128
+template <bool SORT>
+__device__ __forceinline__ void dc_sparse_fetch(const link_dc_grid_t &g, __amdgpu_buffer_rsrc_t r_slots, int lane, bool mine, int pc,
+                                                int nv, int excl, int Ttot, int4 *list, int *scell, int *sseg, int *tmp_id) {
+  if (mine)
+    for (int k = 0; k < nv; k++) { scell[excl + k] = pc; sseg[excl + k] = excl | (nv << 16); }
+  __builtin_amdgcn_wave_barrier();
+  int4 rec[DC_SP_LCAP / 64];
+  int seg[DC_SP_LCAP / 64], pcj[DC_SP_LCAP / 64];
+#pragma unroll
+  for (int i = 0; i < DC_SP_LCAP / 64; i++) {
+    const int p = lane + 64 * i;
+    const bool on = p < Ttot;
+    pcj[i] = on ? scell[p] : 0;
+    seg[i] = on ? sseg[p] : 0;
+    const v4i_t rv = __builtin_amdgcn_raw_buffer_load_b128(r_slots, on ? dc_slot(g, pcj[i], p - (seg[i] & 0xFFFF)) * 16u : DC_OOB, 0, 0);
+    rec[i] = make_int4(rv.x, rv.y, rv.z, rv.w);
+  }
+  if constexpr (SORT) {
+#pragma unroll
+    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
+      const int p = lane + 64 * i;
+      if (p < Ttot) tmp_id[p] = rec[i].w;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
+      const int p = lane + 64 * i;
+      if (p < Ttot) {
+        const int st = seg[i] & 0xFFFF, len = seg[i] >> 16;
+        int r = 0;
+        for (int q = 0; q < len; q++) r += tmp_id[st + q] < rec[i].w;
+        list[st + r] = rec[i];
+        st16i(r_slots, dc_slot(g, pcj[i], r) * 16u, rec[i]);      // id order goes back to the slot list
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
+      const int p = lane + 64 * i;
+      if (p < Ttot) list[p] = rec[i];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // NB = number of distinct 16-channel theta blocks of a voxel: channel ch uses theta[ch % cg]; when cg is a
 // multiple of 16 the MFMA channel block tp (channels 16 tp + 4 g + r of lane group g) uses theta block
 // tp % (cg/16), so a lane evaluates 4*NB sincos per voxel instead of 4*T; otherwise NB = T.
@@ -121,8 +175,10 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   int4 rf0 = make_int4(0, 0, 0, 0), rf1 = rf0, rf2 = rf0, rf3 = rf0;
   if (c_begin < c_end) {
     pc_f = cell_of(c_begin, (c_end - c_begin < 64) ? c_end - c_begin : 64);
-    rf0 = slots[(int64_t)pc_f * DC_INL + 0]; rf1 = slots[(int64_t)pc_f * DC_INL + 1];
-    rf2 = slots[(int64_t)pc_f * DC_INL + 2]; rf3 = slots[(int64_t)pc_f * DC_INL + 3];
+    if constexpr (!SPARSE) {
+      rf0 = slots[(int64_t)pc_f * DC_INL + 0]; rf1 = slots[(int64_t)pc_f * DC_INL + 1];
+      rf2 = slots[(int64_t)pc_f * DC_INL + 2]; rf3 = slots[(int64_t)pc_f * DC_INL + 3];
+    }
     nv_f = (int)csrc[pc_f];
   }
   bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
@@ -189,12 +245,15 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
       pc = pc_f; nv = nv_f; r0 = rf0; r1 = rf1; r2 = rf2; r3 = rf3;
     } else {
       pc = cell_of(chunk, nrem);
-      r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
-      r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
+      if constexpr (!SPARSE) {
+        r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
+        r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
+      }
       nv = (int)csrc[pc];
     }
+    constexpr int LCAPX = SPARSE ? DC_SP_LCAP : K::LCAP;
     nv = nv < g.k ? nv : g.k;
-    nv = nv < K::LCAP ? nv : K::LCAP;
+    nv = nv < LCAPX ? nv : LCAPX;
     if (lane >= nrem) nv = 0;
     int incl = nv;                                      // inclusive prefix over the wave
 #pragma unroll
@@ -202,10 +261,16 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
       const int u = __shfl_up(incl, o, 64);
       if (lane >= o) incl += u;
     }
-    const unsigned long long fit = __ballot(lane < nrem && incl <= K::LCAP);
+    const unsigned long long fit = __ballot(lane < nrem && incl <= LCAPX);
     const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
     const int Ttot = __builtin_amdgcn_readfirstlane(__shfl(incl, nfit - 1, 64));
-    if (lane < nfit) {
+    if constexpr (SPARSE) {
+      // cooperative fetch (dc_sparse_fetch): list positions [0, 128) of the wave's list, sseg behind scell's first 128 entries,
+      // the id scratch behind the list's first 128 records
+      int *sseg = scell + DC_SP_LCAP, *tmp_id = reinterpret_cast<int *>(list + DC_SP_LCAP);
+      if (warm) dc_sparse_fetch<false>(g, r_slots, lane, lane < nfit, pc, nv, incl - nv, Ttot, list, scell, sseg, tmp_id);
+      else dc_sparse_fetch<true>(g, r_slots, lane, lane < nfit, pc, nv, incl - nv, Ttot, list, scell, sseg, tmp_id);
+    } else if (lane < nfit) {
       const int excl = incl - nv;
       // order the inline records by voxel id: keys id*4+slot through a 5-exchange network
       int k0 = nv > 0 ? r0.w * 4 + 0 : INT_MAX, k1 = nv > 1 ? r1.w * 4 + 1 : INT_MAX;
@@ -566,12 +631,19 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
   return check_launch("link_dc_premix_modsum");
 }
 
-// sparse-cell layout: one chunk of 64 voxel ids per wave (the cells those voxels were first in)
+// sparse-cell layout: voxel ids per wave (the cells those voxels were first in).  Small frames want many light waves (the
+// general layout's tile form runs ONE 16-voxel tile per wave below 32 k voxels for the same reason: a wave is a chain of
+// dependent round trips, and 47 waves of 64 voxels took 36 us on a 3 k-voxel frame); tune.k1_wgs > 0 overrides (sweeps)
+static inline int dc_sparse_ids_per_wave(const link_dc_buffers_t *b, int64_t n) {
+  if (b->tune.k1_wgs > 0 && b->tune.k1_wgs <= 64) return b->tune.k1_wgs;
+  return n <= 32768 ? 8 : 16;                          // measured on the S-kitti stage frames (tools/lidar_core.py, IPW sweep)
+}
+// sparse-cell layout: the fused pre_mix kernel over ranges of voxel ids
 template <int C, int OP, int NB>
 static int launch_k1_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                             bool warm, const int32_t *occ, hipStream_t st) {
   using K = dc_k1_cfg<C, OP>;
-  const int cpw = 64;
+  const int cpw = dc_sparse_ids_per_wave(b, n);
   const int64_t wgs = (n + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
   if (K::LDS_BYTES > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, false, true>),
@@ -1586,6 +1658,11 @@ int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
 
 int run_premix_modsum_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                              bool warm, const int32_t *occ, hipStream_t st) {
+  if (b->tune.k1_form == 2 && d.op != LINK_OP_COSX) {  // matrix-core sums form on request (measured slower here: 78 against 50 us on
+                                                       // S-kitti stage 1; its cos_x instantiation spills): the cell-range form is the default
+    if (d.c == 64) return dispatch_k1ms<64>(b, g, d, n, warm, occ, st);
+    if (d.c == 32) return dispatch_k1ms<32>(b, g, d, n, warm, occ, st);
+  }
   switch (d.c) {
     case 16: return dispatch_k1s_op<16>(b, g, d, n, warm, occ, st);
     case 32: return dispatch_k1s_op<32>(b, g, d, n, warm, occ, st);

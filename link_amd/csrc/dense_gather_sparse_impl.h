@@ -29,14 +29,15 @@ struct dc_gs_cfg {
   static constexpr int P = op_parts<OP>::value;
   static constexpr int RS = P * C;                     // floats of one table row
   static constexpr int R3 = R * R * R;
-  static constexpr int LCAP = 128;                     // records of one chunk of cells in LDS (>= the largest cell: 64)
+  static constexpr int LCAP = DC_SP_LCAP;              // records of one chunk of cells in LDS (>= the largest cell: 64)
   static constexpr int WP = 4 * G < 64 ? 4 * G : 64;   // positions per pass: 4 voxel steps per lane group
   static constexpr int STEPS = WP / G;
   static constexpr int RMAX = WP / 2 < 8 ? WP / 2 : 8; // blocks whose neighbour sums sit in LDS at a time
   static constexpr int NW = 4;
   static constexpr int LIST_OFF = 0;
   static constexpr int SCELL_OFF = LCAP * 16;
-  static constexpr int A_OFF = SCELL_OFF + LCAP * 4;
+  static constexpr int SSEG_OFF = SCELL_OFF + LCAP * 4;
+  static constexpr int A_OFF = SSEG_OFF + LCAP * 4;
   static constexpr int NB_OFF = A_OFF + RMAX * RS * 4;
   static constexpr int CN_OFF = NB_OFF + ((RMAX * R3 * 4 + 15) & ~15);
   static constexpr int RUN_OFF = CN_OFF + ((RMAX * R3 * 4 + 15) & ~15);
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(256) k_dc_gather_demod_sparse(
     const float *__restrict__ S, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const int32_t *__restrict__ occ, const float *__restrict__ fin, const float *__restrict__ w_pos,
     const float *__restrict__ alpha, const float *__restrict__ ln_w, const float *__restrict__ ln_b, int cg, float coord_div,
-    float eps, int64_t n, link_dc_grid_t g, void *__restrict__ out) {
+    float eps, int64_t n, link_dc_grid_t g, int ipw, void *__restrict__ out) {
   using K = dc_gs_cfg<C, OP, R>;
   constexpr int LPR = K::LPR, G = K::G, P = K::P, RS = K::RS, R2 = R * R, R3 = K::R3, WP = K::WP;
   constexpr int LO = -((R + 1) / 2) + 1;               // nn/utils/kernel.py:21: r = 2 -> {0, 1}, r = 3 -> {-1, 0, 1}
@@ -59,13 +60,15 @@ __global__ void __launch_bounds__(256) k_dc_gather_demod_sparse(
   char *wbase = smem_raw + wave * K::WAVE_BYTES;
   int4 *list = reinterpret_cast<int4 *>(wbase + K::LIST_OFF);
   int32_t *scell = reinterpret_cast<int32_t *>(wbase + K::SCELL_OFF);
+  int32_t *sseg = reinterpret_cast<int32_t *>(wbase + K::SSEG_OFF);
+  const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
   float *A_lds = reinterpret_cast<float *>(wbase + K::A_OFF);
   int32_t *nb_lds = reinterpret_cast<int32_t *>(wbase + K::NB_OFF);
   int32_t *cn_lds = reinterpret_cast<int32_t *>(wbase + K::CN_OFF);
   int32_t *run_cell = reinterpret_cast<int32_t *>(wbase + K::RUN_OFF);
-  const int64_t c_begin = ((int64_t)blockIdx.x * K::NW + wave) * 64;
+  const int64_t c_begin = ((int64_t)blockIdx.x * K::NW + wave) * ipw;       // ipw <= 64 voxel ids per wave
   if (c_begin >= n) return;                            // wave-uniform; nothing below is a workgroup barrier
-  const int c_end = (int)(c_begin + 64 < n ? c_begin + 64 : n);
+  const int c_end = (int)(c_begin + ipw < n ? c_begin + ipw : n);
   // parameters of this lane's four channels
   const int ch0 = 4 * li;
   float w0[4], w1[4], w2[4], al[4];
@@ -85,8 +88,6 @@ __global__ void __launch_bounds__(256) k_dc_gather_demod_sparse(
     int nv = pc ? cell_n[pc] : 0;
     nv = nv < g.k ? nv : g.k;
     nv = nv < K::LCAP ? nv : K::LCAP;
-    const int4 r0 = slots[(int64_t)pc * DC_INL + 0], r1 = slots[(int64_t)pc * DC_INL + 1];
-    const int4 r2 = slots[(int64_t)pc * DC_INL + 2], r3 = slots[(int64_t)pc * DC_INL + 3];
     int incl = nv;                                      // inclusive prefix over the wave (DPP row scan + row totals)
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
@@ -100,18 +101,8 @@ __global__ void __launch_bounds__(256) k_dc_gather_demod_sparse(
     const unsigned long long fit = __ballot(lane < nrem && incl <= K::LCAP);
     const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
     const int Ttot = __builtin_amdgcn_readlane(incl, nfit - 1);
-    if (lane < nfit && nv > 0) {                        // the records are in id order already (the pre_mix kernel wrote them back)
-      const int excl = incl - nv;
-      if (nv > 0) { list[excl + 0] = r0; scell[excl + 0] = pc; }
-      if (nv > 1) { list[excl + 1] = r1; scell[excl + 1] = pc; }
-      if (nv > 2) { list[excl + 2] = r2; scell[excl + 2] = pc; }
-      if (nv > 3) { list[excl + 3] = r3; scell[excl + 3] = pc; }
-      for (int k = DC_INL; k < nv; k++) {
-        list[excl + k] = slots[dc_slot(g, pc, k)];
-        scell[excl + k] = pc;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+    // the records are in id order already (the pre_mix kernel wrote them back): all of them in one round trip
+    dc_sparse_fetch<false>(g, r_slots, lane, lane < nfit, pc, nv, incl - nv, Ttot, list, scell, sseg, nullptr);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // ---- passes of WP positions of the block-major list ----
@@ -261,13 +252,14 @@ template <int C, int OP, int R>
 static int launch_gs(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                      const int32_t *occ, hipStream_t st) {
   using K = dc_gs_cfg<C, OP, R>;
-  const int64_t wgs = (n + 64 * K::NW - 1) / (64 * K::NW);
+  const int ipw = dc_sparse_ids_per_wave(b, n);
+  const int64_t wgs = (n + (int64_t)ipw * K::NW - 1) / ((int64_t)ipw * K::NW);
   if (K::LDS_BYTES > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_gather_demod_sparse<C, OP, R>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
   hipLaunchKernelGGL((k_dc_gather_demod_sparse<C, OP, R>), dim3((unsigned)wgs), dim3(256), K::LDS_BYTES, st, b->S, b->cell_n,
                      reinterpret_cast<const int4 *>(b->slots), occ, b->fin, b->w_pos, b->alpha, b->ln_w, b->ln_b, d.cg,
-                     d.coord_div, d.eps, n, g, b->out);
+                     d.coord_div, d.eps, n, g, ipw, b->out);
   return check_launch("link_dc_gather_demod(sparse)");
 }
 

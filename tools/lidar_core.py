@@ -27,7 +27,7 @@ def capture(blocks, step):
     def wrap(b, f0):
         def core(st, s_eff, r, w_pos, alpha, cg, coord_div):
             rec.append(dict(blk=b, coords=st.C.contiguous(), feats=st.F.contiguous().float(), s_eff=int(s_eff), r=int(r), w_pos=w_pos,
-                            alpha=alpha, cg=int(cg), coord_div=float(coord_div)))
+                            alpha=alpha, cg=int(cg), coord_div=float(coord_div), stride=int(st.s[0]) if hasattr(st, "s") else 1))
             return f0(st, s_eff, r, w_pos, alpha, cg, coord_div)
         return core
     for b, f0 in zip(blocks, saved):
@@ -91,10 +91,19 @@ def main():
         with torch.no_grad():
             ref = b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]).float()
             row["module_warm_us"] = round(ev_time(lambda: b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]), iters), 1)
-            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True))):
+            cap = max(1, r["s_eff"] // max(r["stride"], 1)) ** 3      # voxel sites of a block at this tensor stride
+            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), ("sparse", dict(layout="sparse", slot_cap=cap, **({"k1_wgs": int(os.environ["IPW"])} if os.environ.get("IPW") else {})))):
                 if os.environ.get("FORM", name) != name:
                     continue
-                plan = ElkCorePlan(n, c, b.baseop, r["cg"], r["r"], r["s_eff"], bounds, dev, coord_div=r["coord_div"], layout=layout, **kw)
+                if name == "sparse" and (cap > 64 or c not in (16, 32, 64)):
+                    continue                                 # big blocks stay on the general layout's tile form
+                kw = dict(kw)
+                try:
+                    plan = ElkCorePlan(n, c, b.baseop, r["cg"], r["r"], r["s_eff"], bounds, dev, coord_div=r["coord_div"],
+                                       layout=kw.pop("layout", layout), **kw)
+                except la._lib.LinkAmdError as e:
+                    row[name + "_skipped"] = str(e)[:80]
+                    continue
                 plan.bind(b.pre_mix[0].weight, b.pre_mix[1].weight, b.pre_mix[1].bias, r["w_pos"], r["alpha"], b.norm.weight, b.norm.bias)
                 got = plan.run(feats, coords, build_index=True).clone()
                 m = plan.blocks()
@@ -102,7 +111,7 @@ def main():
                 t_cold = ev_time(lambda: plan.run(feats, coords, build_index=True), iters)
                 t_warm = ev_time(lambda: plan.run(feats, coords, build_index=False), iters)
                 again = plan.run(feats, coords, build_index=False)
-                row.update({"m": m, "cells": int(plan.grid.cells), "roof_us": round(alg / 8e12 * 1e6, 2),
+                row.update({"m": m, "cells": int(plan.grid.cells), "slot_cap": cap, "roof_us": round(alg / 8e12 * 1e6, 2),
                             name + "_cold_us": round(t_cold, 1), name + "_warm_us": round(t_warm, 1),
                             name + "_frac_warm": round(alg / 8e12 * 1e6 / t_warm, 4), name + "_err": float((got - ref).abs().max()),
                             name + "_repeat_bitwise": bool(torch.equal(got, again))})
