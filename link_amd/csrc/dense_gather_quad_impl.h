@@ -86,6 +86,37 @@ __device__ __forceinline__ void lds_rd8_b128(uint32_t a0, uint32_t a1, v4f_t (&x
                : "v"(a0), "v"(a1)
                : "memory");
 }
+#ifndef DC_K2Q_OVERLAP
+#define DC_K2Q_OVERLAP 1   /* consumers: theta / sincos run while the eight A-row pieces are still on their way (LDS returns in order:
+                              the record is waited for alone), and the LayerNorm weights are requested before the statistics'
+                              reductions instead of after them -- two LDS latencies off the round's dependent chain (0: round-3 order) */
+#endif
+// The same nine reads, but only the FIRST (the record) is waited for: LDS reads return in order, so lgkmcnt(8) means "the record
+// is here"; lds_wait_pieces() later makes the eight A pieces valid (guide section 5.7 form (ii): the waiting statement names them "+v").
+__device__ __forceinline__ void lds_rd9_b128_rec_first(uint32_t ar, uint32_t a0, uint32_t a1, v4f_t &r, v4f_t (&x)[2][4]) {
+  asm volatile("ds_read_b128 %0, %9\n\t"
+               "ds_read_b128 %1, %10\n\tds_read_b128 %2, %10 offset:64\n\tds_read_b128 %3, %10 offset:128\n\tds_read_b128 %4, %10 offset:192\n\t"
+               "ds_read_b128 %5, %11\n\tds_read_b128 %6, %11 offset:64\n\tds_read_b128 %7, %11 offset:128\n\tds_read_b128 %8, %11 offset:192\n\t"
+               "s_waitcnt lgkmcnt(8)"
+               : "=&v"(r), "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[0][3]), "=&v"(x[1][0]), "=&v"(x[1][1]),
+                 "=&v"(x[1][2]), "=&v"(x[1][3])
+               : "v"(ar), "v"(a0), "v"(a1)
+               : "memory");
+}
+__device__ __forceinline__ void lds_rd8_b128_nowait(uint32_t a0, uint32_t a1, v4f_t (&x)[2][4]) {
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:192\n\t"
+               "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:64\n\tds_read_b128 %6, %9 offset:128\n\tds_read_b128 %7, %9 offset:192"
+               : "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[0][3]), "=&v"(x[1][0]), "=&v"(x[1][1]), "=&v"(x[1][2]),
+                 "=&v"(x[1][3])
+               : "v"(a0), "v"(a1)
+               : "memory");
+}
+__device__ __forceinline__ void lds_wait_pieces(v4f_t (&x)[2][4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3])
+               :
+               : "memory");
+}
 // the counts of a lane's N row pieces: N reads in flight, one wait
 template <int N>
 __device__ __forceinline__ void lds_rd_counts(uint32_t base, const uint32_t (&off)[N], int (&cn)[N]) {
@@ -446,8 +477,12 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
         k = v - start;
       }
       v4f_t rq, Av[2][4];
-      lds_rd9_b128(recb + (uint32_t)((c * DC_INL + (k < DC_INL ? k : 0)) * 16), abuf + (uint32_t)(c * RB + q * 16),
-                   abuf + (uint32_t)(c * RB + C * 4 + q * 16), rq, Av);
+      if (DC_K2Q_OVERLAP)
+        lds_rd9_b128_rec_first(recb + (uint32_t)((c * DC_INL + (k < DC_INL ? k : 0)) * 16), abuf + (uint32_t)(c * RB + q * 16),
+                               abuf + (uint32_t)(c * RB + C * 4 + q * 16), rq, Av);
+      else
+        lds_rd9_b128(recb + (uint32_t)((c * DC_INL + (k < DC_INL ? k : 0)) * 16), abuf + (uint32_t)(c * RB + q * 16),
+                     abuf + (uint32_t)(c * RB + C * 4 + q * 16), rq, Av);
       int4 rec = make_int4(__float_as_int(rq.x), __float_as_int(rq.y), __float_as_int(rq.z), __float_as_int(rq.w));
       if (k >= DC_INL) {                                // overflow records (cells with more than DC_INL voxels): ordinary loads
         const int pcell = ((b * PDx + x0 + c / TY + 1) * PDy + y0 + c % TY + 1) * PDz + po;
@@ -481,6 +516,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
 #pragma unroll
           for (int e = 0; e < 4; e++) sincos_small(th[j][e], sn[j][e], cs[j][e]);
       }
+      if (DC_K2Q_OVERLAP) lds_wait_pieces(Av);          // the A pieces arrived while theta / sincos were evaluated
       float nv[4][4], s = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -495,6 +531,8 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
           }
           s += nv[j][e];
         }
+      v4f_t gwb[2][4];                                  // LayerNorm weight | bias pieces q, q+4, q+8, q+12
+      if (DC_K2Q_OVERLAP) lds_rd8_b128_nowait(par, par + 256u, gwb);      // land during the two reductions below
       s = dc_quad_sum(s);
       const float mean = s * (1.0f / C);
       float qq = 0.f;
@@ -507,8 +545,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
         }
       qq = dc_quad_sum(qq);
       const float rs = __builtin_amdgcn_rsqf(qq * (1.0f / C) + eps);
-      v4f_t gwb[2][4];                                  // LayerNorm weight | bias pieces q, q+4, q+8, q+12
-      lds_rd8_b128(par, par + 256u, gwb);
+      if (DC_K2Q_OVERLAP) lds_wait_pieces(gwb); else lds_rd8_b128(par, par + 256u, gwb);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         float4 o;
