@@ -277,6 +277,13 @@ class ElkCorePlan:
         multi = self.frames_in_flight > 1
         t.k1_wgs, t.k2_zsplit = (256, 2) if multi else (512, 0)
         t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = t.k1_pipe = 0
+        if not multi and self.c in (32, 64) and self.baseop != "cos_x" and "k1_form" not in kw:
+            # one frame alone: the matrix-core sums form at four waves per SIMD (4096 waves) -- 49.6-50.3 us per step against
+            # 52.8-53.3 for the cell-range form (A/B on one box, round 4); with frames in flight the cell-range form at one
+            # wave per SIMD leaves more of the CU to the other frames' kernels (35.9 against 37.9 us/frame)
+            t.k1_form = 2
+            if "k1_wgs" not in kw:
+                t.k1_wgs = 1024
         for k, v in kw.items():
             if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg", "k2_dbg"):
                 raise L.LinkAmdError(f"ElkCorePlan.set_tuning: unknown key {k!r}")

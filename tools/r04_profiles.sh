@@ -1,14 +1,14 @@
 #!/bin/bash
-# tools/r03_profiles.sh -- everything profiles/r03_* is made from, one gpurun call:
+# tools/r04_profiles.sh -- everything profiles/r04_* is made from, one gpurun call:
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (3 frames in flight) and of --streams 1
 #   2. the default bench line, the half-row line and the labelled cfg3 / cfg5 lines (these carry per-stage R_core rooflines)
 #   2b. R_core on the LiDAR stage frames: tools/lidar_core.py table + kernel traces of two stages
 #   3. PMC passes (FETCH_SIZE / WRITE_SIZE / TCC hit+miss / SQ; counters only, separate passes) over tools/dcstep.py
 #      (cold steps, one stream) -> pmc_counters.txt -> traffic.json (tools/traffic_json.py)
-# TAG=<name> bash tools/r03_profiles.sh ; results under gpurun_out/r03_<TAG>/  (copy into profiles/ as r03_<TAG>_*)
+# TAG=<name> bash tools/r04_profiles.sh ; results under gpurun_out/r04_<TAG>/  (copy into profiles/ as r04_<TAG>_*)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r03_${TAG:-x}
+OUT=$R/gpurun_out/r04_${TAG:-x}
 rm -rf $OUT; mkdir -p $OUT
 for ST in 3 1; do
   D=$OUT/trace_s$ST; mkdir -p $D
@@ -26,7 +26,7 @@ timeout 300 python $R/bench.py --workload cfg5 --steps 30 --warmup 3 2>/dev/null
 timeout 300 python $R/bench.py --workload cfg5 --io f16 --steps 30 --warmup 3 2>/dev/null | grep '^{' > $OUT/bench_cfg5_f16.json
 # R_core on the LiDAR stage frames (cfg3 / cfg5 stages, tools/lidar_core.py): event-timed table over the 8 stages, both forms
 # of the general layout, then kernel traces of the tile form on a cfg3 and a cfg5 stage
-timeout 300 python $R/tools/lidar_core.py 2>/dev/null | grep '^{' > $OUT/lidar_stages.jsonl
+timeout 400 python $R/tools/lidar_core.py 2>/dev/null | grep '^{' > $OUT/lidar_stages.jsonl
 for s in 0 4; do
   D=$OUT/trace_lidar$s; mkdir -p $D
   FORM=tiles STAGE=$s ITERS=100 timeout 150 rocprofv3 --kernel-trace --stats -d $D -o trace -- python $R/tools/lidar_core.py > $D/log.txt 2>&1
@@ -35,7 +35,7 @@ for s in 0 4; do
   rm -rf $D
 done
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+for set in "FETCH_SIZE" "WRITE_SIZE TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
   i=$((i+1))
   D=$OUT/pmc_$i; mkdir -p $D
   DC_STEPS=60 timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $D -o pmc -- python $R/tools/dcstep.py > $D/log.txt 2>&1
@@ -45,5 +45,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_
   rm -rf $D
 done
 cat $OUT/pmc_counters.txt
-python $R/tools/traffic_json.py $OUT/pmc_counters.txt $OUT/traffic.json "${COMMIT:-unknown}" "profiles/r03_${TAG:-x}_pmc_counters.txt"
+python $R/tools/traffic_json.py $OUT/pmc_counters.txt $OUT/traffic.json "${COMMIT:-unknown}" "profiles/r04_${TAG:-x}_pmc_counters.txt"
 cat $OUT/traffic.json
