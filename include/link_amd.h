@@ -659,8 +659,8 @@ typedef struct {
                           forms); bit 2: own-cell form (a lane group de-modulates its own cell from the A row in registers; 2-slot
                           plane ring fed by a dedicated DMA wave; 39 KB of LDS) */
   int32_t mode;        /* 0 = default (7); else bit 0 fused pre_mix+modsum, bit 1 dense-cell demod kernel, bit 2 fused
-                          gather + de-modulate (C = 64), bit 3 the fused gather at C = 16 / 32 / 128 too (cells form: measured slower than
-                          the two kernels, off by default) -- the unfused stages are what the fused ones are tested against */
+                          gather + de-modulate (C = 64; the other widths keep box sum and de-modulation as two kernels: a fused form for them
+                          measured slower and was removed in round 4) -- the unfused stages are what the fused ones are tested against */
   int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */
   int32_t reserved;
   uint64_t *k1_dbg;    /* bench only: device buffer u64[waves*8] for per-wave phase timings of the fused pre_mix kernel; NULL = off */
@@ -716,10 +716,11 @@ int link_dc_demod(const float *A, const float *fin, const int32_t *coords, const
                   const float *w_pos, const float *alpha, const float *ln_w, const float *ln_b,
                   const link_elk_desc_t *desc /* host */, const link_dc_grid_t *g /* host */, int64_t n, void *out,
                   int32_t io_dtype, void *stream);
-/*   link_dc_gather_demod   box sum + de-modulate + LayerNorm in ONE kernel (C = 64: producer / consumer forms; C = 16 / 32 /
- *                          128: cells form, a wave per 16 cells): the normalised neighbour sums
- *                          of a z-plane live in LDS only and the plane's voxels are dealt out to the workgroup's
- *                          16 lane groups as pairs; neither the A table nor its per-voxel gather exists */
+/*   link_dc_gather_demod   box sum + de-modulate + LayerNorm in ONE kernel (C = 64 only: producer / consumer forms; LINK_ERR_ARG
+ *                          at other widths, which run link_dc_gather + link_dc_demod): the normalised neighbour sums
+ *                          of a z-plane live in LDS only and the plane's voxels are dealt out to the consumer waves -- a voxel
+ *                          per quad of lanes through a map a mapper wave lays out two steps ahead (round 4), or as pairs to 16
+ *                          lane groups (round-2 form); neither the A table nor its per-voxel gather exists */
 int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                          const link_elk_desc_t *desc /* host */, int64_t n, void *stream);
 /* One call = one R_core step on the dense-cell path (build_index = 0 reuses slots/cell_n of the previous

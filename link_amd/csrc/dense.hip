@@ -788,10 +788,10 @@ extern "C" int link_elk_core_dense_forward(const link_dc_buffers_t *b, const lin
                         b->hdr, stream);
     if (rc != LINK_OK) return rc;
   }
-  // box sum + de-modulate fused, the A table never exists: C = 64 (producer / consumer forms) by default; the other
-  // widths have a fused form too (cells form, dense_gather_cells_impl.h, mode bit 3) but it is slower than the two kernels
-  // below at every size measured (C = 16: 22.6 against 19.7 us at 10k voxels; C = 128: 108 against 50 us at 30k)
-  if ((mode & 4) && (desc->c == 64 || (mode & 8)))
+  // box sum + de-modulate fused, the A table never exists: C = 64 (producer / consumer forms).  The other widths take the two
+  // kernels below: a fused form for them (a wave per 16 cells, round 3) measured slower at every size (C = 16: 22.6 against
+  // 19.7 us at 10k voxels; C = 128: 108 against 50 us at 30k -- DESIGN.md section 5c) and was removed in round 4
+  if ((mode & 4) && desc->c == 64)
     return link_dc_gather_demod(b, g, desc, n, stream);
   rc = link_dc_gather(b->S, b->cell_n, desc, g, b->A, stream);
   if (rc != LINK_OK) return rc;

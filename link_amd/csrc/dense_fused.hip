@@ -33,8 +33,6 @@ int dc_tiles_modsum(const link_dc_buffers_t *b, const link_dc_grid_t *g, const l
                 const float *, const float *, const link_elk_desc_t &, const link_dc_grid_t &, int64_t, void *,            \
                 hipStream_t);                                                                                              \
   int run_gather_demod(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, hipStream_t); \
-  int run_gather_demod_cells(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t,          \
-                             hipStream_t);                                                                                 \
   int run_premix_modsum_sparse(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t, bool,  \
                                const int32_t *, hipStream_t);                                                              \
   int run_gather_demod_sparse(const link_dc_buffers_t *, const link_dc_grid_t &, const link_elk_desc_t &, int64_t,         \
@@ -237,13 +235,7 @@ extern "C" int link_dc_gather_demod(const link_dc_buffers_t *b, const link_dc_gr
   if (!b->S || !b->cell_n || !b->slots || !b->w_pos || !b->ln_w || !b->ln_b || !b->out || (d->op == LINK_OP_COSX && !b->fin))
     return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  if (d->c != 64) {                                    // cells form (dense_gather_cells_impl.h): C = 16 / 32 / 128
-    switch (b->io_dtype) {
-      case 1: return dcio_f16::run_gather_demod_cells(b, *g, *d, n, st);
-      case 2: return dcio_bf16::run_gather_demod_cells(b, *g, *d, n, st);
-      default: return dcio_f32::run_gather_demod_cells(b, *g, *d, n, st);
-    }
-  }
+  if (d->c != 64) return LINK_ERR_ARG;               // the fused gather + de-modulate kernels are built for C = 64; other widths: link_dc_gather + link_dc_demod
   switch (b->io_dtype) {
     case 1: return dcio_f16::run_gather_demod(b, *g, *d, n, st);
     case 2: return dcio_bf16::run_gather_demod(b, *g, *d, n, st);

@@ -1225,7 +1225,6 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
 #include "dense_gather_own_impl.h"
 
 #include "dense_gather_quad_impl.h"
-#include "dense_gather_cells_impl.h"
 
 template <int OP, int R, bool PAIR, bool DIV>
 __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(

@@ -56,28 +56,6 @@ def test_dense_vs_oracle_and_general(C, groups, baseop, s, r, grid, n, k1_form, 
     assert int(dense.cnt.abs().sum().item()) == 0           # the counters cleaned themselves
 
 
-@pytest.mark.parametrize("C,groups,baseop,s,r,grid,n", [(16, 2, "cos", 7, 3, 256, 10000), (32, 2, "sin", 3, 2, 40, 6000),
-                                                       (128, 2, "cos", 5, 3, 60, 7000), (16, 1, "cos_x", 2, 2, 24, 3000),
-                                                       (128, 1, "cos_x", 4, 2, 40, 3000), (32, 1, "cos", 7, 3, 24, 6000)])
-def test_dense_fused_gather_cells_form_other_widths(C, groups, baseop, s, r, grid, n):
-    """mode bit 3: box sum + de-modulate + LayerNorm in one kernel at C = 16 / 32 / 128 (cells form; 3 launches per step)
-    against the oracle and the default two-kernel form; cells of up to 80 voxels in the last case."""
-    import link_amd as la
-    torch.manual_seed(6)
-    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop).cuda().eval()
-    coords = s_uniform(n, grid=grid, seed=C + r).cuda()
-    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(3)).cuda()
-    bounds = ((0, 0, 0, 0), (grid - 1, grid - 1, grid - 1, 0))
-    cells = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense", mode=15)
-    two = _plan(la, blk, n, C, groups, baseop, r, s, bounds, "dense")
-    oc = cells.run(feats, coords).clone()
-    ot = two.run(feats, coords).clone()
-    ref = _oracle(blk, feats, coords, s, r, baseop, groups)
-    assert rel_err(oc.cpu().numpy(), ref) < 1e-4
-    assert rel_err(oc.cpu().numpy(), ot.cpu().numpy()) < 2e-5
-    assert torch.equal(cells.run(feats, coords, build_index=False), oc)
-
-
 @pytest.mark.parametrize("k1_form,k2_form", [(0, 0), (1, 0), (2, 0), (0, 4), (0, 8)])
 def test_dense_large_cells_negative_coords_batches(k1_form, k2_form):
     """Cells with many voxels (~80 per cell: the counting-rank pass of the tile form, the insertion path of the cell-range
