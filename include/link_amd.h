@@ -540,7 +540,9 @@ int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int
 /* All three steps in one call, for capacity-sized lists (what link_amd's device-laid-out plans use): the fill pass computes
  * ext_start i32[n + 1] itself (wg_ext i32[ceil(n/256)] scratch: rows of earlier workgroups) and the layout pass writes -1
  * into the unused tail of every offset's last granule, so neither a prefix-sum pass nor a fill of pair_in / pair_out
- * (i32[gran_cap * 128] each, otherwise uninitialised) is needed.  ext_list i32[>= n * kvol]. */
+ * (i32[gran_cap * 128] each, otherwise uninitialised) is needed.  ext_list i32[>= n * kvol].  gran_cap below
+ * ceil((n * (kvol - skip_centre) + 127 * kvol) / 128) -- the capacity that can never be exceeded -- is LINK_ERR_ARG: the
+ * lists would be written past it before the header's overflow flag exists. */
 int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap, int32_t *wg_counts,
                          int32_t *row_info, int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_ext,
                          int32_t *wg_k, int32_t *hdr, int32_t *ext_start, int32_t *pair_in, int32_t *pair_out,

@@ -1007,6 +1007,9 @@ extern "C" int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol,
     return LINK_ERR_ARG;
   const int64_t nwg = (n + 255) / 256;
   if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
+  // pair_in / pair_out hold gran_cap granules of 128 rows: every (voxel, offset) may be a pair and every offset's last granule
+  // partly filled -- a smaller capacity would be written past (the header's overflow flag is raised only afterwards)
+  if (gran_cap < (n * (int64_t)(kvol - (skip_centre ? 1 : 0)) + 127 * (int64_t)kvol + 127) / 128) return LINK_ERR_ARG;
   int rc = link_pair_plan_count(nbr, n, kvol, wg_counts, row_info, stream);
   if (rc != LINK_OK) return rc;
   hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(1024), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),

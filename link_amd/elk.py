@@ -25,6 +25,7 @@ Two execution paths, both HIP:
 from __future__ import annotations
 
 import ctypes
+import weakref
 import math
 from typing import Dict, Optional, Tuple
 
@@ -905,6 +906,24 @@ PAIR_DENSITY_MAX = 17.0
 ASYNC_PAIR_PLANS = True      # lay pair plans out on the device when the table's structure is known (no host round trip)
 ASYNC_PAIR_PLAN_MAX = 8_000_000   # ... up to this many table entries: the buffers are sized for every entry being a pair
                                   # (contribution rows at 64 channels: 256 B per entry), beyond it the exact host layout
+ASYNC_PAIR_PLAN_MAX_BYTES = 1 << 30   # ... and up to this many bytes of capacity-sized contribution rows (entries x Cout x 4)
+_PENDING_PLANS: list = []             # weak references to device-laid-out plans whose counts have not been looked at yet
+
+
+def _poll_pending_plans() -> None:
+    """Look at the counts of every device-laid-out plan whose kernels have finished: a table handed over as submanifold that
+    is not one (duplicate coordinates) raises HERE -- at the next plan, the next frame at the latest -- instead of only when
+    somebody happens to ask the plan for its density."""
+    keep = []
+    for ref in _PENDING_PLANS:
+        plan = ref()
+        if plan is None or plan.exact or plan._density is not None:
+            continue
+        if plan._ev.query():
+            plan._arrived(False)                         # raises LinkAmdError on a bad table
+        else:
+            keep.append(ref)
+    _PENDING_PLANS[:] = keep
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
 _BBOX_STATS_INIT: Dict[torch.device, torch.Tensor] = {}   # (bbox init, zeroed occupancy counters) per device
 
@@ -938,12 +957,13 @@ class _PairPlan:
     rows in ascending offset order (`ext_start`, `ext_list`).  For a submanifold table (odd kernel, same
     coordinates in and out) the centre pairs are the identity and occupy rows [0, n)."""
 
-    def __init__(self, nbr: torch.Tensor, subm: Optional[bool] = None):
+    def __init__(self, nbr: torch.Tensor, subm: Optional[bool] = None, cout_hint: int = 64):
         """`subm`: what the caller knows about the table structurally -- True: a submanifold table (odd kernel, the same
         unique coordinates in and out, so the centre column is the identity), False: not one, None: unknown.  With a
         structural answer and ASYNC_PAIR_PLANS the plan is laid out on the device (link_pair_plan_layout) over capacity-
         sized buffers and nothing waits for the host; the counts arrive later in pinned memory (`density`, `finalize`)."""
-        if subm is not None and ASYNC_PAIR_PLANS and nbr.is_cuda and 0 < nbr.shape[0] * nbr.shape[1] <= ASYNC_PAIR_PLAN_MAX:
+        if (subm is not None and ASYNC_PAIR_PLANS and nbr.is_cuda and 0 < nbr.shape[0] * nbr.shape[1] <= ASYNC_PAIR_PLAN_MAX
+                and nbr.shape[0] * nbr.shape[1] * max(int(cout_hint), 1) * 4 <= ASYNC_PAIR_PLAN_MAX_BYTES):
             self._init_async(nbr, bool(subm))
             return
         self.exact = True
@@ -1000,6 +1020,7 @@ class _PairPlan:
         self._contrib: Dict[int, torch.Tensor] = {}
 
     def _init_async(self, nbr: torch.Tensor, direct: bool):
+        _poll_pending_plans()                            # an earlier plan's verdict (duplicate coordinates) surfaces here at the latest
         n, kvol = nbr.shape
         dev = nbr.device
         lib, st = L.lib(), _st()
@@ -1035,6 +1056,7 @@ class _PairPlan:
         self._host.copy_(hdr, non_blocking=True)
         self._ev = torch.cuda.Event()
         self._ev.record()
+        _PENDING_PLANS.append(weakref.ref(self))
 
     def _arrived(self, wait: bool) -> bool:
         if self.exact or self._density is not None:
@@ -1053,7 +1075,8 @@ class _PairPlan:
         self._density = (pairs + (self.n if self.direct else 0)) / max(self.n, 1)
         self._exact_rows = rows
         _DENSITY_SEEN[self.kvol] = self._density
-        return True
+        self._contrib.clear()                            # capacity-sized contribution rows (every entry a pair): the next request
+        return True                                      # allocates the exact size (contrib)
 
     @property
     def density(self) -> float:
@@ -1083,17 +1106,17 @@ class _PairPlan:
         return self
 
     def contrib(self, cout: int, dtype=torch.float32) -> torch.Tensor:
+        rows = self.rows_launch                          # the exact count once it has arrived, the capacity before
         if dtype != torch.float32:
             buf = self._contrib.get((cout, dtype))
             if buf is None:
-                buf = self._contrib[(cout, dtype)] = torch.empty((max(self.rows_pad, 1), cout), dtype=dtype, device=self.pair_in.device)
+                buf = self._contrib[(cout, dtype)] = torch.empty((max(rows, 1), cout), dtype=dtype, device=self.pair_in.device)
             return buf
         buf = self._contrib.get(cout)
         if buf is None:
             if len(self._contrib) >= 2:
                 self._contrib.clear()
-            buf = self._contrib[cout] = torch.empty((max(self.rows_pad, 1), cout), dtype=torch.float32,
-                                                    device=self.pair_in.device)
+            buf = self._contrib[cout] = torch.empty((max(rows, 1), cout), dtype=torch.float32, device=self.pair_in.device)
         return buf
 
 
@@ -1106,7 +1129,7 @@ def _pair_plan(nbr: torch.Tensor, cin: int, cout: int) -> Optional[_PairPlan]:
         return None                 # the pair plan holds one 64-bit offset mask per voxel: 5^3 / 7^3 kernels run the table kernel
     plan = getattr(nbr, "_link_pairs", False)
     if plan is False:
-        plan = _PairPlan(nbr, None if torch.is_grad_enabled() else getattr(nbr, "_link_subm", None))
+        plan = _PairPlan(nbr, None if torch.is_grad_enabled() else getattr(nbr, "_link_subm", None), cout_hint=cout)
         nbr._link_pairs = plan
     if torch.is_grad_enabled() and not plan.exact:
         plan.finalize()

@@ -56,7 +56,23 @@ def _lookup(keys: torch.Tensor, x: SparseTensor, r: int) -> torch.Tensor:
     """int64 [P, r^3]: row of x.C holding keys[p] + offset_k * x.stride (offset order of get_kernel_offsets(r)), -1
     if absent.  Dense cell table of x.C; hash table beyond the dense-grid limit."""
     try:
-        return foreign_neighbor_map(keys.contiguous(), r, step=int(x.s[0]), table_rows=x.C, bounds=_bounds_of(x)).long()
+        st = int(x.s[0])
+        if st > 1:
+            # coordinates at tensor stride st are multiples of st: look up on the grid of SITES (coordinates / st, edge 1, step 1)
+            # -- st^3 times fewer cells than an edge-1 grid over the raw coordinates, which hit the dense-grid limit (or a 1 GiB
+            # table) at stride 4-8 on full LiDAR extents.  The divided rows of x.C are cached with the tensor's maps.
+            ckey = ("link_site_rows", x.C.data_ptr(), x.C.shape[0], st)
+            ent = x.cmaps.get(ckey)
+            if ent is None:
+                div = torch.tensor([st, st, st, 1], dtype=torch.int32, device=x.C.device)
+                b = _bounds_of(x)
+                sb = None if b is None else (tuple(int(v) // st for v in b[0][:3]) + (int(b[0][3]),),
+                                             tuple(int(v) // st for v in b[1][:3]) + (int(b[1][3]),))
+                ent = x.cmaps[ckey] = (torch.div(x.C, div, rounding_mode="floor").contiguous(), div, sb)
+            rows, div, sb = ent
+            return foreign_neighbor_map(torch.div(keys, div, rounding_mode="floor").contiguous(), r, step=1, table_rows=rows,
+                                        bounds=sb).long()
+        return foreign_neighbor_map(keys.contiguous(), r, step=st, table_rows=x.C, bounds=_bounds_of(x)).long()
     except GridTooLarge:
         if r == 1:
             return F.sphashquery(F.sphash(keys), F.sphash(x.C)).view(-1, 1)

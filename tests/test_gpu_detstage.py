@@ -162,6 +162,44 @@ def test_sparse_conv3d_sites_and_values_vs_dense_definition():
         assert rel_err(out.features.cpu().numpy(), rf.numpy()) < 1e-5
 
 
+def dense_backbone_reference(net, feats, indices, shape):
+    """The sparse half of SpMiddleResNetFHDELKv3 (scn.py:570-626) BY DEFINITION, float64 on the CPU: submanifold / regular
+    sparse convolutions as dense conv3d of the zero-filled grid, eval-mode BatchNorm, TSELKBlock cores through the oracle.
+    Returns ({stage: (indices, features, shape)}, (indices, features, shape) of stage 4 for the caller's extra_conv, state dict)."""
+    from oracle import link_oracle as O
+    sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
+
+    def bn(pre, v):
+        return (v - sd[pre + ".running_mean"].double()) / torch.sqrt(sd[pre + ".running_var"].double() + 1e-3) \
+            * sd[pre + ".weight"].double() + sd[pre + ".bias"].double()
+
+    shape = list(shape)
+    f = torch.relu(bn("conv_input.1", dense_subm(feats, indices, shape, sd["conv_input.0.weight"], None)))
+    ind = indices
+    pads = {2: (1, 1, 1), 3: (1, 1, 1), 4: (0, 1, 1)}
+    out = {}
+    for k in (1, 2, 3, 4):
+        if k > 1:
+            ind, f, shape = dense_regular(f, ind, shape, sd[f"down{k}.0.weight"], (3, 3, 3), (2, 2, 2), pads[k], 1)
+            f = torch.relu(bn(f"down{k}.1", f))
+        xx = f
+        for i in range(2):
+            h = torch.relu(bn(f"conv{k}.{i}.bn1", dense_subm(xx, ind, shape, sd[f"conv{k}.{i}.conv1.weight"], sd[f"conv{k}.{i}.conv1.bias"])))
+            xx = torch.relu(bn(f"conv{k}.{i}.bn2", dense_subm(h, ind, shape, sd[f"conv{k}.{i}.conv2.weight"], sd[f"conv{k}.{i}.conv2.bias"])) + xx)
+        x_conv = bn(f"conv{k}_tail.1", dense_subm(xx, ind, shape, sd[f"conv{k}_tail.0.weight"], None))
+        coords = ind[:, [3, 2, 1, 0]].contiguous()
+        elk = {kk[len(f"elk{k}."):]: v for kk, v in sd.items() if kk.startswith(f"elk{k}.")}
+        c = f.shape[1]
+        core = O.elk_core_torch(f.float(), coords, elk, 7, 3, "cos", 1, variant="det", agg=O.aggregate_c).double()
+        local = O.subm_conv_torch(f, coords, elk["local_mix.0.kernel"].double(), 1)
+        local = torch.nn.functional.layer_norm(local, (c,), elk["norm_local.weight"].double(), elk["norm_local.bias"].double(), 1e-6)
+        e = torch.relu(core + local)
+        x_lk = bn(f"elk{k}_tail.1", dense_subm(e, ind, shape, sd[f"elk{k}_tail.0.weight"], None))
+        f = torch.relu(x_conv + x_lk)
+        out[k] = (ind, f, list(shape))
+    return out, (ind, f, shape), sd
+
+
 def test_backbone_sparse_half_vs_dense_oracle():
     """SpMiddleResNetFHDELKv3.forward (scn.py:570-626) on a small grid: every active-site set, the four multi-scale
     outputs and the BEV tensor against the dense definitions + the oracle's TSELKBlock; fused inference and the
@@ -183,37 +221,16 @@ def test_backbone_sparse_half_vs_dense_oracle():
     feats = torch.randn(5000, 5, generator=g)
     with torch.no_grad():
         bev, scales = net(feats.cuda(), indices.cuda(), 1, input_shape)
-    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    stage_ref, (ind, f, shape), sd = dense_backbone_reference(net, feats, indices, [41, 32, 32])
+    for k in (1, 2, 3, 4):
+        rind, rf, rshape = stage_ref[k]
+        got = scales[f"conv{k}"]
+        assert torch.equal(got.indices.cpu(), rind) and list(got.spatial_shape) == rshape, f"stage {k} sites"
+        assert rel_err(got.features.cpu().numpy(), rf.numpy()) < 1e-4, f"stage {k} features"
 
     def bn(pre, v):
         return (v - sd[pre + ".running_mean"].double()) / torch.sqrt(sd[pre + ".running_var"].double() + 1e-3) \
             * sd[pre + ".weight"].double() + sd[pre + ".bias"].double()
-
-    shape = [41, 32, 32]
-    f = torch.relu(bn("conv_input.1", dense_subm(feats, indices, shape, sd["conv_input.0.weight"], None)))
-    ind = indices
-    pads = {2: (1, 1, 1), 3: (1, 1, 1), 4: (0, 1, 1)}
-    for k in (1, 2, 3, 4):
-        if k > 1:
-            ind, f, shape = dense_regular(f, ind, shape, sd[f"down{k}.0.weight"], (3, 3, 3), (2, 2, 2), pads[k], 1)
-            f = torch.relu(bn(f"down{k}.1", f))
-        xx = f
-        for i in range(2):
-            h = torch.relu(bn(f"conv{k}.{i}.bn1", dense_subm(xx, ind, shape, sd[f"conv{k}.{i}.conv1.weight"], sd[f"conv{k}.{i}.conv1.bias"])))
-            xx = torch.relu(bn(f"conv{k}.{i}.bn2", dense_subm(h, ind, shape, sd[f"conv{k}.{i}.conv2.weight"], sd[f"conv{k}.{i}.conv2.bias"])) + xx)
-        x_conv = bn(f"conv{k}_tail.1", dense_subm(xx, ind, shape, sd[f"conv{k}_tail.0.weight"], None))
-        coords = ind[:, [3, 2, 1, 0]].contiguous()
-        elk = {kk[len(f"elk{k}."):]: v for kk, v in sd.items() if kk.startswith(f"elk{k}.")}
-        c = f.shape[1]
-        core = O.elk_core_torch(f.float(), coords, elk, 7, 3, "cos", 1, variant="det", agg=O.aggregate_c).double()
-        local = O.subm_conv_torch(f, coords, elk["local_mix.0.kernel"].double(), 1)
-        local = torch.nn.functional.layer_norm(local, (c,), elk["norm_local.weight"].double(), elk["norm_local.bias"].double(), 1e-6)
-        e = torch.relu(core + local)
-        x_lk = bn(f"elk{k}_tail.1", dense_subm(e, ind, shape, sd[f"elk{k}_tail.0.weight"], None))
-        f = torch.relu(x_conv + x_lk)
-        got = scales[f"conv{k}"]
-        assert torch.equal(got.indices.cpu(), ind) and list(got.spatial_shape) == shape, f"stage {k} sites"
-        assert rel_err(got.features.cpu().numpy(), f.numpy()) < 1e-4, f"stage {k} features"
     ind, f, shape = dense_regular(f, ind, shape, sd["extra_conv.0.weight"], (3, 1, 1), (2, 1, 1), (0, 0, 0), 1)
     f = torch.relu(bn("extra_conv.1", f))
     ref = torch.zeros(1, shape[0], shape[1], shape[2], 128, dtype=torch.float64)
@@ -227,6 +244,41 @@ def test_backbone_sparse_half_vs_dense_oracle():
     assert rel_err(bev2.detach().cpu().numpy(), ref.numpy()) < 1e-4
     bev2.square().sum().backward()
     assert torch.isfinite(fin.grad).all() and net.down3[0].weight.grad.abs().sum() > 0
+
+
+def test_amp_backbone_on_a_real_frame_crop_vs_dense_definition():
+    """The AMP form of the backbone (fp16 rows + fp16 convolution weights on the f16 matrix cores, fp32 accumulation) pinned
+    on something that is not this library: a 128 x 128 x 40 crop around the sensor of the S-nusc frame (real LiDAR-shaped
+    occupancy: dense ground rings, 20+ voxels per LinK block) against the float64 dense-convolution definition of the same
+    network.  Site sets bit-exact at every stage; stage features within 2e-2 of the stage maximum -- thirty layers of
+    half-precision rows (the fp32 path meets the same reference to 1e-4 above)."""
+    import link_amd as la
+    from link_amd.synth import s_nusc
+    co, fe = s_nusc(seed=0)                                         # (x, y, z, b) on the 1440 x 1440 x 40 grid
+    lo = 720 - 64
+    keep = (co[:, 0] >= lo) & (co[:, 0] < lo + 128) & (co[:, 1] >= lo) & (co[:, 1] < lo + 128)
+    co, fe = co[keep].copy(), fe[keep]
+    co[:, 0] -= lo; co[:, 1] -= lo
+    assert 3000 < co.shape[0] < 60000, co.shape
+    indices = torch.from_numpy(co[:, [3, 2, 1, 0]].copy()).int()
+    feats = torch.from_numpy(fe).half().float()                     # both sides see the fp16-rounded inputs
+    torch.manual_seed(1)
+    net = la.SpMiddleResNetFHDELKv3(num_input_features=5).cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.6)
+            m.weight.data.uniform_(0.6, 1.4); m.bias.data.uniform_(-0.2, 0.2)
+    net.eval()
+    with torch.no_grad():
+        bev16, sc16 = net(feats.half().cuda(), indices.cuda(), 1, [128, 128, 40])
+    assert bev16.dtype == torch.float16
+    stage_ref, _, _ = dense_backbone_reference(net, feats, indices, [41, 128, 128])
+    for k in (1, 2, 3, 4):
+        rind, rf, rshape = stage_ref[k]
+        got = sc16[f"conv{k}"]
+        assert torch.equal(got.indices.cpu(), rind) and list(got.spatial_shape) == rshape, f"stage {k} sites"
+        assert rel_err(got.features.float().cpu().numpy(), rf.numpy()) < 2e-2, f"stage {k} features"
+    print("AMP backbone vs dense definition: voxels", co.shape[0], "stage sites", [stage_ref[k][0].shape[0] for k in (1, 2, 3, 4)])
 
 
 def test_backbone_maps_ahead_on_side_stream_is_bitwise_the_same(monkeypatch):
