@@ -744,6 +744,21 @@ int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const l
 int link_elk_core_sparse_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                  const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index, int32_t *occ,
                                  const int32_t *occ_prev, int64_t n_prev, void *stream);
+/* One STEP of the three-frame pipeline on the dense-cell layout (round 4, csrc/dense_step3_impl.h): ONE launch whose grid is three
+ * ranges of workgroups -- the gather + de-modulate kernel of the frame in `b_k2`, the fused pre_mix kernel (matrix-core sums form)
+ * of the frame in `b_k1`, the slot insert of the frame in `b_insert` -- each range running the same device code as the stand-alone
+ * kernel of its stage.  A frame passes through three consecutive steps on its own buffers (insert, K1, K2); the three frames of a
+ * step are independent, so the stages overlap by construction instead of by what the hardware queues of separate streams happen
+ * to interleave.  Steady state: one frame completes per launch.  A null frame is an absent stage (pipeline fill / drain).
+ * All frames: the same grid, descriptor, parameters and io_dtype; C = 64, cg = 32 (two-part rows whose channels j and j + 32 share
+ * theta), op cos / sin, r in {2, 3}, coord_div = 1, no alpha, slot capacity <= 352 -- LINK_ERR_ARG otherwise (the caller runs
+ * link_elk_core_dense_forward per frame).  buf->tune of each frame: k1_wgs (x 4 waves; 0 = 512) and k2_zsplit (0 = enough segments
+ * for ~256 workgroups: the other half of the chip's workgroup slots is K1's).  insert_wgs: 512-thread workgroups of the insert
+ * range, 0 = one per 2048 voxels.  Results are those of link_elk_core_dense_forward with tune.k1_form = 2, bit for bit. */
+int link_elk_core_dense_step3(const link_dc_buffers_t *b_insert /* host */, int64_t n_insert,
+                              const link_dc_buffers_t *b_k1 /* host */, int64_t n_k1,
+                              const link_dc_buffers_t *b_k2 /* host */, int64_t n_k2, const link_dc_grid_t *g /* host */,
+                              const link_elk_desc_t *desc /* host */, int32_t insert_wgs, void *stream);
 /* The slot insert of a step (the form buf->tune picks) that also reports the frame's occupancy on this grid: stats
  * i32[16][16] (device, zeroed by the caller): 16 partial slots on separate cache lines, [k][0] += voxels inside the grid,
  * [k][1] += occupied cells, [k][2] max= fullest cell's count -- the reader sums / sums / maxes over k.  For the

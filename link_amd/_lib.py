@@ -18,7 +18,7 @@ HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -207,6 +207,9 @@ SIGNATURES = {
                                             c_int64, c_int32, c_void_p]),
     "link_elk_core_sparse_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                              c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "link_elk_core_dense_step3": (c_int, [POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcBuffers), c_int64,
+                                          POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcGrid), POINTER(LinkElkDesc),
+                                          c_int32, c_void_p]),
     "link_dc_index_probe": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), c_int64, c_void_p, c_void_p]),
     "link_dc_index_ids": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_index": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),

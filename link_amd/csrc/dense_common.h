@@ -73,6 +73,36 @@ __device__ __forceinline__ uint32_t dc_slot(const link_dc_grid_t &g, int pcell, 
                        : (uint32_t)g.vp * DC_INL + (uint32_t)pcell * (uint32_t)(g.k - DC_INL) + (uint32_t)(rank - DC_INL);
 }
 
+// The slot insert of the dense-cell index as a device function of (workgroup number, workgroups, threads per workgroup):
+// k_dc_index (dense_fused.hip) runs it over its own grid, the three-stage step kernel (dense_step3_impl.h) over a range of a
+// shared one.  rank = cnt[cell]++, slots[cell][rank] = (x, y, z, id), vcell[id] = cell; a voxel outside the grid or past a
+// full cell sets its bit of the status accumulator and is left out.
+template <bool STATS>
+__device__ __forceinline__ void dc_index_body(const int4 *__restrict__ coords, int64_t n, const link_dc_grid_t &g,
+                                              uint32_t *__restrict__ cnt, int4 *__restrict__ slots,
+                                              int32_t *__restrict__ vcell, int32_t *__restrict__ hdr, int bid, int nblk,
+                                              int nthr, int &st_in, int &st_first, int &st_max) {
+  const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
+  const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  if (bid == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
+  for (int64_t v = (int64_t)bid * nthr + threadIdx.x; v < n; v += (int64_t)nblk * nthr) {
+    const int4 rc = coords[v];
+    const unsigned ux = (unsigned)(floordiv(rc.x, g.s) - g.lo[0]), uy = (unsigned)(floordiv(rc.y, g.s) - g.lo[1]);
+    const unsigned uz = (unsigned)(floordiv(rc.z, g.s) - g.lo[2]), ub = (unsigned)(rc.w - g.lo[3]);
+    const bool inside = ux < (unsigned)g.dim[0] && uy < (unsigned)g.dim[1] && uz < (unsigned)g.dim[2] &&
+                        ub < (unsigned)g.dim[3];
+    if (!inside) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 1);
+    const int pcell = inside ? dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub) : 0;
+    const int rank = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, r_cnt, pcell ? (uint32_t)pcell * 4u : DC_OOB, 0, 0);
+    const bool full = pcell != 0 && rank >= g.k;
+    if (full) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 2);
+    const bool keep = pcell != 0 && !full;
+    st16i(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
+    vcell[v] = keep ? pcell : 0;
+    if (STATS) { st_in += pcell != 0; st_first += (pcell != 0 && rank == 0); st_max = max(st_max, pcell != 0 ? rank + 1 : 0); }
+  }
+}
+
 // Id lists of the tile form (link_dc_buffers_t::sid): DC_SID_INL voxel ids inline per cell (32 contiguous bytes: what a
 // lane of the fused pre_mix kernel reads for its cell), then the overflow region with k - DC_SID_INL ids per cell.
 #define DC_SID_INL 8

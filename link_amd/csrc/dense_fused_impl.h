@@ -1697,4 +1697,6 @@ int run_gather_demod(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   }
 }
 
+#include "dense_step3_impl.h"
+
 }  // namespace DC_IO_NS

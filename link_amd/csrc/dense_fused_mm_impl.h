@@ -84,13 +84,15 @@ struct dc_k1m_cfg {
 
 // SPARSE: the sparse-cell layout (dense_gather_sparse_impl.h) -- the wave's cells are those marked in `occ` over its range of
 // voxel ids, their records come by the cooperative fetch of dc_sparse_fetch; everything after the cell section is the same.
+// The kernel body is a device function of the workgroup number `bid`: k_dc_premix_modsum_mm runs it over its own grid, the
+// three-stage step kernel (dense_step3_impl.h) over one range of a grid it shares with the other two stages.
 template <int C, int OP, int NB, bool SPARSE = false>
-__global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_modsum_mm(
+__device__ __forceinline__ void dc_k1m_body(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
     const float *__restrict__ w_pre, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg, float coord_div, float eps, int64_t n,
-    link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
-    unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks = nullptr) {
+    const link_dc_grid_t &g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
+    unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks, const int bid) {
   using K = dc_k1m_cfg<C, OP, SPARSE>;
   constexpr int T = K::T, KB = K::KB, P = K::P, RB = K::RB;
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_mm = 0, tq_ln = 0, tq_sum = 0;
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
   float *carry = reinterpret_cast<float *>(wbase + K::CARRY_OFF);
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
   const int Vi = SPARSE ? (int)n : Dx * Dy * Dz * g.dim[3];
-  const int wid = blockIdx.x * K::NW + wave;
+  const int wid = bid * K::NW + wave;
   const int c_begin = wid * cpw;
   const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     reinterpret_cast<float4 *>(smem_raw + K::PW_OFF)[li * T + cb] =
         make_float4(w_pos[3 * tc + 0], w_pos[3 * tc + 1], w_pos[3 * tc + 2], alpha ? alpha[tc] : 1.0f);
   }
-  if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
+  if (bid == 0 && tid == 0 && !warm) {                 // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
@@ -572,6 +574,17 @@ __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_mods
     const unsigned long long te = __builtin_amdgcn_s_memtime();
     d[0] = tq1 - tq0; d[1] = tq_cell; d[2] = tq_mm; d[3] = tq_ln; d[4] = tq_sum; d[5] = te - tq0; d[6] = tq_tiles; d[7] = tq0;
   }
+}
+
+template <int C, int OP, int NB, bool SPARSE = false>
+__global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_modsum_mm(
+    const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
+    const float *__restrict__ w_pre, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg, float coord_div, float eps, int64_t n,
+    link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
+    unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks = nullptr) {
+  dc_k1m_body<C, OP, NB, SPARSE>(feats, slots, cnt, cell_n, w_pre, ln_w, ln_b, w_pos, alpha, cg, coord_div, eps, n, g, cpw, warm,
+                                 S_, fin, hdr, dbg, occ_marks, (int)blockIdx.x);
 }
 
 template <int C, int OP, int NB>

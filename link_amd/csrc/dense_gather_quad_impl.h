@@ -143,12 +143,13 @@ __device__ __forceinline__ float dc_quad_sum(float v) {
   return v;
 }
 
+// the kernel body as a device function of the workgroup number `bid` (see dc_k1m_body)
 template <int OP, int R, bool DIV>
-__global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0)), 4) k_dc_gather_demod_quad(
+__device__ __forceinline__ void dc_k2q_body(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
-    const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
-    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg) {
+    const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, const link_dc_grid_t &g, int txn, int tyn,
+    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg, const int bid) {
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
   // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
   const bool producer = threadIdx.x < 256;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x & 255) >> 6);
   const int per = (nwg + 7) >> 3;
-  const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int L = (bid & 7) * per + (bid >> 3);
   if (L >= nwg) return;
   int t = L;
   const int zseg = t % zsplit; t /= zsplit;
@@ -560,4 +561,14 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
     unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
     d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = 0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
   }
+}
+
+template <int OP, int R, bool DIV>
+__global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0)), 4) k_dc_gather_demod_quad(
+    const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
+    const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
+    const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
+    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg) {
+  dc_k2q_body<OP, R, DIV>(S_, cell_n, slots, w_pos, alpha, ln_w, ln_b, cg, coord_div, eps, n, g, txn, tyn, zsplit, nwg, out, dbg,
+                          (int)blockIdx.x);
 }

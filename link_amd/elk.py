@@ -431,6 +431,115 @@ class ElkCorePlan:
         return int(h[L.HDR_M])
 
 
+class ElkCorePipeline:
+    """R_core of a STREAM of frames, three frames in flight, one launch per frame (link_elk_core_dense_step3,
+    csrc/dense_step3_impl.h): each `push` issues one kernel whose workgroups run the slot insert of the new frame, the fused
+    pre_mix kernel of the previous frame and the gather + de-modulate kernel of the frame before that.  A frame's result is
+    complete (in stream order) after the second push that follows its own -- `push` returns it -- or after `flush()`.
+
+    What a serving loop over a sensor stream holds instead of one ElkCorePlan per HIP stream: the overlap of the three stages
+    is a property of the launch, not of how the hardware queues interleave (36-41 us / frame on cfg2 with three streams,
+    depending on the box).  Dense-cell layout only; C = 64, cg = 32, cos / sin, r in {2, 3}, coord_div = 1, no alpha.
+    Numerically identical to ElkCorePlan(layout="dense", k1_form=2)."""
+
+    STAGES = 3
+
+    def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device, eps: float = 1e-6,
+                 slot_cap: int = 0, insert_wgs: int = 0, **tuning):
+        if c != 64 or cg != 32 or baseop not in ("cos", "sin") or r not in (2, 3):
+            raise L.LinkAmdError("ElkCorePipeline: C = 64, cg = 32, cos / sin, r in {2, 3} (include/link_amd.h, "
+                                 "link_elk_core_dense_step3)")
+        tuning.setdefault("k1_form", 2)
+        tuning.setdefault("k1_wgs", 512)
+        tuning.setdefault("k2_zsplit", 0)
+        self.plans = [ElkCorePlan(n_cap, c, baseop, cg, r, s, bounds, device, eps=eps, layout="dense", slot_cap=slot_cap,
+                                  **tuning) for _ in range(self.STAGES)]
+        if int(self.plans[0].dcg.k) > 352:
+            raise L.LinkAmdError("ElkCorePipeline: slot capacity above 352")
+        self.n_cap, self.c, self.device = n_cap, c, device
+        self.insert_wgs = int(insert_wgs)
+        self._t = 0                                      # frames pushed
+        self._live = [None] * self.STAGES                # per plan: (feats, coords, out tensor, n) of the frame it holds
+        self._fn = L.lib().link_elk_core_dense_step3
+
+    def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
+        if alpha is not None:
+            raise L.LinkAmdError("ElkCorePipeline: alpha is not supported")
+        for p in self.plans:
+            p.bind(w_pre, pre_ln_w, pre_ln_b, w_pos, None, ln_w, ln_b)
+        return self
+
+    def _stage(self, back: int):
+        """(buffers, n) of the frame pushed `back` pushes before the current step, or (None, 0)."""
+        t = self._t - back
+        if t < 0:
+            return None, 0
+        live = self._live[t % self.STAGES]
+        if live is None or live[4] != t:
+            return None, 0
+        return ctypes.byref(self.plans[t % self.STAGES].buf), live[3]
+
+    def _launch(self):
+        b0, n0 = self._stage(0)
+        b1, n1 = self._stage(1)
+        b2, n2 = self._stage(2)
+        p = self.plans[0]
+        rc = self._fn(b0, n0, b1, n1, b2, n2, ctypes.byref(p.dcg), ctypes.byref(p.desc), self.insert_wgs,
+                      L.current_stream_handle())
+        if rc != 0:
+            L.check(rc, "link_elk_core_dense_step3")
+        done = None
+        t2 = self._t - 2
+        if b2 is not None:
+            live = self._live[t2 % self.STAGES]
+            done = live[2][:live[3]]
+            self._live[t2 % self.STAGES] = None
+        self._t += 1
+        return done
+
+    def push(self, feats: torch.Tensor, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Enter a frame; returns the result of the frame pushed two calls earlier (None while the pipeline fills).  `feats`,
+        `coords` (and `out`, if given) must stay untouched until that result has been returned."""
+        n = feats.shape[0]
+        assert 0 < n <= self.n_cap and feats.shape[1] == self.c and feats.dtype in _IO_DTYPES
+        assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
+        k = self._t % self.STAGES
+        plan = self.plans[k]
+        for other in self._live:
+            if other is not None and other[0].dtype != feats.dtype:
+                raise L.LinkAmdError("ElkCorePipeline: frames in flight must share a row dtype (flush() first)")
+        own = plan.out
+        if feats.dtype != torch.float32:
+            own = plan.__dict__.setdefault("_out_half", {}).get(feats.dtype)
+            if own is None and out is None:
+                own = plan._out_half[feats.dtype] = torch.empty((self.n_cap, self.c), dtype=feats.dtype, device=self.device)
+        if out is not None:
+            assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
+        dst = out if out is not None else own
+        b = plan.buf
+        b.feats, b.coords, b.out, b.io_dtype = feats.data_ptr(), coords.data_ptr(), dst.data_ptr(), _IO_DTYPES[feats.dtype]
+        self._live[k] = (feats, coords, dst, n, self._t)
+        return self._launch()
+
+    def flush(self):
+        """Drain: the results of the frames still in flight, oldest first (at most two launches)."""
+        res = []
+        for _ in range(self.STAGES - 1):
+            if all(l is None for l in self._live):
+                break
+            r = self._launch()
+            if r is not None:
+                res.append(r)
+        return res
+
+    def check(self) -> None:
+        for p in self.plans:
+            p.check()
+
+    def arena_bytes(self) -> int:
+        return sum(p.arena_bytes() for p in self.plans)
+
+
 # ------------------------------------------------------------------------------------------------
 # differentiable R_core (training)
 # ------------------------------------------------------------------------------------------------
