@@ -754,7 +754,7 @@ int link_elk_core_sparse_forward(const link_dc_buffers_t *buf /* host */, const 
  * theta), op cos / sin, r in {2, 3}, coord_div = 1, no alpha, slot capacity <= 352 -- LINK_ERR_ARG otherwise (the caller runs
  * link_elk_core_dense_forward per frame).  buf->tune of each frame: k1_wgs (x 4 waves; 0 = 512) and k2_zsplit (0 = enough segments
  * for ~256 workgroups: the other half of the chip's workgroup slots is K1's).  insert_wgs: 512-thread workgroups of the insert
- * range, 0 = one per 2048 voxels.  Results are those of link_elk_core_dense_forward with tune.k1_form = 2, bit for bit. */
+ * range, 0 = one per 2048 voxels.  Results are those of link_elk_core_dense_forward with tune.k1_form = 2 and the same k1_wgs / k2_zsplit, bit for bit. */
 int link_elk_core_dense_step3(const link_dc_buffers_t *b_insert /* host */, int64_t n_insert,
                               const link_dc_buffers_t *b_k1 /* host */, int64_t n_k1,
                               const link_dc_buffers_t *b_k2 /* host */, int64_t n_k2, const link_dc_grid_t *g /* host */,

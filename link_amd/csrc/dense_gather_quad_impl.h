@@ -349,7 +349,7 @@ __device__ __forceinline__ void dc_k2q_body(
     }
     if (dbg && lane == 0) {
       unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
-      d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_work; d[4] = 0; d[5] = 0; d[6] = nplanes; d[7] = 1;
+      d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_work; d[4] = tq0; d[5] = 0; d[6] = nplanes; d[7] = 1;
     }
     return;
   }
@@ -504,7 +504,8 @@ __device__ __forceinline__ void dc_k2q_body(
         mx = fmaxf(fmaxf(mx, fabsf(th[0][3])), fabsf(th[1][0]));                       // NaN on either path)
         mx = fmaxf(fmaxf(mx, fabsf(th[1][1])), fabsf(th[1][2]));
         mx = fmaxf(mx, fabsf(th[1][3]));
-        big = !(mx < 32768.0f);
+        big = valid && !(mx < 32768.0f);                // (a quad without a voxel may hold the stale record of an empty cell: it
+                                                        // must not pick the wave's path, or results depend on the previous frame)
       }
       if (__builtin_expect(__any(big), 0)) {
 #pragma unroll
@@ -559,7 +560,7 @@ __device__ __forceinline__ void dc_k2q_body(
   }
   if (dbg && lane == 0) {
     unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
-    d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = 0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
+    d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
   }
 }
 

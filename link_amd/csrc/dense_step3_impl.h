@@ -20,6 +20,12 @@
 // (cg = 32), no alpha, coord_div = 1: the configuration the quad kernel serves.
 #pragma once
 
+#ifndef DC_S3_K2_PRIO
+#define DC_S3_K2_PRIO 3    /* wave priority of the gather range (the longer one: 34.0-36.7 us / frame against 36.0-40.1 at 0) / the pre_mix range */
+#endif
+#ifndef DC_S3_K1_PRIO
+#define DC_S3_K1_PRIO 0
+#endif
 struct dc_s3_k2_t {
   const float *S; const int32_t *cell_n; const int4 *slots; void *out; unsigned long long *dbg; int64_t n;
   int txn, tyn, zsplit, nwg;
@@ -42,12 +48,14 @@ __global__ void __launch_bounds__(512, 4) k_dc_step3(dc_s3_k2_t a2, dc_s3_k1_t a
   constexpr int C = 64, NB = 2;
   int bid = (int)blockIdx.x;
   if (bid < n_k2) {
+    if (DC_S3_K2_PRIO) __builtin_amdgcn_s_setprio(DC_S3_K2_PRIO);
     dc_k2q_body<OP, R, false>(a2.S, a2.cell_n, a2.slots, p.w_pos, nullptr, p.ln_w, p.ln_b, p.cg, 1.0f, p.eps, a2.n, g, a2.txn,
                               a2.tyn, a2.zsplit, a2.nwg, a2.out, a2.dbg, bid);
     return;
   }
   bid -= n_k2;
   if (bid < n_k1) {
+    if (DC_S3_K1_PRIO) __builtin_amdgcn_s_setprio(DC_S3_K1_PRIO);
     dc_k1m_body<C, OP, NB, false>(a1.feats, a1.slots, a1.cnt, a1.cell_n, p.w_pre, p.pre_ln_w, p.pre_ln_b, p.w_pos, nullptr, p.cg,
                                   1.0f, p.eps, a1.n, g, a1.cpw, false, a1.S, a1.fin, a1.hdr, a1.dbg, nullptr, bid);
     return;

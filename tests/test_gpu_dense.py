@@ -274,3 +274,25 @@ def test_module_first_visits_probe_once_and_guess_the_grid(C, groups, baseop, s,
     for plan in blk._dc_plans.values():
         if plan is not None and plan.__dict__.get("_indexed") is None:
             assert int(plan.cnt.sum()) == 0 and int(plan.hdr.abs().sum()) == 0
+
+
+def test_a_frame_result_does_not_depend_on_the_frame_before_it():
+    """The same frame through a fresh plan and through a plan that has just run a bigger, different frame: bitwise equal.
+    (Round 4: quads of the gather kernel that hold no voxel read the record slot of an empty cell -- whatever an earlier frame
+    left there -- and used to take part in the wave's choice between the two sincos paths.)"""
+    import link_amd as la
+    torch.manual_seed(7)
+    blk = la.ELKBlock(64, 64, groups=2, baseop="sin").cuda().eval()
+    par = (blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight,
+           blk.norm.bias)
+    bounds = ((0, 0, 0, 0), (63, 63, 63, 0))
+    a = (torch.randn(20000, 64, generator=torch.Generator().manual_seed(40)).cuda(), s_uniform(20000, grid=64, seed=50).cuda())
+    b = (torch.randn(7000, 64, generator=torch.Generator().manual_seed(41)).cuda(), s_uniform(7000, grid=64, seed=51).cuda())
+    junk = [torch.randint(-2 ** 31, 2 ** 31 - 1, (32 << 20,), dtype=torch.int32, device="cuda") for _ in range(4)]
+    del junk                                             # what torch.empty hands the plans next is not zero
+    for form in (0, 2):
+        mk = lambda: la.ElkCorePlan(20000, 64, "sin", 32, 2, 5, bounds, "cuda", layout="dense", k1_form=form).bind(*par)
+        p1, p2 = mk(), mk()
+        p1.run(*a)
+        after, alone = p1.run(*b).clone(), p2.run(*b).clone()
+        assert torch.equal(after, alone)

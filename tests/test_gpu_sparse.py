@@ -62,8 +62,15 @@ def test_sparse_layout_on_lidar_like_frames(C, groups, baseop, stride, s, r):
         assert rel_err(got.cpu().numpy(), ref) < TOL
         assert rel_err(got.cpu().numpy(), gen.cpu().numpy()) < TOL
         assert torch.equal(sp.run(f, c, build_index=False), got)          # warm index: bitwise
-        for _ in range(3):                                                 # rebuilt: bitwise too (which voxel came first does not matter)
-            assert torch.equal(sp.run(f, c), got)
+        for _ in range(3):
+            # rebuilt: the wave that owns a cell is the one whose id range holds the voxel inserted FIRST (atomic order), so a
+            # cell's rows can sit at other positions of a matrix-core tile and its fp32 sum associate differently: last-bit
+            # agreement, not bitwise (the cell-range form of cos_x sums a cell's rows in id order: bitwise)
+            again = sp.run(f, c)
+            if baseop == "cos_x":
+                assert torch.equal(again, got)
+            else:
+                assert rel_err(again.cpu().numpy(), got.cpu().numpy()) < 2e-6
         assert int(sp.cnt.abs().sum().item()) == 0                         # the counters cleaned themselves
 
 

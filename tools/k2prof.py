@@ -34,5 +34,7 @@ for zs in (0, 2):
             continue
         print(f"zsplit {zs} {nm}: {len(e)} waves, planes {e[:, 6].mean():.1f}; ticks per wave mean (per plane-step)")
         for i, k in enumerate(["total", "dma wait", "barrier", "box sums", "pairs"]):
+            if (role == 2 and i == 1) or (role == 1 and i == 4):   # those words hold the wave's start time
+                continue
             print(f"   {k:10s} {e[:, i].mean():9.0f}  ({e[:, i].sum() / e[:, 6].sum():7.0f})   max {e[:, i].max():9.0f}")
         print(f"   pair-loop iterations per plane-step {e[:, 5].sum() / e[:, 6].sum():.2f}")
