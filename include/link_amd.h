@@ -158,6 +158,19 @@ int link_index_build(const int32_t *coords, int64_t n, const link_grid_t *grid /
                      int32_t *vox_blk, int64_t *idx_query, int32_t *perm, int32_t *vox_sorted,
                      int32_t *pos_blk, int32_t *blk_start, int32_t *blk_coords, int32_t *counts,
                      int32_t *hdr, void *stream);
+/* link_index_build with the blocks numbered in FIRST-VOXEL order instead of cell order: block b is the b-th voxel, in id order,
+ * that has the smallest id of its cell.  For callers that need a numbering, not the reference's (ElkCorePlan: block order never
+ * leaves the arena): the scan runs over the N voxels instead of the V cells of the grid -- on LiDAR stage frames (1-2 % of the
+ * cells occupied) the cell scan is 10-17 us of a 28 us index.  Same outputs and meanings as link_index_build (replaces
+ * utils.py:44-58 up to the order of the rows of small_x.C), except: block order; no cell_counts (cell_pair takes its place);
+ * the previous frame's entries of cell_blk are cleared through its block list (hdr[LINK_HDR_M] rows of blk_coords as the previous
+ * call on these buffers left them), so cell_blk / hdr / blk_coords must be the ones the previous call wrote (or zero-filled).
+ * cell_pair: u64[V], zero-filled once by the caller, zero again after every call.  n < 2^30.  Deterministic: voxel ids, not
+ * insertion order, decide. */
+int link_index_build_first(const int32_t *coords, int64_t n, const link_grid_t *grid /* host */, uint64_t *cell_pair, void *scratch,
+                           size_t scratch_bytes, int32_t *cell_blk, int32_t *vox_blk, int64_t *idx_query, int32_t *perm,
+                           int32_t *vox_sorted, int32_t *pos_blk, int32_t *blk_start, int32_t *blk_coords, int32_t *counts,
+                           int32_t *hdr, void *stream);
 /* The cell half of link_index_build alone (no voxel placement): sorted unique block coordinates blk_coords i32[.,4],
  * counts, cell table and hdr[LINK_HDR_M] of the rows `coords` -- rows outside the grid are dropped (status word).
  * Same scratch / cell_counts contract as link_index_build.  Used for the output-site set of site-creating
@@ -320,6 +333,7 @@ typedef struct {
   int32_t io_dtype;          /* LINK_IO_F32 (0) / LINK_IO_F16 / LINK_IO_BF16: element type of feats and out; 16-bit rows need
                                 LINK_ELK_TILES (the four-kernel form is fp32) */
   int32_t reserved;
+  uint64_t *cell_pair;       /* u64[V] zero-filled once, self-cleaning: link_index_build_first (build_index = 2); NULL otherwise */
 } link_elk_buffers_t;
 
 /* Tile form of the section-C kernels on a built index (elk_tiles_impl.h): TWO launches for R_core instead of four, made for
@@ -358,7 +372,8 @@ int link_elk_gather_demod_tiles_io(const float *S, const float *fin, const int32
                                    const float *ln_b, const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                                    void *out, int32_t io_dtype, void *stream);
 
-
+/* build_index: 0 = the index of the previous call on these buffers (same coordinates); 1 = link_index_build first;
+ * 2 = link_index_build_first first (buf->cell_pair must be set). */
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           int32_t build_index, void *stream);

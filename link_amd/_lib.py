@@ -52,7 +52,7 @@ class LinkElkBuffers(Structure):
                [("scratch_bytes", c_size_t)] + \
                [(k, c_void_p) for k in ("cell_blk", "vox_blk", "idx_query", "perm", "vox_sorted", "pos_blk", "blk_start",
                                         "blk_coords", "counts", "hdr", "fin", "S", "A", "out")] + \
-               [("s_bytes", c_int64), ("io_dtype", c_int32), ("reserved", c_int32)]
+               [("s_bytes", c_int64), ("io_dtype", c_int32), ("reserved", c_int32), ("cell_pair", c_void_p)]
 
 
 class LinkDcGrid(Structure):
@@ -106,6 +106,7 @@ SIGNATURES = {
     "link_index_build": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_size_t,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_index_build_first": (c_int, [c_void_p, c_int64, POINTER(LinkGrid), c_void_p, c_void_p, c_size_t] + [c_void_p] * 11),
     "link_block_gather": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LinkGrid), c_void_p,
                                   POINTER(LinkElkDesc), c_int64, c_void_p, c_void_p]),
     "link_voxel_demod_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

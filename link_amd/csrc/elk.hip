@@ -2611,7 +2611,13 @@ extern "C" int link_elk_core_forward(const link_elk_buffers_t *b, const link_gri
                                      int32_t build_index, void *stream) {
   if (!b || !grid || check_desc(desc) != LINK_OK) return LINK_ERR_ARG;
   int rc;
-  if (build_index) {
+  if (build_index == 2) {                                      // a numbering, not the reference's: scan over the voxels
+    if (!b->cell_pair) return LINK_ERR_ARG;
+    rc = link_index_build_first(b->coords, n, grid, b->cell_pair, b->scratch, b->scratch_bytes, b->cell_blk,
+                                b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->pos_blk, b->blk_start, b->blk_coords,
+                                b->counts, b->hdr, stream);
+    if (rc != LINK_OK) return rc;
+  } else if (build_index) {
     rc = link_index_build(b->coords, n, grid, b->cell_counts, b->scratch, b->scratch_bytes, b->cell_blk,
                           b->vox_blk, b->idx_query, b->perm, b->vox_sorted, b->pos_blk, b->blk_start,
                           b->blk_coords, b->counts, b->hdr, stream);

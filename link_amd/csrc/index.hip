@@ -116,7 +116,7 @@ static inline int64_t scan_tiles(int64_t v) { return (v + SCAN_TILE - 1) / SCAN_
 extern "C" size_t link_index_scratch_bytes(int64_t n, int64_t v) {
   if (n < 0) n = 0;
   if (v < 0) v = 0;
-  return 4 * align256((size_t)n * 4) + align256((size_t)v * 4) + align256((size_t)scan_tiles(v) * 8) + 256;
+  return 4 * align256((size_t)n * 4) + align256((size_t)v * 4) + align256((size_t)scan_tiles(v > n ? v : n) * 8) + 256;
 }
 
 static IndexScratch carve(void *scratch, int64_t n, int64_t v) {
@@ -127,7 +127,7 @@ static IndexScratch carve(void *scratch, int64_t n, int64_t v) {
   s.perm_tmp = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
   s.pos_tmp = reinterpret_cast<int32_t *>(p); p += align256((size_t)n * 4);
   s.cell_start = reinterpret_cast<int32_t *>(p); p += align256((size_t)v * 4);
-  s.desc = reinterpret_cast<unsigned long long *>(p); p += align256((size_t)scan_tiles(v) * 8);
+  s.desc = reinterpret_cast<unsigned long long *>(p); p += align256((size_t)scan_tiles(v > n ? v : n) * 8);
   s.ticket = reinterpret_cast<unsigned int *>(p);
   return s;
 }
@@ -345,12 +345,20 @@ __global__ void __launch_bounds__(256) k_sort_seg(const int32_t *__restrict__ pe
                                                   const int32_t *__restrict__ hdr, int64_t n,
                                                   const int4 *__restrict__ coords,
                                                   int32_t *__restrict__ perm,
-                                                  int4 *__restrict__ vox_sorted) {
+                                                  int4 *__restrict__ vox_sorted,
+                                                  unsigned long long *cell_pair = nullptr,
+                                                  const int4 *__restrict__ blk_coords = nullptr,
+                                                  link_grid_t g = link_grid_t{}) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || p >= hdr[LINK_HDR_NVALID]) return;
   const int32_t i = perm_tmp[p];
   const int32_t b = pos_blk_in[p];                  // same hop as perm_tmp (no voxel -> block chase)
   int32_t st = blk_start[b], en = blk_start[b + 1];
+  if (cell_pair && p == st) {                       // first-voxel numbering: the block's pair word has been read by every voxel
+    const int4 bc = blk_coords[b];                  // of it (k_place_first): back to zero for the next frame's atomics
+    const int32_t cell = cell_of(g, bc.x, bc.y, bc.z, bc.w);
+    if (cell >= 0) cell_pair[cell] = 0ULL;
+  }
   int32_t len = en - st;
   int64_t dst = p;
   if (len > 1 && len <= SORT_MAX_SEG) {
@@ -403,9 +411,266 @@ extern "C" int link_index_build(const int32_t *coords, int64_t n, const link_gri
                        cell_blk, sc.cell_start, sc.perm_tmp, pb, vox_blk, idx_query, hdr);
     hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, pb,
                        blk_start, hdr, n, reinterpret_cast<const int4 *>(coords), perm,
-                       reinterpret_cast<int4 *>(vox_sorted));
+                       reinterpret_cast<int4 *>(vox_sorted), (unsigned long long *)nullptr, (const int4 *)nullptr, *grid);
   }
   return check_launch("link_index_build");
+}
+
+// ---------------------------------------------------------------------------------------------
+// first-voxel numbering: the index of a frame that occupies a small part of a big grid (LiDAR)
+// ---------------------------------------------------------------------------------------------
+// link_index_build numbers the blocks in cell order (what torch.unique gives the reference: utils.py:50-58) with a scan over ALL
+// V cells of the grid -- 10-17 us of the 28 us an S-kitti stage pays for its index, for 1-2 % occupied cells.  A caller that only
+// needs A numbering (ElkCorePlan: the step's output is per voxel, block order never leaves the arena) gets one from a scan over
+// the N voxels instead: block b = the b-th voxel, in id order, that is the smallest id of its cell.  Deterministic (ids, not
+// insertion order, decide), same tables as link_index_build except that blocks are in first-voxel order.  One 8-byte word per
+// cell carries the frame through the three kernels -- (count | code of the smallest id) while the voxels are counted, (segment
+// start | block + 1) once the scan has numbered the cell, zero again when the last kernel is through -- so every kernel reaches
+// what it needs in two dependent loads.  The previous frame's cells leave cell_blk through its block list (hdr[LINK_HDR_M] rows
+// of blk_coords): nothing here is proportional to V.
+constexpr int VSCAN_ITEMS = SCAN_ITEMS;             // tiles over n voxels <= the descriptor slots carved for max(n, v) cells
+constexpr int VSCAN_TILE = SCAN_THREADS * VSCAN_ITEMS;
+constexpr int VSCAN_RESIDENT = 1024;                // tiles that are certainly co-resident (256 CUs x >= 4 such workgroups)
+static inline int64_t vscan_tiles(int64_t n) { return (n + VSCAN_TILE - 1) / VSCAN_TILE; }
+#define LINK_FIRST_CODE(i) (0x7FFFFFFFu - (unsigned int)(i))     /* atomicMax over a zero-initialised word: the smallest id wins */
+
+__global__ void __launch_bounds__(256) k_cell_count_first(const int4 *__restrict__ coords, int64_t n, link_grid_t g,
+                                                          unsigned int *cell_pair /* [V][2]: count, code */,
+                                                          int32_t *__restrict__ vox_cell, int32_t *__restrict__ vox_rank,
+                                                          unsigned long long *desc, int64_t tiles, unsigned int *ticket,
+                                                          int32_t *cell_blk, const int4 *__restrict__ blk_coords_prev,
+                                                          int32_t *hdr) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (gid < n) c = coords[gid];
+  for (int64_t t = gid; t < tiles; t += nthr) desc[t] = 0ULL;
+  if (gid == 0) *ticket = 0u;
+  {                                                  // the previous frame's blocks leave the cell table (their pair words were
+    const int64_t m_prev = hdr[LINK_HDR_M];           // zeroed by that frame's k_sort_seg); hdr: what the previous call on
+    for (int64_t b = gid; b < m_prev; b += nthr) {    // these buffers wrote -- 0 in a zero-filled hdr
+      const int4 pc = blk_coords_prev[b];
+      const int32_t pcell = cell_of(g, pc.x, pc.y, pc.z, pc.w);
+      if (pcell >= 0) cell_blk[pcell] = 0;
+    }
+  }
+  int32_t cell = -1;
+  if (gid < n) {
+    cell = cell_of(g, floordiv(c.x, g.s), floordiv(c.y, g.s), floordiv(c.z, g.s), c.w);
+    vox_cell[gid] = cell;
+    if (cell < 0) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 1);      // published (and reset) by the scan's last tile
+  }
+  // lanes of a wave in the same cell: one pair of atomics between them (see k_cell_count); the group's lowest lane holds
+  // its smallest voxel id
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(cell >= 0), mine = 0;
+  while (todo) {
+    const int cj = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
+    const unsigned long long m = __ballot(cell == cj);
+    if (cell == cj) mine = m;
+    todo &= ~m;
+  }
+  const int leader = mine ? __builtin_ctzll(mine) : lane;
+  unsigned int base = 0;
+  if (cell >= 0 && lane == leader) {
+    base = atomicAdd(&cell_pair[2 * (int64_t)cell], (unsigned int)__popcll(mine));
+    atomicMax(&cell_pair[2 * (int64_t)cell + 1], LINK_FIRST_CODE(gid));
+  }
+  base = __shfl(base, leader, 64);
+  if (cell >= 0) vox_rank[gid] = (int32_t)(base + (unsigned int)__popcll(mine & ((1ull << lane) - 1ull)));
+}
+
+// One decoupled-look-back scan over the N voxels of (is the smallest id of its cell, voxels of that cell).
+// (Placing the voxels in the same pass -- every voxel waiting for its cell's pair word to turn into (start | block + 1) -- was
+// tried: one launch fewer, 2-4 us MORE per stage frame; the placement stores then sit behind the look-back chain.)
+template <bool TICKET>
+__global__ void __launch_bounds__(SCAN_THREADS) k_vox_scan(
+    const int32_t *__restrict__ vox_cell, int64_t n, link_grid_t g, unsigned long long *cell_pair, unsigned long long *desc,
+    unsigned int *ticket, int64_t tiles, int32_t *__restrict__ cell_blk, int32_t *__restrict__ blk_start,
+    int32_t *__restrict__ blk_coords, int32_t *__restrict__ counts, int32_t *__restrict__ hdr) {
+  __shared__ unsigned int s_tile;
+  __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+  __shared__ unsigned long long s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t tile = blockIdx.x;                          // few tiles: all resident, a predecessor is always running
+  if (TICKET) {
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);     // dynamic tile id: predecessors have all started
+    __syncthreads();
+    tile = s_tile;
+  }
+  const int64_t base = tile * VSCAN_TILE + (int64_t)tid * VSCAN_ITEMS;
+  int32_t cell[VSCAN_ITEMS];
+  unsigned int cnt[VSCAN_ITEMS];
+  if (base + VSCAN_ITEMS <= n) {
+#pragma unroll
+    for (int k = 0; k < VSCAN_ITEMS; k += 4) {
+      const int4 q = *reinterpret_cast<const int4 *>(vox_cell + base + k);
+      cell[k] = q.x; cell[k + 1] = q.y; cell[k + 2] = q.z; cell[k + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < VSCAN_ITEMS; k++) cell[k] = (base + k < n) ? vox_cell[base + k] : -1;
+  }
+  unsigned long long pr[VSCAN_ITEMS];
+#pragma unroll
+  for (int k = 0; k < VSCAN_ITEMS; k++) pr[k] = cell[k] >= 0 ? cell_pair[cell[k]] : 0ULL;
+#pragma unroll
+  for (int k = 0; k < VSCAN_ITEMS; k++) {
+    // (a cell already numbered by its first voxel's thread shows (start | block + 1): block + 1 is no voxel's code)
+    const bool first = cell[k] >= 0 && (unsigned int)(pr[k] >> 32) == LINK_FIRST_CODE(base + k);
+    cnt[k] = first ? (unsigned int)pr[k] : 0u;
+    if (!first) cell[k] = -1;
+  }
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int k = 0; k < VSCAN_ITEMS; k++) mine += ((unsigned long long)(cell[k] >= 0) << 32) | cnt[k];
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    unsigned long long x = s_wave[w];
+    if (w < wave) wave_off += x;
+    total += x;
+  }
+  if (wave == 0) {
+    const unsigned t_occ = (unsigned)(total >> 32), t_cnt = (unsigned)(total & 0xFFFFFFFFu);
+    unsigned long long excl = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&desc[0], pack_desc(2u, t_occ, t_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&desc[tile], pack_desc(1u, t_occ, t_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t look = tile - 1;
+      for (;;) {
+        const int64_t t = look - lane;
+        unsigned long long d;
+        if (t >= 0) {
+          do {
+            d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((d >> 62) == 0ULL);
+        } else {
+          d = pack_desc(2u, 0u, 0u);
+        }
+        const unsigned flag = (unsigned)(d >> 62);
+        const unsigned long long val = (((d >> 31) & 0x7FFFFFFFULL) << 32) | (d & 0x7FFFFFFFULL);
+        const unsigned long long pmask = __ballot(flag == 2u);
+        unsigned long long contrib = val;
+        if (pmask != 0ULL) contrib = (lane <= __ffsll((long long)pmask) - 1) ? val : 0ULL;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+        excl += contrib;
+        if (pmask != 0ULL) break;
+        look -= 64;
+      }
+      if (lane == 0) {
+        const unsigned long long inc = excl + total;
+        __hip_atomic_store(&desc[tile], pack_desc(2u, (unsigned)(inc >> 32), (unsigned)(inc & 0xFFFFFFFFu)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == tiles - 1) {
+        const unsigned long long inc = excl + total;
+        const int32_t m = (int32_t)(inc >> 32), nv = (int32_t)(inc & 0xFFFFFFFFu);
+        hdr[LINK_HDR_M] = m;
+        hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];       // bit 0: a voxel outside the grid (k_cell_count_first)
+        hdr[LINK_HDR_STATUS_ACC] = 0;
+        hdr[LINK_HDR_NVALID] = nv;
+        blk_start[m] = nv;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned long long pre = s_excl + wave_off + (incl - mine);
+  unsigned occ = (unsigned)(pre >> 32), vox = (unsigned)(pre & 0xFFFFFFFFu);
+  const uint32_t d3 = (uint32_t)g.dim[3], d2 = (uint32_t)g.dim[2], d1 = (uint32_t)g.dim[1];
+#pragma unroll
+  for (int k = 0; k < VSCAN_ITEMS; k++) {
+    if (cell[k] >= 0) {
+      cell_blk[cell[k]] = (int32_t)occ + 1;
+      cell_pair[cell[k]] = ((unsigned long long)(occ + 1u) << 32) | (unsigned long long)vox;      // (start | block + 1)
+      blk_start[occ] = (int32_t)vox;
+      counts[occ] = (int32_t)cnt[k];
+      uint32_t cc = (uint32_t)cell[k];
+      const uint32_t ub = cc % d3; cc /= d3;
+      const uint32_t uz = cc % d2; cc /= d2;
+      const uint32_t uy = cc % d1; cc /= d1;
+      reinterpret_cast<int4 *>(blk_coords)[occ] =
+          make_int4((int32_t)cc + g.lo[0], (int32_t)uy + g.lo[1], (int32_t)uz + g.lo[2], (int32_t)ub + g.lo[3]);
+      occ++;
+      vox += cnt[k];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_place_first(const int32_t *__restrict__ vox_cell, const int32_t *__restrict__ vox_rank,
+                                                     int64_t n, const unsigned long long *__restrict__ cell_pair,
+                                                     int32_t *__restrict__ perm_tmp, int32_t *__restrict__ pos_blk_out,
+                                                     int32_t *__restrict__ vox_blk, int64_t *__restrict__ idx_query) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t cell = vox_cell[i];
+  const int32_t rank = vox_rank[i];
+  int32_t blk = -1;
+  if (cell >= 0) {
+    const unsigned long long p = cell_pair[cell];     // (segment start | block + 1)
+    blk = (int32_t)(p >> 32) - 1;
+    const int32_t pos = (int32_t)(unsigned int)p + rank;
+    perm_tmp[pos] = (int32_t)i;
+    pos_blk_out[pos] = blk;
+  }
+  vox_blk[i] = blk;
+  if (idx_query) idx_query[i] = (int64_t)blk;
+}
+
+extern "C" int link_index_build_first(const int32_t *coords, int64_t n, const link_grid_t *grid, uint64_t *cell_pair,
+                                      void *scratch, size_t scratch_bytes, int32_t *cell_blk, int32_t *vox_blk,
+                                      int64_t *idx_query, int32_t *perm, int32_t *vox_sorted, int32_t *pos_blk,
+                                      int32_t *blk_start, int32_t *blk_coords, int32_t *counts, int32_t *hdr, void *stream) {
+  if (n < 0 || n >= (1LL << 30) || !grid || !hdr) return LINK_ERR_ARG;
+  int64_t v = 1;
+  for (int a = 0; a < 4; a++) {
+    if (grid->dim[a] <= 0) return LINK_ERR_ARG;
+    v *= grid->dim[a];
+    if (v >= (1LL << 30)) return LINK_ERR_ARG;
+  }
+  if (grid->s <= 0) return LINK_ERR_ARG;
+  if (!cell_pair || !scratch || !cell_blk || !blk_start || !blk_coords || !counts) return LINK_ERR_ARG;
+  if (n > 0 && (!coords || !vox_blk || !perm)) return LINK_ERR_ARG;
+  if (scratch_bytes < link_index_scratch_bytes(n, v)) return LINK_ERR_WORKSPACE;
+  IndexScratch sc = carve(scratch, n, v);
+  const int64_t tiles = vscan_tiles(n);              // <= the descriptor slots carved for max(n, v) cells
+  hipStream_t st = S(stream);
+  unsigned long long *pair = reinterpret_cast<unsigned long long *>(cell_pair);
+  int64_t cc_threads = n > tiles ? n : tiles;
+  if (cc_threads < 65536) cc_threads = 65536;        // (also the threads that walk the previous frame's block list)
+  hipLaunchKernelGGL(k_cell_count_first, dim3(blocks_for(cc_threads, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const int4 *>(coords), n, *grid, reinterpret_cast<unsigned int *>(cell_pair), sc.vox_cell,
+                     sc.vox_rank, sc.desc, tiles, sc.ticket, cell_blk, reinterpret_cast<const int4 *>(blk_coords), hdr);
+  if (n == 0) {                                      // an empty frame: M = 0 (k_vox_scan has no tile to write the totals from)
+    (void)hipMemsetAsync(hdr, 0, 4 * LINK_HDR_WORDS, st);
+    (void)hipMemsetAsync(blk_start, 0, 4, st);
+    return check_launch("link_index_build_first");
+  }
+  if (tiles <= VSCAN_RESIDENT)
+    hipLaunchKernelGGL(k_vox_scan<false>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, st, sc.vox_cell, n, *grid, pair, sc.desc,
+                       sc.ticket, tiles, cell_blk, blk_start, blk_coords, counts, hdr);
+  else
+    hipLaunchKernelGGL(k_vox_scan<true>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, st, sc.vox_cell, n, *grid, pair, sc.desc,
+                       sc.ticket, tiles, cell_blk, blk_start, blk_coords, counts, hdr);
+  int32_t *pb = pos_blk ? pos_blk : sc.pos_tmp;
+  hipLaunchKernelGGL(k_place_first, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.vox_cell, sc.vox_rank, n, pair, sc.perm_tmp, pb,
+                     vox_blk, idx_query);
+  hipLaunchKernelGGL(k_sort_seg, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.perm_tmp, pb, blk_start, hdr, n,
+                     reinterpret_cast<const int4 *>(coords), perm, reinterpret_cast<int4 *>(vox_sorted), pair,
+                     reinterpret_cast<const int4 *>(blk_coords), *grid);
+  return check_launch("link_index_build_first");
 }
 
 // The first half of link_index_build alone: which cells of the grid are occupied, in cell order -- sorted unique

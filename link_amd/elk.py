@@ -165,9 +165,18 @@ class ElkCorePlan:
 
     def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
                  coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0,
-                 frames_in_flight: int = 1, slot_cap: int = 0, sparse_auto: bool = False, **tuning):
+                 frames_in_flight: int = 1, slot_cap: int = 0, sparse_auto: bool = False, block_order: str = "auto",
+                 **tuning):
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
         self.frames_in_flight = max(1, int(frames_in_flight))
+        if block_order not in ("auto", "first", "cell"):
+            raise ValueError(f"block_order must be auto|first|cell, got {block_order!r}")
+        # general layout: "first" numbers the blocks by a scan over the voxels (link_index_build_first) instead of over every cell
+        # of the grid; "cell" keeps the reference's order of small_x.C in the plan's blk_coords / counts (link_index_build).
+        # A/B on one box over the eight LiDAR stage frames (tools/lidar_core.py, ORDER=cell|first): the voxel scan wins where the
+        # grid has many more cells than the frame has voxels (S-kitti stage 1: 982k cells, 59k voxels: 60.4 against 67.2 us with
+        # the index rebuilt) and loses 2-7 us everywhere else (cells <= 5 x voxels) -- "auto" draws the line at 8 x n_cap
+        self.block_order = block_order
         self._tuning = dict(tuning)
         self._tiles_opt = bool(self._tuning.pop("tiles", True))     # general layout: the two-launch tile form where it applies
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
@@ -301,7 +310,11 @@ class ElkCorePlan:
         self.cell_counts = torch.zeros(max(v, 1), **i32)            # self-cleaning
         nbytes = L.lib().link_index_scratch_bytes(n_cap, v)
         self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.cell_blk = torch.empty(max(v, 1), **i32)
+        if self.block_order == "auto":
+            self.block_order = "first" if v > 8 * max(n_cap, 1) else "cell"
+        first = self.block_order == "first"
+        self.cell_blk = torch.zeros(max(v, 1), **i32) if first else torch.empty(max(v, 1), **i32)
+        self.cell_pair = torch.zeros(max(v, 1), dtype=torch.int64, device=device) if first else None      # self-cleaning
         self.vox_blk = torch.empty(n_cap, **i32)
         self.idx_query = torch.empty(n_cap, dtype=torch.int64, device=device)
         self.perm = torch.empty(n_cap, **i32)
@@ -330,6 +343,7 @@ class ElkCorePlan:
         b.vox_sorted, b.pos_blk = self.vox_sorted.data_ptr(), self.pos_blk.data_ptr()
         b.A, b.s_bytes = (self.A.data_ptr() if self.A is not None else None), s_bytes
         b.counts, b.hdr = self.counts.data_ptr(), self.hdr.data_ptr()
+        b.cell_pair = self.cell_pair.data_ptr() if first else None
         b.fin, b.S, b.out = self.fin.data_ptr(), self.S.data_ptr(), self.out.data_ptr()
         self._fn = L.lib().link_elk_core_forward
         self.m_cap = n_cap
@@ -383,7 +397,7 @@ class ElkCorePlan:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n, int(build_index), st)
         else:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
-                          min(self.m_cap, n), 1 if build_index else 0, st)
+                          min(self.m_cap, n), (2 if self.block_order == "first" else 1) if build_index else 0, st)
         if rc != 0:
             L.check(rc, "link_elk_core_dense_forward" if self.dense else "link_elk_core_forward")
         if L.DEBUG:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert L.lib().link_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header (sizes in bytes)
     assert ctypes.sizeof(L.LinkGrid) == 36 and ctypes.sizeof(L.LinkElkDesc) == 28
-    assert ctypes.sizeof(L.LinkElkBuffers) == 28 * 8
+    assert ctypes.sizeof(L.LinkElkBuffers) == 29 * 8
     for which, cls in enumerate((L.LinkGrid, L.LinkElkDesc, L.LinkElkBuffers, L.LinkDcGrid, L.LinkDcTuning, L.LinkDcBuffers)):
         assert handle.link_abi_struct_size(which) == ctypes.sizeof(cls), cls.__name__
     assert handle.link_abi_struct_size(99) == -1

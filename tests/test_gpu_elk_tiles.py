@@ -17,7 +17,10 @@ def _plan_pair(la, blk, n, C, baseop, groups, r, s, coords, coord_div=1.0):
     bounds = coords_bounds(coords)
     plans = []
     for tiles in (True, False):
-        p = la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, coords.device, coord_div=coord_div, layout="general", tiles=tiles)
+        # block_order="cell": the numbering of the module path (BlockIndex = the reference's), so that the bitwise comparisons
+        # with it below hold; the voxel-scan numbering is covered by tests/test_gpu_index_first.py
+        p = la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, coords.device, coord_div=coord_div, layout="general", tiles=tiles,
+                           block_order="cell")
         p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
                blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
         plans.append(p)

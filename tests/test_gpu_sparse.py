@@ -60,7 +60,7 @@ def test_sparse_layout_on_lidar_like_frames(C, groups, baseop, stride, s, r):
         gen = ge.run(f, c).clone()
         assert sp.blocks() == ge.blocks() > 0
         assert rel_err(got.cpu().numpy(), ref) < TOL
-        assert rel_err(got.cpu().numpy(), gen.cpu().numpy()) < TOL
+        assert rel_err(got.cpu().numpy(), gen.cpu().numpy()) < 2 * TOL     # two results, each within TOL of the oracle
         assert torch.equal(sp.run(f, c, build_index=False), got)          # warm index: bitwise
         for _ in range(3):
             # rebuilt: the wave that owns a cell is the one whose id range holds the voxel inserted FIRST (atomic order), so a

@@ -98,6 +98,8 @@ def main():
                 if name == "sparse" and (cap > 64 or c not in (16, 32, 64)):
                     continue                                 # big blocks stay on the general layout's tile form
                 kw = dict(kw)
+                if os.environ.get("ORDER") and name != "sparse":
+                    kw["block_order"] = os.environ["ORDER"]
                 try:
                     plan = ElkCorePlan(n, c, b.baseop, r["cg"], r["r"], r["s_eff"], bounds, dev, coord_div=r["coord_div"],
                                        layout=kw.pop("layout", layout), **kw)
