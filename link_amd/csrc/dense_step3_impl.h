@@ -4,9 +4,9 @@
 // A frame's R_core is three dependent launches -- slot insert, K1 (pre_mix + modulate + per-cell sums), K2 (box gather +
 // de-modulate) -- and none of them fills the chip on its own: K1 is bound by the latency of its record -> row -> MFMA chain at
 // 16 waves per CU, K2 by its plane ring at two workgroups per CU.  Frames issued on separate HIP streams overlap by what the
-// hardware queues happen to interleave (36-41 us / frame on cfg2 depending on the box); stage streams
-// chained by events are worse (54 us: a cross-queue event costs ~14 us, tools/pipe3.py).  The step kernel makes the overlap a
-// property of the launch: its grid is three ranges of workgroups,
+// hardware queues happen to interleave; stage streams chained by events are worse (54 us / frame: a cross-queue event costs
+// ~14 us, tools/pipe3.py).  The step kernel makes the overlap a property of ONE stream and ONE launch per frame: its grid is
+// three ranges of workgroups,
 //
 //     [ K2 of frame t-2 | K1 of frame t-1 | slot insert of frame t ]
 //
@@ -16,12 +16,20 @@
 // whatever their roles; the K2 range is first in the grid so that its workgroups -- the longest -- are placed first, the
 // insert is last and its few workgroups take the slots the other two leave.
 //
+// Measured (cfg2, three different frames in rotation, tools/step3.py, profiles/r04_*_step_kernel_vs_streams.txt): 36.5-42.9 us
+// per frame against 32.9-39.9 for three plans on three streams on the same boxes -- the launch lasts as long as its K2 range
+// (70 k shader ticks; K1's waves end at 47 k on average, 62 k at the latest), and with every wave slot of the chip taken either
+// way the wave-time of the two kernels is what both arrangements are bound by.  So bench.py keeps the streams; the step
+// kernel is for a caller that has ONE stream (a sensor loop inside a larger graph) and wants the overlap anyway: against one
+// plan on one stream (52 us / frame) it is the faster form.
+//
 // A role whose frame pointer is null is absent (pipeline fill and drain).  Two-part rows at C = 64 with the pair form
 // (cg = 32), no alpha, coord_div = 1: the configuration the quad kernel serves.
 #pragma once
 
 #ifndef DC_S3_K2_PRIO
-#define DC_S3_K2_PRIO 3    /* wave priority of the gather range (the longer one: 34.0-36.7 us / frame against 36.0-40.1 at 0) / the pre_mix range */
+#define DC_S3_K2_PRIO 3    /* wave priority of the gather range (the longer one; one frame over and over: 34.0-36.7 us / frame against
+                              36.0-40.1 at priority 0, A/B on one box) / of the pre_mix range */
 #endif
 #ifndef DC_S3_K1_PRIO
 #define DC_S3_K1_PRIO 0

@@ -451,10 +451,12 @@ class ElkCorePipeline:
     pre_mix kernel of the previous frame and the gather + de-modulate kernel of the frame before that.  A frame's result is
     complete (in stream order) after the second push that follows its own -- `push` returns it -- or after `flush()`.
 
-    What a serving loop over a sensor stream holds instead of one ElkCorePlan per HIP stream: the overlap of the three stages
-    is a property of the launch, not of how the hardware queues interleave (36-41 us / frame on cfg2 with three streams,
-    depending on the box).  Dense-cell layout only; C = 64, cg = 32, cos / sin, r in {2, 3}, coord_div = 1, no alpha.
-    Numerically identical to ElkCorePlan(layout="dense", k1_form=2)."""
+    For a caller that has ONE stream (a sensor loop inside a larger graph): the overlap of the three stages is a property of the
+    launch, not of separate hardware queues.  Measured on cfg2 (tools/step3.py): 36.5-42.9 us / frame, against 52 for one
+    ElkCorePlan on one stream and 32.9-39.9 for three plans on three streams on the same boxes -- where several streams are
+    available they remain the faster arrangement (what bench.py times).  Dense-cell layout only; C = 64, cg = 32, cos / sin,
+    r in {2, 3}, coord_div = 1, no alpha.  Bitwise the results of ElkCorePlan(layout="dense", k1_form=2) at the same k1_wgs /
+    k2_zsplit."""
 
     STAGES = 3
 
@@ -1038,13 +1040,15 @@ def _poll_pending_plans() -> None:
     is not one (duplicate coordinates) raises HERE -- at the next plan, the next frame at the latest -- instead of only when
     somebody happens to ask the plan for its density."""
     keep = []
-    for ref in _PENDING_PLANS:
-        plan = ref()
+    waiting = False                                      # plans are issued in stream order: behind the first one whose kernels are
+    for ref in _PENDING_PLANS:                           # still running nothing is asked (an event query is ~5 us of host time,
+        plan = ref()                                     # and a frame with every map rebuilt makes tens of plans)
         if plan is None or plan.exact or plan._density is not None:
             continue
-        if plan._ev.query():
+        if not waiting and plan._ev.query():
             plan._arrived(False)                         # raises LinkAmdError on a bad table
         else:
+            waiting = True
             keep.append(ref)
     _PENDING_PLANS[:] = keep
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host

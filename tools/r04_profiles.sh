@@ -34,6 +34,11 @@ for s in 0 4; do
   [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/kernel_stats_lidar_stage$s.csv | grep -E "k_elk|k_cell_c|k_cell_s|k_place|k_sort" | head -6
   rm -rf $D
 done
+# the voxel-scan numbering of the general layout's index against the cell scan (A/B on this box), and the three-frame step
+# kernel against three plans on three streams
+for o in cell first; do ORDER=$o FORM=tiles timeout 300 python $R/tools/lidar_core.py 2>/dev/null | grep '^{' > $OUT/lidar_stages_order_$o.jsonl; done
+FRAMES=600 timeout 200 python $R/tools/step3.py 2>&1 | grep -E "^frame|us/frame" > $OUT/step_kernel_vs_streams.txt
+cat $OUT/step_kernel_vs_streams.txt
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
   i=$((i+1))
