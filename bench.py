@@ -890,6 +890,37 @@ def main():
         "ranks": rank_rows,          # the trivial result gather: one summary row per rank (frame 0 of each rank)
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
     }
+    # ---- the same frames through ONE stream with the three-frame step kernel (ElkCorePipeline: one launch per frame runs the
+    # slot insert, pre_mix and gather of three consecutive frames) -- what a caller without spare streams gets; reported beside
+    # `single_stream_value`, never the headline (three plans on three streams are faster: DESIGN.md section 4e)
+    if plan.dense and C == 64 and G == 2 and args.io == "f32" and not plan.__dict__.get("sparse"):
+        try:
+            pipe = la.ElkCorePipeline(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
+            pipe.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
+                      blk.norm.weight, blk.norm.bias)
+            k = max(args.steps, 50) * NS
+            got = []
+            for j in range(NS):
+                r_ = pipe.push(frames[j][0], frames[j][1])
+                if r_ is not None:
+                    got.append(r_.clone())
+            got += [t.clone() for t in pipe.flush()]
+            err = max(float((a.float() - b_.float()).abs().max() / b_.float().abs().max()) for a, b_ in zip(got, outs_timed))
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for f in range(k):
+                    pipe.push(frames[f % NS][0], frames[f % NS][1])
+                pipe.flush()
+                torch.cuda.synchronize()
+                t_pipe = time.perf_counter() - t0
+            line["single_stream_step_kernel"] = {
+                "us_per_frame": round(1e6 * t_pipe / k, 2), "value": round(N * k / t_pipe, 1), "frames": k,
+                "max_rel_err_vs_timed_configuration": err,
+                "note": "ElkCorePipeline / link_elk_core_dense_step3: one stream, one launch per frame (fill and drain included)"}
+            del pipe
+        except Exception as e:                          # a side measurement must never cost the line
+            line["single_stream_step_kernel"] = {"error": repr(e)[:200]}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -44,6 +44,9 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     chk = single["timed_configuration_check"]
     assert chk["frames"] == 3 and chk["max_rel_err_vs_single_frame_geometry"] < 2e-6
     assert single["roofline"]["bound"] == "hbm" and 0 < single["roofline"]["frac"] < 1
+    # side measurement: the same frames through one stream with the three-frame step kernel, checked against the timed rows
+    sk = single["single_stream_step_kernel"]
+    assert "error" not in sk and sk["us_per_frame"] > 0 and sk["max_rel_err_vs_timed_configuration"] < 2e-6
 
 
 def test_bench_half_rows_check_reads_what_the_step_wrote():
