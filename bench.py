@@ -230,6 +230,8 @@ def core_roofline(torch, blocks, step, iters=20):
             rec[i]["ev"].append((e0, e1))
             if rec[i]["meta"] is None:
                 rec[i]["call"] = (st.C.contiguous(), st.F.contiguous(), int(s_eff), int(r), w_pos, alpha, int(cg), float(coord_div))
+                ts_ = getattr(st, "s", 1)
+                rec[i]["stride"] = int(ts_[0] if isinstance(ts_, (tuple, list)) else ts_)
                 c = st.C
                 blk = torch.cat([torch.div(c[:, :3], int(s_eff), rounding_mode="floor"), c[:, 3:]], 1)
                 m = int(torch.unique(blk, dim=0).shape[0])
@@ -261,25 +263,40 @@ def core_roofline(torch, blocks, step, iters=20):
     def plan_times(i):
         coords, feats, s_eff, r, w_pos, alpha, cg, coord_div = rec[i]["call"]
         b = blocks[i]
-        try:
-            plan = ElkCorePlan(feats.shape[0], feats.shape[1], b.baseop, cg, r, s_eff, coords_bounds(coords), feats.device,
-                               coord_div=coord_div, layout="general")
-        except Exception:  # noqa: BLE001 -- widths the plan does not take: report the module figure only
-            return None
-        plan.bind(b.pre_mix[0].weight, b.pre_mix[1].weight, b.pre_mix[1].bias, w_pos, alpha, b.norm.weight, b.norm.bias)
-        out = {}
-        for key, rebuild in (("rebuilt", True), ("warm", False)):
-            for _ in range(5):
-                plan.run(feats, coords, build_index=rebuild)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(50):
-                plan.run(feats, coords, build_index=rebuild)
-            e1.record()
-            torch.cuda.synchronize()
-            out[key] = 1e3 * e0.elapsed_time(e1) / 50
-        out["launches_rebuilt"] = 6 if getattr(plan, "tiles", False) else 8
-        return out
+        # voxel sites a block can hold at this tensor stride (coordinates are multiples of the stride)
+        ts = max(int(rec[i]["stride"]), 1)
+        cap = max(1, int(s_eff) // ts) ** 3 if int(s_eff) % ts == 0 else int(s_eff) ** 3
+        best = None
+        for form, kw in (("tiles", dict(layout="general")), ("lean", dict(layout="lean", slot_cap=min(cap, 352)))):
+            try:
+                plan = ElkCorePlan(feats.shape[0], feats.shape[1], b.baseop, cg, r, s_eff, coords_bounds(coords), feats.device,
+                                   coord_div=coord_div, **kw)
+            except Exception:  # noqa: BLE001 -- widths / block sizes the form does not take
+                continue
+            plan.bind(b.pre_mix[0].weight, b.pre_mix[1].weight, b.pre_mix[1].bias, w_pos, alpha, b.norm.weight, b.norm.bias)
+            out = {"form": form}
+            for key, rebuild in (("rebuilt", True), ("warm", False)):
+                for _ in range(5):
+                    plan.run(feats, coords, build_index=rebuild)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    plan.run(feats, coords, build_index=rebuild)
+                e1.record()
+                torch.cuda.synchronize()
+                out[key] = 1e3 * e0.elapsed_time(e1) / 50
+            if form == "lean":
+                plan.check()                                  # no voxel dropped: the slot capacity held
+            out["launches_rebuilt"] = 3 if form == "lean" else (6 if getattr(plan, "tiles", False) else 8)
+            out["by_form"] = dict(best["by_form"]) if best else {}
+            out["by_form"][form] = {"rebuilt_us": round(out["rebuilt"], 2), "warm_us": round(out["warm"], 2),
+                                    "launches_rebuilt": out["launches_rebuilt"]}
+            if best is None or out["rebuilt"] < best["rebuilt"]:
+                best = out
+            else:
+                best["by_form"] = out["by_form"]
+            del plan
+        return best
     stages, tot_b, tot_t, tot_reb = [], 0.0, 0.0, 0.0
     for i, r_ in enumerate(rec):
         m = r_["meta"]
@@ -294,7 +311,7 @@ def core_roofline(torch, blocks, step, iters=20):
             st_row.update({"plan_us_rebuilt_index": round(pt["rebuilt"], 2), "plan_us_warm_index": round(pt["warm"], 2),
                            "frac_rebuilt_index": round(alg / (pt["rebuilt"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                            "frac_warm_index": round(alg / (pt["warm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                           "launches_rebuilt": pt["launches_rebuilt"]})
+                           "launches_rebuilt": pt["launches_rebuilt"], "form_rebuilt": pt["form"], "rebuilt_by_form": pt["by_form"]})
             tot_reb += pt["rebuilt"]
         stages.append(st_row)
         tot_b += alg

@@ -37,7 +37,7 @@ extern "C" {
 /* Version of this ABI (bumped on any signature change). */
 int link_abi_version(void);
 /* sizeof of the structs crossing this boundary (0 link_grid_t, 1 link_elk_desc_t, 2 link_elk_buffers_t, 3 link_dc_grid_t,
- * 4 link_dc_tuning_t, 5 link_dc_buffers_t; -1 otherwise): what a binding checks its own layout against. */
+ * 4 link_dc_tuning_t, 5 link_dc_buffers_t, 6 link_lean_buffers_t; -1 otherwise): what a binding checks its own layout against. */
 int32_t link_abi_struct_size(int32_t which);
 /* Human-readable last HIP error string of the calling thread ("" if none). Host pointer. */
 const char *link_last_error(void);
@@ -377,6 +377,47 @@ int link_elk_gather_demod_tiles_io(const float *S, const float *fin, const int32
 int link_elk_core_forward(const link_elk_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                           const link_elk_desc_t *desc /* host */, int64_t n, int64_t m_cap,
                           int32_t build_index, void *stream);
+
+/* Lean form of R_core with the index REBUILT every call (round 4, csrc/elk_lean_impl.h): THREE launches, none proportional to the
+ * grid, for the LiDAR stage frames the reference feeds its blocks (linkunet.py:345-363, scn.py:586-607: a few thousand to a few ten
+ * thousand voxels, block grid 1-20 % occupied).  Replaces, per call, what the reference rebuilds per call: sphash + torch.unique +
+ * sphashquery (utils.py:44-63, query_cuda.cu:9-58) and the voxelize / devoxelize pair (voxelize_cuda.cu:12-25,
+ * devoxelize_cuda.cu:11-34) around linkunet.py:132-178.
+ *   launch 1  X rows [F cos | F sin (| F theta)] of the voxels in input order (pre_mix on the matrix cores, LayerNorm, theta,
+ *             sincos) into `X`; rank = cnt[cell]++, list[cell][rank] = voxel id; one work item (cell * 16 + chunk) per started
+ *             chunk of 32 voxels of a cell, appended to one of 16 item lists (one atomic per workgroup); workgroups behind the
+ *             frame's own clear the previous frame's counters through its item lists;
+ *   launch 2  a wave per item: the chunk's voxels in ascending id (ranked by counting),
+ *             S[cell][chunk] = sum of their X rows, their records (x, y, z, id) in that order -> rec2;
+ *   launch 3  a wave per item: chunk rows of the r^3 neighbour cells (present iff cnt > 0; the first chunk of each is requested
+ *             together with the counts) summed and divided by the summed count, the chunk's voxels de-modulated and
+ *             LayerNorm'ed -> out.  cos_x reads fin * theta back from the voxel's X row.
+ * Bitwise reproducible (sums in id order, fixed combination order).  No block numbering exists: tables are addressed by grid
+ * cell and touched only where voxels land.  C in {16, 32, 64, 128}, r in {2, 3}, k <= 352, cells < 2^27.
+ * The caller alternates (cnt, occ, ctrl) with (cnt_prev, occ_prev, ctrl_prev) between indexed steps (build_index = 1); with
+ * build_index = 0 the lists of the previous step on the same buffers are reused (same coordinates) and the *_prev members are
+ * not touched.  `n_prev`: voxels of the previous indexed step (0 on the first).
+ * hdr: STATUS bit 0 a voxel outside the grid, bit 1 a cell over capacity (such voxels get no output row). */
+typedef struct {
+  const void *feats;          /* [N,C] io_dtype rows */
+  const int32_t *coords;      /* i32[N,4] */
+  const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;   /* as link_elk_buffers_t */
+  uint32_t *cnt, *cnt_prev;   /* u32[V] each, zero-filled once; self-cleaning from then on */
+  int32_t *list;              /* i32[V*k]: voxel ids of a cell in arrival order */
+  int32_t *rec2;              /* i32[16*seg_cap*32][4]: records (x, y, z, id) of an item's voxels in ascending id */
+  int32_t *occ, *occ_prev;    /* i32[16 * seg_cap] each: work items, list l at l * seg_cap */
+  uint32_t *ctrl, *ctrl_prev; /* u32[256] each, zero-filled once: item count of list l at word 16 l */
+  float *X;                   /* f32[n_cap, P*C] scratch */
+  float *S;                   /* f32[V * kch, P*C] chunk rows by cell, kch = ceil(k / 32); needs no initialisation */
+  int32_t *hdr;               /* i32[8] zero-filled once */
+  void *out;                  /* [N,C] io_dtype rows */
+  int64_t seg_cap;            /* items a list holds: >= ceil(ceil(n_cap / 64) / 16) * 64 + 64 */
+  int32_t k;                  /* slot capacity of a cell (s^3 clipped to 352) */
+  int32_t io_dtype;           /* LINK_IO_* */
+} link_lean_buffers_t;
+int link_elk_core_lean_forward(const link_lean_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
+                               const link_elk_desc_t *desc /* host */, int64_t n, int64_t n_prev, int32_t build_index,
+                               void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training form of R_core (forward with saved state + hand-written backward).

@@ -18,7 +18,7 @@ HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -80,6 +80,15 @@ class LinkDcBuffers(Structure):
                                         "ln_w", "ln_b", "cnt", "slots", "sid", "vrec", "vcell", "cell_n", "hdr", "fin",
                                         "S", "A", "out")] + [("io_dtype", c_int32), ("tune", LinkDcTuning)]
 
+
+class LinkLeanBuffers(Structure):
+    """link_lean_buffers_t (lean form of R_core: three launches with the index rebuilt)"""
+    _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha", "ln_w", "ln_b",
+                                        "cnt", "cnt_prev", "list", "rec2", "occ", "occ_prev", "ctrl", "ctrl_prev", "X", "S",
+                                        "hdr", "out")] + [("seg_cap", c_int64), ("k", c_int32), ("io_dtype", c_int32)]
+
+
+LEAN_KMAX, LEAN_SEGS, LEAN_CHUNK = 352, 16, 32
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
 SIGNATURES = {
@@ -208,6 +217,8 @@ SIGNATURES = {
                                             c_int64, c_int32, c_void_p]),
     "link_elk_core_sparse_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                              c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "link_elk_core_lean_forward": (c_int, [POINTER(LinkLeanBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc), c_int64, c_int64,
+                                           c_int32, c_void_p]),
     "link_elk_core_dense_step3": (c_int, [POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcBuffers), c_int64,
                                           POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                           c_int32, c_void_p]),
@@ -245,7 +256,7 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         if handle.link_abi_version() != ABI_VERSION:
             raise LinkAmdError("liblink_amd.so ABI version mismatch; rebuild with link_amd/build.py")
-        for which, cls in enumerate((LinkGrid, LinkElkDesc, LinkElkBuffers, LinkDcGrid, LinkDcTuning, LinkDcBuffers)):
+        for which, cls in enumerate((LinkGrid, LinkElkDesc, LinkElkBuffers, LinkDcGrid, LinkDcTuning, LinkDcBuffers, LinkLeanBuffers)):
             if handle.link_abi_struct_size(which) != ctypes.sizeof(cls):
                 raise LinkAmdError(f"liblink_amd.so: layout of {cls.__name__} differs from include/link_amd.h "
                                    f"({ctypes.sizeof(cls)} bytes here, {handle.link_abi_struct_size(which)} in the library)")

@@ -18,7 +18,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 SO = os.path.join(LIBDIR, "liblink_amd.so")
 SOURCES = ["ops.hip", "index.hip", "aggregate.hip", "elk.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "dense.hip", "dense_fused.hip", "dense_fused_f16.hip", "dense_fused_bf16.hip",
-           "dense_tiles.hip", "dense_tiles_f16.hip", "dense_tiles_bf16.hip", "elk_tiles.hip", "elk_tiles_f16.hip", "elk_tiles_bf16.hip"]
+           "dense_tiles.hip", "dense_tiles_f16.hip", "dense_tiles_bf16.hip", "elk_tiles.hip", "elk_tiles_f16.hip", "elk_tiles_bf16.hip",
+           "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("LINK_AMD_CXXFLAGS", "").split()      # A/B experiments (-DNAME=value); part of the build stamp
@@ -39,6 +40,21 @@ def _stamp():
     return h.hexdigest()
 
 
+def _obj_key(src, dep_file):
+    """Hash of one translation unit's inputs: the files its last compile read (hipcc -MD) + the flags."""
+    deps = [os.path.join(CSRC, src)]
+    if os.path.exists(dep_file):
+        txt = open(dep_file).read().replace("\\\n", " ")
+        deps = [d for d in txt.split(":", 1)[1].split() if d.startswith(ROOT)] or deps
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in sorted(set(deps)):
+        if not os.path.exists(d):
+            return None
+        with open(d, "rb") as f:
+            h.update(d.encode()); h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     stamp_file = os.path.join(LIBDIR, "stamp")
@@ -48,11 +64,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cc = _hipcc()
 
     def one(src):
+        # per-object rebuild: an object is kept while the files its last compile read (its .d list) and the flags are unchanged
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        dep, key_file = obj + ".d", obj + ".key"
+        key = _obj_key(src, dep)
+        if not force and key and os.path.exists(obj) and os.path.exists(key_file) and open(key_file).read() == key:
+            return obj
+        cmd = [cc] + FLAGS + ["-MD", "-MF", dep, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        key = _obj_key(src, dep)
+        if key:
+            with open(key_file, "w") as f:
+                f.write(key)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

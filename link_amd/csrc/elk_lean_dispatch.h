@@ -1,0 +1,80 @@
+// link_amd/csrc/elk_lean_dispatch.h -- launch + template dispatch of the lean-form kernels (elk_lean_impl.h) for the I/O type
+// of the including translation unit (DC_IO / DC_IO_NS).  Defines DC_IO_NS::run_lean, which the C ABI in elk_lean.hip calls
+// after validating the arguments.
+namespace DC_IO_NS {
+using namespace link;
+
+template <int C, int OP, int NB>
+static void launch_lean_a(const lean_args &a, int64_t n_prev, hipStream_t st) {
+  const int lds = dc_wimg<C>::W_BYTES;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lean_insert_premix<C, OP, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  // the frame's workgroups, then (indexed steps) 256 item slots of the previous frame per workgroup to clean its counters
+  const int64_t wgs = (int64_t)a.nwg + (a.build ? ((int64_t)LEAN_SEGS * a.idx_cap_prev + 255) / 256 : 0);
+  if (wgs < 1) return;
+  hipLaunchKernelGGL((k_lean_insert_premix<C, OP, NB>), dim3((unsigned)wgs), dim3(256), lds, st, a);
+}
+
+template <int C, int OP>
+static void lean_nb(const link_elk_desc_t &d, const lean_args &a, int64_t n_prev, hipStream_t st) {
+  constexpr int T = C / 16;
+  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
+  if (nb > T) nb = T;
+  if (T >= 2 && nb == T / 2) return launch_lean_a<C, OP, (T >= 2 ? T / 2 : 1)>(a, n_prev, st);
+  if (T >= 4 && nb == T / 4) return launch_lean_a<C, OP, (T >= 4 ? T / 4 : 1)>(a, n_prev, st);
+  return launch_lean_a<C, OP, T>(a, n_prev, st);
+}
+
+// a wave per item slot (16 lists x idx_cap entries), at most 4096 workgroups (then a wave strides through its list); a multiple
+// of 4 workgroups so that the stride is a multiple of the 16 lists
+static unsigned lean_item_wgs(int idx_cap) {
+  int64_t w = ((int64_t)LEAN_SEGS * idx_cap + LEAN_IW - 1) / LEAN_IW;
+  if (w > 4096) w = 4096;
+  if (w < 4) w = 4;
+  return (unsigned)((w + 3) & ~(int64_t)3);
+}
+
+template <int C, int OP>
+static int lean_c_op(const link_elk_desc_t &d, const lean_args &a, int64_t n_prev, hipStream_t st) {
+  constexpr int P = op_parts<OP>::value;
+  lean_nb<C, OP>(d, a, n_prev, st);
+  hipLaunchKernelGGL((k_lean_sums<C, P>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
+  if (d.r == 2) hipLaunchKernelGGL((k_lean_gather<C, OP, 2>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
+  else hipLaunchKernelGGL((k_lean_gather<C, OP, 3>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
+  return check_launch("link_elk_core_lean_forward");
+}
+
+template <int C>
+static int lean_c(const link_elk_desc_t &d, const lean_args &a, int64_t n_prev, hipStream_t st) {
+  switch (d.op) {
+    case LINK_OP_COS: return lean_c_op<C, LINK_OP_COS>(d, a, n_prev, st);
+    case LINK_OP_SIN: return lean_c_op<C, LINK_OP_SIN>(d, a, n_prev, st);
+    default: return lean_c_op<C, LINK_OP_COSX>(d, a, n_prev, st);
+  }
+}
+
+int run_lean(const link_lean_buffers_t &b, const link_grid_t &g, const link_elk_desc_t &d, int64_t n, int64_t n_prev, int build,
+             hipStream_t st) {
+  lean_args a;
+  a.feats = b.feats; a.coords = reinterpret_cast<const int4 *>(b.coords);
+  a.w_pre = b.w_pre; a.pre_ln_w = b.pre_ln_w; a.pre_ln_b = b.pre_ln_b; a.w_pos = b.w_pos; a.alpha = b.alpha;
+  a.ln_w = b.ln_w; a.ln_b = b.ln_b;
+  a.g = g; a.cg = d.cg; a.coord_div = d.coord_div; a.eps = d.eps;
+  a.n = (int)n; a.k = b.k; a.kch = (b.k + LEAN_CH - 1) / LEAN_CH; a.build = build;
+  // a list receives the items of every 16th workgroup of launch 1, at most 64 each
+  a.nwg = (int)((n + 63) / 64);
+  a.idx_cap = (int)(((n + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64);
+  a.idx_cap_prev = (int)(((n_prev + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64);
+  a.seg_cap = b.seg_cap;
+  a.cnt = b.cnt; a.cnt_prev = b.cnt_prev; a.list = b.list; a.occ = b.occ; a.occ_prev = b.occ_prev;
+  a.ctrl = b.ctrl; a.ctrl_prev = b.ctrl_prev; a.rec2 = reinterpret_cast<int4 *>(b.rec2);
+  a.X = b.X; a.S = b.S; a.hdr = b.hdr; a.out = b.out;
+  switch (d.c) {
+    case 16: return lean_c<16>(d, a, n_prev, st);
+    case 32: return lean_c<32>(d, a, n_prev, st);
+    case 64: return lean_c<64>(d, a, n_prev, st);
+    default: return lean_c<128>(d, a, n_prev, st);
+  }
+}
+
+}  // namespace DC_IO_NS

@@ -1,0 +1,488 @@
+// link_amd/csrc/elk_lean_impl.h -- lean form of R_core with the index REBUILT every call (round 4; include/link_amd.h
+// section C, link_elk_core_lean_forward): three launches, none of them proportional to the grid, each a short chain of
+// dependent memory round trips -- made for the LiDAR stage frames of linkunet.py:345-363 / scn.py:586-607 (a few thousand to a
+// few ten thousand voxels in a block grid that is 1-20 % occupied), where the reference rebuilds its hash / unique / neighbour
+// maps on every call and the six-launch path (four index kernels + the two tile kernels) spends most of its time in launch
+// boundaries and dependency chains, not in bytes.
+//
+//   k_lean_insert_premix   one 16-voxel tile per wave IN INPUT ORDER (coalesced rows, no index needed): pre_mix on the matrix
+//                          cores + LayerNorm + theta + sincos + modulate -> X rows [F cos | F sin (| F theta)] in a scratch
+//                          matrix; at the same time the voxel's block cell gets it: rank = cnt[cell]++, list[cell][rank] = id,
+//                          and the voxel whose rank is a multiple of 32 appends the work item (cell, rank / 32) to one of 16
+//                          item lists (one atomic per workgroup and list counter: same-address atomics serialise).  Extra
+//                          workgroups behind the frame's own clear the PREVIOUS frame's counters through its item lists
+//                          (cnt is double-buffered).
+//   k_lean_sums            a wave per item = one chunk of <= 32 voxels of one cell, taken in ascending voxel id (the ranks came
+//                          from atomics, so the wave ranks the cell's ids by counting): S[cell][chunk] = sum of their X rows,
+//                          lane groups over the voxels, combined in a fixed order -- bitwise reproducible; the chunk's
+//                          records (x, y, z, id) in id order go to rec2.
+//   k_lean_gather          a wave per item: the first chunk row of each of the r^3 neighbour cells is requested together with
+//                          their counts (address arithmetic only; a row counts iff its cell's cnt > 0), further chunks of
+//                          bigger neighbours after the counts; sum / summed count, then the chunk's voxels de-modulated +
+//                          LayerNorm'ed by the lane groups.
+// Dependent memory round trips per launch: 2-3 (coords + rows -> atomic -> stores; item -> count + ids -> X rows -> stores;
+// item -> records + counts + rows -> stores).
+// The block table is addressed by CELL (no numbering, no scan, no sort of the frame): rows are touched only where voxels
+// land.  cos_x needs no fin matrix: its de-modulation term fin * theta is the third part of the voxel's own X row.
+// Compiled per feature I/O type (DC_IO / DC_IO_NS) like the tile form.
+#pragma once
+#include "tile_common.h"
+
+namespace DC_IO_NS {
+using namespace link;
+
+constexpr int LEAN_CH = 32;          // voxels per chunk (work item; 64 measured slower: the per-item voxel loop is serial)
+constexpr int LEAN_KMAX = 352;       // slot capacity of a cell (7^3 = 343 rounded up to chunks)
+constexpr int LEAN_SEGS = 16;        // item lists (their counters on separate 64-byte lines: same-address atomics serialise)
+constexpr int LEAN_IW = 4;           // waves per workgroup of launches 2 / 3, a wave per item
+
+struct lean_args {
+  const void *feats;
+  const int4 *coords;
+  const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;
+  link_grid_t g;
+  int cg;
+  float coord_div, eps;
+  int n, k, kch, build, nwg, idx_cap, idx_cap_prev;
+  int64_t seg_cap;
+  uint32_t *cnt, *cnt_prev;
+  int32_t *list, *occ;
+  const int32_t *occ_prev;
+  uint32_t *ctrl, *ctrl_prev;
+  int4 *rec2;
+  float *X, *S;
+  int32_t *hdr;
+  void *out;
+};
+
+// Items are appended to list sg = (workgroup of launch 1) % 16 with one atomic per workgroup; wave j of launches 2 / 3 takes
+// entry j / 16 of list j % 16 -- the entry and the list's count are requested together (no prefix over the counts, no
+// dependent fetch), a wave whose entry lies beyond the count has nothing to do.
+
+// ---------------------------------------------------------------------------------------------
+// launch 1: X rows of the voxels in input order + slot insert + clean-up of the previous frame
+// ---------------------------------------------------------------------------------------------
+template <int C, int OP, int NB>
+__global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(const lean_args a) {
+  constexpr int T = C / 16, P = op_parts<OP>::value, W = P * C;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ int s_new[4], s_base;
+  float *ln_lds = reinterpret_cast<float *>(smem_raw + dc_wimg<C>::WIMG_BYTES);
+  float *pw_lds = ln_lds + 2 * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, gq = lane >> 4;
+  // workgroups behind the frame's own: the previous indexed frame's counters go back to zero through its item lists
+  // (nothing is proportional to the grid)
+  if ((int)blockIdx.x >= a.nwg) {
+    const int q = ((int)blockIdx.x - a.nwg) * 256 + tid;
+    const int sg = q & (LEAN_SEGS - 1), idx = q >> 4;
+    if (idx < a.idx_cap_prev) {
+      const int c = (int)a.ctrl_prev[sg * 16];
+      const int it = a.occ_prev[(int64_t)sg * a.seg_cap + idx];
+      if (idx < c && (it & 15) == 0) a.cnt_prev[it >> 4] = 0u;
+    }
+    return;
+  }
+  const int i = blockIdx.x * 64 + wave * 16 + li;
+  const bool valid = i < a.n;
+  const int ic = valid ? i : a.n - 1;
+  const int4 rec = a.coords[ic];
+  const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(a.feats, (uint32_t)((int64_t)a.n * C * IO_BYTES));
+  float4 ff[T];
+  {
+    const uint32_t ro = ((uint32_t)ic * (uint32_t)C + (uint32_t)(4 * gq)) * (uint32_t)IO_BYTES;
+    ff[0] = io_ldb4<0>(r_feats, ro);
+    if constexpr (T > 1) ff[1] = io_ldb4<16>(r_feats, ro);
+    if constexpr (T > 2) { ff[2] = io_ldb4<32>(r_feats, ro); ff[3] = io_ldb4<48>(r_feats, ro); }
+    if constexpr (T > 4) { ff[4] = io_ldb4<64>(r_feats, ro); ff[5] = io_ldb4<80>(r_feats, ro); ff[6] = io_ldb4<96>(r_feats, ro); ff[7] = io_ldb4<112>(r_feats, ro); }
+  }
+  bool w_big = dc_stage_weights<C, 256>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
+  // ---- slot insert: the lane group gq == 0 of each wave speaks for the tile's 16 voxels; the atomic is on its way while
+  // the tile is worked on ----
+  const bool ins = a.build && valid && gq == 0;
+  int cell = -1, rank = 0;
+  if (ins) {
+    cell = cell_of(a.g, floordiv(rec.x, a.g.s), floordiv(rec.y, a.g.s), floordiv(rec.z, a.g.s), rec.w);
+    if (cell < 0) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 1);
+    else rank = (int)atomicAdd(&a.cnt[cell], 1u);
+  }
+  w_big = __syncthreads_or(w_big) != 0;
+  const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
+  floatx4 ac[T];
+  dc_premix_tile<C>(wh, a.w_pre, w_big, li, gq, ff, ac);
+  float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
+  if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
+  float th[NB][4], sn[NB][4], cs[NB][4];
+  auto trig = [&](int tb, float (&th_)[4], float (&sn_)[4], float (&cs_)[4]) {
+    const float4 q0 = *reinterpret_cast<const float4 *>(&pw_lds[16 * tb + 4 * gq]);
+    const float4 q1 = *reinterpret_cast<const float4 *>(&pw_lds[C + 16 * tb + 4 * gq]);
+    const float4 q2 = *reinterpret_cast<const float4 *>(&pw_lds[2 * C + 16 * tb + 4 * gq]);
+    const float4 qa = *reinterpret_cast<const float4 *>(&pw_lds[3 * C + 16 * tb + 4 * gq]);
+    th_[0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th_[1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
+    th_[2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th_[3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) big |= !(fabsf(th_[r]) < 32768.0f);
+    if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sincos_nocall(th_[r], sn_[r], cs_[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sincos_small(th_[r], sn_[r], cs_[r]);
+    }
+  };
+  if constexpr (NB < T) {
+#pragma unroll
+    for (int tb = 0; tb < NB; tb++) trig(tb, th[tb], sn[tb], cs[tb]);
+  }
+  // LayerNorm over the voxel's C channels: 4T in-lane values + the 4 lane groups
+  float s = 0.f;
+#pragma unroll
+  for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
+  s = dc_sum_groups(s);
+  const float mean = s * (1.0f / C);
+  float qq = 0.f;
+#pragma unroll
+  for (int tp = 0; tp < T; tp++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float d = ac[tp][r] - mean;
+      qq += d * d;
+    }
+  qq = dc_sum_groups(qq);
+  const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + a.eps);
+  float *xrow = a.X + (int64_t)ic * W + 4 * gq;
+#pragma unroll
+  for (int tp = 0; tp < T; tp++) {
+    const int tb = tp % NB;
+    const float4 lw = *reinterpret_cast<const float4 *>(&ln_lds[16 * tp + 4 * gq]);
+    const float4 lb = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * tp + 4 * gq]);
+    float th1[4], sn1[4], cs1[4];
+    if constexpr (NB == T) trig(tp, th1, sn1, cs1);
+    const float fv[4] = {(ac[tp][0] - mean) * rstd * lw.x + lb.x, (ac[tp][1] - mean) * rstd * lw.y + lb.y,
+                         (ac[tp][2] - mean) * rstd * lw.z + lb.z, (ac[tp][3] - mean) * rstd * lw.w + lb.w};
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float th_ = NB == T ? th1[r] : th[tb][r], sn_ = NB == T ? sn1[r] : sn[tb][r], cs_ = NB == T ? cs1[r] : cs[tb][r];
+        if (pp == 2) pv[r] = fv[r] * th_;
+        else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[r] = fv[r] * sn_;
+        else pv[r] = fv[r] * cs_;
+      }
+      if (valid) *reinterpret_cast<float4 *>(xrow + pp * C + 16 * tp) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    }
+  }
+  if (!a.build) return;                                  // kernel-uniform
+  // ---- the ranks are back: slot lists, and the work items (one per started chunk of 32) ----
+  const bool full = cell >= 0 && rank >= a.k;
+  if (full) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 2);
+  const bool keep = cell >= 0 && !full;
+  if (keep) a.list[(int64_t)cell * a.k + rank] = i;
+  const bool item = keep && (rank & (LEAN_CH - 1)) == 0;
+  const unsigned long long im = __ballot(item);
+  if (lane == 0) s_new[wave] = __popcll(im);
+  __syncthreads();
+  const int n0 = s_new[0], n1 = s_new[1], n2 = s_new[2], n3 = s_new[3];
+  const int sg = blockIdx.x % LEAN_SEGS;
+  if (tid == 0) s_base = (n0 + n1 + n2 + n3) ? (int)atomicAdd(&a.ctrl[sg * 16], (unsigned)(n0 + n1 + n2 + n3)) : 0;
+  __syncthreads();
+  if (item) {
+    const int before = (wave > 0 ? n0 : 0) + (wave > 1 ? n1 : 0) + (wave > 2 ? n2 : 0) + __popcll(im & ((1ull << lane) - 1ull));
+    a.occ[(int64_t)sg * a.seg_cap + s_base + before] = cell * 16 + rank / LEAN_CH;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch 2: chunk sums
+// ---------------------------------------------------------------------------------------------
+template <int C, int P>
+__global__ void __launch_bounds__(64 * LEAN_IW) k_lean_sums(const lean_args a) {
+  constexpr int W = P * C, LPR = C / 4, G = 64 / LPR;
+  __shared__ __attribute__((aligned(16))) int ids_lds[LEAN_IW][LEAN_KMAX + 4];
+  __shared__ int sorted_lds[LEAN_IW][LEAN_CH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & (LPR - 1), grp = lane / LPR;
+  if (a.build && blockIdx.x == 0 && tid < LEAN_SEGS) a.ctrl_prev[tid * 16] = 0u;      // the next frame appends from zero
+  int *ids = ids_lds[wave], *sorted = sorted_lds[wave];
+  const int kl = a.k < 64 ? a.k : 64;
+  const int j0 = blockIdx.x * LEAN_IW + wave;
+  const int sg = j0 & (LEAN_SEGS - 1);                   // the stride below is a multiple of 16: a wave stays with its list
+  const int nitem = (int)a.ctrl[sg * 16];
+  int idx = j0 >> 4;
+  int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;      // garbage beyond nitem: never used
+  const int step = (int)(gridDim.x * LEAN_IW) >> 4;
+  for (; idx < nitem; idx += step) {
+    const int it = it_n;
+    if (idx + step < nitem) it_n = a.occ[(int64_t)sg * a.seg_cap + idx + step];
+    const int64_t slot = (int64_t)sg * a.seg_cap + idx;
+    const int cell = it >> 4, chunk = it & 15;
+    const int32_t *lst = a.list + (int64_t)cell * a.k;
+    const int spec = lane < kl ? lst[lane] : INT_MAX;    // the first 64 ids without waiting for the count
+    const int cn = (int)a.cnt[cell];
+    const int nc = cn < a.k ? cn : a.k;
+    ids[lane] = lane < nc ? spec : INT_MAX;
+    for (int l = 64 + lane; l < nc + 4; l += 64) ids[l] = l < nc ? lst[l] : INT_MAX;    // padded to whole int4 pieces
+    if (nc < 64 && lane < 4) ids[64 + lane] = INT_MAX;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // rank of every id among the cell's ids (unique: voxel ids) by counting; the chunk's 32 go to their places
+    const int lo = chunk * LEAN_CH;
+    for (int l0 = 0; l0 < nc; l0 += 64) {
+      const int l = l0 + lane;
+      const int my = l < nc ? ids[l] : INT_MAX;
+      int rk = 0;
+      for (int q = 0; q < nc; q += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(&ids[q]);
+        rk += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+      }
+      if (l < nc && rk >= lo && rk < lo + LEAN_CH) sorted[rk - lo] = my;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nch = nc - lo < LEAN_CH ? nc - lo : LEAN_CH;
+    // the chunk's records in id order for launch 3 (no dependent coordinate fetch there)
+    int4 myrec = make_int4(0, 0, 0, 0);
+    if (lane < nch) {
+      const int id = sorted[lane];
+      myrec = a.coords[id];
+      myrec.w = id;
+    }
+    float4 acc[P];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;                                 // rows in flight per lane group
+    for (int m0 = 0; m0 < nch; m0 += U * G) {
+      float4 v[U][P];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int m = m0 + u * G + grp;
+        const int id = sorted[m < nch ? m : 0];
+        const float *row = a.X + (int64_t)id * W + 4 * li;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) v[u][pp] = *reinterpret_cast<const float4 *>(row + pp * C);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool ok = m0 + u * G + grp < nch;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          acc[pp].x += ok ? v[u][pp].x : 0.f; acc[pp].y += ok ? v[u][pp].y : 0.f;
+          acc[pp].z += ok ? v[u][pp].z : 0.f; acc[pp].w += ok ? v[u][pp].w : 0.f;
+        }
+      }
+    }
+    if (lane < nch) a.rec2[slot * LEAN_CH + lane] = myrec;
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        acc[pp].x += __shfl_xor(acc[pp].x, o, 64); acc[pp].y += __shfl_xor(acc[pp].y, o, 64);
+        acc[pp].z += __shfl_xor(acc[pp].z, o, 64); acc[pp].w += __shfl_xor(acc[pp].w, o, 64);
+      }
+      if (grp == 0) *reinterpret_cast<float4 *>(a.S + ((int64_t)cell * a.kch + chunk) * W + pp * C + 4 * li) = acc[pp];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch 3: neighbour sum + de-modulate + LayerNorm
+// ---------------------------------------------------------------------------------------------
+template <int C, int OP, int R>
+__global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a) {
+  constexpr int P = op_parts<OP>::value, W = P * C, LPR = C / 4, G = 64 / LPR, R3 = R * R * R;
+  constexpr int LO = -((R + 1) / 2) + 1;               // nn/utils/kernel.py:21
+  constexpr int MAXROWS = R3 * ((LEAN_KMAX + LEAN_CH - 1) / LEAN_CH);
+  constexpr int NT = (R3 + G - 1) / G;                 // neighbours per lane group
+  constexpr int UBMAX = P == 3 ? 4 : 6;                // first-chunk rows in flight per lane group (9 / 14: -1 us on the 10k-30k-voxel
+                                                       // detection stages, +2-5 us on every frame above 50k voxels: registers)
+  constexpr int UB = NT < UBMAX ? NT : UBMAX;
+  __shared__ int rows_lds[LEAN_IW][MAXROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & (LPR - 1), grp = lane / LPR;
+  if (a.build && blockIdx.x == 0 && tid == 0) {          // publish the status bits the insert collected
+    a.hdr[LINK_HDR_STATUS] = a.hdr[LINK_HDR_STATUS_ACC];
+    a.hdr[LINK_HDR_STATUS_ACC] = 0;
+    a.hdr[LINK_HDR_NVALID] = a.n;
+  }
+  const int j0 = blockIdx.x * LEAN_IW + wave;
+  const int sg = j0 & (LEAN_SEGS - 1);
+  const int nitem = (int)a.ctrl[sg * 16];
+  int idx = j0 >> 4;
+  int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;
+  const int step = (int)(gridDim.x * LEAN_IW) >> 4;
+  const int ch0 = 4 * li;
+  float w0[4], w1[4], w2[4], al[4];
+#pragma unroll
+  for (int e_ = 0; e_ < 4; e_++) {
+    const int tc = (ch0 + e_) % a.cg;
+    w0[e_] = a.w_pos[3 * tc + 0]; w1[e_] = a.w_pos[3 * tc + 1]; w2[e_] = a.w_pos[3 * tc + 2];
+    al[e_] = a.alpha ? a.alpha[tc] : 1.0f;
+  }
+  const float4 gw = *reinterpret_cast<const float4 *>(&a.ln_w[ch0]), gb = *reinterpret_cast<const float4 *>(&a.ln_b[ch0]);
+  int *rows = rows_lds[wave];
+  const int d0 = a.g.dim[0], d1 = a.g.dim[1], d2 = a.g.dim[2], d3 = a.g.dim[3];
+  for (; idx < nitem; idx += step) {
+    const int it = it_n;
+    if (idx + step < nitem) it_n = a.occ[(int64_t)sg * a.seg_cap + idx + step];
+    const int64_t slot = (int64_t)sg * a.seg_cap + idx;
+    const int cell = it >> 4, chunk = it & 15;
+    const int lo = chunk * LEAN_CH;
+    // everything the item needs is addressed from (cell, slot): the chunk's records, the counts of the r^3 neighbour cells
+    // and -- without waiting for those counts -- the first chunk row of each of them
+    const int4 myrec = a.rec2[slot * LEAN_CH + (lane & (LEAN_CH - 1))];
+    const int cn_own = (int)a.cnt[cell];
+    const int ub = cell % d3, t1 = cell / d3;
+    const int uz = t1 % d2, t2 = t1 / d2;
+    const int uy = t2 % d1, ux = t2 / d1;
+    auto nb_cell = [&](int t) -> int {
+      const int ox = LO + t % R, oy = LO + (t / R) % R, oz = LO + t / (R * R);
+      const unsigned vx = (unsigned)(ux + ox), vy = (unsigned)(uy + oy), vz = (unsigned)(uz + oz);
+      return (t < R3 && vx < (unsigned)d0 && vy < (unsigned)d1 && vz < (unsigned)d2) ? (((int)vx * d1 + (int)vy) * d2 + (int)vz) * d3 + ub : -1;
+    };
+    const int nbc = nb_cell(lane);
+    int cn = nbc >= 0 ? (int)a.cnt[nbc] : 0;
+    float4 acc[P];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cn = cn < a.k ? cn : a.k;
+#pragma unroll 1
+    for (int b0 = 0; b0 < NT; b0 += UB) {
+      float4 v[UB][P];
+      int tt[UB];
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        tt[u] = (b0 + u) * G + grp;
+        const int c_ = (b0 + u < NT) ? nb_cell(tt[u]) : -1;
+        const float *row = a.S + (int64_t)(c_ >= 0 ? c_ : cell) * a.kch * W + ch0;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) v[u][pp] = *reinterpret_cast<const float4 *>(row + pp * C);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        const int cn_t = __shfl(cn, tt[u] < R3 ? tt[u] : 0, 64);
+        const bool ok = (b0 + u < NT) && tt[u] < R3 && cn_t > 0;
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          acc[pp].x += ok ? v[u][pp].x : 0.f; acc[pp].y += ok ? v[u][pp].y : 0.f;
+          acc[pp].z += ok ? v[u][pp].z : 0.f; acc[pp].w += ok ? v[u][pp].w : 0.f;
+        }
+      }
+    }
+    // neighbours of more than 32 voxels: their further chunk rows, in (neighbour, chunk) order
+    const int nrow = (cn + LEAN_CH - 1) / LEAN_CH;
+    const int nx = nrow > 1 ? nrow - 1 : 0;
+    int pre = nx, den_i = cn;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int u = __shfl_up(pre, o, 64);
+      if (lane >= o) pre += u;
+      den_i += __shfl_xor(den_i, o, 64);
+    }
+    const int NR = __shfl(pre, 31, 64);
+    const float den = (float)__shfl(den_i, 0, 64);
+    if (NR > 0) {                                        // wave-uniform
+      for (int c = 0; c < nx; c++) rows[pre - nx + c] = nbc * a.kch + 1 + c;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int U = 4;
+      for (int m0 = 0; m0 < NR; m0 += U * G) {
+        float4 v[U][P];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int m = m0 + u * G + grp;
+          const float *row = a.S + (int64_t)rows[m < NR ? m : 0] * W + ch0;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) v[u][pp] = *reinterpret_cast<const float4 *>(row + pp * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const bool ok = m0 + u * G + grp < NR;
+#pragma unroll
+          for (int pp = 0; pp < P; pp++) {
+            acc[pp].x += ok ? v[u][pp].x : 0.f; acc[pp].y += ok ? v[u][pp].y : 0.f;
+            acc[pp].z += ok ? v[u][pp].z : 0.f; acc[pp].w += ok ? v[u][pp].w : 0.f;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int nc = cn_own < a.k ? cn_own : a.k;
+    const int nch = nc - lo < LEAN_CH ? nc - lo : LEAN_CH;
+    float A[P][4];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        acc[pp].x += __shfl_xor(acc[pp].x, o, 64); acc[pp].y += __shfl_xor(acc[pp].y, o, 64);
+        acc[pp].z += __shfl_xor(acc[pp].z, o, 64); acc[pp].w += __shfl_xor(acc[pp].w, o, 64);
+      }
+      A[pp][0] = acc[pp].x / den; A[pp][1] = acc[pp].y / den; A[pp][2] = acc[pp].z / den; A[pp][3] = acc[pp].w / den;   // utils.py:80
+    }
+    // ---- the chunk's voxels, G at a time: the record of voxel m sits in lane m ----
+    const int steps = (nch + G - 1) / G;
+    float4 xl_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (OP == LINK_OP_COSX) {
+      const int id0 = __shfl(myrec.w, grp < nch ? grp : 0, 64);
+      xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)id0 * W + 2 * C + ch0);
+    }
+    for (int mi = 0; mi < steps; mi++) {
+      const int m = mi * G + grp;
+      const bool ok = m < nch;
+      const int src = ok ? m : 0;
+      const int rx = __shfl(myrec.x, src, 64), ry = __shfl(myrec.y, src, 64), rz = __shfl(myrec.z, src, 64);
+      const int id = __shfl(myrec.w, src, 64);
+      const float4 xl = xl_n;
+      if (OP == LINK_OP_COSX && mi + 1 < steps) {
+        const int idn = __shfl(myrec.w, m + G < nch ? m + G : 0, 64);
+        xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)idn * W + 2 * C + ch0);
+      }
+      float x = (float)rx, y = (float)ry, z = (float)rz;
+      if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
+      float th[4], sn[4], cs[4];
+      bool big = false;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        th[q] = theta_of(x, y, z, w0[q], w1[q], w2[q], al[q]);
+        big |= !(fabsf(th[q]) < 32768.0f);
+      }
+      if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sincos_nocall(th[q], sn[q], cs[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sincos_small(th[q], sn[q], cs[q]);
+      }
+      const float xlv[4] = {xl.x, xl.y, xl.z, xl.w};
+      float nvv[4], s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float va;
+        if (OP == LINK_OP_SIN) va = __fsub_rn(__fmul_rn(A[0][q], cs[q]), __fmul_rn(A[1][q], sn[q]));
+        else va = __fadd_rn(__fmul_rn(A[0][q], cs[q]), __fmul_rn(A[1][q], sn[q]));
+        if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A[P - 1][q], xlv[q]));     // linkunet.py:176; X's third part is fin * theta
+        nvv[q] = va;
+        s += va;
+      }
+      s = grp_sum<LPR>(s);
+      const float mean = s * (1.0f / C);
+      float qq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float d = nvv[q] - mean;
+        qq += d * d;
+      }
+      qq = grp_sum<LPR>(qq);
+      const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + a.eps);
+      if (ok) {
+        const float4 o = make_float4((nvv[0] - mean) * rstd * gw.x + gb.x, (nvv[1] - mean) * rstd * gw.y + gb.y,
+                                     (nvv[2] - mean) * rstd * gw.z + gb.z, (nvv[3] - mean) * rstd * gw.w + gb.w);
+        io_st4_ptr(a.out, (int64_t)id * C + ch0, o);
+      }
+    }
+  }
+}
+
+}  // namespace DC_IO_NS

@@ -55,6 +55,7 @@ def _st():
 # ------------------------------------------------------------------------------------------------
 # fused R_core (inference)
 # ------------------------------------------------------------------------------------------------
+LEAN_FORM = True      # inference R_core of coordinate sets without a block index: the three-launch lean form (tests flip it)
 TILE_FORM = True      # inference R_core on the general layout: the two-launch tile form where its widths / r apply (tests flip it)
 
 
@@ -183,8 +184,12 @@ class ElkCorePlan:
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
         self.device = device
-        if layout not in ("auto", "dense", "general", "sparse"):
-            raise ValueError(f"layout must be auto|dense|general|sparse, got {layout!r}")
+        if layout not in ("auto", "dense", "general", "sparse", "lean"):
+            raise ValueError(f"layout must be auto|dense|general|sparse|lean, got {layout!r}")
+        self.lean = False
+        if layout == "lean":
+            self._init_lean(int(slot_cap))
+            return
         try:
             dcg = L.dc_grid_from(self.grid, int(slot_cap) if slot_cap else 0) if layout != "general" else None
         except L.LinkAmdError:
@@ -207,6 +212,11 @@ class ElkCorePlan:
         if self.sparse:
             self.dense = True                            # same buffers and one-call structure; run() picks the entry point
         self.dcg = dcg if self.dense else None
+        if layout == "auto" and not self.dense and slot_cap and self.lean_auto(n_cap, c, baseop, r, self.s, bounds, int(slot_cap)):
+            # LiDAR-shaped frame of moderate size whose blocks hold at most `slot_cap` voxels: three launches with the index
+            # rebuilt instead of six (profiles/r04_v3_lidar_stages.jsonl)
+            self._init_lean(int(slot_cap))
+            return
         self.out = torch.empty((n_cap, c), dtype=torch.float32, device=device)
         self.fin = torch.empty((n_cap, c), dtype=torch.float32, device=device)
         self.hdr = torch.zeros(L.HDR_WORDS, dtype=torch.int32, device=device)
@@ -271,6 +281,78 @@ class ElkCorePlan:
         self._fn = L.lib().link_elk_core_dense_forward
         self.m_cap = vp
         self.set_tuning(**self._tuning)
+
+    LEAN_MAX_BYTES = 3 << 30
+
+    @classmethod
+    def lean_supported(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, slot_cap: int = 0) -> bool:
+        """Whether ElkCorePlan(layout='lean') takes this block: widths / r of the fused kernels, blocks of at most 352 voxels,
+        fewer than 2^27 grid cells, and tables (addressed by cell, touched only where voxels land) within LEAN_MAX_BYTES."""
+        try:
+            grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
+        except L.LinkAmdError:
+            return False
+        k = int(slot_cap) if slot_cap else int(s) ** 3
+        w = (3 if baseop == "cos_x" else 2) * c
+        v = grid.cells
+        kch = (min(k, L.LEAN_KMAX) + L.LEAN_CHUNK - 1) // L.LEAN_CHUNK
+        return (c in (16, 32, 64, 128) and r in (2, 3) and k <= L.LEAN_KMAX and v < 2 ** 27 and n_cap * c * 4 < 2 ** 32
+                and v * kch * w * 4 + v * k * 4 + n_cap * (w * 4 + 512) <= cls.LEAN_MAX_BYTES)
+
+    LEAN_AUTO_FLOATS = 6_500_000
+
+    @classmethod
+    def lean_auto(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, slot_cap: int) -> bool:
+        """Where the lean form is the faster one with the index rebuilt (A/B over the eight LiDAR stage frames, round 4): frames
+        whose scratch matrix X (n x P*C floats, written by launch 1 and read by launch 2) stays below ~26 MB -- up to ~30k
+        voxels at C = 64 cos_x, ~100k at C = 32; above that the tile form's single pass over the rows wins."""
+        w = (3 if baseop == "cos_x" else 2) * c
+        return n_cap * w <= cls.LEAN_AUTO_FLOATS and cls.lean_supported(n_cap, c, baseop, r, s, bounds, slot_cap)
+
+    def _init_lean(self, slot_cap: int):
+        """Lean form (link_elk_core_lean_forward, csrc/elk_lean_impl.h): three launches with the index rebuilt, tables addressed
+        by grid cell.  `slot_cap` = the most voxels a block can hold (0: s^3, what unique coordinates at tensor stride 1 allow;
+        a caller at tensor stride t passes (s / t)^3)."""
+        dev, n_cap, c = self.device, self.n_cap, self.c
+        k = int(slot_cap) if slot_cap else self.s ** 3
+        w = self.parts * c
+        v = self.grid.cells
+        if not (c in (16, 32, 64, 128) and self.r in (2, 3) and 1 <= k <= L.LEAN_KMAX and v < 2 ** 27 and n_cap * c * 4 < 2 ** 32):
+            raise L.LinkAmdError("ElkCorePlan(layout='lean'): needs C in {16,32,64,128}, r in {2,3}, slot capacity <= 352 and "
+                                 "fewer than 2^27 grid cells (include/link_amd.h, link_elk_core_lean_forward)")
+        kch = (k + L.LEAN_CHUNK - 1) // L.LEAN_CHUNK
+        if v * kch * w * 4 + v * k * 4 + n_cap * (w * 4 + 512) > self.LEAN_MAX_BYTES:
+            raise L.LinkAmdError("ElkCorePlan(layout='lean'): tables beyond ElkCorePlan.LEAN_MAX_BYTES")
+        self.lean, self.dense, self.sparse, self.dcg, self.k = True, False, False, None, k
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.out = torch.empty((n_cap, c), dtype=torch.float32, device=dev)
+        self.hdr = torch.zeros(L.HDR_WORDS, dtype=torch.int32, device=dev)
+        self.cnt2 = [torch.zeros(max(v, 1), **i32), torch.zeros(max(v, 1), **i32)]      # self-cleaning, alternating
+        self.list = torch.empty(v * k, **i32)
+        self.seg_cap = (n_cap // 64 + 16) // L.LEAN_SEGS * 64 + 64
+        self.rec2 = torch.empty((L.LEAN_SEGS * self.seg_cap * L.LEAN_CHUNK, 4), **i32)
+        self.occ2 = [torch.empty(L.LEAN_SEGS * self.seg_cap, **i32), torch.empty(L.LEAN_SEGS * self.seg_cap, **i32)]
+        self.ctrl2 = [torch.zeros(256, **i32), torch.zeros(256, **i32)]
+        self.X = torch.empty((n_cap, w), dtype=torch.float32, device=dev)
+        self.S = torch.empty((v * kch, w), dtype=torch.float32, device=dev)            # touched only where voxels land
+        self._cur, self._n_prev = 0, 0
+        b = self.buf = L.LinkLeanBuffers()
+        b.list, b.rec2, b.X, b.S = self.list.data_ptr(), self.rec2.data_ptr(), self.X.data_ptr(), self.S.data_ptr()
+        b.hdr, b.out, b.seg_cap, b.k = self.hdr.data_ptr(), self.out.data_ptr(), self.seg_cap, k
+        self.m_cap = n_cap
+
+    def _run_lean(self, n: int, build_index: bool, st) -> int:
+        if build_index:
+            self._cur ^= 1
+        cur, b = self._cur, self.buf
+        b.cnt, b.cnt_prev = self.cnt2[cur].data_ptr(), self.cnt2[cur ^ 1].data_ptr()
+        b.occ, b.occ_prev = self.occ2[cur].data_ptr(), self.occ2[cur ^ 1].data_ptr()
+        b.ctrl, b.ctrl_prev = self.ctrl2[cur].data_ptr(), self.ctrl2[cur ^ 1].data_ptr()
+        rc = L.lib().link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
+                                                int(self._n_prev) if build_index else 0, int(bool(build_index)), st)
+        if build_index:
+            self._n_prev = n
+        return rc
 
     def set_tuning(self, **kw):
         """Launch geometry / kernel selection of THIS plan (link_dc_tuning_t; nothing is process-global).  Defaults follow
@@ -373,7 +455,7 @@ class ElkCorePlan:
         own = self.out
         if feats.dtype != torch.float32:
             # fp16 / bf16 rows at the kernel boundary (AMP): the fused dense-cell kernels, or the tile form of the general layout
-            if not ((self.dense and self.c <= 64 and int(self.dcg.k) <= 352) or (not self.dense and getattr(self, "tiles", False))):
+            if not (self.lean or (self.dense and self.c <= 64 and int(self.dcg.k) <= 352) or (not self.dense and getattr(self, "tiles", False))):
                 raise L.LinkAmdError("ElkCorePlan: fp16/bf16 feature rows need the fused dense-cell kernels (dense layout, "
                                      "C <= 64, s^3 <= 352) or the tile form of the general layout (tiles=True)")
             own = self.__dict__.setdefault("_out_half", {}).get(feats.dtype)
@@ -384,7 +466,9 @@ class ElkCorePlan:
             assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
         self.buf.out = (out if out is not None else own).data_ptr()
         st = L.current_stream_handle()
-        if self.dense and self.sparse:
+        if self.lean:
+            rc = self._run_lean(n, build_index, st)
+        elif self.dense and self.sparse:
             if build_index:
                 self._occ_cur ^= 1
             cur, prev = self.occ[self._occ_cur], self.occ[self._occ_cur ^ 1]
@@ -424,7 +508,8 @@ class ElkCorePlan:
 
     def arena_bytes(self) -> int:
         """Device bytes this plan holds (its preallocated buffers)."""
-        return sum(t.numel() * t.element_size() for t in self.__dict__.values() if isinstance(t, torch.Tensor))
+        ts = [t for v in self.__dict__.values() for t in (v if isinstance(v, (list, tuple)) else (v,)) if isinstance(t, torch.Tensor)]
+        return sum(t.numel() * t.element_size() for t in ts)
 
     def check(self) -> None:
         """Read the device status word of the last step (one 32-byte D2H sync) and raise if a voxel was
@@ -440,6 +525,8 @@ class ElkCorePlan:
         the dense-cell layout, found its cell's slot list full: duplicate coordinates)."""
         self.check()
         h = self.hdr.tolist()
+        if self.lean:
+            return int((self.cnt2[self._cur] > 0).sum().item())
         if self.dense:
             return int((self.cell_n > 0).sum().item())
         return int(h[L.HDR_M])
@@ -1769,6 +1856,59 @@ class _ELKBase(nn.Module):
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
         return out
 
+    def _core_lean(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
+        """Inference R_core through the lean form (ElkCorePlan(layout='lean'): three launches, nothing cached between calls
+        but the arena) for coordinate sets that have no block index yet -- the first visit of a LiDAR stage frame, i.e. every
+        call in a stream of frames.  None when the form does not apply (then the general layout builds its index)."""
+        feats, coords = st.F, st.C
+        n, c = feats.shape
+        if n == 0 or c not in (16, 32, 64, 128) or r not in (2, 3) or not feats.is_cuda or not LEAN_FORM:
+            return None
+        if st.kmaps.get(("link_block_index", coords.data_ptr(), n, int(s_eff))) is not None:
+            return None                                       # an index of these coordinates exists: the two tile launches
+        ts = st.s[0] if isinstance(st.s, (tuple, list)) else st.s
+        ts = max(int(ts), 1)
+        # coordinates of a tensor at stride ts are multiples of ts (torchsparse/nn/functional/downsample.py:27-40), so a block
+        # of edge s_eff holds at most (s_eff / ts)^3 of them; a frame that breaks the promise raises the plan's status word
+        k = (max(int(s_eff) // ts, 1)) ** 3 if int(s_eff) % ts == 0 else int(s_eff) ** 3
+        n_cap = 1 << max(10, (n - 1).bit_length())
+        if k > L.LEAN_KMAX or n_cap * (3 if self.baseop == "cos_x" else 2) * c > ElkCorePlan.LEAN_AUTO_FLOATS:
+            return None
+        bkey = ("link_bounds", coords.data_ptr(), n)
+        bounds = st.cmaps.get(bkey)
+        if bounds is None:
+            from .index import coords_bounds
+            bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
+        q = int(s_eff)
+        qbounds = (tuple((int(v) // q) * q for v in bounds[0][:3]) + (int(bounds[0][3]),),
+                   tuple((int(v) // q) * q + q - 1 for v in bounds[1][:3]) + (int(bounds[1][3]),))
+        cache = self.__dict__.setdefault("_lean_plans", {})
+        key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, qbounds, float(coord_div), k)
+        plan = cache.get(key, False)
+        if plan is False:
+            plan = None
+            if ElkCorePlan.lean_supported(n_cap, c, self.baseop, r, s_eff, qbounds, k):
+                try:
+                    plan = ElkCorePlan(n_cap, c, self.baseop, cg, r, s_eff, qbounds, feats.device, coord_div=coord_div,
+                                       layout="lean", slot_cap=k)
+                except L.LinkAmdError:
+                    plan = None
+            budget = DENSE_PLAN_CACHE_BYTES - (plan.arena_bytes() if plan is not None else 0)
+            while cache and (len(cache) >= 8 or sum(p.arena_bytes() for p in cache.values() if p is not None) > max(budget, 0)):
+                cache.pop(next(iter(cache)))
+            cache[key] = plan
+        if plan is None:
+            return None
+        plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
+                  self.norm.weight, self.norm.bias)
+        ikey = (coords.data_ptr(), n, coords._version)
+        alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
+        out = alloc((n, c), dtype=feats.dtype, device=feats.device)
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
+        plan._indexed = ikey
+        plan._keepalive = coords
+        return out
+
     def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         """R_core as the reference writes it (linkunet.py:124-176), op by op on voxel_to_aux / aux_to_voxel:
         any grid extent, any width; differentiable through the ops' autograd Functions."""
@@ -1807,6 +1947,8 @@ class _ELKBase(nn.Module):
             p.requires_grad for p in self.parameters()))
         if not needs_grad0 and st.F.dtype in _IO_DTYPES and st.C.dtype == torch.int32:
             out = self._core_dense(st, s_eff, r, w_pos, alpha, cg, coord_div)
+            if out is None:
+                out = self._core_lean(st, s_eff, r, w_pos, alpha, cg, coord_div)
             if out is not None:
                 return out
         try:

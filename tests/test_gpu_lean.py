@@ -1,0 +1,133 @@
+"""Lean form of R_core with the index rebuilt every call (include/link_amd.h: link_elk_core_lean_forward;
+link_amd/csrc/elk_lean_impl.h) -- three launches, tables addressed by grid cell -- against the CPU oracle and the general layout
+on the frames it is made for: LiDAR-shaped block grids (reference call sites linkunet.py:345-363, scn.py:586-607), every width of
+the detection backbone, blocks of a few to a few hundred voxels."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import lidar_like, rel_err, s_uniform
+from oracle import link_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _bind(p, blk, baseop):
+    return p.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
+                  blk.alpha if baseop == "cos_x" else None, blk.norm.weight, blk.norm.bias)
+
+
+def _plans(la, blk, n, C, baseop, groups, r, s, coords, slot_cap, coord_div=1.0):
+    from link_amd.index import coords_bounds
+    bounds = coords_bounds(coords)
+    lean = _bind(la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, coords.device, coord_div=coord_div, layout="lean",
+                                slot_cap=slot_cap), blk, baseop)
+    gen = _bind(la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, coords.device, coord_div=coord_div, layout="general"), blk, baseop)
+    assert lean.lean and not lean.dense and not gen.dense
+    return lean, gen
+
+
+def _block(la, C, groups, baseop, seed):
+    torch.manual_seed(seed)
+    blk = la.ELKBlock(C, C, groups=groups, baseop=baseop, variant="encoder").cuda().eval()
+    with torch.no_grad():
+        for nme, p in blk.named_parameters():
+            if "norm" in nme or "pre_mix.1" in nme or nme == "alpha":
+                p.add_(0.2 * torch.randn_like(p))
+    return blk, {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+
+
+@pytest.mark.parametrize("C,groups,baseop,stride,s,r", [(64, 1, "cos_x", 2, 6, 2), (64, 2, "cos", 2, 6, 3), (32, 2, "sin", 2, 6, 2),
+                                                        (16, 2, "cos", 2, 8, 3), (64, 1, "cos_x", 4, 12, 2), (32, 1, "cos_x", 2, 4, 3),
+                                                        (128, 2, "cos", 2, 6, 3), (128, 1, "cos_x", 2, 6, 2)])
+def test_lean_form_on_lidar_like_frames(C, groups, baseop, stride, s, r):
+    """LiDAR-like frames at tensor stride `stride`, block edge s in coordinate units (slot capacity (s / stride)^3): oracle,
+    general layout (block count too), warm == rebuilt == rebuilt again BITWISE (sums run in id order whatever order the
+    atomics handed out), and frames of different sizes alternating through one plan (the counters of the frame before must be
+    gone, also when it was the bigger one)."""
+    import link_amd as la
+    blk, params = _block(la, C, groups, baseop, C + r)
+    cap = (s // stride) ** 3
+    frames = []
+    for seed, npts in ((3, 30000), (4, 9000)):
+        coords = torch.from_numpy(lidar_like(npts, seed=seed, stride=stride, voxel=0.2 if C == 16 else 0.05))
+        feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(seed))
+        frames.append((coords, feats))
+    n_cap = max(c.shape[0] for c, _ in frames)
+    allc = torch.cat([c for c, _ in frames])
+    le, ge = _plans(la, blk, n_cap, C, baseop, groups, r, s, allc.cuda(), cap, coord_div=float(stride) if baseop == "cos_x" else 1.0)
+    for coords, feats in frames + frames[:1]:
+        n = coords.shape[0]
+        ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                               agg=O.aggregate_c).numpy()
+        f, c = feats.cuda(), coords.cuda()
+        got = le.run(f, c).clone()
+        gen = ge.run(f, c).clone()
+        assert le.blocks() == ge.blocks() > 0
+        assert rel_err(got.cpu().numpy(), ref) < TOL
+        assert rel_err(got.cpu().numpy(), gen.cpu().numpy()) < 2 * TOL
+        assert torch.equal(le.run(f, c, build_index=False), got)
+        for _ in range(3):
+            assert torch.equal(le.run(f, c), got)
+        le.check()
+        assert int(le.cnt2[le._cur ^ 1].abs().sum().item()) == 0          # the other parity's counters are clean
+
+
+@pytest.mark.parametrize("C,r", [(16, 3), (64, 3), (128, 3), (32, 2)])
+def test_lean_form_big_blocks(C, r):
+    """Blocks of up to 343 voxels (s = 7 at tensor stride 1: the detection blocks, ts_elk.py:87,168): cells span several
+    chunks of 32, chunk rows of the 27 neighbours are summed in a fixed order."""
+    import link_amd as la
+    groups, baseop, s = 2, "cos", 7
+    blk, params = _block(la, C, groups, baseop, 7 * C + r)
+    n = 24000
+    coords = s_uniform(n, grid=40, seed=5)              # 64000 sites, 37.5 % occupied: ~130 voxels per 7^3 block
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(6))
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", agg=O.aggregate_c).numpy()
+    le, ge = _plans(la, blk, n, C, baseop, groups, r, s, coords.cuda(), 0)
+    got = le.run(feats.cuda(), coords.cuda()).clone()
+    ge.run(feats.cuda(), coords.cuda())
+    assert le.blocks() == ge.blocks() > 0
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+    assert torch.equal(le.run(feats.cuda(), coords.cuda()), got)
+    le.check()
+
+
+def test_lean_form_half_rows_status_and_limits():
+    """fp16 / bf16 rows at the kernel boundary; a voxel outside the plan's bounds is dropped and reported; an empty frame;
+    geometry the form does not take is refused."""
+    import link_amd as la
+    C, groups, baseop, s, r = 64, 2, "cos", 3, 3
+    blk, params = _block(la, C, groups, baseop, 11)
+    n = 20000
+    coords = s_uniform(n, grid=60, seed=9)
+    feats = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    le, ge = _plans(la, blk, n, C, baseop, groups, r, s, coords.cuda(), 27)
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", agg=O.aggregate_c).numpy()
+    got = le.run(feats.cuda(), coords.cuda()).clone()
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        h = feats.to(dt)
+        ref_h = O.elk_core_torch(h.float(), coords, params, s, r, baseop, groups, variant="encoder", agg=O.aggregate_c).numpy()
+        got_h = le.run(h.cuda(), coords.cuda())
+        assert got_h.dtype == dt
+        assert rel_err(got_h.float().cpu().numpy(), ref_h) < tol
+    # empty frame, then the full one again
+    le.run(feats[:0].cuda(), coords[:0].cuda())
+    assert torch.equal(le.run(feats.cuda(), coords.cuda()), got)
+    # a voxel outside the bounds: status bit 0, every other row as before
+    bad = coords.clone()
+    bad[17, 0] = 10_000
+    out_bad = le.run(feats.cuda(), bad.cuda()).clone()
+    with pytest.raises(la._lib.LinkAmdError):
+        le.check()
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[17] = False
+    ref_bad = O.elk_core_torch(feats[keep], coords[keep], params, s, r, baseop, groups, variant="encoder", agg=O.aggregate_c).numpy()
+    assert rel_err(out_bad.cpu().numpy()[keep.numpy()], ref_bad) < TOL
+    assert torch.equal(le.run(feats.cuda(), coords.cuda()), got)
+    le.check()
+    with pytest.raises(la._lib.LinkAmdError):            # blocks of 8^3 voxels: beyond the slot capacity the form takes
+        la.ElkCorePlan(1000, C, baseop, C // groups, r, 8, ((0, 0, 0, 0), (59, 59, 59, 0)), torch.device("cuda"), layout="lean")
+    assert not la.ElkCorePlan.lean_supported(1000, 48, baseop, r, 3, ((0, 0, 0, 0), (59, 59, 59, 0)))

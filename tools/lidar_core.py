@@ -2,7 +2,8 @@
 modules: captures the (coords, C, op, s_eff, r, cg, coord_div) every LinK block of the two networks is called with,
 then times ElkCorePlan steps on each (one FFI call per step, preallocated arena) with HIP events over back-to-back
 steps, cold (index rebuilt) and warm, next to the module path's host-inclusive time.  STAGE=<k> restricts the run to
-one stage (for a rocprofv3 pass: kernel names are shared by the stages); LAYOUT=general|sparse picks the plan layout.
+one stage (for a rocprofv3 pass: kernel names are shared by the stages); LAYOUT=general|sparse picks the plan layout;
+FORM=four|tiles|sparse|lean restricts the run to one form (lean: link_elk_core_lean_forward, three launches rebuilt).
 
     python tools/lidar_core.py                  # table over the 8 stages
     STAGE=4 ITERS=200 python tools/lidar_core.py
@@ -92,13 +93,14 @@ def main():
             ref = b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]).float()
             row["module_warm_us"] = round(ev_time(lambda: b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]), iters), 1)
             cap = max(1, r["s_eff"] // max(r["stride"], 1)) ** 3      # voxel sites of a block at this tensor stride
-            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), ("sparse", dict(layout="sparse", slot_cap=cap, **({"k1_wgs": int(os.environ["IPW"])} if os.environ.get("IPW") else {})))):
+            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), ("sparse", dict(layout="sparse", slot_cap=cap, **({"k1_wgs": int(os.environ["IPW"])} if os.environ.get("IPW") else {}))),
+                             ("lean", dict(layout="lean", slot_cap=min(cap, 343)))):
                 if os.environ.get("FORM", name) != name:
                     continue
                 if name == "sparse" and (cap > 64 or c not in (16, 32, 64)):
                     continue                                 # big blocks stay on the general layout's tile form
                 kw = dict(kw)
-                if os.environ.get("ORDER") and name != "sparse":
+                if os.environ.get("ORDER") and name not in ("sparse", "lean"):
                     kw["block_order"] = os.environ["ORDER"]
                 try:
                     plan = ElkCorePlan(n, c, b.baseop, r["cg"], r["r"], r["s_eff"], bounds, dev, coord_div=r["coord_div"],
