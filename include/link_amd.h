@@ -265,6 +265,8 @@ typedef struct {
 #define LINK_ELK_NO_PAIR 2         /* no voxel-pair sharing of sincos between channels j and j + C/2 */
 #define LINK_ELK_FUSED_GATHER 4    /* one fused gather + de-modulate kernel instead of block gather + per-voxel kernel */
 #define LINK_ELK_NO_DENSE_GRID 8   /* block gather: column-walking form even on mostly occupied grids */
+#define LINK_ELK_LEAN_CS 32        /* link_elk_core_lean_forward: channel-split form of launch 1 whenever C is 64 / 128 */
+#define LINK_ELK_LEAN_NO_CS 64     /* ... never (default: by frame size) */
 #define LINK_ELK_TILES 16          /* link_elk_core_forward: the tile form (two launches: link_elk_premix_modsum_tiles +
                                       link_elk_gather_demod_tiles); needs link_elk_buffers_t::s_bytes */
 
@@ -402,7 +404,7 @@ typedef struct {
   const void *feats;          /* [N,C] io_dtype rows */
   const int32_t *coords;      /* i32[N,4] */
   const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *alpha, *ln_w, *ln_b;   /* as link_elk_buffers_t */
-  uint32_t *cnt, *cnt_prev;   /* u32[V] each, zero-filled once; self-cleaning from then on */
+  uint32_t *cnt, *cnt_prev;   /* u32[V << cnt_shift] each, zero-filled once; self-cleaning from then on */
   int32_t *list;              /* i32[V*k]: voxel ids of a cell in arrival order */
   int32_t *rec2;              /* i32[16*seg_cap*32][4]: records (x, y, z, id) of an item's voxels in ascending id */
   int32_t *occ, *occ_prev;    /* i32[16 * seg_cap] each: work items, list l at l * seg_cap */
@@ -414,6 +416,10 @@ typedef struct {
   int64_t seg_cap;            /* items a list holds: >= ceil(ceil(n_cap / 64) / 16) * 64 + 64 */
   int32_t k;                  /* slot capacity of a cell (s^3 clipped to 352) */
   int32_t io_dtype;           /* LINK_IO_* */
+  int32_t cnt_shift;          /* the counter of cell c is word c << cnt_shift (0 .. 5): on a small grid every counter gets its own
+                                 line, because the atomics of a few hundred cells with hundreds of voxels each would otherwise
+                                 serialise on a handful of lines */
+  int32_t reserved;
 } link_lean_buffers_t;
 int link_elk_core_lean_forward(const link_lean_buffers_t *buf /* host */, const link_grid_t *grid /* host */,
                                const link_elk_desc_t *desc /* host */, int64_t n, int64_t n_prev, int32_t build_index,

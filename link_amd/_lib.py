@@ -17,6 +17,7 @@ LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
+ELK_LEAN_CS, ELK_LEAN_NO_CS = 32, 64
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
 ABI_VERSION = 9
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
@@ -85,7 +86,7 @@ class LinkLeanBuffers(Structure):
     """link_lean_buffers_t (lean form of R_core: three launches with the index rebuilt)"""
     _fields_ = [(k, c_void_p) for k in ("feats", "coords", "w_pre", "pre_ln_w", "pre_ln_b", "w_pos", "alpha", "ln_w", "ln_b",
                                         "cnt", "cnt_prev", "list", "rec2", "occ", "occ_prev", "ctrl", "ctrl_prev", "X", "S",
-                                        "hdr", "out")] + [("seg_cap", c_int64), ("k", c_int32), ("io_dtype", c_int32)]
+                                        "hdr", "out")] + [("seg_cap", c_int64), ("k", c_int32), ("io_dtype", c_int32), ("cnt_shift", c_int32), ("reserved", c_int32)]
 
 
 LEAN_KMAX, LEAN_SEGS, LEAN_CHUNK = 352, 16, 32

@@ -20,7 +20,8 @@ extern "C" int link_elk_core_lean_forward(const link_lean_buffers_t *b, const li
   if (!b || !grid || !d || n < 0 || n_prev < 0 || n >= (1LL << 31) || n_prev >= (1LL << 31)) return LINK_ERR_ARG;
   if (!dc_width_ok(d->c) || (d->r != 2 && d->r != 3) || d->cg < 1 || d->c % d->cg != 0) return LINK_ERR_ARG;
   if (d->op != LINK_OP_COS && d->op != LINK_OP_SIN && d->op != LINK_OP_COSX) return LINK_ERR_ARG;
-  if (b->io_dtype < LINK_IO_F32 || b->io_dtype > LINK_IO_BF16 || b->k < 1 || b->k > elkl_f32::LEAN_KMAX) return LINK_ERR_ARG;
+  if (b->io_dtype < LINK_IO_F32 || b->io_dtype > LINK_IO_BF16 || b->k < 1 || b->k > elkl_f32::LEAN_KMAX || b->cnt_shift < 0 || b->cnt_shift > 5)
+    return LINK_ERR_ARG;
   int64_t v = 1;
   for (int ax = 0; ax < 4; ax++) {
     if (grid->dim[ax] <= 0) return LINK_ERR_ARG;

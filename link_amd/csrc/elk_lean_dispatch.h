@@ -15,9 +15,24 @@ static void launch_lean_a(const lean_args &a, int64_t n_prev, hipStream_t st) {
   hipLaunchKernelGGL((k_lean_insert_premix<C, OP, NB>), dim3((unsigned)wgs), dim3(256), lds, st, a);
 }
 
+// which form of launch 1: the channel-split form (16 voxels per workgroup) where a frame is too small to fill the chip with
+// tile-per-wave workgroups; link_elk_desc_t::flags can force either (LINK_ELK_LEAN_CS / LINK_ELK_LEAN_NO_CS)
+static bool lean_use_cs(const link_elk_desc_t &d, int64_t n) {
+  if ((d.c != 64 && d.c != 128) || (d.flags & LINK_ELK_LEAN_NO_CS)) return false;
+  if (d.flags & LINK_ELK_LEAN_CS) return true;
+  return d.c == 64 && n <= 4096;
+}
+
 template <int C, int OP>
 static void lean_nb(const link_elk_desc_t &d, const lean_args &a, int64_t n_prev, hipStream_t st) {
   constexpr int T = C / 16;
+  if constexpr (C == 64 || C == 128) {
+    if (lean_use_cs(d, a.n)) {
+      const int64_t wgs = (int64_t)a.nwg + (a.build ? ((int64_t)LEAN_SEGS * a.idx_cap_prev + 255) / 256 : 0);
+      if (wgs >= 1) hipLaunchKernelGGL((k_lean_insert_premix_cs<C, OP>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+      return;
+    }
+  }
   int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
   if (nb > T) nb = T;
   if (T >= 2 && nb == T / 2) return launch_lean_a<C, OP, (T >= 2 ? T / 2 : 1)>(a, n_prev, st);
@@ -61,11 +76,13 @@ int run_lean(const link_lean_buffers_t &b, const link_grid_t &g, const link_elk_
   a.ln_w = b.ln_w; a.ln_b = b.ln_b;
   a.g = g; a.cg = d.cg; a.coord_div = d.coord_div; a.eps = d.eps;
   a.n = (int)n; a.k = b.k; a.kch = (b.k + LEAN_CH - 1) / LEAN_CH; a.build = build;
-  // a list receives the items of every 16th workgroup of launch 1, at most 64 each
-  a.nwg = (int)((n + 63) / 64);
-  a.idx_cap = (int)(((n + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64);
-  a.idx_cap_prev = (int)(((n_prev + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64);
-  a.seg_cap = b.seg_cap;
+  // a list receives the items of every 16th workgroup of launch 1, at most one per voxel of the workgroup (64, or 16 in the
+  // channel-split form); the previous frame's bound covers either form
+  const int vpw = lean_use_cs(d, n) ? 16 : 64;
+  a.nwg = (int)((n + vpw - 1) / vpw);
+  a.idx_cap = (int)(((int64_t)a.nwg + LEAN_SEGS - 1) / LEAN_SEGS * vpw);
+  a.idx_cap_prev = (int)(((n_prev + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64 + 16);
+  a.seg_cap = b.seg_cap; a.cshift = b.cnt_shift;
   a.cnt = b.cnt; a.cnt_prev = b.cnt_prev; a.list = b.list; a.occ = b.occ; a.occ_prev = b.occ_prev;
   a.ctrl = b.ctrl; a.ctrl_prev = b.ctrl_prev; a.rec2 = reinterpret_cast<int4 *>(b.rec2);
   a.X = b.X; a.S = b.S; a.hdr = b.hdr; a.out = b.out;

@@ -28,6 +28,14 @@
 #pragma once
 #include "tile_common.h"
 
+#ifdef LEAN_DBG           /* profiling builds only: phase ticks of launch 1 summed into hdr[16 + k] (hdr then has 64 words) */
+#define LEAN_TICK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define LEAN_WAITALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define LEAN_TICK(v)
+#define LEAN_WAITALL()
+#endif
+
 namespace DC_IO_NS {
 using namespace link;
 
@@ -43,7 +51,7 @@ struct lean_args {
   link_grid_t g;
   int cg;
   float coord_div, eps;
-  int n, k, kch, build, nwg, idx_cap, idx_cap_prev;
+  int n, k, kch, build, nwg, idx_cap, idx_cap_prev, cshift;
   int64_t seg_cap;
   uint32_t *cnt, *cnt_prev;
   int32_t *list, *occ;
@@ -58,6 +66,23 @@ struct lean_args {
 // Items are appended to list sg = (workgroup of launch 1) % 16 with one atomic per workgroup; wave j of launches 2 / 3 takes
 // entry j / 16 of list j % 16 -- the entry and the list's count are requested together (no prefix over the counts, no
 // dependent fetch), a wave whose entry lies beyond the count has nothing to do.
+
+// Lanes with `act` and the same `cell` form a group (LiDAR frames keep the voxels of a block close in memory: a tile's 16 voxels
+// fall into a handful of cells): the group makes ONE atomic on the cell's counter.  A 7^3 block holds up to 343 voxels and a
+// coarse stage has a few hundred cells, so per-voxel atomics pile up on a few counters -- 14 us of a 20 us launch on the
+// 10k-voxel C = 128 stage (same-address atomics serialise in the L2; for the same reason a counter sits on its own line when
+// the grid is small: cshift).  Returns the group's leader lane, this lane's position in the group and the group's size.
+__device__ __forceinline__ void lean_groups(bool act, int cell, int lane, int &leader, int &off, int &size) {
+  unsigned long long todo = __ballot(act);
+  leader = lane; off = 0; size = act ? 1 : 0;
+  while (todo) {                                         // wave-uniform
+    const int l0 = __builtin_ctzll(todo);
+    const int c0 = __shfl(cell, l0, 64);
+    const unsigned long long m = __ballot(act && cell == c0);
+    if (act && cell == c0) { leader = l0; off = __popcll(m & ((1ull << lane) - 1ull)); size = __popcll(m); }
+    todo &= ~m;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // launch 1: X rows of the voxels in input order + slot insert + clean-up of the previous frame
@@ -79,7 +104,7 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
     if (idx < a.idx_cap_prev) {
       const int c = (int)a.ctrl_prev[sg * 16];
       const int it = a.occ_prev[(int64_t)sg * a.seg_cap + idx];
-      if (idx < c && (it & 15) == 0) a.cnt_prev[it >> 4] = 0u;
+      if (idx < c && (it & 15) == 0) a.cnt_prev[(int64_t)(it >> 4) << a.cshift] = 0u;
     }
     return;
   }
@@ -100,12 +125,13 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
   // ---- slot insert: the lane group gq == 0 of each wave speaks for the tile's 16 voxels; the atomic is on its way while
   // the tile is worked on ----
   const bool ins = a.build && valid && gq == 0;
-  int cell = -1, rank = 0;
+  int cell = -1, base = 0, g_lead, g_off, g_size;
   if (ins) {
     cell = cell_of(a.g, floordiv(rec.x, a.g.s), floordiv(rec.y, a.g.s), floordiv(rec.z, a.g.s), rec.w);
     if (cell < 0) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 1);
-    else rank = (int)atomicAdd(&a.cnt[cell], 1u);
   }
+  lean_groups(ins && cell >= 0, cell, lane, g_lead, g_off, g_size);
+  if (ins && cell >= 0 && lane == g_lead) base = (int)atomicAdd(&a.cnt[(int64_t)cell << a.cshift], (unsigned)g_size);
   w_big = __syncthreads_or(w_big) != 0;
   const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
   floatx4 ac[T];
@@ -176,6 +202,7 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
   }
   if (!a.build) return;                                  // kernel-uniform
   // ---- the ranks are back: slot lists, and the work items (one per started chunk of 32) ----
+  const int rank = __shfl(base, g_lead, 64) + g_off;
   const bool full = cell >= 0 && rank >= a.k;
   if (full) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 2);
   const bool keep = cell >= 0 && !full;
@@ -192,6 +219,197 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
     const int before = (wave > 0 ? n0 : 0) + (wave > 1 ? n1 : 0) + (wave > 2 ? n2 : 0) + __popcll(im & ((1ull << lane) - 1ull));
     a.occ[(int64_t)sg * a.seg_cap + s_base + before] = cell * 16 + rank / LEAN_CH;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch 1, channel-split form (C = 64 / 128): a workgroup takes ONE 16-voxel tile and its four waves split the OUTPUT channels
+// of pre_mix -- wave w owns channels [w C/4, (w + 1) C/4).  Each wave fetches its own C/4 x C slice of W straight into the
+// matrix-core A layout (no LDS image of W, no staging barrier) and issues 1/4 of the tile's matrix instructions of the
+// tile-per-wave form above at a quarter of the operand traffic; the LayerNorm statistics cross the waves through 128 bytes of
+// LDS.  At C = 128 the tile-per-wave form spends ~12 of its 17 us staging a 64 KB W image per workgroup and issuing 192 matrix
+// instructions per wave; small frames have nothing to amortise that over.
+// ---------------------------------------------------------------------------------------------
+template <int C, int OP>
+__global__ void __launch_bounds__(256) k_lean_insert_premix_cs(const lean_args a) {
+  constexpr int T = C / 16, TB = T / 4, P = op_parts<OP>::value, W = P * C;
+  static_assert(C == 64 || C == 128, "channel-split form: 16-channel blocks per wave");
+  __shared__ float s_part[2][4][16];
+  __shared__ __attribute__((aligned(16))) float s_par[6 * C];      // LayerNorm weight | bias | theta w0 | w1 | w2 | alpha, per channel
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, gq = lane >> 4;
+  if ((int)blockIdx.x >= a.nwg) {                        // clean-up workgroups: as in the tile-per-wave form
+    const int q = ((int)blockIdx.x - a.nwg) * 256 + tid;
+    const int sg = q & (LEAN_SEGS - 1), idx = q >> 4;
+    if (idx < a.idx_cap_prev) {
+      const int c = (int)a.ctrl_prev[sg * 16];
+      const int it = a.occ_prev[(int64_t)sg * a.seg_cap + idx];
+      if (idx < c && (it & 15) == 0) a.cnt_prev[(int64_t)(it >> 4) << a.cshift] = 0u;
+    }
+    return;
+  }
+  LEAN_TICK(tk0);
+  const int i = blockIdx.x * 16 + li;
+  const bool valid = i < a.n;
+  const int ic = valid ? i : a.n - 1;
+  const int4 rec = a.coords[ic];
+  const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(a.feats, (uint32_t)((int64_t)a.n * C * IO_BYTES));
+  float4 ff[T];
+  {
+    const uint32_t ro = ((uint32_t)ic * (uint32_t)C + (uint32_t)(4 * gq)) * (uint32_t)IO_BYTES;
+    ff[0] = io_ldb4<0>(r_feats, ro); ff[1] = io_ldb4<16>(r_feats, ro); ff[2] = io_ldb4<32>(r_feats, ro); ff[3] = io_ldb4<48>(r_feats, ro);
+    if constexpr (T > 4) { ff[4] = io_ldb4<64>(r_feats, ro); ff[5] = io_ldb4<80>(r_feats, ro); ff[6] = io_ldb4<96>(r_feats, ro); ff[7] = io_ldb4<112>(r_feats, ro); }
+  }
+  // this wave's slice of W in the A layout: lane (li, gq) holds W[16 tq + li][16 tt + 4 gq .. + 3]
+  float4 wv[TB][T];
+#pragma unroll
+  for (int u = 0; u < TB; u++)
+#pragma unroll
+    for (int tt = 0; tt < T; tt++)
+      wv[u][tt] = *reinterpret_cast<const float4 *>(&a.w_pre[(16 * (wave * TB + u) + li) * C + 16 * tt + 4 * gq]);
+  // parameters per channel (one thread per channel)
+  if (tid < C) {
+    const int tc = tid % a.cg;
+    s_par[tid] = a.pre_ln_w[tid]; s_par[C + tid] = a.pre_ln_b[tid];
+    s_par[2 * C + tid] = a.w_pos[3 * tc + 0]; s_par[3 * C + tid] = a.w_pos[3 * tc + 1]; s_par[4 * C + tid] = a.w_pos[3 * tc + 2];
+    s_par[5 * C + tid] = a.alpha ? a.alpha[tc] : 1.0f;
+  }
+  // slot insert by wave 0 (its lane group gq == 0 speaks for the 16 voxels)
+  const bool ins = a.build && valid && gq == 0 && wave == 0;
+  int cell = -1, base = 0, g_lead = 0, g_off = 0, g_size = 0;
+  if (ins) {
+    cell = cell_of(a.g, floordiv(rec.x, a.g.s), floordiv(rec.y, a.g.s), floordiv(rec.z, a.g.s), rec.w);
+    if (cell < 0) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 1);
+  }
+  if (wave == 0) {                                       // wave-uniform
+    lean_groups(ins && cell >= 0, cell, lane, g_lead, g_off, g_size);
+    if (ins && cell >= 0 && lane == g_lead) base = (int)atomicAdd(&a.cnt[(int64_t)cell << a.cshift], (unsigned)g_size);
+  }
+  LEAN_WAITALL();
+  LEAN_TICK(tk1);
+  // ---- contraction: fp16 hi | lo split of both operands, exact products, fp32 accumulation (as dc_premix_tile) ----
+  floatx4 ac[TB];
+#pragma unroll
+  for (int u = 0; u < TB; u++) ac[u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  uint2 bh[T], bl[T];
+  float mx = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < T; tt++) {
+    dc_split4(ff[tt], bh[tt], bl[tt]);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ff[tt].x), fabsf(ff[tt].y)), fmaxf(fabsf(ff[tt].z), fabsf(ff[tt].w))));
+#pragma unroll
+    for (int u = 0; u < TB; u++)
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(wv[u][tt].x), fabsf(wv[u][tt].y)), fmaxf(fabsf(wv[u][tt].z), fabsf(wv[u][tt].w))));
+  }
+  if (__builtin_expect(!__any(!(mx < 32768.0f)), 1)) {
+#pragma unroll
+    for (int u = 0; u < TB; u++)
+#pragma unroll
+      for (int tt = 0; tt < T; tt += 2) {
+        uint2 ah0, al0, ah1, al1;
+        dc_split4(wv[u][tt], ah0, al0);
+        dc_split4(wv[u][tt + 1], ah1, al1);
+        ac[u] = dc_mfma_f16x2(al0, al1, bh[tt], bh[tt + 1], ac[u]);
+        if constexpr (IO != 1) ac[u] = dc_mfma_f16x2(ah0, ah1, bl[tt], bl[tt + 1], ac[u]);
+        ac[u] = dc_mfma_f16x2(ah0, ah1, bh[tt], bh[tt + 1], ac[u]);
+      }
+  } else {                                               // a value outside the fp16 split's range: the fp32 instruction
+#pragma unroll
+    for (int u = 0; u < TB; u++)
+#pragma unroll
+      for (int tt = 0; tt < T; tt++) {
+        ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][tt].x, ff[tt].x, ac[u], 0, 0, 0);
+        ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][tt].y, ff[tt].y, ac[u], 0, 0, 0);
+        ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][tt].z, ff[tt].z, ac[u], 0, 0, 0);
+        ac[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][tt].w, ff[tt].w, ac[u], 0, 0, 0);
+      }
+  }
+#ifdef LEAN_DBG
+  asm volatile("s_nop 0" ::"v"(ac[0][0]), "v"(ac[TB - 1][3]));
+#endif
+  LEAN_TICK(tk2);
+  // ---- LayerNorm over the voxel's C channels: in-lane, the 4 lane groups, the 4 waves ----
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < TB; u++) s += (ac[u][0] + ac[u][1]) + (ac[u][2] + ac[u][3]);
+  s = dc_sum_groups(s);
+  if (gq == 0) s_part[0][wave][li] = s;
+  __syncthreads();
+  const float mean = ((s_part[0][0][li] + s_part[0][1][li]) + (s_part[0][2][li] + s_part[0][3][li])) * (1.0f / C);
+  float qq = 0.f;
+#pragma unroll
+  for (int u = 0; u < TB; u++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float d = ac[u][r] - mean;
+      qq += d * d;
+    }
+  qq = dc_sum_groups(qq);
+  if (gq == 0) s_part[1][wave][li] = qq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((s_part[1][0][li] + s_part[1][1][li]) + (s_part[1][2][li] + s_part[1][3][li])) * (1.0f / C) + a.eps);
+#ifdef LEAN_DBG
+  asm volatile("s_nop 0" ::"v"(rstd));
+#endif
+  LEAN_TICK(tk3);
+  float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
+  if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
+  float *xrow = a.X + (int64_t)ic * W;
+#pragma unroll
+  for (int u = 0; u < TB; u++) {
+    const int cb = 16 * (wave * TB + u) + 4 * gq;        // this lane's four channels of the block
+    const float4 lw = *reinterpret_cast<const float4 *>(&s_par[cb]), lb = *reinterpret_cast<const float4 *>(&s_par[C + cb]);
+    const float4 q0 = *reinterpret_cast<const float4 *>(&s_par[2 * C + cb]), q1 = *reinterpret_cast<const float4 *>(&s_par[3 * C + cb]);
+    const float4 q2 = *reinterpret_cast<const float4 *>(&s_par[4 * C + cb]), qa = *reinterpret_cast<const float4 *>(&s_par[5 * C + cb]);
+    float th[4], sn[4], cs[4];
+    th[0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th[1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
+    th[2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th[3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) big |= !(fabsf(th[r]) < 32768.0f);
+    if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sincos_nocall(th[r], sn[r], cs[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sincos_small(th[r], sn[r], cs[r]);
+    }
+    const float fv[4] = {(ac[u][0] - mean) * rstd * lw.x + lb.x, (ac[u][1] - mean) * rstd * lw.y + lb.y,
+                         (ac[u][2] - mean) * rstd * lw.z + lb.z, (ac[u][3] - mean) * rstd * lw.w + lb.w};
+#pragma unroll
+    for (int pp = 0; pp < P; pp++) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (pp == 2) pv[r] = fv[r] * th[r];
+        else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[r] = fv[r] * sn[r];
+        else pv[r] = fv[r] * cs[r];
+      }
+      if (valid) *reinterpret_cast<float4 *>(xrow + pp * C + cb) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    }
+  }
+  LEAN_WAITALL();
+  LEAN_TICK(tk4);
+#ifdef LEAN_DBG
+  if (tid == 0) {
+    atomicAdd(&a.hdr[16], (int)((tk1 - tk0) >> 4)); atomicAdd(&a.hdr[17], (int)((tk2 - tk1) >> 4)); atomicAdd(&a.hdr[18], (int)((tk3 - tk2) >> 4));
+    atomicAdd(&a.hdr[19], (int)((tk4 - tk3) >> 4)); atomicAdd(&a.hdr[20], 1);
+  }
+#endif
+  if (!a.build || wave != 0) return;                     // wave-uniform
+  // ---- the ranks are back: slot lists and work items, all inside wave 0 ----
+  const int rank = __shfl(base, g_lead, 64) + g_off;
+  const bool full = cell >= 0 && rank >= a.k;
+  if (full) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 2);
+  const bool keep = cell >= 0 && !full;
+  if (keep) a.list[(int64_t)cell * a.k + rank] = i;
+  const bool item = keep && (rank & (LEAN_CH - 1)) == 0;
+  const unsigned long long im = __ballot(item);
+  if (im == 0) return;
+  const int sg = blockIdx.x % LEAN_SEGS;
+  int ibase = 0;
+  if (lane == 0) ibase = (int)atomicAdd(&a.ctrl[sg * 16], (unsigned)__popcll(im));
+  ibase = __builtin_amdgcn_readfirstlane(ibase);
+  if (item) a.occ[(int64_t)sg * a.seg_cap + ibase + __popcll(im & ((1ull << lane) - 1ull))] = cell * 16 + rank / LEAN_CH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,7 +438,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_sums(const lean_args a) {
     const int cell = it >> 4, chunk = it & 15;
     const int32_t *lst = a.list + (int64_t)cell * a.k;
     const int spec = lane < kl ? lst[lane] : INT_MAX;    // the first 64 ids without waiting for the count
-    const int cn = (int)a.cnt[cell];
+    const int cn = (int)a.cnt[(int64_t)cell << a.cshift];
     const int nc = cn < a.k ? cn : a.k;
     ids[lane] = lane < nc ? spec : INT_MAX;
     for (int l = 64 + lane; l < nc + 4; l += 64) ids[l] = l < nc ? lst[l] : INT_MAX;    // padded to whole int4 pieces
@@ -333,7 +551,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
     // everything the item needs is addressed from (cell, slot): the chunk's records, the counts of the r^3 neighbour cells
     // and -- without waiting for those counts -- the first chunk row of each of them
     const int4 myrec = a.rec2[slot * LEAN_CH + (lane & (LEAN_CH - 1))];
-    const int cn_own = (int)a.cnt[cell];
+    const int cn_own = (int)a.cnt[(int64_t)cell << a.cshift];
     const int ub = cell % d3, t1 = cell / d3;
     const int uz = t1 % d2, t2 = t1 / d2;
     const int uy = t2 % d1, ux = t2 / d1;
@@ -343,7 +561,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
       return (t < R3 && vx < (unsigned)d0 && vy < (unsigned)d1 && vz < (unsigned)d2) ? (((int)vx * d1 + (int)vy) * d2 + (int)vz) * d3 + ub : -1;
     };
     const int nbc = nb_cell(lane);
-    int cn = nbc >= 0 ? (int)a.cnt[nbc] : 0;
+    int cn = nbc >= 0 ? (int)a.cnt[(int64_t)nbc << a.cshift] : 0;
     float4 acc[P];
 #pragma unroll
     for (int pp = 0; pp < P; pp++) acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -180,6 +180,7 @@ class ElkCorePlan:
         self.block_order = block_order
         self._tuning = dict(tuning)
         self._tiles_opt = bool(self._tuning.pop("tiles", True))     # general layout: the two-launch tile form where it applies
+        self._lean_cs = self._tuning.pop("lean_cs", None)           # lean form: channel-split first launch (None: by frame size)
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
@@ -324,10 +325,15 @@ class ElkCorePlan:
         if v * kch * w * 4 + v * k * 4 + n_cap * (w * 4 + 512) > self.LEAN_MAX_BYTES:
             raise L.LinkAmdError("ElkCorePlan(layout='lean'): tables beyond ElkCorePlan.LEAN_MAX_BYTES")
         self.lean, self.dense, self.sparse, self.dcg, self.k = True, False, False, None, k
+        if self._lean_cs is not None:
+            self.desc.flags |= L.ELK_LEAN_CS if self._lean_cs else L.ELK_LEAN_NO_CS
         i32 = dict(dtype=torch.int32, device=dev)
         self.out = torch.empty((n_cap, c), dtype=torch.float32, device=dev)
-        self.hdr = torch.zeros(L.HDR_WORDS, dtype=torch.int32, device=dev)
-        self.cnt2 = [torch.zeros(max(v, 1), **i32), torch.zeros(max(v, 1), **i32)]      # self-cleaning, alternating
+        self.hdr = torch.zeros(64, dtype=torch.int32, device=dev)         # 8 words of header; the rest for profiling builds (-DLEAN_DBG)
+        # a counter per line on small grids (a few hundred cells of up to 343 voxels: the insert's atomics would serialise on a
+        # handful of lines), packed tighter as the grid grows
+        self.cnt_shift = 5 if v <= 32768 else (3 if v <= 262144 else 0)
+        self.cnt2 = [torch.zeros(max(v, 1) << self.cnt_shift, **i32), torch.zeros(max(v, 1) << self.cnt_shift, **i32)]   # self-cleaning, alternating
         self.list = torch.empty(v * k, **i32)
         self.seg_cap = (n_cap // 64 + 16) // L.LEAN_SEGS * 64 + 64
         self.rec2 = torch.empty((L.LEAN_SEGS * self.seg_cap * L.LEAN_CHUNK, 4), **i32)
@@ -338,7 +344,7 @@ class ElkCorePlan:
         self._cur, self._n_prev = 0, 0
         b = self.buf = L.LinkLeanBuffers()
         b.list, b.rec2, b.X, b.S = self.list.data_ptr(), self.rec2.data_ptr(), self.X.data_ptr(), self.S.data_ptr()
-        b.hdr, b.out, b.seg_cap, b.k = self.hdr.data_ptr(), self.out.data_ptr(), self.seg_cap, k
+        b.hdr, b.out, b.seg_cap, b.k, b.cnt_shift = self.hdr.data_ptr(), self.out.data_ptr(), self.seg_cap, k, self.cnt_shift
         self.m_cap = n_cap
 
     def _run_lean(self, n: int, build_index: bool, st) -> int:
@@ -1866,6 +1872,12 @@ class _ELKBase(nn.Module):
             return None
         if st.kmaps.get(("link_block_index", coords.data_ptr(), n, int(s_eff))) is not None:
             return None                                       # an index of these coordinates exists: the two tile launches
+        vkey = ("link_lean_visit", coords.data_ptr(), n, int(s_eff))
+        if st.cmaps.get(vkey):
+            # second visit of one coordinate set (its maps are being kept): worth an index -- from the third visit on the
+            # tile form runs warm, which beats this form's warm step (26 against 36 us on a 24k-voxel stage)
+            return None
+        st.cmaps[vkey] = True
         ts = st.s[0] if isinstance(st.s, (tuple, list)) else st.s
         ts = max(int(ts), 1)
         # coordinates of a tensor at stride ts are multiples of ts (torchsparse/nn/functional/downsample.py:27-40), so a block
@@ -1901,12 +1913,9 @@ class _ELKBase(nn.Module):
             return None
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
-        ikey = (coords.data_ptr(), n, coords._version)
         alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
         out = alloc((n, c), dtype=feats.dtype, device=feats.device)
-        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
-        plan._indexed = ikey
-        plan._keepalive = coords
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=True, out=out)
         return out
 
     def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):

@@ -131,3 +131,40 @@ def test_lean_form_half_rows_status_and_limits():
     with pytest.raises(la._lib.LinkAmdError):            # blocks of 8^3 voxels: beyond the slot capacity the form takes
         la.ElkCorePlan(1000, C, baseop, C // groups, r, 8, ((0, 0, 0, 0), (59, 59, 59, 0)), torch.device("cuda"), layout="lean")
     assert not la.ElkCorePlan.lean_supported(1000, 48, baseop, r, 3, ((0, 0, 0, 0), (59, 59, 59, 0)))
+
+
+def test_module_path_takes_the_lean_form_on_the_first_visit_of_a_coordinate_set():
+    """ELKBlock.forward (inference) on a LiDAR-like frame: the first visit of a coordinate set runs the lean form (a plan in the
+    module's cache, no block index built), a second visit of the SAME tensor's maps builds the index for the tile form; both
+    agree with the oracle, and with the lean form switched off the result is the general layout's."""
+    import link_amd as la
+    from link_amd import elk as E
+    C, groups, baseop, stride, s, r = 64, 1, "cos_x", 2, 6, 2
+    blk, params = _block(la, C, groups, baseop, 5)
+    coords = torch.from_numpy(lidar_like(20000, seed=8, stride=stride))
+    feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(8))
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                           agg=O.aggregate_c)
+
+    def core(st):
+        with torch.no_grad():
+            return blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha, C // groups, float(stride)).float().cpu()
+
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    first = core(st)
+    assert len(blk.__dict__.get("_lean_plans", {})) == 1 and next(iter(blk._lean_plans.values())).lean
+    assert not any(k[0] == "link_block_index" for k in st.kmaps)
+    next(iter(blk._lean_plans.values())).check()
+    second = core(st)                                   # same maps: the general layout builds its index now
+    assert any(k[0] == "link_block_index" for k in st.kmaps)
+    third = core(st)
+    assert rel_err(first.numpy(), ref.numpy()) < TOL and rel_err(second.numpy(), ref.numpy()) < TOL
+    assert torch.equal(second, third)
+    st2 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)          # a fresh coordinate set: lean again, bitwise the same
+    assert torch.equal(core(st2), first)
+    E.LEAN_FORM = False
+    try:
+        st3 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+        assert torch.equal(core(st3), second)
+    finally:
+        E.LEAN_FORM = True

@@ -34,6 +34,14 @@ for s in 0 4; do
   [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/kernel_stats_lidar_stage$s.csv | grep -E "k_elk|k_cell_c|k_cell_s|k_place|k_sort" | head -6
   rm -rf $D
 done
+# the lean form (three launches, index rebuilt) on a small, a mid and a detection stage
+for s in 3 1 6; do
+  D=$OUT/trace_lean$s; mkdir -p $D
+  FORM=lean STAGE=$s ITERS=200 timeout 150 rocprofv3 --kernel-trace --stats -d $D -o trace -- python $R/tools/lidar_core.py > $D/log.txt 2>&1
+  db=$(find $D -name "*.db" | head -1)
+  [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/kernel_stats_lean_stage$s.csv | grep -E "k_lean" | head -4
+  rm -rf $D
+done
 # the voxel-scan numbering of the general layout's index against the cell scan (A/B on this box), and the three-frame step
 # kernel against three plans on three streams
 for o in cell first; do ORDER=$o FORM=tiles timeout 300 python $R/tools/lidar_core.py 2>/dev/null | grep '^{' > $OUT/lidar_stages_order_$o.jsonl; done
