@@ -300,13 +300,13 @@ class ElkCorePlan:
         return (c in (16, 32, 64, 128) and r in (2, 3) and k <= L.LEAN_KMAX and v < 2 ** 27 and n_cap * c * 4 < 2 ** 32
                 and v * kch * w * 4 + v * k * 4 + n_cap * (w * 4 + 512) <= cls.LEAN_MAX_BYTES)
 
-    LEAN_AUTO_FLOATS = 6_500_000
+    LEAN_AUTO_FLOATS = 8_000_000
 
     @classmethod
     def lean_auto(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, slot_cap: int) -> bool:
         """Where the lean form is the faster one with the index rebuilt (A/B over the eight LiDAR stage frames, round 4): frames
-        whose scratch matrix X (n x P*C floats, written by launch 1 and read by launch 2) stays below ~26 MB -- up to ~30k
-        voxels at C = 64 cos_x, ~100k at C = 32; above that the tile form's single pass over the rows wins."""
+        whose scratch matrix X (n x P*C floats, written by launch 1 and read by launch 2) stays below ~32 MB -- 150k voxels at
+        C = 16, 90k at C = 32, 40k at C = 64 cos_x (wins by 6-16 us there; the 59k-voxel C = 64 cos_x stage, 45 MB, loses 4); above that the tile form's single pass over the rows wins."""
         w = (3 if baseop == "cos_x" else 2) * c
         return n_cap * w <= cls.LEAN_AUTO_FLOATS and cls.lean_supported(n_cap, c, baseop, r, s, bounds, slot_cap)
 
@@ -1884,7 +1884,7 @@ class _ELKBase(nn.Module):
         # of edge s_eff holds at most (s_eff / ts)^3 of them; a frame that breaks the promise raises the plan's status word
         k = (max(int(s_eff) // ts, 1)) ** 3 if int(s_eff) % ts == 0 else int(s_eff) ** 3
         n_cap = 1 << max(10, (n - 1).bit_length())
-        if k > L.LEAN_KMAX or n_cap * (3 if self.baseop == "cos_x" else 2) * c > ElkCorePlan.LEAN_AUTO_FLOATS:
+        if k > L.LEAN_KMAX or n * (3 if self.baseop == "cos_x" else 2) * c > ElkCorePlan.LEAN_AUTO_FLOATS:
             return None
         bkey = ("link_bounds", coords.data_ptr(), n)
         bounds = st.cmaps.get(bkey)

@@ -168,3 +168,27 @@ def test_module_path_takes_the_lean_form_on_the_first_visit_of_a_coordinate_set(
         assert torch.equal(core(st3), second)
     finally:
         E.LEAN_FORM = True
+
+
+def test_lean_form_batched_frames():
+    """Two frames in one tensor (batch index in the coordinates, hash_cuda.cu:46): blocks never mix across the batch axis."""
+    import link_amd as la
+    C, groups, baseop, stride, s, r = 32, 2, "cos", 2, 6, 3
+    blk, params = _block(la, C, groups, baseop, 21)
+    a = torch.from_numpy(lidar_like(6000, seed=1, stride=stride))
+    b = torch.from_numpy(lidar_like(9000, seed=2, stride=stride))
+    b[:, 3] = 1
+    coords = torch.cat([a, b])[torch.randperm(a.shape[0] + b.shape[0], generator=torch.Generator().manual_seed(0))].contiguous()
+    feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(3))
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride, agg=O.aggregate_c).numpy()
+    le, ge = _plans(la, blk, coords.shape[0], C, baseop, groups, r, s, coords.cuda(), (s // stride) ** 3)
+    got = le.run(feats.cuda(), coords.cuda()).clone()
+    ge.run(feats.cuda(), coords.cuda())
+    assert le.blocks() == ge.blocks() > 0
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+    # each frame alone gives the same rows
+    for bi, part in ((0, a), (1, b)):
+        m = (coords[:, 3] == bi)
+        ref_b = O.elk_core_torch(feats[m], coords[m], params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                                 agg=O.aggregate_c).numpy()
+        assert rel_err(got.cpu().numpy()[m.numpy()], ref_b) < TOL
