@@ -1863,21 +1863,15 @@ class _ELKBase(nn.Module):
         return out
 
     def _core_lean(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
-        """Inference R_core through the lean form (ElkCorePlan(layout='lean'): three launches, nothing cached between calls
-        but the arena) for coordinate sets that have no block index yet -- the first visit of a LiDAR stage frame, i.e. every
-        call in a stream of frames.  None when the form does not apply (then the general layout builds its index)."""
+        """Inference R_core through the lean form (ElkCorePlan(layout='lean'): three launches with the index rebuilt, nothing
+        cached per coordinate set but the arena) for coordinate sets that have no block index yet -- every call, in a stream
+        of LiDAR frames.  None when the form does not apply (then the general layout builds its index)."""
         feats, coords = st.F, st.C
         n, c = feats.shape
         if n == 0 or c not in (16, 32, 64, 128) or r not in (2, 3) or not feats.is_cuda or not LEAN_FORM:
             return None
         if st.kmaps.get(("link_block_index", coords.data_ptr(), n, int(s_eff))) is not None:
             return None                                       # an index of these coordinates exists: the two tile launches
-        vkey = ("link_lean_visit", coords.data_ptr(), n, int(s_eff))
-        if st.cmaps.get(vkey):
-            # second visit of one coordinate set (its maps are being kept): worth an index -- from the third visit on the
-            # tile form runs warm, which beats this form's warm step (26 against 36 us on a 24k-voxel stage)
-            return None
-        st.cmaps[vkey] = True
         ts = st.s[0] if isinstance(st.s, (tuple, list)) else st.s
         ts = max(int(ts), 1)
         # coordinates of a tensor at stride ts are multiples of ts (torchsparse/nn/functional/downsample.py:27-40), so a block
@@ -1913,9 +1907,15 @@ class _ELKBase(nn.Module):
             return None
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
                   self.norm.weight, self.norm.bias)
+        # a coordinate set that comes back (its maps are kept: the stage of a loop over one frame) stays on this form, so that
+        # a frame's rows do not depend on how often it was seen (rebuilt and reused lists give the same bits); the lists are
+        # reused while the plan has seen nothing else in between
+        ikey = (coords.data_ptr(), n, coords._version)
         alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
         out = alloc((n, c), dtype=feats.dtype, device=feats.device)
-        plan.run(feats.contiguous(), coords.contiguous(), build_index=True, out=out)
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
+        plan._indexed = ikey
+        plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
         return out
 
     def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):

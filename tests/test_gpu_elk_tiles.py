@@ -85,11 +85,23 @@ def test_tiles_on_lidar_like_frame(stride, baseop, groups, s, r):
     tp, fp = _plan_pair(la, blk, n, C, baseop, groups, r, s, coords.cuda(), coord_div=div)
     got = tp.run(feats.cuda(), coords.cuda())
     assert rel_err(got.cpu().numpy(), ref) < TOL
-    # the module path takes the same two kernels
+    # the module path takes the same two kernels once the coordinate set has a block index (without one it runs the lean
+    # form, three launches with the index rebuilt: tests/test_gpu_lean.py), and always with the lean form switched off
+    from link_amd import elk as E
+    from link_amd.aggregate import link_index_of
     st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    link_index_of(st, s)
     with torch.no_grad():
         core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None, C // groups, div)
     assert torch.equal(core, got)
+    E.LEAN_FORM = False
+    try:
+        st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+        with torch.no_grad():
+            core = blk._core(st, s, r, blk.pos_weight[0].weight, blk.alpha if baseop == "cos_x" else None, C // groups, div)
+        assert torch.equal(core, got)
+    finally:
+        E.LEAN_FORM = True
 
 
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 257, 1000])

@@ -133,12 +133,14 @@ def test_lean_form_half_rows_status_and_limits():
     assert not la.ElkCorePlan.lean_supported(1000, 48, baseop, r, 3, ((0, 0, 0, 0), (59, 59, 59, 0)))
 
 
-def test_module_path_takes_the_lean_form_on_the_first_visit_of_a_coordinate_set():
-    """ELKBlock.forward (inference) on a LiDAR-like frame: the first visit of a coordinate set runs the lean form (a plan in the
-    module's cache, no block index built), a second visit of the SAME tensor's maps builds the index for the tile form; both
-    agree with the oracle, and with the lean form switched off the result is the general layout's."""
+def test_module_path_takes_the_lean_form_for_coordinate_sets_without_an_index():
+    """ELKBlock.forward (inference) on a LiDAR-like frame runs the lean form (a plan in the module's cache, no block index
+    built), the same coordinate set again reuses the plan's lists and gives the same bits, a fresh coordinate set too; a
+    coordinate set that already has a block index (an aggregation op built it) takes the tile form; all within the oracle's
+    tolerance."""
     import link_amd as la
     from link_amd import elk as E
+    from link_amd.aggregate import link_index_of
     C, groups, baseop, stride, s, r = 64, 1, "cos_x", 2, 6, 2
     blk, params = _block(la, C, groups, baseop, 5)
     coords = torch.from_numpy(lidar_like(20000, seed=8, stride=stride))
@@ -155,17 +157,18 @@ def test_module_path_takes_the_lean_form_on_the_first_visit_of_a_coordinate_set(
     assert len(blk.__dict__.get("_lean_plans", {})) == 1 and next(iter(blk._lean_plans.values())).lean
     assert not any(k[0] == "link_block_index" for k in st.kmaps)
     next(iter(blk._lean_plans.values())).check()
-    second = core(st)                                   # same maps: the general layout builds its index now
-    assert any(k[0] == "link_block_index" for k in st.kmaps)
-    third = core(st)
-    assert rel_err(first.numpy(), ref.numpy()) < TOL and rel_err(second.numpy(), ref.numpy()) < TOL
-    assert torch.equal(second, third)
-    st2 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)          # a fresh coordinate set: lean again, bitwise the same
+    assert torch.equal(core(st), first)                 # same maps again: reused lists, same bits
+    st2 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)          # a fresh coordinate set: rebuilt, same bits
     assert torch.equal(core(st2), first)
+    assert rel_err(first.numpy(), ref.numpy()) < TOL
+    st3 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    link_index_of(st3, s)                               # an index exists: the two tile launches
+    tiles = core(st3)
+    assert rel_err(tiles.numpy(), ref.numpy()) < TOL
     E.LEAN_FORM = False
     try:
-        st3 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
-        assert torch.equal(core(st3), second)
+        st4 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+        assert torch.equal(core(st4), tiles)
     finally:
         E.LEAN_FORM = True
 
