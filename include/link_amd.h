@@ -267,6 +267,8 @@ typedef struct {
 #define LINK_ELK_NO_DENSE_GRID 8   /* block gather: column-walking form even on mostly occupied grids */
 #define LINK_ELK_LEAN_CS 32        /* link_elk_core_lean_forward: channel-split form of launch 1 whenever C is 64 / 128 */
 #define LINK_ELK_LEAN_NO_CS 64     /* ... never (default: by frame size) */
+#define LINK_ELK_LEAN_PM 128       /* link_elk_core_lean_forward: the form without the scratch matrix X (pre_mix inside launch 2; C <= 64) */
+#define LINK_ELK_LEAN_NO_PM 256    /* ... never (default: by frame size) */
 #define LINK_ELK_TILES 16          /* link_elk_core_forward: the tile form (two launches: link_elk_premix_modsum_tiles +
                                       link_elk_gather_demod_tiles); needs link_elk_buffers_t::s_bytes */
 

@@ -17,7 +17,7 @@ LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
-ELK_LEAN_CS, ELK_LEAN_NO_CS = 32, 64
+ELK_LEAN_CS, ELK_LEAN_NO_CS, ELK_LEAN_PM, ELK_LEAN_NO_PM = 32, 64, 128, 256
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
 ABI_VERSION = 9
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and

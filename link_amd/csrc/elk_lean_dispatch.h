@@ -49,11 +49,50 @@ static unsigned lean_item_wgs(int idx_cap) {
   return (unsigned)((w + 3) & ~(int64_t)3);
 }
 
+// which path: the form without the scratch matrix X (launch 1 = slot insert alone, pre_mix inside launch 2) for C <= 64 on frames
+// big enough that writing and re-reading X costs more than a second pass over the weights (link_elk_desc_t::flags can force
+// either: LINK_ELK_LEAN_PM / LINK_ELK_LEAN_NO_PM)
+static bool lean_use_pm(const link_elk_desc_t &d, int64_t n) {
+  if (d.c > 64 || (d.flags & LINK_ELK_LEAN_NO_PM)) return false;
+  if (d.flags & LINK_ELK_LEAN_PM) return true;
+  return false;      // (by frame size once measured: LEAN_PM_MIN_VOXELS)
+}
+
+template <int C, int OP, int NB>
+static void launch_lean_pm(const lean_args &a, hipStream_t st) {
+  const int lds = dc_wimg<C>::W_BYTES;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lean_sums_pm<C, OP, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((k_lean_sums_pm<C, OP, NB>), dim3(lean_item_wgs(a.idx_cap)), dim3(256), lds, st, a);
+}
+
+template <int C, int OP>
+static void lean_pm_nb(const link_elk_desc_t &d, const lean_args &a, hipStream_t st) {
+  constexpr int T = C / 16;
+  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
+  if (nb > T) nb = T;
+  if (T >= 2 && nb == T / 2) return launch_lean_pm<C, OP, (T >= 2 ? T / 2 : 1)>(a, st);
+  if (T >= 4 && nb == T / 4) return launch_lean_pm<C, OP, (T >= 4 ? T / 4 : 1)>(a, st);
+  return launch_lean_pm<C, OP, T>(a, st);
+}
+
 template <int C, int OP>
 static int lean_c_op(const link_elk_desc_t &d, const lean_args &a, int64_t n_prev, hipStream_t st) {
   constexpr int P = op_parts<OP>::value;
-  lean_nb<C, OP>(d, a, n_prev, st);
-  hipLaunchKernelGGL((k_lean_sums<C, P>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
+  bool pm = false;
+  if constexpr (C <= 64) pm = lean_use_pm(d, a.n);
+  if (pm) {
+    if constexpr (C <= 64) {
+      if (a.build) {
+        const int64_t wgs = (int64_t)a.nwg + ((int64_t)LEAN_SEGS * a.idx_cap_prev + 255) / 256;
+        if (wgs >= 1) hipLaunchKernelGGL(k_lean_insert, dim3((unsigned)wgs), dim3(256), 0, st, a);
+      }
+      lean_pm_nb<C, OP>(d, a, st);
+    }
+  } else {
+    lean_nb<C, OP>(d, a, n_prev, st);
+    hipLaunchKernelGGL((k_lean_sums<C, P>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
+  }
   if (d.r == 2) hipLaunchKernelGGL((k_lean_gather<C, OP, 2>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
   else hipLaunchKernelGGL((k_lean_gather<C, OP, 3>), dim3(lean_item_wgs(a.idx_cap)), dim3(64 * LEAN_IW), 0, st, a);
   return check_launch("link_elk_core_lean_forward");
@@ -78,9 +117,14 @@ int run_lean(const link_lean_buffers_t &b, const link_grid_t &g, const link_elk_
   a.n = (int)n; a.k = b.k; a.kch = (b.k + LEAN_CH - 1) / LEAN_CH; a.build = build;
   // a list receives the items of every 16th workgroup of launch 1, at most one per voxel of the workgroup (64, or 16 in the
   // channel-split form); the previous frame's bound covers either form
-  const int vpw = lean_use_cs(d, n) ? 16 : 64;
+  const bool pm = d.c <= 64 && lean_use_pm(d, n);
+  const int vpw = pm ? 256 : (lean_use_cs(d, n) ? 16 : 64);      // voxels per workgroup of launch 1
   a.nwg = (int)((n + vpw - 1) / vpw);
-  a.idx_cap = (int)(((int64_t)a.nwg + LEAN_SEGS - 1) / LEAN_SEGS * vpw);
+  // (the insert-only launch appends per WAVE of 64 voxels, list = wave % 16)
+  a.idx_cap = pm ? (int)(((n + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64) : (int)(((int64_t)a.nwg + LEAN_SEGS - 1) / LEAN_SEGS * vpw);
+  const int parts = d.op == LINK_OP_COSX ? 3 : 2;
+  a.xl_stride = pm ? d.c : parts * d.c;
+  a.xl_off = pm ? 0 : 2 * d.c;
   a.idx_cap_prev = (int)(((n_prev + 63) / 64 + LEAN_SEGS - 1) / LEAN_SEGS * 64 + 16);
   a.seg_cap = b.seg_cap; a.cshift = b.cnt_shift;
   a.cnt = b.cnt; a.cnt_prev = b.cnt_prev; a.list = b.list; a.occ = b.occ; a.occ_prev = b.occ_prev;

@@ -52,6 +52,7 @@ struct lean_args {
   int cg;
   float coord_div, eps;
   int n, k, kch, build, nwg, idx_cap, idx_cap_prev, cshift;
+  int xl_stride, xl_off;              // where launch 3 finds fin * theta of voxel id (cos_x): X + id * xl_stride + xl_off
   int64_t seg_cap;
   uint32_t *cnt, *cnt_prev;
   int32_t *list, *occ;
@@ -413,6 +414,205 @@ __global__ void __launch_bounds__(256) k_lean_insert_premix_cs(const lean_args a
 }
 
 // ---------------------------------------------------------------------------------------------
+// The form WITHOUT the scratch matrix X (frames of many voxels, C <= 64): launch 1 is the slot insert alone, launch 2 gathers
+// the chunk's feature rows in id order and runs pre_mix + LayerNorm + theta + modulate on them itself, summing the tile in the
+// accumulator layout (a DPP row holds the tile's 16 voxels) -- the n x P*C floats of X are neither written nor read (45 MB each
+// way on the 59k-voxel cos_x stage); cos_x leaves fin * theta of each voxel in an n x C matrix for launch 3.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lean_insert(const lean_args a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  if ((int)blockIdx.x >= a.nwg) {                        // clean-up workgroups (a.nwg counts 256-voxel workgroups here)
+    const int q = ((int)blockIdx.x - a.nwg) * 256 + tid;
+    const int sg = q & (LEAN_SEGS - 1), idx = q >> 4;
+    if (idx < a.idx_cap_prev) {
+      const int c = (int)a.ctrl_prev[sg * 16];
+      const int it = a.occ_prev[(int64_t)sg * a.seg_cap + idx];
+      if (idx < c && (it & 15) == 0) a.cnt_prev[(int64_t)(it >> 4) << a.cshift] = 0u;
+    }
+    return;
+  }
+  const int i = blockIdx.x * 256 + tid;
+  const bool valid = i < a.n;
+  int cell = -1;
+  if (valid) {
+    const int4 rec = a.coords[i];
+    cell = cell_of(a.g, floordiv(rec.x, a.g.s), floordiv(rec.y, a.g.s), floordiv(rec.z, a.g.s), rec.w);
+    if (cell < 0) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 1);
+  }
+  int g_lead, g_off, g_size, base = 0;
+  lean_groups(cell >= 0, cell, lane, g_lead, g_off, g_size);
+  if (cell >= 0 && lane == g_lead) base = (int)atomicAdd(&a.cnt[(int64_t)cell << a.cshift], (unsigned)g_size);
+  const int rank = __shfl(base, g_lead, 64) + g_off;
+  const bool full = cell >= 0 && rank >= a.k;
+  if (full) atomicOr(&a.hdr[LINK_HDR_STATUS_ACC], 2);
+  const bool keep = cell >= 0 && !full;
+  if (keep) a.list[(int64_t)cell * a.k + rank] = i;
+  const bool item = keep && (rank & (LEAN_CH - 1)) == 0;
+  const unsigned long long im = __ballot(item);
+  if (im == 0) return;                                   // wave-uniform
+  const int sg = (blockIdx.x * 4 + (tid >> 6)) % LEAN_SEGS;      // a list per wave here (64 voxels, as the other forms' workgroups)
+  int ibase = 0;
+  if (lane == 0) ibase = (int)atomicAdd(&a.ctrl[sg * 16], (unsigned)__popcll(im));
+  ibase = __builtin_amdgcn_readfirstlane(ibase);
+  if (item) a.occ[(int64_t)sg * a.seg_cap + ibase + __popcll(im & ((1ull << lane) - 1ull))] = cell * 16 + rank / LEAN_CH;
+}
+
+template <int C, int OP, int NB>
+__global__ void __launch_bounds__(256, (C <= 32 ? 3 : 2)) k_lean_sums_pm(const lean_args a) {
+  constexpr int T = C / 16, P = op_parts<OP>::value, W = P * C;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ __attribute__((aligned(16))) int ids_lds[4][LEAN_KMAX + 4];
+  __shared__ int sorted_lds[4][LEAN_CH];
+  float *ln_lds = reinterpret_cast<float *>(smem_raw + dc_wimg<C>::WIMG_BYTES);
+  float *pw_lds = ln_lds + 2 * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, gq = lane >> 4;
+  if (a.build && blockIdx.x == 0 && tid < LEAN_SEGS) a.ctrl_prev[tid * 16] = 0u;      // the next frame appends from zero
+  int *ids = ids_lds[wave], *sorted = sorted_lds[wave];
+  const int kl = a.k < 64 ? a.k : 64;
+  const int j0 = blockIdx.x * 4 + wave;
+  const int sg = j0 & (LEAN_SEGS - 1);
+  const int nitem = (int)a.ctrl[sg * 16];
+  int idx = j0 >> 4;
+  int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;
+  const int step = (int)(gridDim.x * 4) >> 4;
+  bool w_big = dc_stage_weights<C, 256>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
+  w_big = __syncthreads_or(w_big) != 0;                  // before any wave leaves
+  const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
+  const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(a.feats, (uint32_t)((int64_t)a.n * C * IO_BYTES));
+  for (; idx < nitem; idx += step) {
+    const int it = it_n;
+    if (idx + step < nitem) it_n = a.occ[(int64_t)sg * a.seg_cap + idx + step];
+    const int64_t slot = (int64_t)sg * a.seg_cap + idx;
+    const int cell = it >> 4, chunk = it & 15;
+    const int32_t *lst = a.list + (int64_t)cell * a.k;
+    const int spec = lane < kl ? lst[lane] : INT_MAX;
+    const int cn = (int)a.cnt[(int64_t)cell << a.cshift];
+    const int nc = cn < a.k ? cn : a.k;
+    ids[lane] = lane < nc ? spec : INT_MAX;
+    for (int l = 64 + lane; l < nc + 4; l += 64) ids[l] = l < nc ? lst[l] : INT_MAX;
+    if (nc < 64 && lane < 4) ids[64 + lane] = INT_MAX;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int lo = chunk * LEAN_CH;
+    for (int l0 = 0; l0 < nc; l0 += 64) {
+      const int l = l0 + lane;
+      const int my = l < nc ? ids[l] : INT_MAX;
+      int rk = 0;
+      for (int q = 0; q < nc; q += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(&ids[q]);
+        rk += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+      }
+      if (l < nc && rk >= lo && rk < lo + LEAN_CH) sorted[rk - lo] = my;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nch = nc - lo < LEAN_CH ? nc - lo : LEAN_CH;
+    if (lane < nch) {                                    // the chunk's records in id order for launch 3
+      const int id = sorted[lane];
+      int4 myrec = a.coords[id];
+      myrec.w = id;
+      a.rec2[slot * LEAN_CH + lane] = myrec;
+    }
+    float4 acc[P][T];
+#pragma unroll
+    for (int pp = 0; pp < P; pp++)
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) acc[pp][tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 < nch; t0 += 16) {
+      const int m = t0 + li;
+      const bool valid = m < nch;
+      const int id = sorted[valid ? m : 0];
+      const int4 rec = a.coords[id];
+      float4 ff[T];
+      {
+        const uint32_t ro = ((uint32_t)id * (uint32_t)C + (uint32_t)(4 * gq)) * (uint32_t)IO_BYTES;
+        ff[0] = io_ldb4<0>(r_feats, ro);
+        if constexpr (T > 1) ff[1] = io_ldb4<16>(r_feats, ro);
+        if constexpr (T > 2) { ff[2] = io_ldb4<32>(r_feats, ro); ff[3] = io_ldb4<48>(r_feats, ro); }
+        if constexpr (T > 4) { ff[4] = io_ldb4<64>(r_feats, ro); ff[5] = io_ldb4<80>(r_feats, ro); ff[6] = io_ldb4<96>(r_feats, ro); ff[7] = io_ldb4<112>(r_feats, ro); }
+      }
+      floatx4 ac[T];
+      dc_premix_tile<C>(wh, a.w_pre, w_big, li, gq, ff, ac);
+      float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
+      if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
+      float th[NB][4], sn[NB][4], cs[NB][4];
+      auto trig = [&](int tb, float (&th_)[4], float (&sn_)[4], float (&cs_)[4]) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(&pw_lds[16 * tb + 4 * gq]);
+        const float4 q1 = *reinterpret_cast<const float4 *>(&pw_lds[C + 16 * tb + 4 * gq]);
+        const float4 q2 = *reinterpret_cast<const float4 *>(&pw_lds[2 * C + 16 * tb + 4 * gq]);
+        const float4 qa = *reinterpret_cast<const float4 *>(&pw_lds[3 * C + 16 * tb + 4 * gq]);
+        th_[0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th_[1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
+        th_[2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th_[3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
+        bool big = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) big |= !(fabsf(th_[r]) < 32768.0f);
+        if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) sincos_nocall(th_[r], sn_[r], cs_[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) sincos_small(th_[r], sn_[r], cs_[r]);
+        }
+      };
+      if constexpr (NB < T) {
+#pragma unroll
+        for (int tb = 0; tb < NB; tb++) trig(tb, th[tb], sn[tb], cs[tb]);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
+      s = dc_sum_groups(s);
+      const float mean = s * (1.0f / C);
+      float qq = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < T; tp++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float d = ac[tp][r] - mean;
+          qq += d * d;
+        }
+      qq = dc_sum_groups(qq);
+      const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + a.eps);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) {
+        const int tb = tp % NB;
+        const float4 lw = *reinterpret_cast<const float4 *>(&ln_lds[16 * tp + 4 * gq]);
+        const float4 lb = *reinterpret_cast<const float4 *>(&ln_lds[C + 16 * tp + 4 * gq]);
+        float th1[4], sn1[4], cs1[4];
+        if constexpr (NB == T) trig(tp, th1, sn1, cs1);
+        const float fv[4] = {(ac[tp][0] - mean) * rstd * lw.x + lb.x, (ac[tp][1] - mean) * rstd * lw.y + lb.y,
+                             (ac[tp][2] - mean) * rstd * lw.z + lb.z, (ac[tp][3] - mean) * rstd * lw.w + lb.w};
+#pragma unroll
+        for (int pp = 0; pp < P; pp++) {
+          float pv[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float th_ = NB == T ? th1[r] : th[tb][r], sn_ = NB == T ? sn1[r] : sn[tb][r], cs_ = NB == T ? cs1[r] : cs[tb][r];
+            if (pp == 2) pv[r] = fv[r] * th_;
+            else if ((pp == 0) == (OP == LINK_OP_SIN)) pv[r] = fv[r] * sn_;
+            else pv[r] = fv[r] * cs_;
+          }
+          if (pp == 2 && valid)                          // cos_x: fin * theta of this voxel, for launch 3 (linkunet.py:176)
+            *reinterpret_cast<float4 *>(a.X + (int64_t)id * C + 16 * tp + 4 * gq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+          // the tile's 16 voxels sit in one DPP row: all-reduce along it (lanes beyond the chunk add zero)
+          acc[pp][tp].x += grp_sum<16>(valid ? pv[0] : 0.f); acc[pp][tp].y += grp_sum<16>(valid ? pv[1] : 0.f);
+          acc[pp][tp].z += grp_sum<16>(valid ? pv[2] : 0.f); acc[pp][tp].w += grp_sum<16>(valid ? pv[3] : 0.f);
+        }
+      }
+    }
+    if (li == 0) {
+      float *srow = a.S + ((int64_t)cell * a.kch + chunk) * W + 4 * gq;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int tp = 0; tp < T; tp++) *reinterpret_cast<float4 *>(srow + pp * C + 16 * tp) = acc[pp][tp];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch 2: chunk sums
 // ---------------------------------------------------------------------------------------------
 template <int C, int P>
@@ -644,7 +844,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
     float4 xl_n = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP == LINK_OP_COSX) {
       const int id0 = __shfl(myrec.w, grp < nch ? grp : 0, 64);
-      xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)id0 * W + 2 * C + ch0);
+      xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)id0 * a.xl_stride + a.xl_off + ch0);
     }
     for (int mi = 0; mi < steps; mi++) {
       const int m = mi * G + grp;
@@ -655,7 +855,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
       const float4 xl = xl_n;
       if (OP == LINK_OP_COSX && mi + 1 < steps) {
         const int idn = __shfl(myrec.w, m + G < nch ? m + G : 0, 64);
-        xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)idn * W + 2 * C + ch0);
+        xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)idn * a.xl_stride + a.xl_off + ch0);
       }
       float x = (float)rx, y = (float)ry, z = (float)rz;
       if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }

@@ -181,6 +181,7 @@ class ElkCorePlan:
         self._tuning = dict(tuning)
         self._tiles_opt = bool(self._tuning.pop("tiles", True))     # general layout: the two-launch tile form where it applies
         self._lean_cs = self._tuning.pop("lean_cs", None)           # lean form: channel-split first launch (None: by frame size)
+        self._lean_pm = self._tuning.pop("lean_pm", None)           # lean form: pre_mix inside launch 2, no X matrix (None: by frame size)
         self.grid = L.grid_from_bounds(bounds[0], bounds[1], int(s))
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
@@ -327,6 +328,8 @@ class ElkCorePlan:
         self.lean, self.dense, self.sparse, self.dcg, self.k = True, False, False, None, k
         if self._lean_cs is not None:
             self.desc.flags |= L.ELK_LEAN_CS if self._lean_cs else L.ELK_LEAN_NO_CS
+        if self._lean_pm is not None:
+            self.desc.flags |= L.ELK_LEAN_PM if self._lean_pm else L.ELK_LEAN_NO_PM
         i32 = dict(dtype=torch.int32, device=dev)
         self.out = torch.empty((n_cap, c), dtype=torch.float32, device=dev)
         self.hdr = torch.zeros(64, dtype=torch.int32, device=dev)         # 8 words of header; the rest for profiling builds (-DLEAN_DBG)

@@ -255,3 +255,37 @@ def test_bev_half_harness_shapes():
         assert {k: v.shape[1] for k, v in task.items()} == {"reg": 2, "height": 1, "dim": 3, "rot": 2, "vel": 2, "hm": ncls}
         assert all(v.shape[-2:] == (20, 20) for v in task.values())
     assert m.neck.out_channels == 512
+
+
+def test_lean_form_entry_rejects_bad_arguments_without_gpu():
+    """link_elk_core_lean_forward (round 4, ABI 9) validates before touching the device: widths, r, slot capacity, grid size,
+    list capacity, missing buffers; the struct layout is the header's."""
+    import ctypes
+    from link_amd import _lib as L
+    lib = L.lib()
+    assert L.ABI_VERSION == 9 and ctypes.sizeof(L.LinkLeanBuffers) == 21 * 8 + 8 + 4 * 4
+    assert lib.link_abi_struct_size(6) == ctypes.sizeof(L.LinkLeanBuffers)
+    grid = L.grid_from_bounds((0, 0, 0, 0), (63, 63, 63, 0), 7)
+    desc = L.LinkElkDesc(L.OP_COS, 64, 32, 3, 1.0, 1e-6)
+    b = L.LinkLeanBuffers()
+    b.k, b.seg_cap, b.io_dtype = 343, 4096, L.IO_F32
+    call = lambda n=1000, n_prev=0, build=1: lib.link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(grid), ctypes.byref(desc), n, n_prev, build, None)
+    assert call() == L.LINK_ERR_ARG                                   # no buffers
+    assert lib.link_elk_core_lean_forward(None, ctypes.byref(grid), ctypes.byref(desc), 10, 0, 1, None) == L.LINK_ERR_ARG
+    assert call(n=-1) == L.LINK_ERR_ARG
+    for field, bad in (("c", 48), ("r", 4), ("op", 7), ("cg", 0)):
+        d2 = L.LinkElkDesc(L.OP_COS, 64, 32, 3, 1.0, 1e-6)
+        setattr(d2, field, bad)
+        assert lib.link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(grid), ctypes.byref(d2), 10, 0, 1, None) == L.LINK_ERR_ARG, field
+    b.k = 353                                                         # beyond the slot capacity the form takes
+    assert call() == L.LINK_ERR_ARG
+    b.k, b.cnt_shift = 343, 6
+    assert call() == L.LINK_ERR_ARG
+    b.cnt_shift, b.seg_cap = 0, 8                                     # item lists too short for 1000 voxels
+    assert call() == L.LINK_ERR_ARG
+    big = L.LinkGrid()
+    big.s = 1
+    for a in range(4):
+        big.lo[a], big.dim[a] = 0, (1024 if a < 3 else 1)           # 2^30 cells: an item is cell * 16 + chunk in 31 bits
+    b.seg_cap = 4096
+    assert lib.link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(big), ctypes.byref(desc), 10, 0, 1, None) == L.LINK_ERR_ARG

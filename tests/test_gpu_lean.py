@@ -195,3 +195,36 @@ def test_lean_form_batched_frames():
         ref_b = O.elk_core_torch(feats[m], coords[m], params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
                                  agg=O.aggregate_c).numpy()
         assert rel_err(got.cpu().numpy()[m.numpy()], ref_b) < TOL
+
+
+@pytest.mark.parametrize("C,groups,baseop,stride,s,r", [(64, 1, "cos_x", 2, 6, 2), (64, 2, "cos", 1, 7, 3), (32, 2, "sin", 2, 6, 2),
+                                                        (16, 2, "cos", 1, 7, 3), (32, 1, "cos_x", 2, 4, 3)])
+def test_lean_form_without_the_scratch_matrix(C, groups, baseop, stride, s, r):
+    """The form whose first launch is the slot insert alone and whose second launch runs pre_mix on the gathered rows of each
+    chunk (no n x P*C matrix in between; what frames above 16k voxels take at C <= 64), forced on a small and a bigger frame:
+    oracle, the form with the matrix (same sums in another association), bitwise repeatable rebuilt / reused, fp16 rows."""
+    import link_amd as la
+    from link_amd.index import coords_bounds
+    blk, params = _block(la, C, groups, baseop, 3 * C + r)
+    cap = min((s // stride) ** 3, 343)
+    for seed, npts in ((5, 40000), (6, 5000)):
+        coords = torch.from_numpy(lidar_like(npts, seed=seed, stride=stride, voxel=0.2 if C == 16 else 0.05))
+        n = coords.shape[0]
+        feats = torch.randn(n, C, generator=torch.Generator().manual_seed(seed))
+        div = float(stride) if baseop == "cos_x" else 1.0
+        ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                               agg=O.aggregate_c).numpy()
+        bounds = coords_bounds(coords.cuda())
+        plans = [_bind(la.ElkCorePlan(n, C, baseop, C // groups, r, s, bounds, torch.device("cuda"), coord_div=div, layout="lean",
+                                      slot_cap=cap, lean_pm=pm), blk, baseop) for pm in (True, False)]
+        f, c = feats.cuda(), coords.cuda()
+        got = plans[0].run(f, c).clone()
+        other = plans[1].run(f, c).clone()
+        assert rel_err(got.cpu().numpy(), ref) < TOL
+        assert rel_err(got.cpu().numpy(), other.cpu().numpy()) < 2e-5
+        assert torch.equal(plans[0].run(f, c), got) and torch.equal(plans[0].run(f, c, build_index=False), got)
+        plans[0].check()
+        h = feats.half()
+        ref_h = O.elk_core_torch(h.float(), coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
+                                 agg=O.aggregate_c).numpy()
+        assert rel_err(plans[0].run(h.cuda(), c).float().cpu().numpy(), ref_h) < 2e-3

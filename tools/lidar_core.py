@@ -94,7 +94,8 @@ def main():
             row["module_warm_us"] = round(ev_time(lambda: b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]), iters), 1)
             cap = max(1, r["s_eff"] // max(r["stride"], 1)) ** 3      # voxel sites of a block at this tensor stride
             for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), ("sparse", dict(layout="sparse", slot_cap=cap, **({"k1_wgs": int(os.environ["IPW"])} if os.environ.get("IPW") else {}))),
-                             ("lean", dict(layout="lean", slot_cap=min(cap, 343), **({"lean_cs": bool(int(os.environ["CS"]))} if os.environ.get("CS") else {})))):
+                             ("lean", dict(layout="lean", slot_cap=min(cap, 343), **({"lean_cs": bool(int(os.environ["CS"]))} if os.environ.get("CS") else {}),
+                                           **({"lean_pm": bool(int(os.environ["PM"]))} if os.environ.get("PM") else {})))):
                 if os.environ.get("FORM", name) != name:
                     continue
                 if name == "sparse" and (cap > 64 or c not in (16, 32, 64)):
