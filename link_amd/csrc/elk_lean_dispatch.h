@@ -49,13 +49,15 @@ static unsigned lean_item_wgs(int idx_cap) {
   return (unsigned)((w + 3) & ~(int64_t)3);
 }
 
-// which path: the form without the scratch matrix X (launch 1 = slot insert alone, pre_mix inside launch 2) for C <= 64 on frames
-// big enough that writing and re-reading X costs more than a second pass over the weights (link_elk_desc_t::flags can force
-// either: LINK_ELK_LEAN_PM / LINK_ELK_LEAN_NO_PM)
+// The form without the scratch matrix X (launch 1 = slot insert alone, pre_mix inside launch 2; C <= 64) is selected by
+// link_elk_desc_t::flags only (LINK_ELK_LEAN_PM).  Measured on the LiDAR stage frames (tools/lean_pm_ab.sh, one box): with the
+// lists reused it is 4-5 us faster on the cos frames (28.9 against 33.8 us at 31k voxels, C = 64), rebuilt it ties there (its
+// insert-only launch costs what the X round trip saves), and on the cos_x C = 64 frames it loses 13-30 us: every chunk of ~5
+// voxels pays a whole 16-voxel tile of matrix instructions and W reads at two waves per SIMD.
 static bool lean_use_pm(const link_elk_desc_t &d, int64_t n) {
   if (d.c > 64 || (d.flags & LINK_ELK_LEAN_NO_PM)) return false;
   if (d.flags & LINK_ELK_LEAN_PM) return true;
-  return false;      // (by frame size once measured: LEAN_PM_MIN_VOXELS)
+  return false;
 }
 
 template <int C, int OP, int NB>

@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) k_lean_insert_premix_cs(const lean_args a
 }
 
 // ---------------------------------------------------------------------------------------------
-// The form WITHOUT the scratch matrix X (frames of many voxels, C <= 64): launch 1 is the slot insert alone, launch 2 gathers
+// The form WITHOUT the scratch matrix X (C <= 64; selected by flag -- elk_lean_dispatch.h says what it measured): launch 1 is the slot insert alone, launch 2 gathers
 // the chunk's feature rows in id order and runs pre_mix + LayerNorm + theta + modulate on them itself, summing the tile in the
 // accumulator layout (a DPP row holds the tile's 16 voxels) -- the n x P*C floats of X are neither written nor read (45 MB each
 // way on the 59k-voxel cos_x stage); cos_x leaves fin * theta of each voxel in an n x C matrix for launch 3.

@@ -201,14 +201,15 @@ def test_lean_form_batched_frames():
                                                         (16, 2, "cos", 1, 7, 3), (32, 1, "cos_x", 2, 4, 3)])
 def test_lean_form_without_the_scratch_matrix(C, groups, baseop, stride, s, r):
     """The form whose first launch is the slot insert alone and whose second launch runs pre_mix on the gathered rows of each
-    chunk (no n x P*C matrix in between; what frames above 16k voxels take at C <= 64), forced on a small and a bigger frame:
+    chunk (no n x P*C matrix in between; selected by link_elk_desc_t::flags / ElkCorePlan(lean_pm=True)), on a small and a bigger frame:
     oracle, the form with the matrix (same sums in another association), bitwise repeatable rebuilt / reused, fp16 rows."""
     import link_amd as la
     from link_amd.index import coords_bounds
     blk, params = _block(la, C, groups, baseop, 3 * C + r)
     cap = min((s // stride) ** 3, 343)
     for seed, npts in ((5, 40000), (6, 5000)):
-        coords = torch.from_numpy(lidar_like(npts, seed=seed, stride=stride, voxel=0.2 if C == 16 else 0.05))
+        # (stride-1 coordinates with 7^3 blocks: a coarser voxel grid, so that the tables addressed by cell stay small)
+        coords = torch.from_numpy(lidar_like(npts, seed=seed, stride=stride, voxel=0.2 if (C == 16 or stride == 1) else 0.05))
         n = coords.shape[0]
         feats = torch.randn(n, C, generator=torch.Generator().manual_seed(seed))
         div = float(stride) if baseop == "cos_x" else 1.0
