@@ -709,7 +709,10 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_sums(const lean_args a) {
 // launch 3: neighbour sum + de-modulate + LayerNorm
 // ---------------------------------------------------------------------------------------------
 template <int C, int OP, int R>
-__global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a) {
+#ifndef LEAN_GATHER_WAVES
+#define LEAN_GATHER_WAVES 1          /* minimum waves per SIMD the gather kernel is compiled for (registers <= 512 / that) */
+#endif
+__global__ void __launch_bounds__(64 * LEAN_IW, LEAN_GATHER_WAVES) k_lean_gather(const lean_args a) {
   constexpr int P = op_parts<OP>::value, W = P * C, LPR = C / 4, G = 64 / LPR, R3 = R * R * R;
   constexpr int LO = -((R + 1) / 2) + 1;               // nn/utils/kernel.py:21
   constexpr int MAXROWS = R3 * ((LEAN_KMAX + LEAN_CH - 1) / LEAN_CH);
@@ -725,6 +728,7 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
     a.hdr[LINK_HDR_STATUS_ACC] = 0;
     a.hdr[LINK_HDR_NVALID] = a.n;
   }
+  LEAN_TICK(tg0);
   const int j0 = blockIdx.x * LEAN_IW + wave;
   const int sg = j0 & (LEAN_SEGS - 1);
   const int nitem = (int)a.ctrl[sg * 16];
@@ -732,19 +736,39 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
   int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;
   const int step = (int)(gridDim.x * LEAN_IW) >> 4;
   const int ch0 = 4 * li;
-  float w0[4], w1[4], w2[4], al[4];
-#pragma unroll
-  for (int e_ = 0; e_ < 4; e_++) {
-    const int tc = (ch0 + e_) % a.cg;
-    w0[e_] = a.w_pos[3 * tc + 0]; w1[e_] = a.w_pos[3 * tc + 1]; w2[e_] = a.w_pos[3 * tc + 2];
-    al[e_] = a.alpha ? a.alpha[tc] : 1.0f;
+  // The grid is sized by the voxel count (the item count lives on the device), so most waves find no item -- 50-90 % on the
+  // LiDAR stage frames -- and what a wave does before it knows is paid by all of them.  One thread per channel fetches the
+  // channel's six theta / LayerNorm values (6 loads per workgroup instead of 18 gathers per wave), a workgroup without an item
+  // leaves at the first barrier, the others pass the values through LDS.  (Measured: no change in the launch's duration -- with
+  // the per-voxel loop removed it drops from 18.4 to 10.8 us on the 150k-voxel stage, with only the loop's stores removed it
+  // stays at 17.5: what the loop costs is its registers -- 108-134 per lane, four waves per SIMD, so 8k items run as two rounds
+  // of a ~8 us dependency chain -- not its arithmetic, its stores or these fetches.)
+  __shared__ __attribute__((aligned(16))) float par_lds[6 * C];        // ln weight | ln bias | w0 | w1 | w2 | alpha, by channel
+  float pv_[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 1.0f};
+  if (tid < C) {
+    const int tc = tid % a.cg;
+    pv_[0] = a.ln_w[tid]; pv_[1] = a.ln_b[tid];
+    pv_[2] = a.w_pos[3 * tc + 0]; pv_[3] = a.w_pos[3 * tc + 1]; pv_[4] = a.w_pos[3 * tc + 2];
+    if (a.alpha) pv_[5] = a.alpha[tc];
   }
-  const float4 gw = *reinterpret_cast<const float4 *>(&a.ln_w[ch0]), gb = *reinterpret_cast<const float4 *>(&a.ln_b[ch0]);
+  if (!__syncthreads_or(idx < nitem)) return;
+  if (tid < C) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) par_lds[q * C + tid] = pv_[q];
+  }
+  __syncthreads();
+  const float4 gw = *reinterpret_cast<const float4 *>(&par_lds[ch0]), gb = *reinterpret_cast<const float4 *>(&par_lds[C + ch0]);
+  const float4 p0 = *reinterpret_cast<const float4 *>(&par_lds[2 * C + ch0]), p1 = *reinterpret_cast<const float4 *>(&par_lds[3 * C + ch0]);
+  const float4 p2 = *reinterpret_cast<const float4 *>(&par_lds[4 * C + ch0]), p3 = *reinterpret_cast<const float4 *>(&par_lds[5 * C + ch0]);
+  const float w0[4] = {p0.x, p0.y, p0.z, p0.w}, w1[4] = {p1.x, p1.y, p1.z, p1.w};
+  const float w2[4] = {p2.x, p2.y, p2.z, p2.w}, al[4] = {p3.x, p3.y, p3.z, p3.w};
   int *rows = rows_lds[wave];
   const int d0 = a.g.dim[0], d1 = a.g.dim[1], d2 = a.g.dim[2], d3 = a.g.dim[3];
   for (; idx < nitem; idx += step) {
     const int it = it_n;
     if (idx + step < nitem) it_n = a.occ[(int64_t)sg * a.seg_cap + idx + step];
+    LEAN_WAITALL();
+    LEAN_TICK(tg1);
     const int64_t slot = (int64_t)sg * a.seg_cap + idx;
     const int cell = it >> 4, chunk = it & 15;
     const int lo = chunk * LEAN_CH;
@@ -789,6 +813,8 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
         }
       }
     }
+    LEAN_WAITALL();
+    LEAN_TICK(tg2);
     // neighbours of more than 32 voxels: their further chunk rows, in (neighbour, chunk) order
     const int nrow = (cn + LEAN_CH - 1) / LEAN_CH;
     const int nx = nrow > 1 ? nrow - 1 : 0;
@@ -827,6 +853,8 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
       }
       __builtin_amdgcn_wave_barrier();
     }
+    LEAN_WAITALL();
+    LEAN_TICK(tg3);
     const int nc = cn_own < a.k ? cn_own : a.k;
     const int nch = nc - lo < LEAN_CH ? nc - lo : LEAN_CH;
     float A[P][4];
@@ -839,6 +867,10 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
       }
       A[pp][0] = acc[pp].x / den; A[pp][1] = acc[pp].y / den; A[pp][2] = acc[pp].z / den; A[pp][3] = acc[pp].w / den;   // utils.py:80
     }
+#ifdef LEAN_DBG
+    asm volatile("s_nop 0" ::"v"(A[0][0]), "v"(A[P - 1][3]));
+#endif
+    LEAN_TICK(tg4);
     // ---- the chunk's voxels, G at a time: the record of voxel m sits in lane m ----
     const int steps = (nch + G - 1) / G;
     float4 xl_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -846,6 +878,8 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
       const int id0 = __shfl(myrec.w, grp < nch ? grp : 0, 64);
       xl_n = *reinterpret_cast<const float4 *>(a.X + (int64_t)id0 * a.xl_stride + a.xl_off + ch0);
     }
+    LEAN_WAITALL();
+    LEAN_TICK(tg4b);
     for (int mi = 0; mi < steps; mi++) {
       const int m = mi * G + grp;
       const bool ok = m < nch;
@@ -900,6 +934,18 @@ __global__ void __launch_bounds__(64 * LEAN_IW) k_lean_gather(const lean_args a)
         io_st4_ptr(a.out, (int64_t)id * C + ch0, o);
       }
     }
+#ifdef LEAN_DBG
+    {
+      LEAN_TICK(tg4c);
+      LEAN_WAITALL();
+      LEAN_TICK(tg5);
+      if (lane == 0) {
+        atomicAdd(&a.hdr[24], (int)((tg1 - tg0) >> 8)); atomicAdd(&a.hdr[25], (int)((tg2 - tg1) >> 8)); atomicAdd(&a.hdr[26], (int)((tg3 - tg2) >> 8));
+        atomicAdd(&a.hdr[27], (int)((tg4 - tg3) >> 8)); atomicAdd(&a.hdr[28], (int)((tg4b - tg4) >> 8)); atomicAdd(&a.hdr[30], (int)((tg4c - tg4b) >> 8));
+        atomicAdd(&a.hdr[31], (int)((tg5 - tg4c) >> 8)); atomicAdd(&a.hdr[32], steps); atomicAdd(&a.hdr[29], 1);
+      }
+    }
+#endif
   }
 }
 

@@ -21,9 +21,12 @@ for k, (cfg, r) in enumerate(stages(dev)):
         plan.run(feats, coords)
     torch.cuda.synchronize()
     plan.hdr[16:].zero_()
-    for _ in range(50):
+    for _ in range(10):
         plan.run(feats, coords)
     torch.cuda.synchronize()
     h = plan.hdr.tolist()
     cnt = max(h[20], 1)
-    print(k, n, c, "wgs/launch", cnt / 50, "ticks per wg: loads %.0f mfma %.0f ln %.0f trig+stores %.0f" % tuple(16 * h[16 + j] / cnt for j in range(4)))
+    print(k, n, c, "wgs/launch", cnt / 10, "ticks per wg: loads %.0f mfma %.0f ln %.0f trig+stores %.0f" % tuple(16 * h[16 + j] / cnt for j in range(4)))
+    ci = max(h[29], 1)
+    print("   gather: items/launch", ci / 10, "ticks per item: item fetch %.0f | records + counts + first rows %.0f | further rows %.0f | A %.0f | xl wait %.0f | voxel loop %.0f | store wait %.0f | steps %.2f"
+          % (tuple(256 * h[j] / ci for j in (24, 25, 26, 27, 28, 30, 31)) + (h[32] / ci,)))
