@@ -60,6 +60,29 @@ __device__ __forceinline__ void dc_index_stats_flush(int32_t *stats, int n_in, i
   }
 }
 
+// Largest |coordinate| (after the optional division) a voxel INSIDE the plan's bounds can have, per axis: the grid covers
+// blocks lo .. lo + dim - 1 of edge s, and a voxel outside it never reaches the fused kernels (the slot insert drops it and
+// raises status bit 0).  With the theta weights this bounds |theta| for the whole launch, so "does any argument leave the fast
+// sincos range" is decided ONCE per kernel from (grid, weights) instead of per tile / per plane round from the thetas
+// (DC_THETA_BOUND; round 5: 8 compares + a vote less per round -- and, unlike the vote, independent of what the records hold).
+#ifndef DC_THETA_BOUND
+#define DC_THETA_BOUND 1
+#endif
+__device__ __forceinline__ void dc_coord_absmax(const link_dc_grid_t &g, float coord_div, float &ax, float &ay, float &az) {
+  float a[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float lo = (float)g.lo[k] * (float)g.s, hi = ((float)g.lo[k] + (float)g.dim[k]) * (float)g.s;
+    a[k] = fmaxf(fabsf(lo), fabsf(hi)) / coord_div;
+  }
+  ax = a[0]; ay = a[1]; az = a[2];
+}
+// |theta| bound of one channel (1 % slack for the roundings of the bound itself); NaN / inf weights give "not small"
+__device__ __forceinline__ bool dc_theta_leaves_fast_range(float ax, float ay, float az, float w0, float w1, float w2, float alpha) {
+  const float b = (fabsf(w0) * ax + fabsf(w1) * ay + fabsf(w2) * az) * fabsf(alpha) * 1.01f;
+  return !(b < 32768.0f);
+}
+
 __device__ __forceinline__ int dc_cell(const link_dc_grid_t &g, int ux, int uy, int uz, int ub) {
   return ((ub * g.pdim[0] + ux + 1) * g.pdim[1] + uy + 1) * g.pdim[2] + uz + 1;
 }

@@ -40,6 +40,27 @@ using namespace link;
 #ifndef DC_K1_SUMB
 #define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
 #endif
+#ifndef DC_K1_SWAP_SUMS
+#define DC_K1_SWAP_SUMS 1  /* LayerNorm statistics over a voxel's four lane groups through v_permlane32_swap / v_permlane16_swap (VALU) instead
+                              of two ds_bpermute each: four dependent LDS round trips per tile leave the wave's chain (round 5) */
+#endif
+// v + v[lane ^ 16] + v[lane ^ 32] + v[lane ^ 48]
+__device__ __forceinline__ float dc_k1_sum_groups(float v) {
+#if DC_K1_SWAP_SUMS
+  // (inline asm: hipcc 7.2 returns the first result of the permlane swap builtins for both elements -- tile_common.h)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a += b;
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+#else
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+#endif
+}
+
 template <int C, int OP>
 struct dc_k1_cfg {
   static constexpr int T = C / 16;
@@ -182,6 +203,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     nv_f = (int)csrc[pc_f];
   }
   bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
+  bool th_big = false;
   {                                                    // stage W and the LayerNorm parameters
     // all loads first, ONE wait, then the LDS writes -- no predicate around the writes (hipcc turns a
     // predicated write into load / wait / write per iteration: four dependent round trips at C = 64)
@@ -216,8 +238,14 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     else if (tid < 2 * C) ln_lds[tid] = ln_b[tid - C];
     if (tid < C) {                                     // theta weights of channel tid (channel ch uses theta[ch % cg])
       const int tc = tid % cg;
-      pw_lds[tid] = w_pos[3 * tc + 0]; pw_lds[C + tid] = w_pos[3 * tc + 1]; pw_lds[2 * C + tid] = w_pos[3 * tc + 2];
-      pw_lds[3 * C + tid] = alpha ? alpha[tc] : 1.0f;
+      const float q0 = w_pos[3 * tc + 0], q1 = w_pos[3 * tc + 1], q2 = w_pos[3 * tc + 2], qa = alpha ? alpha[tc] : 1.0f;
+      pw_lds[tid] = q0; pw_lds[C + tid] = q1; pw_lds[2 * C + tid] = q2;
+      pw_lds[3 * C + tid] = qa;
+      if (DC_THETA_BOUND) {                            // can any theta of this launch leave the fast sincos range? (dense_common.h)
+        float ax, ay, az;
+        dc_coord_absmax(g, coord_div, ax, ay, az);
+        th_big = dc_theta_leaves_fast_range(ax, ay, az, q0, q1, q2, qa);
+      }
     }
   }
   if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
@@ -225,6 +253,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
   w_big = DC_K1_SPLIT ? __syncthreads_or(w_big) != 0 : (__syncthreads(), false);
+  const bool th_slow = DC_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;     // workgroup-uniform (the same in every workgroup)
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
   if (c_begin >= c_end) return;
   const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * K::RB));
@@ -456,10 +485,12 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
           const float4 qa = *reinterpret_cast<const float4 *>(&pw_lds[3 * C + 16 * tb + 4 * gq]);
           th[tb][0] = theta_of(x, y, z, q0.x, q1.x, q2.x, qa.x); th[tb][1] = theta_of(x, y, z, q0.y, q1.y, q2.y, qa.y);
           th[tb][2] = theta_of(x, y, z, q0.z, q1.z, q2.z, qa.z); th[tb][3] = theta_of(x, y, z, q0.w, q1.w, q2.w, qa.w);
+          if (!DC_THETA_BOUND) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) big |= !(fabsf(th[tb][r]) < 32768.0f);
+            for (int r = 0; r < 4; r++) big |= !(fabsf(th[tb][r]) < 32768.0f);
+          }
         }
-        const bool slow = __any(big);
+        const bool slow = DC_THETA_BOUND ? th_slow : __any(big);
         const bool more = PIPE && t + 1 < ntile;
         (void)recn;
         auto body = [&](auto more_tag, auto slow_tag) {
@@ -479,8 +510,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
           float s = 0.f;
 #pragma unroll
           for (int tp = 0; tp < T; tp++) s += (ac[tp][0] + ac[tp][1]) + (ac[tp][2] + ac[tp][3]);
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
+          s = dc_k1_sum_groups(s);
           const float mean = s * (1.0f / C);
           float qq = 0.f;
 #pragma unroll
@@ -490,8 +520,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
               const float d = ac[tp][r] - mean;
               qq += d * d;
             }
-          qq += __shfl_xor(qq, 16, 64);
-          qq += __shfl_xor(qq, 32, 64);
+          qq = dc_k1_sum_groups(qq);
           const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
 #pragma unroll
           for (int tp = 0; tp < T; tp++) {

@@ -45,6 +45,16 @@
                               matrix pipe's time, 4 x what the adds would take on the VALU, ends up on the wave's critical path:
                               2.8 k ticks per tile measured) instead of the fp16 hi/lo split on v_mfma_f32_16x16x16_f16 */
 #endif
+#ifndef DC_K1M_THETA_BOUND
+#define DC_K1M_THETA_BOUND 0   /* the launch-wide |theta| bound of dense_common.h instead of the per-tile vote: in THIS kernel it costs more
+                                  than it saves -- the flag lives across the whole tile loop of a kernel that sits exactly at its 128-register
+                                  budget, and hipcc spilled 16 more registers (scratch 16 -> 80 B; 23.6 -> 27.4 us, round 5 A/B) */
+#endif
+#ifndef DC_K1M_ROWSUM_ASM
+#define DC_K1M_ROWSUM_ASM 1    /* LayerNorm statistics: the four voxels' sums over a DPP row as 16 v_add_f32_dpp (four interleaved chains, so
+                                  the DPP read-after-write hazard is covered by the other chains' instructions) -- hipcc emits v_mov_b32_dpp +
+                                  v_pk_add_f32 pairs for the builtin form: 32 instructions more per tile */
+#endif
 #ifndef DC_K1M_LCAP
 #define DC_K1M_LCAP 352    /* voxel records of one chunk of cells kept in LDS (>= 7^3: a whole cell) */
 #endif
@@ -56,6 +66,25 @@ __device__ __forceinline__ void dc_ld_row_pieces(__amdgpu_buffer_rsrc_t r, uint3
     ff[TT] = io_ldb4<16 * TT>(r, ro);
     dc_ld_row_pieces<TT + 1, T>(r, ro, ff);
   }
+}
+
+// sums of four values over the 16 lanes of their DPP rows (every lane gets its row's total): xor 1, xor 2, half mirror, mirror
+__device__ __forceinline__ void dc_row16_sum4(float &a, float &b, float &c, float &d) {
+#if DC_K1M_ROWSUM_ASM
+#define DC_RS4_(CTRL)                                                              \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+  // s_nop 1: a VALU write of an operand right in front of the block -> DPP read (hipcc does not look inside asm); inside the
+  // block a value is read again three instructions after it was written
+  asm("s_nop 1\n\t" DC_RS4_("quad_perm:[1,0,3,2]") DC_RS4_("quad_perm:[2,3,0,1]") DC_RS4_("row_half_mirror") DC_RS4_("row_mirror")
+      "s_nop 1"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DC_RS4_
+#else
+  a = grp_sum<16>(a); b = grp_sum<16>(b); c = grp_sum<16>(c); d = grp_sum<16>(d);
+#endif
 }
 
 template <int C, int OP, bool SPARSE = false>
@@ -134,6 +163,7 @@ __device__ __forceinline__ void dc_k1m_body(
   };
   if (c_begin < c_end) request_chunk(c_begin);
   bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
+  bool th_big = false;
   {
     // W image: the float4 W[co][4p .. 4p+3] is piece g = p % 4 of 16-channel block tt = p / 4; its hi / lo halves go to
     // plane [kb = tt / 2][hi | lo][g] at row co, bytes 8 * (tt % 2): a lane's B operand of v_mfma_f32_16x16x32_f16 for
@@ -165,14 +195,20 @@ __device__ __forceinline__ void dc_k1m_body(
     reinterpret_cast<float *>(smem_raw + K::LNW_OFF)[li * T + cb] = ln_w[tid];
     reinterpret_cast<float *>(smem_raw + K::LNB_OFF)[li * T + cb] = ln_b[tid];
     const int tc = tid % cg;                           // channel ch uses theta[ch % cg]; block tb < NB holds channels 16 tb + li
-    reinterpret_cast<float4 *>(smem_raw + K::PW_OFF)[li * T + cb] =
-        make_float4(w_pos[3 * tc + 0], w_pos[3 * tc + 1], w_pos[3 * tc + 2], alpha ? alpha[tc] : 1.0f);
+    const float4 pwv = make_float4(w_pos[3 * tc + 0], w_pos[3 * tc + 1], w_pos[3 * tc + 2], alpha ? alpha[tc] : 1.0f);
+    reinterpret_cast<float4 *>(smem_raw + K::PW_OFF)[li * T + cb] = pwv;
+    if (DC_K1M_THETA_BOUND) {                          // can any theta of this launch leave the fast sincos range? (dense_common.h)
+      float ax, ay, az;
+      dc_coord_absmax(g, coord_div, ax, ay, az);
+      th_big = dc_theta_leaves_fast_range(ax, ay, az, pwv.x, pwv.y, pwv.z, pwv.w);
+    }
   }
   if (bid == 0 && tid == 0 && !warm) {                 // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
   w_big = __syncthreads_or(w_big) != 0;
+  const bool th_slow = DC_K1M_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;  // workgroup-uniform (the same in every workgroup)
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
   if (c_begin >= c_end) return;
   const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * RB));
@@ -328,7 +364,7 @@ __device__ __forceinline__ void dc_k1m_body(
 #pragma unroll
           for (int tb = 0; tb < NB; tb++) {
             th[tb][j] = theta_of(x, y, z, pw[tb].x, pw[tb].y, pw[tb].z, pw[tb].w);
-            mx = fmaxf(mx, fabsf(th[tb][j]));
+            if (!DC_K1M_THETA_BOUND) mx = fmaxf(mx, fabsf(th[tb][j]));
           }
         }
         big = !(mx < 32768.0f);                         // (an infinite theta survives v_max; a NaN gives NaN on either path)
@@ -412,7 +448,7 @@ __device__ __forceinline__ void dc_k1m_body(
       __builtin_amdgcn_sched_barrier(0);
 #endif
       if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_mm += tqb - tqt; tqt = tqb; }
-      const bool slow = __any(big);
+      const bool slow = DC_K1M_THETA_BOUND ? th_slow : __any(big);
       float sn[NB][4], cs[NB][4];
       if (__builtin_expect(slow, 0)) {
 #pragma unroll
@@ -441,21 +477,29 @@ __device__ __forceinline__ void dc_k1m_body(
             lnb[cb] = reinterpret_cast<const float *>(smem_raw + K::LNB_OFF)[l16 * T + cb];
           }
         }
+        float s4[4], q4[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          float s = 0.f;
+          s4[j] = 0.f;
 #pragma unroll
-          for (int cb = 0; cb < T; cb++) s += acc[cb][j];
-          s = grp_sum<16>(s);
-          const float mean = s * inv_c;
-          float qq = 0.f;
+          for (int cb = 0; cb < T; cb++) s4[j] += acc[cb][j];
+        }
+        dc_row16_sum4(s4[0], s4[1], s4[2], s4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float mean = s4[j] * inv_c;
+          q4[j] = 0.f;
 #pragma unroll
           for (int cb = 0; cb < T; cb++) {
             const float d = acc[cb][j] - mean;
             acc[cb][j] = d;
-            qq = fmaf(d, d, qq);
+            q4[j] = fmaf(d, d, q4[j]);
           }
-          qq = grp_sum<16>(qq);
+        }
+        dc_row16_sum4(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float qq = q4[j];
           const float rstd = __builtin_amdgcn_rsqf(fmaf(qq, inv_c, eps));
           bool bj = !(qq < __builtin_inff());
           if (slow) {

@@ -45,6 +45,12 @@
                             map in their loop the producers spilled, and scratch traffic would break their counted vmcnt waits.
                             (0 = round-3 consumers) */
 #endif
+#ifndef DC_K2Q_EARLY
+#define DC_K2Q_EARLY 1   /* a consumer wave whose 16 voxel slots all lie beyond the plane's voxel count leaves the round at once (wave-uniform):
+                            an interior cfg2 plane holds ~32 voxels, so the third wave is needed by 43 % of the planes only, and the
+                            tiles on the grid's rim (1 of 4 columns inside) keep one wave busy -- before, every consumer wave issued
+                            the whole round for slots without a voxel (round 5: -19 % of the kernel's VALU instructions) */
+#endif
 #ifndef DC_K2Q_FMA
 #define DC_K2Q_FMA 1     /* de-modulation A0 cos + A1 sin as mul + fma (0: separate IEEE mul / mul / add like the reference's eager
                             ops -- the difference is one rounding, 6e-8 relative, next to the hardware trig's 4e-7) */
@@ -411,6 +417,17 @@ __device__ __forceinline__ void dc_k2q_body(
       w0[j][e] = w_pos[3 * tc + 0]; w1[j][e] = w_pos[3 * tc + 1]; w2[j][e] = w_pos[3 * tc + 2];
     }
   const uint32_t par = lds_base + (uint32_t)KQ::PAR_OFF + (uint32_t)(q * 16);
+  bool slow_k = false;                                 // wave-uniform, the same in every wave: some |theta| may leave the fast range
+  if (DC_THETA_BOUND) {
+    float ax, ay, az;
+    dc_coord_absmax(g, DIV ? coord_div : 1.0f, ax, ay, az);
+    bool b_ = false;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) b_ |= dc_theta_leaves_fast_range(ax, ay, az, w0[j][e], w1[j][e], w2[j][e], 1.0f);
+    slow_k = __any(b_);
+  }
   for (int i = 0; i <= nplanes; i++) {
     unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_barrier" ::: "memory");
@@ -445,6 +462,7 @@ __device__ __forceinline__ void dc_k2q_body(
       Tv = e_[15];
     }
     for (int base = 0; base < Tv; base += SLOTS) {      // wave-uniform: one pass unless the plane holds more than SLOTS voxels
+      if (DC_K2Q_EARLY && base + wave * 16 >= Tv) break;   // none of this wave's quads has a voxel (wave-uniform)
       if (dbg) tq_rounds++;
       const bool valid = base + qd < Tv;                // quads without a voxel take the plane's first one and store nothing
       int c, k;
@@ -499,7 +517,7 @@ __device__ __forceinline__ void dc_k2q_body(
         for (int e = 0; e < 4; e++) {
           th[j][e] = fmaf(z, w2[j][e], fmaf(y, w1[j][e], x * w0[j][e]));      // theta_of without the scale
         }
-      {                                                 // range of the fast sincos: ONE compare on the largest magnitude (an
+      if (!DC_THETA_BOUND) {                            // range of the fast sincos: ONE compare on the largest magnitude (an
         float mx = fmaxf(fmaxf(fabsf(th[0][0]), fabsf(th[0][1])), fabsf(th[0][2]));   // infinity survives v_max; a NaN theta gives
         mx = fmaxf(fmaxf(mx, fabsf(th[0][3])), fabsf(th[1][0]));                       // NaN on either path)
         mx = fmaxf(fmaxf(mx, fabsf(th[1][1])), fabsf(th[1][2]));
@@ -507,7 +525,7 @@ __device__ __forceinline__ void dc_k2q_body(
         big = valid && !(mx < 32768.0f);                // (a quad without a voxel may hold the stale record of an empty cell: it
                                                         // must not pick the wave's path, or results depend on the previous frame)
       }
-      if (__builtin_expect(__any(big), 0)) {
+      if (__builtin_expect(DC_THETA_BOUND ? slow_k : __any(big), 0)) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll

@@ -85,11 +85,31 @@ __device__ __forceinline__ void io_st4_ptr(void *base, int64_t elem, float4 v) {
 // ---------------------------------------------------------------------------------------------
 // x = hi + lo, hi = fp16(x) (round to nearest), lo = fp16(x - hi): four values -> two packed operands
 typedef _Float16 dc_h4v __attribute__((ext_vector_type(4)));
+#ifndef DC_SPLIT_ASM
+#define DC_SPLIT_ASM 1   /* round 5: the split as THREE instructions per pair of values -- v_cvt_pk_f16_f32 (both hi), then
+                            v_fma_mixlo_f16 / v_fma_mixhi_f16 forming lo = fp16(x - hi) straight from the packed hi (the mix
+                            instructions read an fp16 half as an fp32 operand: (-1) * hi + x is exact, ONE rounding to fp16 --
+                            the same bits as fp16(fp32(x - hi)), since x - hi is exactly representable).  hipcc's own code for the
+                            C++ below is 52 VALU instructions per 16 values (unpacking conversions, scalar subtractions, 8
+                            conversions done twice); this is 24.  0 = the C++ form */
+#endif
+__device__ __forceinline__ void dc_split2(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+  asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(x0), "v"(x1));
+}
 __device__ __forceinline__ void dc_split4(const float4 &v, uint2 &hi, uint2 &lo) {
+#if DC_SPLIT_ASM
+  dc_split2(v.x, v.y, hi.x, lo.x);
+  dc_split2(v.z, v.w, hi.y, lo.y);
+#else
   const dc_h4v h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
   const dc_h4v l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z), (_Float16)(v.w - (float)h.w)};
   hi = __builtin_bit_cast(uint2, h);
   lo = __builtin_bit_cast(uint2, l);
+#endif
 }
 __device__ __forceinline__ floatx4 dc_mfma_f16(uint2 a, uint2 b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(dc_h4v, a), __builtin_bit_cast(dc_h4v, b), c, 0, 0, 0);

@@ -106,7 +106,20 @@ __device__ __forceinline__ void sincos_small(float x, float &sn, float &cs) {
 // multiply by 1/(2 pi) and the two transcendental ops: 8 instructions instead of ~25.  Not the libm rounding:
 // max abs error ~3e-7 for |theta| < 3e4 (tools/sintest2.hip), three orders below the 1e-4 relative bar of the
 // path; only the dense-cell kernels may use it (-DLINK_HW_TRIG=1), same range contract as sincos_small.
+#ifndef LINK_HW_TRIG_REV
+#define LINK_HW_TRIG_REV 1  /* round 5: the reduction is done in REVOLUTIONS, where the hardware wants its argument: k = rint(x / 2pi),
+                               f = fma(x, hi, -k) (the product is exact inside the fma, so this is x * hi - k rounded once: |f| <= 1/2,
+                               error <= 2^-26 turns), f += x * lo with hi + lo = 1 / 2pi to 2^-52 -- 4 instructions in front of
+                               v_sin / v_cos instead of 6, the same 3e-8-turn accuracy for |x| < 2^15 (0: the round-3 form) */
+#endif
 __device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs) {
+#if LINK_HW_TRIG_REV
+  const float k = rintf(x * 0x1.45f306p-3f);
+  float f = fmaf(x, 0x1.45f306p-3f, -k);
+  f = fmaf(x, 0x1.b9391p-28f, f);
+  sn = __builtin_amdgcn_sinf(f);
+  cs = __builtin_amdgcn_cosf(f);
+#else
   const float k = rintf(x * 0.15915494309189535f);
   float r = fmaf(-k, 6.28125f, x);
   r = fmaf(-k, 0x1.fb4p-10f, r);
@@ -114,6 +127,7 @@ __device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs) {
   const float t = r * 0.15915494309189535f;
   sn = __builtin_amdgcn_sinf(t);
   cs = __builtin_amdgcn_cosf(t);
+#endif
 }
 
 template <int LPR>

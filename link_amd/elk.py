@@ -190,6 +190,9 @@ class ElkCorePlan:
             raise ValueError(f"layout must be auto|dense|general|sparse|lean, got {layout!r}")
         self.lean = False
         if layout == "lean":
+            if self._tuning:                             # the lean form has no per-plan launch geometry: say so instead of ignoring it
+                raise L.LinkAmdError(f"ElkCorePlan(layout='lean'): unknown keyword(s) {sorted(self._tuning)} "
+                                     "(it takes lean_cs / lean_pm; launch geometry belongs to the dense-cell layout)")
             self._init_lean(int(slot_cap))
             return
         try:
@@ -351,16 +354,17 @@ class ElkCorePlan:
         self.m_cap = n_cap
 
     def _run_lean(self, n: int, build_index: bool, st) -> int:
-        if build_index:
-            self._cur ^= 1
-        cur, b = self._cur, self.buf
+        cur, b = (self._cur ^ 1 if build_index else self._cur), self.buf
         b.cnt, b.cnt_prev = self.cnt2[cur].data_ptr(), self.cnt2[cur ^ 1].data_ptr()
         b.occ, b.occ_prev = self.occ2[cur].data_ptr(), self.occ2[cur ^ 1].data_ptr()
         b.ctrl, b.ctrl_prev = self.ctrl2[cur].data_ptr(), self.ctrl2[cur ^ 1].data_ptr()
         rc = L.lib().link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(self.grid), ctypes.byref(self.desc), n,
                                                 int(self._n_prev) if build_index else 0, int(bool(build_index)), st)
-        if build_index:
-            self._n_prev = n
+        if build_index and rc == 0:
+            # the alternating counters / marks advance only with a step that was actually launched: a call the library refused
+            # (LINK_ERR_ARG: nothing ran) must leave "current" pointing at the last frame that was really indexed, or the next
+            # insert would count on top of that frame's counters with nothing scheduled to clean them
+            self._cur, self._n_prev = cur, n
         return rc
 
     def set_tuning(self, **kw):
@@ -378,7 +382,7 @@ class ElkCorePlan:
         multi = self.frames_in_flight > 1
         t.k1_wgs, t.k2_zsplit = (256, 2) if multi else (512, 0)
         t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = t.k1_pipe = 0
-        if not multi and self.c in (32, 64) and self.baseop != "cos_x" and "k1_form" not in kw:
+        if not multi and not self.sparse and self.c in (32, 64) and self.baseop != "cos_x" and "k1_form" not in kw:
             # one frame alone: the matrix-core sums form at four waves per SIMD (4096 waves) -- 49.6-50.3 us per step against
             # 52.8-53.3 for the cell-range form (A/B on one box, round 4); with frames in flight the cell-range form at one
             # wave per SIMD leaves more of the CU to the other frames' kernels (35.9 against 37.9 us/frame)
@@ -478,14 +482,13 @@ class ElkCorePlan:
         if self.lean:
             rc = self._run_lean(n, build_index, st)
         elif self.dense and self.sparse:
-            if build_index:
-                self._occ_cur ^= 1
-            cur, prev = self.occ[self._occ_cur], self.occ[self._occ_cur ^ 1]
+            oc = self._occ_cur ^ 1 if build_index else self._occ_cur
+            cur, prev = self.occ[oc], self.occ[oc ^ 1]
             rc = L.lib().link_elk_core_sparse_forward(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
                                                       int(bool(build_index)), cur.data_ptr(), prev.data_ptr(),
                                                       int(self._n_prev) if build_index else 0, st)
-            if build_index:
-                self._n_prev = n
+            if build_index and rc == 0:                  # a refused call launched nothing: the marks stay where they were (_run_lean)
+                self._occ_cur, self._n_prev = oc, n
         elif self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n, int(build_index), st)
         else:
@@ -1135,18 +1138,23 @@ def _poll_pending_plans() -> None:
     """Look at the counts of every device-laid-out plan whose kernels have finished: a table handed over as submanifold that
     is not one (duplicate coordinates) raises HERE -- at the next plan, the next frame at the latest -- instead of only when
     somebody happens to ask the plan for its density."""
-    keep = []
+    keep, err = [], None
     waiting = False                                      # plans are issued in stream order: behind the first one whose kernels are
     for ref in _PENDING_PLANS:                           # still running nothing is asked (an event query is ~5 us of host time,
         plan = ref()                                     # and a frame with every map rebuilt makes tens of plans)
-        if plan is None or plan.exact or plan._density is not None:
+        if plan is None or plan.exact or plan._density is not None or plan._error is not None:
             continue
         if not waiting and plan._ev.query():
-            plan._arrived(False)                         # raises LinkAmdError on a bad table
+            try:
+                plan._arrived(False)                     # a bad table: the plan keeps the error (and raises it again whenever IT is
+            except L.LinkAmdError as e:                  # used) and leaves the list either way -- the verdict is reported from here
+                err = err or e                           # exactly once, never again by the plans of unrelated, valid tables
         else:
             waiting = True
             keep.append(ref)
     _PENDING_PLANS[:] = keep
+    if err is not None:
+        raise err
 _DENSITY_SEEN: Dict[int, float] = {}      # kernel volume -> pairs per row of the last plan whose counts reached the host
 _BBOX_STATS_INIT: Dict[torch.device, torch.Tensor] = {}   # (bbox init, zeroed occupancy counters) per device
 
@@ -1190,6 +1198,7 @@ class _PairPlan:
             self._init_async(nbr, bool(subm))
             return
         self.exact = True
+        self._error = None
         n, kvol = nbr.shape
         dev = nbr.device
         centre = kvol // 2
@@ -1255,6 +1264,7 @@ class _PairPlan:
         gran_cap = (cap_pairs + 127 * kvol + 127) // 128
         self.n, self.kvol, self.direct, self.exact = n, kvol, direct, False
         self.pairs, self.rows_pad, self._density = None, gran_cap * 128, None
+        self._error = None
         # one arena for everything the three kernels touch (count -> layout -> fill, one FFI call: link_pair_plan_build);
         # nothing in it needs initialising
         sizes = [nwg * (kvol + 1), n, kvol + nwg * kvol + kvol + 1, nwg, gran_cap, 8, n + 1, self.rows_pad, self.rows_pad,
@@ -1282,6 +1292,8 @@ class _PairPlan:
         _PENDING_PLANS.append(weakref.ref(self))
 
     def _arrived(self, wait: bool) -> bool:
+        if self._error is not None:                      # a plan whose table was bad stays bad: every use of it says so
+            raise self._error
         if self.exact or self._density is not None:
             return True
         if wait:
@@ -1291,9 +1303,11 @@ class _PairPlan:
         src = self._host if _pinned_current(self._slot, self._gen) else self._hdr      # slot reused since: read the device copy
         pairs, rows, gran, misses, over = [int(v) for v in src[:5].tolist()]
         if over or (self.direct and misses):
-            raise L.LinkAmdError("pair plan: the table handed over as submanifold is not one (duplicate coordinates? "
-                                 f"{misses} rows whose centre neighbour is not the row itself)" if misses else
-                                 "pair plan: granule capacity exceeded")
+            self._error = L.LinkAmdError(
+                (f"pair plan of a [{self.n}, {self.kvol}] neighbour table: the table handed over as submanifold is not one "
+                 f"(duplicate coordinates? {misses} rows whose centre neighbour is not the row itself)") if misses else
+                f"pair plan of a [{self.n}, {self.kvol}] neighbour table: granule capacity exceeded")
+            raise self._error
         self.pairs = pairs
         self._density = (pairs + (self.n if self.direct else 0)) / max(self.n, 1)
         self._exact_rows = rows
@@ -1744,7 +1758,46 @@ class _SubmConv(torch.autograd.Function):
 # modules
 # ------------------------------------------------------------------------------------------------
 DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take
-DENSE_PLAN_CACHE_BYTES = 4 << 30             # arenas a module keeps for its dense-cell plans (ElkCorePlan.arena_bytes)
+DENSE_PLAN_CACHE_BYTES = 4 << 30             # arenas the PROCESS keeps in its modules' plan caches, dense-cell and lean together
+                                             # (ElkCorePlan.arena_bytes; round 5: one budget instead of one per cache and module)
+LEAN_BOUNDS_PAD_BLOCKS = 4                   # lean plans are keyed by bounds padded to this many blocks: their tables are addressed by
+                                             # cell and touched only where voxels land, so the padding costs address space, not time --
+                                             # and the bounding box of a LiDAR stream moves by less than that from frame to frame
+
+
+class _PlanCache(dict):
+    """A module's cache of ElkCorePlan arenas (insertion order = age).  All caches of the process share ONE byte budget."""
+    __slots__ = ("__weakref__",)
+
+
+_PLAN_CACHES: list = []                      # weak references to every live _PlanCache
+
+
+def _plan_cache_of(module, name: str) -> "_PlanCache":
+    cache = module.__dict__.get(name)
+    if cache is None:
+        cache = module.__dict__[name] = _PlanCache()
+        _PLAN_CACHES.append(weakref.ref(cache))
+    return cache
+
+
+def _plan_cache_admit(cache: "_PlanCache", key, plan) -> None:
+    """Insert `plan` (or the None marker "no such plan for this key") and evict -- oldest first, this cache before the others --
+    until the arenas of all caches fit DENSE_PLAN_CACHE_BYTES and this cache holds at most 8 entries."""
+    live = [c for c in (r() for r in _PLAN_CACHES) if c is not None]
+    _PLAN_CACHES[:] = [weakref.ref(c) for c in live]
+    while len(cache) >= 8:
+        cache.pop(next(iter(cache)))
+    cache[key] = plan
+
+    def total():
+        return sum(p.arena_bytes() for c in live for p in c.values() if p is not None)
+    for c in [cache] + [c for c in live if c is not cache]:
+        while total() > DENSE_PLAN_CACHE_BYTES:
+            victim = next((k for k in c if not (c is cache and k == key)), None)
+            if victim is None:
+                break
+            c.pop(victim)
 
 
 class _ELKBase(nn.Module):
@@ -1800,7 +1853,7 @@ class _ELKBase(nn.Module):
             else:
                 from .index import coords_bounds
                 bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
-        cache = self.__dict__.setdefault("_dc_plans", {})
+        cache = _plan_cache_of(self, "_dc_plans")
         # plans are keyed by the bounds padded out to whole blocks (the grid they imply is the same): the exact extents of
         # real frames move from frame to frame, and every new key is a new arena (zero-filled tables, a slot arena of up
         # to 1 GiB) plus an occupancy probe.  Coarser padding would merge more frames but the gather kernel streams every
@@ -1818,11 +1871,8 @@ class _ELKBase(nn.Module):
                                        layout="dense")
                 except L.LinkAmdError:
                     plan = None
-            # arenas are large: the cache is capped by bytes (and by entries, for the None markers)
-            budget = DENSE_PLAN_CACHE_BYTES - (plan.arena_bytes() if plan is not None else 0)
-            while cache and (len(cache) >= 8 or sum(p.arena_bytes() for p in cache.values() if p is not None) > max(budget, 0)):
-                cache.pop(next(iter(cache)))
-            cache[key] = plan
+            # arenas are large: the caches are capped by bytes, process-wide (and by entries, for the None markers)
+            _plan_cache_admit(cache, key, plan)
         if spec is not None and spec[0] is not plan:
             spec[0]._unprobe()                                 # guessed the wrong grid: that plan forgets the frame
             spec = None
@@ -1873,12 +1923,19 @@ class _ELKBase(nn.Module):
         n, c = feats.shape
         if n == 0 or c not in (16, 32, 64, 128) or r not in (2, 3) or not feats.is_cuda or not LEAN_FORM:
             return None
+        self._lean_poll_verdicts()                            # an EARLIER frame that overflowed a slot list is reported here (raises)
         if st.kmaps.get(("link_block_index", coords.data_ptr(), n, int(s_eff))) is not None:
             return None                                       # an index of these coordinates exists: the two tile launches
         ts = st.s[0] if isinstance(st.s, (tuple, list)) else st.s
         ts = max(int(ts), 1)
         # coordinates of a tensor at stride ts are multiples of ts (torchsparse/nn/functional/downsample.py:27-40), so a block
-        # of edge s_eff holds at most (s_eff / ts)^3 of them; a frame that breaks the promise raises the plan's status word
+        # of edge s_eff holds at most (s_eff / ts)^3 of them.  A frame that breaks the promise (coordinates off the stride's
+        # lattice, duplicate coordinates) overflows a slot list: the kernel drops the surplus voxels and raises status bit 1.
+        # The status word of every step travels to pinned memory behind the kernels and is looked at on the next call (no
+        # sync on this path): the broken promise raises LinkAmdError there, this (s_eff, stride) pair goes to the general
+        # layout from then on, and the rows of dropped voxels are zeros, never uninitialised memory (`out` below).
+        if (int(s_eff), ts) in self.__dict__.get("_lean_distrust", ()):
+            return None
         k = (max(int(s_eff) // ts, 1)) ** 3 if int(s_eff) % ts == 0 else int(s_eff) ** 3
         n_cap = 1 << max(10, (n - 1).bit_length())
         if k > L.LEAN_KMAX or n * (3 if self.baseop == "cos_x" else 2) * c > ElkCorePlan.LEAN_AUTO_FLOATS:
@@ -1888,10 +1945,10 @@ class _ELKBase(nn.Module):
         if bounds is None:
             from .index import coords_bounds
             bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
-        q = int(s_eff)
+        q = int(s_eff) * LEAN_BOUNDS_PAD_BLOCKS
         qbounds = (tuple((int(v) // q) * q for v in bounds[0][:3]) + (int(bounds[0][3]),),
                    tuple((int(v) // q) * q + q - 1 for v in bounds[1][:3]) + (int(bounds[1][3]),))
-        cache = self.__dict__.setdefault("_lean_plans", {})
+        cache = _plan_cache_of(self, "_lean_plans")
         key = (feats.device, n_cap, c, self.baseop, cg, r, s_eff, qbounds, float(coord_div), k)
         plan = cache.get(key, False)
         if plan is False:
@@ -1902,10 +1959,7 @@ class _ELKBase(nn.Module):
                                        layout="lean", slot_cap=k)
                 except L.LinkAmdError:
                     plan = None
-            budget = DENSE_PLAN_CACHE_BYTES - (plan.arena_bytes() if plan is not None else 0)
-            while cache and (len(cache) >= 8 or sum(p.arena_bytes() for p in cache.values() if p is not None) > max(budget, 0)):
-                cache.pop(next(iter(cache)))
-            cache[key] = plan
+            _plan_cache_admit(cache, key, plan)
         if plan is None:
             return None
         plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
@@ -1914,12 +1968,41 @@ class _ELKBase(nn.Module):
         # a frame's rows do not depend on how often it was seen (rebuilt and reused lists give the same bits); the lists are
         # reused while the plan has seen nothing else in between
         ikey = (coords.data_ptr(), n, coords._version)
-        alloc = torch.zeros if st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)) else torch.empty
-        out = alloc((n, c), dtype=feats.dtype, device=feats.device)
-        plan.run(feats.contiguous(), coords.contiguous(), build_index=plan.__dict__.get("_indexed") != ikey, out=out)
+        out = torch.zeros((n, c), dtype=feats.dtype, device=feats.device)     # a dropped voxel's row is zero, not whatever was there
+        rebuild = plan.__dict__.get("_indexed") != ikey
+        plan.run(feats.contiguous(), coords.contiguous(), build_index=rebuild, out=out)
         plan._indexed = ikey
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
+        if rebuild:
+            self._lean_post_verdict(plan, int(s_eff), ts, k)
         return out
+
+    def _lean_post_verdict(self, plan, s_eff: int, ts: int, k: int) -> None:
+        """The status word of the step just issued goes to pinned memory behind its kernels (no sync); _lean_poll_verdicts looks."""
+        host, slot, gen = _pinned_slot()
+        host.copy_(plan.hdr[:8], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pend = self.__dict__.setdefault("_lean_pending", [])
+        pend.append((ev, host, slot, gen, s_eff, ts, k))
+        del pend[:-8]                                        # bounded: at most the last eight steps wait for a look
+
+    def _lean_poll_verdicts(self) -> None:
+        pend = self.__dict__.get("_lean_pending")
+        if not pend:
+            return
+        bad = None
+        while pend and pend[0][0].query():
+            ev, host, slot, gen, s_eff, ts, k = pend.pop(0)
+            if _pinned_current(slot, gen) and int(host[L.HDR_STATUS]) & 2:
+                bad = (s_eff, ts, k)
+                self.__dict__.setdefault("_lean_distrust", set()).add((s_eff, ts))
+        if bad is not None:
+            raise L.LinkAmdError(
+                f"{type(self).__name__}: an earlier frame held more than {bad[2]} voxels in a block of edge {bad[0]} at tensor stride "
+                f"{bad[1]} -- coordinates that are not multiples of the tensor stride, or duplicate coordinates (torchsparse's own "
+                "contract: tensor.py / downsample.py).  The surplus voxels of that frame were left out of the block sums and their "
+                "output rows are zero; blocks of this edge and stride take the general layout from here on.")
 
     def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         """R_core as the reference writes it (linkunet.py:124-176), op by op on voxel_to_aux / aux_to_voxel:

@@ -578,6 +578,33 @@ def test_pair_plan_on_device_rejects_a_wrong_structural_claim():
         plan.finalize()
 
 
+def test_a_bad_pair_plan_is_reported_once_and_does_not_poison_later_plans():
+    """the verdict of a device-laid-out plan whose table was bad used to stay in the pending list and re-raise from
+    every later plan -- of unrelated, valid tables -- while the bad neighbour tensor lived.  Now: reported once from the poll, the
+    bad plan itself keeps raising whenever IT is used, plans of valid tables are unaffected."""
+    import link_amd as la
+    from link_amd import _lib as L, elk
+    n = 5000
+    coords = s_uniform(n, grid=40, seed=7).cuda()
+    st = la.SparseTensor(torch.randn(n, 16).cuda(), coords, 1)
+    nbr, _ = elk.neighbor_table_of(st, (3, 3, 3))
+    shuffled = nbr[torch.randperm(n, device=nbr.device)].contiguous()
+    bad = elk._PairPlan(shuffled, True)                  # a wrong structural claim; nobody asks this plan anything
+    assert not bad.exact
+    torch.cuda.synchronize()                             # its counts have arrived
+    with pytest.raises(L.LinkAmdError):
+        elk._PairPlan(nbr, True)                         # the next device-laid-out plan polls: the verdict surfaces HERE, once
+    good = elk._PairPlan(nbr, True)                      # ... and not again: the bad plan has left the pending list
+    good2 = elk._PairPlan(nbr, True)
+    torch.cuda.synchronize()
+    assert good.finalize().exact and good2.density > 0
+    with pytest.raises(L.LinkAmdError):                  # the bad plan itself stays bad
+        bad.finalize()
+    with pytest.raises(L.LinkAmdError):
+        _ = bad.density
+    assert all(r() is not bad for r in elk._PENDING_PLANS)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (16, 32), (32, 16)])
 def test_resident_weights_kernel_exact_and_split(cin, cout):
     """Narrow layers (conv.hip: k_subm_conv_resident, every W_k in LDS): the plain forward on the exact f32 instruction and the

@@ -173,6 +173,67 @@ def test_module_path_takes_the_lean_form_for_coordinate_sets_without_an_index():
         E.LEAN_FORM = True
 
 
+def test_module_path_reports_a_frame_that_breaks_the_stride_promise():
+    """the module path sizes a block's slot list as (s_eff / stride)^3.  A tensor whose stride is set but whose
+    coordinates are NOT multiples of it can put more voxels into a block: the kernel drops the surplus and raises status bit 1.
+    The module path must not hand back uninitialised rows silently: the rows of dropped voxels are zero, the NEXT call raises
+    (the status word travels behind the kernels, no sync), and from then on the general layout -- which has no such limit --
+    serves that block edge / stride and agrees with the oracle."""
+    import link_amd as la
+    from link_amd import _lib as L
+    C, groups, baseop, stride, s, r = 32, 2, "cos", 2, 6, 3
+    blk, params = _block(la, C, groups, baseop, 11)
+    coords = s_uniform(6000, grid=20, seed=3)            # unit-spaced coordinates: up to 216 voxels per block of edge 6, slot list holds 27
+    feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(3))
+
+    def core(st):
+        with torch.no_grad():
+            return blk._core(st, s, r, blk.pos_weight[0].weight, None, C // groups, 1.0).float().cpu()
+
+    st = la.SparseTensor(feats.cuda(), coords.cuda(), stride)       # claims stride 2: the promise is broken
+    first = core(st)
+    assert torch.isfinite(first).all()
+    assert (first.abs().sum(1) == 0).any()               # dropped voxels: zero rows, not whatever the allocator returned
+    torch.cuda.synchronize()
+    st2 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+    with pytest.raises(L.LinkAmdError, match="tensor stride"):
+        core(st2)
+    st3 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)      # reported once; now the general layout
+    got = core(st3)
+    ref = O.elk_core_torch(feats, coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride, agg=O.aggregate_c)
+    assert rel_err(got.numpy(), ref.numpy()) < TOL
+    assert any(k[0] == "link_block_index" for k in st3.kmaps)
+
+
+def test_lean_plan_state_survives_a_refused_call_and_rejects_unknown_tuning():
+    """a call the library refuses (more voxels than the plan's capacity: LINK_ERR_ARG, nothing launched) must
+    not advance the alternating counter state -- the next frame through the plan is still right; tuning keywords the lean form does
+    not have are rejected instead of ignored."""
+    import link_amd as la
+    from link_amd import _lib as L
+    C, groups, baseop, stride, s, r = 32, 2, "cos", 2, 6, 3
+    blk, params = _block(la, C, groups, baseop, 12)
+    coords = torch.from_numpy(lidar_like(9000, seed=5, stride=stride))
+    feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(5))
+    n = coords.shape[0]
+    le, ge = _plans(la, blk, n, C, baseop, groups, r, s, coords.cuda(), (s // stride) ** 3)
+    a = le.run(feats.cuda(), coords.cuda()).clone()
+    keep = le.buf.seg_cap
+    le.buf.seg_cap = 1                                              # the library checks the segment capacity against n: LINK_ERR_ARG
+    with pytest.raises(L.LinkAmdError):
+        le.run(feats.cuda(), coords.cuda())
+    le.buf.seg_cap = keep
+    b = le.run(feats.cuda(), coords.cuda()).clone()                 # rebuilt on the counters the refused call left alone
+    c_ = le.run(feats.cuda(), coords.cuda()).clone()
+    le.check()
+    assert torch.equal(a, b) and torch.equal(a, c_)
+    ge.run(feats.cuda(), coords.cuda())
+    assert le.blocks() == ge.blocks()
+    from link_amd.index import coords_bounds
+    with pytest.raises(L.LinkAmdError):
+        la.ElkCorePlan(n, C, baseop, C // groups, r, s, coords_bounds(coords.cuda()), coords.device, layout="lean", slot_cap=27, k1_wgs=256)
+
+
 def test_lean_form_batched_frames():
     """Two frames in one tensor (batch index in the coordinates, hash_cuda.cu:46): blocks never mix across the batch axis."""
     import link_amd as la
