@@ -96,4 +96,17 @@ __device__ __forceinline__ void store_out(float *base, int64_t elem, float4 v, b
 }
 static inline bool wt_ok(int64_t rows, int64_t row_floats) { return rows * row_floats * 4 < (1LL << 32); }
 
+// a * b as an fp32 VALUE (one rounding), whatever follows.  hipcc compiles with -ffp-contract=fast and __fmul_rn is a plain
+// multiply to it, so `x - __fmul_rn(a, b)` becomes ONE fma with the product unrounded.  That matters where the reference forms a
+// product, ROUNDS it, and uses it twice: the cos_x linear part fin * theta (linkunet.py:164-176) enters the block sums as a rounded
+// product and is subtracted again as "v - fin * theta" -- for a voxel that is alone in its neighbourhood the two cancel EXACTLY in
+// the reference, while an fma on one side leaves the product's rounding error, ~6e-5 at theta ~ 1500, in the row (round 5,
+// tools/core_dbg.py: 1.5e-5 of max|out| on the sparse S-kitti stages against 4.7e-7 with the rounded product).  The empty asm
+// makes the product exist in a register before anything consumes it.
+__device__ __forceinline__ float link_mul_rn(float a, float b) {
+  float p = a * b;
+  asm("" : "+v"(p));
+  return p;
+}
+
 }  // namespace link

@@ -14,6 +14,14 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // s_waitcnt vmcnt the compiler emits is an exact count instead of the vmcnt(0) a conditional VMEM op forces.
 // Tables handled here are < 4 GiB (checked by the launchers).
 #define DC_OOB 0xFFFFFFF0u
+// Per-wave phase timers (link_dc_tuning_t::k1_dbg / k2_dbg -> tools/k1prof.py, k1mprof.py, k2prof.py, step3.py PROF=1) are compiled
+// in only with -DDC_PROF=1 (python tools/mkvariant.py PROF "-DDC_PROF=1").  In the default build the pointer is forced to null at
+// the top of every kernel body, so the `if (dbg)` tests -- a scalar test + branch each, five to eight per plane step / tile in
+// every wave: ~0.3 M scalar instructions per frame on cfg2 -- and the timers fold away (round 5).
+#ifndef DC_PROF
+#define DC_PROF 0
+#endif
+#define DC_PROF_PTR(p) do { if (!DC_PROF) (p) = nullptr; } while (0)
 #ifndef DC_ST_AUX
 #define DC_ST_AUX 16      /* sc1: write-through; 0 = ordinary write-back stores (A/B: LINK_AMD_CXXFLAGS=-DDC_ST_AUX=0) */
 #endif

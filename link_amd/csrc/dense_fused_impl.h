@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg,
     const int32_t *__restrict__ occ = nullptr) {
   using K = dc_k1_cfg<C, OP>;
+  DC_PROF_PTR(dbg);
   // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime deltas
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_fill = 0, tq_body = 0, tq_sum = 0;
   int tq_tiles = 0;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
-  w_big = DC_K1_SPLIT ? __syncthreads_or(w_big) != 0 : (__syncthreads(), false);
+  w_big = DC_K1_SPLIT ? (__syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX)) : (__syncthreads(), false);   // cos_x: exact contraction (elk_common.h)
   const bool th_slow = DC_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;     // workgroup-uniform (the same in every workgroup)
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
   if (c_begin >= c_end) return;
@@ -858,8 +859,8 @@ __global__ void __launch_bounds__(256) k_dc_demod(const float *__restrict__ A_, 
         nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
       }
       if (OP == LINK_OP_COSX) {                                                  // :176
-        nvA[e] = __fadd_rn(nvA[e], __fsub_rn(__int_as_float(a0[P - 1][e]), __fmul_rn(__int_as_float(fx[e]), thA[e])));
-        nvB[e] = __fadd_rn(nvB[e], __fsub_rn(__int_as_float(b0[P - 1][e]), __fmul_rn(__int_as_float(fy[e]), thB[e])));
+        nvA[e] = __fadd_rn(nvA[e], __fsub_rn(__int_as_float(a0[P - 1][e]), link_mul_rn(__int_as_float(fx[e]), thA[e])));
+        nvB[e] = __fadd_rn(nvB[e], __fsub_rn(__int_as_float(b0[P - 1][e]), link_mul_rn(__int_as_float(fy[e]), thB[e])));
       }
       sA += nvA[e]; sB += nvB[e];
     }
@@ -1218,8 +1219,8 @@ __global__ void __launch_bounds__(256, 2) k_dc_gather_demod(
             nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
           }
           if (OP == LINK_OP_COSX) {                                                  // :176
-            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], __fmul_rn(fxa[e], thA[e])));
-            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], __fmul_rn(fya[e], thB[e])));
+            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], link_mul_rn(fxa[e], thA[e])));
+            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], link_mul_rn(fya[e], thB[e])));
           }
           sA += nvA[e]; sB += nvB[e];
         }
@@ -1472,8 +1473,8 @@ __global__ void __launch_bounds__(512, 4) k_dc_gather_demod_split(
             nvB[e] = __fadd_rn(__fmul_rn(B0, csB[e]), __fmul_rn(B1, snB[e]));
           }
           if (OP == LINK_OP_COSX) {                                                  // :176
-            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], __fmul_rn(fxa[e], thA[e])));
-            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], __fmul_rn(fya[e], thB[e])));
+            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(A2v[e], link_mul_rn(fxa[e], thA[e])));
+            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(B2v[e], link_mul_rn(fya[e], thB[e])));
           }
           sA += nvA[e]; sB += nvB[e];
         }

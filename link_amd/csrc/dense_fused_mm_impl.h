@@ -124,6 +124,7 @@ __device__ __forceinline__ void dc_k1m_body(
     unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks, const int bid) {
   using K = dc_k1m_cfg<C, OP, SPARSE>;
   constexpr int T = K::T, KB = K::KB, P = K::P, RB = K::RB;
+  DC_PROF_PTR(dbg);
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_mm = 0, tq_ln = 0, tq_sum = 0;
   int tq_tiles = 0;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -207,7 +208,7 @@ __device__ __forceinline__ void dc_k1m_body(
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
     hdr[LINK_HDR_STATUS_ACC] = 0;
   }
-  w_big = __syncthreads_or(w_big) != 0;
+  w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // cos_x: exact contraction (elk_common.h)
   const bool th_slow = DC_K1M_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;  // workgroup-uniform (the same in every workgroup)
   if (dbg) tq1 = __builtin_amdgcn_s_memtime();
   if (c_begin >= c_end) return;

@@ -274,8 +274,8 @@ __global__ void __launch_bounds__(320, 3) k_dc_gather_demod_own(
             nvB[e] = __fadd_rn(__fmul_rn(A0, csB[e]), __fmul_rn(A1, snB[e]));
           }
           if (OP == LINK_OP_COSX) {                                                  // :176
-            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(Av[P - 1][e], __fmul_rn(fxa[e], thA[e])));
-            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(Av[P - 1][e], __fmul_rn(fya[e], thB[e])));
+            nvA[e] = __fadd_rn(nvA[e], __fsub_rn(Av[P - 1][e], link_mul_rn(fxa[e], thA[e])));
+            nvB[e] = __fadd_rn(nvB[e], __fsub_rn(Av[P - 1][e], link_mul_rn(fya[e], thB[e])));
           }
           sA += nvA[e]; sB += nvB[e];
         }

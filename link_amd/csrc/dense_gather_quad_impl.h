@@ -158,6 +158,7 @@ __device__ __forceinline__ void dc_k2q_body(
     int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg, const int bid) {
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
+  DC_PROF_PTR(dbg);
   // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
   // the quad round
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
@@ -226,17 +227,19 @@ __device__ __forceinline__ void dc_k2q_body(
       cnt_cell0 = col_cell0(e / HY, e % HY);
     }
     const __amdgpu_buffer_rsrc_t r_S = dc_rsrc(S_, (uint32_t)((g.vp + 1) * RB));
-    auto cnt_slot = [&](int plane) -> uint32_t {     // LDS byte offset of the count image of `plane`
-      if (!DC_K2_SKIP) return (uint32_t)((plane % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
+    // (ring slots are carried as rotating counters `pm3` = plane % 3: a modulo by 3 is a multiply-high + shift + multiply + subtract
+    // on the scalar unit, five of them per plane step and wave)
+    auto cnt_slot = [&](int plane, int pm3) -> uint32_t {     // LDS byte offset of the count image of `plane`
+      if (!DC_K2_SKIP) return (uint32_t)(pm3 * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
       const int sl = plane % 5;
       return (uint32_t)((sl % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE + (sl / 3) * 256);
     };
-    auto issue_cnt = [&](int plane) {
+    auto issue_cnt = [&](int plane, int pm3) {
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
       const int32_t *csrc = cell_n + cnt_cell0 + pz;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
-                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane, pm3) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, 0);
     };
     uint32_t rec_cell0;                                // inline slot records of the 16 interior cells of an output plane
     int rec_k;
@@ -247,12 +250,12 @@ __device__ __forceinline__ void dc_k2q_body(
       rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
     }
     const char *Sb = reinterpret_cast<const char *>(S_);
-    auto issue = [&](int plane, bool known) {          // known: the plane's count image is in LDS (every plane but the first two)
+    auto issue = [&](int plane, int pm3, bool known) {   // known: the plane's count image is in LDS (every plane but the first two)
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
-      char *buf = lds + (plane % 3) * K2::SPLIT_BUF_BYTES;
+      char *buf = lds + pm3 * K2::SPLIT_BUF_BYTES;
       if (DC_K2_SKIP && known) {
-        const uint32_t cb = lds_base + cnt_slot(plane);
+        const uint32_t cb = lds_base + cnt_slot(plane, pm3);
         int cn[K::PASSES];
         lds_rd_counts<K::PASSES>(cb, cnt_off, cn);
 #pragma unroll
@@ -274,7 +277,7 @@ __device__ __forceinline__ void dc_k2q_body(
                                            (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
         }
       }
-      issue_cnt(DC_K2_SKIP ? plane + 2 : plane);       // NI instructions per call either way
+      issue_cnt(DC_K2_SKIP ? plane + 2 : plane, pm3);  // NI instructions per call either way
       int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
       po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
       const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
@@ -292,10 +295,11 @@ __device__ __forceinline__ void dc_k2q_body(
     int n_prev = 0;                                    // voxels in this group's cell of the previous plane
 #pragma unroll
     for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DC_K2_SKIP) { issue_cnt(0); issue_cnt(1); }    // older than everything a counted wait leaves in flight
-    issue(0, false);
-    if (nplanes > 1) issue(1, false);
-    for (int i = 0; i <= nplanes; i++) {
+    if (DC_K2_SKIP) { issue_cnt(0, 0); issue_cnt(1, 1); }    // older than everything a counted wait leaves in flight
+    issue(0, 0, false);
+    if (nplanes > 1) issue(1, 1, false);
+    int m3 = 0, m3p2 = 2;                              // i % 3, (i + 2) % 3
+    for (int i = 0; i <= nplanes; i++, m3 = m3 == 2 ? 0 : m3 + 1, m3p2 = m3p2 == 2 ? 0 : m3p2 + 1) {
       unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
       if (i < nplanes) {
         if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
@@ -305,14 +309,14 @@ __device__ __forceinline__ void dc_k2q_body(
       asm volatile("s_barrier" ::: "memory");
       if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
       if (i >= nplanes) break;
-      if (i + 2 < nplanes) issue(i + 2, true);
-      const uint32_t bufa = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES);
+      if (i + 2 < nplanes) issue(i + 2, m3p2, true);
+      const uint32_t bufa = lds_base + (uint32_t)(m3 * K2::SPLIT_BUF_BYTES);
       float4 cur[P];
       float cc = 0.f;
 #pragma unroll
       for (int pp = 0; pp < P; pp++) cur[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
       {
-        const uint32_t ra = bufa + row_lane, ca = lds_base + cnt_slot(i) + cnt_lane;
+        const uint32_t ra = bufa + row_lane, ca = lds_base + cnt_slot(i, m3) + cnt_lane;
         if constexpr (R == 3) {
           dc_read_plane_p2r3<C>(ra, ca, cur, cc);
         } else {
@@ -320,7 +324,7 @@ __device__ __forceinline__ void dc_k2q_body(
           dc_read_dx<C, P, R, 1>(ra, ca, cur, cc);
         }
       }
-      const int n_here = lds_rd_b32(lds_base + cnt_slot(i) + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
+      const int n_here = lds_rd_b32(lds_base + cnt_slot(i, m3) + cnt_lane + (uint32_t)((HLO * HY + HLO) * 4));
       if (i >= R - 1) {
         const uint32_t abuf = abuf0 + (uint32_t)((i & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((i & 1) * K2::NG * 4);
         float4 a[P];
@@ -366,10 +370,11 @@ __device__ __forceinline__ void dc_k2q_body(
     // slot is requested again only at step i + 1).  Lane v finds the cell of the plane's v-th voxel -- cells in group order,
     // slots in id order -- from the plane's 16 interior counts (broadcast reads, four per round trip) and writes
     // cell << 12 | slot; the consumers read the entry two barriers later (plane i is the output plane of step i + 1).
-    for (int i = 0; i <= nplanes; i++) {
+    int m3 = 0;                                        // i % 3
+    for (int i = 0; i <= nplanes; i++, m3 = m3 == 2 ? 0 : m3 + 1) {
       asm volatile("s_barrier" ::: "memory");
       if (i >= nplanes) break;
-      const uint32_t ca = lds_base + (uint32_t)((i % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
+      const uint32_t ca = lds_base + (uint32_t)(m3 * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
       int run = 0, c_ = 0, start = 0;
 #define Q_(k) "i"(((((k) / TY) + HLO) * HY + ((k) % TY) + HLO) * 4)
 #define DC_MAP4(K0)                                                                                                          \
@@ -395,7 +400,7 @@ __device__ __forceinline__ void dc_k2q_body(
       DC_MAP4(0) DC_MAP4(4) DC_MAP4(8) DC_MAP4(12)
 #undef DC_MAP4
 #undef Q_
-      const uint32_t mb = lds_base + (uint32_t)(KQ::MAP_OFF + (i % 3) * KQ::MAP_BYTES);
+      const uint32_t mb = lds_base + (uint32_t)(KQ::MAP_OFF + m3 * KQ::MAP_BYTES);
       lds_wr_b32(mb + (uint32_t)(lane * 4), (c_ << 12) | ((lane - start) & 4095));
       if (lane == 0) lds_wr_b32(mb + 256u, run);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -428,7 +433,8 @@ __device__ __forceinline__ void dc_k2q_body(
       for (int e = 0; e < 4; e++) b_ |= dc_theta_leaves_fast_range(ax, ay, az, w0[j][e], w1[j][e], w2[j][e], 1.0f);
     slow_k = __any(b_);
   }
-  for (int i = 0; i <= nplanes; i++) {
+  int m3p1 = 1;                                        // (i + 1) % 3 == (jp - 1) % 3
+  for (int i = 0; i <= nplanes; i++, m3p1 = m3p1 == 2 ? 0 : m3p1 + 1) {
     unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_barrier" ::: "memory");
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
@@ -441,7 +447,7 @@ __device__ __forceinline__ void dc_k2q_body(
     uint32_t mb = 0;
     if (DC_K2Q_PMAP) {
       // the producers laid the plane's voxel map out two steps ago (plane jp - 1): entry = cell << 12 | slot, then the voxel count
-      mb = lds_base + (uint32_t)(KQ::MAP_OFF + ((jp - 1) % 3) * KQ::MAP_BYTES);
+      mb = lds_base + (uint32_t)(KQ::MAP_OFF + m3p1 * KQ::MAP_BYTES);
       int tv_;
       asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3 offset:256\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(m0), "=&v"(tv_) : "v"(mb + (uint32_t)(qd * 4)), "v"(mb) : "memory");

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_dc_gather_demod_sparse(
             float va;
             if (OP == LINK_OP_SIN) va = __fsub_rn(__fmul_rn(a0[q], cs[q]), __fmul_rn(a1[q], sn[q]));      // linkunet.py:148
             else va = __fadd_rn(__fmul_rn(a0[q], cs[q]), __fmul_rn(a1[q], sn[q]));                         // :162
-            if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(a2[q], __fmul_rn(fv[q], th[q])));         // :176
+            if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(a2[q], link_mul_rn(fv[q], th[q])));         // :176
             nvv[q] = va;
             s += va;
           }

@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_modulate_sum(const float *__restrict__ 
             sincos_fast(th, sn, cs);
             if (OP == LINK_OP_SIN) { a0[q] += f * sn; a1[q] += f * cs; }
             else { a0[q] += f * cs; a1[q] += f * sn; }
-            if (OP == LINK_OP_COSX) a2[q] += f * th;
+            if (OP == LINK_OP_COSX) a2[q] += link_mul_rn(f, th);      // a rounded product, as the reference sums it (common.h)
           }
         }
       }
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln(
             else vv = __fadd_rn(__fmul_rn(A[0][q], cs), __fmul_rn(A[1][q], sn));                      // :162
             if (OP == LINK_OP_COSX) {
               float f = fin[(int64_t)i * c + ch];
-              vv = __fadd_rn(vv, __fsub_rn(A[P - 1][q], __fmul_rn(f, th)));                           // :176
+              vv = __fadd_rn(vv, __fsub_rn(A[P - 1][q], link_mul_rn(f, th)));                           // :176
             }
             nv[q] = vv;
             s += vv;
@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(256) k_gather_demod_ln_g(
             va = __fadd_rn(__fmul_rn(A[0][e], csA_), __fmul_rn(A[1][e], snA_));
             vb = __fadd_rn(__fmul_rn(A[0][e], csB_), __fmul_rn(A[1][e], snB_));
           }
-          if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A[P - 1][e], __fmul_rn(fv[e], th)));   // :176
+          if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A[P - 1][e], link_mul_rn(fv[e], th)));   // :176
           nvA[e] = act ? va : 0.f; nvB[e] = act ? vb : 0.f;
           sA += nvA[e]; sB += nvB[e];
         }
@@ -1556,7 +1556,7 @@ __global__ void __launch_bounds__(256) k_voxel_demod_ln_g(
       va = __fadd_rn(__fmul_rn(A0a[e], csA_), __fmul_rn(A1a[e], snA_));
       vb = __fadd_rn(__fmul_rn(A0b[e], csB_), __fmul_rn(A1b[e], snB_));
     }
-    if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A2a[e], __fmul_rn(fv[e], th)));          // :176
+    if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(A2a[e], link_mul_rn(fv[e], th)));          // :176
     nvA[e] = act ? va : 0.f; nvB[e] = act ? vb : 0.f;
     sA += nvA[e]; sB += nvB[e];
   }
@@ -2002,7 +2002,7 @@ __global__ void __launch_bounds__(256) k_out_ln_bwd_g(
       float va;
       if (OP == LINK_OP_SIN) va = __fsub_rn(__fmul_rn(v0[e], cs), __fmul_rn(v1[e], sn));
       else va = __fadd_rn(__fmul_rn(v0[e], cs), __fmul_rn(v1[e], sn));
-      if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(v2[e], __fmul_rn(fv[e], th)));
+      if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(v2[e], link_mul_rn(fv[e], th)));
       nv[e] = act ? va : 0.f;
       sm += nv[e];
     }

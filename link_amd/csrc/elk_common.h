@@ -130,6 +130,16 @@ __device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs) {
 #endif
 }
 
+// cos_x (linkunet.py:164-176) carries a third, LINEAR channel group fin * theta: whatever error fin has is multiplied by theta,
+// which is a few hundred to a few thousand radians on LiDAR frames.  The fp16 hi | lo split of the pre_mix contraction
+// represents its operands to 2^-22: harmless for cos / sin (|modulation| <= 1), but 5-8 x the fp32 reference's own conditioning
+// error once it is scaled by theta (S-kitti stage 1, theta up to 744 / 1489: 1.1e-4 / 1.6e-4 of max|out| against 2.3e-5 / 2.9e-5
+// for the reference evaluated in fp32, both measured against a float64 evaluation: tools/lidar_core_parity.py, round 5).  So the
+// fused kernels take the exact fp32 matrix instruction for cos_x (0: the split everywhere, the round-3/4 behaviour).
+#ifndef LINK_COSX_EXACT
+#define LINK_COSX_EXACT 1
+#endif
+
 template <int LPR>
 __device__ __forceinline__ float grp_sum(float v) {
   // butterfly over the LPR lanes of a group; steps <= 8 stay inside a 16-lane DPP row
@@ -163,7 +173,7 @@ __device__ __forceinline__ void mod_accum(float &a0, float &a1, float &a2, float
   if (OP == LINK_OP_SIN) { a0 += f * sn; a1 += f * cs; }
   else if (OP == LINK_OPI_SIN_BWD) { a0 += f * cs; a1 -= f * sn; }
   else { a0 += f * cs; a1 += f * sn; }
-  if (OP == LINK_OP_COSX) a2 += f * th;
+  if (OP == LINK_OP_COSX) a2 += link_mul_rn(f, th);        // a rounded product, as the reference sums it (common.h)
   if (OP == LINK_OPI_COSX_BWD) a2 += f;
 }
 

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
   }
   lean_groups(ins && cell >= 0, cell, lane, g_lead, g_off, g_size);
   if (ins && cell >= 0 && lane == g_lead) base = (int)atomicAdd(&a.cnt[(int64_t)cell << a.cshift], (unsigned)g_size);
-  w_big = __syncthreads_or(w_big) != 0;
+  w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // cos_x: exact contraction (elk_common.h)
   const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
   floatx4 ac[T];
   dc_premix_tile<C>(wh, a.w_pre, w_big, li, gq, ff, ac);
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_lean_insert_premix_cs(const lean_args a
     for (int u = 0; u < TB; u++)
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(wv[u][tt].x), fabsf(wv[u][tt].y)), fmaxf(fabsf(wv[u][tt].z), fabsf(wv[u][tt].w))));
   }
-  if (__builtin_expect(!__any(!(mx < 32768.0f)), 1)) {
+  if (__builtin_expect(!(LINK_COSX_EXACT && OP == LINK_OP_COSX) && !__any(!(mx < 32768.0f)), 1)) {
 #pragma unroll
     for (int u = 0; u < TB; u++)
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256, (C <= 32 ? 3 : 2)) k_lean_sums_pm(const l
   int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;
   const int step = (int)(gridDim.x * 4) >> 4;
   bool w_big = dc_stage_weights<C, 256>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
-  w_big = __syncthreads_or(w_big) != 0;                  // before any wave leaves
+  w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // before any wave leaves; cos_x: exact contraction
   const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
   const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(a.feats, (uint32_t)((int64_t)a.n * C * IO_BYTES));
   for (; idx < nitem; idx += step) {

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
   ld_rec(1, rec1, blk1);
   bool w_big = dc_stage_weights<C, 64 * K::NW>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
   for (int i = lane; i < K::CARRY_BYTES / 4; i += 64) carry[i] = 0.f;     // read unconditionally by every tile (times 0 unless a block straddles)
-  w_big = __syncthreads_or(w_big) != 0;
+  w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // cos_x: exact contraction (elk_common.h)
   if (a >= e) return;                                  // nominal span inside one block that an earlier workgroup owns
   ELK_T_TICK(tq2);
 #ifdef ELK_T_DBG
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256) k_elk_gather_tiles(
         float va;
         if (OP == LINK_OP_SIN) va = __fsub_rn(__fmul_rn(a0[q], cs[q]), __fmul_rn(a1[q], sn[q]));
         else va = __fadd_rn(__fmul_rn(a0[q], cs[q]), __fmul_rn(a1[q], sn[q]));
-        if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(a2[q], __fmul_rn(fv[q], th[q])));
+        if (OP == LINK_OP_COSX) va = __fadd_rn(va, __fsub_rn(a2[q], link_mul_rn(fv[q], th[q])));
         nvv[q] = va;
         s += va;
       }

@@ -329,6 +329,7 @@ class SparseConv3d(nn.Module):
         table._link_subm = False                         # structural mark for the pair plan: a gather table between two site sets
         back = None                                      # transposed direction: built on the first backward
         hit = sct.indice_dict[key] = [out_ind.contiguous(), table, back, sct.indices]
+        sct.indice_dict[("link_unique", hit[0].data_ptr(), hit[0].shape[0])] = True     # sorted unique cells: unique by construction
         return hit[0], hit[1], hit[2]
 
     def _out_tensor(self, sct, out_ind, feats):

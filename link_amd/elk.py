@@ -878,6 +878,15 @@ class _StridedMap:
         return self._nbr_up
 
 
+TRUST_UNIQUE_INPUT_COORDS = True   # caller-supplied coordinate sets are taken as unique (torchsparse's contract), verified on the device
+
+
+def mark_unique(cmaps: dict, coords: torch.Tensor) -> None:
+    """Record in a tensor's cmaps that `coords` has unique rows BY CONSTRUCTION (output sites of a strided convolution, a voxeliser's
+    output): neighbor_table_of may then hand its table to the pair planner as submanifold without relying on the caller's word."""
+    cmaps[("link_unique", coords.data_ptr(), coords.shape[0])] = True
+
+
 def neighbor_table_of(x: SparseTensor, kernel_size):
     """Per-output neighbour table of a stride-1 convolution over x's voxels: (int32[N, K], spatial tile order or
     None), cached on the tensor's kmaps (every convolution with this kernel size over these coordinates shares it)."""
@@ -902,8 +911,15 @@ def neighbor_table_of(x: SparseTensor, kernel_size):
             offs = get_kernel_offsets(kernel_size, stride=x.s, device=x.F.device)
             nbr = sphashquery(sphash(x.C, offs), sphash(x.C)).t().contiguous().int()
         try:
-            # structural mark for the pair plan: odd kernel over one coordinate set -> the centre column is the identity
-            nbr._link_subm = all(int(k) % 2 == 1 for k in kernel_size)
+            # structural mark for the pair plan: odd kernel over ONE coordinate set whose rows are unique -> the centre column is
+            # the identity.  Uniqueness is structurally known for coordinate sets this package produced (mark_unique: the output
+            # sites of strided convolutions); for coordinates handed in by the caller it is torchsparse's contract (sparse_quantize,
+            # tensor.py) and TRUST_UNIQUE_INPUT_COORDS decides whether the claim is made -- it is then VERIFIED on the device
+            # (rows whose centre neighbour is not the row itself are counted by link_pair_plan_build) and a wrong claim raises at
+            # the next plan.  None = "unknown": the plan is laid out on the host from exact counts (one round trip).
+            odd = all(int(k) % 2 == 1 for k in kernel_size)
+            known = bool(x.cmaps.get(("link_unique", x.C.data_ptr(), x.C.shape[0])))
+            nbr._link_subm = (True if (known or TRUST_UNIQUE_INPUT_COORDS) else None) if odd else False
         except AttributeError:
             pass
         nbr = (nbr, _TileOrder(x.C, 4 * ts))
@@ -1016,6 +1032,7 @@ class Conv3d(nn.Module):
                 oy = r1 % ext[1]; r2 = torch.div(r1, ext[1], rounding_mode="floor")
                 ox = r2 % ext[0]; ob = torch.div(r2, ext[0], rounding_mode="floor")
                 out_c = torch.stack([(ox + lo[0]) * ss, (oy + lo[1]) * ss, (oz + lo[2]) * ss, ob + bounds[0][3]], 1).int().contiguous()
+            mark_unique(x.cmaps, out_c)                    # unique rows by construction (sorted unique cells)
             # the coarse set's bounding box follows from the fine one: no second pass over the coordinates, no round trip
             x.cmaps.setdefault(("link_bounds", out_c.data_ptr(), out_c.shape[0]),
                                ((lo[0] * ss, lo[1] * ss, lo[2] * ss, bounds[0][3]), (hi[0] * ss, hi[1] * ss, hi[2] * ss, bounds[1][3])))
@@ -1945,7 +1962,10 @@ class _ELKBase(nn.Module):
         if bounds is None:
             from .index import coords_bounds
             bounds = st.cmaps[bkey] = coords_bounds(coords.contiguous())
-        q = int(s_eff) * LEAN_BOUNDS_PAD_BLOCKS
+        # bounds measured on the frame move from frame to frame: pad them coarsely; bounds the caller declared (spatial_shape: fixed for
+        # the network, and what lies beyond them must be dropped -- INTEGRATION.md) are taken block-exact
+        unchecked = bool(st.cmaps.get(("link_bounds_unchecked", coords.data_ptr(), n)))
+        q = int(s_eff) * (1 if unchecked else LEAN_BOUNDS_PAD_BLOCKS)
         qbounds = (tuple((int(v) // q) * q for v in bounds[0][:3]) + (int(bounds[0][3]),),
                    tuple((int(v) // q) * q + q - 1 for v in bounds[1][:3]) + (int(bounds[1][3]),))
         cache = _plan_cache_of(self, "_lean_plans")
@@ -2144,6 +2164,8 @@ def spconv2ts(sct):
         ent = sct.indice_dict.get(key)
         if ent is None:
             ent = sct.indice_dict[key] = (ind[:, [3, 2, 1, 0]].contiguous(), ind, {}, {})
+            if sct.indice_dict.get(("link_unique", ind.data_ptr(), ind.shape[0])):       # sites a strided convolution created
+                mark_unique(ent[2], ent[0])
     coords = ent[0] if ent is not None else ind[:, [3, 2, 1, 0]].contiguous()
     st = SparseTensor(sct.features, coords, 1)
     if ent is not None:

@@ -36,7 +36,15 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     # a step = one batch of 3 frames per GPU: 6 frames per step over the two ranks; value = voxels of all timed frames / time
     assert d["frames_per_step"] == 6 and abs(d["us_per_frame"] * 3 - d["ms_per_step"] * 1e3) < 0.05
     assert abs(d["value"] - 2 * 100000 / (d["us_per_frame"] * 1e-6)) < 1e-3 * d["value"]
+    # SURVEY.md 8e side figures of the N > 1 line: the collective really spans both ranks, the summary gather sits inside a
+    # reported end-to-end time, the full-tensor gather ([N, C] rows of every rank, two-phase pattern) is timed on its own
+    mg = d["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["world_size"] == 2 and mg["all_reduce_of_ones"] == 2.0 and mg["collective_spans_all_ranks"]
+    assert mg["end_to_end_ms"] >= d["ms_per_step"] * d["steps"] * 0.5 and mg["end_to_end_ms"] > 0
+    assert mg["full_tensor_gather_ms"] > 0 and mg["full_tensor_gather_ok"] and mg["full_tensor_gather_bytes_per_rank"] == 100000 * 64 * 4
     single = _run(["--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+    assert single["multi_gpu"] is None
+    assert "gpu_state" in single and isinstance(single["gpu_state"], dict)          # clock / power state (amdsmi) or why it is missing
     assert single["n_gpus"] == 1 and single["ranks"][0]["blocks"] == d["ranks"][0]["blocks"]
     assert single["frames_per_step"] == 3 and abs(single["value"] - 100000 / (single["us_per_frame"] * 1e-6)) < 1e-3 * single["value"]
     assert abs(single["roofline"]["whole_step"]["us"] - single["us_per_frame"]) < 0.02
