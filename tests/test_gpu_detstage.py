@@ -85,7 +85,12 @@ def test_stage_forward_vs_dense_oracle(planes, n, grid):
     with torch.no_grad():
         out = stage(sct)
         out2 = stage(sct)
-    assert torch.equal(out.indices.cpu(), indices) and torch.equal(out.features, out2.features)
+        out3 = stage(sct)
+    # a coordinate set's FIRST visit runs the lean form of the LinK core (no block index built), a set that comes back gets an
+    # index and the tile form from then on (elk.LEAN_SECOND_VISIT_INDEX, round 5): visits 2, 3, ... agree bit for bit, visit 1
+    # with them to the forms' agreement
+    assert torch.equal(out.indices.cpu(), indices) and torch.equal(out2.features, out3.features)
+    assert rel_err(out.features.cpu().numpy(), out2.features.cpu().numpy()) < 2e-6
     ref = oracle_stage(stage, feats, indices, shape, stage.block_sz)
     assert rel_err(out.features.cpu().numpy(), ref.numpy()) < 2e-5
     # module-by-module execution (what runs with grad enabled) gives the same features

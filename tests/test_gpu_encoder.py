@@ -76,7 +76,7 @@ def test_cfg3_full_size_s_kitti_encoder():
     for i, (o, (ro, rc)) in enumerate(zip(outs, ref)):
         assert np.array_equal(o.C.cpu().numpy(), rc), f"stage {i} coordinates"
         err = rel_err(o.F.detach().cpu().numpy(), ro.detach().numpy())
-        assert err < 5e-4, f"stage {i} output {err}"
+        assert err < 5e-5, f"stage {i} output {err}"   # observed 2.5e-6 ... 4.2e-6 (round 5, after the cos_x parity fixes; 5e-4 before)
         ts = 2 ** (i + 1)
         m = np.unique(np.concatenate([rc[:, :3] // (ts * 3), rc[:, 3:]], 1), axis=0).shape[0]
         report.append((ts, rc.shape[0], m, round(rc.shape[0] / m, 2), err))
@@ -267,4 +267,4 @@ def test_cfg4_frames_encoder_forward_vs_oracle(seed):
     for i, (o, (ro, rc)) in enumerate(zip(outs, ref)):
         assert np.array_equal(o.C.cpu().numpy(), rc), f"seed {seed} stage {i} coordinates"
         err = rel_err(o.F.detach().cpu().numpy(), ro.detach().numpy())
-        assert err < 5e-4, f"seed {seed} stage {i} output {err}"
+        assert err < 5e-5, f"seed {seed} stage {i} output {err}"   # as the cfg3 test: observed a few 1e-6

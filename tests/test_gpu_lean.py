@@ -157,7 +157,20 @@ def test_module_path_takes_the_lean_form_for_coordinate_sets_without_an_index():
     assert len(blk.__dict__.get("_lean_plans", {})) == 1 and next(iter(blk._lean_plans.values())).lean
     assert not any(k[0] == "link_block_index" for k in st.kmaps)
     next(iter(blk._lean_plans.values())).check()
-    assert torch.equal(core(st), first)                 # same maps again: reused lists, same bits
+    # the same maps again: a coordinate set that comes back gets a block index and moves to the tile form (faster on a built index);
+    # within the forms' agreement of the first visit, and the third visit gives the second's bits
+    second = core(st)
+    assert any(k[0] == "link_block_index" for k in st.kmaps)
+    assert rel_err(second.numpy(), first.numpy()) < 2e-6 and rel_err(second.numpy(), ref.numpy()) < TOL
+    assert torch.equal(core(st), second)
+    E.LEAN_SECOND_VISIT_INDEX = False
+    try:                                                # switch off: the set stays on the lean form, lists reused, same bits
+        stb = la.SparseTensor(feats.cuda(), coords.cuda(), stride)
+        fb = core(stb)
+        assert torch.equal(fb, first) and torch.equal(core(stb), first)
+        assert not any(k[0] == "link_block_index" for k in stb.kmaps)
+    finally:
+        E.LEAN_SECOND_VISIT_INDEX = True
     st2 = la.SparseTensor(feats.cuda(), coords.cuda(), stride)          # a fresh coordinate set: rebuilt, same bits
     assert torch.equal(core(st2), first)
     assert rel_err(first.numpy(), ref.numpy()) < TOL

@@ -1,4 +1,4 @@
-"""tools/traffic_json.py -- profiles/traffic.json from a pmc_counters.txt of tools/r04_profiles.sh:
+"""tools/traffic_json.py -- profiles/traffic.json from a pmc_counters_streams1.txt of tools/r05_profiles.sh:
 memory-side bytes per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (KiB counters; the gfx950 wide-read correction
 of MI355X_MICROARCH.md; Infinity-Cache hits are counted), per kernel of the dense-cell step.
 usage: traffic_json.py pmc_counters.txt out.json <commit> <source label>"""
@@ -21,8 +21,8 @@ for line in open(src):
 kern = {k: int(round(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024)) for k, v in vals.items()
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
 mfma = {k: int(round(v["SQ_VALU_MFMA_BUSY_CYCLES"])) for k, v in vals.items() if v.get("SQ_VALU_MFMA_BUSY_CYCLES")}
-json.dump({"mfma_busy_cycles": mfma, "source": f"{label} (tools/r04_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                     "tools/dcstep.py, cfg2, one stream; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 -- the gfx950 wide-read "
+json.dump({"mfma_busy_cycles": mfma, "source": f"{label} (tools/r05_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                     "tools/dcstep3.py with one frame in flight, cfg2; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 -- the gfx950 wide-read "
                      f"correction of MI355X_MICROARCH.md; Infinity-Cache hits are counted) at commit {commit}",
            "commit": commit, "kernels": kern}, open(out, "w"), indent=1)
 print(kern)
