@@ -854,6 +854,19 @@ int link_bn_forward_stats(const float *x, int64_t n, int32_t c, float eps, float
 int link_bn_backward_reduce(const float *g, const float *x, const float *mean, const float *invstd, int64_t n, int32_t c,
                             double *partial, float *sum_g, float *sum_gx, const float *weight /* NULL: 1 */,
                             float *coef /* [3c] or NULL */, void *stream);
+/* Round 5: the normalisation and the input gradient as ONE pass each, with the ReLU that follows the BatchNorm in the
+ * reference's blocks (linkunet.py:23-38: Conv3d -> BatchNorm -> ReLU(True)) folded in -- a training step of the cfg3
+ * encoder spent a quarter of its 9 ms in torch's elementwise kernels (x - mean, addcmul, clamp, threshold_backward, ...).
+ *   link_bn_apply_forward          y = (x - mean) * scale + shift, relu != 0: y = max(y, 0)
+ *   link_bn_backward_reduce_relu   link_bn_backward_reduce on g' = g masked by y > 0 (y recomputed from x, scale, shift)
+ *   link_bn_apply_backward         gx = a * g' + bq * (x - mean) + cq; scale / shift NULL: g' = g (no relu in the forward) */
+int link_bn_apply_forward(const float *x, const float *mean, const float *scale, const float *shift, int64_t n, int32_t c,
+                          int32_t relu, float *y, void *stream);
+int link_bn_backward_reduce_relu(const float *g, const float *x, const float *mean, const float *invstd, const float *scale,
+                                 const float *shift, int64_t n, int32_t c, double *partial, float *sum_g, float *sum_gx,
+                                 const float *weight /* NULL: 1 */, float *coef /* [3c] */, void *stream);
+int link_bn_apply_backward(const float *g, const float *x, const float *mean, const float *coef, const float *scale /* NULL: no relu */,
+                           const float *shift, int64_t n, int32_t c, float *gx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 ELK_LEAN_CS, ELK_LEAN_NO_CS, ELK_LEAN_PM, ELK_LEAN_NO_PM = 32, 64, 128, 256
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -185,6 +185,10 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "link_bn_backward_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "link_bn_apply_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "link_bn_backward_reduce_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "link_bn_apply_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "link_conv_pairs_gemm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "link_pair_plan_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "link_pair_plan_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -14,10 +14,13 @@
 
 using namespace link;
 
-template <bool BWD>
+// RELU (backward only): the gradient arriving is that of relu(y), y = (x - mean) * scale + shift -- rows are masked by y > 0,
+// recomputed from x with the forward's own scale / shift (one multiply-add per element; no second [N, C] matrix is kept).
+template <bool BWD, bool RELU = false>
 __global__ void __launch_bounds__(256) k_col_moments(const float *__restrict__ x, const float *__restrict__ g,
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                     int64_t n, int c, double *__restrict__ partial) {
+                                                     int64_t n, int c, double *__restrict__ partial,
+                                                     const float *__restrict__ scale = nullptr, const float *__restrict__ shift = nullptr) {
   __shared__ double red[256][8];
   const int tid = threadIdx.x;
   const int cq = c >> 2, rpp = 256 / cq;
@@ -25,13 +28,20 @@ __global__ void __launch_bounds__(256) k_col_moments(const float *__restrict__ x
   const bool act = r < rpp;
   double s0[4] = {0., 0., 0., 0.}, s1[4] = {0., 0., 0., 0.};
   float4 m = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (BWD && act) {
     m = *reinterpret_cast<const float4 *>(mean + 4 * q);
     is = *reinterpret_cast<const float4 *>(invstd + 4 * q);
+    if (RELU) { sc = *reinterpret_cast<const float4 *>(scale + 4 * q); sh = *reinterpret_cast<const float4 *>(shift + 4 * q); }
   }
   if (act) {
     const int64_t stride = (int64_t)gridDim.x * rpp;
-    auto add = [&](const float4 &v, const float4 &gv) {
+    auto add = [&](const float4 &v, const float4 &g_) {
+      float4 gv = g_;
+      if (BWD && RELU) {                                     // gradient of relu(y): zero where y <= 0
+        gv.x = fmaf(v.x - m.x, sc.x, sh.x) > 0.f ? gv.x : 0.f; gv.y = fmaf(v.y - m.y, sc.y, sh.y) > 0.f ? gv.y : 0.f;
+        gv.z = fmaf(v.z - m.z, sc.z, sh.z) > 0.f ? gv.z : 0.f; gv.w = fmaf(v.w - m.w, sc.w, sh.w) > 0.f ? gv.w : 0.f;
+      }
       if (BWD) {
         s0[0] += gv.x; s0[1] += gv.y; s0[2] += gv.z; s0[3] += gv.w;
         s1[0] += (double)(gv.x * ((v.x - m.x) * is.x)); s1[1] += (double)(gv.y * ((v.y - m.y) * is.y));
@@ -137,6 +147,40 @@ __global__ void __launch_bounds__(256) k_bn_finalize_backward(const double *__re
   }
 }
 
+// y = (x - mean) * scale + shift (centred first: no cancellation), optionally relu -- the normalisation itself, one pass.
+// BWD: grad_x = a * g' + bq * (x - mean) + cq with g' = g masked by y > 0 when the forward ended in relu (coef = a | bq | cq of
+// k_bn_finalize_backward, formed from the same masked gradient).  A thread owns 4 consecutive channels of a row.
+template <bool BWD, bool RELU>
+__global__ void __launch_bounds__(256) k_bn_apply(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ mean,
+                                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                                  const float *__restrict__ coef, int64_t n, int c, float *__restrict__ out) {
+  const int cq = c >> 2;
+  const int64_t total = n * cq;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int q = (int)(e % cq);
+    const float4 v = *reinterpret_cast<const float4 *>(x + 4 * e);
+    const float4 m = *reinterpret_cast<const float4 *>(mean + 4 * q);
+    float4 o;
+    if (!BWD) {
+      const float4 sc = *reinterpret_cast<const float4 *>(scale + 4 * q), sh = *reinterpret_cast<const float4 *>(shift + 4 * q);
+      o.x = fmaf(v.x - m.x, sc.x, sh.x); o.y = fmaf(v.y - m.y, sc.y, sh.y); o.z = fmaf(v.z - m.z, sc.z, sh.z); o.w = fmaf(v.w - m.w, sc.w, sh.w);
+      if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    } else {
+      float4 gv = *reinterpret_cast<const float4 *>(g + 4 * e);
+      if (RELU) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + 4 * q), sh = *reinterpret_cast<const float4 *>(shift + 4 * q);
+        gv.x = fmaf(v.x - m.x, sc.x, sh.x) > 0.f ? gv.x : 0.f; gv.y = fmaf(v.y - m.y, sc.y, sh.y) > 0.f ? gv.y : 0.f;
+        gv.z = fmaf(v.z - m.z, sc.z, sh.z) > 0.f ? gv.z : 0.f; gv.w = fmaf(v.w - m.w, sc.w, sh.w) > 0.f ? gv.w : 0.f;
+      }
+      const float4 a = *reinterpret_cast<const float4 *>(coef + 4 * q), bq = *reinterpret_cast<const float4 *>(coef + c + 4 * q);
+      const float4 cq_ = *reinterpret_cast<const float4 *>(coef + 2 * c + 4 * q);
+      o.x = fmaf(v.x - m.x, bq.x, fmaf(gv.x, a.x, cq_.x)); o.y = fmaf(v.y - m.y, bq.y, fmaf(gv.y, a.y, cq_.y));
+      o.z = fmaf(v.z - m.z, bq.z, fmaf(gv.z, a.z, cq_.z)); o.w = fmaf(v.w - m.w, bq.w, fmaf(gv.w, a.w, cq_.w));
+    }
+    *reinterpret_cast<float4 *>(out + 4 * e) = o;
+  }
+}
+
 static bool bn_width_ok(int32_t c) { return c >= 4 && c <= 1024 && (c & 3) == 0; }
 
 extern "C" int32_t link_bn_partial_workgroups(int64_t n, int32_t c) {
@@ -171,4 +215,40 @@ extern "C" int link_bn_backward_reduce(const float *g, const float *x, const flo
   hipLaunchKernelGGL(k_col_moments<true>, dim3(wgs), dim3(256), 0, st, x, g, mean, invstd, n, (int)c, partial);
   hipLaunchKernelGGL(k_bn_finalize_backward, dim3((c + 15) / 16), dim3(256), 0, st, partial, wgs, (int)c, sum_g, sum_gx, weight, mean, invstd, n, coef);
   return check_launch("link_bn_backward_reduce");
+}
+
+static unsigned bn_apply_grid(int64_t n, int32_t c) {
+  const int64_t wgs = (n * (c / 4) + 256 * 4 - 1) / (256 * 4);       // ~4 pieces per thread
+  return (unsigned)(wgs < 1 ? 1 : (wgs > 4096 ? 4096 : wgs));
+}
+
+extern "C" int link_bn_apply_forward(const float *x, const float *mean, const float *scale, const float *shift, int64_t n, int32_t c,
+                                     int32_t relu, float *y, void *stream) {
+  if (n < 1 || !bn_width_ok(c) || n * (int64_t)c >= (1LL << 40) || !x || !mean || !scale || !shift || !y) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  if (relu) hipLaunchKernelGGL((k_bn_apply<false, true>), dim3(bn_apply_grid(n, c)), dim3(256), 0, st, x, nullptr, mean, scale, shift, nullptr, n, (int)c, y);
+  else hipLaunchKernelGGL((k_bn_apply<false, false>), dim3(bn_apply_grid(n, c)), dim3(256), 0, st, x, nullptr, mean, scale, shift, nullptr, n, (int)c, y);
+  return check_launch("link_bn_apply_forward");
+}
+
+extern "C" int link_bn_backward_reduce_relu(const float *g, const float *x, const float *mean, const float *invstd, const float *scale,
+                                            const float *shift, int64_t n, int32_t c, double *partial, float *sum_g, float *sum_gx,
+                                            const float *weight, float *coef, void *stream) {
+  if (n < 1 || !bn_width_ok(c) || n * (int64_t)c >= (1LL << 40)) return LINK_ERR_ARG;
+  if (!g || !x || !mean || !invstd || !scale || !shift || !partial || !sum_g || !sum_gx) return LINK_ERR_ARG;
+  const int wgs = link_bn_partial_workgroups(n, c);
+  hipStream_t st = S(stream);
+  hipLaunchKernelGGL((k_col_moments<true, true>), dim3(wgs), dim3(256), 0, st, x, g, mean, invstd, n, (int)c, partial, scale, shift);
+  hipLaunchKernelGGL(k_bn_finalize_backward, dim3((c + 15) / 16), dim3(256), 0, st, partial, wgs, (int)c, sum_g, sum_gx, weight, mean, invstd, n, coef);
+  return check_launch("link_bn_backward_reduce_relu");
+}
+
+extern "C" int link_bn_apply_backward(const float *g, const float *x, const float *mean, const float *coef, const float *scale,
+                                      const float *shift, int64_t n, int32_t c, float *gx, void *stream) {
+  if (n < 1 || !bn_width_ok(c) || n * (int64_t)c >= (1LL << 40) || !g || !x || !mean || !coef || !gx) return LINK_ERR_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  if (scale) hipLaunchKernelGGL((k_bn_apply<true, true>), dim3(bn_apply_grid(n, c)), dim3(256), 0, st, x, g, mean, scale, shift, coef, n, (int)c, gx);
+  else hipLaunchKernelGGL((k_bn_apply<true, false>), dim3(bn_apply_grid(n, c)), dim3(256), 0, st, x, g, mean, nullptr, nullptr, coef, n, (int)c, gx);
+  return check_launch("link_bn_apply_backward");
 }

@@ -25,7 +25,10 @@ class _BatchNormTrain(torch.autograd.Function):
     place; backward: grad_x = a * g + bq * (x - mean) + cq per channel, grad_weight = sum g * xhat, grad_bias = sum g."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu=False):
+        """relu: the ReLU that follows the BatchNorm in the reference's blocks (linkunet.py:23-38) applied in the same pass,
+        its gradient mask recomputed in the backward's two passes (round 5: one launch for the normalisation, one for the input
+        gradient, instead of torch's x - mean / addcmul / clamp and threshold_backward / x - mean / addcmul / addcmul_)."""
         from . import _lib as L
         n, c = x.shape
         x = x.contiguous()
@@ -42,7 +45,11 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.save_for_backward(x, vec, *((w,) if w is not None else ()))
         ctx.partial = partial
         ctx.has_wb = (weight is not None, bias is not None)
-        return torch.addcmul(vec[3], x - vec[0], vec[2])          # centred first, as torch's kernel: no cancellation
+        ctx.relu = bool(relu)
+        y = torch.empty_like(x)                                   # y = (x - mean) * scale + shift, centred first: no cancellation
+        L.check(lib.link_bn_apply_forward(x.data_ptr(), vec[0].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), n, c,
+                                          1 if relu else 0, y.data_ptr(), st), "link_bn_apply_forward")
+        return y
 
     @staticmethod
     def backward(ctx, g):
@@ -53,12 +60,24 @@ class _BatchNormTrain(torch.autograd.Function):
         g = g.contiguous()
         lib, st = L.lib(), L.current_stream_handle()
         out = torch.empty((5, c), dtype=torch.float32, device=x.device)           # sum_g | sum_gx | a | bq | cq
-        L.check(lib.link_bn_backward_reduce(g.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), n, c,
-                                            ctx.partial.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                            w.data_ptr() if w is not None else None, out[2].data_ptr(), st),
-                "link_bn_backward_reduce")
-        gx = torch.addcmul(out[4], g, out[2]).addcmul_(x - vec[0], out[3]) if ctx.needs_input_grad[0] else None
-        return gx, (out[1] if ctx.has_wb[0] else None), (out[0] if ctx.has_wb[1] else None), None, None, None, None
+        g = g.float()
+        if ctx.relu:                                          # g masked by y > 0 inside both passes (y recomputed from x)
+            L.check(lib.link_bn_backward_reduce_relu(g.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                     vec[3].data_ptr(), n, c, ctx.partial.data_ptr(), out[0].data_ptr(),
+                                                     out[1].data_ptr(), w.data_ptr() if w is not None else None, out[2].data_ptr(), st),
+                    "link_bn_backward_reduce_relu")
+        else:
+            L.check(lib.link_bn_backward_reduce(g.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), n, c,
+                                                ctx.partial.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                w.data_ptr() if w is not None else None, out[2].data_ptr(), st),
+                    "link_bn_backward_reduce")
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.check(lib.link_bn_apply_backward(g.data_ptr(), x.data_ptr(), vec[0].data_ptr(), out[2].data_ptr(),
+                                               vec[2].data_ptr() if ctx.relu else None, vec[3].data_ptr() if ctx.relu else None,
+                                               n, c, gx.data_ptr(), st), "link_bn_apply_backward")
+        return gx, (out[1] if ctx.has_wb[0] else None), (out[0] if ctx.has_wb[1] else None), None, None, None, None, None
 
 
 class BatchNorm(nn.BatchNorm1d):
@@ -67,16 +86,22 @@ class BatchNorm(nn.BatchNorm1d):
 
     hip_stats = True
 
-    def forward(self, input: SparseTensor) -> SparseTensor:
-        x = input.feats
-        if (self.hip_stats and self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 1
+    def _hip_train_ok(self, x: torch.Tensor) -> bool:
+        return (self.hip_stats and self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 1
                 and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024 and self.momentum is not None
-                and (self.weight is None or self.weight.dtype == torch.float32)):
+                and (self.weight is None or self.weight.dtype == torch.float32))
+
+    def forward(self, input: SparseTensor, relu: bool = False) -> SparseTensor:
+        """relu=True (used by the fused containers of fuse_for_inference in TRAINING mode): the ReLU module that follows this
+        BatchNorm runs inside its passes -- same values as BatchNorm then ReLU."""
+        x = input.feats
+        if self._hip_train_ok(x):
             rm, rv = (self.running_mean, self.running_var) if self.track_running_stats else (None, None)
             if self.track_running_stats and self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
-            return fapply(input, lambda f: _BatchNormTrain.apply(f, self.weight, self.bias, rm, rv, self.momentum, self.eps))
-        return fapply(input, super().forward)
+            return fapply(input, lambda f: _BatchNormTrain.apply(f, self.weight, self.bias, rm, rv, self.momentum, self.eps, relu))
+        out = fapply(input, super().forward)
+        return fapply(out, torch.relu) if relu else out
 
 
 class ReLU(nn.ReLU):
@@ -97,8 +122,20 @@ class _FusedSequential(nn.Sequential):
     def forward(self, input):
         mods = list(self)
         if torch.is_grad_enabled() or self.training or not isinstance(input, SparseTensor) or not input.F.is_cuda:
-            for m in mods:
+            # training / autograd: the modules one by one -- except that a ReLU straight after a BatchNorm in training mode runs
+            # inside the BatchNorm's passes (same values; hooks on either module keep the plain path)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if (isinstance(m, BatchNorm) and m.training and type(nxt) in (ReLU, nn.ReLU) and isinstance(input, SparseTensor)
+                        and m._hip_train_ok(input.feats) and not (m._forward_hooks or m._forward_pre_hooks or nxt._forward_hooks
+                                                                   or nxt._forward_pre_hooks)):
+                    input = m(input, relu=True)
+                    i += 2
+                    continue
                 input = m(input)
+                i += 1
             return input
         from .elk import fold_batchnorm
         i = 0

@@ -213,6 +213,48 @@ def test_batchnorm_training_statistics_on_the_hip_reductions(n, c):
     assert torch.equal(again(la.SparseTensor(x, coords, 1)).F, first)
 
 
+@pytest.mark.parametrize("n,c", [(59444, 64), (3005, 128), (7, 4)])
+def test_batchnorm_relu_in_one_pass_in_training_mode(n, c):
+    """Round 5: a ReLU straight after a training-mode BatchNorm runs inside the BatchNorm's passes (link_bn_apply_forward,
+    link_bn_backward_reduce_relu, link_bn_apply_backward) when the container went through fuse_for_inference -- same output, same
+    three gradients and running statistics as nn.BatchNorm1d + ReLU in fp64; a hook on either module keeps the plain path."""
+    import link_amd as la
+    torch.manual_seed(6)
+    x = (torch.randn(n, c) * torch.rand(c) * 3 + torch.randn(c) * 2).cuda()
+    gy = torch.randn(n, c).cuda()
+    coords = torch.zeros(n, 4, dtype=torch.int32).cuda()
+    seq = la.fuse_for_inference(torch.nn.Sequential(torch.nn.Sequential(la.Conv3d(c, c, 1), la.BatchNorm(c, eps=1e-3, momentum=0.01),
+                                                                        la.ReLU(True)))).cuda().train()[0]
+    bn = seq[1]
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda().double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    err = lambda a, b: rel_err(a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy())
+    calls = []
+    real = la.modules._BatchNormTrain.apply
+    xa, xb = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+    # the BatchNorm + ReLU tail of the fused container alone (the 1x1x1 convolution in front of it is not under test)
+    tail = type(seq)(bn, seq[2]).train()
+    tail._link_groups = {}
+    ya = tail(la.SparseTensor(xa, coords, 1)).F
+    yb = torch.relu(ref(xb))
+    ya.backward(gy); yb.backward(gy.double())
+    assert float(ya.min()) == 0.0 and err(ya, yb) < 5e-6 and err(xa.grad, xb.grad) < 1e-5
+    assert err(bn.weight.grad, ref.weight.grad) < 1e-5 and err(bn.bias.grad, ref.bias.grad) < 1e-5
+    assert err(bn.running_mean, ref.running_mean) < 1e-6 and err(bn.running_var, ref.running_var) < 1e-5
+    # the plain path (a forward hook observes the BatchNorm's own output) gives the same values
+    seen = {}
+    h = bn.register_forward_hook(lambda m, i, o: seen.__setitem__("pre_relu_min", float(o.F.min())))     # returns None: output kept
+    bn.zero_grad()
+    xc = x.clone().requires_grad_(True)
+    yc = tail(la.SparseTensor(xc, coords, 1)).F
+    yc.backward(gy)
+    h.remove()
+    assert seen["pre_relu_min"] < 0.0                     # the hook saw the un-rectified rows: the modules ran one by one
+    assert err(yc, yb) < 5e-6 and err(xc.grad, xb.grad) < 1e-5
+
+
 def test_fuse_for_inference_skips_batchnorm_without_running_statistics_and_invalidation_hook():
     """fuse_for_inference folds a BatchNorm only when it normalises with running statistics (affine optional); a Conv-BN
     group with track_running_stats=False keeps running module by module; writes through `.data` (which bump no tensor

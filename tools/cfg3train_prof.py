@@ -15,6 +15,15 @@ from link_amd.synth import s_kitti
 
 from link_amd import elk as E
 
+if os.environ.get("BN_FUSE") == "0":                   # A/B: the BatchNorm + ReLU passes of round 5 off (torch elementwise kernels)
+    from link_amd import modules as _M
+    _M.BatchNorm._hip_train_ok_orig = _M.BatchNorm._hip_train_ok
+    _M._FusedSequential.forward = lambda self, input: _plain(self, input)
+
+    def _plain(self, input):
+        for m in self:
+            input = m(input)
+        return input
 if os.environ.get("WGRAD_TABLE") is not None:          # A/B: table weight-gradient kernel (1, default) against the pair-list form (0)
     E.WGRAD_TABLE_SQUARE = bool(int(os.environ["WGRAD_TABLE"]))
 dev = torch.device("cuda", 0)
@@ -39,14 +48,15 @@ K = int(os.environ.get("K", 12))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-t0 = time.perf_counter()
-e0.record()
-for _ in range(K):
-    step()
-e1.record()
-torch.cuda.synchronize()
-print(f"cfg3 train step: wall {(time.perf_counter() - t0) / K * 1e3:.3f} ms/step, device span {e0.elapsed_time(e1) / K:.3f} ms/step, N = {coords.shape[0]}")
+for rep in range(int(os.environ.get("REPS", 1))):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(K):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"cfg3 train step: wall {(time.perf_counter() - t0) / K * 1e3:.3f} ms/step, device span {e0.elapsed_time(e1) / K:.3f} ms/step, N = {coords.shape[0]}")
 if os.environ.get("CPROF"):
     import cProfile
     import pstats
