@@ -420,7 +420,8 @@ def cfg3_mode(args, la, dev, rank, world, dist):
         x = la.SparseTensor(f, coords, 1)
         x.kmaps, x.cmaps = st0.kmaps, st0.cmaps
         if train:
-            net(x, 3, 2)[1][-1].F.square().sum().backward()
+            net.zero_grad(set_to_none=True)       # what a training loop does between steps (optimizer.zero_grad): without it every
+            net(x, 3, 2)[1][-1].F.square().sum().backward()   # step also ADDS its ~110 parameter gradients onto the previous step's
         else:
             with torch.no_grad():
                 net(x, 3, 2)

@@ -531,6 +531,13 @@ int link_subm_conv_ln_add_relu(const float *feats, const int32_t *nbr, const flo
 int32_t link_subm_conv_wgrad_chunks(void);
 int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c,
                          int32_t kvol, float *partial, void *stream);
+/* Round 5: the split is the caller's -- `chunks` pieces of the voxel range per offset, and `centre_extra` MORE pieces for the
+ * centre offset kvol / 2, whose column is dense on a submanifold table (every voxel pairs with itself: with one workgroup per
+ * (offset, chunk) its workgroups set the kernel's time).  partial f32[kvol * chunks + centre_extra][c][c]; g_w[k] = sum over
+ * chunk of slot [chunk * kvol + k], plus for k = kvol / 2 the slots from kvol * chunks on.  (conv.py:67-101, the reference's
+ * convolution backward.) */
+int link_subm_conv_wgrad_split(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c, int32_t kvol,
+                               int32_t chunks, int32_t centre_extra, float *partial, void *stream);
 
 /* Pair-list form of the same convolution, for sparse frames (few of the K neighbours present per voxel).
  * The kernel map is the reference's own: per kernel offset the list of (input row, output row) pairs

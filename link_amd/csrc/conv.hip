@@ -857,15 +857,26 @@ __global__ void __launch_bounds__(256) k_subm_conv_generic(const float *__restri
 // waves' accumulators are summed through LDS in a fixed order and written as one [C x C] partial per
 // (chunk, k): deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_subm_conv_wgrad(const float *__restrict__ feats,
+// Balance (round 5): on a submanifold table the centre offset's column is DENSE (every voxel pairs with itself) while the
+// other 26 hold a fifth of that on LiDAR frames -- with one workgroup per (offset, chunk) the centre's workgroups set the
+// kernel's time (284 us on the 113k-voxel stem of the cfg3 encoder, a quarter of whose training step was this kernel).  The
+// centre column is therefore cut into `chunks + centre_extra` pieces: workgroups [kvol * chunks, kvol * chunks + centre_extra)
+// take the extra pieces; partial slot = workgroup number either way.
+__global__ void __launch_bounds__(256, 4) k_subm_conv_wgrad(const float *__restrict__ feats,
                                                          const float *__restrict__ gout,
                                                          const int32_t *__restrict__ nbr_t, int64_t n, int c,
-                                                         int kvol, int chunks, float *__restrict__ partial) {
+                                                         int kvol, int chunks, int centre_extra, float *__restrict__ partial) {
   __shared__ int2 queue[4][96];                     // per wave: pending (in row, out row) pairs
-  __shared__ float red[4][16][4][64];               // [wave][r*4+q][e][lane]  (64 KB)
+  __shared__ float red[4][4][4][64];                // [wave][q][e][lane] of ONE r at a time (16 KB: the cross-wave sum runs in four
+                                                    // passes -- with the whole 64 KB image two workgroups filled a CU's LDS, i.e. two
+                                                    // waves per SIMD to hide the row gathers of a kernel that lives on them; round 5)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int k = blockIdx.x % kvol, chunk = blockIdx.x / kvol;
+  const int centre = kvol >> 1;
+  const bool extra_wg = (int)blockIdx.x >= kvol * chunks;
+  const int k = extra_wg ? centre : (int)blockIdx.x % kvol;
+  const int chunk = extra_wg ? chunks + ((int)blockIdx.x - kvol * chunks) : (int)blockIdx.x / kvol;
+  const int pieces = (k == centre && centre_extra > 0) ? chunks + centre_extra : chunks;
   const bool act = 4 * li < c;
   const int cofs = act ? 4 * li : 0;
   floatx4 acc[4][4];
@@ -875,7 +886,7 @@ __global__ void __launch_bounds__(256) k_subm_conv_wgrad(const float *__restrict
     for (int q = 0; q < 4; q++) acc[r][q] = (floatx4){0.f, 0.f, 0.f, 0.f};
   // voxel range of this wave: the chunk's range cut in 4, in units of 64 voxels
   const int64_t units = (n + 63) / 64;
-  const int64_t per_chunk = (units + chunks - 1) / chunks;
+  const int64_t per_chunk = (units + pieces - 1) / pieces;
   const int64_t u0 = (int64_t)chunk * per_chunk, u1 = (u0 + per_chunk < units) ? u0 + per_chunk : units;
   const int32_t *col = nbr_t + (int64_t)k * n;
   int2 *my_q = queue[wave];
@@ -927,20 +938,21 @@ __global__ void __launch_bounds__(256) k_subm_conv_wgrad(const float *__restrict
   }
   if (qn > 0) consume(0, qn);                       // tail (qn < 16)
   // fixed-order sum of the 4 waves, then one [C x C] partial per (chunk, k)
+  float *dst = partial + (int64_t)blockIdx.x * c * c;             // slot = workgroup number (= chunk * kvol + k below kvol * chunks)
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int r = 0; r < 4; r++) {
+    if (r) __syncthreads();                          // the previous pass has been read
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) red[wave][r * 4 + q][e][lane] = acc[r][q][e];
-  __syncthreads();
-  float *dst = partial + ((int64_t)chunk * kvol + k) * c * c;
-  for (int idx = tid; idx < 16 * 4 * 64; idx += 256) {
-    const int l = idx & 63, e = (idx >> 6) & 3, rq = idx >> 8;
-    const int r = rq >> 2, q = rq & 3;
-    const int ci = 4 * (4 * (l >> 4) + e) + r, co = 4 * (l & 15) + q;   // D[i = 4g+e][j = li] of product (r, q)
-    if (ci < c && co < c)
-      dst[ci * c + co] = (red[0][rq][e][l] + red[1][rq][e][l]) + (red[2][rq][e][l] + red[3][rq][e][l]);
+      for (int e = 0; e < 4; e++) red[wave][q][e][lane] = acc[r][q][e];
+    __syncthreads();
+    for (int idx = tid; idx < 4 * 4 * 64; idx += 256) {
+      const int l = idx & 63, e = (idx >> 6) & 3, q = idx >> 8;
+      const int ci = 4 * (4 * (l >> 4) + e) + r, co = 4 * (l & 15) + q;   // D[i = 4g+e][j = li] of product (r, q)
+      if (ci < c && co < c)
+        dst[ci * c + co] = (red[0][q][e][l] + red[1][q][e][l]) + (red[2][q][e][l] + red[3][q][e][l]);
+    }
   }
 }
 
@@ -953,8 +965,22 @@ extern "C" int link_subm_conv_wgrad(const float *feats, const float *gout, const
   if (n > 0 && (!feats || !gout || !nbr_t)) return LINK_ERR_ARG;
   const int chunks = link_subm_conv_wgrad_chunks();
   hipLaunchKernelGGL(k_subm_conv_wgrad, dim3((unsigned)(kvol * chunks)), dim3(256), 0, S(stream), feats, gout, nbr_t, n,
-                     (int)c, (int)kvol, chunks, partial);
+                     (int)c, (int)kvol, chunks, 0, partial);
   return check_launch("link_subm_conv_wgrad");
+}
+
+// Round 5: the caller picks the split.  partial = f32[(kvol * chunks + centre_extra)][c][c]; g_w[k] = sum over chunk of slot
+// [chunk * kvol + k], plus, for k = kvol / 2, the slots [kvol * chunks, kvol * chunks + centre_extra).  centre_extra > 0 only
+// for tables whose centre column is dense (odd kernel over one coordinate set).
+extern "C" int link_subm_conv_wgrad_split(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c,
+                                          int32_t kvol, int32_t chunks, int32_t centre_extra, float *partial, void *stream) {
+  if (n < 0 || c <= 0 || c > 64 || (c & 3) != 0 || kvol <= 0 || chunks < 1 || chunks > 1024 || centre_extra < 0 || centre_extra > 4096)
+    return LINK_ERR_ARG;
+  if (!partial) return LINK_ERR_ARG;
+  if (n > 0 && (!feats || !gout || !nbr_t)) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_subm_conv_wgrad, dim3((unsigned)(kvol * chunks + centre_extra)), dim3(256), 0, S(stream), feats, gout, nbr_t, n,
+                     (int)c, (int)kvol, (int)chunks, (int)centre_extra, partial);
+  return check_launch("link_subm_conv_wgrad_split");
 }
 
 static constexpr int g_conv_wgs = 1024;  // cap (sweep recorded in DESIGN.md 4b)

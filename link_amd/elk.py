@@ -1712,16 +1712,24 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
         return gw
     if cin == cout and cin <= 64 and cin % 4 == 0 and (WGRAD_TABLE_SQUARE or len(kernel_shape) != 3):
         lib = L.lib()
-        chunks = int(lib.link_subm_conv_wgrad_chunks())
         nbr_t = getattr(nbr, "_link_t", None)          # transposed table cached on the (kmaps-cached) tensor
         if nbr_t is None:
             nbr_t = nbr.t().contiguous()
             nbr._link_t = nbr_t
-        part = torch.empty((chunks, kvol, cin, cout), dtype=torch.float32, device=g.device)
+        # the split: enough pieces to fill the chip on big frames, and the DENSE centre column of a submanifold table (every
+        # voxel pairs with itself; the other offsets hold a fifth of that on LiDAR frames) cut four times finer -- its
+        # workgroups set the kernel's time otherwise (284 -> ~80 us on the 113k-voxel stem of the cfg3 encoder)
+        chunks = 16 if n_out < 16000 else (32 if n_out < 60000 else 64)
+        dense_centre = bool(getattr(nbr, "_link_subm", False)) and kvol % 2 == 1 and kvol > 1 and n_out >= 4096
+        extra = 3 * chunks if dense_centre else 0
+        part = torch.empty((chunks * kvol + extra, cin, cout), dtype=torch.float32, device=g.device)
         f = feats.detach().contiguous().float()
-        L.check(lib.link_subm_conv_wgrad(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n_out, cin, kvol,
-                                         part.data_ptr(), _st()), "link_subm_conv_wgrad")
-        return part.sum(0)
+        L.check(lib.link_subm_conv_wgrad_split(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n_out, cin, kvol, chunks, extra,
+                                               part.data_ptr(), _st()), "link_subm_conv_wgrad_split")
+        gw = part[: chunks * kvol].view(chunks, kvol, cin, cout).sum(0)
+        if extra:
+            gw[kvol // 2] += part[chunks * kvol:].sum(0)
+        return gw
     padded = torch.cat([feats.detach().float(), feats.new_zeros(1, cin)], dim=0)
     idx = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr).long()
     return torch.stack([_weight_grad(padded[idx[:, k]], g) for k in range(kvol)], 0)

@@ -41,6 +41,8 @@ def step():
     f = feats.detach().requires_grad_(True)
     x = la.SparseTensor(f, coords, 1)
     x.kmaps, x.cmaps = st0.kmaps, st0.cmaps
+    if os.environ.get("ZERO_GRAD", "1") == "1":
+        net.zero_grad(set_to_none=True)
     net(x, 3, 2)[1][-1].F.square().sum().backward()
 
 
