@@ -2011,7 +2011,10 @@ class _ELKBase(nn.Module):
         plan.run(feats.contiguous(), coords.contiguous(), build_index=rebuild, out=out)
         plan._indexed = ikey
         plan._keepalive = coords                             # the pointer in ikey stays valid while we hold it
-        if rebuild:
+        if rebuild and k < int(s_eff) ** 3:
+            # only a slot list SMALLER than what unique coordinates could fill rests on the stride promise; at k = s_eff^3
+            # (tensor stride 1: the detection blocks) it cannot overflow without duplicate coordinates, and the ~20 us of host
+            # time per block (pinned copy + event) stay off the sync-free detection path
             self._lean_post_verdict(plan, int(s_eff), ts, k)
         st.kmaps[vkey] = True
         return out
