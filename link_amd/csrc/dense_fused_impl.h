@@ -40,6 +40,9 @@ using namespace link;
 #ifndef DC_K1_SUMB
 #define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
 #endif
+#ifndef DC_K1_PRIO
+#define DC_K1_PRIO 0
+#endif
 #ifndef DC_K1_SWAP_SUMS
 #define DC_K1_SWAP_SUMS 1  /* LayerNorm statistics over a voxel's four lane groups through v_permlane32_swap / v_permlane16_swap (VALU) instead
                               of two ds_bpermute each: four dependent LDS round trips per tile leave the wave's chain (round 5) */
@@ -163,6 +166,9 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     const int32_t *__restrict__ occ = nullptr) {
   using K = dc_k1_cfg<C, OP>;
   DC_PROF_PTR(dbg);
+#if DC_K1_PRIO
+  __builtin_amdgcn_s_setprio(DC_K1_PRIO);               // A/B (round 5): wave priority of the pre_mix kernel against a co-resident gather kernel
+#endif
   // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime deltas
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_fill = 0, tq_body = 0, tq_sum = 0;
   int tq_tiles = 0;
@@ -285,15 +291,18 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
     nv = nv < g.k ? nv : g.k;
     nv = nv < LCAPX ? nv : LCAPX;
     if (lane >= nrem) nv = 0;
-    int incl = nv;                                      // inclusive prefix over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
+    int incl = nv;                                      // inclusive prefix over the wave: DPP row scan (zeros shifted in) + the three row
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // totals as scalars (round 5; were six dependent ds_bpermute
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // round trips per chunk: the __shfl_up form)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+    {
+      const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+      incl += gq == 0 ? 0 : (gq == 1 ? t0 : (gq == 2 ? t0 + t1 : t0 + t1 + t2));
     }
     const unsigned long long fit = __ballot(lane < nrem && incl <= LCAPX);
     const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
-    const int Ttot = __builtin_amdgcn_readfirstlane(__shfl(incl, nfit - 1, 64));
+    const int Ttot = __builtin_amdgcn_readlane(incl, nfit - 1);
     if constexpr (SPARSE) {
       // cooperative fetch (dc_sparse_fetch): list positions [0, 128) of the wave's list, sseg behind scell's first 128 entries,
       // the id scratch behind the list's first 128 records

@@ -51,6 +51,15 @@
                             tiles on the grid's rim (1 of 4 columns inside) keep one wave busy -- before, every consumer wave issued
                             the whole round for slots without a voxel (round 5: -19 % of the kernel's VALU instructions) */
 #endif
+#ifndef DC_K2Q_RIM
+#define DC_K2Q_RIM 1
+#endif
+#ifndef DC_K2_PRIO_ALL
+#define DC_K2_PRIO_ALL 0
+#endif
+#ifndef DC_K2_PRIO_PROD
+#define DC_K2_PRIO_PROD 0
+#endif
 #ifndef DC_K2Q_FMA
 #define DC_K2Q_FMA 1     /* de-modulation A0 cos + A1 sin as mul + fma (0: separate IEEE mul / mul / add like the reference's eager
                             ops -- the difference is one rounding, 6e-8 relative, next to the hardware trig's 4e-7) */
@@ -159,6 +168,9 @@ __device__ __forceinline__ void dc_k2q_body(
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
   DC_PROF_PTR(dbg);
+#if DC_K2_PRIO_ALL
+  __builtin_amdgcn_s_setprio(DC_K2_PRIO_ALL);           // A/B (round 5): wave priority of the whole gather kernel against co-resident kernels
+#endif
   // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
   // the quad round
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
@@ -204,6 +216,9 @@ __device__ __forceinline__ void dc_k2q_body(
     par[threadIdx.x] = threadIdx.x < 64 ? ln_w[threadIdx.x] : ln_b[threadIdx.x - 64];
   }
   if (producer) {
+#if DC_K2_PRIO_PROD
+    __builtin_amdgcn_s_setprio(DC_K2_PRIO_PROD);        // A/B (round 5): the producers' chain is the plane step's critical path
+#endif
     // ================= producers: plane ring (LDS-DMA, 3 slots, prefetch distance 2) + box sums -> A rows =================
     auto col_cell0 = [&](int hx, int hy) {           // padded cell id of (haloed column, z = 0), clamped into the grid
       int px = x0 + 1 - HLO + hx, py = y0 + 1 - HLO + hy;
@@ -286,8 +301,21 @@ __device__ __forceinline__ void dc_k2q_body(
                                          (__attribute__((address_space(3))) void *)(lds + K2::SPLIT_REC_OFF + (plane & 3) * K2::REC_BYTES + wave * 256), 16, 0, 0);
     };
     const int grp = tid >> 4, li = tid & 15;
-    const int ix = grp / TY, iy = grp % TY;
+    // Rim tiles (DC_K2Q_RIM, round 5).  The 4 x 4 tiling of a 37 x 37 grid has 19 rim tiles of 100 whose columns beyond the grid
+    // hold nothing; their producer waves used to form box sums for them all the same (a quarter of a rim tile's columns are real).
+    // A producer wave whose four lane groups are all outside skips the plane's reads, sums and row writes -- it still issues its
+    // share of the plane DMA and keeps the barriers.  Wave w owns columns ix = w (groups 4w .. 4w+3 = iy 0..3), which makes whole
+    // waves idle on the x rim only; on the y rim the (group -> column) map is transposed (wave w owns iy = w).  The A image and
+    // the counts stay addressed by the canonical cell number ix * TY + iy the mapper and the consumers use.
+    const bool rim_t = DC_K2Q_RIM && (y0 + TY > Dy) && (x0 + TX <= Dx);      // workgroup-uniform
+    const int ix = rim_t ? grp % TX : grp / TY, iy = rim_t ? grp / TX : grp % TY;
+    const int cell = ix * TY + iy;
     const bool col_ok = (x0 + ix < Dx) && (y0 + iy < Dy);
+    const bool wave_has = (DC_K2Q_RIM && DC_K2Q_PMAP) ? __any(col_ok) : true;   // wave-uniform
+    if (!wave_has && li == 0) {                        // its cells hold nothing in any plane: both count images say so once (the
+      lds_wr_b32(ncnt0 + (uint32_t)(cell * 4), 0);     // consumers walk them for planes of more than 64 voxels)
+      lds_wr_b32(ncnt0 + (uint32_t)(K2::NG * 4 + cell * 4), 0);
+    }
     const uint32_t row_lane = (uint32_t)((ix * HY + iy) * RB + li * 16);
     const uint32_t cnt_lane = (uint32_t)((ix * HY + iy) * 4);
     float4 r0[P], r1[P];
@@ -311,6 +339,7 @@ __device__ __forceinline__ void dc_k2q_body(
       if (i >= nplanes) break;
       if (i + 2 < nplanes) issue(i + 2, m3p2, true);
       const uint32_t bufa = lds_base + (uint32_t)(m3 * K2::SPLIT_BUF_BYTES);
+      if (!wave_has) continue;                            // rim tile: none of this wave's columns lies inside the grid
       float4 cur[P];
       float cc = 0.f;
 #pragma unroll
@@ -347,9 +376,9 @@ __device__ __forceinline__ void dc_k2q_body(
         const float inv = den > 0.f ? 1.0f / den : 0.f;
 #pragma unroll
         for (int pp = 0; pp < P; pp++)
-          lds_wr_b128(abuf + (uint32_t)(grp * RB + pp * C * 4 + li * 16),
+          lds_wr_b128(abuf + (uint32_t)(cell * RB + pp * C * 4 + li * 16),
                       make_float4(a[pp].x * inv, a[pp].y * inv, a[pp].z * inv, a[pp].w * inv));
-        if (li == 0) lds_wr_b32(ncnt + (uint32_t)(grp * 4), col_ok ? n_prev : 0);   // the plane that closed is the previous one for both R
+        if (li == 0) lds_wr_b32(ncnt + (uint32_t)(cell * 4), col_ok ? n_prev : 0);   // the plane that closed is the previous one for both R
       }
 #pragma unroll
       for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
