@@ -766,9 +766,19 @@ def main():
     # settling phase of SETTLE_STEPS of the same steps (~60 ms) brings it to operating clocks before the W warm-up steps and the timed
     # K (at the driver's --steps 20 --warmup 5 the timed region is 2.5 ms: 41.8 us/frame without it, 39-40 with, the
     # figure a 200-step run reports either way)
-    timed(SETTLE_STEPS)                              # a fixed count: every rank passes the same barriers
+    # Round 5: the settling steps are issued in REGIONS OF THE TIMED SHAPE -- K steps between synchronisations -- instead of one
+    # long run.  tools/graphstep.py, 20-step regions back to back on one box: 39.3 38.8 38.3 37.2 36.7 36.1 ... settling at 34.8-35.0
+    # us/frame after ~10 regions (a 600-step run on the same box: 33.2): a device that has just worked through one long burst
+    # answers the first short bursts 10 % slower, so a 2 ms timed region has to be preceded by bursts of its own length.  Same
+    # step count as before (>= SETTLE_STEPS; a fixed number of regions: every rank passes the same barriers).
+    import gc
+    for _ in range(max(3, -(-SETTLE_STEPS // max(args.steps, 1)))):
+        timed(args.steps)
+    gc.collect()
+    gc.disable()                                     # no collection inside the warm-up / timed regions (re-enabled right after)
     timed(max(args.warmup, 1))
     elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt for every frame)
+    gc.enable()
     # what was just timed is what gets checked: every plan's output under the timed configuration (NS frames in flight,
     # their launch geometry), kept for the comparison with the single-frame geometry below and with the oracle
     outs_timed = [o.clone() for o in last_out]       # the rows the timed steps wrote, in the row type they were written in
@@ -1007,7 +1017,7 @@ def main():
     line = {
         "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
         "value": round(total_vox * frames_timed / elapsed, 1), "unit": "voxels/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "settle_steps_before_warmup": SETTLE_STEPS, "ms_per_step": round(ms, 5),
+        "steps": args.steps, "warmup": args.warmup, "settle_steps_before_warmup": max(3, -(-SETTLE_STEPS // max(args.steps, 1))) * args.steps, "ms_per_step": round(ms, 5),
         "ms_per_step_event_median": round(batch_ev["median_us"] * 1e-3, 5), "batch_period_events": batch_ev,
         "frames_per_step": NS * world,
         "us_per_frame": round(1e6 * elapsed / frames_timed, 2), "higher_is_better": True,
