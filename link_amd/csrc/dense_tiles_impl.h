@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
   };
   if (c_begin < c_end) load_chunk(c_begin);
   // stage W (fp16 hi | lo image) and the parameters; a weight outside the fp16 split's range: fp32 contraction
-  bool w_big = dc_stage_weights<C, 64 * K::NW>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
+  bool w_big = dc_stage_weights<C, 64 * K::NW, LINK_TILE_EXACT(OP)>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
   for (int i = lane; i < K::CARRY_BYTES / 4; i += 64) carry[i] = 0.f;     // read unconditionally by every tile (times 0 unless a cell straddles)
   if (blockIdx.x == 0 && tid == 0 && !warm) {          // publish the step's status word
     hdr[LINK_HDR_STATUS] = hdr[LINK_HDR_STATUS_ACC];
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256, DC_T2_WAVES) k_dc_tiles(
       for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){ff[tp].x, ff[tp].y, ff[tp].z, ff[tp].w};
       return;
     }
-    dc_premix_tile<C>(wh, w_pre, w_big, li, gq, ff, cc);
+    dc_premix_tile<C, LINK_TILE_EXACT(OP)>(wh, w_pre, w_big, li, gq, ff, cc);
   };
 
   for (int chunk = c_begin; chunk < c_end; chunk += 64) {

@@ -139,6 +139,12 @@ __device__ __forceinline__ void sincos_hw(float x, float &sn, float &cs) {
 #ifndef LINK_COSX_EXACT
 #define LINK_COSX_EXACT 1
 #endif
+// The tile kernels (tile_common.h: dc_stage_weights / dc_premix_tile) take the exact contraction from an fp32 image of W in LDS;
+// LINK_TILES_EXACT_ALL 1 makes them do so for every operator (A/B switch, docs/experiments.md 5e).
+#ifndef LINK_TILES_EXACT_ALL
+#define LINK_TILES_EXACT_ALL 0
+#endif
+#define LINK_TILE_EXACT(OP) ((LINK_COSX_EXACT && (OP) == LINK_OP_COSX) || LINK_TILES_EXACT_ALL)
 
 template <int LPR>
 __device__ __forceinline__ float grp_sum(float v) {

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
     if constexpr (T > 2) { ff[2] = io_ldb4<32>(r_feats, ro); ff[3] = io_ldb4<48>(r_feats, ro); }
     if constexpr (T > 4) { ff[4] = io_ldb4<64>(r_feats, ro); ff[5] = io_ldb4<80>(r_feats, ro); ff[6] = io_ldb4<96>(r_feats, ro); ff[7] = io_ldb4<112>(r_feats, ro); }
   }
-  bool w_big = dc_stage_weights<C, 256>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
+  bool w_big = dc_stage_weights<C, 256, LINK_TILE_EXACT(OP)>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
   // ---- slot insert: the lane group gq == 0 of each wave speaks for the tile's 16 voxels; the atomic is on its way while
   // the tile is worked on ----
   const bool ins = a.build && valid && gq == 0;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, (C <= 64 ? 3 : 1)) k_lean_insert_premix(c
   w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // cos_x: exact contraction (elk_common.h)
   const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
   floatx4 ac[T];
-  dc_premix_tile<C>(wh, a.w_pre, w_big, li, gq, ff, ac);
+  dc_premix_tile<C, LINK_TILE_EXACT(OP)>(wh, a.w_pre, w_big, li, gq, ff, ac);
   float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
   if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
   float th[NB][4], sn[NB][4], cs[NB][4];
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, (C <= 32 ? 3 : 2)) k_lean_sums_pm(const l
   int idx = j0 >> 4;
   int it_n = idx < a.idx_cap ? a.occ[(int64_t)sg * a.seg_cap + idx] : 0;
   const int step = (int)(gridDim.x * 4) >> 4;
-  bool w_big = dc_stage_weights<C, 256>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
+  bool w_big = dc_stage_weights<C, 256, LINK_TILE_EXACT(OP)>(smem_raw, a.w_pre, a.pre_ln_w, a.pre_ln_b, a.w_pos, a.alpha, a.cg, tid);
   w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // before any wave leaves; cos_x: exact contraction
   const unsigned short *wh = reinterpret_cast<const unsigned short *>(smem_raw);
   const __amdgpu_buffer_rsrc_t r_feats = dc_rsrc(a.feats, (uint32_t)((int64_t)a.n * C * IO_BYTES));
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256, (C <= 32 ? 3 : 2)) k_lean_sums_pm(const l
         if constexpr (T > 4) { ff[4] = io_ldb4<64>(r_feats, ro); ff[5] = io_ldb4<80>(r_feats, ro); ff[6] = io_ldb4<96>(r_feats, ro); ff[7] = io_ldb4<112>(r_feats, ro); }
       }
       floatx4 ac[T];
-      dc_premix_tile<C>(wh, a.w_pre, w_big, li, gq, ff, ac);
+      dc_premix_tile<C, LINK_TILE_EXACT(OP)>(wh, a.w_pre, w_big, li, gq, ff, ac);
       float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
       if (a.coord_div != 1.0f) { x = x / a.coord_div; y = y / a.coord_div; z = z / a.coord_div; }
       float th[NB][4], sn[NB][4], cs[NB][4];

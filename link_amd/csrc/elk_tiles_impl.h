@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
   int blk0, blk1;
   ld_rec(0, rec0, blk0);
   ld_rec(1, rec1, blk1);
-  bool w_big = dc_stage_weights<C, 64 * K::NW>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
+  bool w_big = dc_stage_weights<C, 64 * K::NW, LINK_TILE_EXACT(OP)>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, tid);
   for (int i = lane; i < K::CARRY_BYTES / 4; i += 64) carry[i] = 0.f;     // read unconditionally by every tile (times 0 unless a block straddles)
   w_big = __syncthreads_or(w_big) != 0 || (LINK_COSX_EXACT && OP == LINK_OP_COSX);   // cos_x: exact contraction (elk_common.h)
   if (a >= e) return;                                  // nominal span inside one block that an earlier workgroup owns
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, (elk_t_cfg<C, OP>::WAVES)) k_elk_tiles(
       ELK_T_TICK(tb);
       tq_rows += tb - ta;
 #endif
-      dc_premix_tile<C>(wh, w_pre, w_big, li, gq, ff, ac);
+      dc_premix_tile<C, LINK_TILE_EXACT(OP)>(wh, w_pre, w_big, li, gq, ff, ac);
 #ifdef ELK_T_DBG
       asm volatile("s_nop 0" ::"v"(ac[0][0]));
       ELK_T_TICK(tc);

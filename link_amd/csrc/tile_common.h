@@ -53,7 +53,11 @@ __device__ __forceinline__ int dc_dpp_i(int v, int oob) {      // lanes without 
 
 // Stage the image with NT threads (NT >= 2C): all loads, ONE wait, then the writes.  Returns whether THIS thread saw a
 // weight outside the fp16 split's range (the caller ORs over the workgroup with its barrier: then the fp32 instruction runs).
-template <int C, int NT>
+// EXACT (round 5, cos_x: elk_common.h LINK_COSX_EXACT): the image holds W itself in fp32, row co = C floats + 4 of padding -- the
+// same bytes per row as the hi | lo image, so every LDS layout behind it is unchanged -- and dc_premix_tile<C, true> runs the exact
+// fp32 matrix instruction from it (the "outside the fp16 range" path reads W from global memory per tile: fine for a rarity, not
+// for the form every cos_x block takes).
+template <int C, int NT, bool EXACT = false>
 __device__ __forceinline__ bool dc_stage_weights(char *smem_raw, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
                                                  const float *__restrict__ ln_b, const float *__restrict__ w_pos,
                                                  const float *__restrict__ alpha, int cg, int tid) {
@@ -77,12 +81,17 @@ __device__ __forceinline__ bool dc_stage_weights(char *smem_raw, const float *__
       if (NF4 % NT != 0 && e >= C * C) e = 0;         // C = 16: surplus lanes rewrite piece 0 with its own value
       const int r = e / C, col = e - r * C;
       const float4 wq = (NF4 % NT == 0 || (i * NT + tid) * 4 < C * C) ? wv[i] : *reinterpret_cast<const float4 *>(&w_pre[0]);
-      uint2 hi, lo;
-      dc_split4(wq, hi, lo);
-      unsigned short *wh = reinterpret_cast<unsigned short *>(smem_raw);
-      *reinterpret_cast<uint2 *>(&wh[r * WI::LDH + col]) = hi;
-      *reinterpret_cast<uint2 *>(&wh[r * WI::LDH + C + col]) = lo;
-      w_big |= !(fmaxf(fmaxf(fabsf(wq.x), fabsf(wq.y)), fmaxf(fabsf(wq.z), fabsf(wq.w))) < 32768.0f);
+      if constexpr (EXACT) {
+        static_assert(WI::LDH * 2 == (C + 4) * 4, "fp32 rows of C + 4 floats fill the hi | lo image's rows exactly");
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(smem_raw) + r * (C + 4) + col) = wq;
+      } else {
+        uint2 hi, lo;
+        dc_split4(wq, hi, lo);
+        unsigned short *wh = reinterpret_cast<unsigned short *>(smem_raw);
+        *reinterpret_cast<uint2 *>(&wh[r * WI::LDH + col]) = hi;
+        *reinterpret_cast<uint2 *>(&wh[r * WI::LDH + C + col]) = lo;
+        w_big |= !(fmaxf(fmaxf(fabsf(wq.x), fabsf(wq.y)), fmaxf(fabsf(wq.z), fabsf(wq.w))) < 32768.0f);
+      }
     }
     if (tid < C) ln_lds_[tid] = ln_w[tid];
     else if (tid < 2 * C) ln_lds_[tid] = ln_b[tid - C];
@@ -98,13 +107,31 @@ __device__ __forceinline__ bool dc_stage_weights(char *smem_raw, const float *__
 // ---- pre_mix contraction of one tile: D[co][voxel] = sum_ci W[co][ci] x[voxel][ci] as an fp16 hi/lo split of both
 // operands on v_mfma_f32_16x16x32_f16 (exact products, fp32 accumulation, the dropped lo*lo term is 2^-22 relative;
 // fp16 rows have lo = 0); |x| or |w| >= 2^15 takes the fp32 instruction with W from global memory, wave-uniform ----
-template <int C>
+template <int C, bool EXACT = false>
 __device__ __forceinline__ void dc_premix_tile(const unsigned short *wh, const float *__restrict__ w_pre, bool w_big, int li, int gq,
                                                const float4 (&ff)[C / 16], floatx4 (&cc)[C / 16]) {
   using WI = dc_wimg<C>;
   constexpr int T = C / 16;
 #pragma unroll
   for (int tp = 0; tp < T; tp++) cc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (EXACT) {                                // W in fp32 in LDS (dc_stage_weights<C, NT, true>): the exact matrix instruction
+    const float *wf = reinterpret_cast<const float *>(wh);
+#pragma unroll
+    for (int tt = 0; tt < T; tt++) {
+      float4 a[T];
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) a[tp] = *reinterpret_cast<const float4 *>(&wf[(16 * tp + li) * (C + 4) + 16 * tt + 4 * gq]);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].x, ff[tt].x, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].y, ff[tt].y, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].z, ff[tt].z, cc[tp], 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < T; tp++) cc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tp].w, ff[tt].w, cc[tp], 0, 0, 0);
+    }
+    return;
+  }
   uint2 bh[T], bl[T];
   float mx = 0.f;
 #pragma unroll
