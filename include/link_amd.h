@@ -37,7 +37,7 @@ extern "C" {
 /* Version of this ABI (bumped on any signature change). */
 int link_abi_version(void);
 /* sizeof of the structs crossing this boundary (0 link_grid_t, 1 link_elk_desc_t, 2 link_elk_buffers_t, 3 link_dc_grid_t,
- * 4 link_dc_tuning_t, 5 link_dc_buffers_t, 6 link_lean_buffers_t; -1 otherwise): what a binding checks its own layout against. */
+ * 4 link_dc_tuning_t, 5 link_dc_buffers_t, 6 link_lean_buffers_t, 7 link_block_args_t; -1 otherwise): what a binding checks its own layout against. */
 int32_t link_abi_struct_size(int32_t which);
 /* Human-readable last HIP error string of the calling thread ("" if none). Host pointer. */
 const char *link_last_error(void);
@@ -874,6 +874,70 @@ int link_bn_backward_reduce_relu(const float *g, const float *x, const float *me
                                  const float *weight /* NULL: 1 */, float *coef /* [3c] */, void *stream);
 int link_bn_apply_backward(const float *g, const float *x, const float *mean, const float *coef, const float *scale /* NULL: no relu */,
                            const float *shift, int64_t n, int32_t c, float *gx, void *stream);
+
+/* =============================================================================================
+ * G. One host call per LinK block on a NEW coordinate set (round 5)
+ *
+ * ELKBlock.forward / TSELKBlock.forward_ of the reference is one Python call that rebuilds every map of its coordinate set
+ * (linkunet.py:124-185: voxel_to_aux's hash / unique / query chain, utils.py:44-52; the 3x3x3 convolution's kernel map with
+ * `nbsizes.cpu()`, nn/functional/conv.py:103-122).  link_elk_block_forward is that call for the inference forward on the
+ * dense-cell layout: bounding box + slot insert with occupancy counters -> ONE host round trip -> R_core (section E) on the
+ * caller's stream, behind the 27-neighbour table read off the frame's slot lists (link_dc_neighbor_map), while the context's side
+ * stream lays the pair plan out on the device and runs the pair GEMM (section D) -> the convolution's finish: centre offset + pair sums + LayerNorm + add(R_core) + ReLU.
+ * The frame is TRIED on the plan the caller hands over (the module's last plan: frames of a stream share their grid): when a voxel
+ * lies outside that grid or the occupancy is not what the dense-cell kernels are built for (more than mean_max voxels per occupied
+ * cell on average / cell_max in the fullest), the call returns
+ * LINK_BLOCK_MISS with bbox / stats filled in and nothing of the frame left in the plan (counters and status word zeroed) --
+ * the caller continues on its per-stage entry points without measuring the bounds again.
+ * fp32 rows, C = cin = cout with link_conv_pairs_supported(C, C), a submanifold table (subm != 0: unique coordinates, so the centre
+ * column is the identity -- verified on the device, pair header word 3).  LINK_ERR_WORKSPACE when pair_arena / contrib are smaller
+ * than link_pair_plan_arena says.  The context owns a non-blocking side stream, two events and 2 x 1 KB of scratch (device +
+ * pinned host); create one per device and host thread.
+ * ============================================================================================= */
+typedef struct link_block_ctx link_block_ctx_t;
+int link_block_ctx_create(link_block_ctx_t **out);     /* on the current device */
+int link_block_ctx_destroy(link_block_ctx_t *ctx);
+/* Word offsets (16-byte aligned pieces) of the arena link_pair_plan_build works in with capacity-sized lists:
+ * offs[0..9] = wg_counts | row_info | base_k + wg_base + gran_start | wg_ext | wg_k | hdr | ext_start | pair_in | pair_out |
+ * ext_list, offs[10] = total words.  Returns the granule capacity (contribution rows = 128 x that) or -1. */
+int64_t link_pair_plan_arena(int64_t n, int32_t kvol, int32_t skip_centre, int64_t offs[11]);
+
+/* The 3x3x3 neighbour table of a frame from its freshly inserted slot lists (between link_dc_index / link_dc_index_probe and the
+ * pre_mix kernel, which re-orders the lists and resets the counters): nbr i32[n, 27], entry [i][k] = row of the voxel at
+ * coords[i] + offset_k * step in get_kernel_offsets(3) order, -1 absent -- the table of link_cell_table_build + link_neighbor_map
+ * (conv.py:103-113) without the voxel-resolution cell table.  Voxels the insert dropped (outside the grid) are absent. */
+int link_dc_neighbor_map(const int32_t *coords, int64_t n, const link_dc_grid_t *g /* host */, const uint32_t *cnt,
+                         const int32_t *slots, int32_t step, int32_t *nbr, void *stream);
+
+#define LINK_BLOCK_DONE 0
+#define LINK_BLOCK_MISS 1
+typedef struct {
+  const link_dc_buffers_t *buf;   /* the plan the frame is tried on; feats / coords = the frame, out = R_core's rows [n, C]
+                                     (the convolution's addend), parameters bound */
+  const link_dc_grid_t *g;
+  const link_elk_desc_t *desc;
+  int64_t n;
+  int32_t mean_max, cell_max;     /* occupancy the dense-cell kernels take: voxels per occupied cell, mean and maximum */
+  int32_t ts;                     /* tensor stride: neighbour of voxel i at coords_i + offset * ts (conv.py:105-113) */
+  int32_t subm;                   /* the coordinates are unique (must be non-zero) */
+  int32_t *nbr;                   /* out: i32[n, 27] neighbour table (kept by the caller for later layers on these coordinates) */
+  int32_t *pair_arena;            /* out: the pair plan (link_pair_plan_arena layout) */
+  int64_t pair_arena_words;
+  float *contrib;                 /* scratch: contribution rows f32[contrib_rows, C] */
+  int64_t contrib_rows;
+  const float *w;                 /* local_mix kernel f32[27, C, C] */
+  const void *ws;                 /* its fp16 hi | lo split (link_conv_pairs_gemm_split), or NULL: link_conv_pairs_gemm_io */
+  const int32_t *w_big;
+  const float *nl_w, *nl_b;       /* norm_local */
+  float nl_eps;
+  int32_t flags;                  /* bit 0: ReLU */
+  void *out;                      /* [n, C]: relu(R_core + LayerNorm(conv(feats))) */
+  int32_t bbox[8];                /* results (host): min x,y,z,b, max x,y,z,b */
+  int32_t stats[4];               /* voxels inside the plan's grid, occupied cells, fullest cell, miss reasons (1 outside, 2 occupancy) */
+  int32_t verdict;                /* LINK_BLOCK_DONE / LINK_BLOCK_MISS */
+  int32_t reserved;
+} link_block_args_t;
+int link_elk_block_forward(link_block_ctx_t *ctx, link_block_args_t *args /* host, in/out */, void *stream);
 
 #ifdef __cplusplus
 }

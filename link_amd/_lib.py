@@ -19,7 +19,7 @@ OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 ELK_LEAN_CS, ELK_LEAN_NO_CS, ELK_LEAN_PM, ELK_LEAN_NO_PM = 32, 64, 128, 256
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -90,6 +90,18 @@ class LinkLeanBuffers(Structure):
 
 
 LEAN_KMAX, LEAN_SEGS, LEAN_CHUNK = 352, 16, 32
+BLOCK_DONE, BLOCK_MISS = 0, 1
+
+
+class LinkBlockArgs(Structure):
+    """link_block_args_t (section G: one host call per LinK block on a new coordinate set)"""
+    _fields_ = [("buf", POINTER(LinkDcBuffers)), ("g", POINTER(LinkDcGrid)), ("desc", POINTER(LinkElkDesc)), ("n", c_int64),
+                ("mean_max", c_int32), ("cell_max", c_int32), ("ts", c_int32), ("subm", c_int32),
+                ("nbr", c_void_p), ("pair_arena", c_void_p),
+                ("pair_arena_words", c_int64), ("contrib", c_void_p), ("contrib_rows", c_int64), ("w", c_void_p), ("ws", c_void_p),
+                ("w_big", c_void_p), ("nl_w", c_void_p), ("nl_b", c_void_p), ("nl_eps", c_float), ("flags", c_int32),
+                ("out", c_void_p), ("bbox", c_int32 * 8), ("stats", c_int32 * 4), ("verdict", c_int32), ("reserved", c_int32)]
+
 
 # name -> (restype, argtypes); every symbol include/link_amd.h declares
 SIGNATURES = {
@@ -236,6 +248,11 @@ SIGNATURES = {
     "link_dc_gather_demod": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc), c_int64, c_void_p]),
     "link_dc_demod": (c_int, [c_void_p] * 8 + [POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_int64, c_void_p, c_int32,
                               c_void_p]),
+    "link_block_ctx_create": (c_int, [POINTER(c_void_p)]),
+    "link_block_ctx_destroy": (c_int, [c_void_p]),
+    "link_pair_plan_arena": (c_int64, [c_int64, c_int32, c_int32, POINTER(c_int64)]),
+    "link_dc_neighbor_map": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid), c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "link_elk_block_forward": (c_int, [c_void_p, POINTER(LinkBlockArgs), c_void_p]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }
@@ -262,7 +279,7 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         if handle.link_abi_version() != ABI_VERSION:
             raise LinkAmdError("liblink_amd.so ABI version mismatch; rebuild with link_amd/build.py")
-        for which, cls in enumerate((LinkGrid, LinkElkDesc, LinkElkBuffers, LinkDcGrid, LinkDcTuning, LinkDcBuffers, LinkLeanBuffers)):
+        for which, cls in enumerate((LinkGrid, LinkElkDesc, LinkElkBuffers, LinkDcGrid, LinkDcTuning, LinkDcBuffers, LinkLeanBuffers, LinkBlockArgs)):
             if handle.link_abi_struct_size(which) != ctypes.sizeof(cls):
                 raise LinkAmdError(f"liblink_amd.so: layout of {cls.__name__} differs from include/link_amd.h "
                                    f"({ctypes.sizeof(cls)} bytes here, {handle.link_abi_struct_size(which)} in the library)")

@@ -849,32 +849,98 @@ extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, 
 // link_pair_plan_fill after reading the counts back): one workgroup.  Phase 1: a wave per offset column, exclusive scan of
 // the per-workgroup counts (-> wg_base) and the column totals.  Phase 2 (one lane): granule-aligned row ranges per offset.
 // Phase 3: the offset of every granule up to the caller's capacity, -1 behind the last one (the GEMM kernels return there).
+#ifdef PP_DBG
+__device__ unsigned long long g_pp_dbg[8];
+#define PP_T(i) do { __syncthreads(); if (threadIdx.x == 0) g_pp_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_T(i) do { } while (0)
+#endif
+template <int PP_KMAX>
 __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
                                                           int skip_centre, int64_t gran_cap, int32_t *__restrict__ base_k,
                                                           int32_t *__restrict__ wg_base, int32_t *__restrict__ gran_start,
                                                           int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr,
-                                                          int32_t *__restrict__ wg_ext = nullptr, int32_t *__restrict__ pair_in = nullptr,
-                                                          int32_t *__restrict__ pair_out = nullptr,
-                                                          int32_t *__restrict__ ext_total = nullptr) {
+                                                          int32_t *__restrict__ wg_ext, int32_t *__restrict__ pair_in,
+                                                          int32_t *__restrict__ pair_out, int32_t *__restrict__ ext_total) {
   __shared__ int s_tot[65], s_gs[66], s_base[65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nthr = (int)blockDim.x, nwave = nthr >> 6;    // one workgroup of 16 waves: the offset columns are scanned two per wave
-  for (int k = wave; k <= kvol; k += nwave) {
-    int running = 0;
-    for (int c = 0; c < nwg; c += 64) {
-      const int w = c + lane;
-      const int v = w < nwg ? wg_counts[(int64_t)w * (kvol + 1) + k] : 0;
-      int incl = v;
+  // Phase 1, a thread per count-pass workgroup (round 5).  This is ONE workgroup: what bounds it is how many memory
+  // transactions one CU can issue.  Before, a lane per table row read / wrote single ints 108 bytes apart -- one transaction
+  // per lane, 21 k of them: 27 us on a 100k-voxel table (391 rows), 42 us when it shared the CU.  Now the rows of a chunk (up
+  // to 256: 30 KB, so that the workgroup finds a CU next to whatever else is running) pass through LDS: coalesced 16-byte reads of the count table, a thread per row scanning its kvol + 1 columns across
+  // the wave by shuffles (28 independent chains) and across the 16 waves through LDS, coalesced writes of wg_base.
+  PP_T(0);
+  extern __shared__ int32_t s_rows[];                    // [rows of a chunk][RS]
+  constexpr int RS = PP_KMAX | 1;                        // odd row stride: the per-row walk is bank-conflict free
+  __shared__ int s_wt[16][PP_KMAX], s_carry[PP_KMAX];
+  if (threadIdx.x < PP_KMAX) s_carry[threadIdx.x] = 0;
+  const int kc = kvol + 1;
+  for (int c0 = 0; c0 < nwg; c0 += nthr) {
+    const int rows = nwg - c0 < nthr ? nwg - c0 : nthr;
+    __syncthreads();
+    {
+      // every load of the chunk is in flight before the first one is used: the loop form waited a full memory round trip per
+      // iteration (28 of them per chunk, ~1600 ticks each: 90 k of this kernel's 112 k ticks -- tools/layout_bench.hip)
+      int ld[PP_KMAX];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += u;
+      for (int i = 0; i < PP_KMAX; i++) {
+        const int e = (int)threadIdx.x + i * nthr;
+        ld[i] = e < rows * kc ? wg_counts[(int64_t)c0 * kc + e] : 0;
       }
-      if (w < nwg && k < kvol) wg_base[(int64_t)w * kvol + k] = running + incl - v;
-      running += __shfl(incl, 63, 64);
+#pragma unroll
+      for (int i = 0; i < PP_KMAX; i++) {
+        const int e = (int)threadIdx.x + i * nthr;
+        if (e < rows * kc) s_rows[(e / kc) * RS + e % kc] = ld[i];
+      }
     }
-    if (lane == 0) s_tot[k] = running;
+    __syncthreads();
+    const int w = c0 + (int)threadIdx.x;
+    const bool livew = w < nwg;
+    int v[PP_KMAX], ex[PP_KMAX];
+#pragma unroll
+    for (int k = 0; k < PP_KMAX; k++) v[k] = (livew && k <= kvol) ? s_rows[threadIdx.x * RS + k] : 0;
+#pragma unroll
+    for (int k = 0; k < PP_KMAX; k++) {
+      if (k > kvol) break;                               // uniform
+      // inclusive scan over the wave on the VALU: DPP row scan (zeros shifted in) + the three row totals as scalars
+      // (six ds_bpermute round trips per column -- __shfl_up -- were most of this kernel's time)
+      int incl = v[k];
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+      {
+        const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+        const int gq = lane >> 4;
+        incl += gq == 0 ? 0 : (gq == 1 ? t0 : (gq == 2 ? t0 + t1 : t0 + t1 + t2));
+      }
+      ex[k] = incl - v[k];
+      if (lane == 63) s_wt[wave][k] = incl;
+    }
+    __syncthreads();
+    int ext = 0;
+#pragma unroll
+    for (int k = 0; k < PP_KMAX; k++) {
+      if (k >= kvol) break;                              // uniform (column kvol = the centre misses: total only)
+      int before = s_carry[k];
+      for (int u = 0; u < wave; u++) before += s_wt[u][k];
+      const int base = before + ex[k];
+      if (livew) s_rows[threadIdx.x * RS + k] = base;
+      ext += (skip_centre && k == centre) ? 0 : base;
+    }
+    if (wg_ext && livew) wg_ext[w] = ext;
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * kvol; e += nthr) wg_base[(int64_t)c0 * kvol + e] = s_rows[(e / kvol) * RS + e % kvol];
+    if ((int)threadIdx.x <= kvol) {
+      int tot = 0;
+      for (int u = 0; u < nwave; u++) tot += s_wt[u][threadIdx.x];
+      s_carry[threadIdx.x] += tot;
+    }
   }
+  __syncthreads();
+  PP_T(1);
+  if ((int)threadIdx.x <= kvol) s_tot[threadIdx.x] = s_carry[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {
     int64_t rows = 0, gran = 0, pairs = 0;
@@ -897,14 +963,11 @@ __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__rest
     if (ext_total) *ext_total = (int32_t)pairs;       // ext_start[n]
   }
   __syncthreads();
+  PP_T(2);
   if (wg_ext) {
-    // rows of earlier workgroups over all offsets (the fill kernel's CSR starts), and -1 in the unused tail of every
-    // offset's last granule (the only padding a GEMM workgroup ever reads: granules behind the last one return on wg_k)
-    for (int w = threadIdx.x; w < nwg; w += nthr) {
-      int acc = 0;
-      for (int k = 0; k < kvol; k++) acc += (skip_centre && k == centre) ? 0 : wg_base[(int64_t)w * kvol + k];
-      wg_ext[w] = acc;
-    }
+    // (wg_ext -- rows of earlier workgroups over all offsets, the fill kernel's CSR starts -- was written in phase 1)
+    // -1 in the unused tail of every offset's last granule (the only padding a GEMM workgroup ever reads: granules behind
+    // the last one return on wg_k)
     for (int k = 0; k < kvol; k++) {
       const int cnt = (skip_centre && k == centre) ? 0 : s_tot[k];
       const int end = ((cnt + 127) / 128) * 128;
@@ -914,8 +977,13 @@ __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__rest
       }
     }
   }
+  PP_T(3);
   const int total = s_gs[kvol];
-  for (int64_t g = threadIdx.x; g < gran_cap; g += nthr) {
+  // the granules in use (a few hundred) one by one; the capacity behind them (tens of thousands of -1) in 16-byte stores
+  int64_t g_vec = gran_cap;                              // first granule of the vector part
+  if ((reinterpret_cast<uintptr_t>(wg_k) & 15) == 0) g_vec = ((int64_t)total + 3) & ~(int64_t)3;
+  if (g_vec > gran_cap) g_vec = gran_cap;
+  for (int64_t g = threadIdx.x; g < g_vec; g += nthr) {
     int k = -1;
     if (g < total) {
       k = 0;
@@ -923,6 +991,10 @@ __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__rest
     }
     wg_k[g] = k;
   }
+  const int64_t nvec = (gran_cap - g_vec) >> 2;
+  for (int64_t q = threadIdx.x; q < nvec; q += nthr) reinterpret_cast<int4 *>(wg_k + g_vec)[q] = make_int4(-1, -1, -1, -1);
+  for (int64_t g = g_vec + (nvec << 2) + threadIdx.x; g < gran_cap; g += nthr) wg_k[g] = -1;
+  PP_T(4);
 }
 
 extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
@@ -932,8 +1004,17 @@ extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_
   if (!wg_counts || !base_k || !wg_base || !gran_start || !hdr || (gran_cap > 0 && !wg_k)) return LINK_ERR_ARG;
   const int64_t nwg = (n + 255) / 256;
   if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
-  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(1024), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                     (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr);
+  if (kvol < 28)
+    hipLaunchKernelGGL(k_pair_plan_layout<28>, dim3(1), dim3(256), (size_t)256 * 29 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr);
+  else if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_plan_layout<65>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               512 * 65 * 4) != hipSuccess)
+    return LINK_ERR_LAUNCH;
+  else
+    hipLaunchKernelGGL(k_pair_plan_layout<65>, dim3(1), dim3(512), (size_t)512 * 65 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr);
   return check_launch("link_pair_plan_layout");
 }
 
@@ -1012,8 +1093,15 @@ extern "C" int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol,
   if (gran_cap < (n * (int64_t)(kvol - (skip_centre ? 1 : 0)) + 127 * (int64_t)kvol + 127) / 128) return LINK_ERR_ARG;
   int rc = link_pair_plan_count(nbr, n, kvol, wg_counts, row_info, stream);
   if (rc != LINK_OK) return rc;
-  hipLaunchKernelGGL(k_pair_plan_layout, dim3(1), dim3(1024), 0, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                     (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
+  if (kvol < 28)
+    hipLaunchKernelGGL(k_pair_plan_layout<28>, dim3(1), dim3(256), (size_t)256 * 29 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
+  else if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_plan_layout<65>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               512 * 65 * 4) != hipSuccess)
+    return LINK_ERR_LAUNCH;
+  else
+    hipLaunchKernelGGL(k_pair_plan_layout<65>, dim3(1), dim3(512), (size_t)512 * 65 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
+                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
   rc = check_launch("link_pair_plan_build");
   if (rc != LINK_OK) return rc;
   hipLaunchKernelGGL(k_pair_plan<true>, dim3((unsigned)nwg), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,

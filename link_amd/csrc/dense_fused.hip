@@ -181,6 +181,236 @@ extern "C" int link_elk_core_dense_step3(const link_dc_buffers_t *b_insert, int6
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// slot insert + occupancy counters + bounding box, published to HOST memory by the last workgroup (section G)
+// ---------------------------------------------------------------------------------------------
+// The block driver's first launch (csrc/block.hip): what link_coords_bbox + link_dc_index_probe + a device-to-host copy did in
+// three launches and a stream synchronisation.  `cur` i32[272]: the top-level ticket at 8, 16 result slots of 16 words at 16
+// (counters, arrivals, coordinate minima / maxima: dc_probe_scratch_word) -- every workgroup adds its partial results to one slot,
+// and the LAST one to finish (two-level ticket) reduces the slots, writes bbox -> host[0..8) and (voxels inside, occupied cells,
+// fullest cell) -> host[16..19) (mapped, coherent memory) and, behind a system-scope fence, `seq` into host[8]: the host polls that word instead of synchronising the stream.  Workgroup 0 also lays out `next` (the scratch
+// of the following call) so that no initialiser launch is needed.
+__device__ __host__ inline int dc_probe_scratch_word(int i) {        // initial value of word i of the 272-word scratch
+  const int j = i >= 16 ? (i - 16) & 15 : -1;
+  return (j >= 4 && j < 8) ? INT_MAX : ((j >= 8 && j < 12) ? INT_MIN : 0);
+}
+__global__ void k_dc_probe_scratch_init(int32_t *w) { w[threadIdx.x] = dc_probe_scratch_word((int)threadIdx.x); }
+__global__ void __launch_bounds__(256) k_dc_index_probe_bbox(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
+                                                             uint32_t *__restrict__ cnt, int4 *__restrict__ slots,
+                                                             int32_t *__restrict__ vcell, int32_t *__restrict__ hdr,
+                                                             int32_t *__restrict__ cur, int32_t *__restrict__ next,
+                                                             int32_t *__restrict__ host, int seq) {
+  const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
+  const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(cnt, (uint32_t)(g.vp * 4));
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) hdr[LINK_HDR_NVALID] = (int32_t)n;
+    for (int i = threadIdx.x; i < 272; i += 256) next[i] = dc_probe_scratch_word(i);
+  }
+  int st_in = 0, st_first = 0, st_max = 0;
+  int mn[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, mx[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
+    const int4 rc = coords[v];
+    mn[0] = min(mn[0], rc.x); mx[0] = max(mx[0], rc.x); mn[1] = min(mn[1], rc.y); mx[1] = max(mx[1], rc.y);
+    mn[2] = min(mn[2], rc.z); mx[2] = max(mx[2], rc.z); mn[3] = min(mn[3], rc.w); mx[3] = max(mx[3], rc.w);
+    const unsigned ux = (unsigned)(floordiv(rc.x, g.s) - g.lo[0]), uy = (unsigned)(floordiv(rc.y, g.s) - g.lo[1]);
+    const unsigned uz = (unsigned)(floordiv(rc.z, g.s) - g.lo[2]), ub = (unsigned)(rc.w - g.lo[3]);
+    const bool inside = ux < (unsigned)g.dim[0] && uy < (unsigned)g.dim[1] && uz < (unsigned)g.dim[2] && ub < (unsigned)g.dim[3];
+    if (!inside) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 1);
+    const int pcell = inside ? dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub) : 0;
+    const int rank = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, r_cnt, pcell ? (uint32_t)pcell * 4u : DC_OOB, 0, 0);
+    const bool full = pcell != 0 && rank >= g.k;
+    if (full) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 2);
+    const bool keep = pcell != 0 && !full;
+    st16i(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
+    vcell[v] = keep ? pcell : 0;
+    st_in += pcell != 0; st_first += (pcell != 0 && rank == 0); st_max = max(st_max, pcell != 0 ? rank + 1 : 0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    st_in += __shfl_xor(st_in, o, 64); st_first += __shfl_xor(st_first, o, 64); st_max = max(st_max, __shfl_xor(st_max, o, 64));
+#pragma unroll
+    for (int a = 0; a < 4; a++) { mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64)); }
+  }
+  __shared__ int s_part[4][11];
+  __shared__ int s_last;
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  if (lane == 0) {
+    s_part[wave][0] = st_in; s_part[wave][1] = st_first; s_part[wave][2] = st_max;
+    for (int a = 0; a < 4; a++) { s_part[wave][3 + a] = mn[a]; s_part[wave][7 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // one of 16 result slots per workgroup, each on its own 64-byte line: [0] voxels inside, [1] occupied cells, [2] fullest cell,
+    // [3] arrivals, [4..8) minima, [8..12) maxima (same-address atomics serialise in the L2: 391 workgroups on one line made this
+    // kernel 64 us instead of 9).  All of them are RETURNING atomics whose results feed the ticket below, so the slot is complete
+    // when the ticket is drawn -- no device-wide fence (an L2 write-back per workgroup) is needed for words only atomics touch.
+    int a_ = 0, f_ = 0, m_ = 0;
+    for (int w = 0; w < 4; w++) { a_ += s_part[w][0]; f_ += s_part[w][1]; m_ = max(m_, s_part[w][2]); }
+    int32_t *slot = cur + 16 + (blockIdx.x % DC_STATS_SLOTS) * 16;
+    int dep = atomicAdd(&slot[0], a_) & 0;
+    dep |= atomicAdd(&slot[1], f_) & 0;
+    dep |= atomicMax(&slot[2], m_) & 0;
+    for (int a = 0; a < 4; a++) {
+      dep |= atomicMin(&slot[4 + a], min(min(s_part[0][3 + a], s_part[1][3 + a]), min(s_part[2][3 + a], s_part[3][3 + a]))) & 0;
+      dep |= atomicMax(&slot[8 + a], max(max(s_part[0][7 + a], s_part[1][7 + a]), max(s_part[2][7 + a], s_part[3][7 + a]))) & 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // two-level ticket: the last arrival of a slot (its share of the workgroups) draws the top-level ticket
+    const int share = ((int)gridDim.x - 1 - (int)(blockIdx.x % DC_STATS_SLOTS)) / DC_STATS_SLOTS + 1;
+    int last = 0;
+    if (atomicAdd(&slot[3], 1 + dep) == share - 1) {
+      const int live = (int)gridDim.x < DC_STATS_SLOTS ? (int)gridDim.x : DC_STATS_SLOTS;
+      last = atomicAdd(&cur[8], 1) == live - 1;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the last workgroup: reduce the 16 slots and publish to the host
+  if (threadIdx.x < 64) {
+    const int k = (int)threadIdx.x & 15;
+    int32_t *slot = cur + 16 + k * 16;
+    int vin = __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int vfi = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int vmx = __hip_atomic_load(&slot[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bmn[4], bmx[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      bmn[a] = __hip_atomic_load(&slot[4 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bmx[a] = __hip_atomic_load(&slot[8 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      vin += __shfl_xor(vin, o, 64); vfi += __shfl_xor(vfi, o, 64); vmx = max(vmx, __shfl_xor(vmx, o, 64));
+#pragma unroll
+      for (int a = 0; a < 4; a++) { bmn[a] = min(bmn[a], __shfl_xor(bmn[a], o, 64)); bmx[a] = max(bmx[a], __shfl_xor(bmx[a], o, 64)); }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        __hip_atomic_store(&host[a], bmn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host[4 + a], bmx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(&host[16], vin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host[17], vfi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host[18], vmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      __hip_atomic_store(&host[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+namespace link {
+int dc_probe_scratch_init_run(int32_t *w, hipStream_t st) {
+  hipLaunchKernelGGL(k_dc_probe_scratch_init, dim3(1), dim3(272), 0, st, w);
+  return check_launch("link_elk_block_forward (init)");
+}
+int dc_index_probe_bbox_run(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *cur, int32_t *next,
+                            int32_t *host_dev, int seq, hipStream_t st) {
+  if (!b->coords || !b->cnt || !b->slots || !b->vcell || !b->hdr || !cur || !next || !host_dev) return LINK_ERR_ARG;
+  if (g->k < DC_INL || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || n >= (1LL << 29) || n <= 0) return LINK_ERR_ARG;
+  int64_t wgs = (n + 255) / 256;
+  if (wgs > 4096) wgs = 4096;
+  hipLaunchKernelGGL(k_dc_index_probe_bbox, dim3((unsigned)wgs), dim3(256), 0, st, reinterpret_cast<const int4 *>(b->coords), n, *g, b->cnt,
+                     reinterpret_cast<int4 *>(b->slots), b->vcell, b->hdr, cur, next, host_dev, seq);
+  return check_launch("link_elk_block_forward (probe)");
+}
+}  // namespace link
+
+// ---------------------------------------------------------------------------------------------
+// 3x3x3 neighbour table of a frame from its freshly inserted slot lists (section G: the one-call block driver)
+// ---------------------------------------------------------------------------------------------
+// nbr[i][k] = row of the voxel at coords[i] + offset_k * step, -1 absent; offsets in get_kernel_offsets(3) order (x fastest:
+// nn/utils/kernel.py:11-32), i.e. the table link_cell_table_build + link_neighbor_map give -- the reference's sphash ->
+// sphashquery kernel map (nn/functional/conv.py:103-113) -- without the voxel-resolution cell table: the target's block cell
+// is arithmetic, its slot list (cnt[cell] records (x, y, z, id), arrival order: between the insert and the pre_mix kernel)
+// is scanned for the coordinates.  The tables it reads are the frame's own index, a few MB that stay in the L2s (cfg2: 0.26 MB
+// of counters, 3.2 MB of inline records), where the cell table is 67 MB of random 4-byte reads behind a build and a clear.
+// Duplicate coordinates: the smallest row wins (link_cell_table_build's rule).
+// floor(a / s) through the float reciprocal, exact for |a| < 2^22 (the float quotient is within one of the true one; the
+// remainder corrects it) -- the integer division hipcc emits is ~25 instructions, and a thread needs three of them
+__device__ __forceinline__ int dc_floordiv_fast(int a, int s, float inv) {
+  if (__builtin_expect(a >= (1 << 22) || a <= -(1 << 22), 0)) return link::floordiv(a, s);
+  int q = (int)floorf((float)a * inv);
+  const int r = a - q * s;
+  q += (r >= s ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+// A thread owns one (voxel, dx, dy) column of the 3 x 3 x 3 neighbourhood: z is the fastest axis of the cell numbering, so its three
+// targets lie in one cell (one scan of that cell's records answers all three) unless the column crosses a block boundary.
+__global__ void __launch_bounds__(256) k_dc_neighbor_map(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
+                                                         const uint32_t *__restrict__ cnt, const int4 *__restrict__ slots, int step,
+                                                         int32_t *__restrict__ nbr) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * 9) return;
+  const int64_t row = t / 9;
+  const int kxy = (int)(t - row * 9);
+  const int4 c = coords[row];
+  const float inv = 1.0f / (float)g.s;
+  const int tx = c.x + (kxy % 3 - 1) * step, ty = c.y + (kxy / 3 - 1) * step;
+  const unsigned ux = (unsigned)(dc_floordiv_fast(tx, g.s, inv) - g.lo[0]), uy = (unsigned)(dc_floordiv_fast(ty, g.s, inv) - g.lo[1]);
+  const unsigned ub = (unsigned)(c.w - g.lo[3]);
+  const bool okxy = ux < (unsigned)g.dim[0] && uy < (unsigned)g.dim[1] && ub < (unsigned)g.dim[3];
+  const int bz = dc_floordiv_fast(c.z, g.s, inv);
+  const int rz = c.z - bz * g.s;                       // 0 .. s-1
+  int f[3] = {-1, -1, -1};
+  if (okxy) {
+    const bool one_cell = step <= g.s && rz - step >= 0 && rz + step < g.s;      // the three targets share the voxel's z-block
+    if (one_cell) {
+      const unsigned uz = (unsigned)(bz - g.lo[2]);
+      if (uz < (unsigned)g.dim[2]) {
+        const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
+        // the count and the cell's four inline records (one 64-byte line) are requested together: two dependent round trips
+        // per thread (coordinates -> cell) instead of 2 + the cell's voxel count
+        int nn = (int)cnt[pcell];
+        const int4 *inl = slots + (int64_t)pcell * DC_INL;
+        const int4 r4[4] = {inl[0], inl[1], inl[2], inl[3]};
+        nn = nn < g.k ? nn : g.k;
+        auto take = [&](const int4 &r) {
+          if (r.x == tx && r.y == ty) {
+            const int d = r.z - c.z;
+            if (d == -step && (f[0] < 0 || r.w < f[0])) f[0] = r.w;
+            if (d == 0 && (f[1] < 0 || r.w < f[1])) f[1] = r.w;
+            if (d == step && (f[2] < 0 || r.w < f[2])) f[2] = r.w;
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < nn) take(r4[j]);
+        for (int j = DC_INL; j < nn; j++) take(slots[link::dc_slot(g, pcell, j)]);
+      }
+    } else {
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) {
+        const int tz = c.z + (dz - 1) * step;
+        const unsigned uz = (unsigned)(dc_floordiv_fast(tz, g.s, inv) - g.lo[2]);
+        if (uz >= (unsigned)g.dim[2]) continue;
+        const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
+        int nn = (int)cnt[pcell];
+        nn = nn < g.k ? nn : g.k;
+        int found = -1;
+        for (int j = 0; j < nn; j++) {
+          const int4 r = slots[link::dc_slot(g, pcell, j)];
+          if (r.x == tx && r.y == ty && r.z == tz && (found < 0 || r.w < found)) found = r.w;
+        }
+        f[dz] = found;
+      }
+    }
+  }
+  int32_t *o = nbr + row * 27 + kxy;
+  o[0] = f[0]; o[9] = f[1]; o[18] = f[2];
+}
+
+extern "C" int link_dc_neighbor_map(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt,
+                                    const int32_t *slots, int32_t step, int32_t *nbr, void *stream) {
+  if (n < 0 || !g || step <= 0) return LINK_ERR_ARG;
+  if (n == 0) return LINK_OK;
+  if (!coords || !cnt || !slots || !nbr || n * 27 >= (1LL << 31)) return LINK_ERR_ARG;
+  hipLaunchKernelGGL(k_dc_neighbor_map, dim3(link::blocks_for(n * 9, 256)), dim3(256), 0, link::S(stream),
+                     reinterpret_cast<const int4 *>(coords), n, *g, cnt, reinterpret_cast<const int4 *>(slots), (int)step, nbr);
+  return link::check_launch("link_dc_neighbor_map");
+}
+
 namespace link {
 // the insert of link_dc_index + occupancy statistics (behind link_dc_index_probe, dense.hip)
 int dc_index_stats_run(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *stats, hipStream_t st) {

@@ -18,7 +18,7 @@ void set_error(const char *what, hipError_t e) {
 
 using namespace link;
 
-extern "C" int link_abi_version(void) { return 10; }
+extern "C" int link_abi_version(void) { return 11; }
 extern "C" int32_t link_abi_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(link_grid_t);
@@ -28,6 +28,7 @@ extern "C" int32_t link_abi_struct_size(int32_t which) {
     case 4: return (int32_t)sizeof(link_dc_tuning_t);
     case 5: return (int32_t)sizeof(link_dc_buffers_t);
     case 6: return (int32_t)sizeof(link_lean_buffers_t);
+    case 7: return (int32_t)sizeof(link_block_args_t);
     default: return -1;
   }
 }

@@ -1272,42 +1272,54 @@ class _PairPlan:
     def _init_async(self, nbr: torch.Tensor, direct: bool):
         _poll_pending_plans()                            # an earlier plan's verdict (duplicate coordinates) surfaces here at the latest
         n, kvol = nbr.shape
-        dev = nbr.device
         lib, st = L.lib(), _st()
         nbr = nbr.contiguous()
-        i32 = dict(dtype=torch.int32, device=dev)
+        # one arena for everything the three kernels touch (count -> layout -> fill, one FFI call: link_pair_plan_build);
+        # nothing in it needs initialising.  Capacity: every (voxel, offset) a pair, every offset's last granule partly filled
+        # (link_pair_plan_arena: the piece offsets, shared with the one-call block driver of include/link_amd.h section G)
+        offs = (ctypes.c_int64 * 11)()
+        gran_cap = int(lib.link_pair_plan_arena(n, kvol, 1 if direct else 0, offs))
+        arena = torch.empty(int(offs[10]), dtype=torch.int32, device=nbr.device)
+        self._adopt(n, kvol, direct, arena, offs, gran_cap)
+        meta = self._meta
+        L.check(lib.link_pair_plan_build(nbr.data_ptr(), n, kvol, 1 if direct else 0, gran_cap, arena[int(offs[0]):].data_ptr(),
+                                         arena[int(offs[1]):].data_ptr(), meta.data_ptr(), meta[kvol:].data_ptr(),
+                                         self.gran_start.data_ptr(), arena[int(offs[3]):].data_ptr(), self.wg_k.data_ptr(),
+                                         self._hdr.data_ptr(), self.ext_start.data_ptr(), self.pair_in.data_ptr(),
+                                         self.pair_out.data_ptr(), self.ext_list.data_ptr(), st), "link_pair_plan_build")
+        self._post_build()
+
+    def _adopt(self, n: int, kvol: int, direct: bool, arena: torch.Tensor, offs, gran_cap: int) -> None:
+        """Views into a capacity-sized arena laid out by link_pair_plan_arena."""
         nwg = (n + 255) // 256
-        # capacity: every (voxel, offset) a pair, every offset's last granule partly filled
         cap_pairs = n * (kvol - (1 if direct else 0))
-        gran_cap = (cap_pairs + 127 * kvol + 127) // 128
         self.n, self.kvol, self.direct, self.exact = n, kvol, direct, False
         self.pairs, self.rows_pad, self._density = None, gran_cap * 128, None
         self._error = None
-        # one arena for everything the three kernels touch (count -> layout -> fill, one FFI call: link_pair_plan_build);
-        # nothing in it needs initialising
-        sizes = [nwg * (kvol + 1), n, kvol + nwg * kvol + kvol + 1, nwg, gran_cap, 8, n + 1, self.rows_pad, self.rows_pad,
-                 max(cap_pairs, 1)]
-        offs = [0]
-        for sz in sizes:
-            offs.append(offs[-1] + ((sz + 3) & ~3))          # 16-byte aligned pieces
-        arena = torch.empty(offs[-1], **i32)
-        wg_counts, row_info, meta, wg_ext, wg_k, hdr, ext_start, pair_in, pair_out, ext_list = [
-            arena[offs[i]: offs[i] + sizes[i]] for i in range(len(sizes))]
-        gs = meta[kvol + nwg * kvol:]
-        L.check(lib.link_pair_plan_build(nbr.data_ptr(), n, kvol, 1 if direct else 0, gran_cap, wg_counts.data_ptr(),
-                                         row_info.data_ptr(), meta.data_ptr(), meta[kvol:].data_ptr(), gs.data_ptr(),
-                                         wg_ext.data_ptr(), wg_k.data_ptr(), hdr.data_ptr(), ext_start.data_ptr(),
-                                         pair_in.data_ptr(), pair_out.data_ptr(), ext_list.data_ptr(), st), "link_pair_plan_build")
-        self._meta, self._hdr, self._arena = meta, hdr, arena
-        self.pair_in, self.pair_out, self.ext_start, self.ext_list = pair_in, pair_out, ext_start, ext_list
-        self.gran_start, self.wg_k = gs, wg_k
+        o = [int(v) for v in offs]
+        meta = arena[o[2]: o[2] + kvol + nwg * kvol + kvol + 1]
+        self._meta, self._hdr, self._arena = meta, arena[o[5]: o[5] + 8], arena
+        self.ext_start = arena[o[6]: o[6] + n + 1]
+        self.pair_in, self.pair_out = arena[o[7]: o[7] + self.rows_pad], arena[o[8]: o[8] + self.rows_pad]
+        self.ext_list = arena[o[9]: o[9] + max(cap_pairs, 1)]
+        self.gran_start, self.wg_k = meta[kvol + nwg * kvol:], arena[o[4]: o[4] + gran_cap]
         self._contrib = {}
+
+    def _post_build(self) -> None:
         # the counts travel to pinned memory behind the kernels; whoever asks first after they arrived checks them
         self._host, self._slot, self._gen = _pinned_slot()
-        self._host.copy_(hdr, non_blocking=True)
+        self._host.copy_(self._hdr, non_blocking=True)
         self._ev = torch.cuda.Event()
         self._ev.record()
         _PENDING_PLANS.append(weakref.ref(self))
+
+    @classmethod
+    def _from_arena(cls, nbr: torch.Tensor, arena: torch.Tensor, offs, gran_cap: int) -> "_PairPlan":
+        """The plan of a submanifold table whose arena link_elk_block_forward has already filled (same layout, same kernels)."""
+        self = cls.__new__(cls)
+        self._adopt(nbr.shape[0], nbr.shape[1], True, arena, offs, gran_cap)
+        self._post_build()
+        return self
 
     def _arrived(self, wait: bool) -> bool:
         if self._error is not None:                      # a plan whose table was bad stays bad: every use of it says so
@@ -1783,6 +1795,23 @@ class _SubmConv(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # modules
 # ------------------------------------------------------------------------------------------------
+BLOCK_DRIVER = True           # a coordinate set nothing is known about: the whole block as ONE host call (link_elk_block_forward)
+_BLOCK_CTX: dict = {}         # (device index, host thread) -> link_block_ctx_t* (side stream, events, pinned scratch)
+_BLOCK_CONTRIB: dict = {}     # (device, stream) -> contribution rows of the block driver's pair GEMM (scratch, grow-only)
+BLOCK_DRIVER_CALLS = {"done": 0, "miss": 0}   # diagnostics (tests, tools): how the driver's calls ended
+
+
+def _block_ctx(device):
+    import threading
+    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    ctx = _BLOCK_CTX.get(key)
+    if ctx is None:
+        h = ctypes.c_void_p()
+        L.check(L.lib().link_block_ctx_create(ctypes.byref(h)), "link_block_ctx_create")
+        ctx = _BLOCK_CTX[key] = h
+    return ctx
+
+
 DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take
 DENSE_PLAN_CACHE_BYTES = 4 << 30             # arenas the PROCESS keeps in its modules' plan caches, dense-cell and lean together
                                              # (ElkCorePlan.arena_bytes; round 5: one budget instead of one per cache and module)
@@ -2046,6 +2075,90 @@ class _ELKBase(nn.Module):
                 "contract: tensor.py / downsample.py).  The surplus voxels of that frame were left out of the block sums and their "
                 "output rows are zero; blocks of this edge and stride take the general layout from here on.")
 
+    def _block_native(self, st: SparseTensor, conv, s_eff: int, r: int, w_pos, alpha, cg, coord_div) -> bool:
+        """The whole block on a coordinate set nothing is known about yet, as ONE host call (include/link_amd.h section G,
+        csrc/block.hip): the frame is tried on the module's last dense-cell plan -- bounding box + slot insert with occupancy
+        counters, one round trip, then R_core on the caller's stream while the neighbour table, the pair plan and the pair GEMM
+        of local_mix run on the driver's side stream, and the convolution's finish adds the two.  Returns False (having touched
+        nothing but st.cmaps' bounds) when the call does not apply or the frame missed the plan: the per-stage path takes over.
+        What the call built is registered where the per-stage path would have put it (cmaps / kmaps / the table's pair plan),
+        so later blocks on the same coordinates find warm maps."""
+        feats, coords = st.F, st.C
+        n, c = feats.shape
+        if (n == 0 or not feats.is_cuda or coords.dtype != torch.int32 or L.DEBUG or getattr(self, "dense_layout", None) is False
+                or not (ASYNC_PAIR_PLANS and TRUST_UNIQUE_INPUT_COORDS) or conv.bias is not None):
+            return False
+        bkey, okey = ("link_bounds", coords.data_ptr(), n), ("link_dense_ok", coords.data_ptr(), n, s_eff)
+        kkey = ("link_conv_nbr", coords.data_ptr(), n, st.s, tuple(conv.kernel_size))
+        if bkey in st.cmaps or okey in st.cmaps or kkey in st.kmaps:
+            return False                                   # something is known already: the per-stage path reuses it
+        n_cap = 1 << max(10, (n - 1).bit_length())
+        sig, plan = self._dc_last
+        if sig != (feats.device, n_cap, c, self.baseop, cg, r, s_eff, float(coord_div)) or not plan._probe_fused():
+            return False
+        lib = L.lib()
+        if (not lib.link_conv_pairs_supported(c, c) or _resident_form(c, c, 27, False, "auto") or n * 27 > ASYNC_PAIR_PLAN_MAX
+                or n * 27 * c * 4 > ASYNC_PAIR_PLAN_MAX_BYTES or _DENSITY_SEEN.get(27, 0.0) > PAIR_DENSITY_MAX):
+            return False
+        kernel = conv.kernel
+        if kernel.dtype != torch.float32 or not kernel.is_contiguous() or tuple(kernel.shape) != (27, c, c):
+            return False
+        dev = feats.device
+        ctx = _block_ctx(dev)
+        feats_c, cc = feats.contiguous(), coords.contiguous()
+        plan.bind(self.pre_mix[0].weight, self.pre_mix[1].weight, self.pre_mix[1].bias, w_pos, alpha,
+                  self.norm.weight, self.norm.bias)
+        offs = (ctypes.c_int64 * 11)()
+        gran_cap = int(lib.link_pair_plan_arena(n, 27, 1, offs))
+        rows = gran_cap * 128
+        ck = (dev, _st())
+        contrib = _BLOCK_CONTRIB.get(ck)
+        if contrib is None or contrib.numel() < rows * c:
+            contrib = _BLOCK_CONTRIB[ck] = torch.empty(rows * c, dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        core_out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        nbr = torch.empty((n, 27), **i32)
+        arena = torch.empty(int(offs[10]), **i32)
+        nl = self.norm_local
+        a = plan.__dict__.get("_blk_args")
+        if a is None:
+            a = plan._blk_args = L.LinkBlockArgs()
+            a.buf, a.g, a.desc = ctypes.pointer(plan.buf), ctypes.pointer(plan.dcg), ctypes.pointer(plan.desc)
+            a.mean_max, a.cell_max, a.subm, a.flags = int(DENSE_MAX_MEAN), int(DENSE_MAX_CELL), 1, 1
+        b = plan.buf
+        b.feats, b.coords, b.out, b.io_dtype = feats_c.data_ptr(), cc.data_ptr(), core_out.data_ptr(), L.IO_F32
+        a.n, a.ts = n, int(st.s[0])
+        a.nbr, a.pair_arena, a.pair_arena_words = nbr.data_ptr(), arena.data_ptr(), arena.numel()
+        a.contrib, a.contrib_rows = contrib.data_ptr(), contrib.numel() // c
+        a.w = kernel.data_ptr()
+        if SPLIT_MFMA and c >= 32:
+            ws, big = _split_weights(kernel)
+            a.ws, a.w_big = ws.data_ptr(), big.data_ptr()
+        else:
+            a.ws = a.w_big = None
+        nlw, nlb = nl.weight, nl.bias
+        a.nl_w, a.nl_b, a.nl_eps, a.out = nlw.data_ptr(), nlb.data_ptr(), float(nl.eps), out.data_ptr()
+        plan._indexed = None                               # the probe overwrites the plan's slot lists
+        _poll_pending_plans()
+        rc = lib.link_elk_block_forward(ctx, ctypes.byref(a), _st())
+        if rc < 0:
+            L.check(rc, "link_elk_block_forward")
+        bb = list(a.bbox)
+        st.cmaps[bkey] = (tuple(bb[:4]), tuple(bb[4:]))
+        if rc != L.BLOCK_DONE:
+            BLOCK_DRIVER_CALLS["miss"] += 1
+            return False
+        BLOCK_DRIVER_CALLS["done"] += 1
+        st.cmaps[okey] = True
+        plan._indexed = (coords.data_ptr(), n, coords._version)
+        plan._keepalive = coords
+        nbr._link_subm = True
+        nbr._link_pairs = _PairPlan._from_arena(nbr, arena, offs, gran_cap)
+        st.kmaps[kkey] = (nbr, _TileOrder(coords, 4 * int(st.s[0])))
+        st.F = out
+        return True
+
     def _core_generic(self, st: SparseTensor, s_eff: int, r: int, w_pos, alpha, cg, coord_div):
         """R_core as the reference writes it (linkunet.py:124-176), op by op on voxel_to_aux / aux_to_voxel:
         any grid extent, any width; differentiable through the ops' autograd Functions."""
@@ -2106,15 +2219,20 @@ class _ELKBase(nn.Module):
             return elk_core_autograd(*args)      # op-by-op composition: any width / r
         return elk_core_fused(*args)
 
-    def _finish(self, st: SparseTensor, core_fn):
+    def _finish(self, st: SparseTensor, core_fn, core_args=None):
         """st.F = relu(core + norm_local(local_mix(st).F))  (linkunet.py:125,183 / ts_elk.py:146,228).
         Inference: the LayerNorm + add + ReLU run in the convolution kernel's store phase (row N2); with
-        grad enabled, or when forward hooks observe local_mix / norm_local, the modules run one by one."""
+        grad enabled, or when forward hooks observe local_mix / norm_local, the modules run one by one.
+        A coordinate set nothing is known about yet takes the one-call block driver when it applies (_block_native)."""
         conv = self.local_mix[0]
         needs_grad = torch.is_grad_enabled() and (st.F.requires_grad or any(
             p.requires_grad for p in self.parameters()))
         hooked = any(m._forward_hooks or m._forward_pre_hooks
                      for m in (self.local_mix, conv, self.norm_local, self.activate))
+        if (BLOCK_DRIVER and core_args is not None and not needs_grad and not hooked and conv.kernel_volume == 27
+                and st.F.dtype == torch.float32 and self.__dict__.get("_dc_last") is not None
+                and self._block_native(st, conv, *core_args)):
+            return st
         if needs_grad or hooked or conv.kernel_volume == 1 or st.F.dtype != torch.float32:
             local = self.local_mix(st)
             new = core_fn()
@@ -2157,7 +2275,7 @@ class ELKBlock(_ELKBase):
         coord_div = float(st.s[0]) if (self.variant == "encoder" and self.baseop == "cos_x") else 1.0
         cg = self.inc // self.groups
         return self._finish(st, lambda: self._core(st, int(s), int(r), self.pos_weight[0].weight, alpha, cg,
-                                                   coord_div))
+                                                   coord_div), (int(s), int(r), self.pos_weight[0].weight, alpha, cg, coord_div))
 
 
 class SparseConvTensor:
@@ -2247,4 +2365,4 @@ class TSELKBlock(_ELKBase):
             w_pos, cg = self.pos_weight[0].weight[: self.inc // 2], self.inc // 2
         else:                          # 'sin' (ts_elk.py:155-156): all C columns, untiled
             w_pos, cg = self.pos_weight[0].weight, self.inc
-        return self._finish(st, lambda: self._core(st, int(stride), 3, w_pos, None, cg, 1.0))
+        return self._finish(st, lambda: self._core(st, int(stride), 3, w_pos, None, cg, 1.0), (int(stride), 3, w_pos, None, cg, 1.0))
