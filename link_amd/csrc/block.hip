@@ -29,6 +29,12 @@
 namespace link {
 // dense_fused.hip: the initial image of a 272-word scratch half (only before the first call / after a change of stream); slot insert + occupancy counters + bounding box in one launch, published to host memory by its last workgroup
 int dc_probe_scratch_init_run(int32_t *w, hipStream_t st);
+// dense_fused.hip: the neighbour table off the slot lists, with the pair plan's count pass done on the tile; conv_pairs.hip: layout + fill
+int dc_neighbor_map_count_run(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt, const int32_t *slots,
+                              int32_t step, int32_t *nbr, int32_t *wg_counts, int32_t *row_info, hipStream_t st);
+int pair_plan_build_counted(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap, const int32_t *wg_counts,
+                            int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_ext, int32_t *wg_k, int32_t *hdr,
+                            int32_t *ext_start, int32_t *pair_in, int32_t *pair_out, int32_t *ext_list, hipStream_t st);
 int dc_index_probe_bbox_run(const link_dc_buffers_t *b, const link_dc_grid_t *g, int64_t n, int32_t *cur, int32_t *next,
                             int32_t *host_dev, int seq, hipStream_t st);
 }  // namespace link
@@ -187,7 +193,10 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   // ---- 3. main stream: the 27-neighbour table read off the slot lists the probe has just filled (before the pre_mix kernel
   //         re-orders them), then R_core on that insert.  The launches are issued in the order the device needs them: the
   //         side stream's chain (~50 us) and R_core (~50 us) start together behind the neighbour table ----
-  rc = link_dc_neighbor_map(b->coords, n, g, b->cnt, b->slots, a->ts, a->nbr, stream);
+  int32_t *pa = a->pair_arena;
+  int32_t *wg_counts = pa + po[0], *row_info = pa + po[1], *meta = pa + po[2], *wg_ext = pa + po[3], *wg_k = pa + po[4], *phdr = pa + po[5];
+  int32_t *ext_start = pa + po[6], *pair_in = pa + po[7], *pair_out = pa + po[8], *ext_list = pa + po[9];
+  rc = link::dc_neighbor_map_count_run(b->coords, n, g, b->cnt, reinterpret_cast<const int32_t *>(b->slots), a->ts, a->nbr, wg_counts, row_info, st);
   if (rc != LINK_OK) return rc;
   hipStream_t sd = c->side;
   e = hipEventRecord(c->fork, st);
@@ -196,14 +205,11 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
 
   // ---- 4. side stream: pair plan laid out on the device + the pair GEMM (they need the table and the input rows only) ----
   e = hipStreamWaitEvent(sd, c->fork, 0);
-  int32_t *pa = a->pair_arena;
-  int32_t *wg_counts = pa + po[0], *row_info = pa + po[1], *meta = pa + po[2], *wg_ext = pa + po[3], *wg_k = pa + po[4], *phdr = pa + po[5];
-  int32_t *ext_start = pa + po[6], *pair_in = pa + po[7], *pair_out = pa + po[8], *ext_list = pa + po[9];
   const int64_t nwg = (n + 255) / 256;
   int rs = e == hipSuccess ? LINK_OK : LINK_ERR_LAUNCH;
   if (rs == LINK_OK)
-    rs = link_pair_plan_build(a->nbr, n, kvol, 1, gran_cap, wg_counts, row_info, meta, meta + kvol, meta + kvol + nwg * kvol,
-                              wg_ext, wg_k, phdr, ext_start, pair_in, pair_out, ext_list, sd);
+    rs = link::pair_plan_build_counted(a->nbr, n, kvol, 1, gran_cap, wg_counts, meta, meta + kvol, meta + kvol + nwg * kvol, wg_ext, wg_k, phdr,
+                                       ext_start, pair_in, pair_out, ext_list, sd);
   if (rs == LINK_OK) {
     if (a->ws && a->w_big)
       rs = link_conv_pairs_gemm_split(reinterpret_cast<const float *>(b->feats), pair_in, wg_k, gran_cap * 128, a->ws, a->w, a->w_big, C, C,

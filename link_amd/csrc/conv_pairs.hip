@@ -846,102 +846,81 @@ extern "C" int link_pair_plan_fill(const int32_t *nbr, int64_t n, int32_t kvol, 
 }
 
 // Layout of a pair plan ON THE DEVICE (what the host otherwise computes between link_pair_plan_count and
-// link_pair_plan_fill after reading the counts back): one workgroup.  Phase 1: a wave per offset column, exclusive scan of
-// the per-workgroup counts (-> wg_base) and the column totals.  Phase 2 (one lane): granule-aligned row ranges per offset.
-// Phase 3: the offset of every granule up to the caller's capacity, -1 behind the last one (the GEMM kernels return there).
+// link_pair_plan_fill after reading the counts back), two launches (round 5):
+//   k_pair_plan_colscan   a wave per offset column: exclusive scan of the per-workgroup counts down the column (-> wg_base) and
+//                         the column's total (left in base_k[k]; the centre-miss column's in hdr[3])
+//   k_pair_plan_finish    one workgroup: granule-aligned row ranges per offset (one lane), rows of earlier workgroups over all
+//                         offsets (wg_ext), -1 tails, the offset of every granule up to the caller's capacity (-1 behind the
+//                         last one: the GEMM kernels return there)
+// Until round 5 this was ONE workgroup doing everything: 27 us on a 100k-voxel table (391 count workgroups) -- 46-58 us next to
+// other kernels -- of which 35 us were the column scans (tools/layout_bench.hip: a single workgroup is bound by the latency
+// of its own instruction stream, one wave per SIMD; staging the table through LDS, DPP scans and batched loads each moved it by
+// a few us only).  A wave per column on 28 CUs does the scans in ~3 us.
 #ifdef PP_DBG
 __device__ unsigned long long g_pp_dbg[8];
 #define PP_T(i) do { __syncthreads(); if (threadIdx.x == 0) g_pp_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PP_T(i) do { } while (0)
 #endif
-template <int PP_KMAX>
-__global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__restrict__ wg_counts, int nwg, int kvol, int centre,
-                                                          int skip_centre, int64_t gran_cap, int32_t *__restrict__ base_k,
-                                                          int32_t *__restrict__ wg_base, int32_t *__restrict__ gran_start,
-                                                          int32_t *__restrict__ wg_k, int32_t *__restrict__ hdr,
-                                                          int32_t *__restrict__ wg_ext, int32_t *__restrict__ pair_in,
-                                                          int32_t *__restrict__ pair_out, int32_t *__restrict__ ext_total) {
-  __shared__ int s_tot[65], s_gs[66], s_base[65];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nthr = (int)blockDim.x, nwave = nthr >> 6;    // one workgroup of 16 waves: the offset columns are scanned two per wave
-  // Phase 1, a thread per count-pass workgroup (round 5).  This is ONE workgroup: what bounds it is how many memory
-  // transactions one CU can issue.  Before, a lane per table row read / wrote single ints 108 bytes apart -- one transaction
-  // per lane, 21 k of them: 27 us on a 100k-voxel table (391 rows), 42 us when it shared the CU.  Now the rows of a chunk (up
-  // to 256: 30 KB, so that the workgroup finds a CU next to whatever else is running) pass through LDS: coalesced 16-byte reads of the count table, a thread per row scanning its kvol + 1 columns across
-  // the wave by shuffles (28 independent chains) and across the 16 waves through LDS, coalesced writes of wg_base.
-  PP_T(0);
-  extern __shared__ int32_t s_rows[];                    // [rows of a chunk][RS]
-  constexpr int RS = PP_KMAX | 1;                        // odd row stride: the per-row walk is bank-conflict free
-  __shared__ int s_wt[16][PP_KMAX], s_carry[PP_KMAX];
-  if (threadIdx.x < PP_KMAX) s_carry[threadIdx.x] = 0;
+__global__ void __launch_bounds__(64) k_pair_plan_colscan(const int32_t *__restrict__ wg_counts, int nwg, int kvol,
+                                                          int32_t *__restrict__ wg_base, int32_t *__restrict__ base_k,
+                                                          int32_t *__restrict__ hdr) {
+  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;          // column 0 .. kvol (kvol = rows whose centre entry is not the row)
   const int kc = kvol + 1;
-  for (int c0 = 0; c0 < nwg; c0 += nthr) {
-    const int rows = nwg - c0 < nthr ? nwg - c0 : nthr;
-    __syncthreads();
-    {
-      // every load of the chunk is in flight before the first one is used: the loop form waited a full memory round trip per
-      // iteration (28 of them per chunk, ~1600 ticks each: 90 k of this kernel's 112 k ticks -- tools/layout_bench.hip)
-      int ld[PP_KMAX];
+  int running = 0;
+  for (int c0 = 0; c0 < nwg; c0 += 512) {
+    int vv[8];
 #pragma unroll
-      for (int i = 0; i < PP_KMAX; i++) {
-        const int e = (int)threadIdx.x + i * nthr;
-        ld[i] = e < rows * kc ? wg_counts[(int64_t)c0 * kc + e] : 0;
-      }
-#pragma unroll
-      for (int i = 0; i < PP_KMAX; i++) {
-        const int e = (int)threadIdx.x + i * nthr;
-        if (e < rows * kc) s_rows[(e / kc) * RS + e % kc] = ld[i];
-      }
+    for (int j = 0; j < 8; j++) {                        // eight chunks of 64 rows requested together
+      const int w = c0 + 64 * j + lane;
+      vv[j] = w < nwg ? wg_counts[(int64_t)w * kc + k] : 0;
     }
-    __syncthreads();
-    const int w = c0 + (int)threadIdx.x;
-    const bool livew = w < nwg;
-    int v[PP_KMAX], ex[PP_KMAX];
 #pragma unroll
-    for (int k = 0; k < PP_KMAX; k++) v[k] = (livew && k <= kvol) ? s_rows[threadIdx.x * RS + k] : 0;
-#pragma unroll
-    for (int k = 0; k < PP_KMAX; k++) {
-      if (k > kvol) break;                               // uniform
-      // inclusive scan over the wave on the VALU: DPP row scan (zeros shifted in) + the three row totals as scalars
-      // (six ds_bpermute round trips per column -- __shfl_up -- were most of this kernel's time)
-      int incl = v[k];
+    for (int j = 0; j < 8; j++) {
+      if (c0 + 64 * j >= nwg) break;                     // uniform
+      const int w = c0 + 64 * j + lane;
+      int incl = vv[j];
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
-      {
-        const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
-        const int gq = lane >> 4;
-        incl += gq == 0 ? 0 : (gq == 1 ? t0 : (gq == 2 ? t0 + t1 : t0 + t1 + t2));
+      const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+      const int gq = lane >> 4;
+      incl += gq == 0 ? 0 : (gq == 1 ? t0 : (gq == 2 ? t0 + t1 : t0 + t1 + t2));
+      if (w < nwg && k < kvol) wg_base[(int64_t)w * kvol + k] = running + incl - vv[j];
+      running += __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+  if (lane == 0) {
+    if (k < kvol) base_k[k] = running; else hdr[3] = running;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pair_plan_finish(int nwg, int kvol, int centre, int skip_centre, int64_t gran_cap,
+                                                          int32_t *__restrict__ base_k, const int32_t *__restrict__ wg_base,
+                                                          int32_t *__restrict__ gran_start, int32_t *__restrict__ wg_k,
+                                                          int32_t *__restrict__ hdr, int32_t *__restrict__ wg_ext,
+                                                          int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out,
+                                                          int32_t *__restrict__ ext_total) {
+  __shared__ int s_tot[65], s_gs[66], s_base[65];
+  const int nthr = (int)blockDim.x;
+  PP_T(0);
+  if ((int)threadIdx.x < kvol) s_tot[threadIdx.x] = base_k[threadIdx.x];      // the column totals k_pair_plan_colscan left there
+  if (wg_ext) {
+    // rows of earlier workgroups over all offsets (the fill kernel's CSR starts): a thread per count workgroup, its kvol
+    // values requested together
+    for (int w = threadIdx.x; w < nwg; w += nthr) {
+      int acc = 0;
+#pragma unroll 32
+      for (int k = 0; k < kvol; k++) {
+        const int v = wg_base[(int64_t)w * kvol + k];
+        acc += (skip_centre && k == centre) ? 0 : v;
       }
-      ex[k] = incl - v[k];
-      if (lane == 63) s_wt[wave][k] = incl;
-    }
-    __syncthreads();
-    int ext = 0;
-#pragma unroll
-    for (int k = 0; k < PP_KMAX; k++) {
-      if (k >= kvol) break;                              // uniform (column kvol = the centre misses: total only)
-      int before = s_carry[k];
-      for (int u = 0; u < wave; u++) before += s_wt[u][k];
-      const int base = before + ex[k];
-      if (livew) s_rows[threadIdx.x * RS + k] = base;
-      ext += (skip_centre && k == centre) ? 0 : base;
-    }
-    if (wg_ext && livew) wg_ext[w] = ext;
-    __syncthreads();
-    for (int e = threadIdx.x; e < rows * kvol; e += nthr) wg_base[(int64_t)c0 * kvol + e] = s_rows[(e / kvol) * RS + e % kvol];
-    if ((int)threadIdx.x <= kvol) {
-      int tot = 0;
-      for (int u = 0; u < nwave; u++) tot += s_wt[u][threadIdx.x];
-      s_carry[threadIdx.x] += tot;
+      wg_ext[w] = acc;
     }
   }
   __syncthreads();
   PP_T(1);
-  if ((int)threadIdx.x <= kvol) s_tot[threadIdx.x] = s_carry[threadIdx.x];
-  __syncthreads();
   if (threadIdx.x == 0) {
     int64_t rows = 0, gran = 0, pairs = 0;
     for (int k = 0; k < kvol; k++) {
@@ -956,16 +935,14 @@ __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__rest
     gran_start[kvol] = s_gs[kvol] = (int32_t)gran;
     hdr[0] = (int32_t)pairs;
     hdr[1] = (int32_t)rows;
-    hdr[2] = (int32_t)gran;
-    hdr[3] = s_tot[kvol];                              // rows whose centre neighbour is not the row itself
+    hdr[2] = (int32_t)gran;                            // (hdr[3], rows whose centre neighbour is not the row itself: k_pair_plan_colscan)
     hdr[4] = gran > gran_cap ? 1 : 0;                  // capacity exceeded: cannot happen with the bound of the C ABI comment
     hdr[5] = hdr[6] = hdr[7] = 0;
     if (ext_total) *ext_total = (int32_t)pairs;       // ext_start[n]
   }
   __syncthreads();
   PP_T(2);
-  if (wg_ext) {
-    // (wg_ext -- rows of earlier workgroups over all offsets, the fill kernel's CSR starts -- was written in phase 1)
+  if (pair_in) {
     // -1 in the unused tail of every offset's last granule (the only padding a GEMM workgroup ever reads: granules behind
     // the last one return on wg_k)
     for (int k = 0; k < kvol; k++) {
@@ -997,6 +974,17 @@ __global__ void __launch_bounds__(1024) k_pair_plan_layout(const int32_t *__rest
   PP_T(4);
 }
 
+static int pair_plan_layout_run(const int32_t *wg_counts, int64_t nwg, int32_t kvol, int32_t skip_centre, int64_t gran_cap, int32_t *base_k,
+                                int32_t *wg_base, int32_t *gran_start, int32_t *wg_k, int32_t *hdr, int32_t *wg_ext, int32_t *pair_in,
+                                int32_t *pair_out, int32_t *ext_total, hipStream_t st, const char *what) {
+  hipLaunchKernelGGL(k_pair_plan_colscan, dim3((unsigned)(kvol + 1)), dim3(64), 0, st, wg_counts, (int)nwg, (int)kvol, wg_base, base_k, hdr);
+  int rc = check_launch(what);
+  if (rc != LINK_OK) return rc;
+  hipLaunchKernelGGL(k_pair_plan_finish, dim3(1), dim3(256), 0, st, (int)nwg, (int)kvol, (int)(kvol / 2), (int)skip_centre, gran_cap, base_k,
+                     (const int32_t *)wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_total);
+  return check_launch(what);
+}
+
 extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap,
                                      int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_k, int32_t *hdr,
                                      void *stream) {
@@ -1004,18 +992,8 @@ extern "C" int link_pair_plan_layout(const int32_t *wg_counts, int64_t n, int32_
   if (!wg_counts || !base_k || !wg_base || !gran_start || !hdr || (gran_cap > 0 && !wg_k)) return LINK_ERR_ARG;
   const int64_t nwg = (n + 255) / 256;
   if (nwg >= (1LL << 31)) return LINK_ERR_ARG;
-  if (kvol < 28)
-    hipLaunchKernelGGL(k_pair_plan_layout<28>, dim3(1), dim3(256), (size_t)256 * 29 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr);
-  else if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_plan_layout<65>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               512 * 65 * 4) != hipSuccess)
-    return LINK_ERR_LAUNCH;
-  else
-    hipLaunchKernelGGL(k_pair_plan_layout<65>, dim3(1), dim3(512), (size_t)512 * 65 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr);
-  return check_launch("link_pair_plan_layout");
+  return pair_plan_layout_run(wg_counts, nwg, kvol, skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, nullptr, nullptr, nullptr,
+                              nullptr, S(stream), "link_pair_plan_layout");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1093,22 +1071,33 @@ extern "C" int link_pair_plan_build(const int32_t *nbr, int64_t n, int32_t kvol,
   if (gran_cap < (n * (int64_t)(kvol - (skip_centre ? 1 : 0)) + 127 * (int64_t)kvol + 127) / 128) return LINK_ERR_ARG;
   int rc = link_pair_plan_count(nbr, n, kvol, wg_counts, row_info, stream);
   if (rc != LINK_OK) return rc;
-  if (kvol < 28)
-    hipLaunchKernelGGL(k_pair_plan_layout<28>, dim3(1), dim3(256), (size_t)256 * 29 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
-  else if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_plan_layout<65>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               512 * 65 * 4) != hipSuccess)
-    return LINK_ERR_LAUNCH;
-  else
-    hipLaunchKernelGGL(k_pair_plan_layout<65>, dim3(1), dim3(512), (size_t)512 * 65 * 4, S(stream), wg_counts, (int)nwg, (int)kvol, (int)(kvol / 2),
-                       (int)skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out, ext_start + n);
-  rc = check_launch("link_pair_plan_build");
+  rc = pair_plan_layout_run(wg_counts, nwg, kvol, skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out,
+                            ext_start + n, S(stream), "link_pair_plan_build");
   if (rc != LINK_OK) return rc;
   hipLaunchKernelGGL(k_pair_plan<true>, dim3((unsigned)nwg), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, S(stream), nbr, n,
                      (int)kvol, (int)(kvol / 2), (int)skip_centre, base_k, wg_base, (const int32_t *)nullptr, (int32_t *)nullptr,
                      (int32_t *)nullptr, pair_in, pair_out, ext_list, wg_ext, ext_start);
   return check_launch("link_pair_plan_build");
 }
+
+namespace link {
+// link_pair_plan_build behind a count pass somebody else has done (the block driver's neighbour-map kernel counts on the tile
+// it holds: dense_fused.hip, k_dc_neighbor_map<true>): layout + fill
+int pair_plan_build_counted(const int32_t *nbr, int64_t n, int32_t kvol, int32_t skip_centre, int64_t gran_cap, const int32_t *wg_counts,
+                            int32_t *base_k, int32_t *wg_base, int32_t *gran_start, int32_t *wg_ext, int32_t *wg_k, int32_t *hdr,
+                            int32_t *ext_start, int32_t *pair_in, int32_t *pair_out, int32_t *ext_list, hipStream_t st) {
+  if (n <= 0 || kvol <= 0 || kvol > 64 || gran_cap <= 0) return LINK_ERR_ARG;
+  const int64_t nwg = (n + 255) / 256;
+  if (gran_cap < (n * (int64_t)(kvol - (skip_centre ? 1 : 0)) + 127 * (int64_t)kvol + 127) / 128) return LINK_ERR_ARG;
+  int rc = pair_plan_layout_run(wg_counts, nwg, kvol, skip_centre, gran_cap, base_k, wg_base, gran_start, wg_k, hdr, wg_ext, pair_in, pair_out,
+                                ext_start + n, st, "link_elk_block_forward (pair plan)");
+  if (rc != LINK_OK) return rc;
+  hipLaunchKernelGGL(k_pair_plan<true>, dim3((unsigned)nwg), dim3(256), (size_t)(256 * kvol + 4 * (kvol + 1)) * 4, st, nbr, n, (int)kvol,
+                     (int)(kvol / 2), (int)skip_centre, base_k, wg_base, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                     pair_in, pair_out, ext_list, wg_ext, ext_start);
+  return check_launch("link_elk_block_forward (pair plan)");
+}
+}  // namespace link
 
 // ---------------------------------------------------------------------------------------------
 // gather table of a site-creating convolution, straight from the (b, z, y, x) rows

@@ -336,80 +336,146 @@ __device__ __forceinline__ int dc_floordiv_fast(int a, int s, float inv) {
   q += (r >= s ? 1 : 0) - (r < 0 ? 1 : 0);
   return q;
 }
-// A thread owns one (voxel, dx, dy) column of the 3 x 3 x 3 neighbourhood: z is the fastest axis of the cell numbering, so its three
-// targets lie in one cell (one scan of that cell's records answers all three) unless the column crosses a block boundary.
-__global__ void __launch_bounds__(256) k_dc_neighbor_map(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
+// A thread owns (voxel, dx) -- three (dx, dy) columns of the 3 x 3 x 3 neighbourhood, nine entries; z is the fastest axis of the
+// cell numbering, so a column's three targets lie in one cell (one scan of that cell's records answers all three) unless the
+// column crosses a block boundary.  A workgroup of 768 threads owns 256 table rows -- the unit of the pair plan's count pass
+// (conv_pairs.hip: k_pair_plan<false>) -- and lays them out in LDS: the table leaves in coalesced 16-byte stores, and with COUNT the
+// workgroup also does that count pass on the tile it holds (pairs per offset -> wg_counts[blockIdx][28], rows whose centre entry
+// is not the row itself in column 27; row_info[i] = #valid | centre valid << 16), so the pair plan needs no pass of its own over
+// the table before its layout.
+template <bool COUNT>
+__global__ void __launch_bounds__(768) k_dc_neighbor_map(const int4 *__restrict__ coords, int64_t n, link_dc_grid_t g,
                                                          const uint32_t *__restrict__ cnt, const int4 *__restrict__ slots, int step,
-                                                         int32_t *__restrict__ nbr) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * 9) return;
-  const int64_t row = t / 9;
-  const int kxy = (int)(t - row * 9);
-  const int4 c = coords[row];
-  const float inv = 1.0f / (float)g.s;
-  const int tx = c.x + (kxy % 3 - 1) * step, ty = c.y + (kxy / 3 - 1) * step;
-  const unsigned ux = (unsigned)(dc_floordiv_fast(tx, g.s, inv) - g.lo[0]), uy = (unsigned)(dc_floordiv_fast(ty, g.s, inv) - g.lo[1]);
-  const unsigned ub = (unsigned)(c.w - g.lo[3]);
-  const bool okxy = ux < (unsigned)g.dim[0] && uy < (unsigned)g.dim[1] && ub < (unsigned)g.dim[3];
-  const int bz = dc_floordiv_fast(c.z, g.s, inv);
-  const int rz = c.z - bz * g.s;                       // 0 .. s-1
-  int f[3] = {-1, -1, -1};
-  if (okxy) {
-    const bool one_cell = step <= g.s && rz - step >= 0 && rz + step < g.s;      // the three targets share the voxel's z-block
-    if (one_cell) {
-      const unsigned uz = (unsigned)(bz - g.lo[2]);
-      if (uz < (unsigned)g.dim[2]) {
-        const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
-        // the count and the cell's four inline records (one 64-byte line) are requested together: two dependent round trips
-        // per thread (coordinates -> cell) instead of 2 + the cell's voxel count
-        int nn = (int)cnt[pcell];
-        const int4 *inl = slots + (int64_t)pcell * DC_INL;
-        const int4 r4[4] = {inl[0], inl[1], inl[2], inl[3]};
-        nn = nn < g.k ? nn : g.k;
-        auto take = [&](const int4 &r) {
-          if (r.x == tx && r.y == ty) {
-            const int d = r.z - c.z;
-            if (d == -step && (f[0] < 0 || r.w < f[0])) f[0] = r.w;
-            if (d == 0 && (f[1] < 0 || r.w < f[1])) f[1] = r.w;
-            if (d == step && (f[2] < 0 || r.w < f[2])) f[2] = r.w;
+                                                         int32_t *__restrict__ nbr, int32_t *__restrict__ wg_counts,
+                                                         int32_t *__restrict__ row_info) {
+  __shared__ int32_t tile[256 * 27];
+  __shared__ int32_t wcnt[4 * 28];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const int rows = (int)((n - row0 < 256) ? n - row0 : 256);
+  const int r = (int)threadIdx.x / 3, kx = (int)threadIdx.x - 3 * r;
+  if (r < rows) {
+    const int4 c = coords[row0 + r];
+    const float inv = 1.0f / (float)g.s;
+    const int tx = c.x + (kx - 1) * step;
+    const unsigned ux = (unsigned)(dc_floordiv_fast(tx, g.s, inv) - g.lo[0]), ub = (unsigned)(c.w - g.lo[3]);
+    const bool okx = ux < (unsigned)g.dim[0] && ub < (unsigned)g.dim[3];
+    const int bz = dc_floordiv_fast(c.z, g.s, inv);
+    const int rz = c.z - bz * g.s;                     // 0 .. s-1
+    const bool one_cell = step <= g.s && rz - step >= 0 && rz + step < g.s;      // a column's three targets share the voxel's z-block
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int ty = c.y + (ky - 1) * step;
+      const unsigned uy = (unsigned)(dc_floordiv_fast(ty, g.s, inv) - g.lo[1]);
+      int f[3] = {-1, -1, -1};
+      if (okx && uy < (unsigned)g.dim[1]) {
+        if (one_cell) {
+          const unsigned uz = (unsigned)(bz - g.lo[2]);
+          if (uz < (unsigned)g.dim[2]) {
+            const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
+            // the count and the cell's four inline records (one 64-byte line) are requested together: two dependent round
+            // trips per column (coordinates -> cell) instead of 2 + the cell's voxel count
+            int nn = (int)cnt[pcell];
+            const int4 *inl = slots + (int64_t)pcell * DC_INL;
+            const int4 r4[4] = {inl[0], inl[1], inl[2], inl[3]};
+            nn = nn < g.k ? nn : g.k;
+            auto take = [&](const int4 &q) {
+              if (q.x == tx && q.y == ty) {
+                const int d = q.z - c.z;
+                if (d == -step && (f[0] < 0 || q.w < f[0])) f[0] = q.w;
+                if (d == 0 && (f[1] < 0 || q.w < f[1])) f[1] = q.w;
+                if (d == step && (f[2] < 0 || q.w < f[2])) f[2] = q.w;
+              }
+            };
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (j < nn) take(r4[j]);
+            for (int j = DC_INL; j < nn; j++) take(slots[link::dc_slot(g, pcell, j)]);
           }
-        };
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (j < nn) take(r4[j]);
-        for (int j = DC_INL; j < nn; j++) take(slots[link::dc_slot(g, pcell, j)]);
-      }
-    } else {
-#pragma unroll
-      for (int dz = 0; dz < 3; dz++) {
-        const int tz = c.z + (dz - 1) * step;
-        const unsigned uz = (unsigned)(dc_floordiv_fast(tz, g.s, inv) - g.lo[2]);
-        if (uz >= (unsigned)g.dim[2]) continue;
-        const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
-        int nn = (int)cnt[pcell];
-        nn = nn < g.k ? nn : g.k;
-        int found = -1;
-        for (int j = 0; j < nn; j++) {
-          const int4 r = slots[link::dc_slot(g, pcell, j)];
-          if (r.x == tx && r.y == ty && r.z == tz && (found < 0 || r.w < found)) found = r.w;
+          for (int dz = 0; dz < 3; dz++) {
+            const int tz = c.z + (dz - 1) * step;
+            const unsigned uz = (unsigned)(dc_floordiv_fast(tz, g.s, inv) - g.lo[2]);
+            if (uz >= (unsigned)g.dim[2]) continue;
+            const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
+            int nn = (int)cnt[pcell];
+            nn = nn < g.k ? nn : g.k;
+            int found = -1;
+            for (int j = 0; j < nn; j++) {
+              const int4 q = slots[link::dc_slot(g, pcell, j)];
+              if (q.x == tx && q.y == ty && q.z == tz && (found < 0 || q.w < found)) found = q.w;
+            }
+            f[dz] = found;
+          }
         }
-        f[dz] = found;
       }
+      int32_t *o = tile + r * 27 + kx + 3 * ky;
+      o[0] = f[0]; o[9] = f[1]; o[18] = f[2];
     }
   }
-  int32_t *o = nbr + row * 27 + kxy;
-  o[0] = f[0]; o[9] = f[1]; o[18] = f[2];
+  __syncthreads();
+  {                                                    // the tile leaves as it lies: rows * 27 contiguous ints
+    const int tot = rows * 27;
+    int32_t *dst = nbr + row0 * 27;                    // 256 * 27 * 4 bytes per workgroup: 16-byte aligned when nbr is
+    if ((reinterpret_cast<uintptr_t>(nbr) & 15) == 0) {
+      for (int e = threadIdx.x; e < (tot >> 2); e += 768) reinterpret_cast<int4 *>(dst)[e] = reinterpret_cast<const int4 *>(tile)[e];
+      for (int e = (tot & ~3) + threadIdx.x; e < tot; e += 768) dst[e] = tile[e];
+    } else {
+      for (int e = threadIdx.x; e < tot; e += 768) dst[e] = tile[e];
+    }
+  }
+  if (!COUNT) return;
+  // the pair plan's count pass on this tile (k_pair_plan<false>, conv_pairs.hip): thread = row, the first four waves
+  const int rr = (int)threadIdx.x;
+  if (rr < 256) {
+    const bool live = rr < rows;
+    const int32_t *mine = tile + (live ? rr : 0) * 27;
+    const int lane = rr & 63, wave = rr >> 6;
+    int nvalid = 0, cvalid = 0;
+    for (int k = 0; k < 27; k++) {
+      const int v = live ? mine[k] : -1;
+      const bool valid = v >= 0;
+      if (k == 13) {
+        cvalid = valid ? 1 : 0;
+        const unsigned long long bad = __ballot(live && v != (int)(row0 + rr));
+        if (lane == 0) wcnt[wave * 28 + 27] = __popcll(bad);
+      }
+      const unsigned long long m = __ballot(valid);
+      if (lane == 0) wcnt[wave * 28 + k] = __popcll(m);
+      nvalid += valid ? 1 : 0;
+    }
+    if (live) row_info[row0 + rr] = nvalid | (cvalid << 16);
+  }
+  __syncthreads();
+  if (rr <= 27) wg_counts[(int64_t)blockIdx.x * 28 + rr] = wcnt[rr] + wcnt[28 + rr] + wcnt[56 + rr] + wcnt[84 + rr];
 }
 
-extern "C" int link_dc_neighbor_map(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt,
-                                    const int32_t *slots, int32_t step, int32_t *nbr, void *stream) {
+static int dc_neighbor_map_run(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt, const int32_t *slots,
+                               int32_t step, int32_t *nbr, int32_t *wg_counts, int32_t *row_info, hipStream_t st) {
   if (n < 0 || !g || step <= 0) return LINK_ERR_ARG;
   if (n == 0) return LINK_OK;
   if (!coords || !cnt || !slots || !nbr || n * 27 >= (1LL << 31)) return LINK_ERR_ARG;
-  hipLaunchKernelGGL(k_dc_neighbor_map, dim3(link::blocks_for(n * 9, 256)), dim3(256), 0, link::S(stream),
-                     reinterpret_cast<const int4 *>(coords), n, *g, cnt, reinterpret_cast<const int4 *>(slots), (int)step, nbr);
+  const unsigned wgs = (unsigned)((n + 255) / 256);
+  if (wg_counts && row_info)
+    hipLaunchKernelGGL(k_dc_neighbor_map<true>, dim3(wgs), dim3(768), 0, st, reinterpret_cast<const int4 *>(coords), n, *g, cnt,
+                       reinterpret_cast<const int4 *>(slots), (int)step, nbr, wg_counts, row_info);
+  else
+    hipLaunchKernelGGL(k_dc_neighbor_map<false>, dim3(wgs), dim3(768), 0, st, reinterpret_cast<const int4 *>(coords), n, *g, cnt,
+                       reinterpret_cast<const int4 *>(slots), (int)step, nbr, (int32_t *)nullptr, (int32_t *)nullptr);
   return link::check_launch("link_dc_neighbor_map");
 }
+extern "C" int link_dc_neighbor_map(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt,
+                                    const int32_t *slots, int32_t step, int32_t *nbr, void *stream) {
+  return dc_neighbor_map_run(coords, n, g, cnt, slots, step, nbr, nullptr, nullptr, link::S(stream));
+}
+namespace link {
+// ... with the pair plan's count pass done on the way (wg_counts i32[ceil(n/256)][28], row_info i32[n]: link_pair_plan_count's outputs)
+int dc_neighbor_map_count_run(const int32_t *coords, int64_t n, const link_dc_grid_t *g, const uint32_t *cnt, const int32_t *slots,
+                              int32_t step, int32_t *nbr, int32_t *wg_counts, int32_t *row_info, hipStream_t st) {
+  if (!wg_counts || !row_info) return LINK_ERR_ARG;
+  return dc_neighbor_map_run(coords, n, g, cnt, slots, step, nbr, wg_counts, row_info, st);
+}
+}  // namespace link
 
 namespace link {
 // the insert of link_dc_index + occupancy statistics (behind link_dc_index_probe, dense.hip)

@@ -1,4 +1,4 @@
-// tools/layout_bench.hip -- where the single-workgroup layout kernel of the pair plan spends its time (s_memtime at its phase
+// tools/layout_bench.hip -- where the layout step of the pair plan (column scans + finish kernel) spends its time (s_memtime at its phase
 // boundaries; -DPP_DBG build of conv_pairs.hip included as a whole).   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPP_DBG
 //   -Iinclude -Ilink_amd/csrc tools/layout_bench.hip -o tools/bin/layout_bench
 #include "../link_amd/csrc/conv_pairs.hip"
@@ -23,15 +23,14 @@ int main() {
     link_pair_plan_count(nbr, n, kvol, arena + offs[0], arena + offs[1], nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_pair_plan_layout<28>, dim3(1), dim3(256), (size_t)256 * 29 * 4, nullptr, arena + offs[0], (int)nwg, kvol, kvol / 2, 1, gran_cap,
-                       meta, meta + kvol, meta + kvol + nwg * kvol, arena + offs[4], arena + offs[5], arena + offs[3], arena + offs[7], arena + offs[8],
-                       arena + offs[6] + n);
+    pair_plan_layout_run(arena + offs[0], nwg, kvol, 1, gran_cap, meta, meta + kvol, meta + kvol + nwg * kvol, arena + offs[4], arena + offs[5],
+                         arena + offs[3], arena + offs[7], arena + offs[8], arena + offs[6] + n, nullptr, "layout");
     hipEventRecord(e1, nullptr);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long t[8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pp_dbg), sizeof(t));
     int32_t hdr[8]; hipMemcpy(hdr, arena + offs[5], 32, hipMemcpyDeviceToHost);
-    printf("layout %.1f us (events); ticks: phase1 %llu, serial %llu, tails %llu, wg_k %llu  | pairs %d rows %d gran %d\n", ms * 1e3, t[1] - t[0], t[2] - t[1],
+    printf("colscan + finish %.1f us (events); finish ticks: totals + wg_ext %llu, serial %llu, tails %llu, wg_k %llu  | pairs %d rows %d gran %d\n", ms * 1e3, t[1] - t[0], t[2] - t[1],
            t[3] - t[2], t[4] - t[3], hdr[0], hdr[1], hdr[2]);
   }
   return 0;
