@@ -78,6 +78,8 @@ def _workspace(device) -> _Workspace:
 
 
 _BBOX_INIT: Dict[torch.device, torch.Tensor] = {}
+SPECULATE_GRID = True       # BlockIndex without bounds: built on the last grid of its block edge, box + M in one round trip
+_SPEC_GRID: Dict = {}       # (device, block edge) -> bounds (padded to whole blocks) of the last index whose bounds were measured
 
 
 def coords_bounds(coords: torch.Tensor) -> Tuple[Tuple[int, ...], Tuple[int, ...]]:
@@ -115,14 +117,50 @@ class BlockIndex:
         # bounds handed in by the caller (spatial_shape) are trusted without a sync: a voxel outside them is
         # dropped and reported in hdr[STATUS]; consumers zero-fill their outputs in that case (rows_checked)
         self.rows_checked = bounds is None
+        self._m: Optional[int] = None
+        self._nbr: Dict[Tuple[int, bool], torch.Tensor] = {}
+        if bounds is None and n > 0 and SPECULATE_GRID:
+            # Nobody told us the bounds (voxel_to_aux through the reference's surface, utils.py:44-52): instead of measuring
+            # them (one round trip), building the index, and reading M back (a second one), the index is built on the grid of
+            # the LAST index built for this block edge -- frames of a stream share their extents -- while the bounding box is
+            # taken in the same pass, and ONE 64-byte read answers both: the box lies inside that grid and no voxel was dropped
+            # (then block ids, which are ranks among occupied cells in coordinate order, do not depend on the grid's extent) or
+            # the index is built again on the measured bounds.  A grid more than twice the measured one is not kept either.
+            spec = _SPEC_GRID.get((dev, s))
+            if spec is not None:
+                got = self._build(spec, want_idx64, with_bbox=True)
+                box = (tuple(got[:4]), tuple(got[4:8]))
+                ok = got[8 + L.HDR_STATUS] == 0 and all(a <= b for a, b in zip(spec[0], box[0])) and all(
+                    a >= b for a, b in zip(spec[1], box[1]))
+                if ok:
+                    try:
+                        ok = self.v <= 2 * max(L.grid_from_bounds(box[0], box[1], s).cells, 1)
+                    except L.LinkAmdError:
+                        ok = False
+                if ok:
+                    self.bounds = box                       # what other map builders read from cmaps: the measured box
+                    self._m = int(got[8 + L.HDR_M])
+                    return
+                bounds = box
         if bounds is None:
             if n == 0:
                 bounds = ((0, 0, 0, 0), (0, 0, 0, 0))
             else:
                 bounds = coords_bounds(self.coords)
-        self.bounds = (tuple(int(x) for x in bounds[0]), tuple(int(x) for x in bounds[1]))
+        bounds = (tuple(int(x) for x in bounds[0]), tuple(int(x) for x in bounds[1]))
+        self._build(bounds, want_idx64, with_bbox=False)
+        self.bounds = bounds
+        if self.rows_checked and n > 0:
+            q = int(s)                                      # remembered padded to whole blocks: equal extents, equal grid
+            _SPEC_GRID[(dev, s)] = (tuple((v // q) * q for v in bounds[0][:3]) + (bounds[0][3],),
+                                    tuple((v // q) * q + q - 1 for v in bounds[1][:3]) + (bounds[1][3],))
+
+    def _build(self, bounds, want_idx64: bool, with_bbox: bool):
+        """Allocate and launch the index build on the grid of `bounds`; with_bbox: the bounding-box kernel in the same pass,
+        returns [bbox(8) | hdr(8)] read back in one transfer."""
+        n, s, dev = self.n, self.s, self.coords.device
         try:
-            self.grid = L.grid_from_bounds(self.bounds[0], self.bounds[1], s)
+            self.grid = L.grid_from_bounds(bounds[0], bounds[1], s)
         except L.LinkAmdError as e:
             raise GridTooLarge(str(e))
         self.v = v = self.grid.cells
@@ -140,9 +178,19 @@ class BlockIndex:
         self.blk_start = torch.empty(n + 1, **i32)
         self.blk_coords = torch.empty((max(n, 1), 4), **i32)
         self.counts_buf = torch.empty(max(n, 1), **i32)
-        self.hdr = torch.empty(L.HDR_WORDS, **i32)
-        self._m: Optional[int] = None
-        self._nbr: Dict[Tuple[int, bool], torch.Tensor] = {}
+        both = None
+        if with_bbox:
+            init = _BBOX_INIT.get(dev)
+            if init is None:
+                imax, imin = 2 ** 31 - 1, -2 ** 31
+                init = _BBOX_INIT[dev] = torch.tensor([imax] * 4 + [imin] * 4, dtype=torch.int32, device=dev)
+            both = torch.empty(8 + L.HDR_WORDS, **i32)
+            both[:8].copy_(init)
+            self.hdr = both[8:]
+            L.check(L.lib().link_coords_bbox(self.coords.data_ptr(), n, both.data_ptr(), L.current_stream_handle()),
+                    "link_coords_bbox")
+        else:
+            self.hdr = torch.empty(L.HDR_WORDS, **i32)
         L.check(L.lib().link_index_build(
             self.coords.data_ptr(), n, ctypes.byref(self.grid), cell_counts.data_ptr(), scratch.data_ptr(),
             scratch.numel(), self.cell_blk.data_ptr(), self.vox_blk.data_ptr(),
@@ -150,6 +198,7 @@ class BlockIndex:
             self.pos_blk.data_ptr(),
             self.blk_start.data_ptr(), self.blk_coords.data_ptr(), self.counts_buf.data_ptr(),
             self.hdr.data_ptr(), L.current_stream_handle()), "link_index_build")
+        return both.tolist() if with_bbox else None
 
     # -- lazily synchronised facts ------------------------------------------------------------------
     @property

@@ -115,3 +115,51 @@ def test_foreign_neighbor_map():
     for r in (2, 3):
         out = foreign_neighbor_map(torch.from_numpy(rows).cuda(), r).cpu().numpy()
         assert np.array_equal(out, O.neighbor_index(rows, r))
+
+
+def test_index_without_bounds_is_built_on_the_last_grid_in_one_round_trip():
+    """BlockIndex(coords, s) with nobody telling the bounds (voxel_to_aux through the reference's surface): from the second frame
+    of a block edge on, the index is built on the last frame's grid while the bounding box is taken in the same pass (index.py:
+    SPECULATE_GRID).  Same extents / a frame inside the grid: accepted, everything bit for bit what the oracle says, `bounds` = the
+    measured box, M already on the host.  A frame beyond the grid, and one that fills less than half of it: built again."""
+    import link_amd as la
+    from link_amd import index as I
+    s = 5
+    I._SPEC_GRID.clear()
+    a = s_uniform(9000, grid=60, seed=3).numpy(); a[0, :3] = 0; a[1, :3] = 59
+    b = s_uniform(8000, grid=60, seed=4).numpy(); b[0, :3] = 0; b[1, :3] = 59
+    inside = s_uniform(7000, grid=50, seed=5).numpy() + np.array([3, 4, 5, 0], np.int32)
+    beyond = s_uniform(7000, grid=60, seed=6).numpy() + np.array([30, 0, 0, 0], np.int32)
+    small = s_uniform(800, grid=20, seed=7).numpy() + np.array([35, 2, 2, 0], np.int32)
+    negative = s_uniform(5000, grid=40, seed=8).numpy() - np.array([17, 3, 9, 0], np.int32)
+    spec_before = None
+    for name, c in [("a", a), ("b", b), ("inside", inside), ("beyond", beyond), ("small", small), ("negative", negative), ("negative2", negative)]:
+        ct = torch.from_numpy(np.ascontiguousarray(c)).cuda()
+        idx = la.BlockIndex(ct, s)
+        small_c, idxq, counts = O.voxel_to_aux_index(c, s)
+        spec_taken = idx._m is not None                       # M came with the one round trip
+        assert spec_taken == (name in ("b", "inside", "negative2")), (name, spec_taken)
+        assert idx.M == small_c.shape[0], name
+        assert np.array_equal(idx.block_coords.cpu().numpy(), small_c), name
+        assert np.array_equal(idx.idx_query.cpu().numpy(), idxq) and np.array_equal(idx.counts.cpu().numpy(), counts), name
+        assert np.array_equal(idx.perm.cpu().numpy(), np.argsort(idxq, kind="stable").astype(np.int32)), name
+        assert idx.bounds == (tuple(int(v) for v in c.min(0)), tuple(int(v) for v in c.max(0))), name
+        for r in (2, 3):
+            assert np.array_equal(idx.neighbor_map(r).cpu().numpy(), O.neighbor_index(small_c, r)), (name, r)
+        if spec_taken:
+            assert I._SPEC_GRID[(ct.device, s)] == spec_before   # an accepted guess does not move the remembered grid
+        spec_before = I._SPEC_GRID[(ct.device, s)]
+    # voxel_to_aux / aux_to_voxel through the surface on a guessed grid: the same rows as with the guess switched off
+    x = torch.randn(b.shape[0], 32, generator=torch.Generator().manual_seed(1)).cuda()
+    ct = torch.from_numpy(np.ascontiguousarray(b)).cuda()
+    outs = []
+    for flag in (True, False):
+        I.SPECULATE_GRID = flag
+        try:
+            st = la.SparseTensor(x, ct.clone(), 1)
+            sm, iq, cn = la.voxel_to_aux(st, s)
+            outs.append((la.aux_to_voxel(sm, st, iq, cn, 3).F, sm.C, iq, cn))
+        finally:
+            I.SPECULATE_GRID = True
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
