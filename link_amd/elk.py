@@ -42,7 +42,7 @@ from .utils import get_kernel_offsets, make_ntuple
 
 __all__ = ["ELKBlock", "TSELKBlock", "Conv3d", "spconv2ts", "ts2spconv", "SparseConvTensor",
            "elk_core_fused", "elk_core_autograd", "elk_core_train", "ElkCorePlan", "subm_conv", "subm_conv_ln_add_relu",
-           "invalidate_derived_weights"]
+           "invalidate_derived_weights", "release_block_driver"]
 
 _OPS = {"cos": L.OP_COS, "sin": L.OP_SIN, "cos_x": L.OP_COSX}
 _IO_DTYPES = {torch.float32: L.IO_F32, torch.float16: L.IO_F16, torch.bfloat16: L.IO_BF16}
@@ -459,9 +459,12 @@ class ElkCorePlan:
         return self
 
     def run(self, feats: torch.Tensor, coords: torch.Tensor, build_index: bool = True,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
         """One R_core step.  `out` (fp32 [n, C], contiguous): write the result there instead of the plan's
-        own buffer (what the module path does: the block's output tensor must outlive the plan)."""
+        own buffer (what the module path does: the block's output tensor must outlive the plan).
+        `stream`: raw hipStream_t (`torch.cuda.Stream.cuda_stream`) to launch on instead of torch's current stream -- a
+        serving loop that keeps several frames in flight passes its streams here and skips torch's stream context
+        (entering and leaving `torch.cuda.stream(...)` costs more host time than the step's three launches)."""
         n = feats.shape[0]
         assert n <= self.n_cap and feats.shape[1] == self.c and feats.dtype in _IO_DTYPES
         assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
@@ -479,7 +482,7 @@ class ElkCorePlan:
         if out is not None:
             assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
         self.buf.out = (out if out is not None else own).data_ptr()
-        st = L.current_stream_handle()
+        st = L.current_stream_handle() if stream is None else int(stream)
         if self.lean:
             rc = self._run_lean(n, build_index, st)
         elif self.dense and self.sparse:
@@ -1810,6 +1813,17 @@ def _block_ctx(device):
         L.check(L.lib().link_block_ctx_create(ctypes.byref(h)), "link_block_ctx_create")
         ctx = _BLOCK_CTX[key] = h
     return ctx
+
+
+def release_block_driver() -> None:
+    """Destroy the block driver's contexts (side stream, events, scratch) and free its contribution-row scratch -- up to 1 GiB per
+    (device, stream) that has run link_elk_block_forward ("persistent footprint")."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    for h in _BLOCK_CTX.values():
+        L.lib().link_block_ctx_destroy(h)
+    _BLOCK_CTX.clear()
+    _BLOCK_CONTRIB.clear()
 
 
 DENSE_MAX_MEAN, DENSE_MAX_CELL = 6.0, 24     # voxels per occupied block: mean and maximum the dense-cell kernels take

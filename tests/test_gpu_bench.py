@@ -33,8 +33,8 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     assert all(r["voxels"] == 100000 and 43000 < r["blocks"] < 43700 for r in d["ranks"])
     assert d["ranks"][0]["checksum"] != d["ranks"][1]["checksum"]           # different frames per rank
     assert d["value"] > 0 and d["config"]["frames_in_flight_per_gpu"] == 3
-    # a step = one batch of 3 frames per GPU: 6 frames per step over the two ranks; value = voxels of all timed frames / time
-    assert d["frames_per_step"] == 6 and abs(d["us_per_frame"] * 3 - d["ms_per_step"] * 1e3) < 0.05
+    # a step = one batch of 24 frames per GPU (8 rounds of the 3 in flight): 48 frames per step over the two ranks; value = voxels of all timed frames / time
+    assert d["frames_per_step"] == 48 and abs(d["us_per_frame"] * 24 - d["ms_per_step"] * 1e3) < 0.4
     assert abs(d["value"] - 2 * 100000 / (d["us_per_frame"] * 1e-6)) < 1e-3 * d["value"]
     # SURVEY.md 8e side figures of the N > 1 line: the collective really spans both ranks, the summary gather sits inside a
     # reported end-to-end time, the full-tensor gather ([N, C] rows of every rank, two-phase pattern) is timed on its own
@@ -46,7 +46,7 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     assert single["multi_gpu"] is None
     assert "gpu_state" in single and isinstance(single["gpu_state"], dict)          # clock / power state (amdsmi) or why it is missing
     assert single["n_gpus"] == 1 and single["ranks"][0]["blocks"] == d["ranks"][0]["blocks"]
-    assert single["frames_per_step"] == 3 and abs(single["value"] - 100000 / (single["us_per_frame"] * 1e-6)) < 1e-3 * single["value"]
+    assert single["frames_per_step"] == 24 and single["three_frame_step"]["us_per_frame"] > 0 and abs(single["value"] - 100000 / (single["us_per_frame"] * 1e-6)) < 1e-3 * single["value"]
     assert abs(single["roofline"]["whole_step"]["us"] - single["us_per_frame"]) < 0.02
     assert abs(single["ranks"][0]["checksum"] - d["ranks"][0]["checksum"]) <= 1e-6 * abs(single["ranks"][0]["checksum"]) + 1e-3
     chk = single["timed_configuration_check"]
