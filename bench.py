@@ -274,8 +274,12 @@ def timed_regions(la, blk, feats, coords, C, s, r, iters=30):
         with torch.no_grad():
             return blk(st, s, r).F
 
-    return {"R_agg_cold_us": med(lambda: r_agg(False)), "R_agg_warm_us": med(lambda: r_agg(True)),
-            "R_block_cold_us": med(lambda: r_block(False)), "R_block_warm_us": med(lambda: r_block(True)),
+    from link_amd import elk as _elk
+    calls0 = dict(_elk.BLOCK_DRIVER_CALLS)
+    res = {"R_agg_cold_us": med(lambda: r_agg(False)), "R_agg_warm_us": med(lambda: r_agg(True)),
+           "R_block_cold_us": med(lambda: r_block(False)), "R_block_warm_us": med(lambda: r_block(True))}
+    res["block_driver_calls"] = {k: _elk.BLOCK_DRIVER_CALLS[k] - calls0[k] for k in calls0}    # how R_block cold ran: link_elk_block_forward done / missed
+    return {**res,
             "note": "host-inclusive device-event medians through the Python module surface (allocating path); "
                     "R_core cold/warm are `value`/`warm_index_value` (arena path, one FFI call per step)"}
 

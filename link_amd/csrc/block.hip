@@ -20,6 +20,8 @@
 // here is a kernel the other sections export (and test), plus two of dense_fused.hip written for it: the fused first launch
 // (k_dc_index_probe_bbox) and the neighbour table read off the slot lists (k_dc_neighbor_map).
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -60,11 +62,16 @@ extern "C" int link_block_ctx_create(link_block_ctx_t **out) {
   link_block_ctx *c = new link_block_ctx();
   memset(c, 0, sizeof(*c));
   hipError_t e = hipGetDevice(&c->device);
-  // the side stream carries the call's longest chain (pair plan + GEMM: four small kernels that compete with the two fused R_core
-  // kernels for workgroup slots): highest priority, so that its workgroups are placed first when a slot frees up
-  int pr_least = 0, pr_greatest = 0;
-  if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr_greatest);
+  // (LINK_BLOCK_SIDE_PRIO=1, A/B only: the side stream at the highest stream priority)
+  if (e == hipSuccess) {
+    if (getenv("LINK_BLOCK_SIDE_PRIO")) {
+      int pr_least = 0, pr_greatest = 0;
+      e = hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr_greatest);
+    } else {
+      e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    }
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), 2 * BLOCK_WORDS * sizeof(int32_t));
@@ -107,6 +114,17 @@ extern "C" int64_t link_pair_plan_arena(int64_t n, int32_t kvol, int32_t skip_ce
   return gran_cap;
 }
 
+// LINK_BLOCK_PROF=1: host-side phase times of link_elk_block_forward (us since entry), printed every 64th call
+struct block_prof {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  double t[8];
+  int n;
+  block_prof() : on(getenv("LINK_BLOCK_PROF") != nullptr), n(0) {}
+  void start() { if (on) { t0 = std::chrono::steady_clock::now(); n = 0; } }
+  void mark() { if (on && n < 8) t[n++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 static int block_fail(const char *what, hipError_t e) {
   link::set_error(what, e);
   return LINK_ERR_LAUNCH;
@@ -135,6 +153,9 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   if (gran_cap < 0 || po[10] > a->pair_arena_words || a->contrib_rows < gran_cap * 128) return LINK_ERR_WORKSPACE;
   hipStream_t st = link::S(stream);
   a->verdict = LINK_BLOCK_MISS;
+  static thread_local block_prof prof;
+  static thread_local unsigned prof_calls = 0;
+  prof.start();
 
   // ---- 1. slot insert with occupancy counters + bounding box: ONE launch whose last workgroup writes the 272 result words into
   //         mapped host memory and then the call's sequence number into word 8 -- the host polls that word (a stream
@@ -153,6 +174,7 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   if (rc != LINK_OK) { c->primed = false; return rc; }
   c->primed = true;
   c->last_stream = st;
+  prof.mark();                                         // 0: probe launched
   {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
@@ -168,6 +190,7 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
     if (!arrived) { c->primed = false; return block_fail("link_elk_block_forward (results never arrived)", hipErrorUnknown); }
   }
   hipError_t e = hipSuccess;
+  prof.mark();                                         // 1: results arrived
   const int32_t *h = c->host;
   const int64_t n_in = h[16], m = h[17];
   const int32_t mx = h[18];
@@ -198,11 +221,13 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   int32_t *ext_start = pa + po[6], *pair_in = pa + po[7], *pair_out = pa + po[8], *ext_list = pa + po[9];
   rc = link::dc_neighbor_map_count_run(b->coords, n, g, b->cnt, reinterpret_cast<const int32_t *>(b->slots), a->ts, a->nbr, wg_counts, row_info, st);
   if (rc != LINK_OK) return rc;
+  prof.mark();                                         // 2: neighbour table launched
   hipStream_t sd = c->side;
   e = hipEventRecord(c->fork, st);
   if (e != hipSuccess) return block_fail("link_elk_block_forward (fork)", e);
   rc = link_elk_core_dense_forward(b, g, a->desc, n, 2, stream);
 
+  prof.mark();                                         // 3: fork recorded + R_core launched
   // ---- 4. side stream: pair plan laid out on the device + the pair GEMM (they need the table and the input rows only) ----
   e = hipStreamWaitEvent(sd, c->fork, 0);
   const int64_t nwg = (n + 255) / 256;
@@ -217,6 +242,7 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
     else
       rs = link_conv_pairs_gemm_io(b->feats, LINK_IO_F32, pair_in, wg_k, gran_cap * 128, a->w, C, C, a->contrib, sd);
   }
+  prof.mark();                                         // 4: side chain launched
   const hipError_t e1 = hipEventRecord(c->join, sd);
   const hipError_t e2 = hipStreamWaitEvent(st, c->join, 0);        // joined whatever happened: nothing of this call outlives it unordered
   if (e != hipSuccess) return block_fail("link_elk_block_forward (fork)", e);
@@ -228,6 +254,10 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   rc = link_conv_centre_sum_io(b->feats, a->w, kvol / 2, a->contrib, gran_cap * 128, ext_start, ext_list, n, C, C, nullptr, a->nl_w,
                                a->nl_b, a->nl_eps, b->out, a->flags, a->out, LINK_IO_F32, stream);
   if (rc != LINK_OK) return rc;
+  prof.mark();                                         // 5: join + finish launched
+  if (prof.on && (++prof_calls & 63u) == 0)
+    fprintf(stderr, "link_elk_block_forward host us: probe launched %.1f | results %.1f | table %.1f | fork + R_core %.1f | side chain %.1f | join + finish %.1f\n",
+            prof.t[0], prof.t[1], prof.t[2], prof.t[3], prof.t[4], prof.t[5]);
   a->verdict = LINK_BLOCK_DONE;
   return LINK_BLOCK_DONE;
 }
