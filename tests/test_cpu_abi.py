@@ -289,3 +289,23 @@ def test_lean_form_entry_rejects_bad_arguments_without_gpu():
         big.lo[a], big.dim[a] = 0, (1024 if a < 3 else 1)           # 2^30 cells: an item is cell * 16 + chunk in 31 bits
     b.seg_cap = 4096
     assert lib.link_elk_core_lean_forward(ctypes.byref(b), ctypes.byref(big), ctypes.byref(desc), 10, 0, 1, None) == L.LINK_ERR_ARG
+
+
+def test_block_driver_struct_and_arena_helper():
+    """Section G (ABI 11): link_block_args_t as ctypes sees it is what the library was compiled with (checked at load through
+    link_abi_struct_size(7)), and link_pair_plan_arena -- a host helper, no GPU -- lays the ten pieces out 16-byte aligned with the
+    capacity link_pair_plan_build demands."""
+    from link_amd import _lib as L
+    lib = L.lib()
+    assert L.ABI_VERSION >= 11 and lib.link_abi_struct_size(7) == ctypes.sizeof(L.LinkBlockArgs)
+    offs = (ctypes.c_int64 * 11)()
+    for n, kvol, skip in ((100000, 27, 1), (777, 27, 0), (5, 8, 0), (300000, 27, 1)):
+        gran = lib.link_pair_plan_arena(n, kvol, skip, offs)
+        nwg, cap = (n + 255) // 256, n * (kvol - skip)
+        assert gran == (cap + 127 * kvol + 127) // 128
+        o = [int(v) for v in offs]
+        assert o[0] == 0 and all(v % 4 == 0 for v in o) and all(b > a for a, b in zip(o, o[1:]))
+        sizes = [nwg * (kvol + 1), n, kvol + nwg * kvol + kvol + 1, nwg, gran, 8, n + 1, gran * 128, gran * 128, max(cap, 1)]
+        assert all(o[i + 1] - o[i] >= sizes[i] for i in range(10))
+    assert lib.link_pair_plan_arena(0, 27, 1, offs) == -1 and lib.link_pair_plan_arena(10, 65, 0, offs) == -1
+    assert lib.link_elk_block_forward(None, None, None) == L.LINK_ERR_ARG       # argument validation before anything touches a device
