@@ -157,3 +157,47 @@ def test_dc_neighbor_map_equals_the_cell_table_map(s, step, grid, n):
     assert torch.equal(nbr, want)
     assert int((nbr[:, 13] != torch.arange(m, device=c.device, dtype=torch.int32)).sum()) == 0
     plan._unprobe()
+
+
+def test_block_driver_across_streams_release_and_workspace_errors():
+    """The driver's context keeps per-call scratch that the previous call lays out in stream order: calls that alternate between
+    two torch streams (the context then re-initialises its scratch behind a synchronisation) give the same rows; a pair-plan arena
+    or contribution buffer smaller than link_pair_plan_arena says is refused with LINK_ERR_WORKSPACE before anything is launched;
+    release_block_driver() frees contexts and scratch and the next call builds them again."""
+    import ctypes
+    import link_amd as la
+    from link_amd import elk
+    from link_amd import _lib as L
+    C, s, r = 64, 7, 3
+    blk = _blk(C, 2, "cos")
+    n, grid = 12000, 96
+    frames = _frames(n, grid, 3)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():
+        want = [blk(la.SparseTensor(x, c.clone(), 1), s, r).F.clone() for c in frames]       # frame 0 per stage, 1-2 through the driver
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        before = elk.BLOCK_DRIVER_CALLS["done"]
+        for rep in range(3):
+            for k, c in enumerate(frames):
+                with torch.cuda.stream(streams[(rep + k) % 2]):
+                    got = blk(la.SparseTensor(x, c.clone(), 1), s, r).F
+                torch.cuda.synchronize()
+                assert torch.equal(got, want[k]), (rep, k)
+        assert elk.BLOCK_DRIVER_CALLS["done"] - before == 9
+        elk.release_block_driver()
+        assert not elk._BLOCK_CTX and not elk._BLOCK_CONTRIB
+        got = blk(la.SparseTensor(x, frames[1].clone(), 1), s, r).F
+        assert torch.equal(got, want[1]) and len(elk._BLOCK_CTX) == 1
+    # a call whose arena is too small launches nothing
+    plan = blk._dc_last[1]
+    a = L.LinkBlockArgs()
+    ctypes.memmove(ctypes.byref(a), ctypes.byref(plan._blk_args), ctypes.sizeof(a))
+    a.pair_arena_words = 16
+    ctx = elk._block_ctx(x.device)
+    assert L.lib().link_elk_block_forward(ctx, ctypes.byref(a), L.current_stream_handle()) == L.LINK_ERR_WORKSPACE
+    ctypes.memmove(ctypes.byref(a), ctypes.byref(plan._blk_args), ctypes.sizeof(a))
+    a.contrib_rows = 128
+    assert L.lib().link_elk_block_forward(ctx, ctypes.byref(a), L.current_stream_handle()) == L.LINK_ERR_WORKSPACE
+    torch.cuda.synchronize()
+    assert int(plan.cnt.sum()) == 0 or plan.__dict__.get("_indexed") is not None
