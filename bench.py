@@ -102,7 +102,9 @@ def gpu_state_during(run, device_index=0, period_s=0.001):
 
 
 ROUNDS = max(1, int(os.environ.get("LINK_BENCH_ROUNDS", "8")))   # a step = ROUNDS rounds of the frames in flight (see timed())
-SETTLE_STEPS = 500      # untimed steps before the warm-up (clock ramp, ~60 ms on cfg2); reported in the line
+SETTLE_STEPS = int(os.environ.get("LINK_BENCH_SETTLE", "60"))      # untimed steps before the warm-up (clock ramp); reported in the line.
+# (500 until the step became a batch of 24 frames: three regions of the timed shape are 50 ms at the driver's --steps 20, and the
+# figure is the same with 60 as with 500 -- 34.7 / 35.0 against 35.3 / 35.7 us/frame, alternating on one box)
 
 
 def s_uniform(n, grid=256, seed=0):
