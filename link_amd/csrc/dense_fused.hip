@@ -361,70 +361,53 @@ __global__ void __launch_bounds__(768) k_dc_neighbor_map(const int4 *__restrict_
     const bool okx = ux < (unsigned)g.dim[0] && ub < (unsigned)g.dim[3];
     const int bz = dc_floordiv_fast(c.z, g.s, inv);
     const int rz = c.z - bz * g.s;                     // 0 .. s-1
-    const bool one_cell = step <= g.s && rz - step >= 0 && rz + step < g.s;      // a column's three targets share the voxel's z-block
+    // A column's three targets (z - step, z, z + step) lie in the voxel's own z-block A and at most in the blocks below (L) and
+    // above (U) it; a record of any of these cells is a target iff its (x, y) match and its z differs from the voxel's by -step,
+    // 0 or +step -- no need to ask which cell a target falls into.  A and one neighbour block B (L or U: 2 of 7 z-positions cross
+    // a boundary at s = 7, step 1) are looked up TOGETHER -- two counts and two 64-byte lines of inline records in flight per
+    // column: one memory round trip -- and U on its own only when a column crosses both ways (block edge < 2 x step: rare).
+    // (Versions before: cell after cell, record after record, 38 us; a one-cell path NEXT TO a three-cells path, both of which
+    // every wave ran: 30 us, 943 vector instructions and 86 loads per wave -- tools/_pmc counters in docs/experiments.md.)
+    const bool lowc = rz - step < 0, upc = rz + step >= g.s;
+    const unsigned uzA = (unsigned)(bz - g.lo[2]);
+    const unsigned uzB = (unsigned)((lowc ? dc_floordiv_fast(c.z - step, g.s, inv) : dc_floordiv_fast(c.z + step, g.s, inv)) - g.lo[2]);
+    const unsigned uzU = (unsigned)(dc_floordiv_fast(c.z + step, g.s, inv) - g.lo[2]);
+    const bool hasB = lowc || upc, both = lowc && upc;
+    const bool any_both = __any(both);                   // wave-uniform
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
       const int ty = c.y + (ky - 1) * step;
       const unsigned uy = (unsigned)(dc_floordiv_fast(ty, g.s, inv) - g.lo[1]);
       int f[3] = {-1, -1, -1};
-      if (okx && uy < (unsigned)g.dim[1]) {
-        if (one_cell) {
-          const unsigned uz = (unsigned)(bz - g.lo[2]);
-          if (uz < (unsigned)g.dim[2]) {
-            const int pcell = link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub);
-            // the count and the cell's four inline records (one 64-byte line) are requested together: two dependent round
-            // trips per column (coordinates -> cell) instead of 2 + the cell's voxel count
-            int nn = (int)cnt[pcell];
-            const int4 *inl = slots + (int64_t)pcell * DC_INL;
-            const int4 r4[4] = {inl[0], inl[1], inl[2], inl[3]};
-            nn = nn < g.k ? nn : g.k;
-            auto take = [&](const int4 &q) {
-              if (q.x == tx && q.y == ty) {
-                const int d = q.z - c.z;
-                if (d == -step && (f[0] < 0 || q.w < f[0])) f[0] = q.w;
-                if (d == 0 && (f[1] < 0 || q.w < f[1])) f[1] = q.w;
-                if (d == step && (f[2] < 0 || q.w < f[2])) f[2] = q.w;
-              }
-            };
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (j < nn) take(r4[j]);
-            for (int j = DC_INL; j < nn; j++) take(slots[link::dc_slot(g, pcell, j)]);
-          }
-        } else {
-          // the column crosses a block boundary (2 of 7 z-positions at s = 7 -- and a wave waits for its slowest lane, so
-          // every wave takes this branch): the three targets' cells are looked up TOGETHER, counts and inline records of all
-          // three in flight at once.  (First version: cell after cell, record after record -- ~36 dependent round trips per
-          // thread; the kernel took 38 us for 10.8 MB of output.)
-          int pc[3], nn[3];
-          int4 rr[3][4];
-#pragma unroll
-          for (int dz = 0; dz < 3; dz++) {
-            const int tz = c.z + (dz - 1) * step;
-            const unsigned uz = (unsigned)(dc_floordiv_fast(tz, g.s, inv) - g.lo[2]);
-            pc[dz] = uz < (unsigned)g.dim[2] ? link::dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub) : 0;      // 0: the padding cell, count 0
-          }
-#pragma unroll
-          for (int dz = 0; dz < 3; dz++) {
-            nn[dz] = (int)cnt[pc[dz]];
-            const int4 *inl = slots + (int64_t)pc[dz] * DC_INL;
-            rr[dz][0] = inl[0]; rr[dz][1] = inl[1]; rr[dz][2] = inl[2]; rr[dz][3] = inl[3];
-          }
-#pragma unroll
-          for (int dz = 0; dz < 3; dz++) {
-            const int tz = c.z + (dz - 1) * step;
-            int m = pc[dz] ? (nn[dz] < g.k ? nn[dz] : g.k) : 0;
-            int found = -1;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (j < m && rr[dz][j].x == tx && rr[dz][j].y == ty && rr[dz][j].z == tz && (found < 0 || rr[dz][j].w < found)) found = rr[dz][j].w;
-            for (int j = DC_INL; j < m; j++) {
-              const int4 q = slots[link::dc_slot(g, pc[dz], j)];
-              if (q.x == tx && q.y == ty && q.z == tz && (found < 0 || q.w < found)) found = q.w;
-            }
-            f[dz] = found;
-          }
+      const bool okxy = okx && uy < (unsigned)g.dim[1];
+      auto take = [&](const int4 &q) {
+        if (q.x == tx && q.y == ty) {
+          const int d = q.z - c.z;
+          if (d == -step && (f[0] < 0 || q.w < f[0])) f[0] = q.w;
+          if (d == 0 && (f[1] < 0 || q.w < f[1])) f[1] = q.w;
+          if (d == step && (f[2] < 0 || q.w < f[2])) f[2] = q.w;
         }
+      };
+      // cell 0 is a padding cell: its count is 0 and its line is always there to be read
+      const int pcA = (okxy && uzA < (unsigned)g.dim[2]) ? link::dc_cell(g, (int)ux, (int)uy, (int)uzA, (int)ub) : 0;
+      const int pcB = (okxy && hasB && uzB < (unsigned)g.dim[2]) ? link::dc_cell(g, (int)ux, (int)uy, (int)uzB, (int)ub) : 0;
+      int nA = (int)cnt[pcA], nB = (int)cnt[pcB];
+      const int4 *iA = slots + (int64_t)pcA * DC_INL, *iB = slots + (int64_t)pcB * DC_INL;
+      const int4 rA[4] = {iA[0], iA[1], iA[2], iA[3]}, rB[4] = {iB[0], iB[1], iB[2], iB[3]};
+      nA = pcA ? (nA < g.k ? nA : g.k) : 0;
+      nB = pcB ? (nB < g.k ? nB : g.k) : 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (j < nA) take(rA[j]);
+        if (j < nB) take(rB[j]);
+      }
+      for (int j = DC_INL; j < nA; j++) take(slots[link::dc_slot(g, pcA, j)]);
+      for (int j = DC_INL; j < nB; j++) take(slots[link::dc_slot(g, pcB, j)]);
+      if (any_both) {
+        const int pcU = (okxy && both && uzU < (unsigned)g.dim[2]) ? link::dc_cell(g, (int)ux, (int)uy, (int)uzU, (int)ub) : 0;
+        int nU = pcU ? (int)cnt[pcU] : 0;
+        nU = nU < g.k ? nU : g.k;
+        for (int j = 0; j < nU; j++) take(slots[link::dc_slot(g, pcU, j)]);
       }
       int32_t *o = tile + r * 27 + kx + 3 * ky;
       o[0] = f[0]; o[9] = f[1]; o[18] = f[2];

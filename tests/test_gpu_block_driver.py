@@ -128,7 +128,7 @@ def test_block_driver_vs_oracle():
     assert elk.BLOCK_DRIVER_CALLS["done"] - before == 1
 
 
-@pytest.mark.parametrize("s,step,grid,n", [(7, 1, 64, 9000), (5, 1, 40, 6000), (6, 2, 48, 3000), (3, 1, 24, 5000)])
+@pytest.mark.parametrize("s,step,grid,n", [(7, 1, 64, 9000), (5, 1, 40, 6000), (6, 2, 48, 3000), (3, 1, 24, 5000), (3, 2, 30, 2500), (4, 4, 48, 1200)])
 def test_dc_neighbor_map_equals_the_cell_table_map(s, step, grid, n):
     """link_dc_neighbor_map (the 27-neighbour table read off a frame's freshly inserted slot lists) against
     link_cell_table_build + link_neighbor_map, the table every convolution test pins on the reference's kernel maps: bit-exact,
