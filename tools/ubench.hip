@@ -47,6 +47,21 @@ __global__ void __launch_bounds__(256) k_rowgather(const float4 *in, const int *
   if (r < rows) out[(size_t)r * 16 + l] = in[(size_t)perm[r] * 16 + l];
 }
 
+// the same rows read only (summed into a register) / written only (to permuted positions): the two access patterns of the fused
+// R_core kernels on S-uniform frames -- voxel rows gathered by id, output rows stored by id (round 5)
+__global__ void __launch_bounds__(256) k_rowgather_ro(const float4 *in, const int *perm, float *out, int rows, int reps) {
+  int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+  float acc = 0;
+  if (r < rows)
+    for (int k = 0; k < reps; k++) { const float4 v = in[((size_t)perm[r] + (size_t)k * rows) * 16 + l]; acc += v.x + v.y + v.z + v.w; }
+  if (acc == 123.456f) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_rowscatter(float4 *out, const int *perm, int rows, int reps) {
+  int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+  if (r < rows)
+    for (int k = 0; k < reps; k++) out[((size_t)perm[r] + (size_t)k * rows) * 16 + l] = make_float4(1, 2, 3, (float)k);
+}
+
 template <typename F> float timeit(F f, int reps = 20) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   f(); f(); hipDeviceSynchronize();
@@ -85,6 +100,16 @@ int main() {
     int *perm; CK(hipMalloc(&perm, rows * 4)); CK(hipMemcpy(perm, h.data(), rows * 4, hipMemcpyHostToDevice));
     float us = timeit([&] { hipLaunchKernelGGL(k_rowgather, dim3((rows * 16 + 255) / 256), dim3(256), 0, 0, (const float4 *)buf, perm, (float4 *)buf2, rows); });
     printf("row gather 100k x 256 B (25.6 MB in + out): %.2f us\n", us);
+    // a pseudo-random permutation (the multiplicative one above keeps neighbours 7919 rows apart: DRAM pages still line up)
+    unsigned long long x = 88172645463325252ull;
+    for (int i = rows - 1; i > 0; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; int j = (int)(x % (unsigned)(i + 1)); int t = h[i]; h[i] = h[j]; h[j] = t; }
+    CK(hipMemcpy(perm, h.data(), rows * 4, hipMemcpyHostToDevice));
+    for (int reps : {1, 8}) {
+      const double mb = 25.6 * reps;
+      float g = timeit([&] { hipLaunchKernelGGL(k_rowgather_ro, dim3((rows * 16 + 255) / 256), dim3(256), 0, 0, (const float4 *)buf, perm, buf2, rows, reps); });
+      float w = timeit([&] { hipLaunchKernelGGL(k_rowscatter, dim3((rows * 16 + 255) / 256), dim3(256), 0, 0, (float4 *)buf, perm, rows, reps); });
+      printf("random 256-B rows, %d x 100k (%.1f MB): read-only gather %.2f us (%.2f TB/s)  scatter store %.2f us (%.2f TB/s)\n", reps, mb, g, mb / g, w, mb / w);
+    }
   }
   return 0;
 }
