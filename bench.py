@@ -885,12 +885,13 @@ def main():
                  "full_tensor_gather_ok": bool(float(side[2]) == 1.0),
                  "full_tensor_gather_note": "all_gather of every rank's fp32 [N, C] result rows (sizes, then padded payload), best of 3, max "
                                             "over ranks; reported separately, never inside `value` (SURVEY.md 8e)"}
-        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single]],
+        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single, elapsed_r1]],
                             dtype=torch.float64, device=cdev)
         rows = gather_frame_rows(mine).cpu()
         elapsed = float(rows[:, 4].max())
         elapsed_warm = float(rows[:, 5].max())
         elapsed_single = float(rows[:, 6].max())
+        elapsed_r1 = float(rows[:, 7].max())
         total_vox = float(rows[:, 1].sum())
         rank_rows = [{"rank": int(r[0]), "voxels": int(r[1]), "blocks": int(r[2]), "checksum": float(r[3])}
                      for r in rows[rows[:, 0].argsort()].tolist()]
