@@ -34,6 +34,9 @@ def test_surface_vs_golden(name):
            else la.small_to_large_v2(small, large, idx, counts))
     assert out is large                                                         # utils.py:82-84 in place
     assert rel_err(large.F.cpu().numpy(), g["out"]) < 1e-5
+    if r == 3:        # round 6: the same call through the reference's COMPILED devoxelize_forward_cpu (8-wide slices, make_golden.py)
+        assert "reference compiled ops" in g["meta"]["devoxelize"]
+        assert rel_err(large.F.cpu().numpy(), g["out_refcpu"]) < 1e-5
 
 
 def test_block_mean_bit_exact_vs_oracle():

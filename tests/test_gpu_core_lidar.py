@@ -26,11 +26,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4              # north_star: within 1e-4 rel on fp32 features (max|a - b| / max|b|)
 
 
+# Round 6: seeds 0, 1 and 7 -- on seed 0 the biggest stage sits at 0.93 of the gate for the four-kernel and
+# lean forms (the float64 arbiter shows the ORACLE is 2-3e-5 from the truth there), so one frame proves little.  The per-form maxima
+# of every (variant, seed, stage) go to gpurun_out/lidar_parity_maxima.jsonl (committed as profiles/r06_lidar_parity_maxima.jsonl).
+@pytest.mark.parametrize("seed", [0, 1, 7])
 @pytest.mark.parametrize("variant", ["encoder", "unet"])
-def test_core_forms_on_full_size_s_kitti_stage_frames_vs_oracle_and_float64(variant):
+def test_core_forms_on_full_size_s_kitti_stage_frames_vs_oracle_and_float64(variant, seed):
+    import json
     from tools.lidar_core_parity import core_refs, forms_of, seg_stage_calls
     dev = torch.device("cuda:0")
-    calls = seg_stage_calls(dev, variant)
+    calls = seg_stage_calls(dev, variant, seed=seed)
+    rows = []
     assert len(calls) == 4 and calls[0]["feats"].shape[0] > 40000          # full-size frame: ~59k voxels at stride 2
     for k, r in enumerate(calls):
         ref32, ref64 = core_refs(r, variant)
@@ -43,5 +49,14 @@ def test_core_forms_on_full_size_s_kitti_stage_frames_vs_oracle_and_float64(vari
         for name, out in got.items():
             rel32 = float((out - ref32).abs().max() / ref32.abs().max())
             rel64 = float((out.double() - ref64).abs().max() / s64)
-            assert rel32 < TOL, (variant, k + 1, name, rel32)
-            assert rel64 <= 2.0 * o64 + 2e-6, (variant, k + 1, name, rel64, o64)
+            rows.append({"variant": variant, "seed": seed, "stage": k + 1, "voxels": int(r["feats"].shape[0]), "form": name,
+                         "rel32": rel32, "rel64": rel64, "oracle_rel64": o64, "share_of_gate": rel32 / TOL})
+            assert rel32 < TOL, (variant, seed, k + 1, name, rel32)
+            assert rel64 <= 2.0 * o64 + 2e-6, (variant, seed, k + 1, name, rel64, o64)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "lidar_parity_maxima.jsonl"), "a") as f:
+            for row in rows:
+                f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass

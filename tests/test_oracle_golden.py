@@ -63,6 +63,14 @@ def test_aggregate_vs_reference(name):
     assert np.array_equal(aux_f, g["aux_f"])               # same op order as voxelize_cpu.cpp -> exact
     out = O.aux_to_voxel(aux_f, small_c, idx, counts, r)
     assert rel_err(out, g["out"]) < 2e-6
+    if r == 3:
+        # round 6: the r = 3 forward pinned on reference OUTPUT -- the fixture also holds the same aux_to_voxel call with spdevoxelize
+        # routed through the reference's compiled devoxelize_forward_cpu (devoxelize_cpu.cpp:9-31: K = 8 per call -> four 8-wide
+        # slices of the [M, 27] map padded to 32 columns with (-1, 0), partial outputs added; make_golden.py::_CompiledDevox).
+        # It agrees with the torch restatement of devoxelize_cuda.cu:21-33 to summation order (27 terms in one chain / four groups)
+        assert "r=3 forward: reference compiled ops" in g["meta"]["devoxelize"]
+        assert rel_err(g["out"], g["out_refcpu"]) < 5e-7
+        assert rel_err(out, g["out_refcpu"]) < 2e-6
 
 
 @pytest.mark.parametrize("name", golden_files("g_agg_*.npz"))
@@ -112,6 +120,9 @@ def test_block_core_and_grads_vs_reference(name):
                               m["s"], m["r"], m["baseop"], m["groups"], m["variant"],
                               m["tensor_stride"], agg=O.aggregate_c)
     assert rel_err(core_c.numpy(), g["core"]) < 1e-5
+    if m["r"] == 3:              # r = 3: the block's forward through the reference's compiled CPU devoxelize (see test_aggregate_vs_reference)
+        assert rel_err(g["core"], g["core_refcpu"]) < 1e-6 and rel_err(g["out"], g["out_refcpu"]) < 1e-6
+        assert rel_err(core.detach().numpy(), g["core_refcpu"]) < 1e-5 and rel_err(core_c.numpy(), g["core_refcpu"]) < 1e-5
     names = sorted(params)
     grads = torch.autograd.grad(core, [feats] + [params[n] for n in names], torch.from_numpy(g["grad_out"]))
     assert rel_err(grads[0].numpy(), g["grad_feats"]) < 1e-4
