@@ -705,6 +705,18 @@ def main():
 
     import link_amd as la
     from link_amd import _lib as L
+    from link_amd.parallel import pin_rank_to_gpu_numa
+
+    # Host placement: with several ranks on one node every rank pins itself to CPUs of ITS GPU's NUMA node
+    # (its own slice of them when ranks share a node) -- the issuing thread spends 12-20 us per 35 us frame, and an unpinned rank may
+    # sit on the far socket.  One rank alone is left where the launcher put it (the cpu_baseline thread sweep needs every core);
+    # LINK_BENCH_PIN=1 / 0 forces either.  The record of every rank is in the line (`cpu_affinity`).
+    pin_env = os.environ.get("LINK_BENCH_PIN", "")
+    if (world > 1 and pin_env != "0") or pin_env == "1":
+        affinity = pin_rank_to_gpu_numa(local_rank, local_rank, min(world, torch.cuda.device_count()))
+    else:
+        affinity = {"pinned": False, "numa_node": None, "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0,
+                    "first_cpu": None, "reason": "single rank: left where the launcher put it"}
 
     if args.workload == "cfg3":
         return cfg3_mode(args, la, dev, rank, world, dist)
@@ -848,6 +860,9 @@ def main():
         # pattern (sizes, then payload padded to the longest; det3d/torchie/trainer/utils.py:114-155) -- timed on its own.
         ones = torch.ones(1, dtype=torch.float64, device=cdev)
         dist.all_reduce(ones)
+        if float(ones.item()) != float(world):           # fail loudly: a job whose collective does not span --gpus ranks measured something else
+            raise SystemExit(f"bench.py: all_reduce of ones gave {float(ones.item())} on rank {rank}, expected {world} "
+                             f"(backend {dist.get_backend()}): the process group does not span --gpus {args.gpus} ranks")
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -885,7 +900,9 @@ def main():
                  "full_tensor_gather_ok": bool(float(side[2]) == 1.0),
                  "full_tensor_gather_note": "all_gather of every rank's fp32 [N, C] result rows (sizes, then padded payload), best of 3, max "
                                             "over ranks; reported separately, never inside `value` (SURVEY.md 8e)"}
-        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single, elapsed_r1]],
+        mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single, elapsed_r1,
+                              1.0 if affinity["pinned"] else 0.0, float(-1 if affinity["numa_node"] is None else affinity["numa_node"]),
+                              float(affinity["cpus"]), float(-1 if affinity["first_cpu"] is None else affinity["first_cpu"])]],
                             dtype=torch.float64, device=cdev)
         rows = gather_frame_rows(mine).cpu()
         elapsed = float(rows[:, 4].max())
@@ -895,9 +912,12 @@ def main():
         total_vox = float(rows[:, 1].sum())
         rank_rows = [{"rank": int(r[0]), "voxels": int(r[1]), "blocks": int(r[2]), "checksum": float(r[3])}
                      for r in rows[rows[:, 0].argsort()].tolist()]
+        affinity_rows = [{"rank": int(r[0]), "pinned": bool(r[8]), "numa_node": (None if r[9] < 0 else int(r[9])), "cpus": int(r[10]),
+                          "first_cpu": (None if r[11] < 0 else int(r[11]))} for r in rows[rows[:, 0].argsort()].tolist()]
     else:
         total_vox = float(N)
         rank_rows = [{"rank": 0, "voxels": N, "blocks": int(M), "checksum": checksum}]
+        affinity_rows = [dict(rank=0, **{k: affinity[k] for k in ("pinned", "numa_node", "cpus", "first_cpu")})]
 
     if rank != 0:
         if world > 1:
@@ -1059,6 +1079,9 @@ def main():
         "timed_configuration_check": timed_check,
         "gpu_state": gpu_state,        # shader / memory clock and socket power under this load (amdsmi)
         "ranks": rank_rows,          # the trivial result gather: one summary row per rank (frame 0 of each rank)
+        "cpu_affinity": {"ranks": affinity_rows, "rank0_reason": affinity["reason"],
+                         "note": "N > 1: every rank pins itself to CPUs of its GPU's NUMA node (link_amd.parallel.pin_rank_to_gpu_numa); "
+                                 "LINK_BENCH_PIN=0/1 overrides"},
         "multi_gpu": multi,          # N > 1 only: backend, all_reduce check, end-to-end time, full-tensor gather
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
     }

@@ -33,6 +33,7 @@ extern "C" {
 #define LINK_ERR_ARG (-1)       /* null pointer / negative size / unsupported width */
 #define LINK_ERR_LAUNCH (-2)    /* hipGetLastError() != hipSuccess after a launch */
 #define LINK_ERR_WORKSPACE (-3) /* caller-provided workspace too small */
+#define LINK_BATCH_TIMEOUT (-4) /* link_dc_batch_status: a bounded wait inside a persistent batch kernel gave up (section H) */
 
 /* Version of this ABI (bumped on any signature change). */
 int link_abi_version(void);
@@ -938,6 +939,38 @@ typedef struct {
   int32_t reserved;
 } link_block_args_t;
 int link_elk_block_forward(link_block_ctx_t *ctx, link_block_args_t *args /* host, in/out */, void *stream);
+
+/* =============================================================================================
+ * H. R_core of a BATCH of independent frames in one call (round 6; csrc/dense_batch.hip)
+ *
+ * The reference batches frames by the batch column of its coordinates (the batch index is part of every block key,
+ * segmentation/core/models/utils.py:45; linkunet.py:132,151-162,178 run one ELKBlock over the whole collated batch) and shards
+ * independent frames over GPUs (BASELINE.json configs[3]: "a batch of 8 independent frames").  link_elk_core_dense_forward_batch
+ * is the dense-cell R_core (section E) of `nframes` frames -- each with its own link_dc_buffers_t, all on one grid, one block's
+ * parameters, one descriptor -- as THREE launches, two of them persistent: the slot insert of every frame (one ordinary grid), a
+ * K1-role kernel (one workgroup per CU; parameters staged once; every wave walks the frames: its range of cells of frame f as soon
+ * as the insert of f has arrived) and a K2-role kernel (one workgroup per CU pulling (frame, tile) items off per-XCD cursors: a tile
+ * of frame f as soon as K1 of f has arrived).  The stages of different frames overlap by construction -- per-frame arrival counters
+ * with write-through stores / one agent-scope acquire per item replace the stream-ordered launch boundaries of the per-frame calls.
+ * Results: those of link_elk_core_dense_forward(build_index = 1) per frame, bit for bit.
+ *
+ * Contract: C = 64, cg = 32 (two-part rows whose channels j and j + 32 share theta), op cos / sin, r in {2, 3}, coord_div = 1, no
+ * alpha, fp32 rows, slot capacity <= 352, every frame its own cnt / slots / vcell / cell_n / S / hdr / out -- LINK_ERR_ARG otherwise
+ * (nothing launched; the caller runs the frames through section E one by one).  frames[i].tune is not read (the geometry is the
+ * roles': workgroups = CUs, 2 z-segments).  The call returns when everything is ENQUEUED; the results are complete in `stream`
+ * order.  Calls whose frames share no buffers overlap on the device (K1 of the next batch starts under K2 of the previous one):
+ * a caller that keeps two batches in flight alternates two sets of frame buffers and two streams.  The context owns three
+ * non-blocking streams, 20 events and 19 KB of counters; create one per device (and per host thread).
+ * link_dc_batch_status synchronises the context's streams and returns LINK_BATCH_TIMEOUT if a bounded wait inside a kernel gave
+ * up (the frames' rows are then undefined), LINK_OK otherwise; out[0] = the first error word, out[1] = launch sets so far.
+ * ============================================================================================= */
+typedef struct link_dc_batch link_dc_batch_t;
+int link_dc_batch_create(link_dc_batch_t **out);       /* on the current device */
+int link_dc_batch_destroy(link_dc_batch_t *ctx);
+int link_elk_core_dense_forward_batch(link_dc_batch_t *ctx, const link_dc_buffers_t *frames /* host [nframes] */,
+                                      const int64_t *n /* host [nframes] */, int32_t nframes, const link_dc_grid_t *g /* host */,
+                                      const link_elk_desc_t *desc /* host */, void *stream);
+int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
 
 #ifdef __cplusplus
 }

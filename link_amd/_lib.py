@@ -13,13 +13,13 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "liblink_amd.so")
 
-LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE = 0, -1, -2, -3
+LINK_OK, LINK_ERR_ARG, LINK_ERR_LAUNCH, LINK_ERR_WORKSPACE, LINK_BATCH_TIMEOUT = 0, -1, -2, -3, -4
 HDR_M, HDR_STATUS, HDR_NVALID, HDR_STATUS_ACC, HDR_WORDS = 0, 1, 2, 3, 8
 OP_COS, OP_SIN, OP_COSX = 0, 1, 2
 ELK_LANE_CHANNEL, ELK_NO_PAIR, ELK_FUSED_GATHER, ELK_NO_DENSE_GRID, ELK_TILES = 1, 2, 4, 8, 16     # link_elk_desc_t::flags
 ELK_LEAN_CS, ELK_LEAN_NO_CS, ELK_LEAN_PM, ELK_LEAN_NO_PM = 32, 64, 128, 256
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 # LINK_AMD_DEBUG=1: read the device status word back after every core call (one 32-byte D2H sync per call) and
 # raise when the index dropped a voxel -- the sync-free default trusts the caller's bounds
 DEBUG = os.environ.get("LINK_AMD_DEBUG", "0") not in ("", "0")
@@ -253,6 +253,11 @@ SIGNATURES = {
     "link_pair_plan_arena": (c_int64, [c_int64, c_int32, c_int32, POINTER(c_int64)]),
     "link_dc_neighbor_map": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid), c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "link_elk_block_forward": (c_int, [c_void_p, POINTER(LinkBlockArgs), c_void_p]),
+    "link_dc_batch_create": (c_int, [POINTER(c_void_p)]),
+    "link_dc_batch_destroy": (c_int, [c_void_p]),
+    "link_elk_core_dense_forward_batch": (c_int, [c_void_p, POINTER(LinkDcBuffers), POINTER(c_int64), c_int32, POINTER(LinkDcGrid),
+                                                  POINTER(LinkElkDesc), c_void_p]),
+    "link_dc_batch_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }
@@ -301,7 +306,8 @@ def current_stream_handle() -> int:
 def check(rc: int, what: str) -> None:
     if rc != LINK_OK:
         msg = {LINK_ERR_ARG: "invalid argument", LINK_ERR_LAUNCH: "HIP launch failure",
-               LINK_ERR_WORKSPACE: "workspace too small"}.get(rc, f"error {rc}")
+               LINK_ERR_WORKSPACE: "workspace too small",
+               LINK_BATCH_TIMEOUT: "a bounded wait inside a persistent batch kernel gave up"}.get(rc, f"error {rc}")
         detail = lib().link_last_error()
         raise LinkAmdError(f"{what}: {msg}" + (f" ({detail.decode()})" if detail else ""))
 

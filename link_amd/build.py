@@ -19,7 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 SO = os.path.join(LIBDIR, "liblink_amd.so")
 SOURCES = ["ops.hip", "index.hip", "aggregate.hip", "elk.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "dense.hip", "dense_fused.hip", "dense_fused_f16.hip", "dense_fused_bf16.hip",
            "dense_tiles.hip", "dense_tiles_f16.hip", "dense_tiles_bf16.hip", "elk_tiles.hip", "elk_tiles_f16.hip", "elk_tiles_bf16.hip",
-           "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip", "block.hip"]
+           "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip", "block.hip", "dense_batch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("LINK_AMD_CXXFLAGS", "").split()      # A/B experiments (-DNAME=value); part of the build stamp

@@ -1,0 +1,452 @@
+// link_amd/csrc/dense_batch.hip -- R_core of a BATCH of independent frames on the dense-cell layout as THREE launches, two of them
+// persistent and queue-fed (include/link_amd.h section H; round 6, VERDICT round 5 "next 1").
+//
+// What it replaces.  A frame's R_core is three dependent launches (slot insert, K1 = fused pre_mix + modulate + per-cell sums,
+// K2 = fused box sum + de-modulate); BASELINE.json configs[3] is "a batch of 8 independent frames", and until this round the
+// product's answer to several frames per GPU was "the caller keeps three plans on three HIP streams" -- the overlap of the stages
+// of different frames was whatever the hardware queues happened to interleave, and every frame paid two stream-ordered launch
+// boundaries and the fill / drain of two grids.  Here the batch is ONE call:
+//
+//   stream C   k_dc_batch_insert   ordinary grid, (frame, chunk of voxels) per workgroup, frames in order; the records are stored
+//                                  write-through (sc1) and every workgroup ends with one arrival on ins_done[frame]
+//   stream A   k_dc_batch_k1       PERSISTENT, one 4-wave workgroup per CU: stages W / LayerNorm / theta parameters ONCE, then every
+//                                  wave walks the frames: wait ins_done[f] -> its range of cells of frame f (dc_k1_range, the body of
+//                                  the stand-alone kernel, reading the insert's records with sc1 loads and publishing S rows / counts
+//                                  / sorted records with sc1 stores) -> s_waitcnt vmcnt(0) -> one arrival on k1_done[f]
+//   stream B   k_dc_batch_k2       PERSISTENT, one 8-wave workgroup per CU: pulls (frame, tile) items off eight per-XCD cursors
+//                                  (tiles of a frame keep the XCD they have in the stand-alone kernel: halo planes stay in one L2),
+//                                  ONE relaxed poll of k1_done[frame] + ONE agent-scope acquire + barrier per item, then
+//                                  dc_k2q_body (the stand-alone kernel's body) on that tile
+//
+// No workgroup ever waits on a workgroup of its OWN kernel, so no kernel needs all of its workgroups resident: insert waits on
+// nothing, K1 on insert arrivals, K2 on K1 arrivals.  What must hold is that a K1 workgroup can always be placed while K2 workgroups
+// spin (and vice versa): a CU's 160 KB of LDS take exactly one K1 (80 896 B) + one K2 workgroup (padded to 82 432 B, so that TWO
+// K2 workgroups do not fit and cannot squat a CU a K1 workgroup needs); registers: 200 + 2 x 120 of 512 per SIMD, which leaves the
+// LDS-free insert kernel (<= 64 registers) its wave.  Every spin is bounded (DC_BT_TIMEOUT_TICKS of the 100 MHz clock) and watches
+// a shared error word: a violated assumption ends the call with LINK_BATCH_TIMEOUT in link_dc_batch_status, not with a hung GPU.
+//
+// Visibility inside the launches follows MI355X_MICROARCH.md "inter-workgroup visibility": producers store write-through (sc1)
+// and drain vmcnt before their arrival atomic; K1 reads the insert's tables with sc1 loads (no acquire per wave and frame), K2
+// runs one agent-scope acquire per item (it reads through LDS-DMA and plain loads).  The atomic counters of the insert (cnt) are
+// device-scope atomics and live at the memory side.
+//
+// Results: bit for bit those of link_elk_core_dense_forward per frame (same device bodies, same arithmetic; the launch
+// geometry -- cells per K1 wave, z-segments of K2 -- does not enter any sum's order).  C = 64, cg = 32, cos / sin, r in {2, 3},
+// coord_div = 1, no alpha, fp32 rows, slot capacity <= 352: what the quad-consumer K2 serves; LINK_ERR_ARG otherwise (the caller
+// runs the frames one by one).
+#define DC_IO 0
+#define DC_IO_NS dcb_f32
+#include <stdlib.h>
+
+#include <type_traits>
+#include <vector>
+
+#include "dense_gather.h"
+#include "dense_io.h"
+
+#ifndef DC_BT_MAX
+#define DC_BT_MAX 32                 /* frames per launch set (the frame table travels as a kernel argument: 32 x 80 B) */
+#endif
+#ifndef DC_BT_TIMEOUT_TICKS
+#define DC_BT_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz s_memrealtime clock */
+#endif
+#ifndef DC_BT_RELEASE_FENCE
+#define DC_BT_RELEASE_FENCE 0       /* 1: K1 publishes with an agent-scope release fence (buffer_wbl2) in front of its arrival as well
+                                       -- belt and braces for A/B; every published table is stored write-through already */
+#endif
+
+namespace DC_IO_NS {
+using namespace link;
+
+#include "dense_k1_impl.h"
+#include "dense_k2_cfg.h"
+#include "dense_gather_quad_impl.h"
+
+static_assert(DC_ST_AUX == 16, "the S rows must leave the L2 (sc1) for the in-launch hand-off K1 -> K2");
+
+struct dc_bt_frame_t {               // one frame's buffers (device pointers), 80 bytes
+  const void *feats; const int4 *coords; int4 *slots; uint32_t *cnt; int32_t *cell_n; int32_t *vcell; float *S; int32_t *hdr;
+  void *out; int64_t n;
+};
+struct dc_bt_frames_t { dc_bt_frame_t f[DC_BT_MAX]; };
+struct dc_bt_par_t {
+  const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *ln_w, *ln_b;
+  int cg; float eps;
+};
+// sync words of one call (int32, zeroed before the launches): every counter on its own 64-byte line
+__host__ __device__ constexpr int bt_err() { return 0; }
+__host__ __device__ constexpr int bt_cursor(int xcd) { return 16 * (1 + xcd); }          // K2's item cursors, one per XCD queue
+__host__ __device__ constexpr int bt_k1cur(int xcd) { return 16 * (9 + xcd); }          // K1's item cursors, one per XCD slab
+__host__ __device__ constexpr int bt_ins(int f) { return 16 * (17 + 2 * f); }           // arrivals of the frame's insert workgroups
+__host__ __device__ constexpr int bt_k1(int f) { return 16 * (18 + 2 * f); }            // arrivals of the frame's K1 ranges
+constexpr int BT_SYNC_WORDS = 16 * (17 + 2 * DC_BT_MAX);
+
+// Lane 0 polls *p until it reaches `target` (relaxed agent-scope loads: sc1, L2-served), sleeping between polls, giving up when the
+// call's error word is set or after DC_BT_TIMEOUT_TICKS; returns (wave-uniform) whether the target was reached.
+__device__ __forceinline__ bool bt_wait_ge(int32_t *sync, int word, int target) {
+  int ok = 1;
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int spins = 0;
+    while (__hip_atomic_load(&sync[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if ((++spins & 15) == 0) {
+        if (__hip_atomic_load(&sync[bt_err()], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > DC_BT_TIMEOUT_TICKS) {
+          __hip_atomic_store(&sync[bt_err()], 1 + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// slot insert of every frame of the batch: workgroup -> (frame, chunk); write-through records; one arrival per workgroup
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dc_batch_insert(dc_bt_frames_t fr, link_dc_grid_t g, int wpf, int32_t *__restrict__ sync) {
+  const int f = (int)blockIdx.x / wpf, j = (int)blockIdx.x - f * wpf;
+  const dc_bt_frame_t &F = fr.f[f];
+  int s0 = 0, s1 = 0, s2 = 0;
+  dc_index_body<false, true>(F.coords, F.n, g, F.cnt, F.slots, F.vcell, F.hdr, j, wpf, 256, s0, s1, s2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through records (and its counter atomics) have left
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[bt_ins(f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K1 role: parameters staged once, then (frame, range of cells) items in frame order
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A frame's cells are cut into `nranges` ranges of `cpw` cells, dealt to eight per-XCD cursors as contiguous slabs of `per`
+// ranges; item t of XCD x's cursor is range x * per + t % per of frame t / per.  A wave pulls items off its XCD's cursor until
+// the cursor runs past the batch.  Every global round trip costs 1-3 us under load, so none of the loop's own is left exposed:
+//   * the NEXT item is drawn (returning atomic) before the current range is worked on -- its result is there when it is needed;
+//   * an item's arrival on k1_done is posted when the NEXT item's first loads have been waited for (memory operations retire in
+//     order: the item's write-through stores have been acknowledged by then) instead of behind a drain of its own;
+//   * the frame's insert arrivals are read with the item's first loads; only a wave that finds them incomplete polls.
+// (History, same box, 24 frames x 2 sets: wave w owning range w of every frame 48.7 us / frame -- K2 of a frame waits for the frame's
+// LAST range, so the batch advanced at the pace of its slowest wave while the fast ones ran frames ahead for nothing; dynamic items
+// with blocking draws, a drain per item and eight slab probes at every frame's end 64.8, two / four ranges per wave and frame 83.6 /
+// 116: ~17 us of exposed round trips per item.  Three plans on three streams: 34.7.)
+template <int OP, int NB>
+__global__ void __launch_bounds__(64 * DC_K1_NW, DC_K1_WAVES) k_dc_batch_k1(dc_bt_frames_t fr, dc_bt_par_t p, link_dc_grid_t g, int nframes,
+                                                                           int cpw, int nranges, int wpf, int32_t *__restrict__ sync) {
+  constexpr int C = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  bool w_big = false, th_big = false;
+  dc_k1_stage<C, OP>(smem_raw, p.w_pre, p.pre_ln_w, p.pre_ln_b, p.w_pos, nullptr, p.cg, 1.0f, g, tid, w_big, th_big);
+  w_big = DC_K1_SPLIT ? (__syncthreads_or(w_big) != 0) : (__syncthreads(), false);
+  const bool th_slow = DC_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;
+  const int Vi = g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
+  const int x = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u);
+  const int per = (nranges + 7) >> 3;                  // ranges of one XCD slab
+  const int lo = x * per;
+  const int mine = (lo + per < nranges ? lo + per : nranges) - lo;     // ranges of this XCD's slab (<= 0: none)
+  if (mine <= 0) return;
+  const int total = nframes * mine;
+  int32_t *cur = &sync[bt_k1cur(x)];
+  int t_next = 0;
+  if (lane == 0) t_next = __hip_atomic_fetch_add(cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int pend_f = -1;                                     // frame of the item whose arrival has not been posted yet
+  int ins_known = -1;                                  // frames 0 .. ins_known have all their insert arrivals
+  for (;;) {
+    const int t = __builtin_amdgcn_readfirstlane(t_next);
+    if (t >= total) break;
+    const int f = t / mine, i = lo + (t - f * mine);
+    if (lane == 0) t_next = __hip_atomic_fetch_add(cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the item after this one
+    const dc_bt_frame_t &F = fr.f[f];
+    // insert arrivals of this frame (if not known yet) and of the NEXT one: a wave works on about one range per frame, so without
+    // the look-ahead every item would begin with "are the records there?" -> first loads, two dependent round trips
+    int ins_a = wpf, ins_b = wpf;
+    if (lane == 0) {
+      if (f > ins_known) ins_a = __hip_atomic_load(&sync[bt_ins(f)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (f + 1 < nframes && f + 1 > ins_known) ins_b = __hip_atomic_load(&sync[bt_ins(f + 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int c_begin = i * cpw;
+    const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
+    int pc_f, nv_f;
+    int4 rf0, rf1, rf2, rf3;
+    if (f <= ins_known) dc_k1_prefetch<false, true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, nullptr, c_begin, c_end, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... which the range needs at once; everything older has retired too
+    if (pend_f >= 0 && lane == 0) __hip_atomic_fetch_add(&sync[bt_k1(pend_f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_f = f;
+    if (f > ins_known) {                               // not known in advance (first frame, or the insert is only just ahead)
+      if (__builtin_amdgcn_readfirstlane(ins_a) < wpf && !bt_wait_ge(sync, bt_ins(f), wpf)) return;
+      ins_known = f;
+      dc_k1_prefetch<false, true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, nullptr, c_begin, c_end, lane);
+    }
+    if (f + 1 < nframes && f + 1 > ins_known && __builtin_amdgcn_readfirstlane(ins_b) >= wpf) ins_known = f + 1;
+    if (i == 0 && lane == 0) {                         // publish the frame's status word (collected by the insert's atomics)
+      F.hdr[LINK_HDR_STATUS] = __hip_atomic_load(&F.hdr[LINK_HDR_STATUS_ACC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&F.hdr[LINK_HDR_STATUS_ACC], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    dc_k1_range<C, OP, NB, false, false, true>(smem_raw, F.feats, F.slots, F.cnt, F.cell_n, p.w_pre, 1.0f, p.eps, F.n, g, false, F.S, nullptr,
+                                               nullptr, nullptr, c_begin, c_end, pc_f, nv_f, rf0, rf1, rf2, rf3, w_big, th_slow, i, 0, 0);
+  }
+  // the last item's arrival: every table K2 reads was stored write-through, so once the stores are acknowledged they are in memory
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DC_BT_RELEASE_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  if (pend_f >= 0 && lane == 0) __hip_atomic_fetch_add(&sync[bt_k1(pend_f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K2 role: (frame, tile) items off per-XCD cursors
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct dc_bt_k2_args_t {                               // the K2-role kernel's ONLY argument: the kernarg segment is this struct
+  dc_bt_frames_t fr;
+  dc_bt_par_t p;
+  link_dc_grid_t g;
+  int nframes, txn, tyn, zsplit, nwg, k1_target;
+  int32_t *sync;
+};
+
+// Item t of XCD x's cursor is tile j = t % per of frame t / per, run as workgroup number j * 8 + x of the stand-alone kernel (which
+// maps it to L = x * per + j: a frame's tiles keep the XCD -- the L2 -- they have there).  The loop's control costs no exposed round
+// trip either: the mapper wave (it lays out voxel maps two planes ahead and is idle most of a plane step) draws the NEXT item before
+// the tile starts and, once its own plane loop is through, looks at the next item's k1_done -- by the tile's closing barrier the
+// answer is in LDS; only when K1 of that frame has really not arrived does it poll.  No acquire: K1 stored write-through, the body
+// reads with sc1 loads (COH).
+template <int OP, int R>
+__global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0)), 4) k_dc_batch_k2(dc_bt_k2_args_t args_by_value) {
+  // Nothing may stay live in scalar registers from one item to the next: the tile body (dc_k2q_body) runs at the scalar-register
+  // limit on its own, and as loop invariants the block's parameters, the grid and the geometry (~40 scalars) were kept across it
+  // -- spilled into vector registers, then 200+ bytes of scratch, whose traffic breaks the producers' counted vmcnt waits.  So the
+  // arguments are read through the kernarg segment pointer, passed through an opaque asm every iteration (the loads cannot be
+  // hoisted: 118-123 registers, no scratch, like the stand-alone kernel), the loop control lives in LDS, and the thread number the
+  // body derives its roles from is opaque per iteration as well.
+  (void)args_by_value;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(DC_K2Q_PMAP == 1, "the mapper wave draws the items");
+  typedef const __attribute__((address_space(4))) dc_bt_k2_args_t *args_ptr_t;
+  constexpr unsigned CTL_THREAD = 256 + 64 * DC_K2Q_CW;  // lane 0 of the mapper wave
+  __shared__ int s_ctl[2];                             // [0] frame of the item (-1: done), [1] bid for dc_k2q_body
+  const int x = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u);
+  int t_next = 0;                                      // (control thread only) the item after the current one
+  if (threadIdx.x == CTL_THREAD) {
+    args_ptr_t a = (args_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    int32_t *sy = a->sync;
+    const int per = (a->nwg + 7) >> 3;
+    const int t = __hip_atomic_fetch_add(&sy[bt_cursor(x)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t_next = __hip_atomic_fetch_add(&sy[bt_cursor(x)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int f = t < a->nframes * per ? t / per : -1;
+    if (f >= 0 && !bt_wait_ge(sy, bt_k1(f), a->k1_target)) f = -1;
+    s_ctl[0] = f; s_ctl[1] = f >= 0 ? (t - f * per) * 8 + x : 0;
+  }
+  __syncthreads();
+  for (;;) {
+    args_ptr_t a = (args_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    const int f = __builtin_amdgcn_readfirstlane(s_ctl[0]), bid = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    if (f < 0) break;
+    __syncthreads();                                   // everyone has read the item: the control thread may lay out the next
+    {
+      const link_dc_grid_t g = a->g;
+      unsigned tidx = threadIdx.x;                     // nothing derived from the thread number may be hoisted in front of the loop (lane roles,
+      asm volatile("" : "+v"(tidx));                   // tile columns, LDS addresses were live across every role of every item)
+      dc_k2q_body<OP, R, false, true>(a->fr.f[f].S, a->fr.f[f].cell_n, a->fr.f[f].slots, a->p.w_pos, nullptr, a->p.ln_w, a->p.ln_b, a->p.cg,
+                                      1.0f, a->p.eps, a->fr.f[f].n, g, a->txn, a->tyn, a->zsplit, a->nwg, a->fr.f[f].out, nullptr, bid, tidx);
+    }
+    if (threadIdx.x == CTL_THREAD) {                   // the mapper's plane loop is through: the next item
+      int32_t *sy = a->sync;
+      const int per = (a->nwg + 7) >> 3;
+      const int t = t_next;
+      int fn = t < a->nframes * per ? t / per : -1;
+      if (fn >= 0) {
+        t_next = __hip_atomic_fetch_add(&sy[bt_cursor(x)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!bt_wait_ge(sy, bt_k1(fn), a->k1_target)) fn = -1;
+      }
+      s_ctl[0] = fn; s_ctl[1] = fn >= 0 ? (t - fn * per) * 8 + x : 0;
+    }
+    __syncthreads();                                   // the tile's LDS images are free again, the next item is laid out
+  }
+#endif
+}
+
+}  // namespace DC_IO_NS
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------------
+using namespace link;
+using namespace dcb_f32;
+
+static constexpr int BT_RING = 4;
+struct link_dc_batch {
+  int device, cus;
+  hipStream_t sa, sb, sc;                              // K1 role, K2 role, insert
+  int32_t *sync;                                       // BT_RING x BT_SYNC_WORDS
+  hipEvent_t ev_in[BT_RING], ev_ms[BT_RING], ev_a[BT_RING], ev_c[BT_RING], ev_out[BT_RING];
+  std::vector<const void *> bufs[BT_RING];             // S pointers of the frames the ring slot's call worked on
+  bool used[BT_RING];
+  long long calls;
+};
+
+extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
+  if (!out) return LINK_ERR_ARG;
+  link_dc_batch *c = new link_dc_batch();
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&pr, c->device) != hipSuccess) { delete c; return LINK_ERR_LAUNCH; }
+  c->cus = pr.multiProcessorCount;
+  bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->sb, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
+            hipMemset(c->sync, 0, sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess;
+  for (int i = 0; i < BT_RING && ok; i++) {
+    ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_ms[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_c[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) == hipSuccess;
+    c->used[i] = false;
+  }
+  c->calls = 0;
+  if (!ok) { (void)hipGetLastError(); delete c; return LINK_ERR_LAUNCH; }   // (a failed create leaks what it had made: process-fatal anyway)
+  *out = c;
+  return LINK_OK;
+}
+
+extern "C" int link_dc_batch_destroy(link_dc_batch_t *c) {
+  if (!c) return LINK_OK;
+  (void)hipStreamSynchronize(c->sa); (void)hipStreamSynchronize(c->sb); (void)hipStreamSynchronize(c->sc);
+  for (int i = 0; i < BT_RING; i++) {
+    (void)hipEventDestroy(c->ev_in[i]); (void)hipEventDestroy(c->ev_ms[i]); (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_c[i]);
+    (void)hipEventDestroy(c->ev_out[i]);
+  }
+  (void)hipFree(c->sync);
+  (void)hipStreamDestroy(c->sa); (void)hipStreamDestroy(c->sb); (void)hipStreamDestroy(c->sc);
+  delete c;
+  return LINK_OK;
+}
+
+// status of the calls made so far (synchronises the context's streams): out[0] = first non-zero error word of the ring (0 = none;
+// 1 + the sync word a spin gave up on), out[1] = calls made
+extern "C" int link_dc_batch_status(link_dc_batch_t *c, int32_t *out) {
+  if (!c || !out) return LINK_ERR_ARG;
+  if (hipStreamSynchronize(c->sa) != hipSuccess || hipStreamSynchronize(c->sb) != hipSuccess || hipStreamSynchronize(c->sc) != hipSuccess)
+    return LINK_ERR_LAUNCH;
+  out[0] = 0;
+  out[1] = (int32_t)c->calls;
+  for (int i = 0; i < BT_RING; i++) {
+    int32_t e = 0;
+    if (hipMemcpy(&e, c->sync + (size_t)i * BT_SYNC_WORDS + bt_err(), sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return LINK_ERR_LAUNCH;
+    if (e && !out[0]) out[0] = e;
+  }
+  return out[0] ? LINK_BATCH_TIMEOUT : LINK_OK;
+}
+
+template <int OP, int R>
+static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const dc_bt_par_t &p, const link_dc_grid_t &g, const link_elk_desc_t &d,
+                        int nframes, int64_t nmax) {
+  using K1 = dc_k1_cfg<64, OP>;
+  using KQ = dc_k2q_cfg<OP, R>;
+  using KG = typename dc_k2_cfg<OP, R>::G;
+  constexpr int LDS_CU = 160 * 1024;
+  // one K1 + one K2 workgroup fill a CU; two K2 workgroups must NOT fit (they would take the room of a K1 workgroup they wait for)
+  constexpr int k1_lds = K1::LDS_BYTES;
+  constexpr int k2_lds = (KQ::LDS_BYTES > LDS_CU / 2 + 512 ? KQ::LDS_BYTES : LDS_CU / 2 + 512);
+  static_assert(k1_lds + k2_lds <= LDS_CU && 2 * k2_lds > LDS_CU, "LDS shaping of the two persistent roles");
+  int32_t *sync = c->sync + (size_t)q * BT_SYNC_WORDS;
+  const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
+  const int k1_wgs = c->cus;
+  // ranges per K1 wave and frame (1: a range is ~6.6 tiles of 16 voxels on cfg2); LINK_DC_BATCH_RPW (experiments only) cuts finer
+  static const int rpw = [] { const char *e = getenv("LINK_DC_BATCH_RPW"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+  int cpw = (int)((vi + (int64_t)k1_wgs * K1::NW * rpw - 1) / ((int64_t)k1_wgs * K1::NW * rpw));
+  if (cpw < 1) cpw = 1;
+  const int k1_target = (int)((vi + cpw - 1) / cpw);    // ranges of a frame
+  const int txn = (g.dim[0] + KG::TX - 1) / KG::TX, tyn = (g.dim[1] + KG::TY - 1) / KG::TY;
+  int zsplit = 2;                                        // the geometry of frames in flight (fewer halo planes summed twice)
+  if (zsplit > g.dim[2]) zsplit = g.dim[2];
+  const int64_t nwg = (int64_t)txn * tyn * g.dim[3] * zsplit;
+  if (nwg > (1 << 20)) return LINK_ERR_ARG;
+  int wpf = (int)((nmax + 255) / 256);
+  if (wpf > 2048) wpf = 2048;
+  if (wpf < 1) wpf = 1;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_batch_k1<OP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, k1_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_batch_k2<OP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, k2_lds);
+  hipLaunchKernelGGL(k_dc_batch_insert, dim3((unsigned)(wpf * nframes)), dim3(256), 0, c->sc, fr, g, wpf, sync);
+  int rc = check_launch("link_elk_core_dense_forward_batch (insert)");
+  if (rc != LINK_OK) return rc;
+  hipLaunchKernelGGL((k_dc_batch_k1<OP, 2>), dim3((unsigned)k1_wgs), dim3(64 * K1::NW), k1_lds, c->sa, fr, p, g, nframes, cpw, k1_target, wpf, sync);
+  rc = check_launch("link_elk_core_dense_forward_batch (K1)");
+  if (rc != LINK_OK) return rc;
+  const dc_bt_k2_args_t a2{fr, p, g, nframes, txn, tyn, zsplit, (int)nwg, k1_target, sync};
+  static_assert(sizeof(dc_bt_k2_args_t) <= 4096, "kernel arguments");
+  hipLaunchKernelGGL((k_dc_batch_k2<OP, R>), dim3((unsigned)c->cus), dim3(KQ::THREADS), k2_lds - (int)sizeof(int) * 2, c->sb, a2);
+  return check_launch("link_elk_core_dense_forward_batch (K2)");
+}
+
+extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_dc_buffers_t *frames, const int64_t *n, int32_t nframes,
+                                                 const link_dc_grid_t *g, const link_elk_desc_t *d, void *stream) {
+  if (!c || !g || !d || nframes < 0 || (nframes > 0 && (!frames || !n))) return LINK_ERR_ARG;
+  if (nframes == 0) return LINK_OK;
+  // what the quad-consumer K2 and the cell-range K1 serve (the caller runs anything else frame by frame)
+  if (d->c != 64 || d->cg != 32 || (d->op != LINK_OP_COS && d->op != LINK_OP_SIN) || (d->r != 2 && d->r != 3) || d->coord_div != 1.0f) return LINK_ERR_ARG;
+  if (g->k < DC_INL || g->k > 352 || g->vp * (int64_t)g->k * 16 >= (1LL << 32) || (g->vp + 1) * (int64_t)2 * 64 * 4 >= (1LL << 32)) return LINK_ERR_ARG;
+  if constexpr (!(dc_k2q_cfg<LINK_OP_COS, 3>::FITS && dc_k2q_cfg<LINK_OP_COS, 2>::FITS)) return LINK_ERR_ARG;
+  const link_dc_buffers_t &b0 = frames[0];
+  for (int i = 0; i < nframes; i++) {
+    const link_dc_buffers_t &b = frames[i];
+    if (n[i] <= 0 || n[i] >= (1LL << 29) || n[i] * 64 * 4 >= (1LL << 32) || b.io_dtype != LINK_IO_F32 || b.alpha) return LINK_ERR_ARG;
+    if (!b.feats || !b.coords || !b.slots || !b.cnt || !b.cell_n || !b.vcell || !b.S || !b.hdr || !b.out) return LINK_ERR_ARG;
+    if (b.w_pre != b0.w_pre || b.pre_ln_w != b0.pre_ln_w || b.pre_ln_b != b0.pre_ln_b || b.w_pos != b0.w_pos || b.ln_w != b0.ln_w || b.ln_b != b0.ln_b)
+      return LINK_ERR_ARG;                               // one block's parameters for the whole batch
+    for (int k = 0; k < i; k++)
+      if (frames[k].S == b.S || frames[k].cnt == b.cnt || frames[k].out == b.out) return LINK_ERR_ARG;   // a frame needs its own buffers
+  }
+  if (!b0.w_pre || !b0.pre_ln_w || !b0.pre_ln_b || !b0.w_pos || !b0.ln_w || !b0.ln_b) return LINK_ERR_ARG;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return LINK_ERR_ARG;
+  hipStream_t st = S(stream);
+  const dc_bt_par_t p{b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, b0.ln_w, b0.ln_b, d->cg, d->eps};
+  for (int base = 0; base < nframes; base += DC_BT_MAX) {
+    const int nb = nframes - base < DC_BT_MAX ? nframes - base : DC_BT_MAX;
+    const int q = (int)(c->calls % BT_RING);
+    dc_bt_frames_t fr{};
+    int64_t nmax = 0;
+    std::vector<const void *> keys;
+    for (int i = 0; i < nb; i++) {
+      const link_dc_buffers_t &b = frames[base + i];
+      fr.f[i] = dc_bt_frame_t{b.feats, reinterpret_cast<const int4 *>(b.coords), reinterpret_cast<int4 *>(b.slots), b.cnt, b.cell_n, b.vcell, b.S,
+                              b.hdr, b.out, n[base + i]};
+      nmax = n[base + i] > nmax ? n[base + i] : nmax;
+      keys.push_back(b.S);
+    }
+    // order: behind everything already in the caller's stream; behind the ring slot's previous call (its sync words are about to be
+    // cleared); behind every earlier call that worked on one of these frames' buffers (K1 overwrites what that call's K2 read, the
+    // insert counts into counters that call's K1 zeroed).  Calls on disjoint buffers overlap: K1 of this call starts when K1 of the
+    // previous one ends, under the previous call's K2.
+    bool fail = hipEventRecord(c->ev_in[q], st) != hipSuccess;
+    fail = fail || hipStreamWaitEvent(c->sa, c->ev_in[q], 0) != hipSuccess || hipStreamWaitEvent(c->sb, c->ev_in[q], 0) != hipSuccess ||
+           hipStreamWaitEvent(c->sc, c->ev_in[q], 0) != hipSuccess;
+    for (int r = 0; r < BT_RING && !fail; r++) {
+      if (!c->used[r]) continue;
+      bool dep = r == q;
+      for (size_t i = 0; i < keys.size() && !dep; i++)
+        for (size_t k = 0; k < c->bufs[r].size() && !dep; k++) dep = keys[i] == c->bufs[r][k];
+      if (dep)
+        fail = hipStreamWaitEvent(c->sa, c->ev_out[r], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_out[r], 0) != hipSuccess ||
+               hipStreamWaitEvent(c->sa, c->ev_a[r], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_a[r], 0) != hipSuccess;
+    }
+    int32_t *sync = c->sync + (size_t)q * BT_SYNC_WORDS;
+    fail = fail || hipMemsetAsync(sync, 0, sizeof(int32_t) * BT_SYNC_WORDS, c->sa) != hipSuccess || hipEventRecord(c->ev_ms[q], c->sa) != hipSuccess ||
+           hipStreamWaitEvent(c->sb, c->ev_ms[q], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_ms[q], 0) != hipSuccess;
+    if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+    int rc;
+    if (d->op == LINK_OP_COS) rc = d->r == 3 ? batch_launch<LINK_OP_COS, 3>(c, q, fr, p, *g, *d, nb, nmax) : batch_launch<LINK_OP_COS, 2>(c, q, fr, p, *g, *d, nb, nmax);
+    else rc = d->r == 3 ? batch_launch<LINK_OP_SIN, 3>(c, q, fr, p, *g, *d, nb, nmax) : batch_launch<LINK_OP_SIN, 2>(c, q, fr, p, *g, *d, nb, nmax);
+    // whatever was launched must be joined, or the caller's stream would run ahead of it
+    fail = hipEventRecord(c->ev_a[q], c->sa) != hipSuccess || hipEventRecord(c->ev_c[q], c->sc) != hipSuccess || hipEventRecord(c->ev_out[q], c->sb) != hipSuccess ||
+           hipStreamWaitEvent(st, c->ev_a[q], 0) != hipSuccess || hipStreamWaitEvent(st, c->ev_c[q], 0) != hipSuccess ||
+           hipStreamWaitEvent(st, c->ev_out[q], 0) != hipSuccess;
+    c->bufs[q] = keys;
+    c->used[q] = true;
+    c->calls++;
+    if (rc != LINK_OK) return rc;
+    if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+  }
+  return LINK_OK;
+}

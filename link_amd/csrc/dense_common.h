@@ -22,6 +22,10 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 #define DC_PROF 0
 #endif
 #define DC_PROF_PTR(p) do { if (!DC_PROF) (p) = nullptr; } while (0)
+// the timers' clock: s_memtime (shader-clock ticks: fine phase resolution, but every XCD counts on its own -- start stamps of waves
+// on different XCDs cannot be compared) or, with -DDC_PROF=2, s_memrealtime (the 100 MHz reference counter all XCDs share: 10 ns
+// steps -- what tools/slot_timeline.py needs to lay the waves of a launch out on ONE time axis; round 6)
+#define DC_NOW() (DC_PROF == 2 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime())
 #ifndef DC_ST_AUX
 #define DC_ST_AUX 16      /* sc1: write-through; 0 = ordinary write-back stores (A/B: LINK_AMD_CXXFLAGS=-DDC_ST_AUX=0) */
 #endif
@@ -39,6 +43,34 @@ __device__ __forceinline__ void st16i(__amdgpu_buffer_rsrc_t r, uint32_t byte_of
 }
 __device__ __forceinline__ void st4i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int v) {
   __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, 0);
+}
+// Hand-offs INSIDE a launch (round 6, the persistent batch kernels of dense_batch.hip): a table another workgroup reads before the
+// launch ends is stored write-through (aux 16 = sc1: the bytes leave the XCD's L2, so the publishing wave needs only `s_waitcnt
+// vmcnt(0)` before its arrival atomic, no `buffer_wbl2`) and, where the reader does not run an agent-scope acquire, loaded with
+// sc1 as well (served by the L2, never by the CU's L1) -- MI355X_MICROARCH.md "inter-workgroup visibility".  COH = false: the plain
+// forms the stand-alone kernels have always used (a kernel boundary orders them).
+template <bool COH>
+__device__ __forceinline__ void st16i_c(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int4 v) {
+  const v4i_t x = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, byte_off, 0, COH ? 16 : 0);
+}
+template <bool COH>
+__device__ __forceinline__ void st4i_c(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, int v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, COH ? 16 : 0);
+}
+template <bool COH>
+__device__ __forceinline__ int4 ld16i_c(__amdgpu_buffer_rsrc_t r, const int4 *base, uint32_t idx) {      // record `idx` of the table
+  if constexpr (COH) {
+    const v4i_t x = __builtin_amdgcn_raw_buffer_load_b128(r, idx * 16u, 0, 16);
+    return make_int4(x.x, x.y, x.z, x.w);
+  } else {
+    return base[idx];
+  }
+}
+template <bool COH>
+__device__ __forceinline__ int ld4i_c(__amdgpu_buffer_rsrc_t r, const uint32_t *base, uint32_t idx) {
+  if constexpr (COH) return __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 16);
+  else return (int)base[idx];
 }
 
 // Occupancy statistics of an insert pass (the STATS variants of the index kernels).  Every lane keeps its own three numbers
@@ -108,7 +140,7 @@ __device__ __forceinline__ uint32_t dc_slot(const link_dc_grid_t &g, int pcell, 
 // k_dc_index (dense_fused.hip) runs it over its own grid, the three-stage step kernel (dense_step3_impl.h) over a range of a
 // shared one.  rank = cnt[cell]++, slots[cell][rank] = (x, y, z, id), vcell[id] = cell; a voxel outside the grid or past a
 // full cell sets its bit of the status accumulator and is left out.
-template <bool STATS>
+template <bool STATS, bool COH = false>
 __device__ __forceinline__ void dc_index_body(const int4 *__restrict__ coords, int64_t n, const link_dc_grid_t &g,
                                               uint32_t *__restrict__ cnt, int4 *__restrict__ slots,
                                               int32_t *__restrict__ vcell, int32_t *__restrict__ hdr, int bid, int nblk,
@@ -128,7 +160,7 @@ __device__ __forceinline__ void dc_index_body(const int4 *__restrict__ coords, i
     const bool full = pcell != 0 && rank >= g.k;
     if (full) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 2);
     const bool keep = pcell != 0 && !full;
-    st16i(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
+    st16i_c<COH>(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, (int)v));
     vcell[v] = keep ? pcell : 0;
     if (STATS) { st_in += pcell != 0; st_first += (pcell != 0 && rank == 0); st_max = max(st_max, pcell != 0 ? rank + 1 : 0); }
   }

@@ -159,12 +159,16 @@ __device__ __forceinline__ float dc_quad_sum(float v) {
 }
 
 // the kernel body as a device function of the workgroup number `bid` (see dc_k1m_body)
-template <int OP, int R, bool DIV>
+// COH (round 6, the persistent batch kernel of dense_batch.hip): the tables were stored write-through by ANOTHER workgroup of a
+// launch that is still running -> every global read (plane DMA, counts, records) is an sc1 load (L2-served, never the CU's L1), which
+// replaces an agent-scope acquire per tile (MI355X_MICROARCH.md "inter-workgroup visibility").  false: plain loads behind a kernel
+// boundary, as ever.
+template <int OP, int R, bool DIV, bool COH = false>
 __device__ __forceinline__ void dc_k2q_body(
     const float *__restrict__ S_, const int32_t *__restrict__ cell_n, const int4 *__restrict__ slots,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, const link_dc_grid_t &g, int txn, int tyn,
-    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg, const int bid) {
+    int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg, const int bid, const unsigned tidx) {
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
   DC_PROF_PTR(dbg);
@@ -173,15 +177,15 @@ __device__ __forceinline__ void dc_k2q_body(
 #endif
   // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
   // the quad round
-  unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
+  unsigned long long tq0 = dbg ? DC_NOW() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
   int tq_rounds = 0;
   using K = typename K2::G;
   constexpr int C = 64, P = 2, TY = K::TY, TX = K::TX, HY = K::HY, HLO = K::HLO;
   constexpr int RB = P * C * 4;
   static_assert(K2::P == 2, "two-part rows");
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const bool producer = threadIdx.x < 256;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x & 255) >> 6);
+  const bool producer = tidx < 256;
+  const int tid = tidx & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((tidx & 255) >> 6);
   const int per = (nwg + 7) >> 3;
   const int L = (bid & 7) * per + (bid >> 3);
   if (L >= nwg) return;
@@ -211,9 +215,9 @@ __device__ __forceinline__ void dc_k2q_body(
   const int pz0 = zs + 1 - HLO;
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)lds;
   const uint32_t abuf0 = lds_base + K2::SPLIT_ABUF_OFF, ncnt0 = lds_base + K2::SPLIT_NCNT_OFF;
-  if (threadIdx.x < 128) {                             // LayerNorm weight | bias image for the consumers
+  if (tidx < 128) {                             // LayerNorm weight | bias image for the consumers
     float *par = reinterpret_cast<float *>(lds + KQ::PAR_OFF);
-    par[threadIdx.x] = threadIdx.x < 64 ? ln_w[threadIdx.x] : ln_b[threadIdx.x - 64];
+    par[tidx] = tidx < 64 ? ln_w[tidx] : ln_b[tidx - 64];
   }
   if (producer) {
 #if DC_K2_PRIO_PROD
@@ -254,7 +258,7 @@ __device__ __forceinline__ void dc_k2q_body(
       pz = pz < PDz - 1 ? pz : PDz - 1;
       const int32_t *csrc = cell_n + cnt_cell0 + pz;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
-                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane, pm3) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane, pm3) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, COH ? 16 : 0);
     };
     uint32_t rec_cell0;                                // inline slot records of the 16 interior cells of an output plane
     int rec_k;
@@ -280,7 +284,7 @@ __device__ __forceinline__ void dc_k2q_body(
           const uint32_t off = (surplus ? src_off[0] : src_off[i]) + (uint32_t)pz * (uint32_t)RB;
           const int c_ = surplus ? cn[0] : cn[i];
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r_S, (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16,
-                                                   c_ != 0 ? off : DC_OOB, 0, 0, 0);
+                                                   c_ != 0 ? off : DC_OOB, 0, 0, COH ? 16 : 0);
         }
       } else {
 #pragma unroll
@@ -289,7 +293,7 @@ __device__ __forceinline__ void dc_k2q_body(
           const int ii = surplus ? 0 : i;
           const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, COH ? 16 : 0);
         }
       }
       issue_cnt(DC_K2_SKIP ? plane + 2 : plane, pm3);  // NI instructions per call either way
@@ -298,7 +302,7 @@ __device__ __forceinline__ void dc_k2q_body(
       const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
       if (lane < 16)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rsrc,
-                                         (__attribute__((address_space(3))) void *)(lds + K2::SPLIT_REC_OFF + (plane & 3) * K2::REC_BYTES + wave * 256), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(lds + K2::SPLIT_REC_OFF + (plane & 3) * K2::REC_BYTES + wave * 256), 16, 0, COH ? 16 : 0);
     };
     const int grp = tid >> 4, li = tid & 15;
     // Rim tiles (DC_K2Q_RIM, round 5).  The 4 x 4 tiling of a 37 x 37 grid has 19 rim tiles of 100 whose columns beyond the grid
@@ -328,14 +332,14 @@ __device__ __forceinline__ void dc_k2q_body(
     if (nplanes > 1) issue(1, 1, false);
     int m3 = 0, m3p2 = 2;                              // i % 3, (i + 2) % 3
     for (int i = 0; i <= nplanes; i++, m3 = m3 == 2 ? 0 : m3 + 1, m3p2 = m3p2 == 2 ? 0 : m3p2 + 1) {
-      unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      unsigned long long tqa = dbg ? DC_NOW() : 0;
       if (i < nplanes) {
         if (i + 1 < nplanes) wait_vmcnt<K2::NI>(); else wait_vmcnt<0>();
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the A rows of the previous step are in LDS
-      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_dma += tqb - tqa; tqa = tqb; }
+      if (dbg) { const unsigned long long tqb = DC_NOW(); tq_dma += tqb - tqa; tqa = tqb; }
       asm volatile("s_barrier" ::: "memory");
-      if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
+      if (dbg) { const unsigned long long tqb = DC_NOW(); tq_bar += tqb - tqa; tqa = tqb; }
       if (i >= nplanes) break;
       if (i + 2 < nplanes) issue(i + 2, m3p2, true);
       const uint32_t bufa = lds_base + (uint32_t)(m3 * K2::SPLIT_BUF_BYTES);
@@ -384,11 +388,11 @@ __device__ __forceinline__ void dc_k2q_body(
       for (int pp = 0; pp < P; pp++) { r0[pp] = r1[pp]; r1[pp] = cur[pp]; }
       c0 = c1; c1 = cc;
       n_prev = n_here;
-      if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_work += __builtin_amdgcn_s_memtime() - tqa; }
+      if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_work += DC_NOW() - tqa; }
     }
     if (dbg && lane == 0) {
-      unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
-      d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_work; d[4] = tq0; d[5] = 0; d[6] = nplanes; d[7] = 1;
+      unsigned long long *d = dbg + ((size_t)L * 8 + (tidx >> 6)) * 8;
+      d[0] = DC_NOW() - tq0; d[1] = tq_dma; d[2] = tq_bar; d[3] = tq_work; d[4] = tq0; d[5] = 0; d[6] = nplanes; d[7] = 1;
     }
     return;
   }
@@ -464,9 +468,9 @@ __device__ __forceinline__ void dc_k2q_body(
   }
   int m3p1 = 1;                                        // (i + 1) % 3 == (jp - 1) % 3
   for (int i = 0; i <= nplanes; i++, m3p1 = m3p1 == 2 ? 0 : m3p1 + 1) {
-    unsigned long long tqa = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long tqa = dbg ? DC_NOW() : 0;
     asm volatile("s_barrier" ::: "memory");
-    if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_bar += tqb - tqa; tqa = tqb; }
+    if (dbg) { const unsigned long long tqb = DC_NOW(); tq_bar += tqb - tqa; tqa = tqb; }
     const int jp = i - 1;                               // the output-plane step whose A rows the producers finished last step
     if (jp < R - 1 || jp >= nplanes) continue;
     const uint32_t abuf = abuf0 + (uint32_t)((jp & 1) * K2::NG * RB), ncnt = ncnt0 + (uint32_t)((jp & 1) * K2::NG * 4);
@@ -540,7 +544,7 @@ __device__ __forceinline__ void dc_k2q_body(
       int4 rec = make_int4(__float_as_int(rq.x), __float_as_int(rq.y), __float_as_int(rq.z), __float_as_int(rq.w));
       if (k >= DC_INL) {                                // overflow records (cells with more than DC_INL voxels): ordinary loads
         const int pcell = ((b * PDx + x0 + c / TY + 1) * PDy + y0 + c % TY + 1) * PDz + po;
-        rec = slots[dc_slot(g, pcell, k)];
+        rec = ld16i_c<COH>(dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16)), slots, dc_slot(g, pcell, k));
       }
       float x = (float)rec.x, y = (float)rec.y, z = (float)rec.z;
       if (DIV) { x = x / coord_div; y = y / coord_div; z = z / coord_div; }
@@ -609,11 +613,11 @@ __device__ __forceinline__ void dc_k2q_body(
         io_st4(r_out, (uint32_t)rec.w * (uint32_t)C + (uint32_t)(16 * j + 4 * q), valid, o);
       }
     }
-    if (dbg) tq_work += __builtin_amdgcn_s_memtime() - tqa;
+    if (dbg) tq_work += DC_NOW() - tqa;
   }
   if (dbg && lane == 0) {
-    unsigned long long *d = dbg + ((size_t)L * 8 + (threadIdx.x >> 6)) * 8;
-    d[0] = __builtin_amdgcn_s_memtime() - tq0; d[1] = tq0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
+    unsigned long long *d = dbg + ((size_t)L * 8 + (tidx >> 6)) * 8;
+    d[0] = DC_NOW() - tq0; d[1] = tq0; d[2] = tq_bar; d[3] = 0; d[4] = tq_work; d[5] = tq_rounds; d[6] = nplanes; d[7] = 2;
   }
 }
 
@@ -624,5 +628,5 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
     const float *__restrict__ ln_b, int cg, float coord_div, float eps, int64_t n, link_dc_grid_t g, int txn, int tyn,
     int zsplit, int nwg, void *__restrict__ out, unsigned long long *__restrict__ dbg) {
   dc_k2q_body<OP, R, DIV>(S_, cell_n, slots, w_pos, alpha, ln_w, ln_b, cg, coord_div, eps, n, g, txn, tyn, zsplit, nwg, out, dbg,
-                          (int)blockIdx.x);
+                          (int)blockIdx.x, threadIdx.x);
 }

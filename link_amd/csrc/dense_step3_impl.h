@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512, 4) k_dc_step3(dc_s3_k2_t a2, dc_s3_k1_t a
   if (bid < n_k2) {
     if (DC_S3_K2_PRIO) __builtin_amdgcn_s_setprio(DC_S3_K2_PRIO);
     dc_k2q_body<OP, R, false>(a2.S, a2.cell_n, a2.slots, p.w_pos, nullptr, p.ln_w, p.ln_b, p.cg, 1.0f, p.eps, a2.n, g, a2.txn,
-                              a2.tyn, a2.zsplit, a2.nwg, a2.out, a2.dbg, bid);
+                              a2.tyn, a2.zsplit, a2.nwg, a2.out, a2.dbg, bid, threadIdx.x);
     return;
   }
   bid -= n_k2;

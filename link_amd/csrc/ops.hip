@@ -18,7 +18,7 @@ void set_error(const char *what, hipError_t e) {
 
 using namespace link;
 
-extern "C" int link_abi_version(void) { return 11; }
+extern "C" int link_abi_version(void) { return 12; }
 extern "C" int32_t link_abi_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(link_grid_t);

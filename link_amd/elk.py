@@ -659,6 +659,103 @@ class ElkCorePipeline:
         return sum(p.arena_bytes() for p in self.plans)
 
 
+class ElkCoreBatch:
+    """R_core of a BATCH of independent frames in ONE call (include/link_amd.h section H, csrc/dense_batch.hip): the slot insert of
+    every frame as one grid + two persistent kernels -- a pre_mix role that walks the frames (a frame's ranges of cells as soon as
+    its insert has arrived) and a gather role that pulls (frame, tile) items off per-XCD queues (a tile as soon as the frame's
+    pre_mix has arrived).  The stages of different frames overlap by construction; per-frame arrival counters replace the two
+    stream-ordered launch boundaries every frame of `ElkCorePlan.run` pays.  What BASELINE.json configs[3] ("a batch of 8 independent
+    frames") and the reference's collated batches (linkunet.py:132,151-162,178 over batch-indexed coordinates) are to this product.
+
+    `frames` arenas (ElkCorePlan buffers, dense-cell layout) are allocated once; `run(feats_list, coords_list)` takes up to that many
+    frames and returns their result rows (views of the arenas' `out` buffers, complete in stream order).  Results are bit for bit
+    those of `ElkCorePlan.run` per frame.  C = 64, cg = 32, cos / sin, r in {2, 3}, fp32 rows, coord_div = 1, no alpha, slot capacity
+    <= 352 -- LinkAmdError otherwise (run such frames through ElkCorePlan).  Two batches in flight: two ElkCoreBatch objects sharing
+    ONE context (`ElkCoreBatch(..., share=first)`), alternated with two streams -- the pre_mix role of the second batch starts
+    under the gather role of the first.  `check()` raises if a voxel was dropped or a kernel's bounded wait gave up."""
+
+    def __init__(self, frames: int, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device, eps: float = 1e-6,
+                 slot_cap: int = 0, share: Optional["ElkCoreBatch"] = None):
+        if c != 64 or cg != 32 or baseop not in ("cos", "sin") or r not in (2, 3):
+            raise L.LinkAmdError("ElkCoreBatch: C = 64, cg = 32, cos / sin, r in {2, 3} (include/link_amd.h section H)")
+        if frames < 1:
+            raise ValueError("ElkCoreBatch: at least one frame")
+        self.plans = [ElkCorePlan(n_cap, c, baseop, cg, r, s, bounds, device, eps=eps, layout="dense", slot_cap=slot_cap)
+                      for _ in range(frames)]
+        if int(self.plans[0].dcg.k) > 352:
+            raise L.LinkAmdError("ElkCoreBatch: slot capacity above 352")
+        self.n_cap, self.c, self.device = n_cap, c, device
+        self._bufs = (L.LinkDcBuffers * frames)()
+        self._n = (ctypes.c_int64 * frames)()
+        if share is not None:
+            self._ctx, self._owner = share._ctx, share          # keep the owner alive
+        else:
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                L.check(L.lib().link_dc_batch_create(ctypes.byref(h)), "link_dc_batch_create")
+            self._ctx, self._owner = h, None
+        self._fn = L.lib().link_elk_core_dense_forward_batch
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owner", None) is None and getattr(self, "_ctx", None):
+                L.lib().link_dc_batch_destroy(self._ctx)
+                self._ctx = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
+        if alpha is not None:
+            raise L.LinkAmdError("ElkCoreBatch: alpha is not supported")
+        self.plans[0].bind(w_pre, pre_ln_w, pre_ln_b, w_pos, None, ln_w, ln_b)
+        b0 = self.plans[0].buf
+        for p in self.plans[1:]:                                 # ONE copy of the block's parameters for the whole batch
+            p._params, p._bound = self.plans[0]._params, self.plans[0]._bound
+            (p.buf.w_pre, p.buf.pre_ln_w, p.buf.pre_ln_b, p.buf.w_pos, p.buf.alpha, p.buf.ln_w, p.buf.ln_b) = (
+                b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, None, b0.ln_w, b0.ln_b)
+        return self
+
+    def run(self, feats, coords, outs=None, stream: Optional[int] = None):
+        """feats / coords: sequences of [n_i, C] fp32 rows and [n_i, 4] int32 coordinates (at most `frames` of them); `outs`:
+        optional result tensors.  Returns the list of result rows."""
+        k = len(feats)
+        assert 0 < k <= len(self.plans) and len(coords) == k and (outs is None or len(outs) == k)
+        res = []
+        for i in range(k):
+            f, co, p = feats[i], coords[i], self.plans[i]
+            n = f.shape[0]
+            assert 0 < n <= self.n_cap and f.shape[1] == self.c and f.dtype == torch.float32 and f.is_contiguous()
+            assert co.is_contiguous() and co.dtype == torch.int32 and co.shape[0] == n
+            dst = p.out if outs is None else outs[i]
+            assert dst.dtype == torch.float32 and dst.is_contiguous()
+            b = p.buf
+            b.feats, b.coords, b.out, b.io_dtype = f.data_ptr(), co.data_ptr(), dst.data_ptr(), L.IO_F32
+            self._bufs[i] = b
+            self._n[i] = n
+            res.append(dst[:n])
+        p0 = self.plans[0]
+        st = L.current_stream_handle() if stream is None else int(stream)
+        rc = self._fn(self._ctx, self._bufs, self._n, k, ctypes.byref(p0.dcg), ctypes.byref(p0.desc), st)
+        if rc != 0:
+            L.check(rc, "link_elk_core_dense_forward_batch")
+        if L.DEBUG:
+            self.check()
+        return res
+
+    def check(self) -> None:
+        """Synchronises the context's streams; raises if a bounded wait inside a kernel gave up or a frame dropped a voxel."""
+        st = (ctypes.c_int32 * 2)()
+        rc = L.lib().link_dc_batch_status(self._ctx, st)
+        if rc != 0:
+            raise L.LinkAmdError(f"ElkCoreBatch: link_dc_batch_status = {rc} (error word {st[0]}: a persistent kernel's bounded "
+                                 "wait gave up; the batch's rows are undefined)")
+        for p in self.plans:
+            p.check()
+
+    def arena_bytes(self) -> int:
+        return sum(p.arena_bytes() for p in self.plans)
+
+
 # ------------------------------------------------------------------------------------------------
 # differentiable R_core (training)
 # ------------------------------------------------------------------------------------------------

@@ -10,12 +10,84 @@ Backend: torch.distributed "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in 
 """
 from __future__ import annotations
 
-from typing import List
+import glob
+import os
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_frames", "gather_frame_rows"]
+__all__ = ["shard_frames", "gather_frame_rows", "gpu_numa_node", "pin_rank_to_gpu_numa"]
+
+
+def _parse_cpulist(txt: str) -> List[int]:
+    """'0-63,128-191' -> [0, ..., 63, 128, ..., 191] (the kernel's cpulist format)."""
+    cpus: List[int] = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index: int, sysfs: str = "/sys") -> Optional[int]:
+    """NUMA node of the GPU torch calls `cuda:device_index`, from sysfs (`<pci device>/numa_node`); None when unknown (-1, a
+    container without sysfs, a PCI address that is not there).  The PCI address comes from torch's device properties, so the
+    answer follows HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remapping (a bare /sys/class/drm/card<i> index would not)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        addr = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        path = os.path.join(sysfs, "bus", "pci", "devices", addr, "numa_node")
+        node = int(open(path).read().strip())
+        return node if node >= 0 else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pin_rank_to_gpu_numa(device_index: int, local_rank: int = 0, local_world: int = 1, sysfs: str = "/sys") -> Dict:
+    """Pin THIS process (the thread that issues the rank's launches included) to CPUs of its GPU's NUMA node.
+
+    A rank's issuing thread spends 12-20 us of host time per 35 us frame; on a two-socket host an unpinned rank may run -- and
+    allocate its launch queues -- on the far socket from its GPU.  The reference leaves placement to its launcher
+    (detection/det3d/torchie/trainer/utils.py:99-112 only picks the device); here every rank narrows its affinity mask to the
+    CPUs of `numa_node` of its GPU's PCI device that its current mask allows, and when several ranks share a node each takes
+    its own slice of those CPUs (by local rank) so that eight issuing threads never contend for one core.  Nothing is pinned
+    when the node is unknown or the slice would be empty -- the returned record says which:
+    {"pinned": bool, "numa_node": int | None, "cpus": n, "first_cpu": c, "reason": str}."""
+    rec: Dict = {"pinned": False, "numa_node": None, "cpus": 0, "first_cpu": None, "reason": ""}
+    if not hasattr(os, "sched_setaffinity"):
+        rec["reason"] = "no sched_setaffinity on this platform"
+        return rec
+    allowed = sorted(os.sched_getaffinity(0))
+    rec["cpus"], rec["first_cpu"] = len(allowed), allowed[0] if allowed else None
+    node = gpu_numa_node(device_index, sysfs)
+    rec["numa_node"] = node
+    if node is None:
+        rec["reason"] = "NUMA node of the GPU unknown (sysfs numa_node missing or -1)"
+        return rec
+    try:
+        node_cpus = set(_parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read()))
+    except Exception as e:  # noqa: BLE001
+        rec["reason"] = f"node{node}/cpulist unreadable: {e!r}"[:120]
+        return rec
+    mine = [c for c in allowed if c in node_cpus]
+    if not mine:
+        rec["reason"] = f"no allowed CPU on node {node}"
+        return rec
+    # ranks that share the node share its CPUs evenly: local ranks whose GPU sits on the same node, in local-rank order
+    peers = [r for r in range(max(local_world, 1)) if gpu_numa_node(r, sysfs) == node] if local_world > 1 else [local_rank]
+    if local_rank in peers and len(peers) > 1 and len(mine) >= len(peers):
+        per = len(mine) // len(peers)
+        k = peers.index(local_rank)
+        mine = mine[k * per:(k + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        rec["reason"] = f"sched_setaffinity refused: {e!r}"[:120]
+        return rec
+    rec.update(pinned=True, cpus=len(mine), first_cpu=mine[0], reason=f"{len(mine)} CPUs of NUMA node {node}")
+    return rec
 
 
 def shard_frames(n_frames: int, world_size: int, rank: int) -> List[int]:

@@ -1,0 +1,130 @@
+"""GPU parity of the batch entry point (include/link_amd.h section H: link_elk_core_dense_forward_batch, csrc/dense_batch.hip):
+R_core of a batch of independent frames as one slot-insert grid + two persistent, queue-fed kernels.  Everything here goes through
+the C ABI (ElkCoreBatch -> ctypes) and is compared BIT FOR BIT with the per-frame path (ElkCorePlan.run), which the other test files
+pin on the oracle and the reference fixtures (linkunet.py:132,151-162,178 + utils.py:44-84 semantics; BASELINE.json configs[3])."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests.helpers import rel_err, s_uniform  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BOUNDS = ((0, 0, 0, 0), (255, 255, 255, 0))
+
+
+def _block(c, baseop, dev):
+    import link_amd as la
+    torch.manual_seed(2)
+    return la.ELKBlock(c, c, groups=2, baseop=baseop).to(dev).eval()
+
+
+def _bind(obj, blk):
+    obj.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight,
+             blk.norm.bias)
+    return obj
+
+
+def _frames(k, n, c, dev, seed0=0, ragged=False):
+    out = []
+    for i in range(k):
+        ni = n - (137 * i if ragged else 0)
+        g = torch.Generator().manual_seed(100 + seed0 + i)
+        out.append((torch.randn(ni, c, generator=g).to(dev), s_uniform(ni, seed=seed0 + i).to(dev)))
+    return out
+
+
+@pytest.mark.parametrize("baseop,r,s", [("cos", 3, 7), ("sin", 3, 7), ("cos", 2, 7), ("cos", 3, 5)])
+def test_batch_equals_per_frame_plans_bitwise(baseop, r, s):
+    """8 frames of 20 k voxels (ragged sizes) in one call == ElkCorePlan.run per frame, bit for bit; status words clean; a second
+    call on the same arenas (buffers reused: the call is ordered behind the first) reproduces it."""
+    import link_amd as la
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 20000, 8
+    blk = _block(C, baseop, dev)
+    frames = _frames(K, N, C, dev, ragged=True)
+    # (k1_form = 0: the cell-range form of the pre_mix kernel, whose body the batch's K1 role runs -- the matrix-core sums form a
+    # single plan picks for one frame alone adds a cell's voxels in another association: 2e-7 apart on sparse frames)
+    plan = _bind(la.ElkCorePlan(N, C, baseop, C // 2, r, s, BOUNDS, dev, layout="dense", k1_form=0), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    batch = _bind(la.ElkCoreBatch(K, N, C, baseop, C // 2, r, s, BOUNDS, dev), blk)
+    for _ in range(2):
+        outs = [o.clone() for o in batch.run([f for f, _ in frames], [co for _, co in frames])]
+        batch.check()
+        for i in range(K):
+            assert outs[i].shape == ref[i].shape
+            assert torch.equal(outs[i], ref[i]), (i, rel_err(outs[i].cpu().numpy(), ref[i].cpu().numpy()))
+
+
+def test_batch_full_size_cfg2_vs_oracle_and_plans():
+    """cfg2-sized frames (100 k voxels, C = 64, cos, r = 3, s = 7): 6 frames in one call against the oracle (1e-4 rel, north_star) on
+    frame 0 and bit for bit against the per-frame plans on all; fewer frames than arenas; caller-provided result tensors."""
+    import numpy as np
+    import link_amd as la
+    from oracle import link_oracle as O
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 100000, 6
+    blk = _block(C, "cos", dev)
+    frames = _frames(K, N, C, dev)
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, BOUNDS, dev, layout="dense", k1_form=0), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    batch = _bind(la.ElkCoreBatch(8, N, C, "cos", C // 2, 3, 7, BOUNDS, dev), blk)
+    dst = [torch.full((N, C), float("nan"), device=dev) for _ in range(K)]
+    outs = batch.run([f for f, _ in frames], [co for _, co in frames], outs=dst)
+    batch.check()
+    for i in range(K):
+        assert outs[i].data_ptr() == dst[i].data_ptr()
+        assert torch.equal(outs[i], ref[i]), i
+    params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    core = O.elk_core_torch(frames[0][0].cpu(), frames[0][1].cpu(), params, 7, 3, "cos", 2, agg=O.aggregate_c)
+    assert rel_err(outs[0].cpu().numpy(), core.numpy()) < 1e-4
+    assert np.isfinite(outs[K - 1].cpu().numpy()).all()
+
+
+def test_two_batches_in_flight_share_one_context():
+    """Two ElkCoreBatch objects on ONE context, alternated on two streams (the bench's arrangement): calls on disjoint arenas overlap
+    on the device, calls on the same arenas are ordered; 6 rounds, every result bit-equal to the per-frame path."""
+    import link_amd as la
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 30000, 4
+    blk = _block(C, "cos", dev)
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, BOUNDS, dev, layout="dense", k1_form=0), blk)
+    sets = [_frames(K, N, C, dev, seed0=10 * j) for j in range(2)]
+    refs = [[plan.run(f, co).clone() for f, co in fs] for fs in sets]
+    b0 = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, BOUNDS, dev), blk)
+    b1 = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, BOUNDS, dev, share=b0), blk)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        j = rnd & 1
+        with torch.cuda.stream(streams[j]):
+            outs = (b0, b1)[j].run([f for f, _ in sets[j]], [co for _, co in sets[j]])
+            got = [o.clone() for o in outs]              # stream-ordered behind the batch
+        streams[j].synchronize()
+        for i in range(K):
+            assert torch.equal(got[i], refs[j][i]), (rnd, i)
+    b0.check()
+    b1.check()
+
+
+def test_batch_reports_a_dropped_voxel_and_refuses_what_it_does_not_serve():
+    import link_amd as la
+    from link_amd import _lib as L
+    dev = torch.device("cuda:0")
+    C, N = 64, 5000
+    blk = _block(C, "cos", dev)
+    with pytest.raises(L.LinkAmdError):
+        la.ElkCoreBatch(2, N, 32, "cos", 16, 3, 7, BOUNDS, dev)                  # C = 32: not this entry point
+    with pytest.raises(L.LinkAmdError):
+        la.ElkCoreBatch(2, N, C, "cos_x", 64, 3, 7, BOUNDS, dev)                # three-part rows: not this entry point
+    batch = _bind(la.ElkCoreBatch(2, N, C, "cos", C // 2, 3, 7, BOUNDS, dev), blk)
+    frames = _frames(2, N, C, dev)
+    bad = frames[1][1].clone()
+    bad[7, 0] = 300                                                               # outside the plan's bounds (0 .. 255)
+    batch.run([frames[0][0], frames[1][0]], [frames[0][1], bad])
+    with pytest.raises(L.LinkAmdError, match="outside the plan's bounds"):
+        batch.check()

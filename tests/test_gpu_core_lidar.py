@@ -51,12 +51,13 @@ def test_core_forms_on_full_size_s_kitti_stage_frames_vs_oracle_and_float64(vari
             rel64 = float((out.double() - ref64).abs().max() / s64)
             rows.append({"variant": variant, "seed": seed, "stage": k + 1, "voxels": int(r["feats"].shape[0]), "form": name,
                          "rel32": rel32, "rel64": rel64, "oracle_rel64": o64, "share_of_gate": rel32 / TOL})
-            assert rel32 < TOL, (variant, seed, k + 1, name, rel32)
-            assert rel64 <= 2.0 * o64 + 2e-6, (variant, seed, k + 1, name, rel64, o64)
-    try:
+    try:                                                  # the table first, the verdicts after: a failing form still leaves its row
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "lidar_parity_maxima.jsonl"), "a") as f:
             for row in rows:
                 f.write(json.dumps(row) + "\n")
     except OSError:
         pass
+    for row in rows:
+        assert row["rel32"] < TOL, row
+        assert row["rel64"] <= 2.0 * row["oracle_rel64"] + 2e-6, row
