@@ -971,6 +971,10 @@ int link_elk_core_dense_forward_batch(link_dc_batch_t *ctx, const link_dc_buffer
                                       const int64_t *n /* host [nframes] */, int32_t nframes, const link_dc_grid_t *g /* host */,
                                       const link_elk_desc_t *desc /* host */, void *stream);
 int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
+/* Profiling hook (tools/batch_timeline.py): device buffers of 8 x u64 rows the K1 / K2 items append 100 MHz timestamps to (word 0 =
+ * rows so far, zeroed by the caller; word 1 = capacity in rows).  Honoured by a -DDC_BT_PROF=1 build of csrc/dense_batch.hip (returns
+ * LINK_OK), ignored by the default build (returns 1). */
+int link_dc_batch_set_debug(link_dc_batch_t *ctx, uint64_t *k1_rows, uint64_t *k2_rows);
 
 #ifdef __cplusplus
 }

@@ -7,8 +7,9 @@
 // of different frames was whatever the hardware queues happened to interleave, and every frame paid two stream-ordered launch
 // boundaries and the fill / drain of two grids.  Here the batch is ONE call:
 //
-//   stream C   k_dc_batch_insert   ordinary grid, (frame, chunk of voxels) per workgroup, frames in order; the records are stored
-//                                  write-through (sc1) and every workgroup ends with one arrival on ins_done[frame]
+//   stream C   k_dc_batch_insert   PERSISTENT, four single-wave workgroups per CU: (frame, chunk of 256 voxels) items off one cursor,
+//                                  frames in order; the records are stored write-through (sc1); one arrival on ins_done[frame]
+//                                  per item
 //   stream A   k_dc_batch_k1       PERSISTENT, one 4-wave workgroup per CU: stages W / LayerNorm / theta parameters ONCE, then every
 //                                  wave walks the frames: wait ins_done[f] -> its range of cells of frame f (dc_k1_range, the body of
 //                                  the stand-alone kernel, reading the insert's records with sc1 loads and publishing S rows / counts
@@ -50,6 +51,10 @@
 #ifndef DC_BT_TIMEOUT_TICKS
 #define DC_BT_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz s_memrealtime clock */
 #endif
+#ifndef DC_BT_PROF
+#define DC_BT_PROF 0                /* 1 (python tools/mkvariant.py BTPROF "-DDC_BT_PROF=1" dense_batch.hip): every K1 / K2 item leaves a row of 100 MHz
+                                       timestamps in the buffers given to link_dc_batch_set_debug (tools/batch_timeline.py) */
+#endif
 #ifndef DC_BT_RELEASE_FENCE
 #define DC_BT_RELEASE_FENCE 0       /* 1: K1 publishes with an agent-scope release fence (buffer_wbl2) in front of its arrival as well
                                        -- belt and braces for A/B; every published table is stored write-through already */
@@ -72,14 +77,25 @@ struct dc_bt_frames_t { dc_bt_frame_t f[DC_BT_MAX]; };
 struct dc_bt_par_t {
   const float *w_pre, *pre_ln_w, *pre_ln_b, *w_pos, *ln_w, *ln_b;
   int cg; float eps;
+  unsigned long long *dbg1, *dbg2;     // DC_BT_PROF rows (word 0 = rows appended so far, word 1 = capacity), or NULL
 };
+// one row of eight 64-bit words per item, at the item's own place `r` (no returning atomic: a wave that waits for one drains every
+// store it has in flight, and the first version of these timers measured mostly that)
+__device__ __forceinline__ void bt_row(unsigned long long *dbg, unsigned long long r, unsigned long long a, unsigned long long b,
+                                       unsigned long long c, unsigned long long d, unsigned long long e, unsigned long long f) {
+  if (!DC_BT_PROF || !dbg) return;
+  if (r + 1 >= dbg[1]) return;
+  unsigned long long *o = dbg + 8 * (r + 1);
+  o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = e; o[5] = f; o[6] = 1;
+}
 // sync words of one call (int32, zeroed before the launches): every counter on its own 64-byte line
 __host__ __device__ constexpr int bt_err() { return 0; }
 __host__ __device__ constexpr int bt_cursor(int xcd) { return 16 * (1 + xcd); }          // K2's item cursors, one per XCD queue
 __host__ __device__ constexpr int bt_k1cur(int xcd) { return 16 * (9 + xcd); }          // K1's item cursors, one per XCD slab
-__host__ __device__ constexpr int bt_ins(int f) { return 16 * (17 + 2 * f); }           // arrivals of the frame's insert workgroups
-__host__ __device__ constexpr int bt_k1(int f) { return 16 * (18 + 2 * f); }            // arrivals of the frame's K1 ranges
-constexpr int BT_SYNC_WORDS = 16 * (17 + 2 * DC_BT_MAX);
+__host__ __device__ constexpr int bt_inscur() { return 16 * 17; }                       // the insert's item cursor
+__host__ __device__ constexpr int bt_ins(int f) { return 16 * (18 + 2 * f); }           // arrivals of the frame's insert chunks
+__host__ __device__ constexpr int bt_k1(int f) { return 16 * (19 + 2 * f); }            // arrivals of the frame's K1 ranges
+constexpr int BT_SYNC_WORDS = 16 * (18 + 2 * DC_BT_MAX);
 
 // Lane 0 polls *p until it reaches `target` (relaxed agent-scope loads: sc1, L2-served), sleeping between polls, giving up when the
 // call's error word is set or after DC_BT_TIMEOUT_TICKS; returns (wave-uniform) whether the target was reached.
@@ -106,14 +122,40 @@ __device__ __forceinline__ bool bt_wait_ge(int32_t *sync, int word, int target) 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // slot insert of every frame of the batch: workgroup -> (frame, chunk); write-through records; one arrival per workgroup
 // ---------------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_dc_batch_insert(dc_bt_frames_t fr, link_dc_grid_t g, int wpf, int32_t *__restrict__ sync) {
-  const int f = (int)blockIdx.x / wpf, j = (int)blockIdx.x - f * wpf;
-  const dc_bt_frame_t &F = fr.f[f];
-  int s0 = 0, s1 = 0, s2 = 0;
-  dc_index_body<false, true>(F.coords, F.n, g, F.cnt, F.slots, F.vcell, F.hdr, j, wpf, 256, s0, s1, s2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through records (and its counter atomics) have left
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[bt_ins(f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// PERSISTENT too: single-wave workgroups, four per CU (a wave per SIMD), 34 registers, NO LDS and no barrier -- a CU's 128 LDS
+// granules are taken by one K1 + one K2 workgroup, so a kernel that asks for a single byte of LDS finds no room beside them.  (As an
+// ordinary grid of 9 400 workgroups the batch's insert took every free wave slot and register of the chip at the start of a call,
+// and K1 / K2 workgroups of the same call found no room until it had drained: tools/batch_timeline.py, first version -- the first
+// frame's last K1 range ended 176 us into the call.)  A resident wave per SIMD inserts a frame in ~10 us, twice as fast as K1
+// consumes them.
+struct dc_bt_ins_args_t { dc_bt_frames_t fr; link_dc_grid_t g; int nframes, wpf; int32_t *sync; };   // the kernel's only argument
+__global__ void __launch_bounds__(64) k_dc_batch_insert(dc_bt_ins_args_t args_by_value) {
+  (void)args_by_value;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Items (frame, chunk of 256 voxels) off ONE cursor, frames in order; an item's arrival goes to ins_done[frame] (target: the
+  // chunks of a frame).  Drawn, not dealt: whichever of this kernel's waves are resident insert the whole batch -- nothing waits
+  // for a workgroup that has not found room yet.  (Arguments through the laundered kernarg pointer, as in the K2 role: hoisted out
+  // of the loop the grid's fields and the frame's descriptors cost registers this kernel does not have -- it must fit the 48 per
+  // SIMD the other two leave.)
+  typedef const __attribute__((address_space(4))) dc_bt_ins_args_t *args_ptr_t;
+  for (;;) {
+    args_ptr_t a = (args_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    int t = 0;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(&a->sync[bt_inscur()], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int wpf = a->wpf;
+    if (t >= a->nframes * wpf) break;
+    const int f = t / wpf, j = t - f * wpf;
+    const link_dc_grid_t g = a->g;
+    int s0 = 0, s1 = 0, s2 = 0;
+    _Pragma("unroll 1") for (int k = 0; k < 4; k++)       // voxels [256 j, 256 j + 256), 64 at a time (NOT unrolled: 42 registers; unrolled 49-50 -> 56 allocated, and 208 + 2 x 128 + 56 > 512)
+      dc_index_body<false, true>(a->fr.f[f].coords, a->fr.f[f].n, g, a->fr.f[f].cnt, a->fr.f[f].slots, a->fr.f[f].vcell, a->fr.f[f].hdr,
+                                 4 * j + k, 4 * wpf, 64, s0, s1, s2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through records (and its counter atomics) have left
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&a->sync[bt_ins(f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -155,6 +197,7 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, DC_K1_WAVES) k_dc_batch_k1(dc_b
   for (;;) {
     const int t = __builtin_amdgcn_readfirstlane(t_next);
     if (t >= total) break;
+    const unsigned long long tp0 = DC_BT_PROF ? __builtin_amdgcn_s_memrealtime() : 0;
     const int f = t / mine, i = lo + (t - f * mine);
     if (lane == 0) t_next = __hip_atomic_fetch_add(cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the item after this one
     const dc_bt_frame_t &F = fr.f[f];
@@ -183,8 +226,10 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, DC_K1_WAVES) k_dc_batch_k1(dc_b
       F.hdr[LINK_HDR_STATUS] = __hip_atomic_load(&F.hdr[LINK_HDR_STATUS_ACC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&F.hdr[LINK_HDR_STATUS_ACC], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    const unsigned long long tp1 = DC_BT_PROF ? __builtin_amdgcn_s_memrealtime() : 0;
     dc_k1_range<C, OP, NB, false, false, true>(smem_raw, F.feats, F.slots, F.cnt, F.cell_n, p.w_pre, 1.0f, p.eps, F.n, g, false, F.S, nullptr,
                                                nullptr, nullptr, c_begin, c_end, pc_f, nv_f, rf0, rf1, rf2, rf3, w_big, th_slow, i, 0, 0);
+    if (DC_BT_PROF && lane == 0) bt_row(p.dbg1, (unsigned long long)f * nranges + i, (unsigned long long)f, (unsigned long long)i, tp0, tp1, __builtin_amdgcn_s_memrealtime(), (unsigned long long)(blockIdx.x * 4 + (tid >> 6)));
   }
   // the last item's arrival: every table K2 reads was stored write-through, so once the stores are acknowledged they are in memory
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,6 +277,8 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
     args_ptr_t a = (args_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     int32_t *sy = a->sync;
     const int per = (a->nwg + 7) >> 3;
+    if (DC_BT_PROF)                                    // when this workgroup became resident (row behind the items' rows; kind 7)
+      bt_row(a->p.dbg2, (unsigned long long)a->nframes * (8 * per) + blockIdx.x, 9999, 0, __builtin_amdgcn_s_memrealtime(), 0, 0, blockIdx.x);
     const int t = __hip_atomic_fetch_add(&sy[bt_cursor(x)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_next = __hip_atomic_fetch_add(&sy[bt_cursor(x)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int f = t < a->nframes * per ? t / per : -1;
@@ -244,6 +291,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
     asm volatile("" : "+s"(a));
     const int f = __builtin_amdgcn_readfirstlane(s_ctl[0]), bid = __builtin_amdgcn_readfirstlane(s_ctl[1]);
     if (f < 0) break;
+    const unsigned long long tq0 = DC_BT_PROF ? __builtin_amdgcn_s_memrealtime() : 0;
     __syncthreads();                                   // everyone has read the item: the control thread may lay out the next
     {
       const link_dc_grid_t g = a->g;
@@ -253,6 +301,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
                                       1.0f, a->p.eps, a->fr.f[f].n, g, a->txn, a->tyn, a->zsplit, a->nwg, a->fr.f[f].out, nullptr, bid, tidx);
     }
     if (threadIdx.x == CTL_THREAD) {                   // the mapper's plane loop is through: the next item
+      const unsigned long long tq1 = DC_BT_PROF ? __builtin_amdgcn_s_memrealtime() : 0;
       int32_t *sy = a->sync;
       const int per = (a->nwg + 7) >> 3;
       const int t = t_next;
@@ -262,6 +311,7 @@ __global__ void __launch_bounds__(256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0))
         if (!bt_wait_ge(sy, bt_k1(fn), a->k1_target)) fn = -1;
       }
       s_ctl[0] = fn; s_ctl[1] = fn >= 0 ? (t - fn * per) * 8 + x : 0;
+      if (DC_BT_PROF) bt_row(a->p.dbg2, (unsigned long long)f * (8 * per) + bid, (unsigned long long)f, (unsigned long long)bid, tq0, tq1, __builtin_amdgcn_s_memrealtime(), (unsigned long long)blockIdx.x);
     }
     __syncthreads();                                   // the tile's LDS images are free again, the next item is laid out
   }
@@ -285,6 +335,7 @@ struct link_dc_batch {
   std::vector<const void *> bufs[BT_RING];             // S pointers of the frames the ring slot's call worked on
   bool used[BT_RING];
   long long calls;
+  unsigned long long *dbg1, *dbg2;                     // DC_BT_PROF rows (link_dc_batch_set_debug)
 };
 
 extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
@@ -293,8 +344,17 @@ extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
   hipDeviceProp_t pr;
   if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&pr, c->device) != hipSuccess) { delete c; return LINK_ERR_LAUNCH; }
   c->cus = pr.multiProcessorCount;
-  bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->sb, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking) == hipSuccess &&
+  // The three roles must sit in three DIFFERENT hardware queues: a kernel queued behind another in one queue starts when that one
+  // ends, and a K2 role behind its own K1 role runs the batch serially (first versions: 47 us / frame, tools/batch_timeline.py showed
+  // K2's first item starting when K1's last one ended).  The runtime hands hardware queues out per stream PRIORITY class, a few per
+  // class, shared round-robin by all streams of the class -- and the default class is where the caller's (and torch's) streams live.
+  // So K1 and K2 take the high class, the insert the low one: classes the rest of the process rarely uses.  (Launch order inside a
+  // call stays insert -> K1 -> K2, the order of the dependences, so that even a shared queue serialises instead of deadlocking.)
+  int pr_lo = 0, pr_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);                 // numerically: least = greatest number
+  bool ok = hipStreamCreateWithPriority(&c->sa, hipStreamNonBlocking, pr_hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->sb, hipStreamNonBlocking, pr_hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, pr_lo) == hipSuccess &&
             hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
             hipMemset(c->sync, 0, sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess;
   for (int i = 0; i < BT_RING && ok; i++) {
@@ -304,6 +364,7 @@ extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
     c->used[i] = false;
   }
   c->calls = 0;
+  c->dbg1 = c->dbg2 = nullptr;
   if (!ok) { (void)hipGetLastError(); delete c; return LINK_ERR_LAUNCH; }   // (a failed create leaks what it had made: process-fatal anyway)
   *out = c;
   return LINK_OK;
@@ -320,6 +381,15 @@ extern "C" int link_dc_batch_destroy(link_dc_batch_t *c) {
   (void)hipStreamDestroy(c->sa); (void)hipStreamDestroy(c->sb); (void)hipStreamDestroy(c->sc);
   delete c;
   return LINK_OK;
+}
+
+// Profiling hook (tools only): device buffers of 8-word rows the K1 / K2 items append their timestamps to -- word 0 of a buffer = rows
+// so far (zeroed by the caller), word 1 = capacity in rows; honoured by a -DDC_BT_PROF=1 build, ignored otherwise.
+extern "C" int link_dc_batch_set_debug(link_dc_batch_t *c, uint64_t *k1_rows, uint64_t *k2_rows) {
+  if (!c) return LINK_ERR_ARG;
+  c->dbg1 = reinterpret_cast<unsigned long long *>(k1_rows);
+  c->dbg2 = reinterpret_cast<unsigned long long *>(k2_rows);
+  return DC_BT_PROF ? LINK_OK : 1;
 }
 
 // status of the calls made so far (synchronises the context's streams): out[0] = first non-zero error word of the ring (0 = none;
@@ -344,11 +414,17 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   using K1 = dc_k1_cfg<64, OP>;
   using KQ = dc_k2q_cfg<OP, R>;
   using KG = typename dc_k2_cfg<OP, R>::G;
-  constexpr int LDS_CU = 160 * 1024;
-  // one K1 + one K2 workgroup fill a CU; two K2 workgroups must NOT fit (they would take the room of a K1 workgroup they wait for)
-  constexpr int k1_lds = K1::LDS_BYTES;
-  constexpr int k2_lds = (KQ::LDS_BYTES > LDS_CU / 2 + 512 ? KQ::LDS_BYTES : LDS_CU / 2 + 512);
-  static_assert(k1_lds + k2_lds <= LDS_CU && 2 * k2_lds > LDS_CU, "LDS shaping of the two persistent roles");
+  // LDS is handed out in 128 granules of 1 280 bytes per CU (tools/coresidency_probe.hip: 81 152 + 81 920 bytes share a CU, 81 152 +
+  // 82 048 do not; 82 944 + 80 304 do, 82 944 + 80 896 do not).  With their static LDS (K1: 256 B behind __syncthreads_or; K2: 16 B of
+  // loop control) K1 is padded to 65 granules and K2 takes 63: one of each fills a CU, two K1 workgroups do not fit (the mix bench.py's
+  // stream geometry was tuned to -- k1_lds_pad 2 048).  Two K2 workgroups DO fit where no K1 workgroup sits; nothing depends on that
+  // not happening: every role draws its work from cursors, so whichever workgroups are resident finish the batch.
+  // (First versions padded K2 so that two of them would not fit -- 82 400 bytes = 65 granules next to K1's 64: the pair did not fit,
+  // the K2 role became resident as the K1 role's workgroups left, and the batch ran its two roles one after the other: 44-48 us / frame.)
+  constexpr int LDS_GRAN = 1280, LDS_GRANS = 128, K1_STATIC = 256, K2_STATIC = 16;
+  constexpr int k1_lds = 65 * LDS_GRAN - K1_STATIC;
+  constexpr int k2_lds = KQ::LDS_BYTES;
+  static_assert(k1_lds >= K1::LDS_BYTES && (k2_lds + K2_STATIC + LDS_GRAN - 1) / LDS_GRAN <= LDS_GRANS - 65, "LDS shaping of the two persistent roles");
   int32_t *sync = c->sync + (size_t)q * BT_SYNC_WORDS;
   const int64_t vi = (int64_t)g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
   const int k1_wgs = c->cus;
@@ -367,7 +443,12 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   if (wpf < 1) wpf = 1;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_batch_k1<OP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, k1_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_batch_k2<OP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, k2_lds);
-  hipLaunchKernelGGL(k_dc_batch_insert, dim3((unsigned)(wpf * nframes)), dim3(256), 0, c->sc, fr, g, wpf, sync);
+  // the arrivals a frame's insert posts = its chunks of 256 voxels (wpf).
+  // Launch order = dependence order (insert -> K1 -> K2): should two of the streams share a hardware queue after all, the later
+  // kernel waits for the earlier one to END -- slow, but never a kernel spinning on one that sits behind it in its own queue.
+  const int ins_wgs = c->cus;
+  const dc_bt_ins_args_t a0{fr, g, nframes, wpf, sync};
+  hipLaunchKernelGGL(k_dc_batch_insert, dim3((unsigned)ins_wgs * 4), dim3(64), 0, c->sc, a0);
   int rc = check_launch("link_elk_core_dense_forward_batch (insert)");
   if (rc != LINK_OK) return rc;
   hipLaunchKernelGGL((k_dc_batch_k1<OP, 2>), dim3((unsigned)k1_wgs), dim3(64 * K1::NW), k1_lds, c->sa, fr, p, g, nframes, cpw, k1_target, wpf, sync);
@@ -375,7 +456,7 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   if (rc != LINK_OK) return rc;
   const dc_bt_k2_args_t a2{fr, p, g, nframes, txn, tyn, zsplit, (int)nwg, k1_target, sync};
   static_assert(sizeof(dc_bt_k2_args_t) <= 4096, "kernel arguments");
-  hipLaunchKernelGGL((k_dc_batch_k2<OP, R>), dim3((unsigned)c->cus), dim3(KQ::THREADS), k2_lds - (int)sizeof(int) * 2, c->sb, a2);
+  hipLaunchKernelGGL((k_dc_batch_k2<OP, R>), dim3((unsigned)c->cus), dim3(KQ::THREADS), k2_lds, c->sb, a2);
   return check_launch("link_elk_core_dense_forward_batch (K2)");
 }
 
@@ -401,7 +482,7 @@ extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
-  const dc_bt_par_t p{b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, b0.ln_w, b0.ln_b, d->cg, d->eps};
+  const dc_bt_par_t p{b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, b0.ln_w, b0.ln_b, d->cg, d->eps, c->dbg1, c->dbg2};
   for (int base = 0; base < nframes; base += DC_BT_MAX) {
     const int nb = nframes - base < DC_BT_MAX ? nframes - base : DC_BT_MAX;
     const int q = (int)(c->calls % BT_RING);
