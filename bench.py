@@ -30,6 +30,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes streams onto a few hardware queues (4 by default); this process uses the three frame streams, the batch
+# context's three role streams and two caller streams.  Kernels of streams that share a hardware queue run one after the other (round
+# 6, tools/batch_bench.py: the batch entry point 42.5 us / frame with the default, 35.9 with 8 queues; the three-stream figure moves
+# within its box-to-box noise).  Set before the runtime initialises, unless the caller has chosen a value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 SHADER_CLOCK_HZ = 2.4e9     # nominal; the line carries the MEASURED shader clock (gpu_state) and prices mfma_util with it when it is known
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -1004,39 +1009,89 @@ def main():
     torch.cuda.synchronize()
     step_us = sorted(1e3 * x.elapsed_time(y) for x, y in step_ev)
     core = {k: v for k, v in kern_us.items() if k in kab}
-    dom = max(core, key=core.get)
-    achieved = kab[dom] / (core[dom] * 1e-6) / 1e9
-    # memory-side bytes per launch: rocprofv3 PMC passes over this workload (tools/pmc_dc.sh -> profiles/traffic.json;
-    # they cannot be collected from inside the timed process)
-    traffic, traffic_src, mfma_cyc = None, None, {}
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj) and (N, C) == (100000, 64) and args.io == "f32":
-        tdb = json.load(open(tj))
-        traffic = tdb.get("kernels", {}).get(dom)
-        traffic_src = tdb.get("source")
-        mfma_cyc = tdb.get("mfma_busy_cycles", {})
+    dom1 = max(core, key=core.get)
+    # ---- the same three stages in the TIMED geometry (NS frames in flight on NS streams), device events around every launch: what a
+    # kernel costs while the other frames' kernels run beside it.  (An instrumented replay: the timed region itself is never touched.)
+    live = None
+    if plan.dense and C == 64 and NS > 1:
+        geometry(NS)
+        sh = [s_.cuda_stream for s_ in streams]
+        bj = [plans[j].buf for j in range(NS)]
+        for j in range(NS):
+            bj[j].feats, bj[j].coords = frames[j][0].data_ptr(), frames[j][1].data_ptr()
+        tev = {k: [] for k in ("index", "premix_modsum", "gather_demod")}
+        for it in range(min(args.steps, 60) + 5):
+            for j in range(NS):
+                with torch.cuda.stream(streams[j]):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    ev[0].record()
+                    lib.link_dc_index(bj[j].coords, N, ctypes.byref(g), bj[j].cnt, bj[j].slots, bj[j].vcell, bj[j].hdr, sh[j])
+                    ev[1].record()
+                    lib.link_dc_premix_modsum(ctypes.byref(bj[j]), ctypes.byref(g), ctypes.byref(desc), N, 0, sh[j])
+                    ev[2].record()
+                    lib.link_dc_gather_demod(ctypes.byref(bj[j]), ctypes.byref(g), ctypes.byref(desc), N, sh[j])
+                    ev[3].record()
+                if it >= 5:
+                    for q, k in enumerate(tev):
+                        tev[k].append((ev[q], ev[q + 1]))
+        torch.cuda.synchronize()
+        live = {k: round(1e3 * sum(a.elapsed_time(b_) for a, b_ in v) / len(v), 2) for k, v in tev.items()}
+        geometry(1)
+    # ---- per-kernel figures of the TIMED geometry from the committed rocprofv3 files (profiles/timed_geometry.json, built by
+    # tools/r06_profiles.sh + tools/timed_geometry_json.py from the kernel trace of THIS command and the PMC passes over the same
+    # geometry): frac = algorithmic bytes per launch / (csv average us) / 8 TB/s -- reproducible from profiles/ by hand
+    tg, tg_kern, traffic_frame = None, {}, None
+    tgp = os.path.join(ROOT, "profiles", "timed_geometry.json")
+    if os.path.exists(tgp) and (N, C) == (100000, 64) and args.io == "f32" and plan.dense:
+        tg = json.load(open(tgp))
+        for k, v in tg.get("kernels", {}).items():
+            if k in kab:
+                tg_kern[k] = {"rocprof_name": v["rocprof_name"], "avg_us": v["avg_us"], "launches": v["launches"], "alg_bytes_per_launch": kab[k],
+                              "achieved_gbs": round(kab[k] / (v["avg_us"] * 1e-6) / 1e9, 1),
+                              "frac": round(kab[k] / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic_bytes_per_launch": v.get("traffic_bytes_per_launch"),
+                              "live_event_us_this_run": (live or {}).get(k)}
+        if tg_kern and all(v.get("traffic_bytes_per_launch") for v in tg_kern.values()):
+            traffic_frame = int(sum(v["traffic_bytes_per_launch"] for v in tg_kern.values()))
     clock_hz, clock_src = SHADER_CLOCK_HZ, "nominal 2.4 GHz (no amdsmi reading)"
     if gpu_state and gpu_state.get("sclk_mhz"):
         clock_hz, clock_src = gpu_state["sclk_mhz"]["median"] * 1e6, "amdsmi median shader clock during a replay of the timed steps"
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "alg_bytes_per_launch": kab[dom], "kernel_us": {k: round(v, 2) for k, v in kern_us.items()},
+    us_frame = 1e6 * elapsed / (args.steps * NS * ROUNDS)
+    dom = max(tg_kern, key=lambda k: tg_kern[k]["avg_us"]) if tg_kern else dom1
+    mfma_cyc = (tg or {}).get("kernels", {}).get("premix_modsum", {}).get("mfma_busy_cycles_per_launch")
+    mfma_us = tg_kern.get("premix_modsum", {}).get("avg_us")
+    # The headline of the object is the TIMED REGION: B_alg of a frame over the region's time per frame.  The step is three kernels of
+    # similar length that overlap across the frames in flight, so no single launch "is" the step; `kernel` names the longest launch of
+    # the timed geometry and `timed_geometry.kernels` carries every launch's own figures (rocprofv3 averages of the committed CSV).
+    roofline = {"bound": "hbm", "kernel": (tg_kern[dom]["rocprof_name"] if tg_kern else dom), "achieved": round(ab["total"] / (us_frame * 1e-6) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab["total"] / (us_frame * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "timed region: B_alg of one frame (SURVEY.md 8d) / measured time per frame / 8 TB/s -- the same number as whole_step.frac",
+                "alg_bytes_per_frame": ab["total"], "traffic": traffic_frame,
+                "traffic_what": ("memory-side bytes per FRAME in the timed geometry (sum over the three launches; rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+                                 if traffic_frame else None),
+                "timed_geometry": ({"source_kernel_stats": tg["source_kernel_stats"], "source_pmc": tg["source_pmc"], "commit": tg["commit"],
+                                    "geometry": tg["geometry"], "dominant": dom, "kernels": tg_kern,
+                                    "sum_of_launches_over_frames_in_flight_us": round(sum(v["avg_us"] for v in tg_kern.values()) / NS, 2),
+                                    "note": "frac = alg_bytes_per_launch / (avg_us of the committed CSV) / 8 TB/s; live_event_us_this_run = the same "
+                                            "launch bracketed by HIP events on its stream in an instrumented replay of the timed geometry"}
+                                   if tg_kern else None),
                 "layout": "dense-cell" if plan.dense else "general",
-                # north_star: MFMA utilisation of the kernel that holds the dense contraction = SQ_VALU_MFMA_BUSY_CYCLES (cycles,
-                # summed over the chip's 1024 SIMDs; PMC pass of profiles/traffic.json) / (kernel duration x 1024 SIMDs x clock)
-                "mfma_util": ({"kernel": "premix_modsum", "busy_cycles_per_launch": mfma_cyc["premix_modsum"],
-                               "frac": round(mfma_cyc["premix_modsum"] / (kern_us["premix_modsum"] * 1e-6 * 1024 * clock_hz), 4),
-                               "clock_hz": clock_hz, "clock_source": clock_src,
-                               "note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel us x 1024 SIMDs x shader clock); the contraction is 0.82 GFLOP "
-                                       "per frame -- not a grading bound (SURVEY.md 8d)"}
-                              if "premix_modsum" in mfma_cyc and "premix_modsum" in kern_us else None),
-                "whole_step": {"alg_bytes": ab["total"], "us": round(1e6 * elapsed / (args.steps * NS * ROUNDS), 2),
-                               "frac": round(ab["total"] / (elapsed / (args.steps * NS * ROUNDS)) / 1e9 / HBM_PEAK_GBS, 4),
+                # north_star: MFMA utilisation of the kernel that holds the dense contraction = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the
+                # chip's 1024 SIMDs; PMC pass in the timed geometry) / (its rocprofv3 duration x 1024 SIMDs x clock)
+                "mfma_util": ({"kernel": "premix_modsum", "busy_cycles_per_launch": mfma_cyc,
+                               "frac": round(mfma_cyc / (mfma_us * 1e-6 * 1024 * clock_hz), 4), "clock_hz": clock_hz, "clock_source": clock_src,
+                               "note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel us x 1024 SIMDs x shader clock); the contraction is 0.82 GFLOP per frame -- "
+                                       "not a grading bound (SURVEY.md 8d)"} if mfma_cyc and mfma_us else None),
+                "whole_step": {"alg_bytes": ab["total"], "us": round(us_frame, 2),
+                               "frac": round(ab["total"] / (us_frame * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "per frame: B_alg of one frame over the timed region's time per frame"},
-                "single_frame_step": {"median_us": round(step_us[len(step_us) // 2], 2),
-                                      "mean_us": round(sum(step_us) / len(step_us), 2), "n": len(step_us),
-                                      "frac": round(ab["total"] / (step_us[len(step_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+                "single_frame_geometry": {"what": "ONE frame in flight (other launch geometry: matrix-core sums pre_mix at 1024 workgroups): per-stage HIP events "
+                                                  "around the stage calls, and whole steps one by one -- NOT the timed region",
+                                          "kernel_us_events": {k: round(v, 2) for k, v in kern_us.items()},
+                                          "dominant": dom1, "dominant_frac": round(kab[dom1] / (core[dom1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "step_median_us": round(step_us[len(step_us) // 2], 2), "step_mean_us": round(sum(step_us) / len(step_us), 2),
+                                          "n": len(step_us),
+                                          "frac": round(ab["total"] / (step_us[len(step_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     # ---- CPU baseline: the oracle on this host (rank 0, N=1 only) -------------------------------------
     # (1) the OpenMP twin of the C restatement -- pragmas exactly where the reference's CPU ops have them
@@ -1085,37 +1140,45 @@ def main():
         "multi_gpu": multi,          # N > 1 only: backend, all_reduce check, end-to-end time, full-tensor gather
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
     }
-    # ---- the same frames through ONE stream with the three-frame step kernel (ElkCorePipeline: one launch per frame runs the
-    # slot insert, pre_mix and gather of three consecutive frames) -- what a caller without spare streams gets; reported beside
-    # `single_stream_value`, never the headline (three plans on three streams are faster: DESIGN.md section 4e)
-    if plan.dense and C == 64 and G == 2 and args.io == "f32" and not plan.__dict__.get("sparse"):
+    # ---- the BATCH entry point (include/link_amd.h section H; round 6): the same frames as batches of NS * ROUNDS through
+    # link_elk_core_dense_forward_batch -- one insert kernel + two persistent, queue-fed role kernels per call -- two arena sets
+    # alternated on two streams (the pre_mix role of call s + 1 starts under the gather role of call s).  A step = one call = the
+    # same 24 frames as a step of the headline; reported beside it, never as it.
+    if plan.dense and C == 64 and G == 2 and args.io == "f32" and not plan.__dict__.get("sparse") and world == 1:
         try:
-            pipe = la.ElkCorePipeline(N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)
-            pipe.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None,
-                      blk.norm.weight, blk.norm.bias)
-            k = max(args.steps, 50) * NS
-            got = []
-            for j in range(NS):
-                r_ = pipe.push(frames[j][0], frames[j][1])
-                if r_ is not None:
-                    got.append(r_.clone())
-            got += [t.clone() for t in pipe.flush()]
-            err = max(float((a.float() - b_.float()).abs().max() / b_.float().abs().max()) for a, b_ in zip(got, outs_timed))
-            for _ in range(2):
+            FB, SETS = NS * ROUNDS, 2
+            bsets = [la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)]
+            bsets.append(la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev, share=bsets[0]))
+            for b_ in bsets:
+                b_.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight,
+                        blk.norm.bias)
+            bfe, bco = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
+            bstreams = [torch.cuda.Stream(device=dev) for _ in range(SETS)]
+            ok = True
+            for b_ in bsets:
+                outs_b = b_.run(bfe, bco)
+                torch.cuda.synchronize()
+                b_.check()
+                ok &= all(torch.equal(outs_b[i], outs_timed[i % NS]) for i in range(FB))
+            kb = max(args.steps, 20)
+            tb = None
+            for _ in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for f in range(k):
-                    pipe.push(frames[f % NS][0], frames[f % NS][1])
-                pipe.flush()
+                for s_ in range(kb):
+                    bsets[s_ % SETS].run(bfe, bco, stream=bstreams[s_ % SETS].cuda_stream)
                 torch.cuda.synchronize()
-                t_pipe = time.perf_counter() - t0
-            line["single_stream_step_kernel"] = {
-                "us_per_frame": round(1e6 * t_pipe / k, 2), "value": round(N * k / t_pipe, 1), "frames": k,
-                "max_rel_err_vs_timed_configuration": err,
-                "note": "ElkCorePipeline / link_elk_core_dense_step3: one stream, one launch per frame (fill and drain included)"}
-            del pipe
+                tb = time.perf_counter() - t0
+            bsets[0].check()
+            line["batch_entry_point"] = {
+                "us_per_frame": round(1e6 * tb / (kb * FB), 2), "value": round(N * kb * FB / tb, 1), "frames_per_call": FB, "calls": kb,
+                "arena_sets_in_flight": SETS, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
+                "bitwise_equal_to_timed_configuration": bool(ok),
+                "note": "ElkCoreBatch / link_elk_core_dense_forward_batch: slot insert of the batch + persistent pre_mix and gather role kernels fed "
+                        "by per-XCD cursors, per-frame arrival counters instead of launch boundaries (DESIGN.md 4i)"}
+            del bsets
         except Exception as e:                          # a side measurement must never cost the line
-            line["single_stream_step_kernel"] = {"error": repr(e)[:200]}
+            line["batch_entry_point"] = {"error": repr(e)[:200]}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

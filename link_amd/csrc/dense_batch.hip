@@ -55,6 +55,12 @@
 #define DC_BT_PROF 0                /* 1 (python tools/mkvariant.py BTPROF "-DDC_BT_PROF=1" dense_batch.hip): every K1 / K2 item leaves a row of 100 MHz
                                        timestamps in the buffers given to link_dc_batch_set_debug (tools/batch_timeline.py) */
 #endif
+#ifndef DC_BT_INS_LEAD
+#define DC_BT_INS_LEAD 1000         /* pacing of the insert: at most this many frames (+ the one in progress) ahead of K1.  OFF (1000): paced at 2 with two waves per CU the insert ran beside K1 / K2 all call long and the batch went 36.9 -> 45.0 us / frame (B = 24 x 2 sets); unpaced it floods the first ~200 us of a call and leaves the rest clean */
+#endif
+#ifndef DC_BT_INS_WAVES
+#define DC_BT_INS_WAVES 4           /* single-wave insert workgroups per CU */
+#endif
 #ifndef DC_BT_RELEASE_FENCE
 #define DC_BT_RELEASE_FENCE 0       /* 1: K1 publishes with an agent-scope release fence (buffer_wbl2) in front of its arrival as well
                                        -- belt and braces for A/B; every published table is stored write-through already */
@@ -99,13 +105,14 @@ constexpr int BT_SYNC_WORDS = 16 * (18 + 2 * DC_BT_MAX);
 
 // Lane 0 polls *p until it reaches `target` (relaxed agent-scope loads: sc1, L2-served), sleeping between polls, giving up when the
 // call's error word is set or after DC_BT_TIMEOUT_TICKS; returns (wave-uniform) whether the target was reached.
-__device__ __forceinline__ bool bt_wait_ge(int32_t *sync, int word, int target) {
+template <typename P>
+__device__ __forceinline__ bool bt_wait_ge(P sync, int word, int target, const int nap = 8) {
   int ok = 1;
   if ((threadIdx.x & 63) == 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     int spins = 0;
     while (__hip_atomic_load(&sync[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(8);
+      if (nap > 8) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(8);
       if ((++spins & 15) == 0) {
         if (__hip_atomic_load(&sync[bt_err()], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > DC_BT_TIMEOUT_TICKS) {
@@ -147,11 +154,36 @@ __global__ void __launch_bounds__(64) k_dc_batch_insert(dc_bt_ins_args_t args_by
     const int wpf = a->wpf;
     if (t >= a->nframes * wpf) break;
     const int f = t / wpf, j = t - f * wpf;
+    // Paced: a frame is inserted when K1 has reached the frame DC_BT_INS_LEAD before it.  Unpaced, the insert of all 24 frames ran
+    // flat out through the first ~200 us of a call -- 2.4 M counter atomics and as many scattered 16-byte write-through stores -- and
+    // every K1 item that started in that window took 80-90 us instead of 27 (tools/batch_timeline.py, "first-loads wait" 57 us).
+    if (f >= DC_BT_INS_LEAD && !bt_wait_ge(a->sync, bt_k1(f - DC_BT_INS_LEAD), 1, 64)) break;
     const link_dc_grid_t g = a->g;
-    int s0 = 0, s1 = 0, s2 = 0;
-    _Pragma("unroll 1") for (int k = 0; k < 4; k++)       // voxels [256 j, 256 j + 256), 64 at a time (NOT unrolled: 42 registers; unrolled 49-50 -> 56 allocated, and 208 + 2 x 128 + 56 > 512)
-      dc_index_body<false, true>(a->fr.f[f].coords, a->fr.f[f].n, g, a->fr.f[f].cnt, a->fr.f[f].slots, a->fr.f[f].vcell, a->fr.f[f].hdr,
-                                 4 * j + k, 4 * wpf, 64, s0, s1, s2);
+    // the statements of dc_index_body (dense_common.h) on 32-bit voxel numbers, one pass of 64 voxels at a time: that body's 64-bit
+    // grid-stride loop cost 42 registers here (49-50 unrolled), and this kernel has 40 (208 + 2 x 128 + 40 of a SIMD's 512)
+    const int n = (int)a->fr.f[f].n;
+    const int4 *__restrict__ coords = a->fr.f[f].coords;
+    int32_t *__restrict__ vcell = a->fr.f[f].vcell;
+    int32_t *__restrict__ hdr = a->fr.f[f].hdr;
+    const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(a->fr.f[f].slots, (uint32_t)((int64_t)g.vp * g.k * 16));
+    const __amdgpu_buffer_rsrc_t r_cnt = dc_rsrc(a->fr.f[f].cnt, (uint32_t)(g.vp * 4));
+    if (j == 0 && threadIdx.x == 0) hdr[LINK_HDR_NVALID] = n;
+    _Pragma("unroll 1") for (int k = 0; k < 4; k++) {
+      const int v = (4 * j + k) * 64 + (int)threadIdx.x;
+      if (v >= n) break;
+      const int4 rc = coords[v];
+      const unsigned ux = (unsigned)(floordiv(rc.x, g.s) - g.lo[0]), uy = (unsigned)(floordiv(rc.y, g.s) - g.lo[1]);
+      const unsigned uz = (unsigned)(floordiv(rc.z, g.s) - g.lo[2]), ub = (unsigned)(rc.w - g.lo[3]);
+      const bool inside = ux < (unsigned)g.dim[0] && uy < (unsigned)g.dim[1] && uz < (unsigned)g.dim[2] && ub < (unsigned)g.dim[3];
+      if (!inside) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 1);
+      const int pcell = inside ? dc_cell(g, (int)ux, (int)uy, (int)uz, (int)ub) : 0;
+      const int rank = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, r_cnt, pcell ? (uint32_t)pcell * 4u : DC_OOB, 0, 0);
+      const bool full = pcell != 0 && rank >= g.k;
+      if (full) atomicOr(&hdr[LINK_HDR_STATUS_ACC], 2);
+      const bool keep = pcell != 0 && !full;
+      st16i_c<true>(r_slots, keep ? dc_slot(g, pcell, rank) * 16u : DC_OOB, make_int4(rc.x, rc.y, rc.z, v));
+      vcell[v] = keep ? pcell : 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through records (and its counter atomics) have left
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&a->sync[bt_ins(f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -344,17 +376,15 @@ extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
   hipDeviceProp_t pr;
   if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&pr, c->device) != hipSuccess) { delete c; return LINK_ERR_LAUNCH; }
   c->cus = pr.multiProcessorCount;
-  // The three roles must sit in three DIFFERENT hardware queues: a kernel queued behind another in one queue starts when that one
-  // ends, and a K2 role behind its own K1 role runs the batch serially (first versions: 47 us / frame, tools/batch_timeline.py showed
-  // K2's first item starting when K1's last one ended).  The runtime hands hardware queues out per stream PRIORITY class, a few per
-  // class, shared round-robin by all streams of the class -- and the default class is where the caller's (and torch's) streams live.
-  // So K1 and K2 take the high class, the insert the low one: classes the rest of the process rarely uses.  (Launch order inside a
-  // call stays insert -> K1 -> K2, the order of the dependences, so that even a shared queue serialises instead of deadlocking.)
+  // Three non-blocking streams (tools/queue_probe.hip: kernels on three such streams start within a few us of each other, whatever
+  // else the process has created).  Launch order inside a call is insert -> K1 -> K2, the order of the dependences, so that even a
+  // shared hardware queue would serialise the roles instead of parking a kernel behind one that waits for it.
   int pr_lo = 0, pr_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);                 // numerically: least = greatest number
-  bool ok = hipStreamCreateWithPriority(&c->sa, hipStreamNonBlocking, pr_hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->sb, hipStreamNonBlocking, pr_hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, pr_lo) == hipSuccess &&
+  // the insert's stream has the HIGHEST priority: its waves must find their slot before the two roles that wait for them fill the CUs
+  bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->sb, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, pr_hi) == hipSuccess &&
             hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
             hipMemset(c->sync, 0, sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess;
   for (int i = 0; i < BT_RING && ok; i++) {
@@ -434,7 +464,11 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   if (cpw < 1) cpw = 1;
   const int k1_target = (int)((vi + cpw - 1) / cpw);    // ranges of a frame
   const int txn = (g.dim[0] + KG::TX - 1) / KG::TX, tyn = (g.dim[1] + KG::TY - 1) / KG::TY;
-  int zsplit = 2;                                        // the geometry of frames in flight (fewer halo planes summed twice)
+  // z-segments of a K2 tile: 1 = whole columns.  The stream geometry cuts columns in two so that ONE frame's tiles fill the chip; here
+  // the K2 role's workgroups draw tiles of several frames, and whole columns are 5 % fewer plane steps (B = 32 x 2 sets, one box: 33.9
+  // us / frame against 34.7 with two segments, 35.4 with three).  LINK_DC_BATCH_ZSPLIT (experiments only) overrides.
+  static const int zs_env = [] { const char *e = getenv("LINK_DC_BATCH_ZSPLIT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  int zsplit = zs_env;
   if (zsplit > g.dim[2]) zsplit = g.dim[2];
   const int64_t nwg = (int64_t)txn * tyn * g.dim[3] * zsplit;
   if (nwg > (1 << 20)) return LINK_ERR_ARG;
@@ -448,7 +482,7 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   // kernel waits for the earlier one to END -- slow, but never a kernel spinning on one that sits behind it in its own queue.
   const int ins_wgs = c->cus;
   const dc_bt_ins_args_t a0{fr, g, nframes, wpf, sync};
-  hipLaunchKernelGGL(k_dc_batch_insert, dim3((unsigned)ins_wgs * 4), dim3(64), 0, c->sc, a0);
+  hipLaunchKernelGGL(k_dc_batch_insert, dim3((unsigned)ins_wgs * DC_BT_INS_WAVES), dim3(64), 0, c->sc, a0);
   int rc = check_launch("link_elk_core_dense_forward_batch (insert)");
   if (rc != LINK_OK) return rc;
   hipLaunchKernelGGL((k_dc_batch_k1<OP, 2>), dim3((unsigned)k1_wgs), dim3(64 * K1::NW), k1_lds, c->sa, fr, p, g, nframes, cpw, k1_target, wpf, sync);

@@ -309,3 +309,30 @@ def test_block_driver_struct_and_arena_helper():
         assert all(o[i + 1] - o[i] >= sizes[i] for i in range(10))
     assert lib.link_pair_plan_arena(0, 27, 1, offs) == -1 and lib.link_pair_plan_arena(10, 65, 0, offs) == -1
     assert lib.link_elk_block_forward(None, None, None) == L.LINK_ERR_ARG       # argument validation before anything touches a device
+
+
+def test_batch_kernels_resource_shape():
+    """Section H (round 6): the three kernels of a batch call must fit ONE CU side by side -- a K1-role workgroup (4 waves), a
+    K2-role workgroup (8 waves) and the insert's single-wave workgroups: per SIMD one K1 wave + two K2 waves + one insert wave within
+    512 vector registers; no scratch (scratch traffic would break the K2 producers' counted vmcnt waits); the insert without LDS (the
+    CU's 128 LDS granules of 1 280 bytes are taken by 65 (K1, padded) + 63 (K2): tools/coresidency_probe.hip).  Read from the built
+    code object's metadata (tools/kernel_regs.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_regs import kernel_table
+    from link_amd import build as hip_build
+    hip_build.build()
+    rows = [r for r in kernel_table(os.path.join(ROOT, "link_amd", "lib", "obj", "dense_batch.o")) if "k_dc_batch" in r[0]]
+    assert len(rows) == 7, [r[0] for r in rows]                           # insert + K1 x {cos, sin} + K2 x {cos, sin} x {r 2, 3}
+    al = lambda v: (int(v) + 7) // 8 * 8                                     # vector registers are allocated in eights
+    ins = [r for r in rows if "insert" in r[0]]
+    k1 = [r for r in rows if "batch_k1" in r[0]]
+    k2 = [r for r in rows if "batch_k2" in r[0]]
+    assert len(ins) == 1 and len(k1) == 2 and len(k2) == 4
+    for name, vgpr, agpr, sgpr, lds, scratch, wg in rows:
+        assert int(scratch) == 0 and int(agpr) == 0, (name, scratch, agpr)
+    assert int(ins[0][4]) == 0 and int(ins[0][6]) == 64                     # no LDS, single-wave workgroups
+    worst = max(al(r[1]) for r in k1) + 2 * max(al(r[1]) for r in k2) + al(ins[0][1])
+    assert worst <= 512, worst
+    # LDS granules: K1 static 256 + dynamic padded to 65 granules; K2 static 16 + its plane ring within 63
+    assert all(int(r[4]) == 256 for r in k1) and all(int(r[4]) == 16 for r in k2)

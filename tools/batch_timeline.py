@@ -105,3 +105,4 @@ d = np.diff([r["k1_last_end"] for r in per_frame]); print("K1 frame period (last
 d = np.diff([r["k2_last_end"] for r in per_frame]); print("K2 frame period mean %.2f us" % d.mean())
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump({"summary": summary, "per_frame": per_frame}, open("gpurun_out/batch_timeline.json", "w"), indent=1)
+np.savez_compressed("gpurun_out/batch_timeline_rows.npz", k1=k1, k2=k2, entry2=entry2, t0=np.array([T0]))
