@@ -11,30 +11,31 @@
 //                                  frames in order; the records are stored write-through (sc1); one arrival on ins_done[frame]
 //                                  per item
 //   stream A   k_dc_batch_k1       PERSISTENT, one 4-wave workgroup per CU: stages W / LayerNorm / theta parameters ONCE, then every
-//                                  wave walks the frames: wait ins_done[f] -> its range of cells of frame f (dc_k1_range, the body of
-//                                  the stand-alone kernel, reading the insert's records with sc1 loads and publishing S rows / counts
-//                                  / sorted records with sc1 stores) -> s_waitcnt vmcnt(0) -> one arrival on k1_done[f]
-//   stream B   k_dc_batch_k2       PERSISTENT, one 8-wave workgroup per CU: pulls (frame, tile) items off eight per-XCD cursors
-//                                  (tiles of a frame keep the XCD they have in the stand-alone kernel: halo planes stay in one L2),
-//                                  ONE relaxed poll of k1_done[frame] + ONE agent-scope acquire + barrier per item, then
-//                                  dc_k2q_body (the stand-alone kernel's body) on that tile
+//                                  wave draws (frame, range of cells) items off its XCD's cursor: dc_k1_range (the body of the
+//                                  stand-alone kernel) reading the insert's counts / records with sc1 loads and publishing S rows /
+//                                  counts / sorted records with sc1 stores; one arrival on k1_done[frame] per item
+//   stream B   k_dc_batch_k2       PERSISTENT, one 8-wave workgroup per CU: draws (frame, tile) items off its XCD's cursor (tiles of
+//                                  a frame keep the XCD they have in the stand-alone kernel: halo planes stay in one L2), ONE relaxed
+//                                  poll of k1_done[frame], then dc_k2q_body (the stand-alone kernel's body, every global read an sc1
+//                                  load) on that tile
 //
-// No workgroup ever waits on a workgroup of its OWN kernel, so no kernel needs all of its workgroups resident: insert waits on
-// nothing, K1 on insert arrivals, K2 on K1 arrivals.  What must hold is that a K1 workgroup can always be placed while K2 workgroups
-// spin (and vice versa): a CU's 160 KB of LDS take exactly one K1 (80 896 B) + one K2 workgroup (padded to 82 432 B, so that TWO
-// K2 workgroups do not fit and cannot squat a CU a K1 workgroup needs); registers: 200 + 2 x 120 of 512 per SIMD, which leaves the
-// LDS-free insert kernel (<= 64 registers) its wave.  Every spin is bounded (DC_BT_TIMEOUT_TICKS of the 100 MHz clock) and watches
-// a shared error word: a violated assumption ends the call with LINK_BATCH_TIMEOUT in link_dc_batch_status, not with a hung GPU.
+// No workgroup ever waits on a workgroup of its OWN kernel and every role draws its work off cursors, so whichever workgroups are
+// resident finish the batch: insert waits on nothing, K1 on insert arrivals, K2 on K1 arrivals; launch order = dependence order.
+// Co-residency is shaped, not required: LDS is handed out in 128 granules of 1 280 bytes per CU (tools/coresidency_probe.hip) -- K1
+// padded to 65, K2 63, so one of each fills a CU and two K1 workgroups do not fit; registers per SIMD 208 + 2 x 128 + 32 of 512
+// (tests/test_cpu_abi.py::test_batch_kernels_resource_shape reads them off the built code object); the insert has no LDS at all.
+// Every spin is bounded (DC_BT_TIMEOUT_TICKS of the 100 MHz clock) and watches a shared error word: a violated assumption ends the
+// call with LINK_BATCH_TIMEOUT in link_dc_batch_status, not with a hung GPU.
 //
 // Visibility inside the launches follows MI355X_MICROARCH.md "inter-workgroup visibility": producers store write-through (sc1)
-// and drain vmcnt before their arrival atomic; K1 reads the insert's tables with sc1 loads (no acquire per wave and frame), K2
-// runs one agent-scope acquire per item (it reads through LDS-DMA and plain loads).  The atomic counters of the insert (cnt) are
-// device-scope atomics and live at the memory side.
+// and have their stores acknowledged (vmcnt) before their arrival atomic; consumers read with sc1 loads (served by the L2, never by
+// the CU's L1) -- no buffer_wbl2 / buffer_inv on the path.  The atomic counters of the insert (cnt) are device-scope atomics and live
+// at the memory side.
 //
 // Results: bit for bit those of link_elk_core_dense_forward per frame (same device bodies, same arithmetic; the launch
-// geometry -- cells per K1 wave, z-segments of K2 -- does not enter any sum's order).  C = 64, cg = 32, cos / sin, r in {2, 3},
+// geometry -- cells per K1 item, z-segments of K2 -- does not enter any sum's order).  C = 64, cg = 32, cos / sin, r in {2, 3},
 // coord_div = 1, no alpha, fp32 rows, slot capacity <= 352: what the quad-consumer K2 serves; LINK_ERR_ARG otherwise (the caller
-// runs the frames one by one).
+// runs the frames one by one).  Measurements, dead ends and the timeline of a call: DESIGN.md section 4i.
 #define DC_IO 0
 #define DC_IO_NS dcb_f32
 #include <stdlib.h>

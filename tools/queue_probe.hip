@@ -5,6 +5,7 @@
 // created the way the case says and a small spin kernel (64 workgroups, no LDS, 200 us) is launched on each, in order.  Side by side
 // = all three start within a few us; "behind" = a start ~200 / ~400 us late.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,20 @@ int main() {
       for (int i = 0; i < 3; i++) CK(hipStreamDestroy(s[i]));
     }
     for (auto &s : app) CK(hipStreamDestroy(s));
+  }
+  // ONE stream, hipExtLaunchKernelGGL with hipExtAnyOrderLaunch (the AQL barrier bit cleared): do consecutive kernels of a stream overlap?
+  {
+    hipStream_t s1;
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    for (int rep = 0; rep < 2; rep++) {
+      CK(hipMemset(st, 0, 64 * 8));
+      CK(hipDeviceSynchronize());
+      for (int i = 0; i < 3; i++) hipExtLaunchKernelGGL(spin, dim3(64), dim3(64), 0, s1, nullptr, nullptr, 1 /* hipExtAnyOrderLaunch */, st + i, 20000);
+      CK(hipDeviceSynchronize());
+      unsigned long long h[3];
+      CK(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
+      if (rep == 1) printf("one stream, any-order launches | starts: 0, %+.1f, %+.1f us\n", ((double)h[1] - (double)h[0]) / 100.0, ((double)h[2] - (double)h[0]) / 100.0);
+    }
   }
   return 0;
 }
