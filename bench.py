@@ -405,6 +405,87 @@ def core_roofline(torch, blocks, step, iters=20):
             "stages": stages}
 
 
+def conv_roofline(torch, la, step, iters=10):
+    """Row N1 (missing 5): every sparse convolution of the network against ITS roofline.  Wraps link_amd.Conv3d.forward /
+    forward_affine with HIP events on the launch stream (`step()` runs the network once on warm kernel maps) and prices the device time of a
+    call -- all its launches: pair GEMM / table kernel + finish -- against
+        bytes = rows in (N_in * Cin * esz) + rows out (N_out * Cout * esz) + weights (K * Cin * Cout * 4) + pair list (pairs * 8)
+        flops = 2 * pairs * Cin * Cout                    (pairs = valid (output, offset) entries of the kernel map)
+    (nn/functional/conv.py:16-147, convolution_cuda.cu:53-165: gather -> GEMM per offset -> scatter moves the same rows K times; the
+    algorithmic floor moves them once).  Roofline time = max(bytes / 8 TB/s, flops / 157.3 TF/s: the exact-fp32 matrix peak of
+    MI355X_MICROARCH.md -- the fp16 hi | lo split the pair GEMM uses is three f16 products per fp32 one, priced as fp32 work).
+    Returns per distinct shape (stage voxels, Cin -> Cout, kernel, stride): calls, mean us, bytes, flops, bound, frac; and the sums."""
+    from link_amd.elk import Conv3d
+    rec = {}
+    f_plain, f_aff = Conv3d.forward, Conv3d.forward_affine
+
+    def pairs_of(m, x):
+        try:
+            if m.kernel_volume == 1:
+                return int(x.F.shape[0])
+            if m.stride[0] == 1:
+                nbr, _ = m._neighbor_table(x)
+                return int((nbr >= 0).sum().item())
+            km = m._strided_map(x) if not m.transposed else x.kmaps[(tuple(x.s[k] // m.stride[k] for k in range(3)), m.kernel_size, m.stride, m.dilation)]
+            return int((km.nbr_down >= 0).sum().item())
+        except Exception:  # noqa: BLE001
+            return -1
+
+    def wrap(f0):
+        def fwd(self, x, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_in, cin = int(x.F.shape[0]), int(x.F.shape[1])
+            e0.record()
+            y = f0(self, x, *a, **kw)
+            e1.record()
+            key = (id(self), n_in)
+            r = rec.get(key)
+            if r is None:
+                r = rec[key] = {"n_in": n_in, "n_out": int(y.F.shape[0]), "cin": cin, "cout": int(y.F.shape[1]), "kvol": int(self.kernel_volume),
+                                "stride": int(self.stride[0]), "transposed": bool(self.transposed), "esz": x.F.element_size(), "ev": [],
+                                "pairs": pairs_of(self, x), "fused_epilogue": f0 is f_aff}
+            r["ev"].append((e0, e1))
+            return y
+        return fwd
+    Conv3d.forward, Conv3d.forward_affine = wrap(f_plain), wrap(f_aff)
+    try:
+        for _ in range(2):
+            step()
+        for r in rec.values():
+            r["ev"].clear()
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        Conv3d.forward, Conv3d.forward_affine = f_plain, f_aff
+    shapes = {}
+    for r in rec.values():
+        if not r["ev"] or r["pairs"] < 0:
+            continue
+        us = 1e3 * sum(a.elapsed_time(b) for a, b in r["ev"]) / len(r["ev"])
+        k = (r["n_in"], r["n_out"], r["cin"], r["cout"], r["kvol"], r["stride"], r["transposed"])
+        s_ = shapes.setdefault(k, {"layers": 0, "us": 0.0, "pairs": r["pairs"], "esz": r["esz"]})
+        s_["layers"] += 1
+        s_["us"] += us
+    out, tot_us, tot_roof = [], 0.0, 0.0
+    for (n_in, n_out, cin, cout, kvol, stride, tr), s_ in sorted(shapes.items(), key=lambda kv: -kv[1]["us"]):
+        by = n_in * cin * s_["esz"] + n_out * cout * s_["esz"] + kvol * cin * cout * 4 + s_["pairs"] * 8
+        fl = 2.0 * s_["pairs"] * cin * cout
+        t_mem, t_mm = by / (HBM_PEAK_GBS * 1e9), fl / 157.3e12
+        us = s_["us"] / s_["layers"]
+        roof = max(t_mem, t_mm) * 1e6
+        out.append({"n_in": n_in, "n_out": n_out, "cin": cin, "cout": cout, "kernel_volume": kvol, "stride": stride, "transposed": tr,
+                    "layers": s_["layers"], "pairs": s_["pairs"], "us_per_call": round(us, 2), "alg_bytes": int(by), "flops": int(fl),
+                    "bound": "hbm" if t_mem >= t_mm else "mfma_f32", "roofline_us": round(roof, 3), "frac": round(roof / us, 4),
+                    "achieved_gbs": round(by / (us * 1e-6) / 1e9, 1), "achieved_tflops": round(fl / (us * 1e-6) / 1e12, 2)})
+        tot_us += s_["us"]
+        tot_roof += roof * s_["layers"]
+    return {"what": "every link_amd.Conv3d call of one eval forward (warm kernel maps), HIP events on the launch stream around the call: device "
+                    "time of all its launches against max(bytes / 8 TB/s, 2 * pairs * Cin * Cout / 157.3 TF/s)",
+            "sum_us": round(tot_us, 1), "sum_roofline_us": round(tot_roof, 2), "frac": round(tot_roof / tot_us, 4) if tot_us else None,
+            "shapes": out}
+
+
 def cfg3_mode(args, la, dev, rank, world, dist):
     """BASELINE.json configs[2] shape (labelled, NOT the headline): the encoder common to both segmentation models
     (stem -> 4 x [k2-s2 down, 2 residual blocks + tail || ELKBlock cos_x (2x3)^3 + tail, add/ReLU],
@@ -480,6 +561,8 @@ def cfg3_mode(args, la, dev, rank, world, dist):
     for m, f0 in zip(net.elk, saved):
         m.forward = f0
     roof = core_roofline(torch, net.elk, lambda: step(False)) if rank == 0 else None
+    net.eval()
+    conv_roof = conv_roofline(torch, la, lambda: step(False)) if rank == 0 else None
     nv = torch.tensor([float(n)], device=dev)
     if world > 1:
         dist.all_reduce(nv)
@@ -494,7 +577,7 @@ def cfg3_mode(args, la, dev, rank, world, dist):
                        "voxels": n, "stage_voxels": sizes, "blocks_s6_on_input_voxels": int(block_stats(co, 6)[1]),
                        "parallelism": f"dp{world}"},
             "fwd_bwd_ms": 1e3 * t_tr / max(3, k // 2), "elk_blocks_fwd_ms": 1e3 * elk_t[0] / 5,
-            "roofline": roof, "cpu_baseline": None}))
+            "roofline": roof, "conv_roofline": conv_roof, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -539,6 +539,10 @@ int link_subm_conv_wgrad(const float *feats, const float *gout, const int32_t *n
  * convolution backward.) */
 int link_subm_conv_wgrad_split(const float *feats, const float *gout, const int32_t *nbr_t, int64_t n, int32_t c, int32_t kvol,
                                int32_t chunks, int32_t centre_extra, float *partial, void *stream);
+/* ... and its reduction in one launch: g_w f32[kvol][c][c] = sum over chunk of slot [chunk * kvol + k] (+ the centre_extra slots for
+ * k = kvol / 2), slot order (deterministic). */
+int link_subm_conv_wgrad_reduce(const float *partial, int32_t c, int32_t kvol, int32_t chunks, int32_t centre_extra, float *gw,
+                                void *stream);
 
 /* Pair-list form of the same convolution, for sparse frames (few of the K neighbours present per voxel).
  * The kernel map is the reference's own: per kernel offset the list of (input row, output row) pairs

@@ -217,6 +217,7 @@ SIGNATURES = {
     "link_subm_conv_wgrad_chunks": (c_int32, []),
     "link_subm_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "link_subm_conv_wgrad_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "link_subm_conv_wgrad_reduce": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "link_subm_conv_ln_add_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                            c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p]),
     "link_ln_add_relu_forward": (c_int, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),

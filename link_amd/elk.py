@@ -1612,6 +1612,7 @@ def invalidate_derived_weights(model: nn.Module) -> None:
     convolution weights).  The caches are keyed on tensor versions and storage pointers, which writes through `.data`
     (EMA swaps, `param.data.copy_`) do not change: call this after such writes.  `load_state_dict` bumps versions and
     needs no call."""
+    _FLIPPED.clear()
     for m in model.modules():
         m.__dict__.pop("_link_fold", None)
         if "_kio" in m.__dict__:
@@ -1838,9 +1839,8 @@ def _conv_weight_grad(feats, g, nbr, kernel_shape):
         f = feats.detach().contiguous().float()
         L.check(lib.link_subm_conv_wgrad_split(f.data_ptr(), g.data_ptr(), nbr_t.data_ptr(), n_out, cin, kvol, chunks, extra,
                                                part.data_ptr(), _st()), "link_subm_conv_wgrad_split")
-        gw = part[: chunks * kvol].view(chunks, kvol, cin, cout).sum(0)
-        if extra:
-            gw[kvol // 2] += part[chunks * kvol:].sum(0)
+        gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=g.device)
+        L.check(lib.link_subm_conv_wgrad_reduce(part.data_ptr(), cin, kvol, chunks, extra, gw.data_ptr(), _st()), "link_subm_conv_wgrad_reduce")
         return gw
     padded = torch.cat([feats.detach().float(), feats.new_zeros(1, cin)], dim=0)
     idx = torch.where(nbr < 0, torch.full_like(nbr, feats.shape[0]), nbr).long()
@@ -1869,6 +1869,23 @@ class _GatherConv(torch.autograd.Function):
         return g_feats, g_kernel, None, None
 
 
+_FLIPPED: dict = {}           # (data_ptr, shape) -> (_version, w'[k] = w[K-1-k]^T): the input-gradient weights of _SubmConv, per optimiser step
+
+
+def _flipped_weights(kernel: torch.Tensor) -> torch.Tensor:
+    """w'[k] = w[K-1-k]^T, cached until the parameter changes (`_version` moves with every in-place optimiser update): the flip + the
+    transposing copy were two torch launches per convolution and backward call (450 + 450 per 15 cfg3 training steps)."""
+    key = (kernel.data_ptr(), tuple(kernel.shape), kernel.device)
+    hit = _FLIPPED.get(key)
+    if hit is not None and hit[0] == kernel._version:
+        return hit[1]
+    w = kernel.detach().flip(0).transpose(1, 2).contiguous()
+    if len(_FLIPPED) > 512:
+        _FLIPPED.clear()
+    _FLIPPED[key] = (kernel._version, w)
+    return w
+
+
 class _SubmConv(torch.autograd.Function):
     """Differentiable stride-1 submanifold convolution on the HIP kernel.  Input gradient: the same
     kernel on grad_out with w'[k] = w[K-1-k]^T (odd kernel, same coordinates: nbr[v,k] = u  <=>
@@ -1886,7 +1903,7 @@ class _SubmConv(torch.autograd.Function):
         g = g.contiguous().float()
         g_feats = g_kernel = None
         if ctx.needs_input_grad[0]:
-            g_feats = subm_conv(g, kernel.detach().flip(0).transpose(1, 2).contiguous(), nbr, ctx.order)
+            g_feats = subm_conv(g, _flipped_weights(kernel), nbr, ctx.order)
         if ctx.needs_input_grad[1]:
             g_kernel = _conv_weight_grad(feats, g, nbr, kernel.shape)
         return g_feats, g_kernel, None, None
