@@ -739,7 +739,7 @@ typedef struct {
   int32_t mode;        /* 0 = default (7); else bit 0 fused pre_mix+modsum, bit 1 dense-cell demod kernel, bit 2 fused
                           gather + de-modulate (C = 64; the other widths keep box sum and de-modulation as two kernels: a fused form for them
                           measured slower and was removed in round 4) -- the unfused stages are what the fused ones are tested against */
-  int32_t k1_pipe;     /* cell-range form only: software-pipelined tiles */
+  int32_t reserved0;   /* (was k1_pipe, the software-pipelined tile variant: removed in round 6 -- 35.7 against 34.2 us / frame) */
   int32_t reserved;
   uint64_t *k1_dbg;    /* bench only: device buffer u64[waves*8] for per-wave phase timings of the fused pre_mix kernel; NULL = off */
   uint64_t *k2_dbg;    /* bench only: device buffer u64[workgroups*8*8] for per-wave timings of the producer / consumer gather kernel */
@@ -806,35 +806,6 @@ int link_dc_gather_demod(const link_dc_buffers_t *buf /* host */, const link_dc_
 int link_elk_core_dense_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index,
                                 void *stream);
-/* One call = one R_core step on the SPARSE-CELL layout (round 4): the dense-cell addressing (table row, counter and slot list of a
- * block at its padded grid cell) with a sparse iteration, for frames that occupy a few percent of their block grid (LiDAR:
- * linkunet.py:345-363 call sites) -- three launches with the index rebuilt, no scan / sort / block numbering:
- *   slot insert + `occ[i]` = the cell voxel i was the first of (0 otherwise) + cell_n of the previous frame's cells (its marks
- *   occ_prev[0 .. n_prev)) back to zero  ->  fused pre_mix + LayerNorm + modulate + per-cell sums over the cells marked in each
- *   wave's range of voxel ids  ->  fused r^3 neighbour sum (a neighbour is present iff cell_n > 0) + de-modulate + LayerNorm.
- * Buffers as link_elk_core_dense_forward (cnt, cell_n zero-filled once; S, slots need no initialisation beyond row 0 of S being
- * zero; A, sid, vrec unused) plus two i32[n_cap] mark arrays the caller alternates between steps: `occ` is written (read when
- * build_index = 0), `occ_prev` / `n_prev` are the marks and voxel count of the previous indexed step on these buffers (n_prev = 0
- * on the first).  C in {16, 32, 64}, r in {2, 3}, slot capacity g->k <= 64 (a cell is one wave's serial work; frames with
- * bigger blocks belong on section C's tile form).  Replaces utils.py:44-84 + query_cuda.cu:9-58 on such frames. */
-int link_elk_core_sparse_forward(const link_dc_buffers_t *buf /* host */, const link_dc_grid_t *g /* host */,
-                                 const link_elk_desc_t *desc /* host */, int64_t n, int32_t build_index, int32_t *occ,
-                                 const int32_t *occ_prev, int64_t n_prev, void *stream);
-/* One STEP of the three-frame pipeline on the dense-cell layout (round 4, csrc/dense_step3_impl.h): ONE launch whose grid is three
- * ranges of workgroups -- the gather + de-modulate kernel of the frame in `b_k2`, the fused pre_mix kernel (matrix-core sums form)
- * of the frame in `b_k1`, the slot insert of the frame in `b_insert` -- each range running the same device code as the stand-alone
- * kernel of its stage.  A frame passes through three consecutive steps on its own buffers (insert, K1, K2); the three frames of a
- * step are independent, so the stages overlap by construction instead of by what the hardware queues of separate streams happen
- * to interleave.  Steady state: one frame completes per launch.  A null frame is an absent stage (pipeline fill / drain).
- * All frames: the same grid, descriptor, parameters and io_dtype; C = 64, cg = 32 (two-part rows whose channels j and j + 32 share
- * theta), op cos / sin, r in {2, 3}, coord_div = 1, no alpha, slot capacity <= 352 -- LINK_ERR_ARG otherwise (the caller runs
- * link_elk_core_dense_forward per frame).  buf->tune of each frame: k1_wgs (x 4 waves; 0 = 512) and k2_zsplit (0 = enough segments
- * for ~256 workgroups: the other half of the chip's workgroup slots is K1's).  insert_wgs: 512-thread workgroups of the insert
- * range, 0 = one per 2048 voxels.  Results are those of link_elk_core_dense_forward with tune.k1_form = 2 and the same k1_wgs / k2_zsplit, bit for bit. */
-int link_elk_core_dense_step3(const link_dc_buffers_t *b_insert /* host */, int64_t n_insert,
-                              const link_dc_buffers_t *b_k1 /* host */, int64_t n_k1,
-                              const link_dc_buffers_t *b_k2 /* host */, int64_t n_k2, const link_dc_grid_t *g /* host */,
-                              const link_elk_desc_t *desc /* host */, int32_t insert_wgs, void *stream);
 /* The slot insert of a step (the form buf->tune picks) that also reports the frame's occupancy on this grid: stats
  * i32[16][16] (device, zeroed by the caller): 16 partial slots on separate cache lines, [k][0] += voxels inside the grid,
  * [k][1] += occupied cells, [k][2] max= fullest cell's count -- the reader sums / sums / maxes over k.  For the

@@ -9,7 +9,7 @@ CPU or eager-PyTorch fallback.
 from . import _lib, backend, functional
 from .aggregate import (aux_to_voxel, large_to_small, link_index_of, small_to_large_v2, upsample_voxel,
                         voxel_to_aux)
-from .elk import (Conv3d, ELKBlock, ElkCoreBatch, ElkCorePipeline, ElkCorePlan, SparseConvTensor, TSELKBlock, elk_core_autograd, elk_core_fused,
+from .elk import (Conv3d, ELKBlock, ElkCoreBatch, ElkCorePlan, SparseConvTensor, TSELKBlock, elk_core_autograd, elk_core_fused,
                   invalidate_derived_weights, spconv2ts, ts2spconv)
 from .detstage import ELKv3Stage, SparseBasicBlock, SparseConv3d, SpMiddleResNetFHDELKv3, SubMConv3d, to_dense
 from .functional import calc_ti_weights, spcount, spdevoxelize, sphash, sphashquery, spvoxelize

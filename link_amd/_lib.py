@@ -72,7 +72,7 @@ class LinkDcGrid(Structure):
 class LinkDcTuning(Structure):
     """link_dc_tuning_t: launch geometry / kernel selection of ONE plan (all zero = defaults)"""
     _fields_ = [(k, c_int32) for k in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode",
-                                       "k1_pipe", "reserved")] + [("k1_dbg", c_void_p), ("k2_dbg", c_void_p)]
+                                       "reserved0", "reserved")] + [("k1_dbg", c_void_p), ("k2_dbg", c_void_p)]
 
 
 class LinkDcBuffers(Structure):
@@ -234,13 +234,8 @@ SIGNATURES = {
     "link_dc_gather": (c_int, [c_void_p, c_void_p, POINTER(LinkElkDesc), POINTER(LinkDcGrid), c_void_p, c_void_p]),
     "link_elk_core_dense_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
                                             c_int64, c_int32, c_void_p]),
-    "link_elk_core_sparse_forward": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), POINTER(LinkElkDesc),
-                                             c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "link_elk_core_lean_forward": (c_int, [POINTER(LinkLeanBuffers), POINTER(LinkGrid), POINTER(LinkElkDesc), c_int64, c_int64,
                                            c_int32, c_void_p]),
-    "link_elk_core_dense_step3": (c_int, [POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcBuffers), c_int64,
-                                          POINTER(LinkDcBuffers), c_int64, POINTER(LinkDcGrid), POINTER(LinkElkDesc),
-                                          c_int32, c_void_p]),
     "link_dc_index_probe": (c_int, [POINTER(LinkDcBuffers), POINTER(LinkDcGrid), c_int64, c_void_p, c_void_p]),
     "link_dc_index_ids": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),
     "link_dc_index": (c_int, [c_void_p, c_int64, POINTER(LinkDcGrid)] + [c_void_p] * 5),

@@ -984,34 +984,44 @@ extern "C" int link_subm_conv_wgrad_split(const float *feats, const float *gout,
 }
 
 // g_w from the partial slots of link_subm_conv_wgrad_split in ONE launch (round 6): g_w[k] = sum over chunk of slot [chunk * kvol + k]
-// (+, for k = kvol / 2, the centre_extra slots behind them), in slot order -- deterministic.  Was three torch launches per convolution
+// (+, for k = kvol / 2, the centre_extra slots behind them), in a fixed association -- deterministic.  Was three torch launches per convolution
 // and backward call (two reductions and an add: 885 + 885 of the ~900 launches of a cfg3 training step were these).
 __global__ void __launch_bounds__(256) k_subm_wgrad_reduce(const float *__restrict__ part, int kvol, int chunks, int extra, int cc,
                                                            float *__restrict__ gw) {
-  const int e = (int)(blockIdx.x * 256 + threadIdx.x);          // one float4 of one offset's c x c matrix
+  // eight adjacent lanes share one float4 of one offset's c x c matrix: lane `sub` adds slots sub, sub + 8, ... (the centre offset's
+  // extra slots behind its chunk slots), then a fixed xor tree over the eight -- the same association in every run.  (One thread per
+  // float4 walking all slots -- up to 64 + 192 of them for the centre of a big layer -- took 20 us per call, 59 at worst.)
+  const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int o = e >> 3, sub = e & 7;
   const int per = cc >> 2;
-  if (e >= kvol * per) return;
-  const int k = e / per, q = e - k * per;
+  const bool live = o < kvol * per;
+  const int k = live ? o / per : 0, q = live ? o - k * per : 0;
+  const int nslot = chunks + ((extra > 0 && k == kvol / 2) ? extra : 0);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int ch = 0; ch < chunks; ch++) {
-    const float4 v = *reinterpret_cast<const float4 *>(&part[((int64_t)ch * kvol + k) * cc + 4 * q]);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  }
-  if (extra > 0 && k == kvol / 2) {
-    float4 ex = make_float4(0.f, 0.f, 0.f, 0.f);                // (own sum first, then added: the order of the torch composition it replaces)
-    for (int x = 0; x < extra; x++) {
-      const float4 v = *reinterpret_cast<const float4 *>(&part[((int64_t)chunks * kvol + x) * cc + 4 * q]);
-      ex.x += v.x; ex.y += v.y; ex.z += v.z; ex.w += v.w;
+  for (int s0 = sub; s0 < nslot; s0 += 32) {            // four slots of this lane in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int sl = s0 + 8 * u;
+      sl = sl < nslot ? sl : nslot - 1;
+      const int64_t row = sl < chunks ? (int64_t)sl * kvol + k : (int64_t)chunks * kvol + (sl - chunks);
+      v[u] = *reinterpret_cast<const float4 *>(&part[row * cc + 4 * q]);
     }
-    acc.x += ex.x; acc.y += ex.y; acc.z += ex.z; acc.w += ex.w;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (s0 + 8 * u < nslot) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
-  *reinterpret_cast<float4 *>(&gw[(int64_t)k * cc + 4 * q]) = acc;
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    acc.x += __shfl_xor(acc.x, m, 64); acc.y += __shfl_xor(acc.y, m, 64); acc.z += __shfl_xor(acc.z, m, 64); acc.w += __shfl_xor(acc.w, m, 64);
+  }
+  if (live && sub == 0) *reinterpret_cast<float4 *>(&gw[(int64_t)k * cc + 4 * q]) = acc;
 }
 extern "C" int link_subm_conv_wgrad_reduce(const float *partial, int32_t c, int32_t kvol, int32_t chunks, int32_t centre_extra, float *gw,
                                            void *stream) {
   if (!partial || !gw || c <= 0 || c > 64 || (c & 3) != 0 || kvol <= 0 || chunks < 1 || chunks > 1024 || centre_extra < 0 || centre_extra > 4096)
     return LINK_ERR_ARG;
-  const int cc = c * c, total = kvol * (cc >> 2);
+  const int cc = c * c, total = kvol * (cc >> 2) * 8;
   hipLaunchKernelGGL(k_subm_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), partial, (int)kvol, (int)chunks,
                      (int)centre_extra, cc, gw);
   return check_launch("link_subm_conv_wgrad_reduce");

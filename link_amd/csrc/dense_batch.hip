@@ -245,14 +245,14 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, DC_K1_WAVES) k_dc_batch_k1(dc_b
     const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
     int pc_f, nv_f;
     int4 rf0, rf1, rf2, rf3;
-    if (f <= ins_known) dc_k1_prefetch<false, true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, nullptr, c_begin, c_end, lane);
+    if (f <= ins_known) dc_k1_prefetch<true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, c_begin, c_end, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... which the range needs at once; everything older has retired too
     if (pend_f >= 0 && lane == 0) __hip_atomic_fetch_add(&sync[bt_k1(pend_f)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_f = f;
     if (f > ins_known) {                               // not known in advance (first frame, or the insert is only just ahead)
       if (__builtin_amdgcn_readfirstlane(ins_a) < wpf && !bt_wait_ge(sync, bt_ins(f), wpf)) return;
       ins_known = f;
-      dc_k1_prefetch<false, true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, nullptr, c_begin, c_end, lane);
+      dc_k1_prefetch<true>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, F.slots, F.cnt, c_begin, c_end, lane);
     }
     if (f + 1 < nframes && f + 1 > ins_known && __builtin_amdgcn_readfirstlane(ins_b) >= wpf) ins_known = f + 1;
     if (i == 0 && lane == 0) {                         // publish the frame's status word (collected by the insert's atomics)
@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, DC_K1_WAVES) k_dc_batch_k1(dc_b
       __hip_atomic_store(&F.hdr[LINK_HDR_STATUS_ACC], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const unsigned long long tp1 = DC_BT_PROF ? __builtin_amdgcn_s_memrealtime() : 0;
-    dc_k1_range<C, OP, NB, false, false, true>(smem_raw, F.feats, F.slots, F.cnt, F.cell_n, p.w_pre, 1.0f, p.eps, F.n, g, false, F.S, nullptr,
-                                               nullptr, nullptr, c_begin, c_end, pc_f, nv_f, rf0, rf1, rf2, rf3, w_big, th_slow, i, 0, 0);
+    dc_k1_range<C, OP, NB, false, true>(smem_raw, F.feats, F.slots, F.cnt, F.cell_n, p.w_pre, 1.0f, p.eps, F.n, g, false, F.S, nullptr,
+                                        nullptr, c_begin, c_end, pc_f, nv_f, rf0, rf1, rf2, rf3, w_big, th_slow, i, 0, 0);
     if (DC_BT_PROF && lane == 0) bt_row(p.dbg1, (unsigned long long)f * nranges + i, (unsigned long long)f, (unsigned long long)i, tp0, tp1, __builtin_amdgcn_s_memrealtime(), (unsigned long long)(blockIdx.x * 4 + (tid >> 6)));
   }
   // the last item's arrival: every table K2 reads was stored write-through, so once the stores are acknowledged they are in memory

@@ -39,53 +39,12 @@ static int launch_k1p(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
   return check_launch("link_dc_premix_modsum");
 }
 
-// sparse-cell layout: voxel ids per wave (the cells those voxels were first in).  Small frames want many light waves (the
-// general layout's tile form runs ONE 16-voxel tile per wave below 32 k voxels for the same reason: a wave is a chain of
-// dependent round trips, and 47 waves of 64 voxels took 36 us on a 3 k-voxel frame); tune.k1_wgs > 0 overrides (sweeps)
-static inline int dc_sparse_ids_per_wave(const link_dc_buffers_t *b, int64_t n) {
-  if (b->tune.k1_wgs > 0 && b->tune.k1_wgs <= 64) return b->tune.k1_wgs;
-  return n <= 32768 ? 8 : 16;                          // measured on the S-kitti stage frames (tools/lidar_core.py, IPW sweep)
-}
-// sparse-cell layout: the fused pre_mix kernel over ranges of voxel ids
-template <int C, int OP, int NB>
-static int launch_k1_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                            bool warm, const int32_t *occ, hipStream_t st) {
-  using K = dc_k1_cfg<C, OP>;
-  const int cpw = dc_sparse_ids_per_wave(b, n);
-  const int64_t wgs = (n + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
-  if (K::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum<C, OP, NB, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum<C, OP, NB, false, true>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st,
-                     b->feats, reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b,
-                     b->w_pos, b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
-                     reinterpret_cast<unsigned long long *>(b->tune.k1_dbg), occ);
-  return check_launch("link_dc_premix_modsum(sparse)");
-}
-template <int C, int OP>
-static int dispatch_k1s_nb(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                           bool warm, const int32_t *occ, hipStream_t st) {
-  constexpr int T = C / 16;
-  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
-  if (nb > T) nb = T;
-  if (T >= 2 && nb == T / 2) return launch_k1_sparse<C, OP, (T >= 2 ? T / 2 : 1)>(b, g, d, n, warm, occ, st);
-  if (T >= 4 && nb == T / 4) return launch_k1_sparse<C, OP, (T >= 4 ? T / 4 : 1)>(b, g, d, n, warm, occ, st);
-  return launch_k1_sparse<C, OP, T>(b, g, d, n, warm, occ, st);
-}
-template <int C>
-static int dispatch_k1s_op(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                           bool warm, const int32_t *occ, hipStream_t st) {
-  switch (d.op) {
-    case LINK_OP_COS: return dispatch_k1s_nb<C, LINK_OP_COS>(b, g, d, n, warm, occ, st);
-    case LINK_OP_SIN: return dispatch_k1s_nb<C, LINK_OP_SIN>(b, g, d, n, warm, occ, st);
-    default: return dispatch_k1s_nb<C, LINK_OP_COSX>(b, g, d, n, warm, occ, st);
-  }
-}
-
 template <int C, int OP, int NB>
 static int launch_k1(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                      bool warm, hipStream_t st) {
-  return b->tune.k1_pipe ? launch_k1p<C, OP, NB, true>(b, g, d, n, warm, st) : launch_k1p<C, OP, NB, false>(b, g, d, n, warm, st);
+  // (the software-pipelined tile variant -- PIPE, 253 registers -- was re-measured in round 6 in the timed geometry, where its 256
+  // registers do fit beside two gather waves: 35.7 against 34.2 us / frame; instantiations removed, docs/experiments.md section 6)
+  return launch_k1p<C, OP, NB, false>(b, g, d, n, warm, st);
 }
 
 template <int C, int OP>
@@ -1000,8 +959,6 @@ static int launch_k2(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
   return check_launch("link_dc_gather_demod");
 }
 
-#include "dense_gather_sparse_impl.h"
-
 int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
                       bool warm, hipStream_t st) {
   if (b->tune.k1_form == 2) {                          // matrix-core sums form (dense_fused_mm_impl.h): C = 32 / 64
@@ -1012,20 +969,6 @@ int run_premix_modsum(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
     case 16: return dispatch_k1_op<16>(b, g, d, n, warm, st);
     case 32: return dispatch_k1_op<32>(b, g, d, n, warm, st);
     default: return dispatch_k1_op<64>(b, g, d, n, warm, st);
-  }
-}
-
-int run_premix_modsum_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n,
-                             bool warm, const int32_t *occ, hipStream_t st) {
-  if (b->tune.k1_form == 2 && d.op != LINK_OP_COSX) {  // matrix-core sums form on request (measured slower here: 78 against 50 us on
-                                                       // S-kitti stage 1; its cos_x instantiation spills): the cell-range form is the default
-    if (d.c == 64) return dispatch_k1ms<64>(b, g, d, n, warm, occ, st);
-    if (d.c == 32) return dispatch_k1ms<32>(b, g, d, n, warm, occ, st);
-  }
-  switch (d.c) {
-    case 16: return dispatch_k1s_op<16>(b, g, d, n, warm, occ, st);
-    case 32: return dispatch_k1s_op<32>(b, g, d, n, warm, occ, st);
-    default: return dispatch_k1s_op<64>(b, g, d, n, warm, occ, st);
   }
 }
 
@@ -1056,7 +999,5 @@ int run_gather_demod(const link_dc_buffers_t *b, const link_dc_grid_t &g, const 
     default: return launch_k2<LINK_OP_COSX, 2>(b, g, d, n, st);
   }
 }
-
-#include "dense_step3_impl.h"
 
 }  // namespace DC_IO_NS

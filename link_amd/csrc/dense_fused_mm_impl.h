@@ -87,14 +87,14 @@ __device__ __forceinline__ void dc_row16_sum4(float &a, float &b, float &c, floa
 #endif
 }
 
-template <int C, int OP, bool SPARSE = false>
+template <int C, int OP>
 struct dc_k1m_cfg {
   static_assert(C % 32 == 0, "K blocks of 32 input channels");
   static constexpr int T = C / 16;                     // 16-channel output blocks
   static constexpr int KB = C / 32;                    // K blocks of the f16 matrix instruction
   static constexpr int P = op_parts<OP>::value;
   static constexpr int RB = P * C * 4;                 // bytes of one S row
-  static constexpr int LCAP = SPARSE ? DC_SP_LCAP : DC_K1M_LCAP;   // sparse-cell layout: small chunks, many light waves
+  static constexpr int LCAP = DC_K1M_LCAP;
   static constexpr int PLANE = C * 16;                 // one W plane: C rows (co) x 8 halves
   static constexpr int WIMG_BYTES = KB * 2 * 4 * PLANE;   // [kb][hi | lo][g]
   // per-channel parameter tables, transposed so that a lane (channel l16 of every block) takes ONE 16-byte read per table:
@@ -105,24 +105,21 @@ struct dc_k1m_cfg {
   static constexpr int ORD_OFF = LCAP * 16;            // u8: ordinal (among the chunk's occupied cells) of every entry's cell
   static constexpr int PCS_OFF = ORD_OFF + ((LCAP + 15) / 16) * 16;   // i32[64 + 16]: padded cell id by ordinal
   static constexpr int CARRY_OFF = PCS_OFF + 80 * 4;   // P * C floats: partial sums of a cell that spans tiles
-  static constexpr int SP_OFF = CARRY_OFF + P * C * 4; // sparse-cell layout: cell | segment of every list position, id scratch (3 x LCAP ints)
-  static constexpr int WAVE_BYTES = SP_OFF + (SPARSE ? 3 * LCAP * 4 : 0);
+  static constexpr int WAVE_BYTES = CARRY_OFF + P * C * 4;
   static constexpr int NW = DC_K1M_NW;
   static constexpr int LDS_BYTES = W_BYTES + NW * WAVE_BYTES;
 };
 
-// SPARSE: the sparse-cell layout (dense_gather_sparse_impl.h) -- the wave's cells are those marked in `occ` over its range of
-// voxel ids, their records come by the cooperative fetch of dc_sparse_fetch; everything after the cell section is the same.
-// The kernel body is a device function of the workgroup number `bid`: k_dc_premix_modsum_mm runs it over its own grid, the
-// three-stage step kernel (dense_step3_impl.h) over one range of a grid it shares with the other two stages.
-template <int C, int OP, int NB, bool SPARSE = false>
+// The kernel body is a device function of the workgroup number `bid` (the three-stage step kernel of round 4 ran it over a range
+// of a shared grid; removed in round 6 -- the batch entry point of dense_batch.hip supersedes it).
+template <int C, int OP, int NB>
 __device__ __forceinline__ void dc_k1m_body(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
     const float *__restrict__ w_pre, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg, float coord_div, float eps, int64_t n,
     const link_dc_grid_t &g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
-    unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks, const int bid) {
-  using K = dc_k1m_cfg<C, OP, SPARSE>;
+    unsigned long long *__restrict__ dbg, const int bid) {
+  using K = dc_k1m_cfg<C, OP>;
   constexpr int T = K::T, KB = K::KB, P = K::P, RB = K::RB;
   DC_PROF_PTR(dbg);
   unsigned long long tq0 = dbg ? __builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq_cell = 0, tq_mm = 0, tq_ln = 0, tq_sum = 0;
@@ -136,14 +133,13 @@ __device__ __forceinline__ void dc_k1m_body(
   int *pcs = reinterpret_cast<int *>(wbase + K::PCS_OFF);
   float *carry = reinterpret_cast<float *>(wbase + K::CARRY_OFF);
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
-  const int Vi = SPARSE ? (int)n : Dx * Dy * Dz * g.dim[3];
+  const int Vi = Dx * Dy * Dz * g.dim[3];
   const int wid = bid * K::NW + wave;
   const int c_begin = wid * cpw;
   const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   const uint32_t *__restrict__ csrc = warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt;
   auto cell_of = [&](int chunk, int nrem) {
     const int q = chunk + (lane < nrem ? lane : 0);
-    if constexpr (SPARSE) return lane < nrem ? (int)occ_marks[q] : 0;   // 0: not the first voxel of a cell -- an idle lane
     const int z = q % Dz;
     int t = q / Dz;
     const int y = t % Dy;
@@ -156,10 +152,8 @@ __device__ __forceinline__ void dc_k1m_body(
   int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
   auto request_chunk = [&](int chunk) {
     pc = cell_of(chunk, (c_end - chunk < 64) ? c_end - chunk : 64);
-    if constexpr (!SPARSE) {
-      r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
-      r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
-    }
+    r0 = slots[(int64_t)pc * DC_INL + 0]; r1 = slots[(int64_t)pc * DC_INL + 1];
+    r2 = slots[(int64_t)pc * DC_INL + 2]; r3 = slots[(int64_t)pc * DC_INL + 3];
     nv = (int)csrc[pc];
   };
   if (c_begin < c_end) request_chunk(c_begin);
@@ -249,15 +243,7 @@ __device__ __forceinline__ void dc_k1m_body(
     // ordinal of this cell among the chunk's occupied cells: the column (mod 16) its sums take in the tiles' second product
     const unsigned long long occ = __ballot(mine && nv > 0);
     const int ord = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(occ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)occ, 0u));
-    if constexpr (SPARSE) {
-      int *scell = reinterpret_cast<int *>(wbase + K::SP_OFF), *sseg = scell + K::LCAP, *tmp_id = sseg + K::LCAP;
-      if (mine) {
-        for (int k = 0; k < nv; k++) ordof[excl + k] = (unsigned char)ord;
-        if (nv > 0) pcs[ord] = pc;
-      }
-      if (warm) dc_sparse_fetch<false>(g, r_slots, lane, mine, pc, nv, excl, Ttot, list, scell, sseg, tmp_id);
-      else dc_sparse_fetch<true>(g, r_slots, lane, mine, pc, nv, excl, Ttot, list, scell, sseg, tmp_id);
-    } else if (mine) {
+    if (mine) {
       // order the inline records by voxel id: keys id*4+slot through a 5-exchange network
       int k0 = nv > 0 ? r0.w * 4 + 0 : INT_MAX, k1 = nv > 1 ? r1.w * 4 + 1 : INT_MAX;
       int k2 = nv > 2 ? r2.w * 4 + 2 : INT_MAX, k3 = nv > 3 ? r3.w * 4 + 3 : INT_MAX;
@@ -297,15 +283,13 @@ __device__ __forceinline__ void dc_k1m_body(
       if (nv > 0) pcs[ord] = pc;
     }
     {                                                   // publish the counts, reset the counters
-      const uint32_t coff = (mine && !warm && (!SPARSE || pc != 0)) ? (uint32_t)pc * 4u : DC_OOB;
+      const uint32_t coff = (mine && !warm) ? (uint32_t)pc * 4u : DC_OOB;
       st4i(r_n, coff, nv);
       st4i(r_cnt, coff, 0);
     }
-    if constexpr (!SPARSE) {
-      for (unsigned long long em = __ballot(mine && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
-        const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
-        st16(r_S, ract ? (uint32_t)pcj * (uint32_t)RB + (uint32_t)lane * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
-      }
+    for (unsigned long long em = __ballot(mine && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
+      const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
+      st16(r_S, ract ? (uint32_t)pcj * (uint32_t)RB + (uint32_t)lane * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __builtin_amdgcn_wave_barrier();
     if (dbg) { const unsigned long long tqb = __builtin_amdgcn_s_memtime(); tq_cell += tqb - tqa; tqa = tqb; }
@@ -621,15 +605,15 @@ __device__ __forceinline__ void dc_k1m_body(
   }
 }
 
-template <int C, int OP, int NB, bool SPARSE = false>
+template <int C, int OP, int NB>
 __global__ void __launch_bounds__(64 * DC_K1M_NW, DC_K1M_WAVES) k_dc_premix_modsum_mm(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
     const float *__restrict__ w_pre, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
     const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg, float coord_div, float eps, int64_t n,
     link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_, float *__restrict__ fin, int32_t *__restrict__ hdr,
-    unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ_marks = nullptr) {
-  dc_k1m_body<C, OP, NB, SPARSE>(feats, slots, cnt, cell_n, w_pre, ln_w, ln_b, w_pos, alpha, cg, coord_div, eps, n, g, cpw, warm,
-                                 S_, fin, hdr, dbg, occ_marks, (int)blockIdx.x);
+    unsigned long long *__restrict__ dbg) {
+  dc_k1m_body<C, OP, NB>(feats, slots, cnt, cell_n, w_pre, ln_w, ln_b, w_pos, alpha, cg, coord_div, eps, n, g, cpw, warm,
+                         S_, fin, hdr, dbg, (int)blockIdx.x);
 }
 
 template <int C, int OP, int NB>
@@ -653,42 +637,6 @@ static int launch_k1m(const link_dc_buffers_t *b, const link_dc_grid_t &g, const
                      b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
                      reinterpret_cast<unsigned long long *>(b->tune.k1_dbg));
   return check_launch("link_dc_premix_modsum");
-}
-
-// sparse-cell layout: ranges of voxel ids (dc_sparse_ids_per_wave), cells from the first-voxel marks
-template <int C, int OP, int NB>
-static int launch_k1m_sparse(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n, bool warm,
-                             const int32_t *occ, hipStream_t st) {
-  using K = dc_k1m_cfg<C, OP, true>;
-  const int cpw = dc_sparse_ids_per_wave(b, n);
-  const int64_t wgs = (n + (int64_t)cpw * K::NW - 1) / ((int64_t)cpw * K::NW);
-  if (K::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dc_premix_modsum_mm<C, OP, NB, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-  hipLaunchKernelGGL((k_dc_premix_modsum_mm<C, OP, NB, true>), dim3((unsigned)wgs), dim3(64 * K::NW), K::LDS_BYTES, st, b->feats,
-                     reinterpret_cast<int4 *>(b->slots), b->cnt, b->cell_n, b->w_pre, b->pre_ln_w, b->pre_ln_b, b->w_pos,
-                     b->alpha, d.cg, d.coord_div, d.eps, n, g, cpw, warm, b->S, b->fin, b->hdr,
-                     reinterpret_cast<unsigned long long *>(b->tune.k1_dbg), occ);
-  return check_launch("link_dc_premix_modsum(sparse, mm)");
-}
-template <int C>
-static int dispatch_k1ms(const link_dc_buffers_t *b, const link_dc_grid_t &g, const link_elk_desc_t &d, int64_t n, bool warm,
-                         const int32_t *occ, hipStream_t st) {
-  constexpr int T = C / 16;
-  int nb = (d.cg % 16 == 0) ? d.cg / 16 : T;
-  if (nb > T) nb = T;
-#define LINK_K1MS(OPV)                                                                                         \
-  do {                                                                                                         \
-    if (T >= 2 && nb == T / 2) return launch_k1m_sparse<C, OPV, (T >= 2 ? T / 2 : 1)>(b, g, d, n, warm, occ, st); \
-    if (T >= 4 && nb == T / 4) return launch_k1m_sparse<C, OPV, (T >= 4 ? T / 4 : 1)>(b, g, d, n, warm, occ, st); \
-    return launch_k1m_sparse<C, OPV, T>(b, g, d, n, warm, occ, st);                                            \
-  } while (0)
-  switch (d.op) {
-    case LINK_OP_COS: LINK_K1MS(LINK_OP_COS);
-    case LINK_OP_SIN: LINK_K1MS(LINK_OP_SIN);
-    default: LINK_K1MS(LINK_OP_COSX);
-  }
-#undef LINK_K1MS
 }
 
 template <int C, int OP>

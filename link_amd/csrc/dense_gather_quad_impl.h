@@ -23,15 +23,6 @@
                           (x 2: 54.4 -> 47.9 MB from the memory side) on cfg2, same time */
 #endif
 
-#ifndef DC_K2_SKIP
-#define DC_K2_SKIP 0     /* 1: rows of empty cells (a quarter of cfg2's padded grid) are not fetched -- the plane DMA of such a row
-                          becomes an out-of-range buffer load, which writes zeros to LDS without touching memory; the counts
-                          run two planes ahead of the rows for that.  Correct (tests pass either way) and ~12 MB less traffic
-                          per frame, but the kernel is not bandwidth-bound: the producers' count look-up before every plane
-                          request costs more than the bytes save (same box, cfg2: 27.6 against 26.3 us; 38.2 against 37.1 us
-                          per frame with three frames in flight).  Off. */
-#endif
-
 #ifndef DC_K2Q_CW
 #define DC_K2Q_CW 3      /* consumer waves: 16 voxel slots each.  A cfg2 plane holds ~32 voxels (Poisson: more than 48 in 0.3 % of the
                             planes), so three waves still finish a plane in ONE round and the fourth only issued instructions for empty
@@ -54,12 +45,6 @@
 #ifndef DC_K2Q_RIM
 #define DC_K2Q_RIM 1
 #endif
-#ifndef DC_K2_PRIO_ALL
-#define DC_K2_PRIO_ALL 0
-#endif
-#ifndef DC_K2_PRIO_PROD
-#define DC_K2_PRIO_PROD 0
-#endif
 #ifndef DC_K2Q_FMA
 #define DC_K2Q_FMA 1     /* de-modulation A0 cos + A1 sin as mul + fma (0: separate IEEE mul / mul / add like the reference's eager
                             ops -- the difference is one rounding, 6e-8 relative, next to the hardware trig's 4e-7) */
@@ -77,7 +62,6 @@ struct dc_k2q_cfg {
   static constexpr int MAP_BYTES = 64 * 4 + 16;
   static constexpr int LDS_BYTES = MAP_OFF + (DC_K2Q_PMAP ? 3 * MAP_BYTES : 0);
   static constexpr int THREADS = 256 + 64 * (DC_K2Q_CW + (DC_K2Q_PMAP ? 1 : 0));     // producers + consumers (+ the mapper wave)
-  static_assert(!DC_K2_SKIP || K2::G::NCOL <= 64, "one count image = one wave's 64 entries");
   static constexpr bool FITS = K2::P == 2 && 2 * LDS_BYTES <= 160 * 1024;
 };
 
@@ -172,9 +156,6 @@ __device__ __forceinline__ void dc_k2q_body(
   using K2 = dc_k2_cfg<OP, R>;
   using KQ = dc_k2q_cfg<OP, R>;
   DC_PROF_PTR(dbg);
-#if DC_K2_PRIO_ALL
-  __builtin_amdgcn_s_setprio(DC_K2_PRIO_ALL);           // A/B (round 5): wave priority of the whole gather kernel against co-resident kernels
-#endif
   // optional per-wave timing (tools/k2prof.py): s_memtime ticks waiting for the plane DMA, in the barrier, in the box sums /
   // the quad round
   unsigned long long tq0 = dbg ? DC_NOW() : 0, tq_dma = 0, tq_bar = 0, tq_work = 0;
@@ -220,9 +201,6 @@ __device__ __forceinline__ void dc_k2q_body(
     par[tidx] = tidx < 64 ? ln_w[tidx] : ln_b[tidx - 64];
   }
   if (producer) {
-#if DC_K2_PRIO_PROD
-    __builtin_amdgcn_s_setprio(DC_K2_PRIO_PROD);        // A/B (round 5): the producers' chain is the plane step's critical path
-#endif
     // ================= producers: plane ring (LDS-DMA, 3 slots, prefetch distance 2) + box sums -> A rows =================
     auto col_cell0 = [&](int hx, int hy) {           // padded cell id of (haloed column, z = 0), clamped into the grid
       int px = x0 + 1 - HLO + hx, py = y0 + 1 - HLO + hy;
@@ -241,7 +219,7 @@ __device__ __forceinline__ void dc_k2q_body(
     }
     uint32_t cnt_cell0;
     {
-      int e = DC_K2_SKIP ? lane : wave * 64 + lane;      // skip form: every wave requests the same image (same data, same place)
+      int e = wave * 64 + lane;
       if (e >= K::NCOL) e = K::NCOL - 1;
       cnt_cell0 = col_cell0(e / HY, e % HY);
     }
@@ -249,16 +227,15 @@ __device__ __forceinline__ void dc_k2q_body(
     // (ring slots are carried as rotating counters `pm3` = plane % 3: a modulo by 3 is a multiply-high + shift + multiply + subtract
     // on the scalar unit, five of them per plane step and wave)
     auto cnt_slot = [&](int plane, int pm3) -> uint32_t {     // LDS byte offset of the count image of `plane`
-      if (!DC_K2_SKIP) return (uint32_t)(pm3 * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
-      const int sl = plane % 5;
-      return (uint32_t)((sl % 3) * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE + (sl / 3) * 256);
+      (void)plane;
+      return (uint32_t)(pm3 * K2::SPLIT_BUF_BYTES + K2::SPLIT_PLANE);
     };
     auto issue_cnt = [&](int plane, int pm3) {
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
       const int32_t *csrc = cell_n + cnt_cell0 + pz;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)csrc,
-                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane, pm3) + (DC_K2_SKIP ? 0 : wave * 256)), 4, 0, COH ? 16 : 0);
+                                       (__attribute__((address_space(3))) void *)(lds + cnt_slot(plane, pm3) + wave * 256), 4, 0, COH ? 16 : 0);
     };
     uint32_t rec_cell0;                                // inline slot records of the 16 interior cells of an output plane
     int rec_k;
@@ -269,34 +246,19 @@ __device__ __forceinline__ void dc_k2q_body(
       rec_cell0 = col_cell0(col / TY + HLO, col % TY + HLO);
     }
     const char *Sb = reinterpret_cast<const char *>(S_);
-    auto issue = [&](int plane, int pm3, bool known) {   // known: the plane's count image is in LDS (every plane but the first two)
+    auto issue = [&](int plane, int pm3, bool) {
       int pz = pz0 + plane;
       pz = pz < PDz - 1 ? pz : PDz - 1;
       char *buf = lds + pm3 * K2::SPLIT_BUF_BYTES;
-      if (DC_K2_SKIP && known) {
-        const uint32_t cb = lds_base + cnt_slot(plane, pm3);
-        int cn[K::PASSES];
-        lds_rd_counts<K::PASSES>(cb, cnt_off, cn);
 #pragma unroll
-        for (int i = 0; i < K::PASSES; i++) {
-          const bool surplus = (i * 256 + wave * 64) >= K::NPC;          // wave-uniform: repeat pass 0 (same data, same place)
-          const int ii = surplus ? 0 : i;
-          const uint32_t off = (surplus ? src_off[0] : src_off[i]) + (uint32_t)pz * (uint32_t)RB;
-          const int c_ = surplus ? cn[0] : cn[i];
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_S, (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16,
-                                                   c_ != 0 ? off : DC_OOB, 0, 0, COH ? 16 : 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < K::PASSES; i++) {
-          const bool surplus = (i * 256 + wave * 64) >= K::NPC;          // wave-uniform: repeat pass 0 (same data, same place)
-          const int ii = surplus ? 0 : i;
-          const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, COH ? 16 : 0);
-        }
+      for (int i = 0; i < K::PASSES; i++) {
+        const bool surplus = (i * 256 + wave * 64) >= K::NPC;          // wave-uniform: repeat pass 0 (same data, same place)
+        const int ii = surplus ? 0 : i;
+        const char *src = Sb + (size_t)(surplus ? src_off[0] : src_off[i]) + (size_t)pz * RB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(buf + (ii * 256 + wave * 64) * 16), 16, 0, COH ? 16 : 0);
       }
-      issue_cnt(DC_K2_SKIP ? plane + 2 : plane, pm3);  // NI instructions per call either way
+      issue_cnt(plane, pm3);
       int po = pz0 + plane - (R - 1) + HLO;             // output plane closed by this plane
       po = po < 0 ? 0 : (po < PDz - 1 ? po : PDz - 1);
       const int4 *rsrc = slots + ((size_t)(rec_cell0 + po) * DC_INL + rec_k);
@@ -327,7 +289,6 @@ __device__ __forceinline__ void dc_k2q_body(
     int n_prev = 0;                                    // voxels in this group's cell of the previous plane
 #pragma unroll
     for (int pp = 0; pp < P; pp++) r0[pp] = r1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DC_K2_SKIP) { issue_cnt(0, 0); issue_cnt(1, 1); }    // older than everything a counted wait leaves in flight
     issue(0, 0, false);
     if (nplanes > 1) issue(1, 1, false);
     int m3 = 0, m3p2 = 2;                              // i % 3, (i + 2) % 3

@@ -39,9 +39,6 @@
 #ifndef DC_K1_SUMB
 #define DC_K1_SUMB 8       /* X rows in flight per batch of the per-cell sums */
 #endif
-#ifndef DC_K1_PRIO
-#define DC_K1_PRIO 0
-#endif
 #ifndef DC_K1_SWAP_SUMS
 #define DC_K1_SWAP_SUMS 1  /* LayerNorm statistics over a voxel's four lane groups through v_permlane32_swap / v_permlane16_swap (VALU) instead
                               of two ds_bpermute each: four dependent LDS round trips per tile leave the wave's chain (round 5) */
@@ -86,59 +83,6 @@ struct dc_k1_cfg {
 };
 
 
-// Cell section of the sparse-cell kernels: the records of a chunk's cells into a block-major LDS list, cooperatively.
-// LiDAR blocks hold 5-27 voxels: the dense form's per-cell-lane fetch (4 inline records + a serial loop of dependent loads for
-// the rest, an insertion sort in LDS) took 40-90 us per wave there.  Here the cell lanes only lay out WHERE each list position
-// comes from (scell[p] = its cell, sseg[p] = the cell's first position | count << 16); then every lane takes positions
-// p = lane, lane + 64 and loads slot (cell, p - first) -- all records in one round trip -- and, when the slot order is still the
-// insert's (SORT: rank order of the atomics), finds its place in the cell's id order by counting smaller ids in LDS and writes
-// the record there (and back to the slot list, so that later readers find id order).  At most DC_SP_LCAP records per chunk.
-#define DC_SP_LCAP 128
-template <bool SORT>
-__device__ __forceinline__ void dc_sparse_fetch(const link_dc_grid_t &g, __amdgpu_buffer_rsrc_t r_slots, int lane, bool mine, int pc,
-                                                int nv, int excl, int Ttot, int4 *list, int *scell, int *sseg, int *tmp_id) {
-  if (mine)
-    for (int k = 0; k < nv; k++) { scell[excl + k] = pc; sseg[excl + k] = excl | (nv << 16); }
-  __builtin_amdgcn_wave_barrier();
-  int4 rec[DC_SP_LCAP / 64];
-  int seg[DC_SP_LCAP / 64], pcj[DC_SP_LCAP / 64];
-#pragma unroll
-  for (int i = 0; i < DC_SP_LCAP / 64; i++) {
-    const int p = lane + 64 * i;
-    const bool on = p < Ttot;
-    pcj[i] = on ? scell[p] : 0;
-    seg[i] = on ? sseg[p] : 0;
-    const v4i_t rv = __builtin_amdgcn_raw_buffer_load_b128(r_slots, on ? dc_slot(g, pcj[i], p - (seg[i] & 0xFFFF)) * 16u : DC_OOB, 0, 0);
-    rec[i] = make_int4(rv.x, rv.y, rv.z, rv.w);
-  }
-  if constexpr (SORT) {
-#pragma unroll
-    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
-      const int p = lane + 64 * i;
-      if (p < Ttot) tmp_id[p] = rec[i].w;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
-      const int p = lane + 64 * i;
-      if (p < Ttot) {
-        const int st = seg[i] & 0xFFFF, len = seg[i] >> 16;
-        int r = 0;
-        for (int q = 0; q < len; q++) r += tmp_id[st + q] < rec[i].w;
-        list[st + r] = rec[i];
-        st16i(r_slots, dc_slot(g, pcj[i], r) * 16u, rec[i]);      // id order goes back to the slot list
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < DC_SP_LCAP / 64; i++) {
-      const int p = lane + 64 * i;
-      if (p < Ttot) list[p] = rec[i];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
 // NB = number of distinct 16-channel theta blocks of a voxel: channel ch uses theta[ch % cg]; when cg is a
 // multiple of 16 the MFMA channel block tp (channels 16 tp + 4 g + r of lane group g) uses theta block
 // tp % (cg/16), so a lane evaluates 4*NB sincos per voxel instead of 4*T; otherwise NB = T.
@@ -149,18 +93,9 @@ __device__ __forceinline__ void dc_sparse_fetch(const link_dc_grid_t &g, __amdgp
 #ifndef DC_K1_WAVES
 #define DC_K1_WAVES 2     /* register budget = 512 / this; LDS (80 KB per workgroup) allows 2 workgroups per CU anyway, and at 3 the tile body spills (A/B: LINK_AMD_CXXFLAGS=-DDC_K1_WAVES=3) */
 #endif
-// SPARSE (round 4, the sparse-cell layout of LiDAR-shaped frames: dense_gather_sparse_impl.h): the cells a wave owns are
-// not a range of the grid but the cells whose FIRST voxel (insert rank 0) has an id in the wave's range of voxel ids --
-// `occ[i]` = that cell for voxel i, 0 otherwise (written by k_dc_index_sparse).  Every occupied cell is owned exactly once,
-// no cell of the (mostly empty) grid is visited for nothing, no zero rows are written: absent neighbours are recognised by
-// cell_n == 0 in the gather kernel.  Which wave owns a cell varies from run to run (the atomic ranks do); what it computes
-// for the cell does not (records in id order, sums in that order).
-// padded cell id owned by `lane` in the chunk starting at interior cell number `chunk` (SPARSE: the cell voxel `chunk + lane` was
-// the first of, 0 = none)
-template <bool SPARSE>
-__device__ __forceinline__ int dc_k1_cell_of(const link_dc_grid_t &g, const int32_t *__restrict__ occ, int chunk, int nrem, int lane) {
+// padded cell id owned by `lane` in the chunk starting at interior cell number `chunk`
+__device__ __forceinline__ int dc_k1_cell_of(const link_dc_grid_t &g, int chunk, int nrem, int lane) {
   const int q = chunk + (lane < nrem ? lane : 0);
-  if constexpr (SPARSE) return (int)occ[q];          // 0 = this voxel is not the first of its cell: an idle lane (count 0)
   const int Dx = g.dim[0], Dy = g.dim[1], Dz = g.dim[2];
   const int z = q % Dz;
   int t = q / Dz;
@@ -173,21 +108,18 @@ __device__ __forceinline__ int dc_k1_cell_of(const link_dc_grid_t &g, const int3
 // struct: as a struct the four records went through 32 bytes of scratch)
 // COH (round 6, the persistent batch kernel): counts and records were written by ANOTHER workgroup of a launch that is still
 // running (the batch's slot insert) -> sc1 loads (dense_common.h); the stand-alone kernel reads them behind a kernel boundary.
-template <bool SPARSE, bool COH = false>
+template <bool COH = false>
 __device__ __forceinline__ void dc_k1_prefetch(int &pc_f, int &nv_f, int4 &rf0, int4 &rf1, int4 &rf2, int4 &rf3,
                                                const link_dc_grid_t &g, const int4 *__restrict__ slots,
-                                               const uint32_t *__restrict__ csrc, const int32_t *__restrict__ occ, int c_begin,
-                                               int c_end, int lane) {
+                                               const uint32_t *__restrict__ csrc, int c_begin, int c_end, int lane) {
   pc_f = 0; nv_f = 0;
   rf0 = make_int4(0, 0, 0, 0); rf1 = rf0; rf2 = rf0; rf3 = rf0;
   if (c_begin < c_end) {
-    pc_f = dc_k1_cell_of<SPARSE>(g, occ, c_begin, (c_end - c_begin < 64) ? c_end - c_begin : 64, lane);
+    pc_f = dc_k1_cell_of(g, c_begin, (c_end - c_begin < 64) ? c_end - c_begin : 64, lane);
     const __amdgpu_buffer_rsrc_t r_slots = dc_rsrc(slots, (uint32_t)((int64_t)g.vp * g.k * 16));
     const __amdgpu_buffer_rsrc_t r_c = dc_rsrc(csrc, (uint32_t)(g.vp * 4));
-    if constexpr (!SPARSE) {
-      rf0 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 0); rf1 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 1);
-      rf2 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 2); rf3 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 3);
-    }
+    rf0 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 0); rf1 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 1);
+    rf2 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 2); rf3 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc_f * DC_INL + 3);
     nv_f = ld4i_c<COH>(r_c, csrc, (uint32_t)pc_f);
   }
 }
@@ -254,12 +186,12 @@ __device__ __forceinline__ void dc_k1_stage(char *smem_raw, const float *__restr
 
 // One wave's range of cells.  pc_f .. rf3: what dc_k1_prefetch requested for the range's first chunk; w_big / th_slow: the
 // workgroup-uniform verdicts of the staging; wid: the wave's number in the launch (profiling rows only).
-template <int C, int OP, int NB, bool PIPE, bool SPARSE, bool COH = false>
+template <int C, int OP, int NB, bool PIPE, bool COH = false>
 __device__ __forceinline__ void dc_k1_range(char *smem_raw, const void *__restrict__ feats, int4 *__restrict__ slots,
                                             uint32_t *__restrict__ cnt, int32_t *__restrict__ cell_n,
                                             const float *__restrict__ w_pre, float coord_div, float eps, int64_t n,
                                             const link_dc_grid_t &g, bool warm, float *__restrict__ S_, float *__restrict__ fin,
-                                            unsigned long long *__restrict__ dbg, const int32_t *__restrict__ occ, int c_begin,
+                                            unsigned long long *__restrict__ dbg, int c_begin,
                                             int c_end, const int pc_f, const int nv_f, const int4 rf0, const int4 rf1, const int4 rf2,
                                             const int4 rf3, bool w_big, bool th_slow, int wid,
                                             unsigned long long tq0, unsigned long long tq1) {
@@ -294,14 +226,12 @@ __device__ __forceinline__ void dc_k1_range(char *smem_raw, const void *__restri
     if (chunk == c_begin) {                             // wave-uniform: the first chunk was requested before the staging
       pc = pc_f; nv = nv_f; r0 = rf0; r1 = rf1; r2 = rf2; r3 = rf3;
     } else {
-      pc = dc_k1_cell_of<SPARSE>(g, occ, chunk, nrem, lane);
-      if constexpr (!SPARSE) {
-        r0 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 0); r1 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 1);
-        r2 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 2); r3 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 3);
-      }
+      pc = dc_k1_cell_of(g, chunk, nrem, lane);
+      r0 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 0); r1 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 1);
+      r2 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 2); r3 = ld16i_c<COH>(r_slots, slots, (uint32_t)pc * DC_INL + 3);
       nv = ld4i_c<COH>(warm ? r_n : r_cnt, csrc, (uint32_t)pc);
     }
-    constexpr int LCAPX = SPARSE ? DC_SP_LCAP : K::LCAP;
+    constexpr int LCAPX = K::LCAP;
     nv = nv < g.k ? nv : g.k;
     nv = nv < LCAPX ? nv : LCAPX;
     if (lane >= nrem) nv = 0;
@@ -317,13 +247,7 @@ __device__ __forceinline__ void dc_k1_range(char *smem_raw, const void *__restri
     const unsigned long long fit = __ballot(lane < nrem && incl <= LCAPX);
     const int nfit = __builtin_amdgcn_readfirstlane(__popcll(fit));      // >= 1: a cell never exceeds LCAP
     const int Ttot = __builtin_amdgcn_readlane(incl, nfit - 1);
-    if constexpr (SPARSE) {
-      // cooperative fetch (dc_sparse_fetch): list positions [0, 128) of the wave's list, sseg behind scell's first 128 entries,
-      // the id scratch behind the list's first 128 records
-      int *sseg = scell + DC_SP_LCAP, *tmp_id = reinterpret_cast<int *>(list + DC_SP_LCAP);
-      if (warm) dc_sparse_fetch<false>(g, r_slots, lane, lane < nfit, pc, nv, incl - nv, Ttot, list, scell, sseg, tmp_id);
-      else dc_sparse_fetch<true>(g, r_slots, lane, lane < nfit, pc, nv, incl - nv, Ttot, list, scell, sseg, tmp_id);
-    } else if (lane < nfit) {
+    if (lane < nfit) {
       const int excl = incl - nv;
       // order the inline records by voxel id: keys id*4+slot through a 5-exchange network
       int k0 = nv > 0 ? r0.w * 4 + 0 : INT_MAX, k1 = nv > 1 ? r1.w * 4 + 1 : INT_MAX;
@@ -362,15 +286,13 @@ __device__ __forceinline__ void dc_k1_range(char *smem_raw, const void *__restri
         for (int k = 0; k < nv; k++) st16i_c<COH>(r_slots, dc_slot(g, pc, k) * 16u, list[excl + k]);
     }
     {                                                   // publish the counts, reset the counters
-      const uint32_t coff = (lane < nfit && !warm && (!SPARSE || pc != 0)) ? (uint32_t)pc * 4u : DC_OOB;
+      const uint32_t coff = (lane < nfit && !warm) ? (uint32_t)pc * 4u : DC_OOB;
       st4i_c<COH>(r_n, coff, nv);
       st4i(r_cnt, coff, 0);
     }
-    if constexpr (!SPARSE) {
-      for (unsigned long long em = __ballot(lane < nfit && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
-        const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
-        st16(r_S, ract ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
-      }
+    for (unsigned long long em = __ballot(lane < nfit && nv == 0); em; em &= em - 1) {   // empty cells: zero rows
+      const int pcj = __builtin_amdgcn_readlane(pc, __builtin_ctzll(em));
+      st16(r_S, ract ? (uint32_t)pcj * (uint32_t)K::RB + (uint32_t)rl * 16u : DC_OOB, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -660,31 +582,27 @@ __device__ __forceinline__ void dc_k1_range(char *smem_raw, const void *__restri
   }
 }
 
-template <int C, int OP, int NB, bool PIPE, bool SPARSE = false>
+template <int C, int OP, int NB, bool PIPE>
 __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_premix_modsum(
     const void *__restrict__ feats, int4 *__restrict__ slots, uint32_t *__restrict__ cnt,
     int32_t *__restrict__ cell_n, const float *__restrict__ w_pre, const float *__restrict__ ln_w,
     const float *__restrict__ ln_b, const float *__restrict__ w_pos, const float *__restrict__ alpha, int cg,
     float coord_div, float eps, int64_t n, link_dc_grid_t g, int cpw, bool warm, float *__restrict__ S_,
-    float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg,
-    const int32_t *__restrict__ occ = nullptr) {
+    float *__restrict__ fin, int32_t *__restrict__ hdr, unsigned long long *__restrict__ dbg) {
   using K = dc_k1_cfg<C, OP>;
   DC_PROF_PTR(dbg);
-#if DC_K1_PRIO
-  __builtin_amdgcn_s_setprio(DC_K1_PRIO);               // A/B (round 5): wave priority of the pre_mix kernel against a co-resident gather kernel
-#endif
   // optional phase timing (tools/dcbench.py --phases): per wave 8 slots of s_memtime deltas
   unsigned long long tq0 = dbg ? DC_NOW() : 0, tq1 = 0;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the first chunk's cell records and counts are requested BEFORE W is staged: the two latencies overlap
-  const int Vi = SPARSE ? (int)n : g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
+  const int Vi = g.dim[0] * g.dim[1] * g.dim[2] * g.dim[3];
   const int wid = blockIdx.x * K::NW + wave;
   const int c_begin = wid * cpw;
   const int c_end = (c_begin + cpw < Vi) ? c_begin + cpw : Vi;
   int pc_f, nv_f;
   int4 rf0, rf1, rf2, rf3;
-  dc_k1_prefetch<SPARSE>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, slots, warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt, occ, c_begin, c_end, lane);
+  dc_k1_prefetch<false>(pc_f, nv_f, rf0, rf1, rf2, rf3, g, slots, warm ? reinterpret_cast<const uint32_t *>(cell_n) : cnt, c_begin, c_end, lane);
   bool w_big = false;                                  // a weight outside the fp16 split's range: fp32 contraction (never on sane models)
   bool th_big = false;
   dc_k1_stage<C, OP>(smem_raw, w_pre, ln_w, ln_b, w_pos, alpha, cg, coord_div, g, tid, w_big, th_big);
@@ -696,6 +614,6 @@ __global__ void __launch_bounds__(64 * DC_K1_NW, PIPE ? 2 : DC_K1_WAVES) k_dc_pr
   const bool th_slow = DC_THETA_BOUND ? __syncthreads_or(th_big) != 0 : false;     // workgroup-uniform (the same in every workgroup)
   if (dbg) tq1 = DC_NOW();
   if (c_begin >= c_end) return;
-  dc_k1_range<C, OP, NB, PIPE, SPARSE>(smem_raw, feats, slots, cnt, cell_n, w_pre, coord_div, eps, n, g, warm, S_, fin, dbg, occ, c_begin,
+  dc_k1_range<C, OP, NB, PIPE>(smem_raw, feats, slots, cnt, cell_n, w_pre, coord_div, eps, n, g, warm, S_, fin, dbg, c_begin,
                                        c_end, pc_f, nv_f, rf0, rf1, rf2, rf3, w_big, th_slow, wid, tq0, tq1);
 }

@@ -167,7 +167,7 @@ class ElkCorePlan:
 
     def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device,
                  coord_div: float = 1.0, eps: float = 1e-6, layout: str = "auto", dense_ratio: float = 4.0,
-                 frames_in_flight: int = 1, slot_cap: int = 0, sparse_auto: bool = False, block_order: str = "auto",
+                 frames_in_flight: int = 1, slot_cap: int = 0, block_order: str = "auto",
                  **tuning):
         self.n_cap, self.c, self.baseop, self.cg, self.r, self.s = n_cap, c, baseop, cg, r, int(s)
         self.frames_in_flight = max(1, int(frames_in_flight))
@@ -187,8 +187,8 @@ class ElkCorePlan:
         self.desc = L.LinkElkDesc(_OPS[baseop], c, cg, r, float(coord_div), float(eps))
         self.parts = 3 if baseop == "cos_x" else 2
         self.device = device
-        if layout not in ("auto", "dense", "general", "sparse", "lean"):
-            raise ValueError(f"layout must be auto|dense|general|sparse|lean, got {layout!r}")
+        if layout not in ("auto", "dense", "general", "lean"):
+            raise ValueError(f"layout must be auto|dense|general|lean, got {layout!r}")
         self.lean = False
         if layout == "lean":
             if self._tuning:                             # the lean form has no per-plan launch geometry: say so instead of ignoring it
@@ -199,7 +199,7 @@ class ElkCorePlan:
         try:
             dcg = L.dc_grid_from(self.grid, int(slot_cap) if slot_cap else 0) if layout != "general" else None
         except L.LinkAmdError:
-            if layout in ("dense", "sparse"):
+            if layout == "dense":
                 raise
             dcg = None
         ok = dcg is not None and self._dense_supported(dcg, n_cap, c, r, self.parts)
@@ -207,16 +207,7 @@ class ElkCorePlan:
             raise L.LinkAmdError("ElkCorePlan(layout='dense'): width / r / grid size not supported by the "
                                  "dense-cell path (include/link_amd.h section E)")
         self.dense = ok and (layout == "dense" or (layout == "auto" and dcg.vp <= dense_ratio * max(n_cap, 1)))
-        # sparse-cell layout (round 4): dense-cell addressing, sparse iteration -- frames that occupy a few percent of their
-        # block grid with small blocks (slot capacity <= 64: S-kitti stages; link_elk_core_sparse_forward).  Explicit, or what
-        # "auto" picks when the grid is too empty for the dense-cell kernels but its tables are still addressable.
-        sp_ok = dcg is not None and self._sparse_supported(dcg, n_cap, c, r, self.parts)
-        if layout == "sparse" and not sp_ok:
-            raise L.LinkAmdError("ElkCorePlan(layout='sparse'): needs C in {16,32,64}, r in {2,3}, slot capacity <= 64 and tables "
-                                 "below 4 GiB (include/link_amd.h, link_elk_core_sparse_forward)")
-        self.sparse = (not self.dense) and sp_ok and (layout == "sparse" or (layout == "auto" and sparse_auto))
-        if self.sparse:
-            self.dense = True                            # same buffers and one-call structure; run() picks the entry point
+        self.sparse = False                              # (the sparse-cell layout of round 4 was removed in round 6: docs/experiments.md section 6)
         self.dcg = dcg if self.dense else None
         if layout == "auto" and not self.dense and slot_cap and self.lean_auto(n_cap, c, baseop, r, self.s, bounds, int(slot_cap)):
             # LiDAR-shaped frame of moderate size whose blocks hold at most `slot_cap` voxels: three launches with the index
@@ -237,12 +228,6 @@ class ElkCorePlan:
         return (c in (16, 32, 64, 128) and r in (2, 3) and (dcg.vp + 1) * parts * c * 4 < 2 ** 32
                 and n_cap * c * 4 < 2 ** 32 and dcg.vp * dcg.k * 16 <= 2 ** 30)
 
-    @staticmethod
-    def _sparse_supported(dcg, n_cap: int, c: int, r: int, parts: int) -> bool:
-        # 32-bit byte offsets in every table (S: (vp + 1) rows, slots: vp * k records); memory is touched only where voxels land
-        return (c in (16, 32, 64) and r in (2, 3) and int(dcg.k) <= 64 and (dcg.vp + 1) * parts * c * 4 < 2 ** 32
-                and n_cap * c * 4 < 2 ** 32 and dcg.vp * dcg.k * 16 < 2 ** 32)
-
     @classmethod
     def would_be_dense(cls, n_cap: int, c: int, baseop: str, r: int, s: int, bounds, dense_ratio: float = 4.0) -> bool:
         """What layout='auto' would choose, without allocating anything."""
@@ -262,28 +247,14 @@ class ElkCorePlan:
         self.vrec = torch.empty((n_cap, 4), **i32)
         self.vcell = torch.empty(n_cap, **i32)
         self.cell_n = torch.zeros(vp, **i32)
-        if self.sparse:
-            # rows are touched only where voxels land; row 0 (what absent neighbours point at) must be zero, the rest needs no
-            # initialisation (a row is read only if its cell's count says it was written this frame)
-            self.S = torch.empty((vp + 1, w), **f32)
-            self.S[0].zero_()
-            self.A = self.S[:1]                          # not used by the sparse path
-        else:
-            self.S = torch.zeros((vp + 1, w), **f32)                   # border rows stay zero
-            self.A = torch.zeros((vp + 1, w), **f32)
+        self.S = torch.zeros((vp + 1, w), **f32)                       # border rows stay zero
+        self.A = torch.zeros((vp + 1, w), **f32)
         b = self.buf = L.LinkDcBuffers()
         b.cnt, b.slots, b.vrec, b.vcell = self.cnt.data_ptr(), self.slots.data_ptr(), self.vrec.data_ptr(), self.vcell.data_ptr()
         b.cell_n, b.hdr, b.fin = self.cell_n.data_ptr(), self.hdr.data_ptr(), self.fin.data_ptr()
         b.S, b.A, b.out = self.S.data_ptr(), self.A.data_ptr(), self.out.data_ptr()
-        if self.sparse:
-            # first-voxel marks of the current / previous indexed frame (alternating), and that frame's voxel count
-            self.occ = [torch.zeros(n_cap, **i32), torch.zeros(n_cap, **i32)]
-            self._occ_cur, self._n_prev = 0, 0
-            self.sid = None
-            b.sid = None
-        else:
-            self.sid = torch.empty(vp * max(int(g.k), 8), **i32)          # voxel ids per cell (tile form of the fused pre_mix kernel)
-            b.sid = self.sid.data_ptr()
+        self.sid = torch.empty(vp * max(int(g.k), 8), **i32)              # voxel ids per cell (tile form of the fused pre_mix kernel)
+        b.sid = self.sid.data_ptr()
         self._fn = L.lib().link_elk_core_dense_forward
         self.m_cap = vp
         self.set_tuning(**self._tuning)
@@ -373,7 +344,7 @@ class ElkCorePlan:
         `frames_in_flight`: one frame alone spreads every kernel over two workgroups per CU (k1_wgs 512, z-segments by
         the tile count); with several frames in flight the kernels of different frames share the CUs, so each takes one
         workgroup per CU and the gather kernel 2 z-segments (fewer halo planes summed twice).  Keyword overrides:
-        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form, 2 matrix-core sums form), k2_form, mode, k1_pipe."""
+        k1_wgs, k2_zsplit, k1_lds_pad, k2_lds_pad, k1_form (0 cell-range form, 1 tile form, 2 matrix-core sums form), k2_form, mode."""
         if not self.dense:
             if kw:
                 raise L.LinkAmdError("ElkCorePlan.set_tuning: only the dense-cell layout has per-plan launch geometry "
@@ -382,7 +353,7 @@ class ElkCorePlan:
         t = self.buf.tune
         multi = self.frames_in_flight > 1
         t.k1_wgs, t.k2_zsplit = (256, 2) if multi else (512, 0)
-        t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = t.k1_pipe = 0
+        t.k1_lds_pad = t.k2_lds_pad = t.k1_form = t.k2_form = t.mode = 0
         if not multi and not self.sparse and self.c in (32, 64) and self.baseop != "cos_x" and "k1_form" not in kw:
             # one frame alone: the matrix-core sums form at four waves per SIMD (4096 waves) -- 49.6-50.3 us per step against
             # 52.8-53.3 for the cell-range form (A/B on one box, round 4); with frames in flight the cell-range form at one
@@ -391,7 +362,7 @@ class ElkCorePlan:
             if "k1_wgs" not in kw:
                 t.k1_wgs = 1024
         for k, v in kw.items():
-            if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_pipe", "k1_dbg", "k2_dbg"):
+            if k not in ("k1_wgs", "k2_zsplit", "k1_lds_pad", "k2_lds_pad", "k1_form", "k2_form", "mode", "k1_dbg", "k2_dbg"):
                 raise L.LinkAmdError(f"ElkCorePlan.set_tuning: unknown key {k!r}")
             setattr(t, k, v)
         if t.k1_form == 0 and multi and "k1_lds_pad" not in kw:
@@ -485,14 +456,6 @@ class ElkCorePlan:
         st = L.current_stream_handle() if stream is None else int(stream)
         if self.lean:
             rc = self._run_lean(n, build_index, st)
-        elif self.dense and self.sparse:
-            oc = self._occ_cur ^ 1 if build_index else self._occ_cur
-            cur, prev = self.occ[oc], self.occ[oc ^ 1]
-            rc = L.lib().link_elk_core_sparse_forward(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n,
-                                                      int(bool(build_index)), cur.data_ptr(), prev.data_ptr(),
-                                                      int(self._n_prev) if build_index else 0, st)
-            if build_index and rc == 0:                  # a refused call launched nothing: the marks stay where they were (_run_lean)
-                self._occ_cur, self._n_prev = oc, n
         elif self.dense:
             rc = self._fn(ctypes.byref(self.buf), ctypes.byref(self.dcg), ctypes.byref(self.desc), n, int(build_index), st)
         else:
@@ -546,117 +509,6 @@ class ElkCorePlan:
         if self.dense:
             return int((self.cell_n > 0).sum().item())
         return int(h[L.HDR_M])
-
-
-class ElkCorePipeline:
-    """R_core of a STREAM of frames, three frames in flight, one launch per frame (link_elk_core_dense_step3,
-    csrc/dense_step3_impl.h): each `push` issues one kernel whose workgroups run the slot insert of the new frame, the fused
-    pre_mix kernel of the previous frame and the gather + de-modulate kernel of the frame before that.  A frame's result is
-    complete (in stream order) after the second push that follows its own -- `push` returns it -- or after `flush()`.
-
-    For a caller that has ONE stream (a sensor loop inside a larger graph): the overlap of the three stages is a property of the
-    launch, not of separate hardware queues.  Measured on cfg2 (tools/step3.py): 36.5-42.9 us / frame, against 52 for one
-    ElkCorePlan on one stream and 32.9-39.9 for three plans on three streams on the same boxes -- where several streams are
-    available they remain the faster arrangement (what bench.py times).  Dense-cell layout only; C = 64, cg = 32, cos / sin,
-    r in {2, 3}, coord_div = 1, no alpha.  Bitwise the results of ElkCorePlan(layout="dense", k1_form=2) at the same k1_wgs /
-    k2_zsplit."""
-
-    STAGES = 3
-
-    def __init__(self, n_cap: int, c: int, baseop: str, cg: int, r: int, s: int, bounds, device, eps: float = 1e-6,
-                 slot_cap: int = 0, insert_wgs: int = 0, **tuning):
-        if c != 64 or cg != 32 or baseop not in ("cos", "sin") or r not in (2, 3):
-            raise L.LinkAmdError("ElkCorePipeline: C = 64, cg = 32, cos / sin, r in {2, 3} (include/link_amd.h, "
-                                 "link_elk_core_dense_step3)")
-        tuning.setdefault("k1_form", 2)
-        tuning.setdefault("k1_wgs", 512)
-        tuning.setdefault("k2_zsplit", 0)
-        self.plans = [ElkCorePlan(n_cap, c, baseop, cg, r, s, bounds, device, eps=eps, layout="dense", slot_cap=slot_cap,
-                                  **tuning) for _ in range(self.STAGES)]
-        if int(self.plans[0].dcg.k) > 352:
-            raise L.LinkAmdError("ElkCorePipeline: slot capacity above 352")
-        self.n_cap, self.c, self.device = n_cap, c, device
-        self.insert_wgs = int(insert_wgs)
-        self._t = 0                                      # frames pushed
-        self._live = [None] * self.STAGES                # per plan: (feats, coords, out tensor, n) of the frame it holds
-        self._fn = L.lib().link_elk_core_dense_step3
-
-    def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
-        if alpha is not None:
-            raise L.LinkAmdError("ElkCorePipeline: alpha is not supported")
-        for p in self.plans:
-            p.bind(w_pre, pre_ln_w, pre_ln_b, w_pos, None, ln_w, ln_b)
-        return self
-
-    def _stage(self, back: int):
-        """(buffers, n) of the frame pushed `back` pushes before the current step, or (None, 0)."""
-        t = self._t - back
-        if t < 0:
-            return None, 0
-        live = self._live[t % self.STAGES]
-        if live is None or live[4] != t:
-            return None, 0
-        return ctypes.byref(self.plans[t % self.STAGES].buf), live[3]
-
-    def _launch(self):
-        b0, n0 = self._stage(0)
-        b1, n1 = self._stage(1)
-        b2, n2 = self._stage(2)
-        p = self.plans[0]
-        rc = self._fn(b0, n0, b1, n1, b2, n2, ctypes.byref(p.dcg), ctypes.byref(p.desc), self.insert_wgs,
-                      L.current_stream_handle())
-        if rc != 0:
-            L.check(rc, "link_elk_core_dense_step3")
-        done = None
-        t2 = self._t - 2
-        if b2 is not None:
-            live = self._live[t2 % self.STAGES]
-            done = live[2][:live[3]]
-            self._live[t2 % self.STAGES] = None
-        self._t += 1
-        return done
-
-    def push(self, feats: torch.Tensor, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """Enter a frame; returns the result of the frame pushed two calls earlier (None while the pipeline fills).  `feats`,
-        `coords` (and `out`, if given) must stay untouched until that result has been returned."""
-        n = feats.shape[0]
-        assert 0 < n <= self.n_cap and feats.shape[1] == self.c and feats.dtype in _IO_DTYPES
-        assert feats.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
-        k = self._t % self.STAGES
-        plan = self.plans[k]
-        for other in self._live:
-            if other is not None and other[0].dtype != feats.dtype:
-                raise L.LinkAmdError("ElkCorePipeline: frames in flight must share a row dtype (flush() first)")
-        own = plan.out
-        if feats.dtype != torch.float32:
-            own = plan.__dict__.setdefault("_out_half", {}).get(feats.dtype)
-            if own is None and out is None:
-                own = plan._out_half[feats.dtype] = torch.empty((self.n_cap, self.c), dtype=feats.dtype, device=self.device)
-        if out is not None:
-            assert out.shape == (n, self.c) and out.dtype == feats.dtype and out.is_contiguous()
-        dst = out if out is not None else own
-        b = plan.buf
-        b.feats, b.coords, b.out, b.io_dtype = feats.data_ptr(), coords.data_ptr(), dst.data_ptr(), _IO_DTYPES[feats.dtype]
-        self._live[k] = (feats, coords, dst, n, self._t)
-        return self._launch()
-
-    def flush(self):
-        """Drain: the results of the frames still in flight, oldest first (at most two launches)."""
-        res = []
-        for _ in range(self.STAGES - 1):
-            if all(l is None for l in self._live):
-                break
-            r = self._launch()
-            if r is not None:
-                res.append(r)
-        return res
-
-    def check(self) -> None:
-        for p in self.plans:
-            p.check()
-
-    def arena_bytes(self) -> int:
-        return sum(p.arena_bytes() for p in self.plans)
 
 
 class ElkCoreBatch:
@@ -1612,13 +1464,12 @@ def invalidate_derived_weights(model: nn.Module) -> None:
     convolution weights).  The caches are keyed on tensor versions and storage pointers, which writes through `.data`
     (EMA swaps, `param.data.copy_`) do not change: call this after such writes.  `load_state_dict` bumps versions and
     needs no call."""
-    _FLIPPED.clear()
     for m in model.modules():
         m.__dict__.pop("_link_fold", None)
         if "_kio" in m.__dict__:
             m._kio = None
         for p in m.parameters(recurse=False):
-            for k in ("_link_amp", "_link_split", "_link_padded"):
+            for k in ("_link_amp", "_link_split", "_link_padded", "_link_flip"):
                 p.__dict__.pop(k, None)
 
 
@@ -1869,20 +1720,15 @@ class _GatherConv(torch.autograd.Function):
         return g_feats, g_kernel, None, None
 
 
-_FLIPPED: dict = {}           # (data_ptr, shape) -> (_version, w'[k] = w[K-1-k]^T): the input-gradient weights of _SubmConv, per optimiser step
-
-
 def _flipped_weights(kernel: torch.Tensor) -> torch.Tensor:
-    """w'[k] = w[K-1-k]^T, cached until the parameter changes (`_version` moves with every in-place optimiser update): the flip + the
-    transposing copy were two torch launches per convolution and backward call (450 + 450 per 15 cfg3 training steps)."""
-    key = (kernel.data_ptr(), tuple(kernel.shape), kernel.device)
-    hit = _FLIPPED.get(key)
-    if hit is not None and hit[0] == kernel._version:
+    """w'[k] = w[K-1-k]^T of _SubmConv's input gradient, cached ON the parameter object until it changes (`_version` moves with every
+    in-place optimiser update): the flip + the transposing copy were two torch launches per convolution and backward call (450 + 450
+    per 15 cfg3 training steps).  (Keyed by storage address it went stale when a freed model's storage was handed to the next one.)"""
+    hit = kernel.__dict__.get("_link_flip")
+    if hit is not None and hit[0] == kernel._version and hit[1].shape[0] == kernel.shape[0]:
         return hit[1]
     w = kernel.detach().flip(0).transpose(1, 2).contiguous()
-    if len(_FLIPPED) > 512:
-        _FLIPPED.clear()
-    _FLIPPED[key] = (kernel._version, w)
+    kernel.__dict__["_link_flip"] = (kernel._version, w)
     return w
 
 

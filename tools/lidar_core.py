@@ -93,7 +93,7 @@ def main():
             ref = b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]).float()
             row["module_warm_us"] = round(ev_time(lambda: b._core(st, r["s_eff"], r["r"], r["w_pos"], r["alpha"], r["cg"], r["coord_div"]), iters), 1)
             cap = max(1, r["s_eff"] // max(r["stride"], 1)) ** 3      # voxel sites of a block at this tensor stride
-            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), ("sparse", dict(layout="sparse", slot_cap=cap, **({"k1_wgs": int(os.environ["IPW"])} if os.environ.get("IPW") else {}))),
+            for name, kw in (("four", dict(tiles=False)), ("tiles", dict(tiles=True)), 
                              ("lean", dict(layout="lean", slot_cap=min(cap, 343), **({"lean_cs": bool(int(os.environ["CS"]))} if os.environ.get("CS") else {}),
                                            **({"lean_pm": bool(int(os.environ["PM"]))} if os.environ.get("PM") else {})))):
                 if os.environ.get("FORM", name) != name:

@@ -1,6 +1,6 @@
 """tools/r06_quick.py -- us/frame of the timed geometry (NS plans on NS streams, cold index) over per-plan tuning variants, on ONE box in
 ONE process, alternating (box-to-box spread is larger than most effects).  VARIANTS: ';'-separated 'key=value,key=value' lists of
-link_dc_tuning_t fields ('' = default), e.g.  VARIANTS=";k1_pipe=1;k1_pipe=1,k1_lds_pad=0" python tools/r06_quick.py"""
+link_dc_tuning_t fields ('' = default), e.g.  VARIANTS=";k2_zsplit=1;k1_lds_pad=0" python tools/r06_quick.py"""
 import os
 import sys
 import time
@@ -18,7 +18,7 @@ torch.manual_seed(2)
 blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev).eval()
 frames = [(torch.randn(N, C, generator=torch.Generator().manual_seed(1 + k)).to(dev), s_uniform(N, seed=k).to(dev)) for k in range(NS)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-variants = os.environ.get("VARIANTS", ";k1_pipe=1").split(";")
+variants = os.environ.get("VARIANTS", ";k2_zsplit=1").split(";")
 
 
 def mk(spec):

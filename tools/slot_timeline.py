@@ -23,7 +23,7 @@ REC = int(os.environ.get("REC", 8))                    # recorded steps (x NS fr
 dev = torch.device("cuda")
 torch.manual_seed(2)
 blk = la.ELKBlock(C, C, groups=2, baseop="cos").to(dev).eval()
-tune = {k: int(os.environ[e]) for k, e in (("k1_pipe", "DC_K1_PIPE"), ("k1_wgs", "DC_K1_WGS"), ("k2_zsplit", "DC_K2_ZSPLIT"),
+tune = {k: int(os.environ[e]) for k, e in (("k1_wgs", "DC_K1_WGS"), ("k2_zsplit", "DC_K2_ZSPLIT"),
                                            ("k1_lds_pad", "DC_K1_PAD")) if os.environ.get(e) not in (None, "")}
 frames, plans, streams = [], [], []
 for k in range(NS):
