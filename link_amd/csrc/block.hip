@@ -180,6 +180,7 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
     unsigned spins = 0;
     bool arrived = true;
     while (__atomic_load_n(&c->host[8], __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();                          // (the core's sibling thread and the memory pipeline get the cycles)
       if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
         const hipError_t es = hipStreamSynchronize(st);
         if (es != hipSuccess) { c->primed = false; return block_fail("link_elk_block_forward (round trip)", es); }
@@ -219,13 +220,17 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   int32_t *pa = a->pair_arena;
   int32_t *wg_counts = pa + po[0], *row_info = pa + po[1], *meta = pa + po[2], *wg_ext = pa + po[3], *wg_k = pa + po[4], *phdr = pa + po[5];
   int32_t *ext_start = pa + po[6], *pair_in = pa + po[7], *pair_out = pa + po[8], *ext_list = pa + po[9];
+  // From here on the frame sits in the plan (counters, slot lists, status word): EVERY error return below takes it out again
+  // (block_unprobe), so that a caller who catches the error does not run its next frame on top of non-zero counters.
+  auto fail = [&](int code) { (void)block_unprobe(a, st); return code; };
   rc = link::dc_neighbor_map_count_run(b->coords, n, g, b->cnt, reinterpret_cast<const int32_t *>(b->slots), a->ts, a->nbr, wg_counts, row_info, st);
-  if (rc != LINK_OK) return rc;
+  if (rc != LINK_OK) return fail(rc);
   prof.mark();                                         // 2: neighbour table launched
   hipStream_t sd = c->side;
   e = hipEventRecord(c->fork, st);
-  if (e != hipSuccess) return block_fail("link_elk_block_forward (fork)", e);
+  if (e != hipSuccess) return fail(block_fail("link_elk_block_forward (fork)", e));
   rc = link_elk_core_dense_forward(b, g, a->desc, n, 2, stream);
+  if (rc != LINK_OK) return fail(rc);                  // (argument validation refused the step: its kernels have not consumed the insert)
 
   prof.mark();                                         // 3: fork recorded + R_core launched
   // ---- 4. side stream: pair plan laid out on the device + the pair GEMM (they need the table and the input rows only) ----

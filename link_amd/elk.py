@@ -2030,12 +2030,26 @@ class _ELKBase(nn.Module):
         ev.record()
         pend = self.__dict__.setdefault("_lean_pending", [])
         pend.append((ev, host, slot, gen, s_eff, ts, k))
-        del pend[:-8]                                        # bounded: at most the last eight steps wait for a look
+        if len(pend) > 8:                                    # bounded -- but no verdict is dropped unseen: the oldest is
+            self._lean_poll_verdicts(wait_oldest=True)       # waited for (its kernels ran eight steps ago) and looked at
+        if L.DEBUG:
+            self.flush_lean_verdicts()
 
-    def _lean_poll_verdicts(self) -> None:
+    def flush_lean_verdicts(self) -> None:
+        """Wait for the status words of every lean-form step issued so far and raise if one of them dropped voxels (slot-list
+        overflow).  The sync-free path reports such a frame at a LATER call on the same module; a caller that must know before it
+        uses the rows -- the last frame of a run, a validation loop -- calls this (LINK_AMD_DEBUG=1 does after every step)."""
+        pend = self.__dict__.get("_lean_pending")
+        if pend:
+            pend[-1][0].synchronize()
+            self._lean_poll_verdicts()
+
+    def _lean_poll_verdicts(self, wait_oldest: bool = False) -> None:
         pend = self.__dict__.get("_lean_pending")
         if not pend:
             return
+        if wait_oldest:
+            pend[0][0].synchronize()
         bad = None
         while pend and pend[0][0].query():
             ev, host, slot, gen, s_eff, ts, k = pend.pop(0)
@@ -2117,11 +2131,14 @@ class _ELKBase(nn.Module):
         _poll_pending_plans()
         rc = lib.link_elk_block_forward(ctx, ctypes.byref(a), _st())
         if rc < 0:
+            plan._unprobe()                                # (the driver takes the frame out of the plan on its error paths; belt and braces)
             L.check(rc, "link_elk_block_forward")
         bb = list(a.bbox)
         st.cmaps[bkey] = (tuple(bb[:4]), tuple(bb[4:]))
         if rc != L.BLOCK_DONE:
             BLOCK_DRIVER_CALLS["miss"] += 1
+            if int(a.stats[3]) == 2:                       # inside the grid, occupancy too high: mean / maximum voxels per occupied cell do
+                st.cmaps[okey] = False                     # not depend on the grid's extent -- the verdict stands, no second probe
             return False
         BLOCK_DRIVER_CALLS["done"] += 1
         st.cmaps[okey] = True

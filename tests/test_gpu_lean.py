@@ -303,3 +303,28 @@ def test_lean_form_without_the_scratch_matrix(C, groups, baseop, stride, s, r):
         ref_h = O.elk_core_torch(h.float(), coords, params, s, r, baseop, groups, variant="encoder", tensor_stride=stride,
                                  agg=O.aggregate_c).numpy()
         assert rel_err(plans[0].run(h.cuda(), c).float().cpu().numpy(), ref_h) < 2e-3
+
+
+def test_module_lean_overflow_is_reported_by_flush_and_never_dropped():
+    """a frame that breaks the stride promise (coordinates off the tensor stride's lattice: up to 8 x the voxels a
+    block of edge s_eff may hold at stride 2) overflows a slot list on the module's sync-free lean path.  Its rows come back (dropped
+    voxels as zeros), and `flush_lean_verdicts()` raises for it at once -- the verdict is not left to an unrelated later frame."""
+    import link_amd as la
+    from link_amd import _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    C, n = 32, 6000
+    blk = la.ELKBlock(C, C, groups=1, baseop="cos_x", variant="encoder").to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    lin = torch.randperm(24 ** 3, generator=g)[:n]                      # EVERY integer site of a 24^3 box ...
+    coords = torch.stack([lin % 24, (lin // 24) % 24, lin // 576, torch.zeros_like(lin)], 1).int().to(dev)
+    st = la.SparseTensor(torch.randn(n, C, generator=g).to(dev), coords, 2)      # ... declared as a stride-2 tensor
+    with torch.no_grad():
+        out = blk._core_lean(st, 6, 2, blk.pos_weight[0].weight, blk.alpha, C, 2.0)
+    if out is None:
+        pytest.skip("the lean form did not take this frame")
+    assert out.shape == (n, C) and bool(torch.isfinite(out).all())
+    with pytest.raises(L.LinkAmdError, match="earlier frame held more than"):
+        blk.flush_lean_verdicts()
+    blk.flush_lean_verdicts()                                            # reported once; nothing pending afterwards
+    assert (6, 2) in blk._lean_distrust
