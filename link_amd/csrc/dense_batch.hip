@@ -47,7 +47,7 @@
 #include "dense_io.h"
 
 #ifndef DC_BT_MAX
-#define DC_BT_MAX 32                 /* frames per launch set (the frame table travels as a kernel argument: 32 x 80 B) */
+#define DC_BT_MAX 48                 /* frames per launch set (the frame table travels as a kernel argument: 48 x 80 B of the 4 KB a launch takes) */
 #endif
 #ifndef DC_BT_TIMEOUT_TICKS
 #define DC_BT_TIMEOUT_TICKS 200000000ull   /* 2 s of the 100 MHz s_memrealtime clock */

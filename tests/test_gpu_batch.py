@@ -128,3 +128,24 @@ def test_batch_reports_a_dropped_voxel_and_refuses_what_it_does_not_serve():
     batch.run([frames[0][0], frames[1][0]], [frames[0][1], bad])
     with pytest.raises(L.LinkAmdError, match="outside the plan's bounds"):
         batch.check()
+
+
+def test_batch_longer_than_one_launch_set():
+    """More frames than one launch set holds (50 > 48: the frame table travels as a kernel argument): the call runs two launch sets
+    back to back on the same context; every frame bit-equal to the per-frame path.  Small slot capacity keeps the arenas small."""
+    import link_amd as la
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 4000, 50
+    blk = _block(C, "cos", dev)
+    frames = _frames(K, N, C, dev, seed0=50)
+    bounds = ((0, 0, 0, 0), (63, 63, 63, 0))
+    frames = [(f, (co % 64).contiguous()) for f, co in frames]
+    frames = [(f, torch.unique(co, dim=0)) for f, co in frames]                 # unique coordinates after the fold into 64^3
+    frames = [(f[:co.shape[0]].contiguous(), co.contiguous()) for f, co in frames]
+    nmax = max(co.shape[0] for _, co in frames)
+    plan = _bind(la.ElkCorePlan(nmax, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0, slot_cap=64), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    batch = _bind(la.ElkCoreBatch(K, nmax, C, "cos", C // 2, 3, 7, bounds, dev, slot_cap=64), blk)
+    outs = batch.run([f for f, _ in frames], [co for _, co in frames])
+    batch.check()
+    assert all(torch.equal(outs[i], ref[i]) for i in range(K))

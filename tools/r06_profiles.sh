@@ -37,6 +37,15 @@ if [ -z "$QUICK" ]; then
 timeout 300 python $R/bench.py --workload cfg3 --steps 30 --warmup 3 2>/dev/null | grep '^{' > $OUT/bench_cfg3.json
 timeout 300 python $R/bench.py --workload cfg5 --steps 30 --warmup 3 2>/dev/null | grep '^{' > $OUT/bench_cfg5.json
 timeout 300 python $R/bench.py --workload cfg5 --io f16 --steps 30 --warmup 3 2>/dev/null | grep '^{' > $OUT/bench_cfg5_f16.json
+timeout 200 python $R/bench.py --io f16 --no-cpu-baseline 2>/dev/null | grep '^{' > $OUT/bench_f16.json
+# row N1: kernel trace of the cfg3 line (the convolution kernels' averages next to the line's conv_roofline) and of the training step
+D=$OUT/trace_cfg3; mkdir -p $D
+timeout 300 rocprofv3 --kernel-trace --stats -d $D -o trace -- python $R/bench.py --workload cfg3 --steps 30 --warmup 3 > /dev/null 2>&1
+db=$(find $D -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/cfg3_conv_kernel_stats.csv | head -5; rm -rf $D
+D=$OUT/trace_train; mkdir -p $D
+K=15 REPS=1 timeout 300 rocprofv3 --kernel-trace --stats -d $D -o trace -- python $R/tools/cfg3train_prof.py > $OUT/cfg3_train.log 2>&1
+db=$(find $D -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/cfg3_train_kernel_stats.csv | head -5; rm -rf $D
+timeout 400 python $R/tools/lidar_core.py 2>/dev/null | grep '^{' > $OUT/lidar_stages.jsonl
 fi
 # the batch entry point: kernel trace of its three persistent kernels, and where their workgroups spend the call
 D=$OUT/trace_batch; mkdir -p $D
@@ -45,6 +54,8 @@ db=$(find $D -name "*.db" | head -1)
 [ -n "$db" ] && python $R/tools/rocpd_stats.py $db $OUT/kernel_stats_batch.csv | head -8
 rm -rf $D
 GPU_MAX_HW_QUEUES=8 B=24 SETS=2 timeout 300 python $R/tools/batch_bench.py > $OUT/batch_bench.txt 2>&1
+GPU_MAX_HW_QUEUES=8 B=48 SETS=2 STEPS=30 timeout 300 python $R/tools/batch_bench.py > $OUT/batch_bench_b48.txt 2>&1
+GPU_MAX_HW_QUEUES=8 B=24 SETS=1 timeout 300 python $R/tools/batch_bench.py > $OUT/batch_bench_1set.txt 2>&1
 if [ -f $R/link_amd/lib/variants/lib_BTPROF.so ]; then
   cp $R/link_amd/lib/liblink_amd.so /tmp/lib_orig.so
   cp $R/link_amd/lib/variants/lib_BTPROF.so $R/link_amd/lib/liblink_amd.so
