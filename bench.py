@@ -861,11 +861,21 @@ def main():
         streams.append(torch.cuda.Stream(device=dev))
     feats, coords = frames[0]
     plan = plans[0]
-    # the batch entry point's context (side measurement at the end, `batch_entry_point`) is created and used ONCE here, before any other
-    # stream of this process submits work: its three role streams then get hardware queues of their own -- bound late, they shared
-    # queues with the frame streams and the same measurement read 45.7 instead of 35.4 us / frame (round 6, profiles/r06_v1_*)
+    # The batch entry point (side measurement at the end, `batch_entry_point`).  Its three role kernels of a call and those of the next call
+    # must run side by side, and HOW WELL they do depends on which hardware queues / dispatch pipes the runtime gave the context's three
+    # streams and the two caller streams when they were created -- a property of the (context, caller streams) pair that is fixed for the
+    # life of the process (round 6: the same arenas measured 49.8 us / frame on one pair and 36.9 on another, in one process, repeatably;
+    # link_dc_batch_probe_streams shows all five streams starting kernels side by side in both cases, so it is not queue sharing as such).
+    # The library cannot see the placement; a caller can measure it.  So: a few (context, caller streams) candidates on the SAME
+    # arenas (LINK_BENCH_BATCH_TRIALS, default 5), 2 x 20 calls each, the fastest kept, every trial reported in the line.
+    for j_ in range(NS):                   # the frame streams' first use comes BEFORE the trials: the runtime binds a stream to a hardware queue
+        with torch.cuda.stream(streams[j_]):   # when it is first used, and the headline's placement must not depend on a side measurement
+            plans[j_].run(*frames[j_])
+    torch.cuda.synchronize()
     bsets = None
-    if plan.dense and C == 64 and G == 2 and args.io == "f32" and world == 1 and not plan.__dict__.get("sparse"):
+    btrials = []
+    n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "5"))      # 0: no batch side measurement
+    if plan.dense and C == 64 and G == 2 and args.io == "f32" and world == 1 and n_trials > 0:
         try:
             FB = NS * ROUNDS
             bsets = [la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)]
@@ -873,16 +883,51 @@ def main():
             for b_ in bsets:
                 b_.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight,
                         blk.norm.bias)
-            bstreams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            for j_, b_ in enumerate(bsets):
-                b_.run([frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)], stream=bstreams[j_].cuda_stream)
-            torch.cuda.synchronize()
+            bfe0, bco0 = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
+            best = None
+            for trial in range(n_trials):
+                if trial:
+                    bsets[0].new_context()
+                    bsets[1].adopt_context(bsets[0])
+                cand = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for s_ in range(20):
+                        bsets[s_ % 2].run(bfe0, bco0, stream=cand[s_ % 2].cuda_stream)
+                    torch.cuda.synchronize()
+                    t_trial = 1e6 * (time.perf_counter() - t0) / (20 * FB)
+                btrials.append(round(t_trial, 2))
+                if best is None or t_trial < best[0]:
+                    best = (t_trial, bsets[0].release_context(), cand)
+                else:
+                    bsets[0].release_context(destroy=True)
+            bsets[0].install_context(best[1])
+            bsets[1].adopt_context(bsets[0])
+            bstreams = best[2]
         except Exception as e:  # noqa: BLE001
             bsets = repr(e)[:200]
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def batch_probe(tag):                               # LINK_BENCH_BATCH_PROBE=1: the batch side measurement at several points of the run (stderr)
+        if os.environ.get("LINK_BENCH_BATCH_PROBE") != "1" or bsets is None or isinstance(bsets, str):
+            return
+        bfe_, bco_ = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for s_ in range(100):
+                bsets[s_ % 2].run(bfe_, bco_, stream=bstreams[s_ % 2].cuda_stream)
+            torch.cuda.synchronize()
+            tb_ = time.perf_counter() - t0_
+        print(f"[batch probe] {tag}: {1e6 * tb_ / (100 * FB):.2f} us/frame; stream starts (pre_mix, gather, insert, caller) "
+              f"{[bsets[0].probe_streams(b_.cuda_stream) for b_ in bstreams]} frame streams {[bsets[0].probe_streams(s_.cuda_stream) for s_ in streams]}",
+              file=sys.stderr, flush=True)
+
+    batch_probe("after creation")
 
     def geometry(ns):
         """Launch geometry for the number of frames kept in flight (dense-cell layout) -- per-plan state
@@ -944,6 +989,7 @@ def main():
     gc.enable()
     # what was just timed is what gets checked: every plan's output under the timed configuration (NS frames in flight,
     # their launch geometry), kept for the comparison with the single-frame geometry below and with the oracle
+    batch_probe("after the timed region")
     outs_timed = [o.clone() for o in last_out]       # the rows the timed steps wrote, in the row type they were written in
     for pl in plans:
         pl.check()
@@ -1233,7 +1279,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(blk, feats.float(), coords, outs_timed[0].float(), N, C, S_, R, G)   # the TIMED configuration's output
 
+    batch_probe("before the module-surface regions")
     regions = timed_regions(la, blk, feats.float(), coords, C, S_, R) if (world == 1 and args.io == "f32") else None
+    batch_probe("after the module-surface regions")
     ms = 1e3 * elapsed / args.steps
     frames_timed = args.steps * NS * ROUNDS          # per GPU
     line = {
@@ -1302,7 +1350,7 @@ def main():
             bsets[0].check()
             line["batch_entry_point"] = {
                 "us_per_frame": round(1e6 * tb / (kb * FB), 2), "value": round(N * kb * FB / tb, 1), "frames_per_call": FB, "calls": kb,
-                "arena_sets_in_flight": SETS, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
+                "arena_sets_in_flight": SETS, "placement_trials_us_per_frame": btrials, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
                 "bitwise_equal_to_timed_configuration": bool(ok),
                 "note": "ElkCoreBatch / link_elk_core_dense_forward_batch: slot insert of the batch + persistent pre_mix and gather role kernels fed "
                         "by per-XCD cursors, per-frame arrival counters instead of launch boundaries (DESIGN.md 4i)"}

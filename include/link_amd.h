@@ -950,6 +950,10 @@ int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
  * rows so far, zeroed by the caller; word 1 = capacity in rows).  Honoured by a -DDC_BT_PROF=1 build of csrc/dense_batch.hip (returns
  * LINK_OK), ignored by the default build (returns 1). */
 int link_dc_batch_set_debug(link_dc_batch_t *ctx, uint64_t *k1_rows, uint64_t *k2_rows);
+/* Diagnostic: one 200 us spin kernel on each of the context's role streams (pre_mix, gather, insert) and on `stream`, launched in that
+ * order; starts_us[i] = start of kernel i relative to kernel 0's.  All within a few us = the four run side by side; ~200 us steps =
+ * streams multiplexed onto one hardware queue (GPU_MAX_HW_QUEUES), which serialises the roles of a call.  Synchronises the device. */
+int link_dc_batch_probe_streams(link_dc_batch_t *ctx, hipStream_t stream, double *starts_us /* host [4] */);
 
 #ifdef __cplusplus
 }

@@ -423,6 +423,28 @@ extern "C" int link_dc_batch_set_debug(link_dc_batch_t *c, uint64_t *k1_rows, ui
   return DC_BT_PROF ? LINK_OK : 1;
 }
 
+// Diagnostic (tools, bench.py): do the context's three role streams and the caller's stream run side by side?  One 64-thread spin
+// kernel (200 us) per stream, launched in the order K1 role, K2 role, insert, caller; starts_us = each kernel's start relative to the
+// first one's.  Side by side = all within a few us; a stream that shares a hardware queue with an earlier one starts ~200 us late.
+__global__ void k_dc_batch_spin(unsigned long long *stamp, int ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) *stamp = t0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+extern "C" int link_dc_batch_probe_streams(link_dc_batch_t *c, hipStream_t caller, double *starts_us /* host [4] */) {
+  if (!c || !starts_us) return LINK_ERR_ARG;
+  unsigned long long *st = nullptr, h[4];
+  if (hipMalloc(reinterpret_cast<void **>(&st), sizeof h) != hipSuccess) return LINK_ERR_LAUNCH;
+  bool ok = hipDeviceSynchronize() == hipSuccess && hipMemset(st, 0, sizeof h) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  hipStream_t ss[4] = {c->sa, c->sb, c->sc, caller};
+  for (int i = 0; i < 4 && ok; i++) hipLaunchKernelGGL(k_dc_batch_spin, dim3(1), dim3(64), 0, ss[i], st + i, 20000);
+  ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(st);
+  if (!ok) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+  for (int i = 0; i < 4; i++) starts_us[i] = ((double)h[i] - (double)h[0]) / 100.0;
+  return LINK_OK;
+}
+
 // status of the calls made so far (synchronises the context's streams): out[0] = first non-zero error word of the ring (0 = none;
 // 1 + the sync word a spin gave up on), out[1] = calls made
 extern "C" int link_dc_batch_status(link_dc_batch_t *c, int32_t *out) {

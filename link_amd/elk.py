@@ -556,6 +556,37 @@ class ElkCoreBatch:
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
+    # A context's three streams land on hardware queues the runtime picks at creation, and how well the role kernels of consecutive calls
+    # overlap depends on that placement (bench.py measures 37 vs 50 us / frame between two contexts on the same arenas).  A caller that
+    # cares measures a few contexts and keeps the best: new_context / release_context / install_context / adopt_context move contexts
+    # between batches without touching the arenas.
+    def new_context(self) -> None:
+        """Replace this batch's context by a fresh one (the old one is destroyed if this batch owned it)."""
+        self.release_context(destroy=True)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().link_dc_batch_create(ctypes.byref(h)), "link_dc_batch_create")
+        self._ctx, self._owner = h, None
+
+    def release_context(self, destroy: bool = False):
+        """Detach the context and return its handle (None if it was shared from another batch); `destroy`: free it instead."""
+        h, owned = getattr(self, "_ctx", None), getattr(self, "_owner", None) is None
+        self._ctx, self._owner = None, None
+        if h and owned and destroy:
+            L.lib().link_dc_batch_destroy(h)
+            return None
+        return h if owned else None
+
+    def install_context(self, handle) -> None:
+        """Own `handle` (from release_context) from here on."""
+        self.release_context(destroy=True)
+        self._ctx, self._owner = handle, None
+
+    def adopt_context(self, other: "ElkCoreBatch") -> None:
+        """Share `other`'s context (as `share=other` does at construction)."""
+        self.release_context(destroy=True)
+        self._ctx, self._owner = other._ctx, other
+
     def bind(self, w_pre, pre_ln_w, pre_ln_b, w_pos, alpha, ln_w, ln_b):
         if alpha is not None:
             raise L.LinkAmdError("ElkCoreBatch: alpha is not supported")
@@ -603,6 +634,13 @@ class ElkCoreBatch:
                                  "wait gave up; the batch's rows are undefined)")
         for p in self.plans:
             p.check()
+
+    def probe_streams(self, stream: Optional[int] = None):
+        """Diagnostic (link_dc_batch_probe_streams): start times (us) of one spin kernel on each role stream and on `stream`, relative to
+        the first -- values near 0 = side by side, steps of ~200 = streams sharing a hardware queue."""
+        out = (ctypes.c_double * 4)()
+        L.check(L.lib().link_dc_batch_probe_streams(self._ctx, stream if stream is not None else _st(), out), "link_dc_batch_probe_streams")
+        return [round(float(v), 1) for v in out]
 
     def arena_bytes(self) -> int:
         return sum(p.arena_bytes() for p in self.plans)

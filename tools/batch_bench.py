@@ -73,4 +73,6 @@ t_streams(10); t_batch(10)
 for p in range(PASSES):
     print(f"pass {p}: three plans on three streams {t_streams(STEPS):.2f} us/frame | batch of {B} x {SETS} set(s) {t_batch(STEPS):.2f} us/frame", flush=True)
 batches[0].check()
+print("stream starts (pre_mix, gather, insert, caller):", [batches[0].probe_streams(b.cuda_stream) for b in bstreams], "frame streams",
+      [batches[0].probe_streams(s.cuda_stream) for s in pstreams])
 print("status ok")
