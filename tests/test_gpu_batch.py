@@ -137,11 +137,9 @@ def test_batch_longer_than_one_launch_set():
     dev = torch.device("cuda:0")
     C, N, K = 64, 4000, 50
     blk = _block(C, "cos", dev)
-    frames = _frames(K, N, C, dev, seed0=50)
+    frames = [(torch.randn(N, C, generator=torch.Generator().manual_seed(150 + i)).to(dev), s_uniform(N, grid=64, seed=50 + i).to(dev))
+              for i in range(K)]                                                 # unique coordinates inside 64^3
     bounds = ((0, 0, 0, 0), (63, 63, 63, 0))
-    frames = [(f, (co % 64).contiguous()) for f, co in frames]
-    frames = [(f, torch.unique(co, dim=0)) for f, co in frames]                 # unique coordinates after the fold into 64^3
-    frames = [(f[:co.shape[0]].contiguous(), co.contiguous()) for f, co in frames]
     nmax = max(co.shape[0] for _, co in frames)
     plan = _bind(la.ElkCorePlan(nmax, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0, slot_cap=64), blk)
     ref = [plan.run(f, co).clone() for f, co in frames]
