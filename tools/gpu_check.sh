@@ -3,7 +3,7 @@
 # eat the gpurun budget), then smoke + bench.  Logs under gpurun_out/.
 mkdir -p gpurun_out
 T=${T:-150}
-for f in ${FILES:-tests/test_gpu_ops.py tests/test_gpu_index.py tests/test_gpu_aggregate.py tests/test_gpu_elk.py tests/test_gpu_split_paths.py tests/test_gpu_elk_tiles.py tests/test_gpu_train.py tests/test_gpu_conv.py tests/test_gpu_pointvoxel.py tests/test_gpu_encoder.py tests/test_gpu_dense.py tests/test_gpu_detstage.py tests/test_gpu_sparse.py tests/test_gpu_pipeline.py tests/test_gpu_index_first.py tests/test_gpu_bench.py}; do
+for f in ${FILES:-tests/test_gpu_aggregate.py tests/test_gpu_batch.py tests/test_gpu_bench.py tests/test_gpu_block_driver.py tests/test_gpu_conv.py tests/test_gpu_core_lidar.py tests/test_gpu_dense.py tests/test_gpu_detstage.py tests/test_gpu_elk.py tests/test_gpu_elk_tiles.py tests/test_gpu_encoder.py tests/test_gpu_index.py tests/test_gpu_index_first.py tests/test_gpu_lean.py tests/test_gpu_ops.py tests/test_gpu_pointvoxel.py tests/test_gpu_split_paths.py tests/test_gpu_train.py}; do
   b=$(basename $f .py)
   timeout $T python -m pytest $f -m gpu -x -q --timeout=60 --timeout-method=thread > gpurun_out/$b.log 2>&1
   echo "== $f rc=$? : $(tail -1 gpurun_out/$b.log)"
