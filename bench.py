@@ -877,7 +877,7 @@ def main():
     n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "5"))      # 0: no batch side measurement
     if plan.dense and C == 64 and G == 2 and args.io == "f32" and world == 1 and n_trials > 0:
         try:
-            FB = NS * ROUNDS
+            FB = int(os.environ.get("LINK_BENCH_BATCH_FRAMES", "48"))   # frames per call: 48 = one launch set of the entry point (two steps' worth of frames)
             bsets = [la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)]
             bsets.append(la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev, share=bsets[0]))
             for b_ in bsets:
@@ -1329,12 +1329,12 @@ def main():
     # ---- the BATCH entry point (include/link_amd.h section H; round 6): the same frames as batches of NS * ROUNDS through
     # link_elk_core_dense_forward_batch -- one insert kernel + two persistent, queue-fed role kernels per call -- two arena sets
     # alternated on two streams (the pre_mix role of call s + 1 starts under the gather role of call s).  A step = one call = the
-    # same 24 frames as a step of the headline; reported beside it, never as it.
+    # the headline's frames, 48 per call (LINK_BENCH_BATCH_FRAMES); reported beside the headline, never as it.
     if isinstance(bsets, str):
         line["batch_entry_point"] = {"error": bsets}
     elif bsets is not None:
         try:
-            FB, SETS = NS * ROUNDS, 2
+            SETS = 2
             bfe, bco = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
             ok = True
             for b_ in bsets:

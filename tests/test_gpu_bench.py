@@ -65,7 +65,7 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     assert [r["rank"] for r in single["cpu_affinity"]["ranks"]] == [0] and [r["rank"] for r in d["cpu_affinity"]["ranks"]] == [0, 1]
     # side measurement: the same frames through the batch entry point (one insert + two persistent role kernels per call)
     be = single["batch_entry_point"]
-    assert "error" not in be and be["us_per_frame"] > 0 and be["bitwise_equal_to_timed_configuration"] and be["frames_per_call"] == 24
+    assert "error" not in be and be["us_per_frame"] > 0 and be["bitwise_equal_to_timed_configuration"] and be["frames_per_call"] == 48 and len(be["placement_trials_us_per_frame"]) >= 1
 
 
 def test_bench_half_rows_check_reads_what_the_step_wrote():
