@@ -14,7 +14,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // s_waitcnt vmcnt the compiler emits is an exact count instead of the vmcnt(0) a conditional VMEM op forces.
 // Tables handled here are < 4 GiB (checked by the launchers).
 #define DC_OOB 0xFFFFFFF0u
-// Per-wave phase timers (link_dc_tuning_t::k1_dbg / k2_dbg -> tools/k1prof.py, k1mprof.py, k2prof.py, step3.py PROF=1) are compiled
+// Per-wave phase timers (link_dc_tuning_t::k1_dbg / k2_dbg -> tools/k1prof.py, k1mprof.py, k2prof.py) are compiled
 // in only with -DDC_PROF=1 (python tools/mkvariant.py PROF "-DDC_PROF=1").  In the default build the pointer is forced to null at
 // the top of every kernel body, so the `if (dbg)` tests -- a scalar test + branch each, five to eight per plane step / tile in
 // every wave: ~0.3 M scalar instructions per frame on cfg2 -- and the timers fold away (round 5).
@@ -137,8 +137,8 @@ __device__ __forceinline__ uint32_t dc_slot(const link_dc_grid_t &g, int pcell, 
 }
 
 // The slot insert of the dense-cell index as a device function of (workgroup number, workgroups, threads per workgroup):
-// k_dc_index (dense_fused.hip) runs it over its own grid, the three-stage step kernel (dense_step3_impl.h) over a range of a
-// shared one.  rank = cnt[cell]++, slots[cell][rank] = (x, y, z, id), vcell[id] = cell; a voxel outside the grid or past a
+// k_dc_index (dense_fused.hip) runs it over its own grid (the persistent batch insert, dense_batch.hip, restates it on 32-bit voxel
+// numbers).  rank = cnt[cell]++, slots[cell][rank] = (x, y, z, id), vcell[id] = cell; a voxel outside the grid or past a
 // full cell sets its bit of the status accumulator and is left out.
 template <bool STATS, bool COH = false>
 __device__ __forceinline__ void dc_index_body(const int4 *__restrict__ coords, int64_t n, const link_dc_grid_t &g,

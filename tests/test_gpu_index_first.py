@@ -125,7 +125,7 @@ def test_general_layout_plan_on_either_numbering(C, groups, baseop, s, r):
     params = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
     frames = []
     for seed, npts in ((3, 30000), (4, 8000), (5, 30000)):
-        coords = torch.from_numpy(lidar_like(npts, seed=seed, voxel=0.2 if C == 16 else 0.1))      # (C = 16: see test_gpu_sparse.py on fp32 theta at large coordinates)
+        coords = torch.from_numpy(lidar_like(npts, seed=seed, voxel=0.2 if C == 16 else 0.1))      # (C = 16: coarser voxels keep fp32 theta at large coordinates inside the gate)
         frames.append((coords, torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(seed))))
     bounds = coords_bounds(torch.cat([c for c, _ in frames]).cuda())
     n_cap = max(c.shape[0] for c, _ in frames)
