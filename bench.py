@@ -861,20 +861,35 @@ def main():
         streams.append(torch.cuda.Stream(device=dev))
     feats, coords = frames[0]
     plan = plans[0]
-    # The batch entry point (side measurement at the end, `batch_entry_point`).  Its three role kernels of a call and those of the next call
-    # must run side by side, and HOW WELL they do depends on which hardware queues / dispatch pipes the runtime gave the context's three
-    # streams and the two caller streams when they were created -- a property of the (context, caller streams) pair that is fixed for the
-    # life of the process (round 6: the same arenas measured 49.8 us / frame on one pair and 36.9 on another, in one process, repeatably;
-    # link_dc_batch_probe_streams shows all five streams starting kernels side by side in both cases, so it is not queue sharing as such).
-    # The library cannot see the placement; a caller can measure it.  So: a few (context, caller streams) candidates on the SAME
-    # arenas (LINK_BENCH_BATCH_TRIALS, default 5), 2 x 20 calls each, the fastest kept, every trial reported in the line.
+    # The batch entry point (side measurement at the end, `batch_entry_point`).  Two calls are kept in flight on two arena sets: call s + 1
+    # is SUBMITTED before call s is JOINED, all from one stream (link_dc_batch_submit / link_dc_batch_join).  The first form of this
+    # measurement alternated two caller streams instead, and read 37 or 50 us / frame depending on the streams it happened to get: two
+    # streams the runtime multiplexes onto one hardware queue serialise the calls (the wait of one stream's call sits in front of the
+    # other's submission; tools/batch_overlap.py shows call s + 1 starting when call s has ended).  What is left of the placement is
+    # measured: LINK_BENCH_BATCH_TRIALS contexts (default 3) on the SAME arenas, 2 x 20 calls each, the fastest kept, every trial in the line.
     for j_ in range(NS):                   # the frame streams' first use comes BEFORE the trials: the runtime binds a stream to a hardware queue
         with torch.cuda.stream(streams[j_]):   # when it is first used, and the headline's placement must not depend on a side measurement
             plans[j_].run(*frames[j_])
     torch.cuda.synchronize()
     bsets = None
     btrials = []
-    n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "5"))      # 0: no batch side measurement
+    n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "3"))      # 0: no batch side measurement
+
+    def batch_calls(k_, stream_):
+        """k_ calls alternating the two arena sets, submit(s + 1) before join(s), from one stream; seconds"""
+        h_ = stream_.cuda_stream
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        prev_ = None
+        for s_ in range(k_):
+            _, tk_ = bsets[s_ % 2].submit(bfe0, bco0, stream=h_)
+            if prev_ is not None:
+                bsets[0].join(prev_, stream=h_)
+            prev_ = tk_
+        bsets[0].join(prev_, stream=h_)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_
+
     if plan.dense and C == 64 and G == 2 and args.io == "f32" and world == 1 and n_trials > 0:
         try:
             FB = int(os.environ.get("LINK_BENCH_BATCH_FRAMES", "48"))   # frames per call: 48 = one launch set of the entry point (two steps' worth of frames)
@@ -884,27 +899,24 @@ def main():
                 b_.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight, None, blk.norm.weight,
                         blk.norm.bias)
             bfe0, bco0 = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
+            bstream = torch.cuda.Stream(device=dev)
             best = None
             for trial in range(n_trials):
                 if trial:
                     bsets[0].new_context()
                     bsets[1].adopt_context(bsets[0])
-                cand = [torch.cuda.Stream(device=dev) for _ in range(2)]
-                for _ in range(2):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for s_ in range(20):
-                        bsets[s_ % 2].run(bfe0, bco0, stream=cand[s_ % 2].cuda_stream)
-                    torch.cuda.synchronize()
-                    t_trial = 1e6 * (time.perf_counter() - t0) / (20 * FB)
+                batch_calls(20, bstream)
+                t_trial = 1e6 * batch_calls(20, bstream) / (20 * FB)
                 btrials.append(round(t_trial, 2))
+                if os.environ.get("LINK_BENCH_BATCH_PROBE") == "1":
+                    print(f"[batch trial {trial}] {t_trial:.2f} us/frame; queue delays (pre_mix->gather, pre_mix->insert, gather->insert, caller->pre_mix, "
+                          f"caller->gather, caller->insert) {bsets[0].probe_streams(bstream.cuda_stream)}", file=sys.stderr, flush=True)
                 if best is None or t_trial < best[0]:
-                    best = (t_trial, bsets[0].release_context(), cand)
+                    best = (t_trial, bsets[0].release_context())
                 else:
                     bsets[0].release_context(destroy=True)
             bsets[0].install_context(best[1])
             bsets[1].adopt_context(bsets[0])
-            bstreams = best[2]
         except Exception as e:  # noqa: BLE001
             bsets = repr(e)[:200]
 
@@ -915,17 +927,9 @@ def main():
     def batch_probe(tag):                               # LINK_BENCH_BATCH_PROBE=1: the batch side measurement at several points of the run (stderr)
         if os.environ.get("LINK_BENCH_BATCH_PROBE") != "1" or bsets is None or isinstance(bsets, str):
             return
-        bfe_, bco_ = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for s_ in range(100):
-                bsets[s_ % 2].run(bfe_, bco_, stream=bstreams[s_ % 2].cuda_stream)
-            torch.cuda.synchronize()
-            tb_ = time.perf_counter() - t0_
-        print(f"[batch probe] {tag}: {1e6 * tb_ / (100 * FB):.2f} us/frame; stream starts (pre_mix, gather, insert, caller) "
-              f"{[bsets[0].probe_streams(b_.cuda_stream) for b_ in bstreams]} frame streams {[bsets[0].probe_streams(s_.cuda_stream) for s_ in streams]}",
-              file=sys.stderr, flush=True)
+        batch_calls(50, bstream)
+        print(f"[batch probe] {tag}: {1e6 * batch_calls(50, bstream) / (50 * FB):.2f} us/frame; queue delays "
+              f"{bsets[0].probe_streams(bstream.cuda_stream)}", file=sys.stderr, flush=True)
 
     batch_probe("after creation")
 
@@ -1345,16 +1349,12 @@ def main():
             kb = max(args.steps, 20)
             tb = None
             for _ in range(3):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for s_ in range(kb):
-                    bsets[s_ % SETS].run(bfe, bco, stream=bstreams[s_ % SETS].cuda_stream)
-                torch.cuda.synchronize()
-                tb = time.perf_counter() - t0
+                tb = batch_calls(kb, bstream)
             bsets[0].check()
             line["batch_entry_point"] = {
                 "us_per_frame": round(1e6 * tb / (kb * FB), 2), "value": round(N * kb * FB / tb, 1), "frames_per_call": FB, "calls": kb,
-                "arena_sets_in_flight": SETS, "placement_trials_us_per_frame": btrials, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
+                "arena_sets_in_flight": SETS, "calls_in_flight": "submit(s + 1) before join(s), one caller stream",
+                "placement_trials_us_per_frame": btrials, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
                 "bitwise_equal_to_timed_configuration": bool(ok),
                 "note": "ElkCoreBatch / link_elk_core_dense_forward_batch: slot insert of the batch + persistent pre_mix and gather role kernels fed "
                         "by per-XCD cursors, per-frame arrival counters instead of launch boundaries (DESIGN.md 4i)"}

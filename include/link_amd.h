@@ -945,15 +945,27 @@ int link_dc_batch_destroy(link_dc_batch_t *ctx);
 int link_elk_core_dense_forward_batch(link_dc_batch_t *ctx, const link_dc_buffers_t *frames /* host [nframes] */,
                                       const int64_t *n /* host [nframes] */, int32_t nframes, const link_dc_grid_t *g /* host */,
                                       const link_elk_desc_t *desc /* host */, void *stream);
+/* The same call in two halves, for a caller that keeps several calls in flight from ONE stream: link_dc_batch_submit enqueues the call
+ * behind what `stream` holds so far and hands out a ticket; link_dc_batch_join makes `stream` wait for that call's rows.  Submitting
+ * call s + 1 BEFORE joining call s lets the pre_mix role of s + 1 start under the gather role of s without a second caller stream --
+ * two caller streams that the runtime happens to multiplex onto one hardware queue serialise the calls (the wait of one stream's
+ * join sits in front of the other stream's submit: 50 against 37 us / frame).
+ * link_elk_core_dense_forward_batch == submit + join. */
+int link_dc_batch_submit(link_dc_batch_t *ctx, const link_dc_buffers_t *frames /* host [nframes] */, const int64_t *n /* host [nframes] */,
+                         int32_t nframes, const link_dc_grid_t *g /* host */, const link_elk_desc_t *desc /* host */, void *stream,
+                         int64_t *ticket /* host, out */);
+int link_dc_batch_join(link_dc_batch_t *ctx, int64_t ticket, void *stream);
 int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
 /* Profiling hook (tools/batch_timeline.py): device buffers of 8 x u64 rows the K1 / K2 items append 100 MHz timestamps to (word 0 =
  * rows so far, zeroed by the caller; word 1 = capacity in rows).  Honoured by a -DDC_BT_PROF=1 build of csrc/dense_batch.hip (returns
  * LINK_OK), ignored by the default build (returns 1). */
 int link_dc_batch_set_debug(link_dc_batch_t *ctx, uint64_t *k1_rows, uint64_t *k2_rows);
-/* Diagnostic: one 200 us spin kernel on each of the context's role streams (pre_mix, gather, insert) and on `stream`, launched in that
- * order; starts_us[i] = start of kernel i relative to kernel 0's.  All within a few us = the four run side by side; ~200 us steps =
- * streams multiplexed onto one hardware queue (GPU_MAX_HW_QUEUES), which serialises the roles of a call.  Synchronises the device. */
-int link_dc_batch_probe_streams(link_dc_batch_t *ctx, hipStream_t stream, double *starts_us /* host [4] */);
+/* Diagnostic: does a pair of streams sit on ONE hardware queue (GPU_MAX_HW_QUEUES; an event record on one stream then holds up the
+ * other's kernels)?  A 150 us spin kernel + an event record on the first stream, a stamp kernel on the second; delays_us[6] = the
+ * second's start behind the first's for (pre_mix -> gather), (pre_mix -> insert), (gather -> insert), (stream -> pre_mix),
+ * (stream -> gather), (stream -> insert) and the six reverse pairs: ~5 = separate queues, >= 150 = one queue.  Synchronises the
+ * streams involved.  (link_dc_batch_create runs the same test to put its role streams on queues of their own.) */
+int link_dc_batch_probe_streams(link_dc_batch_t *ctx, hipStream_t stream, double *delays_us /* host [12] */);
 
 #ifdef __cplusplus
 }

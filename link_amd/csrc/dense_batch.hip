@@ -360,9 +360,43 @@ using namespace link;
 using namespace dcb_f32;
 
 static constexpr int BT_RING = 4;
+// Do two HIP streams sit on ONE hardware queue?  The runtime multiplexes streams onto a few queues (GPU_MAX_HW_QUEUES, 4 by default);
+// kernels of two streams that share a queue still start side by side -- but an EVENT RECORD on one of them is a packet with the barrier
+// bit, and every later packet of that queue, whichever stream it belongs to, waits behind it.  A call of the batch entry point records
+// events behind its role kernels; with the pre_mix and the gather stream on one queue, the next call's pre_mix kernel sits behind the
+// gather kernel's completion event and the calls run one after the other (tools/batch_overlap.py: 48 instead of 35 us / frame).
+// The test: a 150 us spin kernel + an event record on `x`, then a stamp kernel on `y`; *us = y's start - x's start (a few us either
+// way on separate queues); false = a HIP call failed.
+__global__ void k_dc_batch_spin(unsigned long long *stamp, int ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) *stamp = t0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+static bool bt_queue_delay_us(hipStream_t x, hipStream_t y, unsigned long long *scratch /* device, 2 words */, hipEvent_t ev, double *us) {
+  unsigned long long h[2] = {0, 0};
+  *us = 0.0;
+  if (hipStreamSynchronize(x) != hipSuccess || hipStreamSynchronize(y) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_dc_batch_spin, dim3(1), dim3(64), 0, x, scratch, 15000);
+  if (hipEventRecord(ev, x) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_dc_batch_spin, dim3(1), dim3(64), 0, y, scratch + 1, 0);
+  if (hipStreamSynchronize(x) != hipSuccess || hipStreamSynchronize(y) != hipSuccess ||
+      hipMemcpy(h, scratch, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+    return false;
+  *us = ((double)h[1] - (double)h[0]) / 100.0;
+  return true;
+}
+static bool bt_share_queue(hipStream_t x, hipStream_t y, unsigned long long *scratch, hipEvent_t ev) {
+  double d = 0.0;
+  return !bt_queue_delay_us(x, y, scratch, ev, &d) || d > 75.0;      // (a failed probe counts as shared: the candidate is passed over)
+}
 struct link_dc_batch {
   int device, cus;
   hipStream_t sa, sb, sc;                              // K1 role, K2 role, insert
+  std::vector<hipStream_t> pool;                       // default-priority streams found on pairwise DIFFERENT hardware queues (sa, sb are two of them)
+  int ia, ib;                                          // sa = pool[ia], sb = pool[ib]
+  std::vector<std::pair<hipStream_t, unsigned>> callers;   // caller streams seen so far -> bit i: shares a hardware queue with pool[i]
+  unsigned long long *probe_scratch;                   // device, 2 words
+  hipEvent_t probe_ev;
   int32_t *sync;                                       // BT_RING x BT_SYNC_WORDS
   hipEvent_t ev_in[BT_RING], ev_ms[BT_RING], ev_a[BT_RING], ev_c[BT_RING], ev_out[BT_RING];
   std::vector<const void *> bufs[BT_RING];             // S pointers of the frames the ring slot's call worked on
@@ -377,16 +411,38 @@ extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
   hipDeviceProp_t pr;
   if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&pr, c->device) != hipSuccess) { delete c; return LINK_ERR_LAUNCH; }
   c->cus = pr.multiProcessorCount;
-  // Three non-blocking streams (tools/queue_probe.hip: kernels on three such streams start within a few us of each other, whatever
-  // else the process has created).  Launch order inside a call is insert -> K1 -> K2, the order of the dependences, so that even a
-  // shared hardware queue would serialise the roles instead of parking a kernel behind one that waits for it.
+  // Launch order inside a call is insert -> pre_mix -> gather, the order of the dependences.
   int pr_lo = 0, pr_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);                 // numerically: least = greatest number
-  // the insert's stream has the HIGHEST priority: its waves must find their slot before the two roles that wait for them fill the CUs
-  bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&c->sb, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, pr_hi) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
+  // The insert's stream has the HIGHEST priority: its waves must find their slot before the two roles that wait for them fill the CUs.
+  // The pre_mix and the gather stream must sit on DIFFERENT hardware queues, and on other queues than the insert's and the caller's: an
+  // event record is a barrier packet for its whole queue, so two of these on one queue run the calls one after the other (48 instead
+  // of 35 us / frame; the runtime gave two streams created back to back the same queue in five contexts out of six).  (This removes
+  // ONE cause of calls running one after the other; tools/batch_overlap.py still finds contexts in that state whose streams pass every
+  // test here -- rocprofv3 queue ids, tools/rocpd_batch_gaps.py: it went with the pre_mix queue's id equal to the insert's or the
+  // caller's modulo 4, a dispatch-pipe relation this code has no handle on.  A caller that cares measures: DESIGN.md 4i.)  Candidates are
+  // created until up to four sit on pairwise different queues (bt_share_queue); the rejected ones are destroyed afterwards -- alive,
+  // they keep their queue's use count up and steer the next candidate elsewhere.
+  bool ok = hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, pr_hi) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&c->probe_scratch), 16) == hipSuccess &&
+            hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming) == hipSuccess;
+  std::vector<hipStream_t> rejected;
+  const bool dbg_place = getenv("LINK_DC_BATCH_DEBUG") != nullptr;
+  for (int cand = 0; ok && cand < 12 && c->pool.size() < 4; cand++) {
+    hipStream_t s_ = nullptr;
+    if (hipStreamCreateWithFlags(&s_, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
+    bool bad = bt_share_queue(c->sc, s_, c->probe_scratch, c->probe_ev);
+    for (size_t i = 0; i < c->pool.size() && !bad; i++) bad = bt_share_queue(c->pool[i], s_, c->probe_scratch, c->probe_ev);
+    (bad ? rejected : c->pool).push_back(s_);
+  }
+  while (ok && c->pool.size() < 2 && !rejected.empty()) { c->pool.push_back(rejected.back()); rejected.pop_back(); }   // (not two clean ones to be had: slower, not wrong)
+  for (hipStream_t s_ : rejected) (void)hipStreamDestroy(s_);
+  ok = ok && c->pool.size() >= 2;
+  if (ok) { c->ia = 0; c->ib = 1; c->sa = c->pool[0]; c->sb = c->pool[1]; }
+  if (dbg_place)
+    fprintf(stderr, "link_dc_batch_create: %zu streams on hardware queues of their own, %zu candidates rejected\n",
+            c->pool.size(), rejected.size());
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
             hipMemset(c->sync, 0, sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess;
   for (int i = 0; i < BT_RING && ok; i++) {
     ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_ms[i], hipEventDisableTiming) == hipSuccess &&
@@ -409,7 +465,10 @@ extern "C" int link_dc_batch_destroy(link_dc_batch_t *c) {
     (void)hipEventDestroy(c->ev_out[i]);
   }
   (void)hipFree(c->sync);
-  (void)hipStreamDestroy(c->sa); (void)hipStreamDestroy(c->sb); (void)hipStreamDestroy(c->sc);
+  (void)hipFree(c->probe_scratch);
+  (void)hipEventDestroy(c->probe_ev);
+  for (hipStream_t s_ : c->pool) (void)hipStreamDestroy(s_);
+  (void)hipStreamDestroy(c->sc);
   delete c;
   return LINK_OK;
 }
@@ -423,25 +482,21 @@ extern "C" int link_dc_batch_set_debug(link_dc_batch_t *c, uint64_t *k1_rows, ui
   return DC_BT_PROF ? LINK_OK : 1;
 }
 
-// Diagnostic (tools, bench.py): do the context's three role streams and the caller's stream run side by side?  One 64-thread spin
-// kernel (200 us) per stream, launched in the order K1 role, K2 role, insert, caller; starts_us = each kernel's start relative to the
-// first one's.  Side by side = all within a few us; a stream that shares a hardware queue with an earlier one starts ~200 us late.
-__global__ void k_dc_batch_spin(unsigned long long *stamp, int ticks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0) *stamp = t0;
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
-}
-extern "C" int link_dc_batch_probe_streams(link_dc_batch_t *c, hipStream_t caller, double *starts_us /* host [4] */) {
-  if (!c || !starts_us) return LINK_ERR_ARG;
-  unsigned long long *st = nullptr, h[4];
-  if (hipMalloc(reinterpret_cast<void **>(&st), sizeof h) != hipSuccess) return LINK_ERR_LAUNCH;
-  bool ok = hipDeviceSynchronize() == hipSuccess && hipMemset(st, 0, sizeof h) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-  hipStream_t ss[4] = {c->sa, c->sb, c->sc, caller};
-  for (int i = 0; i < 4 && ok; i++) hipLaunchKernelGGL(k_dc_batch_spin, dim3(1), dim3(64), 0, ss[i], st + i, 20000);
-  ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+// Diagnostic (tools, bench.py): delays_us[6] = the test above for (pre_mix -> gather), (pre_mix -> insert), (gather -> insert),
+// (caller -> pre_mix), (caller -> gather), (caller -> insert) streams: ~10 = separate hardware queues, >= 150 = one queue.
+extern "C" int link_dc_batch_probe_streams(link_dc_batch_t *c, hipStream_t caller, double *delays_us /* host [12] */) {
+  if (!c || !delays_us) return LINK_ERR_ARG;
+  unsigned long long *st = nullptr;
+  hipEvent_t ev;
+  if (hipMalloc(reinterpret_cast<void **>(&st), 16) != hipSuccess) return LINK_ERR_LAUNCH;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(st); return LINK_ERR_LAUNCH; }
+  hipStream_t xs[12] = {c->sa, c->sa, c->sb, caller, caller, caller, c->sb, c->sc, c->sc, c->sa, c->sb, c->sc},
+              ys[12] = {c->sb, c->sc, c->sc, c->sa, c->sb, c->sc, c->sa, c->sa, c->sb, caller, caller, caller};
+  bool ok = true;
+  for (int i = 0; i < 12; i++) ok = bt_queue_delay_us(xs[i], ys[i], st, ev, &delays_us[i]) && ok;
+  (void)hipEventDestroy(ev);
   (void)hipFree(st);
   if (!ok) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
-  for (int i = 0; i < 4; i++) starts_us[i] = ((double)h[i] - (double)h[0]) / 100.0;
   return LINK_OK;
 }
 
@@ -517,8 +572,40 @@ static int batch_launch(link_dc_batch *c, int q, const dc_bt_frames_t &fr, const
   return check_launch("link_elk_core_dense_forward_batch (K2)");
 }
 
-extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_dc_buffers_t *frames, const int64_t *n, int32_t nframes,
-                                                 const link_dc_grid_t *g, const link_elk_desc_t *d, void *stream) {
+// The call's counters are cleared by a kernel of this file, not by hipMemsetAsync (the runtime's fill goes through its blit path).
+__global__ void k_dc_batch_clear(int32_t *sync, int words) {
+  for (int i = threadIdx.x; i < words; i += blockDim.x) sync[i] = 0;
+}
+
+// A caller stream seen for the first time is tested against the pool (once: ~0.2 ms per pair, and it synchronises that stream); if it
+// shares a hardware queue with the pre_mix or the gather stream -- the join's waits in the caller's queue would then sit in front of
+// the next call's role kernels -- the roles move to two pool streams it does not share a queue with, behind a drain of the old ones
+// (the roles' kernels of consecutive calls must stay in stream order: one pre_mix and one gather workgroup per CU).
+static void bt_mind_caller(link_dc_batch *c, hipStream_t st) {
+  unsigned mask = 0;
+  bool known = false;
+  for (auto &e : c->callers) if (e.first == st) { mask = e.second; known = true; break; }
+  if (!known) {
+    for (size_t i = 0; i < c->pool.size(); i++)
+      if (bt_share_queue(st, c->pool[i], c->probe_scratch, c->probe_ev)) mask |= 1u << i;
+    if (c->callers.size() >= 16) c->callers.erase(c->callers.begin());
+    c->callers.emplace_back(st, mask);
+    if (getenv("LINK_DC_BATCH_DEBUG")) fprintf(stderr, "link_dc_batch: caller stream %p shares a hardware queue with pool streams mask 0x%x\n", (void *)st, mask);
+  }
+  if (!(mask & (1u << c->ia)) && !(mask & (1u << c->ib))) return;
+  int na = -1, nb = -1;
+  for (int i = 0; i < (int)c->pool.size(); i++)
+    if (!(mask & (1u << i))) { if (na < 0) na = i; else if (nb < 0) nb = i; }
+  if (na < 0 || nb < 0) return;                          // not two free queues: stay
+  (void)hipStreamSynchronize(c->sa); (void)hipStreamSynchronize(c->sb); (void)hipStreamSynchronize(c->sc);
+  c->ia = na; c->ib = nb; c->sa = c->pool[na]; c->sb = c->pool[nb];
+}
+
+// submit: everything of a call except making the caller's stream wait for its rows (link_dc_batch_join).  *ticket = the number of
+// the call's last launch set; the sets of a call run in order on the context's streams, so that set's three events cover the call.
+extern "C" int link_dc_batch_submit(link_dc_batch_t *c, const link_dc_buffers_t *frames, const int64_t *n, int32_t nframes,
+                                    const link_dc_grid_t *g, const link_elk_desc_t *d, void *stream, int64_t *ticket) {
+  if (ticket) *ticket = -1;
   if (!c || !g || !d || nframes < 0 || (nframes > 0 && (!frames || !n))) return LINK_ERR_ARG;
   if (nframes == 0) return LINK_OK;
   // what the quad-consumer K2 and the cell-range K1 serve (the caller runs anything else frame by frame)
@@ -539,6 +626,7 @@ extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return LINK_ERR_ARG;
   hipStream_t st = S(stream);
+  bt_mind_caller(c, st);
   const dc_bt_par_t p{b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, b0.ln_w, b0.ln_b, d->cg, d->eps, c->dbg1, c->dbg2};
   for (int base = 0; base < nframes; base += DC_BT_MAX) {
     const int nb = nframes - base < DC_BT_MAX ? nframes - base : DC_BT_MAX;
@@ -570,21 +658,48 @@ extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_
                hipStreamWaitEvent(c->sa, c->ev_a[r], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_a[r], 0) != hipSuccess;
     }
     int32_t *sync = c->sync + (size_t)q * BT_SYNC_WORDS;
-    fail = fail || hipMemsetAsync(sync, 0, sizeof(int32_t) * BT_SYNC_WORDS, c->sa) != hipSuccess || hipEventRecord(c->ev_ms[q], c->sa) != hipSuccess ||
+    if (!fail) hipLaunchKernelGGL(k_dc_batch_clear, dim3(1), dim3(256), 0, c->sa, sync, (int)BT_SYNC_WORDS);   // (not hipMemsetAsync: see k_dc_batch_clear)
+    fail = fail || hipEventRecord(c->ev_ms[q], c->sa) != hipSuccess ||
            hipStreamWaitEvent(c->sb, c->ev_ms[q], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_ms[q], 0) != hipSuccess;
     if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
     int rc;
     if (d->op == LINK_OP_COS) rc = d->r == 3 ? batch_launch<LINK_OP_COS, 3>(c, q, fr, p, *g, *d, nb, nmax) : batch_launch<LINK_OP_COS, 2>(c, q, fr, p, *g, *d, nb, nmax);
     else rc = d->r == 3 ? batch_launch<LINK_OP_SIN, 3>(c, q, fr, p, *g, *d, nb, nmax) : batch_launch<LINK_OP_SIN, 2>(c, q, fr, p, *g, *d, nb, nmax);
-    // whatever was launched must be joined, or the caller's stream would run ahead of it
-    fail = hipEventRecord(c->ev_a[q], c->sa) != hipSuccess || hipEventRecord(c->ev_c[q], c->sc) != hipSuccess || hipEventRecord(c->ev_out[q], c->sb) != hipSuccess ||
-           hipStreamWaitEvent(st, c->ev_a[q], 0) != hipSuccess || hipStreamWaitEvent(st, c->ev_c[q], 0) != hipSuccess ||
-           hipStreamWaitEvent(st, c->ev_out[q], 0) != hipSuccess;
+    // the set's completion events (what link_dc_batch_join, later calls on the same buffers and the ring slot's next user wait for)
+    fail = hipEventRecord(c->ev_a[q], c->sa) != hipSuccess || hipEventRecord(c->ev_c[q], c->sc) != hipSuccess || hipEventRecord(c->ev_out[q], c->sb) != hipSuccess;
     c->bufs[q] = keys;
     c->used[q] = true;
+    if (ticket) *ticket = c->calls;
     c->calls++;
-    if (rc != LINK_OK) return rc;
-    if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+    if (rc != LINK_OK || fail) {                         // whatever was launched is joined: the caller's stream must not run ahead of it
+      (void)hipStreamWaitEvent(st, c->ev_a[q], 0); (void)hipStreamWaitEvent(st, c->ev_c[q], 0); (void)hipStreamWaitEvent(st, c->ev_out[q], 0);
+      if (rc != LINK_OK) return rc;
+      (void)hipGetLastError();
+      return LINK_ERR_LAUNCH;
+    }
   }
   return LINK_OK;
+}
+
+// join: `stream` waits for the rows of the call `ticket` names (and of every earlier call of the context: its streams run their sets in
+// order).  A ticket older than the ring (BT_RING later sets have been submitted) names events a later set has re-recorded: waiting for
+// those waits for more, never for less.
+extern "C" int link_dc_batch_join(link_dc_batch_t *c, int64_t ticket, void *stream) {
+  if (!c || ticket < 0 || ticket >= c->calls) return LINK_ERR_ARG;
+  const int q = (int)(ticket % BT_RING);
+  hipStream_t st = S(stream);
+  if (hipStreamWaitEvent(st, c->ev_a[q], 0) != hipSuccess || hipStreamWaitEvent(st, c->ev_c[q], 0) != hipSuccess ||
+      hipStreamWaitEvent(st, c->ev_out[q], 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return LINK_ERR_LAUNCH;
+  }
+  return LINK_OK;
+}
+
+extern "C" int link_elk_core_dense_forward_batch(link_dc_batch_t *c, const link_dc_buffers_t *frames, const int64_t *n, int32_t nframes,
+                                                 const link_dc_grid_t *g, const link_elk_desc_t *d, void *stream) {
+  int64_t ticket = -1;
+  const int rc = link_dc_batch_submit(c, frames, n, nframes, g, d, stream, &ticket);
+  if (rc != LINK_OK || ticket < 0) return rc;            // (an error path has joined what it launched; nframes == 0 launched nothing)
+  return link_dc_batch_join(c, ticket, stream);
 }

@@ -598,9 +598,7 @@ class ElkCoreBatch:
                 b0.w_pre, b0.pre_ln_w, b0.pre_ln_b, b0.w_pos, None, b0.ln_w, b0.ln_b)
         return self
 
-    def run(self, feats, coords, outs=None, stream: Optional[int] = None):
-        """feats / coords: sequences of [n_i, C] fp32 rows and [n_i, 4] int32 coordinates (at most `frames` of them); `outs`:
-        optional result tensors.  Returns the list of result rows."""
+    def _fill(self, feats, coords, outs):
         k = len(feats)
         assert 0 < k <= len(self.plans) and len(coords) == k and (outs is None or len(outs) == k)
         res = []
@@ -616,6 +614,12 @@ class ElkCoreBatch:
             self._bufs[i] = b
             self._n[i] = n
             res.append(dst[:n])
+        return k, res
+
+    def run(self, feats, coords, outs=None, stream: Optional[int] = None):
+        """feats / coords: sequences of [n_i, C] fp32 rows and [n_i, 4] int32 coordinates (at most `frames` of them); `outs`:
+        optional result tensors.  Returns the list of result rows (complete in stream order)."""
+        k, res = self._fill(feats, coords, outs)
         p0 = self.plans[0]
         st = L.current_stream_handle() if stream is None else int(stream)
         rc = self._fn(self._ctx, self._bufs, self._n, k, ctypes.byref(p0.dcg), ctypes.byref(p0.desc), st)
@@ -624,6 +628,30 @@ class ElkCoreBatch:
         if L.DEBUG:
             self.check()
         return res
+
+    def submit(self, feats, coords, outs=None, stream: Optional[int] = None):
+        """`run` without the wait: enqueues the call behind what the stream holds and returns (result rows, ticket); the rows are NOT
+        ordered against the stream until `join(ticket)`.  Several calls in flight from one stream: submit call s + 1 (on another
+        batch object of the same context: its own arenas), then join call s -- the pre_mix role of s + 1 runs under the gather role of
+        s.  (`run` on two objects from two streams does the same only while the runtime keeps those two streams on different hardware
+        queues: link_dc_batch_submit in include/link_amd.h.)"""
+        k, res = self._fill(feats, coords, outs)
+        p0 = self.plans[0]
+        st = L.current_stream_handle() if stream is None else int(stream)
+        ticket = ctypes.c_int64(-1)
+        rc = L.lib().link_dc_batch_submit(self._ctx, self._bufs, self._n, k, ctypes.byref(p0.dcg), ctypes.byref(p0.desc), st, ctypes.byref(ticket))
+        if rc != 0:
+            L.check(rc, "link_dc_batch_submit")
+        return res, int(ticket.value)
+
+    def join(self, ticket: int, stream: Optional[int] = None) -> None:
+        """The stream waits for the rows of the call `ticket` names (a ticket of ANY batch object sharing this context)."""
+        st = L.current_stream_handle() if stream is None else int(stream)
+        rc = L.lib().link_dc_batch_join(self._ctx, int(ticket), st)
+        if rc != 0:
+            L.check(rc, "link_dc_batch_join")
+        if L.DEBUG:
+            self.check()
 
     def check(self) -> None:
         """Synchronises the context's streams; raises if a bounded wait inside a kernel gave up or a frame dropped a voxel."""
@@ -636,9 +664,10 @@ class ElkCoreBatch:
             p.check()
 
     def probe_streams(self, stream: Optional[int] = None):
-        """Diagnostic (link_dc_batch_probe_streams): start times (us) of one spin kernel on each role stream and on `stream`, relative to
-        the first -- values near 0 = side by side, steps of ~200 = streams sharing a hardware queue."""
-        out = (ctypes.c_double * 4)()
+        """Diagnostic (link_dc_batch_probe_streams): for the pairs (pre_mix -> gather), (pre_mix -> insert), (gather -> insert),
+        (stream -> pre_mix), (stream -> gather), (stream -> insert) how long a kernel on the second stream is held up by a 150 us kernel
+        + event record on the first: ~10 us = separate hardware queues, >= 150 = the two share one."""
+        out = (ctypes.c_double * 12)()
         L.check(L.lib().link_dc_batch_probe_streams(self._ctx, stream if stream is not None else _st(), out), "link_dc_batch_probe_streams")
         return [round(float(v), 1) for v in out]
 

@@ -322,7 +322,7 @@ def test_batch_kernels_resource_shape():
     from kernel_regs import kernel_table
     from link_amd import build as hip_build
     hip_build.build()
-    rows = [r for r in kernel_table(os.path.join(ROOT, "link_amd", "lib", "obj", "dense_batch.o")) if "k_dc_batch" in r[0] and "k_dc_batch_spin" not in r[0]]
+    rows = [r for r in kernel_table(os.path.join(ROOT, "link_amd", "lib", "obj", "dense_batch.o")) if "k_dc_batch" in r[0] and "k_dc_batch_spin" not in r[0] and "k_dc_batch_clear" not in r[0]]
     assert len(rows) == 7, [r[0] for r in rows]                           # insert + K1 x {cos, sin} + K2 x {cos, sin} x {r 2, 3}
     al = lambda v: (int(v) + 7) // 8 * 8                                     # vector registers are allocated in eights
     ins = [r for r in rows if "insert" in r[0]]

@@ -147,3 +147,37 @@ def test_batch_longer_than_one_launch_set():
     outs = batch.run([f for f, _ in frames], [co for _, co in frames])
     batch.check()
     assert all(torch.equal(outs[i], ref[i]) for i in range(K))
+
+
+def test_submit_then_join_from_one_stream_keeps_two_calls_in_flight():
+    """link_dc_batch_submit / link_dc_batch_join: call s + 1 submitted before call s is joined, all from ONE stream, two batch objects on
+    one context; rows bit-equal to the per-frame path; a consumer kernel queued on the stream after join(s) sees call s complete; a
+    ticket that does not exist is refused."""
+    import link_amd as la
+    from link_amd import _lib as L
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 20000, 6
+    blk = _block(C, "cos", dev)
+    bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
+    frames = _frames(2 * K, N, C, dev, seed0=70)
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    a = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev), blk)
+    b = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev, share=a), blk)
+    sets = [([f for f, _ in frames[:K]], [co for _, co in frames[:K]]), ([f for f, _ in frames[K:]], [co for _, co in frames[K:]])]
+    copies, prev = [], None
+    for s in range(6):                                                       # a, b, a, b, ... : s + 1 submitted before s is joined
+        obj, (fs, cs) = (a, b)[s % 2], sets[s % 2]
+        res, tk = obj.submit(fs, cs)
+        if prev is not None:
+            a.join(prev[1])
+            copies.append((prev[2], [r.clone() for r in prev[0]]))           # clones are queued on the stream behind the join
+        prev = (res, tk, s % 2)
+    a.join(prev[1])
+    copies.append((prev[2], [r.clone() for r in prev[0]]))
+    torch.cuda.synchronize()
+    a.check()
+    for which, rows in copies:
+        assert all(torch.equal(rows[i], ref[which * K + i]) for i in range(K))
+    assert L.lib().link_dc_batch_join(a._ctx, 10 ** 6, L.current_stream_handle()) == L.LINK_ERR_ARG
+

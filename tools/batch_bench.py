@@ -69,10 +69,31 @@ def t_batch(k):
     return 1e6 * (time.perf_counter() - t0) / (k * B)
 
 
-t_streams(10); t_batch(10)
+def t_submit(k):
+    """the same calls from ONE stream: submit call s + 1, then join call s (link_dc_batch_submit / link_dc_batch_join)"""
+    one = pstreams[0].cuda_stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prev = None
+    for s in range(k):
+        j = s % SETS
+        _, tk = batches[j].submit(bf[j], bc[j], stream=one)
+        if prev is not None and SETS > 1:
+            batches[0].join(prev, stream=one)
+        prev = tk
+        if SETS == 1:
+            batches[0].join(tk, stream=one)
+    if SETS > 1:
+        batches[0].join(prev, stream=one)
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / (k * B)
+
+
+t_streams(10); t_batch(10); t_submit(10)
 for p in range(PASSES):
-    print(f"pass {p}: three plans on three streams {t_streams(STEPS):.2f} us/frame | batch of {B} x {SETS} set(s) {t_batch(STEPS):.2f} us/frame", flush=True)
+    print(f"pass {p}: three plans on three streams {t_streams(STEPS):.2f} us/frame | batch of {B} x {SETS} set(s), two caller streams {t_batch(STEPS):.2f} | "
+          f"submit / join from one stream {t_submit(STEPS):.2f} us/frame", flush=True)
 batches[0].check()
-print("stream starts (pre_mix, gather, insert, caller):", [batches[0].probe_streams(b.cuda_stream) for b in bstreams], "frame streams",
+print("queue delays (pre_mix->gather, pre_mix->insert, gather->insert, caller->pre_mix, caller->gather, caller->insert):", [batches[0].probe_streams(b.cuda_stream) for b in bstreams], "frame streams",
       [batches[0].probe_streams(s.cuda_stream) for s in pstreams])
 print("status ok")
