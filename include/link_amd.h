@@ -961,7 +961,7 @@ int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
  * LINK_OK), ignored by the default build (returns 1). */
 int link_dc_batch_set_debug(link_dc_batch_t *ctx, uint64_t *k1_rows, uint64_t *k2_rows);
 /* Diagnostic: does a pair of streams sit on ONE hardware queue (GPU_MAX_HW_QUEUES; an event record on one stream then holds up the
- * other's kernels)?  A 150 us spin kernel + an event record on the first stream, a stamp kernel on the second; delays_us[6] = the
+ * other's kernels)?  A 150 us spin kernel + an event record on the first stream, a stamp kernel on the second; delays_us[12] = the
  * second's start behind the first's for (pre_mix -> gather), (pre_mix -> insert), (gather -> insert), (stream -> pre_mix),
  * (stream -> gather), (stream -> insert) and the six reverse pairs: ~5 = separate queues, >= 150 = one queue.  Synchronises the
  * streams involved.  (link_dc_batch_create runs the same test to put its role streams on queues of their own.) */
