@@ -866,7 +866,8 @@ def main():
     # measurement alternated two caller streams instead, and read 37 or 50 us / frame depending on the streams it happened to get: two
     # streams the runtime multiplexes onto one hardware queue serialise the calls (the wait of one stream's call sits in front of the
     # other's submission; tools/batch_overlap.py shows call s + 1 starting when call s has ended).  What is left of the placement is
-    # measured: LINK_BENCH_BATCH_TRIALS contexts (default 3) on the SAME arenas, 2 x 20 calls each, the fastest kept, every trial in the line.
+    # measured: ElkCoreBatch.calibrate -- LINK_BENCH_BATCH_TRIALS contexts (default 3) on the SAME arenas, 2 x 20 calls each, the fastest kept,
+    # every trial in the line.
     for j_ in range(NS):                   # the frame streams' first use comes BEFORE the trials: the runtime binds a stream to a hardware queue
         with torch.cuda.stream(streams[j_]):   # when it is first used, and the headline's placement must not depend on a side measurement
             plans[j_].run(*frames[j_])
@@ -900,23 +901,9 @@ def main():
                         blk.norm.bias)
             bfe0, bco0 = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
             bstream = torch.cuda.Stream(device=dev)
-            best = None
-            for trial in range(n_trials):
-                if trial:
-                    bsets[0].new_context()
-                    bsets[1].adopt_context(bsets[0])
-                batch_calls(20, bstream)
-                t_trial = 1e6 * batch_calls(20, bstream) / (20 * FB)
-                btrials.append(round(t_trial, 2))
-                if os.environ.get("LINK_BENCH_BATCH_PROBE") == "1":
-                    print(f"[batch trial {trial}] {t_trial:.2f} us/frame; queue delays (pre_mix->gather, pre_mix->insert, gather->insert, caller->pre_mix, "
-                          f"caller->gather, caller->insert) {bsets[0].probe_streams(bstream.cuda_stream)}", file=sys.stderr, flush=True)
-                if best is None or t_trial < best[0]:
-                    best = (t_trial, bsets[0].release_context())
-                else:
-                    bsets[0].release_context(destroy=True)
-            bsets[0].install_context(best[1])
-            bsets[1].adopt_context(bsets[0])
+            btrials = bsets[0].calibrate(bfe0, bco0, partner=bsets[1], tries=n_trials, calls=20, stream=bstream.cuda_stream)
+            if os.environ.get("LINK_BENCH_BATCH_PROBE") == "1":
+                print(f"[batch trials] {btrials} us/frame; queue delays of the kept context {bsets[0].probe_streams(bstream.cuda_stream)}", file=sys.stderr, flush=True)
         except Exception as e:  # noqa: BLE001
             bsets = repr(e)[:200]
 

@@ -181,3 +181,29 @@ def test_submit_then_join_from_one_stream_keeps_two_calls_in_flight():
         assert all(torch.equal(rows[i], ref[which * K + i]) for i in range(K))
     assert L.lib().link_dc_batch_join(a._ctx, 10 ** 6, L.current_stream_handle()) == L.LINK_ERR_ARG
 
+
+def test_calibrate_keeps_a_working_context_and_the_rows():
+    """ElkCoreBatch.calibrate: a few contexts measured on the batch's own arenas, the fastest kept (for both objects of a pair); the rows
+    afterwards are still the per-frame path's, bit for bit; a shared (non-owning) batch refuses to calibrate."""
+    import link_amd as la
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 12000, 4
+    blk = _block(C, "cos", dev)
+    bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
+    frames = _frames(K, N, C, dev, seed0=90)
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    a = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev), blk)
+    b = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev, share=a), blk)
+    fs, cs = [f for f, _ in frames], [co for _, co in frames]
+    rates = a.calibrate(fs, cs, partner=b, tries=3, calls=6)
+    assert len(rates) == 3 and all(r > 0 for r in rates) and b._ctx.value == a._ctx.value
+    for obj in (a, b):
+        outs = obj.run(fs, cs)
+        torch.cuda.synchronize()
+        obj.check()
+        assert all(torch.equal(outs[i], ref[i]) for i in range(K))
+    from link_amd import _lib as L
+    with pytest.raises(L.LinkAmdError):
+        b.calibrate(fs, cs)
+
