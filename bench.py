@@ -858,7 +858,10 @@ def main():
         pl.bind(blk.pre_mix[0].weight, blk.pre_mix[1].weight, blk.pre_mix[1].bias, blk.pos_weight[0].weight,
                 None, blk.norm.weight, blk.norm.bias)
         plans.append(pl)
-        streams.append(torch.cuda.Stream(device=dev))
+    # the frame streams: NS streams on hardware queues of their own (two streams the runtime puts on one queue run their frames one after
+    # the other -- the single-stream rate; one of six triples of consecutive torch streams did, tools/stream_placement.py)
+    from link_amd.parallel import streams_on_own_queues
+    streams, frame_stream_check = streams_on_own_queues(NS, dev)
     feats, coords = frames[0]
     plan = plans[0]
     # The batch entry point (side measurement at the end, `batch_entry_point`).  Two calls are kept in flight on two arena sets: call s + 1
@@ -1316,6 +1319,7 @@ def main():
                                  "LINK_BENCH_PIN=0/1 overrides"},
         "multi_gpu": multi,          # N > 1 only: backend, all_reduce check, end-to-end time, full-tensor gather
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
+        "frame_streams": frame_stream_check,         # the NS frame streams sit on hardware queues of their own (link_streams_share_queue)
     }
     # ---- the BATCH entry point (include/link_amd.h section H; round 6): the same frames as batches of NS * ROUNDS through
     # link_elk_core_dense_forward_batch -- one insert kernel + two persistent, queue-fed role kernels per call -- two arena sets

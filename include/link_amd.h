@@ -960,6 +960,10 @@ int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
  * rows so far, zeroed by the caller; word 1 = capacity in rows).  Honoured by a -DDC_BT_PROF=1 build of csrc/dense_batch.hip (returns
  * LINK_OK), ignored by the default build (returns 1). */
 int link_dc_batch_set_debug(link_dc_batch_t *ctx, uint64_t *k1_rows, uint64_t *k2_rows);
+/* Do two streams of the caller sit on ONE hardware queue?  *delay_us = how long a kernel on `b` is held up by a 150 us kernel + event
+ * record on `a`: ~5 = queues of their own, >= 150 = one queue (frames kept in flight on two such streams run one after the other).
+ * Synchronises both streams. */
+int link_streams_share_queue(void *stream_a, void *stream_b, double *delay_us /* host, out */);
 /* Diagnostic: does a pair of streams sit on ONE hardware queue (GPU_MAX_HW_QUEUES; an event record on one stream then holds up the
  * other's kernels)?  A 150 us spin kernel + an event record on the first stream, a stamp kernel on the second; delays_us[12] = the
  * second's start behind the first's for (pre_mix -> gather), (pre_mix -> insert), (gather -> insert), (stream -> pre_mix),

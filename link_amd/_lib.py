@@ -259,6 +259,7 @@ SIGNATURES = {
     "link_dc_batch_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "link_dc_batch_set_debug": (c_int, [c_void_p, c_void_p, c_void_p]),
     "link_dc_batch_probe_streams": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_double)]),
+    "link_streams_share_queue": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_double)]),
     "link_elk_mid_backward": (c_int, [c_void_p] * 9 + [POINTER(LinkGrid), c_void_p, c_void_p, c_void_p,
                                       POINTER(LinkElkDesc), c_int64, c_int64] + [c_void_p] * 5),
 }

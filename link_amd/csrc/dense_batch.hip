@@ -482,6 +482,22 @@ extern "C" int link_dc_batch_set_debug(link_dc_batch_t *c, uint64_t *k1_rows, ui
   return DC_BT_PROF ? LINK_OK : 1;
 }
 
+// The same test for any two streams of the caller (a serving loop that keeps frames in flight on several streams wants them on hardware
+// queues of their own: two of bench.py's six candidate triples ran at the single-stream rate, tools/stream_placement.py).
+// *delay_us: a kernel on `b` behind a 150 us kernel + event record on `a` -- ~5 = separate queues, >= 150 = one queue.  Synchronises both.
+extern "C" int link_streams_share_queue(void *a, void *b, double *delay_us) {
+  if (!delay_us) return LINK_ERR_ARG;
+  unsigned long long *st = nullptr;
+  hipEvent_t ev;
+  if (hipMalloc(reinterpret_cast<void **>(&st), 16) != hipSuccess) return LINK_ERR_LAUNCH;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(st); return LINK_ERR_LAUNCH; }
+  const bool ok = bt_queue_delay_us(S(a), S(b), st, ev, delay_us);
+  (void)hipEventDestroy(ev);
+  (void)hipFree(st);
+  if (!ok) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+  return LINK_OK;
+}
+
 // Diagnostic (tools, bench.py): delays_us[6] = the test above for (pre_mix -> gather), (pre_mix -> insert), (gather -> insert),
 // (caller -> pre_mix), (caller -> gather), (caller -> insert) streams: ~10 = separate hardware queues, >= 150 = one queue.
 extern "C" int link_dc_batch_probe_streams(link_dc_batch_t *c, hipStream_t caller, double *delays_us /* host [12] */) {

@@ -114,3 +114,30 @@ def gather_frame_rows(rows: torch.Tensor) -> torch.Tensor:
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def streams_on_own_queues(n: int, device, max_extra: int = 9):
+    """`n` torch streams that sit on pairwise different hardware queues (include/link_amd.h: link_streams_share_queue -- the runtime
+    multiplexes streams onto a few queues, and frames kept in flight on two streams of one queue run one after the other: one of six
+    triples of consecutive torch streams did, tools/stream_placement.py).  Streams are drawn from torch's pool until `n` pass the test
+    pair by pair (at most `max_extra` rejects; then the best effort so far).  Returns (streams, record) -- record: the delays measured
+    between the kept streams (us; ~5 = own queues) and how many candidates were passed over.  Synchronises the streams it tests."""
+    import ctypes
+    from . import _lib as L
+    lib = L.lib()
+    kept, rejected, delays = [], 0, []
+    while len(kept) < n:
+        s = torch.cuda.Stream(device=device)
+        worst = 0.0
+        for k in kept:
+            d = ctypes.c_double(0.0)
+            L.check(lib.link_streams_share_queue(k.cuda_stream, s.cuda_stream, ctypes.byref(d)), "link_streams_share_queue")
+            worst = max(worst, float(d.value))
+        if worst > 75.0 and rejected < max_extra:
+            rejected += 1
+            continue
+        kept.append(s)
+        delays.append(round(worst, 1))
+    return kept, {"max_delay_us_to_earlier_kept_stream": delays, "candidates_passed_over": rejected,
+                  "note": "a kernel on the stream behind a 150 us kernel + event record on an earlier kept stream: ~5 us = hardware queues of their own"}
+

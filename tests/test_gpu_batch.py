@@ -207,3 +207,23 @@ def test_calibrate_keeps_a_working_context_and_the_rows():
     with pytest.raises(L.LinkAmdError):
         b.calibrate(fs, cs)
 
+
+def test_streams_on_own_queues_and_the_queue_test():
+    """link_streams_share_queue: a stream against itself is one queue by definition (>= 150 us: the stamp kernel sits behind the spin
+    kernel and its event record); streams_on_own_queues hands out streams that pass the test pair by pair."""
+    import ctypes
+    from link_amd import _lib as L
+    from link_amd.parallel import streams_on_own_queues
+    dev = torch.device("cuda:0")
+    s = torch.cuda.Stream(device=dev)
+    d = ctypes.c_double(0.0)
+    assert L.lib().link_streams_share_queue(s.cuda_stream, s.cuda_stream, ctypes.byref(d)) == 0 and d.value >= 140.0
+    kept, rec = streams_on_own_queues(3, dev)
+    assert len(kept) == 3 and len({k.cuda_stream for k in kept}) == 3
+    if rec["candidates_passed_over"] < 9:
+        assert max(rec["max_delay_us_to_earlier_kept_stream"]) < 75.0
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert L.lib().link_streams_share_queue(kept[i].cuda_stream, kept[j].cuda_stream, ctypes.byref(d)) == 0
+            assert d.value < 75.0 or rec["candidates_passed_over"] >= 9
+

@@ -62,6 +62,8 @@ def test_bench_two_ranks_over_gloo_on_one_device():
         assert abs(v["frac"] - v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 8e12) < 2e-4, k
         assert v["live_event_us_this_run"] > 0
     assert rl["kernel"] == tg["kernels"][tg["dominant"]]["rocprof_name"]
+    fs = single["frame_streams"]                       # the three frame streams were tested pair by pair for hardware queues of their own
+    assert len(fs["max_delay_us_to_earlier_kept_stream"]) == 3 and max(fs["max_delay_us_to_earlier_kept_stream"]) < 75.0
     assert [r["rank"] for r in single["cpu_affinity"]["ranks"]] == [0] and [r["rank"] for r in d["cpu_affinity"]["ranks"]] == [0, 1]
     # side measurement: the same frames through the batch entry point (one insert + two persistent role kernels per call)
     be = single["batch_entry_point"]

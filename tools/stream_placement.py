@@ -35,7 +35,18 @@ def timed(streams, k):
     return 1e6 * (time.perf_counter() - t0) / (k * NS)
 
 
+import ctypes
+from link_amd import _lib as L
+
+
+def share(a, b):
+    d = ctypes.c_double(0.0)
+    L.check(L.lib().link_streams_share_queue(a.cuda_stream, b.cuda_stream, ctypes.byref(d)), "link_streams_share_queue")
+    return round(d.value, 1)
+
+
 for t in triples:
     timed(t, 100)
+print("queue test per triple (0>1, 0>2, 1>2; us: ~5 = own queues, >= 150 = one queue):", [[share(t[0], t[1]), share(t[0], t[2]), share(t[1], t[2])] for t in triples])
 for p_ in range(PASSES):
     print(f"pass {p_}: " + "  ".join(f"{timed(t, STEPS):.2f}" for t in triples), flush=True)
