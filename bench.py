@@ -1246,7 +1246,8 @@ def main():
                                     "sum_of_launches_over_frames_in_flight_us": round(sum(v["avg_us"] for v in tg_kern.values()) / NS, 2),
                                     "frac_if_the_launches_tiled_without_gaps": round(ab["total"] / (sum(v["avg_us"] for v in tg_kern.values()) / NS * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                     "note": "frac = alg_bytes_per_launch / (avg_us of the committed CSV) / 8 TB/s; live_event_us_this_run = the same "
-                                            "launch bracketed by HIP events on its stream in an instrumented replay of the timed geometry.  The launches "
+                                            "launch bracketed by HIP events on its stream in an instrumented replay of the timed geometry (the bracket holds the stream-ordered "
+                                            "launch boundary too: 3-6 us more than the kernel's own duration in the trace).  The launches "
                                             "of the frames in flight share the chip (about three are running at any moment), so a launch's OWN fraction "
                                             "is about a third of what the chip sustains meanwhile: the region's fraction is `roofline.frac`, and the sum "
                                             "of the three launch durations over the frames in flight is its lower bound for these kernels"}
