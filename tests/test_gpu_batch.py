@@ -227,3 +227,26 @@ def test_streams_on_own_queues_and_the_queue_test():
             assert L.lib().link_streams_share_queue(kept[i].cuda_stream, kept[j].cuda_stream, ctypes.byref(d)) == 0
             assert d.value < 75.0 or rec["candidates_passed_over"] >= 9
 
+
+@pytest.mark.parametrize("K", [1, 48, 49, 193])
+def test_batch_sizes_around_the_launch_set_and_the_ring(K):
+    """One frame; exactly one launch set (48); one frame more; five sets in ONE call (193 frames: the ring of four sync areas wraps inside
+    the call) -- every frame bit-equal to the per-frame path, and the same again on a second call (arenas and ring slots reused)."""
+    import link_amd as la
+    dev = torch.device("cuda:0")
+    C, N = 64, 1500
+    blk = _block(C, "cos", dev)
+    bounds = ((0, 0, 0, 0), (63, 63, 63, 0))
+    frames = [(torch.randn(N - 7 * (i % 5), C, generator=torch.Generator().manual_seed(300 + i)).to(dev),
+               s_uniform(N - 7 * (i % 5), grid=64, seed=200 + i).to(dev)) for i in range(K)]
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0, slot_cap=64), blk)
+    ref = [plan.run(f, co).clone() for f, co in frames]
+    batch = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev, slot_cap=64), blk)
+    for _ in range(2):
+        outs = batch.run([f for f, _ in frames], [co for _, co in frames])
+        torch.cuda.synchronize()
+        batch.check()
+        assert all(torch.equal(outs[i], ref[i]) for i in range(K))
+        for o in outs:
+            o.zero_()
+
