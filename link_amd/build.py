@@ -20,7 +20,9 @@ SO = os.path.join(LIBDIR, "liblink_amd.so")
 SOURCES = ["ops.hip", "index.hip", "aggregate.hip", "elk.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "dense.hip", "dense_fused.hip", "dense_fused_f16.hip", "dense_fused_bf16.hip",
            "dense_tiles.hip", "dense_tiles_f16.hip", "dense_tiles_bf16.hip", "elk_tiles.hip", "elk_tiles_f16.hip", "elk_tiles_bf16.hip",
            "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip", "block.hip", "dense_batch.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+# --offload-compress: the gfx950 code objects are stored compressed in the fat binary (25.4 -> 6.1 MB; the HIP runtime inflates them when
+# the library is loaded: +0.2 s on the first call of a process, measured on the GPU box)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--offload-compress", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("LINK_AMD_CXXFLAGS", "").split()      # A/B experiments (-DNAME=value); part of the build stamp
 

@@ -33,8 +33,8 @@ def kernel_table(path):
                               stderr=subprocess.DEVNULL)
         blob = open(fat, "rb").read()
         # a shared library concatenates the fat binaries of its objects: split at the bundler magic
-        magic = b"__CLANG_OFFLOAD_BUNDLE__"
-        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        # (plain bundles start with the bundler's magic, compressed ones -- hipcc --offload-compress -- with "CCOB"; the bundler inflates them itself)
+        starts = sorted(m.start() for m in re.finditer(rb"__CLANG_OFFLOAD_BUNDLE__|CCOB", blob))
         rows = []
         for i, s in enumerate(starts):
             part = os.path.join(td, f"part{i}.bin")
