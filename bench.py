@@ -337,6 +337,9 @@ def core_roofline(torch, blocks, step, iters=20):
     # to the warm-index time, HIP events over back-to-back steps
     from link_amd.elk import ElkCorePlan
     from link_amd.index import coords_bounds
+    from link_amd.parallel import streams_on_own_queues
+    n_inflight = max(2, int(os.environ.get("LINK_BENCH_LIDAR_INFLIGHT", "3")))
+    inflight_streams, _ = streams_on_own_queues(n_inflight, blocks[0].norm.weight.device)
 
     def plan_times(i):
         coords, feats, s_eff, r, w_pos, alpha, cg, coord_div = rec[i]["call"]
@@ -387,17 +390,49 @@ def core_roofline(torch, blocks, step, iters=20):
                 del plan2
             except Exception as e:  # noqa: BLE001
                 out["batch2"] = {"error": repr(e)[:120]}
+            # ... and THREE frames in flight (three arenas, three streams on hardware queues of their own), as the headline keeps them:
+            # the launches of a LiDAR stage frame are latency-bound, so the launches of other frames fit beside them
+            try:
+                plans3 = [plan]
+                for _ in range(n_inflight - 1):
+                    p3 = ElkCorePlan(feats.shape[0], feats.shape[1], b.baseop, cg, r, s_eff, coords_bounds(coords), feats.device, coord_div=coord_div, **kw)
+                    p3.bind(b.pre_mix[0].weight, b.pre_mix[1].weight, b.pre_mix[1].bias, w_pos, alpha, b.norm.weight, b.norm.bias)
+                    plans3.append(p3)
+                main = torch.cuda.current_stream()
+
+                def burst(k_):
+                    for s_ in inflight_streams:
+                        s_.wait_stream(main)
+                    for _ in range(k_):
+                        for j_, p3 in enumerate(plans3):
+                            p3.run(feats, coords, build_index=True, stream=inflight_streams[j_].cuda_stream)
+                    for s_ in inflight_streams:
+                        main.wait_stream(s_)
+                burst(5)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                burst(40)
+                e1.record()
+                torch.cuda.synchronize()
+                for p3 in plans3:
+                    p3.check()
+                o_a, o_b = plans3[0].run(feats, coords, build_index=True).clone(), plans3[-1].run(feats, coords, build_index=True)
+                out["inflight3"] = {"frames_in_flight": n_inflight, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / (40 * n_inflight), 2), "rows_identical_across_arenas": bool(torch.equal(o_a, o_b))}
+                del plans3[1:]
+            except Exception as e:  # noqa: BLE001
+                out["inflight3"] = {"error": repr(e)[:120]}
             out["launches_rebuilt"] = 3 if form == "lean" else (6 if getattr(plan, "tiles", False) else 8)
             out["by_form"] = dict(best["by_form"]) if best else {}
             out["by_form"][form] = {"rebuilt_us": round(out["rebuilt"], 2), "warm_us": round(out["warm"], 2),
-                                    "launches_rebuilt": out["launches_rebuilt"], "batch_of_2_rebuilt": out.get("batch2")}
+                                    "launches_rebuilt": out["launches_rebuilt"], "batch_of_2_rebuilt": out.get("batch2"),
+                                    "three_frames_in_flight_rebuilt": out.get("inflight3")}
             if best is None or out["rebuilt"] < best["rebuilt"]:
                 best = out
             else:
                 best["by_form"] = out["by_form"]
             del plan
         return best
-    stages, tot_b, tot_t, tot_reb, tot_b2 = [], 0.0, 0.0, 0.0, 0.0
+    stages, tot_b, tot_t, tot_reb, tot_b2, tot_f3 = [], 0.0, 0.0, 0.0, 0.0, 0.0
     for i, r_ in enumerate(rec):
         m = r_["meta"]
         v = sorted(1e3 * a.elapsed_time(b) for a, b in r_["ev"])
@@ -419,6 +454,12 @@ def core_roofline(torch, blocks, step, iters=20):
                 st_row["plan_us_rebuilt_index_batch_of_2_per_frame"] = min(b2)
                 st_row["frac_rebuilt_index_batch_of_2"] = round(alg / (min(b2) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 tot_b2 += min(b2)
+            f3 = [v["three_frames_in_flight_rebuilt"]["us_per_frame"] for v in pt["by_form"].values()
+                  if v.get("three_frames_in_flight_rebuilt") and "us_per_frame" in v["three_frames_in_flight_rebuilt"]]
+            if f3:
+                st_row["plan_us_rebuilt_index_3_in_flight_per_frame"] = min(f3)
+                st_row["frac_rebuilt_index_3_in_flight"] = round(alg / (min(f3) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                tot_f3 += min(f3)
         stages.append(st_row)
         tot_b += alg
         tot_t += us
@@ -433,6 +474,10 @@ def core_roofline(torch, blocks, step, iters=20):
             "rebuilt_index_batch_of_2": ({"us_per_frame": round(tot_b2, 2), "frac": round(tot_b / (tot_b2 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "the same, two frames per launch set (the reference's batch size), best form per stage, per frame"}
                                          if tot_b2 else None),
+            "rebuilt_index_three_frames_in_flight": ({"us_per_frame": round(tot_f3, 2), "frac": round(tot_b / (tot_f3 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                      "note": "the same with three frames in flight per stage (three arenas, three streams on hardware queues of "
+                                                              "their own -- how the cfg2 headline keeps its frames), best form per stage, per frame"}
+                                                     if tot_f3 else None),
             "stages": stages}
 
 
