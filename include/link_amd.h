@@ -932,10 +932,12 @@ int link_elk_block_forward(link_block_ctx_t *ctx, link_block_args_t *args /* hos
  * Contract: C = 64, cg = 32 (two-part rows whose channels j and j + 32 share theta), op cos / sin, r in {2, 3}, coord_div = 1, no
  * alpha, fp32 rows, slot capacity <= 352, every frame its own cnt / slots / vcell / cell_n / S / hdr / out -- LINK_ERR_ARG otherwise
  * (nothing launched; the caller runs the frames through section E one by one).  frames[i].tune is not read (the geometry is the
- * roles': workgroups = CUs, 2 z-segments).  The call returns when everything is ENQUEUED; the results are complete in `stream`
+ * roles': workgroups = CUs, whole columns per gather tile).  The call returns when everything is ENQUEUED; the results are complete in `stream`
  * order.  Calls whose frames share no buffers overlap on the device (K1 of the next batch starts under K2 of the previous one):
- * a caller that keeps two batches in flight alternates two sets of frame buffers and two streams.  The context owns three
- * non-blocking streams, 20 events and 19 KB of counters; create one per device (and per host thread).
+ * a caller that keeps two batches in flight alternates two sets of frame buffers and submits call s + 1 before it joins call s
+ * (link_dc_batch_submit / link_dc_batch_join below).  Up to 48 frames form one launch set; a longer call runs as consecutive sets.  The
+ * context owns up to five non-blocking streams (drawn at creation so that the roles sit on hardware queues of their own), 21 events
+ * and 29 KB of counters; create one per device (and per host thread).
  * link_dc_batch_status synchronises the context's streams and returns LINK_BATCH_TIMEOUT if a bounded wait inside a kernel gave
  * up (the frames' rows are then undefined), LINK_OK otherwise; out[0] = the first error word, out[1] = launch sets so far.
  * ============================================================================================= */
