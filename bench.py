@@ -939,7 +939,7 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0_
 
-    if plan.dense and C == 64 and G == 2 and args.io == "f32" and world == 1 and n_trials > 0:
+    if plan.dense and C == 64 and G == 2 and world == 1 and n_trials > 0:
         try:
             FB = int(os.environ.get("LINK_BENCH_BATCH_FRAMES", "48"))   # frames per call: 48 = one launch set of the entry point (two steps' worth of frames)
             bsets = [la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)]

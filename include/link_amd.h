@@ -930,7 +930,7 @@ int link_elk_block_forward(link_block_ctx_t *ctx, link_block_args_t *args /* hos
  * Results: those of link_elk_core_dense_forward(build_index = 1) per frame, bit for bit.
  *
  * Contract: C = 64, cg = 32 (two-part rows whose channels j and j + 32 share theta), op cos / sin, r in {2, 3}, coord_div = 1, no
- * alpha, fp32 rows, slot capacity <= 352, every frame its own cnt / slots / vcell / cell_n / S / hdr / out -- LINK_ERR_ARG otherwise
+ * alpha, fp32 / fp16 / bf16 rows (io_dtype: one type for all frames of a call), slot capacity <= 352, every frame its own cnt / slots / vcell / cell_n / S / hdr / out -- LINK_ERR_ARG otherwise
  * (nothing launched; the caller runs the frames through section E one by one).  frames[i].tune is not read (the geometry is the
  * roles': workgroups = CUs, whole columns per gather tile).  The call returns when everything is ENQUEUED; the results are complete in `stream`
  * order.  Calls whose frames share no buffers overlap on the device (K1 of the next batch starts under K2 of the previous one):

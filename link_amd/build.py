@@ -19,7 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 SO = os.path.join(LIBDIR, "liblink_amd.so")
 SOURCES = ["ops.hip", "index.hip", "aggregate.hip", "elk.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "dense.hip", "dense_fused.hip", "dense_fused_f16.hip", "dense_fused_bf16.hip",
            "dense_tiles.hip", "dense_tiles_f16.hip", "dense_tiles_bf16.hip", "elk_tiles.hip", "elk_tiles_f16.hip", "elk_tiles_bf16.hip",
-           "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip", "block.hip", "dense_batch.hip"]
+           "elk_lean.hip", "elk_lean_f16.hip", "elk_lean_bf16.hip", "block.hip", "dense_batch.hip", "dense_batch_f16.hip", "dense_batch_bf16.hip"]
 # --offload-compress: the gfx950 code objects are stored compressed in the fat binary (25.4 -> 6.1 MB; the HIP runtime inflates them when
 # the library is loaded: +0.2 s on the first call of a process, measured on the GPU box)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--offload-compress", "-I" + os.path.join(ROOT, "include"),

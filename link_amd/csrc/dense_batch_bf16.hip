@@ -1,0 +1,5 @@
+// link_amd/csrc/dense_batch_bf16.hip -- the batch entry point's kernels with bf16 feature rows at the kernel boundary
+// (dense_batch_impl.h; fp32 everywhere inside).  The host side is dense_batch.hip.
+#define DC_IO 2
+#define DC_IO_NS dcb_bf16
+#include "dense_batch_impl.h"

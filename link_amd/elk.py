@@ -521,7 +521,7 @@ class ElkCoreBatch:
 
     `frames` arenas (ElkCorePlan buffers, dense-cell layout) are allocated once; `run(feats_list, coords_list)` takes up to that many
     frames and returns their result rows (views of the arenas' `out` buffers, complete in stream order).  Results are bit for bit
-    those of `ElkCorePlan.run` per frame.  C = 64, cg = 32, cos / sin, r in {2, 3}, fp32 rows, coord_div = 1, no alpha, slot capacity
+    those of `ElkCorePlan.run` per frame.  C = 64, cg = 32, cos / sin, r in {2, 3}, fp32 / fp16 / bf16 rows (one type per call), coord_div = 1, no alpha, slot capacity
     <= 352 -- LinkAmdError otherwise (run such frames through ElkCorePlan).  Two batches in flight: two ElkCoreBatch objects sharing
     ONE context (`ElkCoreBatch(..., share=first)`), alternated with two streams -- the pre_mix role of the second batch starts
     under the gather role of the first.  `check()` raises if a voxel was dropped or a kernel's bounded wait gave up."""
@@ -646,15 +646,25 @@ class ElkCoreBatch:
         k = len(feats)
         assert 0 < k <= len(self.plans) and len(coords) == k and (outs is None or len(outs) == k)
         res = []
+        dt = feats[0].dtype
+        assert dt in _IO_DTYPES, "fp32, fp16 or bf16 rows"
         for i in range(k):
             f, co, p = feats[i], coords[i], self.plans[i]
             n = f.shape[0]
-            assert 0 < n <= self.n_cap and f.shape[1] == self.c and f.dtype == torch.float32 and f.is_contiguous()
+            assert 0 < n <= self.n_cap and f.shape[1] == self.c and f.dtype == dt and f.is_contiguous()     # one row type per call
             assert co.is_contiguous() and co.dtype == torch.int32 and co.shape[0] == n
-            dst = p.out if outs is None else outs[i]
-            assert dst.dtype == torch.float32 and dst.is_contiguous()
+            if outs is not None:
+                dst = outs[i]
+            elif dt == torch.float32:
+                dst = p.out
+            else:                                                    # half rows: a buffer of that type per arena (as ElkCorePlan.run keeps)
+                half = p.__dict__.setdefault("_out_half", {})
+                dst = half.get(dt)
+                if dst is None:
+                    dst = half[dt] = torch.empty((self.n_cap, self.c), dtype=dt, device=self.device)
+            assert dst.dtype == dt and dst.is_contiguous()
             b = p.buf
-            b.feats, b.coords, b.out, b.io_dtype = f.data_ptr(), co.data_ptr(), dst.data_ptr(), L.IO_F32
+            b.feats, b.coords, b.out, b.io_dtype = f.data_ptr(), co.data_ptr(), dst.data_ptr(), _IO_DTYPES[dt]
             self._bufs[i] = b
             self._n[i] = n
             res.append(dst[:n])

@@ -322,17 +322,19 @@ def test_batch_kernels_resource_shape():
     from kernel_regs import kernel_table
     from link_amd import build as hip_build
     hip_build.build()
-    rows = [r for r in kernel_table(os.path.join(ROOT, "link_amd", "lib", "obj", "dense_batch.o")) if "k_dc_batch" in r[0] and "k_dc_batch_spin" not in r[0] and "k_dc_batch_clear" not in r[0]]
-    assert len(rows) == 7, [r[0] for r in rows]                           # insert + K1 x {cos, sin} + K2 x {cos, sin} x {r 2, 3}
-    al = lambda v: (int(v) + 7) // 8 * 8                                     # vector registers are allocated in eights
-    ins = [r for r in rows if "insert" in r[0]]
-    k1 = [r for r in rows if "batch_k1" in r[0]]
-    k2 = [r for r in rows if "batch_k2" in r[0]]
-    assert len(ins) == 1 and len(k1) == 2 and len(k2) == 4
-    for name, vgpr, agpr, sgpr, lds, scratch, wg in rows:
-        assert int(scratch) == 0 and int(agpr) == 0, (name, scratch, agpr)
-    assert int(ins[0][4]) == 0 and int(ins[0][6]) == 64                     # no LDS, single-wave workgroups
-    worst = max(al(r[1]) for r in k1) + 2 * max(al(r[1]) for r in k2) + al(ins[0][1])
-    assert worst <= 512, worst
-    # LDS granules: K1 static 256 + dynamic padded to 65 granules; K2 static 16 + its plane ring within 63
-    assert all(int(r[4]) == 256 for r in k1) and all(int(r[4]) == 16 for r in k2)
+    for obj in ("dense_batch.o", "dense_batch_f16.o", "dense_batch_bf16.o"):     # fp32 / fp16 / bf16 rows: one set of kernels each
+        rows = [r for r in kernel_table(os.path.join(ROOT, "link_amd", "lib", "obj", obj))
+                if "k_dc_batch" in r[0] and "k_dc_batch_spin" not in r[0] and "k_dc_batch_clear" not in r[0]]
+        assert len(rows) == 7, (obj, [r[0] for r in rows])                   # insert + K1 x {cos, sin} + K2 x {cos, sin} x {r 2, 3}
+        al = lambda v: (int(v) + 7) // 8 * 8                                 # vector registers are allocated in eights
+        ins = [r for r in rows if "insert" in r[0]]
+        k1 = [r for r in rows if "batch_k1" in r[0]]
+        k2 = [r for r in rows if "batch_k2" in r[0]]
+        assert len(ins) == 1 and len(k1) == 2 and len(k2) == 4
+        for name, vgpr, agpr, sgpr, lds, scratch, wg in rows:
+            assert int(scratch) == 0 and int(agpr) == 0, (name, scratch, agpr)
+        assert int(ins[0][4]) == 0 and int(ins[0][6]) == 64                 # no LDS, single-wave workgroups
+        worst = max(al(r[1]) for r in k1) + 2 * max(al(r[1]) for r in k2) + al(ins[0][1])
+        assert worst <= 512, (obj, worst)
+        # LDS granules: K1 static 256 + dynamic padded to 65 granules; K2 static 16 + its plane ring within 63
+        assert all(int(r[4]) == 256 for r in k1) and all(int(r[4]) == 16 for r in k2)

@@ -250,3 +250,28 @@ def test_batch_sizes_around_the_launch_set_and_the_ring(K):
         for o in outs:
             o.zero_()
 
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_batch_half_rows_equal_the_per_frame_plan_bitwise(dt):
+    """fp16 / bf16 rows at the kernel boundary (the reference's AMP contract; fp32 inside): the batch call's rows are those of
+    ElkCorePlan.run on the same half rows, bit for bit, and within the half tolerance of the fp32 rows; mixed row types are refused."""
+    import link_amd as la
+    from link_amd import _lib as L
+    dev = torch.device("cuda:0")
+    C, N, K = 64, 20000, 5
+    blk = _block(C, "cos", dev)
+    bounds = ((0, 0, 0, 0), (255, 255, 255, 0))
+    frames = _frames(K, N, C, dev, seed0=400, ragged=True)
+    plan = _bind(la.ElkCorePlan(N, C, "cos", C // 2, 3, 7, bounds, dev, layout="dense", k1_form=0), blk)
+    ref32 = [plan.run(f, co).clone() for f, co in frames]
+    ref = [plan.run(f.to(dt), co).clone() for f, co in frames]
+    batch = _bind(la.ElkCoreBatch(K, N, C, "cos", C // 2, 3, 7, bounds, dev), blk)
+    outs = batch.run([f.to(dt) for f, _ in frames], [co for _, co in frames])
+    torch.cuda.synchronize()
+    batch.check()
+    for i in range(K):
+        assert outs[i].dtype == dt and torch.equal(outs[i], ref[i])
+        assert rel_err(outs[i].float().cpu().numpy(), ref32[i].cpu().numpy()) < (4e-3 if dt == torch.float16 else 3e-2)
+    with pytest.raises((L.LinkAmdError, AssertionError)):
+        batch.run([frames[0][0].to(dt), frames[1][0]], [frames[0][1], frames[1][1]])
+
