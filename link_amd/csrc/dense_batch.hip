@@ -300,9 +300,16 @@ extern "C" int link_dc_batch_submit(link_dc_batch_t *c, const link_dc_buffers_t 
                hipStreamWaitEvent(c->sa, c->ev_a[r], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_a[r], 0) != hipSuccess;
     }
     int32_t *sync = c->sync + (size_t)q * BT_SYNC_WORDS;
-    if (!fail) hipLaunchKernelGGL(k_dc_batch_clear, dim3(1), dim3(256), 0, c->sa, sync, (int)BT_SYNC_WORDS);   // (not hipMemsetAsync: see k_dc_batch_clear)
-    fail = fail || hipEventRecord(c->ev_ms[q], c->sa) != hipSuccess ||
-           hipStreamWaitEvent(c->sb, c->ev_ms[q], 0) != hipSuccess || hipStreamWaitEvent(c->sc, c->ev_ms[q], 0) != hipSuccess;
+#ifndef DC_BT_CLEAR_ON_INSERT
+#define DC_BT_CLEAR_ON_INSERT 1
+#endif
+    // The set's counters are cleared on the INSERT's stream (1): the insert of this call then starts as soon as the previous call's
+    // insert has ended -- under the previous call's roles -- instead of behind the previous call's pre_mix kernel (0: cleared on the
+    // pre_mix stream), where its flood of atomics and scattered stores slowed this call's first pre_mix items threefold.
+    hipStream_t s_clear = DC_BT_CLEAR_ON_INSERT ? c->sc : c->sa, s_o1 = DC_BT_CLEAR_ON_INSERT ? c->sa : c->sc;
+    if (!fail) hipLaunchKernelGGL(k_dc_batch_clear, dim3(1), dim3(256), 0, s_clear, sync, (int)BT_SYNC_WORDS);   // (not hipMemsetAsync: see k_dc_batch_clear)
+    fail = fail || hipEventRecord(c->ev_ms[q], s_clear) != hipSuccess ||
+           hipStreamWaitEvent(c->sb, c->ev_ms[q], 0) != hipSuccess || hipStreamWaitEvent(s_o1, c->ev_ms[q], 0) != hipSuccess;
     if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
     int rc;
     const dc_bt_host_t hset{c->sa, c->sb, c->sc, c->cus, sync, c->dbg1, c->dbg2};
