@@ -237,6 +237,11 @@ static void bt_mind_caller(link_dc_batch *c, hipStream_t st) {
   bool known = false;
   for (auto &e : c->callers) if (e.first == st) { mask = e.second; known = true; break; }
   if (!known) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {   // (the test's kernels must not end up in a graph)
+      (void)hipGetLastError();
+      return;
+    }
     for (size_t i = 0; i < c->pool.size(); i++)
       if (bt_share_queue(st, c->pool[i], c->probe_scratch, c->probe_ev)) mask |= 1u << i;
     if (c->callers.size() >= 16) c->callers.erase(c->callers.begin());
