@@ -136,9 +136,15 @@ extern "C" int link_dc_batch_create(link_dc_batch_t **out) {
   ok = ok && hipMalloc(reinterpret_cast<void **>(&c->sync), sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess &&
             hipMemset(c->sync, 0, sizeof(int32_t) * BT_RING * BT_SYNC_WORDS) == hipSuccess;
   for (int i = 0; i < BT_RING && ok; i++) {
-    ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_ms[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_c[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) == hipSuccess;
+#ifndef DC_BT_EVENT_FLAGS
+#define DC_BT_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
+    // The context's events order DEVICE work only (stream against stream); nothing the host reads hangs on them -- a caller that reads
+    // rows on the host synchronises its own stream, which releases to system scope.  Without hipEventDisableSystemFence every record is
+    // a packet with a SYSTEM-scope release: the whole L2 written back behind each role kernel, in front of the queue's next packet.
+    ok = hipEventCreateWithFlags(&c->ev_in[i], DC_BT_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&c->ev_ms[i], DC_BT_EVENT_FLAGS) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_a[i], DC_BT_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&c->ev_c[i], DC_BT_EVENT_FLAGS) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_out[i], DC_BT_EVENT_FLAGS) == hipSuccess;
     c->used[i] = false;
   }
   c->calls = 0;
