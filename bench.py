@@ -939,7 +939,8 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0_
 
-    if plan.dense and C == 64 and G == 2 and world == 1 and n_trials > 0:
+    if (plan.dense and C == 64 and G == 2 and NS == 3 and n_trials > 0 and (N, C) == (100000, 64)
+            and not (world > 1 and backend != "nccl")):     # (ranks sharing ONE device over gloo: persistent kernels of two processes would take turns)
         try:
             FB = int(os.environ.get("LINK_BENCH_BATCH_FRAMES", "48"))   # frames per call: 48 = one launch set of the entry point (two steps' worth of frames)
             bsets = [la.ElkCoreBatch(FB, N, C, "cos", C // G, R, S_, ((0, 0, 0, 0), (255, 255, 255, 0)), dev)]
@@ -949,7 +950,7 @@ def main():
                         blk.norm.bias)
             bfe0, bco0 = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
             bstream = torch.cuda.Stream(device=dev)
-            btrials = bsets[0].calibrate(bfe0, bco0, partner=bsets[1], tries=n_trials, calls=20, stream=bstream.cuda_stream)
+            btrials = bsets[0].calibrate(bfe0, bco0, partner=bsets[1], tries=n_trials, calls=8, stream=bstream.cuda_stream)
             if os.environ.get("LINK_BENCH_BATCH_PROBE") == "1":
                 print(f"[batch trials] {btrials} us/frame; queue delays of the kept context {bsets[0].probe_streams(bstream.cuda_stream)}", file=sys.stderr, flush=True)
         except Exception as e:  # noqa: BLE001
@@ -1025,6 +1026,46 @@ def main():
     timed(max(args.warmup, 1))
     elapsed = timed(args.steps)                      # THE measurement (cold: index rebuilt for every frame)
     elapsed_r1 = timed(args.steps, rounds=1)         # the same K steps with the 3-frame batch of rounds 1-4 (continuity)
+    # ---- the same K steps through the BATCH entry point (include/link_amd.h section H): the frames of a step go through calls of FB
+    # frames (two steps' worth; a last call takes what is left), two arena sets, submit(s + 1) before join(s) from one stream.  Same
+    # contract: settling regions of the timed shape, W warm-up steps, EXACTLY K steps between barrier + synchronize.  The faster of the
+    # two ways to run the K steps is the line's `value` (both are in the line: `paths`); rows are bit-equal (checked below).
+    elapsed_batch, batch_fail = None, None
+
+    def timed_batch(k):
+        frames_total, done, s_, prev_ = k * NS * ROUNDS, 0, 0, None
+        h_ = bstream.cuda_stream
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while done < frames_total:
+            nb = min(FB, frames_total - done)
+            _, tk_ = bsets[s_ % 2].submit(bfe0[:nb], bco0[:nb], stream=h_)
+            if prev_ is not None:
+                bsets[0].join(prev_, stream=h_)
+            prev_, done, s_ = tk_, done + nb, s_ + 1
+        bsets[0].join(prev_, stream=h_)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        return t1 - t0
+
+    batch_usable = bsets is not None and not isinstance(bsets, str)
+    if world > 1:                                    # every rank must take the same branch (the barriers inside timed_batch)
+        flag = torch.tensor([1.0 if batch_usable else 0.0], dtype=torch.float64, device=dev if backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        batch_usable = bool(flag.item() == 1.0)
+    if batch_usable:
+        try:
+            for _ in range(3):
+                timed_batch(args.steps)
+            timed_batch(max(args.warmup, 1))
+            elapsed_batch = timed_batch(args.steps)
+            bsets[0].check()
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise                                # (ranks would part ways at the next barrier: better to stop loudly)
+            batch_fail, elapsed_batch = repr(e)[:200], None
     gc.enable()
     # what was just timed is what gets checked: every plan's output under the timed configuration (NS frames in flight,
     # their launch geometry), kept for the comparison with the single-frame geometry below and with the oracle
@@ -1124,13 +1165,15 @@ def main():
                                             "over ranks; reported separately, never inside `value` (SURVEY.md 8e)"}
         mine = torch.tensor([[float(rank), float(N), float(M), checksum, elapsed, elapsed_warm, elapsed_single, elapsed_r1,
                               1.0 if affinity["pinned"] else 0.0, float(-1 if affinity["numa_node"] is None else affinity["numa_node"]),
-                              float(affinity["cpus"]), float(-1 if affinity["first_cpu"] is None else affinity["first_cpu"])]],
+                              float(affinity["cpus"]), float(-1 if affinity["first_cpu"] is None else affinity["first_cpu"]),
+                              float(-1.0 if elapsed_batch is None else elapsed_batch)]],
                             dtype=torch.float64, device=cdev)
         rows = gather_frame_rows(mine).cpu()
         elapsed = float(rows[:, 4].max())
         elapsed_warm = float(rows[:, 5].max())
         elapsed_single = float(rows[:, 6].max())
         elapsed_r1 = float(rows[:, 7].max())
+        elapsed_batch = float(rows[:, 12].max()) if bool((rows[:, 12] > 0).all()) else None
         total_vox = float(rows[:, 1].sum())
         rank_rows = [{"rank": int(r[0]), "voxels": int(r[1]), "blocks": int(r[2]), "checksum": float(r[3])}
                      for r in rows[rows[:, 0].argsort()].tolist()]
@@ -1367,37 +1410,86 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "regions": regions,
         "frame_streams": frame_stream_check,         # the NS frame streams sit on hardware queues of their own (link_streams_share_queue)
     }
-    # ---- the BATCH entry point (include/link_amd.h section H; round 6): the same frames as batches of NS * ROUNDS through
-    # link_elk_core_dense_forward_batch -- one insert kernel + two persistent, queue-fed role kernels per call -- two arena sets
-    # alternated on two streams (the pre_mix role of call s + 1 starts under the gather role of call s).  A step = one call = the
-    # the headline's frames, 48 per call (LINK_BENCH_BATCH_FRAMES); reported beside the headline, never as it.
-    if isinstance(bsets, str):
-        line["batch_entry_point"] = {"error": bsets}
-    elif bsets is not None:
+    # ---- the two ways through the K steps: three plans on three streams (what the fields above describe) and the batch entry point
+    # (include/link_amd.h section H: one insert kernel + two persistent, queue-fed role kernels per call of FB frames, two arena sets,
+    # submit(s + 1) before join(s)).  Same frames, same rows (checked bit for bit), both timed under the same contract; the faster one
+    # is `value` / `ms_per_step` / `us_per_frame` / `roofline` of the line, both are in `paths`.
+    streams_path = {"us_per_frame": round(1e6 * elapsed / frames_timed, 2), "ms_per_step": round(ms, 5), "value": round(total_vox * frames_timed / elapsed, 1),
+                    "frac": roofline["frac"], "what": f"{NS} ElkCorePlan on {NS} HIP streams, one link_elk_core_dense_forward call (3 launches) per frame"}
+    line["paths"] = {"streams": streams_path, "batch": None, "headline": "streams"}
+    line["config"]["path"] = "streams"
+    if isinstance(bsets, str) or batch_fail:
+        line["batch_entry_point"] = {"error": bsets if isinstance(bsets, str) else batch_fail}
+    elif bsets is not None and elapsed_batch is not None:
         try:
-            SETS = 2
-            bfe, bco = [frames[i % NS][0] for i in range(FB)], [frames[i % NS][1] for i in range(FB)]
             ok = True
-            for b_ in bsets:
-                outs_b = b_.run(bfe, bco)
+            for b_ in bsets:                             # the rows of a full call against the rows the streams' timed steps wrote
+                outs_b = b_.run(bfe0, bco0)
                 torch.cuda.synchronize()
                 b_.check()
                 ok &= all(torch.equal(outs_b[i], outs_timed[i % NS]) for i in range(FB))
-            kb = max(args.steps, 20)
-            tb = None
-            for _ in range(3):
-                tb = batch_calls(kb, bstream)
-            bsets[0].check()
-            line["batch_entry_point"] = {
-                "us_per_frame": round(1e6 * tb / (kb * FB), 2), "value": round(N * kb * FB / tb, 1), "frames_per_call": FB, "calls": kb,
-                "arena_sets_in_flight": SETS, "calls_in_flight": "submit(s + 1) before join(s), one caller stream",
-                "placement_trials_us_per_frame": btrials, "frac": round(ab["total"] / (tb / (kb * FB)) / 1e9 / HBM_PEAK_GBS, 4),
-                "bitwise_equal_to_timed_configuration": bool(ok),
-                "note": "ElkCoreBatch / link_elk_core_dense_forward_batch: slot insert of the batch + persistent pre_mix and gather role kernels fed "
-                        "by per-XCD cursors, per-frame arrival counters instead of launch boundaries (DESIGN.md 4i)"}
-            del bsets
-        except Exception as e:                          # a side measurement must never cost the line
+            # the three kernels of a launch set bracketed by timed events on their own streams, in steady state (the last of four calls)
+            bsets[0].set_timing(True)
+            prev_ = None
+            for s_ in range(4):
+                _, tk_ = bsets[s_ % 2].submit(bfe0, bco0, stream=bstream.cuda_stream)
+                if prev_ is not None:
+                    bsets[0].join(prev_, stream=bstream.cuda_stream)
+                prev_ = tk_
+            bsets[0].join(prev_, stream=bstream.cuda_stream)
+            torch.cuda.synchronize()
+            live_b = bsets[0].kernel_times_us(prev_)
+            bsets[0].set_timing(False)
+            usb = 1e6 * elapsed_batch / frames_timed
+            fracb = round(ab["total"] / (usb * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            tgb, bk = (tg or {}).get("batch"), {}
+            names = {"insert": "index", "premix_modsum": "premix_modsum", "gather_demod": "gather_demod"}
+            if tgb and tgb.get("frames_per_call") == FB and args.io == "f32":
+                for i_, (k_, kk) in enumerate(names.items()):
+                    v = tgb["kernels"].get(k_)
+                    if v:
+                        ablb = kab[kk] * FB
+                        bk[k_] = {"rocprof_name": v["rocprof_name"], "avg_us": v["avg_us"], "launches": v["launches"], "frames_per_launch": FB,
+                                  "alg_bytes_per_launch": ablb, "achieved_gbs": round(ablb / (v["avg_us"] * 1e-6) / 1e9, 1),
+                                  "frac": round(ablb / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic_bytes_per_launch": None,
+                                  "live_event_us_this_run": round(live_b[i_], 1)}
+            batch_path = {"us_per_frame": round(usb, 2), "ms_per_step": round(1e3 * elapsed_batch / args.steps, 5),
+                          "value": round(total_vox * frames_timed / elapsed_batch, 1), "frac": fracb,
+                          "what": f"ElkCoreBatch / link_dc_batch_submit + link_dc_batch_join: calls of {FB} frames (3 launches per call: slot insert of the "
+                                  "batch + persistent pre_mix and gather role kernels fed by per-XCD cursors, per-frame arrival counters instead of "
+                                  "launch boundaries), two arena sets, call s + 1 submitted before call s is joined (DESIGN.md 4i)",
+                          "frames_per_call": FB, "placement_trials_us_per_frame": btrials, "bitwise_equal_to_the_streams_rows": bool(ok),
+                          "kernel_brackets_us_this_run": {"insert": round(live_b[0], 1), "premix_modsum": round(live_b[1], 1), "gather_demod": round(live_b[2], 1)}}
+            line["paths"]["batch"] = batch_path
+            line["batch_entry_point"] = {**batch_path, "calls_in_flight": "submit(s + 1) before join(s), one caller stream", "arena_sets_in_flight": 2,
+                                         "bitwise_equal_to_timed_configuration": bool(ok)}
+            if ok and elapsed_batch < elapsed and os.environ.get("LINK_BENCH_HEADLINE", "") != "streams":
+                # the batch entry point is the faster way through the K steps: it is the line's headline
+                line["paths"]["headline"] = "batch"
+                line["config"]["path"] = "batch"
+                line["config"]["step"] = (f"one batch of {NS * ROUNDS} independent frames per GPU through link_dc_batch_submit / _join in calls of {FB} frames "
+                                          "(two arena sets, two calls in flight); value = voxels of all timed frames / time")
+                line["config"]["parallelism"] = f"{world} GPU(s) x calls of {FB} independent frames (persistent role kernels), no data-path collective"
+                line["value"], line["ms_per_step"], line["us_per_frame"] = batch_path["value"], batch_path["ms_per_step"], batch_path["us_per_frame"]
+                rl = dict(roofline)
+                rl["streams_path"] = {k_: roofline[k_] for k_ in ("kernel", "achieved", "frac", "traffic", "traffic_what", "timed_geometry", "whole_step") if k_ in roofline}
+                domb = max(bk, key=lambda k_: bk[k_]["avg_us"]) if bk else "gather_demod"
+                rl.update({"kernel": bk[domb]["rocprof_name"] if bk else "k_dc_batch_k2", "achieved": round(ab["total"] / (usb * 1e-6) / 1e9, 1), "frac": fracb,
+                           "what": "timed region (batch entry point): B_alg of one frame (SURVEY.md 8d) / measured time per frame / 8 TB/s -- the same number as whole_step.frac",
+                           "traffic": None, "traffic_what": None,
+                           "whole_step": {"alg_bytes": ab["total"], "us": round(usb, 2), "frac": fracb,
+                                          "note": "per frame: B_alg of one frame over the timed region's time per frame"},
+                           "timed_geometry": ({"source_kernel_stats": tg["source_kernel_stats"], "source_pmc": None, "commit": tg["commit"],
+                                               "geometry": tgb.get("geometry"), "dominant": domb, "kernels": bk,
+                                               "note": "frac = alg_bytes_per_launch (frames_per_launch x the kernel's bytes per frame) / (avg_us of the committed "
+                                                       "CSV) / 8 TB/s; live_event_us_this_run = the launch bracketed by timed events on its own stream in THIS "
+                                                       "run (link_dc_batch_kernel_times).  The three kernels of a call run side by side for the whole call "
+                                                       "(and beside the neighbouring calls' kernels), so a kernel's own fraction is below the region's; "
+                                                       "the CSV's averages include the calls of the calibration's other contexts"} if bk else None)})
+                line["roofline"] = rl
+        except Exception as e:                          # a second path must never cost the line
             line["batch_entry_point"] = {"error": repr(e)[:200]}
+    del bsets
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -958,6 +958,11 @@ int link_dc_batch_submit(link_dc_batch_t *ctx, const link_dc_buffers_t *frames /
                          int64_t *ticket /* host, out */);
 int link_dc_batch_join(link_dc_batch_t *ctx, int64_t ticket, void *stream);
 int link_dc_batch_status(link_dc_batch_t *ctx, int32_t *out /* host [2] */);
+/* Measurement hook: with timing on, the three launches of every launch set are bracketed by timed events on their own streams;
+ * link_dc_batch_kernel_times waits for the set `ticket` names (one of the last four) and returns the brackets of its insert, pre_mix and
+ * gather kernels in ms. */
+int link_dc_batch_set_timing(link_dc_batch_t *ctx, int32_t on);
+int link_dc_batch_kernel_times(link_dc_batch_t *ctx, int64_t ticket, float *ms /* host [3] */);
 /* Profiling hook (tools/batch_timeline.py): device buffers of 8 x u64 rows the K1 / K2 items append 100 MHz timestamps to (word 0 =
  * rows so far, zeroed by the caller; word 1 = capacity in rows).  Honoured by a -DDC_BT_PROF=1 build of csrc/dense_batch.hip (returns
  * LINK_OK), ignored by the default build (returns 1). */

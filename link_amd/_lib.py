@@ -256,6 +256,8 @@ SIGNATURES = {
     "link_dc_batch_submit": (c_int, [c_void_p, POINTER(LinkDcBuffers), POINTER(c_int64), c_int32, POINTER(LinkDcGrid),
                                      POINTER(LinkElkDesc), c_void_p, POINTER(c_int64)]),
     "link_dc_batch_join": (c_int, [c_void_p, c_int64, c_void_p]),
+    "link_dc_batch_set_timing": (c_int, [c_void_p, c_int32]),
+    "link_dc_batch_kernel_times": (c_int, [c_void_p, c_int64, POINTER(c_float)]),
     "link_dc_batch_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "link_dc_batch_set_debug": (c_int, [c_void_p, c_void_p, c_void_p]),
     "link_dc_batch_probe_streams": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_double)]),

@@ -88,6 +88,9 @@ struct link_dc_batch {
   std::vector<std::pair<hipStream_t, unsigned>> callers;   // caller streams seen so far -> bit i: shares a hardware queue with pool[i]
   unsigned long long *probe_scratch;                   // device, 2 words
   hipEvent_t probe_ev;
+  bool timing;                                         // link_dc_batch_set_timing: bracket the three launches of every set with timed events
+  hipEvent_t tb[BT_RING][3], te[BT_RING][3];           // (insert, pre_mix, gather) start / end of the ring slot's set; created on first use
+  bool timed[BT_RING];
   int32_t *sync;                                       // BT_RING x BT_SYNC_WORDS
   hipEvent_t ev_in[BT_RING], ev_ms[BT_RING], ev_a[BT_RING], ev_c[BT_RING], ev_out[BT_RING];
   std::vector<const void *> bufs[BT_RING];             // S pointers of the frames the ring slot's call worked on
@@ -161,6 +164,8 @@ extern "C" int link_dc_batch_destroy(link_dc_batch_t *c) {
     (void)hipEventDestroy(c->ev_in[i]); (void)hipEventDestroy(c->ev_ms[i]); (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_c[i]);
     (void)hipEventDestroy(c->ev_out[i]);
   }
+  for (int i = 0; i < BT_RING; i++)
+    for (int k = 0; k < 3; k++) { if (c->tb[i][k]) (void)hipEventDestroy(c->tb[i][k]); if (c->te[i][k]) (void)hipEventDestroy(c->te[i][k]); }
   (void)hipFree(c->sync);
   (void)hipFree(c->probe_scratch);
   (void)hipEventDestroy(c->probe_ev);
@@ -210,6 +215,26 @@ extern "C" int link_dc_batch_probe_streams(link_dc_batch_t *c, hipStream_t calle
   (void)hipEventDestroy(ev);
   (void)hipFree(st);
   if (!ok) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
+  return LINK_OK;
+}
+
+// Measurement hook (bench.py): with timing on, every launch set's three kernels are bracketed by timed events on their own streams;
+// link_dc_batch_kernel_times waits for the set `ticket` names and returns the (insert, pre_mix, gather) brackets in ms.  The ring holds
+// the last BT_RING sets only: LINK_ERR_ARG for an older ticket or a set submitted with timing off.
+extern "C" int link_dc_batch_set_timing(link_dc_batch_t *c, int32_t on) {
+  if (!c) return LINK_ERR_ARG;
+  c->timing = on != 0;
+  return LINK_OK;
+}
+extern "C" int link_dc_batch_kernel_times(link_dc_batch_t *c, int64_t ticket, float *ms /* host [3] */) {
+  if (!c || !ms || ticket < 0 || ticket >= c->calls || c->calls - ticket > BT_RING) return LINK_ERR_ARG;
+  const int q = (int)(ticket % BT_RING);
+  if (!c->timed[q]) return LINK_ERR_ARG;
+  for (int i = 0; i < 3; i++)
+    if (hipEventSynchronize(c->te[q][i]) != hipSuccess || hipEventElapsedTime(&ms[i], c->tb[q][i], c->te[q][i]) != hipSuccess) {
+      (void)hipGetLastError();
+      return LINK_ERR_LAUNCH;
+    }
   return LINK_OK;
 }
 
@@ -323,10 +348,22 @@ extern "C" int link_dc_batch_submit(link_dc_batch_t *c, const link_dc_buffers_t 
            hipStreamWaitEvent(c->sb, c->ev_ms[q], 0) != hipSuccess || hipStreamWaitEvent(s_o1, c->ev_ms[q], 0) != hipSuccess;
     if (fail) { (void)hipGetLastError(); return LINK_ERR_LAUNCH; }
     int rc;
+    hipStream_t role3[3] = {c->sc, c->sa, c->sb};
+    c->timed[q] = false;
+    if (c->timing) {
+      bool okt = true;
+      for (int i = 0; i < 3 && okt; i++) {
+        if (!c->tb[q][i]) okt = hipEventCreate(&c->tb[q][i]) == hipSuccess && hipEventCreate(&c->te[q][i]) == hipSuccess;
+        okt = okt && hipEventRecord(c->tb[q][i], role3[i]) == hipSuccess;
+      }
+      c->timed[q] = okt;
+    }
     const dc_bt_host_t hset{c->sa, c->sb, c->sc, c->cus, sync, c->dbg1, c->dbg2};
     if (b0.io_dtype == LINK_IO_F16) rc = dcb_f16::batch_set_launch(hset, frames + base, n + base, nb, *g, *d);
     else if (b0.io_dtype == LINK_IO_BF16) rc = dcb_bf16::batch_set_launch(hset, frames + base, n + base, nb, *g, *d);
     else rc = dcb_f32::batch_set_launch(hset, frames + base, n + base, nb, *g, *d);
+    if (c->timed[q])
+      for (int i = 0; i < 3; i++) c->timed[q] = hipEventRecord(c->te[q][i], role3[i]) == hipSuccess && c->timed[q];
     // the set's completion events (what link_dc_batch_join, later calls on the same buffers and the ring slot's next user wait for)
     fail = hipEventRecord(c->ev_a[q], c->sa) != hipSuccess || hipEventRecord(c->ev_c[q], c->sc) != hipSuccess || hipEventRecord(c->ev_out[q], c->sb) != hipSuccess;
     c->bufs[q] = keys;

@@ -717,6 +717,16 @@ class ElkCoreBatch:
         for p in self.plans:
             p.check()
 
+    def set_timing(self, on: bool) -> None:
+        """Bracket the three launches of every launch set with timed events on their own streams (link_dc_batch_set_timing)."""
+        L.check(L.lib().link_dc_batch_set_timing(self._ctx, 1 if on else 0), "link_dc_batch_set_timing")
+
+    def kernel_times_us(self, ticket: int):
+        """(insert, pre_mix, gather) brackets of the launch set `ticket` names, in us; waits for that set (one of the last four)."""
+        out = (ctypes.c_float * 3)()
+        L.check(L.lib().link_dc_batch_kernel_times(self._ctx, int(ticket), out), "link_dc_batch_kernel_times")
+        return [1e3 * float(v) for v in out]
+
     def probe_streams(self, stream: Optional[int] = None):
         """Diagnostic (link_dc_batch_probe_streams): for the pairs (pre_mix -> gather), (pre_mix -> insert), (gather -> insert),
         (stream -> pre_mix), (stream -> gather), (stream -> insert) how long a kernel on the second stream is held up by a 150 us kernel

@@ -57,7 +57,15 @@ def test_bench_two_ranks_over_gloo_on_one_device():
     rl = single["roofline"]
     assert abs(rl["frac"] - rl["whole_step"]["frac"]) < 1e-9 and rl["single_frame_geometry"]["step_median_us"] > 0
     tg = rl["timed_geometry"]
-    assert tg is not None and set(tg["kernels"]) == {"index", "premix_modsum", "gather_demod"}
+    # two ways through the K steps are timed -- three plans on three streams, the batch entry point -- and the faster one is the headline
+    paths = single["paths"]
+    assert paths["headline"] in ("streams", "batch") and single["config"]["path"] == paths["headline"]
+    assert abs(paths[paths["headline"]]["us_per_frame"] - single["us_per_frame"]) < 1e-9 and paths["streams"]["us_per_frame"] > 0
+    if paths["batch"] is not None:
+        assert paths["batch"]["bitwise_equal_to_the_streams_rows"] and single["us_per_frame"] <= paths["streams"]["us_per_frame"] + 1e-9
+        assert d["paths"]["batch"] is None                                    # two ranks on one device over gloo: streams only
+    first = "insert" if paths["headline"] == "batch" else "index"
+    assert tg is not None and set(tg["kernels"]) == {first, "premix_modsum", "gather_demod"}
     for k, v in tg["kernels"].items():
         assert abs(v["frac"] - v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 8e12) < 2e-4, k
         assert v["live_event_us_this_run"] > 0

@@ -35,7 +35,19 @@ for key, v in vals.items():
         kern[key]["traffic_bytes_per_launch"] = int(round(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024))
     if key in kern and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         kern[key]["mfma_busy_cycles_per_launch"] = int(round(v["SQ_VALU_MFMA_BUSY_CYCLES"]))
-json.dump({"commit": commit, "geometry": "three ElkCorePlan on three HIP streams, frames_in_flight = 3 (cfg2: N = 100000, C = 64, cos, r = 3, s = 7)",
+# the batch entry point's three kernels in the same bench command (its second timed path: calls of 48 frames): rocprofv3 averages per
+# launch = per CALL; the averages include the launches of the calibration's other contexts and of the rows check
+BKEYS = (("insert", "k_dc_batch_insert"), ("premix_modsum", "k_dc_batch_k1ILi0"), ("gather_demod", "k_dc_batch_k2ILi0ELi3"))
+bkern = {}
+for row in csv.DictReader(open(stats)):
+    for key, pat in BKEYS:
+        if pat in row["name"] and key not in bkern:
+            bkern[key] = {"rocprof_name": row["name"][:96], "launches": int(row["calls"]), "avg_us": float(row["avg_us"]),
+                          "min_us": float(row["min_us"]), "max_us": float(row["max_us"])}
+batch = ({"frames_per_call": int(sys.argv[6]) if len(sys.argv) > 6 else 48,
+          "geometry": "link_dc_batch_submit / link_dc_batch_join: calls of 48 frames, two arena sets, two calls in flight (cfg2: N = 100000, C = 64, cos, r = 3, s = 7)",
+          "kernels": bkern} if len(bkern) == 3 else None)
+json.dump({"commit": commit, "batch": batch, "geometry": "three ElkCorePlan on three HIP streams, frames_in_flight = 3 (cfg2: N = 100000, C = 64, cos, r = 3, s = 7)",
            "source_kernel_stats": f"{label}_kernel_stats_streams3.csv (rocprofv3 --kernel-trace --stats of `python bench.py --steps 100 --warmup 10 --streams 3`)",
            "source_pmc": f"{label}_pmc_counters_streams3.txt (rocprofv3 --pmc, one counter set per pass, over tools/dcstep3.py DC_STREAMS=3)",
            "kernels": kern}, open(out, "w"), indent=1)
