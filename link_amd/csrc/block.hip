@@ -137,6 +137,23 @@ static int block_unprobe(const link_block_args_t *a, hipStream_t st) {
   return e == hipSuccess ? LINK_OK : block_fail("link_elk_block_forward (unprobe)", e);
 }
 
+extern "C" int link_streams_share_queue(void *a, void *b, double *delay_us);
+static void block_side_off_the_callers_queue(link_block_ctx *c, hipStream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+  hipStream_t rejected[8];
+  int nrej = 0;
+  for (int tries = 0; tries < 8; tries++) {
+    double d = 0.0;
+    if (link_streams_share_queue(st, c->side, &d) != LINK_OK || d <= 75.0) break;
+    hipStream_t s_new = nullptr;
+    if (hipStreamCreateWithFlags(&s_new, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+    rejected[nrej++] = c->side;                        // kept alive until the search ends: it holds its queue's use count up
+    c->side = s_new;
+  }
+  for (int i = 0; i < nrej; i++) { (void)hipStreamSynchronize(rejected[i]); (void)hipStreamDestroy(rejected[i]); }
+}
+
 extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a, void *stream) {
   if (!c || !a || !a->buf || !a->g || !a->desc || a->n <= 0) return LINK_ERR_ARG;
   const link_dc_buffers_t *b = a->buf;
@@ -165,6 +182,11 @@ extern "C" int link_elk_block_forward(link_block_ctx_t *c, link_block_args_t *a,
   int rc;
   if (!c->primed || c->last_stream != st) {            // first call / another stream: nobody laid this half out in stream order
     if (c->primed) (void)hipStreamSynchronize(c->last_stream);
+    // The side stream must not sit on the caller's hardware queue (the runtime multiplexes streams onto a few): the fork / join event
+    // records would then be barriers between the two chains this call runs side by side (R_block on a new coordinate set read 151 or
+    // 281 us from process to process).  Tested once per caller stream (link_streams_share_queue, dense_batch.hip); a side stream that
+    // shares is replaced, up to eight times.
+    block_side_off_the_callers_queue(c, st);
     rc = link::dc_probe_scratch_init_run(cur, st);
     if (rc != LINK_OK) return rc;
   }
