@@ -914,7 +914,7 @@ def main():
     # measurement alternated two caller streams instead, and read 37 or 50 us / frame depending on the streams it happened to get: two
     # streams the runtime multiplexes onto one hardware queue serialise the calls (the wait of one stream's call sits in front of the
     # other's submission; tools/batch_overlap.py shows call s + 1 starting when call s has ended).  What is left of the placement is
-    # measured: ElkCoreBatch.calibrate -- LINK_BENCH_BATCH_TRIALS contexts (default 3) on the SAME arenas, 2 x 20 calls each, the fastest kept,
+    # measured: ElkCoreBatch.calibrate -- LINK_BENCH_BATCH_TRIALS contexts (default 8) on the SAME arenas, 2 x 8 calls each (0.3 s in all), the fastest kept,
     # every trial in the line.
     for j_ in range(NS):                   # the frame streams' first use comes BEFORE the trials: the runtime binds a stream to a hardware queue
         with torch.cuda.stream(streams[j_]):   # when it is first used, and the headline's placement must not depend on a side measurement
@@ -922,7 +922,7 @@ def main():
     torch.cuda.synchronize()
     bsets = None
     btrials = []
-    n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "3"))      # 0: no batch side measurement
+    n_trials = int(os.environ.get("LINK_BENCH_BATCH_TRIALS", "8"))      # 0: no batch path (a context is in one of three states: 31.8 / 33.1-33.8 / 39.5 us per frame at 48 frames per call)
 
     def batch_calls(k_, stream_):
         """k_ calls alternating the two arena sets, submit(s + 1) before join(s), from one stream; seconds"""
